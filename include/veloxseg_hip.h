@@ -1,0 +1,135 @@
+/* veloxseg_hip.h -- C ABI of libveloxseg_hip.so (gfx950 / MI355X kernels for the VeloxSeg hot path).
+ *
+ * The reference (JinPLu/VeloxSeg) is pure PyTorch and has no FFI / operator registry: its hot path is
+ * the aten calls issued by the model/ and utils/loss.py modules.  Each entry point below names the reference
+ * lines whose arithmetic it replaces.  Conventions:
+ *   - every tensor is fp32, contiguous, NCDHW (labels: int64 / int32 / uint8), device memory owned by
+ *     the caller (PyTorch); the library never allocates;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*), never synchronises, never reads
+ *     device memory on the host: all entry points are HIP-graph capturable;
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch/runtime failure, -3 unsupported
+ *     shape); vx_last_error() returns a thread-local message.  Nothing aborts.
+ *   - dropout sites take (seed_ptr, dstream, p): seed_ptr -> device uint64[2] {seed, step};
+ *     p == 0 or seed_ptr == NULL disables dropout.  The same triple regenerates the mask in backward.
+ */
+#ifndef VELOXSEG_HIP_H
+#define VELOXSEG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_ABI_VERSION 1
+
+int vx_abi_version(void);
+const char* vx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolutions (cubic kernel K, uniform stride S / padding P, groups G).  Weight layout = PyTorch Conv3d
+ * (Cout, Cin/G, K, K, K).  Input = channel concat of x (first C1 channels) and x2 (rest); C1 <= 0 or
+ * C1 == Cin means "x only".  ps > 1 stores / reads y through PixelShuffle(ps)
+ * (model/components/superpixel.py:16).
+ *   replaces: nn.Conv3d in conv_blocks.py:10-17 (DownConv), :51-58 (JLC grouped 1/3/5), :64-68 (JLC 1x1s),
+ *             Decoder.py:54-57,73-76,150-158, Encoder.py:334-337 (+ torch.cat :344-347), PWA.py:291-298,
+ *             attention_utils.py:56-57,141, MONAI PatchEmbed.proj (Encoder.py:150-156).
+ *   ConvTranspose3d k2 s2 (conv_blocks.py:29-35) = the adjoint: forward -> vx_conv3d_bwd_data (bias via
+ *   bias_like), input gradient -> vx_conv3d_fwd, weight gradient -> vx_conv3d_bwd_weight with (x, dy) swapped.
+ * --------------------------------------------------------------------------------------------- */
+int vx_conv3d_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
+                  int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* dx (=|+=) conv^T(dy); dx/dx2 split like the forward input; bias_like (per input channel) is added when not NULL */
+int vx_conv3d_bwd_data(const float* dy, const float* w, const float* bias_like, float* dx, float* dx2, int C1,
+                       int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps,
+                       int accumulate, void* stream);
+/* dw += x (*) dy ; db += sum dy   (float atomics into caller-zeroed / running gradient buffers; db may be NULL) */
+int vx_conv3d_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                         int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
+ * Encoder.py:334-337, Decoder.py:54-57).  stats[2*bc] = mean, stats[2*bc+1] = rstd.
+ *   vx_in_apply_fwd: out = (res?res:0) + sum_{k<nk} act((y_k-mean_k)*rstd_k), act 0=identity 1=exact GELU
+ *                    (JLC spatial sum conv_blocks.py:73; DownConv+attn2conv add Encoder.py:351-360; UpConv+skip Decoder.py:85-87)
+ *   vx_in_bwd:       dy = rstd*(dz - mean(dz) - z*mean(dz*z)), dz = dout*act'(z); m_ws = 2*BC floats of workspace
+ * --------------------------------------------------------------------------------------------- */
+int vx_in_stats(const float* x, float* stats, long BC, long V, float eps, void* stream);
+int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                    int nk, int act, const float* res, float* out, long BC, long V, void* stream);
+int vx_in_bwd(const float* dout, const float* y, const float* stats, int act, float* m_ws, float* dy, long BC, long V, void* stream);
+
+/* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
+int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);
+int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,
+                 int B, int C, long V, float eps, void* stream);   /* dgamma/dbeta: += */
+
+/* element-wise pieces: h = drop(gelu(a)) (attention_utils.py:64-66, conv_blocks.py:66); out = alpha*x + drop(z)
+ * (PWA.py:377 + :436 double residual, attention_utils.py:68-70, conv_blocks.py:69,74, Encoder.py:196) */
+int vx_gelu_drop_fwd(const float* a, float* h, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+int vx_gelu_drop_bwd(const float* dh, const float* a, float* da, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+int vx_axpy_drop_fwd(const float* x, const float* z, float* out, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+int vx_axpy_drop_bwd(const float* dout, float* dx, float* dz, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+int vx_add(const float* a, const float* b, const float* c, float* out, long n, void* stream);          /* out = a + b (+ c) */
+int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream);                  /* db[c] += sum_{b,v} dy */
+/* PatchMerging.faeture_sample (attention_utils.py:144-159); Dc,Hc,Wc = coarse dims; inverse=1 is the adjoint */
+int vx_space_to_depth2(const float* x, float* out, int B, int C, int Dc, int Hc, int Wc, int inverse, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Paired-Window Attention (model/components/PWA.py).  Geometry of one layer:
+ * --------------------------------------------------------------------------------------------- */
+typedef struct VxPwaPlan {
+    int grid[3];      /* token grid g */
+    int n[3];         /* tokens per window and axis = min_big / min_small (PWA.py:42) */
+    int heads, nb;    /* heads, number of window scales (PWA.py:67 `while (bw <= input).any()`) */
+    int small[4][3];  /* max-pool size of scale i = min_small * 2^i */
+    int nwin[4][3];   /* windows per axis of scale i */
+    int woff[4];      /* offset of scale i on the concatenated window axis */
+    int Ntot;         /* total windows */
+    int l;            /* n[0]*n[1]*n[2] tokens per window per modality */
+} VxPwaPlan;
+
+/* window_gathering_3d (PWA.py:106-140) of modality m into tok[B, heads, Ntot, M*l, c]; bwd routes to the first arg-max */
+int vx_pwa_gather_fwd(const float* src, float* tok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsrc, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+/* window_scattering_3d (PWA.py:177-200): per-window trilinear, align_corners=True */
+int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+/* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).
+ * O: (B,heads,Ntot,M*l,cv); LSE: (B,heads,Ntot,M*l).  bwd: dtable += ; delta_ws = B*heads*Ntot*M*l floats. */
+int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
+                    const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                    const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                    const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
+                    const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                    const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss side (utils/loss.py:30-66, common_function.py:8-14, VeloxSeg.py:177-184)
+ *   labels kind: 0 int64, 1 int32, 2 uint8.  seg acc (double): per head [ce_sum, (I,P,T) x (b,c)].
+ *   coef (float): per head [w_ce, (alpha,beta) x (b,c)], then [rc_coef, gram_coef].
+ * --------------------------------------------------------------------------------------------- */
+int vx_seg_loss_fwd(const float* l0, const float* l1, const float* l2, const float* l3, int nh, const void* labels, int lab_kind,
+                    double* acc, int B, int C, long V, void* stream);
+int vx_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
+int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
+                     const double* rc_acc, long n_rc, float w_rc,
+                     const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,
+                     float* loss_out, float* coef, void* stream);
+int vx_seg_loss_bwd(const float* logits, const void* labels, int lab_kind, const float* coef_head, const float* gout,
+                    float* dlogits, int B, int C, long V, void* stream);
+int vx_mse_bwd(const float* a, const float* b, const float* coef, const float* gout, float* da, long n, void* stream);
+int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const float* g2, const float* g3, int M, const float* coef,
+                    const float* gout, float* dgs, float* d0, float* d1, float* d2, float* d3, long n, void* stream);
+int vx_gram_fwd(const float* x, float* G, int B, int C, long V, void* stream);
+int vx_gram_bwd(const float* x, const float* dG, float* dx, int B, int C, long V, void* stream);
+int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, int d, int h, int w, int D, int H, int W, void* stream);
+int vx_upsample_trilinear_bwd(const float* dout, float* dx, long BC, int d, int h, int w, int D, int H, int W, void* stream);
+
+/* fused AdamW on flat buffers (torch.optim.AdamW maths; config/train_config_bs4.json:66-72); g is scaled by grad_scale first */
+int vx_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, long step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

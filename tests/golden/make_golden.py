@@ -111,6 +111,7 @@ def make_case(name, cfg, B):
     from utils.loss import Loss
     torch.manual_seed(12345)
     model = VeloxSeg(**cfg)
+    init_sha = sd_sha(model.state_dict())      # seed-level init parity (initialization.py:3-14, attention_utils.py:118)
     sd = fill_state_dict(model.state_dict(), seed=7)
     model.load_state_dict(sd)
     x, labels = make_inputs(cfg, B)
@@ -135,7 +136,7 @@ def make_case(name, cfg, B):
     loss.backward()
     grad_norms = {n: float(p.grad.double().norm()) for n, p in model.named_parameters()}
     small = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.numel() <= 600}
-    fix = dict(config=cfg, batch=B, sd_seed=7, sd_sha256=sd_sha(sd), sd_keys=list(sd.keys()),
+    fix = dict(config=cfg, batch=B, init_seed=12345, init_sha256=init_sha, sd_seed=7, sd_sha256=sd_sha(sd), sd_keys=list(sd.keys()),
                sd_shapes={k: list(v.shape) for k, v in sd.items()}, x_sha256=tensor_sha(x), labels_sha256=tensor_sha(labels),
                eval_logits=compact(logits), argmax=logits.argmax(1).to(torch.uint8),
                train_outputs=[compact(o) for o in outs], loss=float(loss),
@@ -269,7 +270,9 @@ def make_ops():
 
 
 if __name__ == "__main__":
+    import atexit, shutil
     install_stub()
+    atexit.register(lambda: shutil.rmtree(sys.path[1], ignore_errors=True) if "monai_stub_" in sys.path[1] else None)
     torch.set_num_threads(8)
     make_ops()
     for name, (cfg, B) in CASES.items():

@@ -1,0 +1,115 @@
+"""GPU parity of the whole path: veloxseg_amd.VeloxSeg (+ Loss) vs the CPU oracle and vs the reference-generated goldens.
+Bar (fp32): |dlogit| <= 1e-4*max(1,|logit|); argmax bit-exact wherever the oracle's top-2 margin exceeds 1e-4;
+loss within 1e-4 relative; parameter gradients within 2e-3 of the oracle's norm."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import veloxseg_oracle as O  # noqa: E402
+from recipe import CASES, LOSS_CFG, check_compact, fill_state_dict, make_inputs  # noqa: E402
+
+
+def _build(name):
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    cfg_d, B = CASES[name]
+    model = VeloxSeg(**cfg_d)
+    sd = fill_state_dict(model.state_dict(), seed=7)
+    model.load_state_dict(sd)
+    x, labels = make_inputs(cfg_d, B)
+    return cfg_d, B, model.cuda(), sd, x, labels
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_eval_logits_vs_oracle_and_golden(golden_dir, name):
+    cfg_d, B, model, sd, x, labels = _build(name)
+    model.eval()
+    with torch.no_grad():
+        logits = model(x.cuda()).cpu()
+        ref = O.forward(x, sd, O.OracleConfig(**cfg_d), training=False)
+    err = (logits - ref).abs()
+    tol = 1e-4 * ref.abs().clamp(min=1.0)
+    assert bool((err <= tol).all()), f"max err {float(err.max()):.3e}, bad frac {float((err > tol).float().mean()):.3e}"
+    top2 = ref.topk(2, dim=1).values
+    confident = (top2[:, 0] - top2[:, 1]) > 1e-4
+    am, amr = logits.argmax(1), ref.argmax(1)
+    assert bool((am == amr)[confident].all()), "argmax differs on a voxel whose margin exceeds the tolerance"
+    fix = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    check_compact(logits, fix["eval_logits"], 2e-4, 2e-4, "eval logits vs reference golden")
+    mism = float((am.to(torch.uint8) != fix["argmax"]).float().mean())
+    assert mism <= 1e-5, f"argmax vs reference golden differs on {mism:.2e} of voxels"
+
+
+@pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2"])
+def test_train_step_vs_oracle(golden_dir, name):
+    from veloxseg_amd.utils.loss import Loss
+    import types
+    cfg_d, B, model, sd, x, labels = _build(name)
+    cfg = O.OracleConfig(**cfg_d)
+    model.train()
+    outs = model(x.cuda())
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, torch.device("cuda"), num_modal=cfg.M)
+    loss = crit(outs, labels.cuda(), sr_labels=x.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(params)
+    ro = O.forward(x, full, cfg, training=True)
+    rl = O.loss(ro, labels, x, cfg.M, LOSS_CFG)
+    rl.backward()
+    assert len(outs) == len(ro)
+    for i, (a, b) in enumerate(zip(outs, ro)):
+        err = (a.detach().cpu() - b.detach()).abs()
+        tol = 1e-4 * b.detach().abs().clamp(min=1.0)
+        assert bool((err <= tol).all()), f"train output {i}: max err {float(err.max()):.3e}"
+    assert abs(float(loss) - float(rl)) <= 1e-4 * abs(float(rl)), (float(loss), float(rl))
+    bad = []
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        g, r = p.grad.detach().cpu().double(), params[k].grad.double()
+        rel = float((g - r).norm() / r.norm().clamp(min=1e-6))
+        if rel > 2e-3:
+            bad.append((k, rel, float(r.norm())))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+    fix = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    if name != "g2_32_m2":
+        assert abs(float(loss) - fix["loss"]) <= 1e-4 * abs(fix["loss"])
+        for k, p in model.named_parameters():
+            gn = float(p.grad.double().norm())
+            assert abs(gn - fix["grad_norms"][k]) <= 3e-3 * max(fix["grad_norms"][k], 1e-3), (k, gn, fix["grad_norms"][k])
+
+
+def test_cpu_input_fails_loudly():
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    cfg_d, B = CASES["g2_32_m2"]
+    model = VeloxSeg(**cfg_d)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model(torch.zeros(1, 2, 32, 32, 32))
+
+
+def test_full_size_properties_128():
+    """BASELINE-size (128^3, M=2, windows [4,8,4,4]) size-independent checks: per-sample independence of the batch
+    (every op is per-sample), finite loss, gradient of every parameter present and finite."""
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    import types
+    cfg = dict(CASES["g1_48_m2"][0], input_size=[128, 128, 128], patch_size=4, min_big_window_sizes=[[4] * 3, [8] * 3, [4] * 3, [4] * 3])
+    torch.manual_seed(1)
+    model = VeloxSeg(**cfg).cuda()
+    x = torch.randn(2, 2, 128, 128, 128, device="cuda")
+    lab = (torch.rand(2, 1, 128, 128, 128, device="cuda") > 0.97).long()
+    model.eval()
+    with torch.no_grad():
+        both = model(x)
+        one = model(x[1:2].contiguous())
+    assert torch.equal(both[1:2], one), "batch samples must not interact"
+    model.train()
+    outs = model(x)
+    loss = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)(outs, lab, sr_labels=x)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k

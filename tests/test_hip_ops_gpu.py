@@ -1,0 +1,268 @@
+"""GPU parity: every HIP operator (forward + backward) against the CPU oracle on the same seeded inputs.
+Calls go through the C ABI (ctypes -> libveloxseg_hip.so).  Tolerances are stated per test (fp32)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import veloxseg_oracle as O  # noqa: E402  (checker only)
+
+
+def _vf():
+    from veloxseg_amd import functional as VF
+    return VF
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, atol, rtol, what):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    if not bool((err <= tol).all()):
+        i = int((err - tol).argmax())
+        raise AssertionError(f"{what}: max abs err {float(err.max()):.3e} (ref max {float(b.abs().max()):.3e}); worst idx {i}: "
+                             f"got {float(a.flatten()[i]):.6e} want {float(b.flatten()[i]):.6e}; bad frac {float((err > tol).double().mean()):.3e}")
+
+
+def run_pair(fn_gpu, fn_cpu, tensors, params=(), atol=2e-5, rtol=2e-4, gtol=None, seed=11, what=""):
+    """tensors / params: lists of CPU tensors.  Both functions take (tensors..., params...).  Compares outputs and all grads."""
+    d = dev()
+    gt = [t.clone().to(d).requires_grad_(t.is_floating_point()) for t in tensors]
+    gp = [t.clone().to(d).requires_grad_(True) for t in params]
+    ct = [t.clone().requires_grad_(t.is_floating_point()) for t in tensors]
+    cp = [t.clone().requires_grad_(True) for t in params]
+    og = fn_gpu(*gt, *gp)
+    oc = fn_cpu(*ct, *cp)
+    og = list(og) if isinstance(og, (list, tuple)) else [og]
+    oc = list(oc) if isinstance(oc, (list, tuple)) else [oc]
+    assert len(og) == len(oc)
+    for i, (a, b) in enumerate(zip(og, oc)):
+        close(a, b, atol, rtol, f"{what} out[{i}]")
+    gys = [rnd(*o.shape, seed=seed + i) for i, o in enumerate(oc)]
+    torch.autograd.backward(oc, gys)
+    torch.autograd.backward(og, [g.to(d) for g in gys])
+    torch.cuda.synchronize()
+    ga, gr = gtol or (atol * 5, rtol * 5)
+    for i, (a, b) in enumerate(zip(gt, ct)):
+        if b.grad is not None:
+            assert a.grad is not None, f"{what}: missing grad for tensor {i}"
+            close(a.grad, b.grad, ga, gr, f"{what} d tensor[{i}]")
+    for i, (a, b) in enumerate(zip(gp, cp)):
+        assert a.grad is not None, f"{what}: missing grad for param {i}"
+        scale = max(1.0, float(b.grad.abs().max()))
+        close(a.grad, b.grad, ga * scale, gr * 4, f"{what} d param[{i}]")
+
+
+CONV_CASES = [
+    # name, B, Cin, D,H,W, Cout, K, S, P, G, ps
+    ("pw16_48", 2, 16, (6, 5, 7), 48, 1, 1, 0, 1, 1),
+    ("pw_head", 2, 32, (4, 4, 4), 2, 1, 1, 0, 1, 1),
+    ("jlc_k3_g4", 2, 16, (6, 6, 6), 16, 3, 1, 1, 4, 1),
+    ("jlc_k5_g4", 1, 16, (7, 6, 5), 16, 5, 1, 2, 4, 1),
+    ("jlc_k5_g8", 1, 64, (4, 4, 4), 64, 5, 1, 2, 8, 1),
+    ("down_k7s4", 2, 2, (16, 16, 16), 16, 7, 4, 3, 1, 1),
+    ("down_k3s2", 2, 16, (8, 8, 6), 32, 3, 2, 1, 1, 1),
+    ("embed_k4s4", 1, 1, (16, 12, 8), 16, 4, 4, 0, 1, 1),
+    ("embed_k2s2", 1, 4, (8, 8, 8), 16, 2, 2, 0, 1, 1),
+    ("expand_ps4", 1, 16, (4, 5, 6), 128, 3, 1, 1, 1, 4),
+    ("expand_ps2", 2, 16, (4, 4, 4), 16, 3, 1, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d(case):
+    VF = _vf()
+    name, B, Cin, sp, Cout, K, S, P, G, ps = case
+    x = rnd(B, Cin, *sp)
+    w = rnd(Cout, Cin // G, K, K, K, seed=1, scale=(Cin // G * K ** 3) ** -0.5)
+    b = rnd(Cout, seed=2, scale=0.1)
+
+    def g(x, w, b):
+        return VF.conv3d(x, w, b, stride=S, padding=P, groups=G, pixel_shuffle=ps)
+
+    def c(x, w, b):
+        y = F.conv3d(x, w, b, stride=S, padding=P, groups=G)
+        return O.pixel_shuffle3d(y, ps) if ps > 1 else y
+
+    run_pair(g, c, [x], [w, b], what=name)
+
+
+def test_conv3d_concat_nobias():
+    VF = _vf()
+    x1, x2 = rnd(2, 16, 4, 4, 4), rnd(2, 32, 4, 4, 4, seed=3)
+    w = rnd(24, 48, 1, 1, 1, seed=4, scale=0.15)
+    run_pair(lambda a, b, w: VF.conv3d(a, w, None, x2=b), lambda a, b, w: F.conv3d(torch.cat([a, b], 1), w), [x1, x2], [w], what="concat")
+
+
+def test_conv_transpose():
+    VF = _vf()
+    x = rnd(2, 32, 3, 4, 5)
+    w = rnd(32, 16, 2, 2, 2, seed=5, scale=0.2)
+    b = rnd(16, seed=6, scale=0.1)
+    run_pair(lambda x, w, b: VF.conv_transpose_k2s2(x, w, b), lambda x, w, b: F.conv_transpose3d(x, w, b, stride=2), [x], [w, b], what="convT")
+
+
+@pytest.mark.parametrize("n,act,res", [(1, False, False), (1, False, True), (2, False, False), (3, True, True)])
+def test_instnorm_sum(n, act, res):
+    VF = _vf()
+    ys = [rnd(2, 8, 5, 4, 3, seed=i) * (1 + i) + i for i in range(n)]
+    r = [rnd(2, 8, 5, 4, 3, seed=9)] if res else []
+
+    def g(*t):
+        return VF.instnorm_sum(list(t[:n]), act=act, res=t[n] if res else None)
+
+    def c(*t):
+        out = t[n] if res else 0
+        for y in t[:n]:
+            z = O.instnorm(y)
+            out = out + (O.gelu(z) if act else z)
+        return out
+
+    run_pair(g, c, ys + r, what=f"in{n}")
+
+
+def test_layernorm_and_s2d():
+    VF = _vf()
+    x = rnd(2, 16, 4, 6, 8)
+    run_pair(lambda x, w, b: VF.layernorm_cf(x, w, b), lambda x, w, b: O.layernorm_cf(x, w, b), [x], [1 + 0.2 * rnd(16, seed=1), 0.2 * rnd(16, seed=2)], what="ln")
+    run_pair(lambda x: VF.space_to_depth2(x), lambda x: O.space_to_depth2(x), [x], atol=0, rtol=0, what="s2d")
+
+
+def test_elementwise():
+    VF = _vf()
+    a, z = rnd(2, 6, 4, 4, 4), rnd(2, 6, 4, 4, 4, seed=3)
+    run_pair(lambda a: VF.gelu_dropout(a), lambda a: O.gelu(a), [a], what="gelu")
+    run_pair(lambda a, z: VF.residual_dropout(a, z, 2.0), lambda a, z: 2 * a + z, [a, z], what="axpy2")
+    run_pair(lambda a, z: VF.residual_dropout(a, z, 1.0), lambda a, z: a + z, [a, z], what="axpy1")
+    run_pair(lambda a, z: VF.add(a, z), lambda a, z: a + z, [a, z], what="add")
+
+
+def test_dropout_statistics_and_bwd_mask():
+    VF = _vf()
+    d = dev()
+    VF.manual_seed(777, d)
+    z = torch.ones(1 << 20, device=d).view(1, 1, 64, 128, 128).requires_grad_(True)
+    out = VF.residual_dropout(None, z, 0.0, 0.1, 5)
+    keep = float((out != 0).float().mean())
+    assert abs(keep - 0.9) < 3e-3, keep
+    assert abs(float(out.max()) - 1 / 0.9) < 1e-6
+    out.sum().backward()
+    assert torch.equal((z.grad != 0), (out != 0)), "backward must regenerate the forward mask"
+    out2 = VF.residual_dropout(None, z.detach(), 0.0, 0.1, 6)
+    assert float(((out2 != 0) != (out != 0)).float().mean()) > 0.1, "different sites must give different masks"
+    VF.advance_rng(d)
+    out3 = VF.residual_dropout(None, z.detach(), 0.0, 0.1, 5)
+    assert float(((out3 != 0) != (out != 0)).float().mean()) > 0.1, "a new step must give a new mask"
+
+
+PWA_CASES = [
+    # grid, big, heads, min_dim_head, C, M
+    ("l2_like", [12, 12, 12], [6, 6, 6], 2, 8, 32, 2),
+    ("l1_like", [8, 8, 8], [2, 2, 2], 1, 4, 16, 2),
+    ("single_modality", [8, 8, 8], [4, 4, 4], 2, 8, 32, 1),
+    ("aniso", [8, 8, 4], [4, 4, 2], 1, 4, 16, 2),
+    ("l4_like", [3, 3, 3], [3, 3, 3], 4, 16, 128, 2),
+]
+
+
+@pytest.mark.parametrize("case", PWA_CASES, ids=[c[0] for c in PWA_CASES])
+def test_pwa_core(case):
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    name, grid, big, heads, mdh, C, M = case
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    n = pl["n"]
+    table = rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)
+    idx = O.relative_position_index(n)
+    qkv = []
+    for m in range(M):
+        qkv += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
+
+    def g(*t):
+        return VF.pwa_core(t[-1], plan, pl["c_qk"], pl["c_v"], list(t[:-1]))
+
+    def c(*t):
+        qs = [O.gather_windows(t[3 * m], pl, pl["c_qk"]) for m in range(M)]
+        ks = [O.gather_windows(t[3 * m + 1], pl, pl["c_qk"]) for m in range(M)]
+        vs = [O.gather_windows(t[3 * m + 2], pl, pl["c_v"]) for m in range(M)]
+        l = qs[0].shape[3]
+        a = O.window_attention(torch.cat(qs, 3), torch.cat(ks, 3), torch.cat(vs, 3), O.relative_bias(t[-1], idx, l), M)
+        return [O.scatter_windows(a[:, :, :, m * l:(m + 1) * l], pl, pl["c_v"]) for m in range(M)]
+
+    run_pair(g, c, qkv, [table], atol=3e-5, rtol=3e-4, what=name)
+
+
+def test_upsample_and_gram():
+    VF = _vf()
+    x = rnd(2, 3, 4, 6, 3)
+    run_pair(lambda x: VF.upsample_trilinear(x, (16, 24, 12)), lambda x: O.upsample_trilinear(x, [16, 24, 12]), [x], what="up")
+    x = rnd(1, 2, 2, 2, 2)
+    run_pair(lambda x: VF.upsample_trilinear(x, (32, 32, 32)), lambda x: O.upsample_trilinear(x, [32, 32, 32]), [x], what="up16x")
+    x = rnd(2, 16, 6, 6, 6)
+    run_pair(lambda x: VF.gram(x), lambda x: O.gram(x), [x], atol=1e-6, rtol=1e-4, what="gram")
+    x = rnd(2, 8, 5, 5, 5)
+    run_pair(lambda x: VF.gram(x), lambda x: O.gram(x), [x], atol=1e-6, rtol=1e-4, what="gram8")
+
+
+@pytest.mark.parametrize("ncls,M,labdtype", [(2, 2, torch.int64), (4, 1, torch.uint8), (3, 2, torch.int32)])
+def test_loss(ncls, M, labdtype):
+    VF = _vf()
+    d = dev()
+    B, S = 2, 8
+    g = torch.Generator().manual_seed(5)
+    outs = [rnd(B, ncls, S, S, S, seed=i) for i in range(4)] + [rnd(B, M, S, S, S, seed=7)] + [rnd(B, 16, 16, seed=8 + i, scale=0.1) for i in range(1 + M)]
+    lab = torch.randint(0, ncls, (B, 1, S, S, S), generator=g)
+    sr = rnd(B, M, S, S, S, seed=99)
+    cfg = {"deep_Loss_weight": [1, 1, 1, 1], "RC_Loss_weight": 0.5, "Feature_Loss_weight": 2.0}
+
+    def gfn(*t):
+        return VF.veloxseg_loss(list(t), lab.to(d).to(labdtype), sr.to(d), [0.25] * 4, 0.5, 2.0, M)
+
+    def cfn(*t):
+        return O.loss(list(t), lab, sr, M, cfg)
+
+    run_pair(gfn, cfn, outs, atol=1e-5, rtol=1e-5, gtol=(1e-8, 1e-3), what=f"loss{ncls}")
+
+
+def test_adamw_matches_torch():
+    from veloxseg_amd import _hip as H
+    d = dev()
+    n = 10007
+    p0, g0 = rnd(n), rnd(n, seed=1)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=2.5e-4, weight_decay=0.01)
+    p = p0.clone().to(d)
+    m, v = torch.zeros(n, device=d), torch.zeros(n, device=d)
+    for step in range(1, 4):
+        gi = g0 * step
+        pt.grad = gi.clone()
+        opt.step()
+        H.call("vx_adamw_step", H.P(p), H.P(gi.to(d)), H.P(m), H.P(v), n, 2.5e-4, 0.9, 0.999, 1e-8, 0.01, step, 1.0, H.stream_ptr())
+    close(p, pt.data, 1e-7, 1e-6, "adamw")
+
+
+def test_errors_are_python_exceptions():
+    VF = _vf()
+    d = dev()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        VF.conv3d(torch.zeros(1, 4, 4, 4, 4), torch.zeros(4, 4, 1, 1, 1))
+    with pytest.raises(RuntimeError, match="InstanceNorm"):
+        VF.instnorm_sum([torch.zeros(1, 4, 1, 1, 1, device=d)])
+    from veloxseg_amd import _hip as H
+    with pytest.raises(RuntimeError, match="vx_conv3d_fwd"):
+        H.call("vx_conv3d_fwd", None, None, 0, None, None, None, 1, 4, 4, 4, 4, 4, 1, 1, 0, 1, 1, 0)

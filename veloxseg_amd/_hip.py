@@ -1,0 +1,137 @@
+"""ctypes binding of libveloxseg_hip.so (C ABI declared in include/veloxseg_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+Prototypes are parsed from the public header so Python and C cannot drift apart.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "veloxseg_hip.h")
+LIB_PATH = os.path.join(_PKG, "lib", "libveloxseg_hip.so")
+ABI_VERSION = 1
+
+_CTYPE = {
+    "int": ctypes.c_int,
+    "long": ctypes.c_long,
+    "float": ctypes.c_float,
+    "unsigned long long": ctypes.c_ulonglong,
+}
+
+
+class VxPwaPlan(ctypes.Structure):
+    """Mirror of `struct VxPwaPlan` (include/veloxseg_hip.h)."""
+    _fields_ = [("grid", ctypes.c_int * 3), ("n", ctypes.c_int * 3), ("heads", ctypes.c_int), ("nb", ctypes.c_int),
+                ("small", (ctypes.c_int * 3) * 4), ("nwin", (ctypes.c_int * 3) * 4), ("woff", ctypes.c_int * 4),
+                ("Ntot", ctypes.c_int), ("l", ctypes.c_int)]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
+    """-> {name: (return type, [(ctype string, arg name), ...])} for every `vx_*` prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const char\*|int)\s+(vx_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        arglist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                ty = mm.group(1).strip()
+                arglist.append((ty, mm.group(2)))
+        protos[name] = (ret, arglist)
+    return protos
+
+
+def _to_ctype(ty: str):
+    if "*" in ty:
+        return ctypes.c_void_p
+    return _CTYPE[ty]
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"veloxseg_amd: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for the VeloxSeg hot path.")
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(dll, name)          # AttributeError here = header/library drift
+            fn.restype = ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int
+            fn.argtypes = [_to_ctype(t) for t, _ in args]
+        v = dll.vx_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"veloxseg_amd: ABI mismatch: library {v}, python {ABI_VERSION}")
+        self._dll = dll
+        return dll
+
+    def call(self, name: str, *args):
+        dll = self.load()
+        rc = getattr(dll, name)(*args)
+        if rc != 0:
+            msg = dll.vx_last_error()
+            raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+LIB = _Lib()
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def P(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("veloxseg_amd: tensors must live on an MI355X (cuda) device; there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"veloxseg_amd: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("veloxseg_amd: tensor must be contiguous (NCDHW)")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    LIB.call(name, *args)
+
+
+def make_plan(grid, n, heads, small, nwin) -> VxPwaPlan:
+    pl = VxPwaPlan()
+    nb = len(small)
+    if nb < 1 or nb > 4:
+        raise ValueError(f"PWA supports 1..4 window scales, got {nb}")
+    for k in range(3):
+        pl.grid[k] = int(grid[k])
+        pl.n[k] = int(n[k])
+    pl.heads, pl.nb = int(heads), nb
+    off = 0
+    for i in range(nb):
+        for k in range(3):
+            pl.small[i][k] = int(small[i][k])
+            pl.nwin[i][k] = int(nwin[i][k])
+        pl.woff[i] = off
+        off += int(nwin[i][0]) * int(nwin[i][1]) * int(nwin[i][2])
+    pl.Ntot = off
+    pl.l = int(n[0]) * int(n[1]) * int(n[2])
+    return pl

@@ -1,0 +1,424 @@
+// Loss-side kernels for gfx950 (fp32 data, fp64 accumulators).
+// Reference: utils/loss.py:30-66 (CE + MONAI DiceLoss deep supervision, MSE reconstruction, SDKT Gram MSE),
+//            model/components/common_function.py:8-14 (Gram), model/VeloxSeg.py:177-184 (trilinear up-sampling of
+//            deep-supervision heads, align_corners=True).
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+#define VX_MAXC 8   // max classes handled in registers
+
+__device__ __forceinline__ int vx_label(const void* lab, int kind, long i) {
+    if (kind == 0) return (int)((const long long*)lab)[i];
+    if (kind == 1) return ((const int*)lab)[i];
+    return (int)((const unsigned char*)lab)[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// seg loss forward: per head h: ce_sum, and per (b,c): I = sum p*t, P = sum p, T = sum t
+// acc layout (double): head h at h*(1 + B*C*3): [ce_sum, (I,P,T) x (b,c)]
+// grid (chunks, B); each thread strides over voxels of batch b
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_seg_loss_fwd_k(const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
+                                                         const float* __restrict__ l3, int nh, const void* __restrict__ lab, int lab_kind,
+                                                         double* __restrict__ acc, int B, int C, long V) {
+    const int b = blockIdx.y;
+    __shared__ float red[4];
+    const float* heads[4] = {l0, l1, l2, l3};
+    for (int h = 0; h < nh; ++h) {
+        const float* __restrict__ lg = heads[h] + (long)b * C * V;
+        float ce = 0.0f, I[VX_MAXC], P[VX_MAXC], T[VX_MAXC];
+#pragma unroll
+        for (int c = 0; c < VX_MAXC; ++c) { I[c] = 0.0f; P[c] = 0.0f; T[c] = 0.0f; }
+        for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+            const int y = vx_label(lab, lab_kind, (long)b * V + v);
+            float z[VX_MAXC], mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = lg[(long)c * V + v]; mx = fmaxf(mx, z[c]); }
+            float se = 0.0f;
+#pragma unroll
+            for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = expf(z[c] - mx); se += z[c]; }
+            const float inv = 1.0f / se;
+#pragma unroll
+            for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+                const float p = z[c] * inv;
+                P[c] += p;
+                if (c == y) { I[c] += p; T[c] += 1.0f; ce -= logf(fmaxf(p, 1e-38f)); }
+            }
+        }
+        double* __restrict__ ah = acc + (long)h * (1 + (long)B * C * 3);
+        float s = vx_block_sum_256(ce, red);
+        if (threadIdx.x == 0) atomicAdd(ah, (double)s);
+        for (int c = 0; c < C; ++c) {
+            float vI = 0.f, vP = 0.f, vT = 0.f;
+#pragma unroll
+            for (int k = 0; k < VX_MAXC; ++k) if (k == c) { vI = I[k]; vP = P[k]; vT = T[k]; }
+            vI = vx_block_sum_256(vI, red);
+            vP = vx_block_sum_256(vP, red);
+            vT = vx_block_sum_256(vT, red);
+            if (threadIdx.x == 0) {
+                double* d = ah + 1 + ((long)b * C + c) * 3;
+                atomicAdd(d, (double)vI); atomicAdd(d + 1, (double)vP); atomicAdd(d + 2, (double)vT);
+            }
+        }
+    }
+}
+
+// squared-difference sum -> acc[0] (double)
+__global__ void __launch_bounds__(256) vx_sqdiff_sum_k(const float* __restrict__ a, const float* __restrict__ b, long n, double* __restrict__ acc) {
+    float s = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float d = a[i] - b[i]; s = fmaf(d, d, s); }
+    __shared__ float red[4];
+    s = vx_block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)s);
+}
+
+// finalize: scalar loss + per-(head,b,c) dice coefficients for the backward pass.
+//   coef layout (float): head h at h*(1 + B*C*2): [w_ce = w_h/(B*V), (alpha, beta) x (b,c)]  with dDice_h/dp_c[v] = alpha*t + beta
+//   misc: [rc_coef = 2*w_rc/N_rc, gram_coef = 2*w_f/(M*B*Cg*Cg)]
+__global__ void vx_loss_finalize_k(const double* __restrict__ acc, int nh, int B, int C, long V, const float* __restrict__ wds,
+                                   const double* __restrict__ rc_acc, long n_rc, float w_rc,
+                                   const float* __restrict__ gs, const float* __restrict__ g0, const float* __restrict__ g1,
+                                   const float* __restrict__ g2, const float* __restrict__ g3, int M, int Cg, float w_f,
+                                   float* __restrict__ loss_out, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double eps = 1e-5;
+    double total = 0.0;
+    for (int h = 0; h < nh; ++h) {
+        const double* ah = acc + (long)h * (1 + (long)B * C * 3);
+        float* ch = coef + (long)h * (1 + (long)B * C * 2);
+        const double w = (double)wds[h];
+        const double ce = ah[0] / ((double)B * (double)V);
+        double dice = 0.0;
+        const double wd = w / ((double)B * (double)(C - 1));
+        ch[0] = (float)(w / ((double)B * (double)V));
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c) {
+                const double I = ah[1 + ((long)b * C + c) * 3], P = ah[2 + ((long)b * C + c) * 3], T = ah[3 + ((long)b * C + c) * 3];
+                const double U = P + T + eps;
+                float al = 0.0f, be = 0.0f;
+                if (c >= 1) {
+                    dice += 1.0 - (2.0 * I + eps) / U;
+                    al = (float)(-2.0 * wd / U);
+                    be = (float)(wd * (2.0 * I + eps) / (U * U));
+                }
+                ch[1 + ((long)b * C + c) * 2] = al;
+                ch[2 + ((long)b * C + c) * 2] = be;
+            }
+        dice /= (double)B * (double)(C - 1);
+        total += w * (ce + dice);
+    }
+    float* misc = coef + (long)nh * (1 + (long)B * C * 2);
+    if (rc_acc) {
+        total += (double)w_rc * rc_acc[0] / (double)n_rc;
+        misc[0] = (float)(2.0 * (double)w_rc / (double)n_rc);
+    } else misc[0] = 0.0f;
+    if (gs && M > 0) {
+        const float* gm[4] = {g0, g1, g2, g3};
+        const long ng = (long)B * Cg * Cg;
+        double feat = 0.0;
+        for (int m = 0; m < M; ++m) {
+            double s = 0.0;
+            for (long i = 0; i < ng; ++i) { const double d = (double)gs[i] - (double)gm[m][i]; s += d * d; }
+            feat += s / (double)ng;
+        }
+        total += (double)w_f * feat / (double)M;
+        misc[1] = (float)(2.0 * (double)w_f / ((double)M * (double)ng));
+    } else misc[1] = 0.0f;
+    loss_out[0] = (float)total;
+}
+
+// seg loss backward for one head: dlogit_c = gout * [ w_ce (p_c - t_c) + p_c (g_c - sum_k p_k g_k) ],  g_c = (c>=1) ? alpha*t_c + beta : 0
+__global__ void __launch_bounds__(256) vx_seg_loss_bwd_k(const float* __restrict__ lg_all, const void* __restrict__ lab, int lab_kind,
+                                                         const float* __restrict__ coef_h, const float* __restrict__ gout,
+                                                         float* __restrict__ dl_all, int B, int C, long V) {
+    const int b = blockIdx.y;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float go = gout ? gout[0] : 1.0f;
+    const float* __restrict__ lg = lg_all + (long)b * C * V;
+    float* __restrict__ dl = dl_all + (long)b * C * V;
+    const int y = vx_label(lab, lab_kind, (long)b * V + v);
+    const float wce = coef_h[0];
+    float z[VX_MAXC], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = lg[(long)c * V + v]; mx = fmaxf(mx, z[c]); }
+    float se = 0.0f;
+#pragma unroll
+    for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = expf(z[c] - mx); se += z[c]; }
+    const float inv = 1.0f / se;
+    float g[VX_MAXC], dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+        z[c] *= inv;
+        const float al = coef_h[1 + ((long)b * C + c) * 2], be = coef_h[2 + ((long)b * C + c) * 2];
+        g[c] = (c == y ? al : 0.0f) + be;
+        dot = fmaf(z[c], g[c], dot);
+    }
+#pragma unroll
+    for (int c = 0; c < VX_MAXC; ++c) if (c < C) dl[(long)c * V + v] = go * (wce * (z[c] - (c == y ? 1.0f : 0.0f)) + z[c] * (g[c] - dot));
+}
+
+// da = gout * coef * (a - b)
+__global__ void __launch_bounds__(256) vx_mse_bwd_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ coef,
+                                                    const float* __restrict__ gout, float* __restrict__ da, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) da[i] = (gout ? gout[0] : 1.0f) * coef[0] * (a[i] - b[i]);
+}
+
+// dGs = gout*coef*sum_m (Gs - Gm) ; dGm = -gout*coef*(Gs - Gm)
+__global__ void __launch_bounds__(256) vx_gram_mse_bwd_k(const float* __restrict__ gs, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                         const float* __restrict__ g2, const float* __restrict__ g3, int M, const float* __restrict__ coef,
+                                                         const float* __restrict__ gout, float* __restrict__ dgs, float* __restrict__ d0, float* __restrict__ d1,
+                                                         float* __restrict__ d2, float* __restrict__ d3, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float k = (gout ? gout[0] : 1.0f) * coef[0];
+    const float* gm[4] = {g0, g1, g2, g3};
+    float* dm[4] = {d0, d1, d2, d3};
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) { const float d = gs[i] - gm[m][i]; s += d; dm[m][i] = -k * d; }
+    dgs[i] = k * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram matrix G[b,m,n] = sum_v x[b,m,v] x[b,n,v] / (C*V)    (C <= 32)
+// ---------------------------------------------------------------------------------------------
+#define VX_GT 64
+__global__ void __launch_bounds__(256) vx_gram_fwd_k(const float* __restrict__ x, float* __restrict__ G, int C, long V, int tiles_per_block) {
+    __shared__ float tile[32][VX_GT + 1];
+    const int b = blockIdx.y;
+    const float* __restrict__ xb = x + (long)b * C * V;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long v_begin = (long)blockIdx.x * tiles_per_block * VX_GT;
+    for (int tl = 0; tl < tiles_per_block; ++tl) {
+        const long v0 = v_begin + (long)tl * VX_GT;
+        if (v0 >= V) break;
+        __syncthreads();
+        for (int e = threadIdx.x; e < C * VX_GT; e += 256) {
+            const int c = e / VX_GT, k = e % VX_GT;
+            tile[c][k] = (v0 + k < V) ? xb[(long)c * V + v0 + k] : 0.0f;
+        }
+        __syncthreads();
+        int slot = 0;
+        for (int pr = threadIdx.x; pr < C * C; pr += 256, ++slot) {
+            const int m = pr / C, n = pr % C;
+            float s = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < VX_GT; ++k) s = fmaf(tile[m][k], tile[n][k], s);
+            acc[slot] += s;
+        }
+    }
+    const float norm = 1.0f / ((float)C * (float)V);
+    int slot = 0;
+    for (int pr = threadIdx.x; pr < C * C; pr += 256, ++slot) atomicAdd(G + (long)b * C * C + pr, acc[slot] * norm);
+}
+
+// dx[b,m,v] = sum_n (dG[b,m,n] + dG[b,n,m]) x[b,n,v] / (C*V)
+__global__ void __launch_bounds__(256) vx_gram_bwd_k(const float* __restrict__ x, const float* __restrict__ dG, float* __restrict__ dx, int C, long V) {
+    const int b = blockIdx.y;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* __restrict__ xb = x + (long)b * C * V + v;
+    const float* __restrict__ gb = dG + (long)b * C * C;
+    const float norm = 1.0f / ((float)C * (float)V);
+    float xv[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) xv[n] = (n < C) ? xb[(long)n * V] : 0.0f;
+    for (int m = 0; m < C; ++m) {
+        float s = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 32; ++n) if (n < C) s = fmaf(gb[m * C + n] + gb[n * C + m], xv[n], s);
+        dx[(long)b * C * V + (long)m * V + v] = s * norm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trilinear up-sampling, align_corners=True
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vx_up_coord(int j, int nin, int nout, int& i0, int& i1, float& lam) {
+    if (nout == nin) { i0 = j; i1 = j; lam = 0.0f; return; }
+    const float ratio = nout > 1 ? (float)(nin - 1) / (float)(nout - 1) : 0.0f;
+    const float s = ratio * (float)j;
+    i0 = (int)s;
+    lam = s - (float)i0;
+    i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(256) vx_upsample_fwd_k(const float* __restrict__ x, float* __restrict__ out, int d, int h, int w, int D, int H, int W) {
+    const long Vo = (long)D * H * W, Vi = (long)d * h * w;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= Vo) return;
+    const long bc = blockIdx.y;
+    const int X = (int)(v % W), Y = (int)((v / W) % H), Z = (int)(v / ((long)W * H));
+    int a0, b0, a1, b1, a2, b2;
+    float l0, l1, l2;
+    vx_up_coord(Z, d, D, a0, b0, l0);
+    vx_up_coord(Y, h, H, a1, b1, l1);
+    vx_up_coord(X, w, W, a2, b2, l2);
+    const float* __restrict__ xb = x + bc * Vi;
+    auto T = [&](int z, int y, int xx) { return xb[((long)z * h + y) * w + xx]; };
+    const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
+    out[bc * Vo + v] = k0 * (k1 * (k2 * T(a0, a1, a2) + l2 * T(a0, a1, b2)) + l1 * (k2 * T(a0, b1, a2) + l2 * T(a0, b1, b2))) +
+                       l0 * (k1 * (k2 * T(b0, a1, a2) + l2 * T(b0, a1, b2)) + l1 * (k2 * T(b0, b1, a2) + l2 * T(b0, b1, b2)));
+}
+
+// adjoint with an LDS copy of one (b,c) low-res volume per block: grid (chunks, B*C); LDS atomics, then one global atomic per low-res voxel
+__global__ void __launch_bounds__(256) vx_upsample_bwd_k(const float* __restrict__ dout, float* __restrict__ dx, int d, int h, int w, int D, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float vx_lds[];
+    const long Vo = (long)D * H * W;
+    const int Vi = d * h * w;
+    const long bc = blockIdx.y;
+    for (int k = threadIdx.x; k < Vi; k += 256) vx_lds[k] = 0.0f;
+    __syncthreads();
+    const float* __restrict__ db = dout + bc * Vo;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < Vo; v += (long)gridDim.x * 256) {
+        const int X = (int)(v % W), Y = (int)((v / W) % H), Z = (int)(v / ((long)W * H));
+        int a0, b0, a1, b1, a2, b2;
+        float l0, l1, l2;
+        vx_up_coord(Z, d, D, a0, b0, l0);
+        vx_up_coord(Y, h, H, a1, b1, l1);
+        vx_up_coord(X, w, W, a2, b2, l2);
+        const float g = db[v];
+        const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
+        auto A = [&](int z, int y, int xx, float wt) { if (wt != 0.0f) atomicAdd(&vx_lds[(z * h + y) * w + xx], wt * g); };
+        A(a0, a1, a2, k0 * k1 * k2); A(a0, a1, b2, k0 * k1 * l2); A(a0, b1, a2, k0 * l1 * k2); A(a0, b1, b2, k0 * l1 * l2);
+        A(b0, a1, a2, l0 * k1 * k2); A(b0, a1, b2, l0 * k1 * l2); A(b0, b1, a2, l0 * l1 * k2); A(b0, b1, b2, l0 * l1 * l2);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < Vi; k += 256) {
+        const float s = vx_lds[k];
+        if (s != 0.0f) atomicAdd(dx + bc * Vi + k, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, amsgrad=False, maximize=False)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+extern "C" int vx_seg_loss_fwd(const float* l0, const float* l1, const float* l2, const float* l3, int nh, const void* labels, int lab_kind,
+                               double* acc, int B, int C, long V, void* stream) {
+    VX_REQUIRE(nh >= 1 && nh <= 4 && l0 && labels && acc && C >= 2 && C <= VX_MAXC && B > 0 && V > 0, "vx_seg_loss_fwd: bad args (C must be 2..%d)", VX_MAXC);
+    VX_REQUIRE(lab_kind >= 0 && lab_kind <= 2, "vx_seg_loss_fwd: label kind must be 0(int64) 1(int32) 2(uint8)");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_fwd: memset failed");
+    int chunks = vx_cdiv(V, 256 * 8);
+    if (chunks > 1024) chunks = 1024;
+    hipLaunchKernelGGL(vx_seg_loss_fwd_k, dim3(chunks, B), dim3(256), 0, st, l0, l1, l2, l3, nh, labels, lab_kind, acc, B, C, V);
+    VX_LAUNCH_CHECK("vx_seg_loss_fwd");
+    return 0;
+}
+
+extern "C" int vx_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream) {
+    VX_REQUIRE(a && b && acc && n > 0, "vx_sqdiff_sum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, sizeof(double), st) != hipSuccess) VX_FAIL(-2, "vx_sqdiff_sum: memset failed");
+    int blocks = vx_cdiv(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(vx_sqdiff_sum_k, dim3(blocks), dim3(256), 0, st, a, b, n, acc);
+    VX_LAUNCH_CHECK("vx_sqdiff_sum");
+    return 0;
+}
+
+extern "C" int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
+                                const double* rc_acc, long n_rc, float w_rc,
+                                const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,
+                                float* loss_out, float* coef, void* stream) {
+    VX_REQUIRE(seg_acc && head_weights && loss_out && coef && nh >= 1 && nh <= 4 && M >= 0 && M <= 4, "vx_loss_finalize: bad args");
+    hipLaunchKernelGGL(vx_loss_finalize_k, dim3(1), dim3(64), 0, (hipStream_t)stream, seg_acc, nh, B, C, V, head_weights, rc_acc, n_rc, w_rc,
+                       gram_seg, g0, g1, g2, g3, M, Cg, w_f, loss_out, coef);
+    VX_LAUNCH_CHECK("vx_loss_finalize");
+    return 0;
+}
+
+extern "C" int vx_seg_loss_bwd(const float* logits, const void* labels, int lab_kind, const float* coef_head, const float* gout,
+                               float* dlogits, int B, int C, long V, void* stream) {
+    VX_REQUIRE(logits && labels && coef_head && dlogits && C >= 2 && C <= VX_MAXC, "vx_seg_loss_bwd: bad args");
+    hipLaunchKernelGGL(vx_seg_loss_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, logits, labels, lab_kind, coef_head, gout, dlogits, B, C, V);
+    VX_LAUNCH_CHECK("vx_seg_loss_bwd");
+    return 0;
+}
+
+extern "C" int vx_mse_bwd(const float* a, const float* b, const float* coef, const float* gout, float* da, long n, void* stream) {
+    VX_REQUIRE(a && b && coef && da && n > 0, "vx_mse_bwd: bad args");
+    hipLaunchKernelGGL(vx_mse_bwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, coef, gout, da, n);
+    VX_LAUNCH_CHECK("vx_mse_bwd");
+    return 0;
+}
+
+extern "C" int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const float* g2, const float* g3, int M, const float* coef,
+                               const float* gout, float* dgs, float* d0, float* d1, float* d2, float* d3, long n, void* stream) {
+    VX_REQUIRE(gs && coef && dgs && M >= 1 && M <= 4 && n > 0, "vx_gram_mse_bwd: bad args");
+    hipLaunchKernelGGL(vx_gram_mse_bwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gs, g0, g1, g2, g3, M, coef, gout, dgs, d0, d1, d2, d3, n);
+    VX_LAUNCH_CHECK("vx_gram_mse_bwd");
+    return 0;
+}
+
+extern "C" int vx_gram_fwd(const float* x, float* G, int B, int C, long V, void* stream) {
+    VX_REQUIRE(x && G && B > 0 && C > 0 && C <= 32 && V > 0, "vx_gram_fwd: bad args (C <= 32)");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(G, 0, sizeof(float) * (size_t)B * C * C, st) != hipSuccess) VX_FAIL(-2, "vx_gram_fwd: memset failed");
+    const long tiles = (V + VX_GT - 1) / VX_GT;
+    int tpb = (int)((tiles + 255) / 256);
+    if (tpb < 1) tpb = 1;
+    hipLaunchKernelGGL(vx_gram_fwd_k, dim3(vx_cdiv(tiles, tpb), B), dim3(256), 0, st, x, G, C, V, tpb);
+    VX_LAUNCH_CHECK("vx_gram_fwd");
+    return 0;
+}
+
+extern "C" int vx_gram_bwd(const float* x, const float* dG, float* dx, int B, int C, long V, void* stream) {
+    VX_REQUIRE(x && dG && dx && B > 0 && C > 0 && C <= 32 && V > 0, "vx_gram_bwd: bad args (C <= 32)");
+    hipLaunchKernelGGL(vx_gram_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, dG, dx, C, V);
+    VX_LAUNCH_CHECK("vx_gram_bwd");
+    return 0;
+}
+
+extern "C" int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, int d, int h, int w, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && out && BC > 0 && d > 0 && h > 0 && w > 0 && D >= d && H >= h && W >= w, "vx_upsample_trilinear_fwd: bad args");
+    hipLaunchKernelGGL(vx_upsample_fwd_k, dim3(vx_cdiv((long)D * H * W, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, d, h, w, D, H, W);
+    VX_LAUNCH_CHECK("vx_upsample_trilinear_fwd");
+    return 0;
+}
+
+extern "C" int vx_upsample_trilinear_bwd(const float* dout, float* dx, long BC, int d, int h, int w, int D, int H, int W, void* stream) {
+    VX_REQUIRE(dout && dx && BC > 0 && d > 0 && h > 0 && w > 0, "vx_upsample_trilinear_bwd: bad args");
+    const size_t shm = sizeof(float) * (size_t)d * h * w;
+    VX_REQUIRE(shm <= 96 * 1024, "vx_upsample_trilinear_bwd: low-res volume %dx%dx%d does not fit the LDS accumulator", d, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)BC * d * h * w, st) != hipSuccess) VX_FAIL(-2, "vx_upsample_trilinear_bwd: memset failed");
+    int chunks = vx_cdiv((long)D * H * W, 256 * 16);
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(vx_upsample_bwd_k, dim3(chunks, (unsigned)BC), dim3(256), shm, st, dout, dx, d, h, w, D, H, W);
+    VX_LAUNCH_CHECK("vx_upsample_trilinear_bwd");
+    return 0;
+}
+
+extern "C" int vx_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, long step, float grad_scale, void* stream) {
+    VX_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vx_adamw_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(vx_adamw_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
+    VX_LAUNCH_CHECK("vx_adamw_step");
+    return 0;
+}
+
+thread_local char vx_err_buf[512] = {0};
+extern "C" const char* vx_last_error(void) { return vx_err_buf; }
+extern "C" int vx_abi_version(void) { return VX_ABI_VERSION; }

@@ -1,0 +1,324 @@
+// Normalisation + element-wise kernels for gfx950 (fp32, NCDHW).
+//   InstanceNorm3d (affine=False, eps 1e-5, biased var; reference common_function.py:63-66) is split into
+//   a per-(b,c) statistics kernel and "apply" kernels that fuse the activation, the JLC 3-way sum and
+//   the residual (conv_blocks.py:72-75, 18-21, 36-39; Encoder.py:351-360; Decoder.py:85-88,160-164).
+//   channels-first LayerNorm (attention_utils.py:29-43, eps 1e-6) is thread-local: one thread = one voxel.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm statistics: one 256-thread block per (b,c) row of V contiguous floats.
+// stats[2*bc] = mean, stats[2*bc+1] = rstd.  fp64 accumulation -> deterministic and cancellation-safe.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_in_stats_k(const float* __restrict__ x, float* __restrict__ stats, long V, float eps) {
+    const long bc = blockIdx.x;
+    const float* __restrict__ row = x + bc * V;
+    double s = 0.0, ss = 0.0;
+    for (long v = threadIdx.x; v < V; v += 256) {
+        const double t = (double)row[v];
+        s += t;
+        ss += t * t;
+    }
+    s = vx_wave_sum(s);
+    ss = vx_wave_sum(ss);
+    __shared__ double sm[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm[wid] = s; sm[4 + wid] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = sm[0] + sm[1] + sm[2] + sm[3], SS = sm[4] + sm[5] + sm[6] + sm[7];
+        const double m = S / (double)V;
+        double var = SS / (double)V - m * m;
+        if (var < 0.0) var = 0.0;
+        stats[2 * bc] = (float)m;
+        stats[2 * bc + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// out = (res ? res : 0) + sum_{k<nk} act((y_k - mean_k) * rstd_k)
+__global__ void __launch_bounds__(256) vx_in_apply_fwd_k(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
+                                                         const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                         int nk, int act, const float* __restrict__ res, float* __restrict__ out, long V) {
+    const long bc = blockIdx.y;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const long i = bc * V + v;
+    float acc = res ? res[i] : 0.0f;
+    {
+        float z = (y0[i] - s0[2 * bc]) * s0[2 * bc + 1];
+        acc += act ? vx_gelu(z) : z;
+    }
+    if (nk > 1) {
+        float z = (y1[i] - s1[2 * bc]) * s1[2 * bc + 1];
+        acc += act ? vx_gelu(z) : z;
+    }
+    if (nk > 2) {
+        float z = (y2[i] - s2[2 * bc]) * s2[2 * bc + 1];
+        acc += act ? vx_gelu(z) : z;
+    }
+    out[i] = acc;
+}
+
+// backward statistics for one branch: m[2bc] = mean(dz), m[2bc+1] = mean(dz*z), dz = dout*act'(z)
+__global__ void __launch_bounds__(256) vx_in_bwd_stats_k(const float* __restrict__ dout, const float* __restrict__ y,
+                                                         const float* __restrict__ st, int act, float* __restrict__ m, long V) {
+    const long bc = blockIdx.x;
+    const float mean = st[2 * bc], rstd = st[2 * bc + 1];
+    double a = 0.0, c = 0.0;
+    for (long v = threadIdx.x; v < V; v += 256) {
+        const long i = bc * V + v;
+        const float z = (y[i] - mean) * rstd;
+        const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
+        a += (double)dz;
+        c += (double)dz * (double)z;
+    }
+    a = vx_wave_sum(a);
+    c = vx_wave_sum(c);
+    __shared__ double sm[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm[wid] = a; sm[4 + wid] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m[2 * bc] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)V);
+        m[2 * bc + 1] = (float)((sm[4] + sm[5] + sm[6] + sm[7]) / (double)V);
+    }
+}
+
+// dy = rstd * (dz - m1 - z*m2)
+__global__ void __launch_bounds__(256) vx_in_bwd_apply_k(const float* __restrict__ dout, const float* __restrict__ y,
+                                                         const float* __restrict__ st, const float* __restrict__ m, int act,
+                                                         float* __restrict__ dy, long V) {
+    const long bc = blockIdx.y;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const long i = bc * V + v;
+    const float mean = st[2 * bc], rstd = st[2 * bc + 1];
+    const float z = (y[i] - mean) * rstd;
+    const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
+    dy[i] = rstd * (dz - m[2 * bc] - z * m[2 * bc + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// channels-first LayerNorm, one thread per voxel (coalesced along V for every channel).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_ln_cf_fwd_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ out, int C, long V, float eps) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* __restrict__ xb = x + (long)blockIdx.y * C * V + v;
+    float* __restrict__ ob = out + (long)blockIdx.y * C * V + v;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xb[(long)c * V];
+    const float u = s / (float)C;
+    float q = 0.0f;
+    for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
+    const float r = 1.0f / sqrtf(q / (float)C + eps);
+    for (int c = 0; c < C; ++c) ob[(long)c * V] = fmaf(gamma[c], (xb[(long)c * V] - u) * r, beta[c]);
+}
+
+// dx = r*(g - mean_c(g) - xhat*mean_c(g*xhat)), g = dout*gamma;  dgamma += sum dout*xhat, dbeta += sum dout
+__global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dout,
+                                                      float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int C, long V, float eps) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = v < V;
+    const long base = (long)blockIdx.y * C * V + (ok ? v : 0);
+    const float* __restrict__ xb = x + base;
+    const float* __restrict__ db = dout + base;
+    float u = 0.0f, r = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (ok) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += xb[(long)c * V];
+        u = s / (float)C;
+        float q = 0.0f;
+        for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
+        r = 1.0f / sqrtf(q / (float)C + eps);
+        for (int c = 0; c < C; ++c) {
+            const float xh = (xb[(long)c * V] - u) * r;
+            const float g = db[(long)c * V] * gamma[c];
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+        }
+        s1 /= (float)C;
+        s2 /= (float)C;
+    }
+    __shared__ float sm[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        float dg = 0.0f, dbt = 0.0f;
+        if (ok) {
+            const float xh = (xb[(long)c * V] - u) * r;
+            const float d = db[(long)c * V];
+            dx[base + (long)c * V] = r * (d * gamma[c] - s1 - xh * s2);
+            dg = d * xh;
+            dbt = d;
+        }
+        dg = vx_wave_sum(dg);
+        dbt = vx_wave_sum(dbt);
+        __syncthreads();
+        if (lane == 0) { sm[wid] = dg; sm[4 + wid] = dbt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(dgamma + c, sm[0] + sm[1] + sm[2] + sm[3]);
+            atomicAdd(dbeta + c, sm[4] + sm[5] + sm[6] + sm[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise
+// ---------------------------------------------------------------------------------------------
+// h = drop(gelu(a))
+__global__ void __launch_bounds__(256) vx_gelu_drop_fwd_k(const float* __restrict__ a, float* __restrict__ h, long n, VxDrop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) h[i] = vx_gelu(a[i]) * vx_drop(d, (uint64_t)i);
+}
+// da = dh * mask * gelu'(a)
+__global__ void __launch_bounds__(256) vx_gelu_drop_bwd_k(const float* __restrict__ dh, const float* __restrict__ a, float* __restrict__ da, long n, VxDrop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) da[i] = dh[i] * vx_drop(d, (uint64_t)i) * vx_gelu_grad(a[i]);
+}
+// out = alpha*x + drop(z)   (x may be null -> out = drop(z))
+__global__ void __launch_bounds__(256) vx_axpy_drop_fwd_k(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out,
+                                                          float alpha, long n, VxDrop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (x ? alpha * x[i] : 0.0f) + z[i] * vx_drop(d, (uint64_t)i);
+}
+// dz = mask*dout ; dx = alpha*dout (if dx != null)
+__global__ void __launch_bounds__(256) vx_axpy_drop_bwd_k(const float* __restrict__ dout, float* __restrict__ dx, float* __restrict__ dz,
+                                                          float alpha, long n, VxDrop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = dout[i];
+    if (dz) dz[i] = g * vx_drop(d, (uint64_t)i);
+    if (dx) dx[i] = alpha * g;
+}
+// out = a + b (+ c)
+__global__ void __launch_bounds__(256) vx_add_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i] + (c ? c[i] : 0.0f);
+}
+// db[c] += sum_{b,v} dy[b,c,v] : one block per channel
+__global__ void __launch_bounds__(256) vx_channel_sum_k(const float* __restrict__ dy, float* __restrict__ db, int B, int C, long V) {
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* __restrict__ row = dy + ((long)b * C + c) * V;
+        for (long v = threadIdx.x; v < V; v += 256) s += row[v];
+    }
+    __shared__ float sm[4];
+    s = vx_block_sum_256(s, sm);
+    if (threadIdx.x == 0) atomicAdd(db + c, s);
+}
+
+// space-to-depth(2): PatchMerging.faeture_sample (attention_utils.py:144-159).  out[b, sub*C + c, d,h,w] = x[b,c,2d+i,2h+j,2w+k], sub = i*4+j*2+k
+__global__ void __launch_bounds__(256) vx_s2d2_k(const float* __restrict__ x, float* __restrict__ out, int C, int D, int H, int W, int inverse) {
+    // thread per (coarse) output element; D,H,W are the COARSE dims
+    const long Vc = (long)D * H * W;
+    const long n = (long)8 * C * Vc;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const long v = i % Vc;
+    const int ch = (int)(i / Vc);
+    const int sub = ch / C, c = ch % C;
+    const int w = (int)(v % W), h = (int)((v / W) % H), d = (int)(v / ((long)W * H));
+    const int fd = 2 * d + (sub >> 2), fh = 2 * h + ((sub >> 1) & 1), fw = 2 * w + (sub & 1);
+    const long fi = (((long)b * C + c) * (2 * D) + fd) * (long)(2 * H) * (2 * W) + (long)fh * (2 * W) + fw;
+    const long ci = (long)b * 8 * C * Vc + i;
+    if (inverse) out[fi] = x[ci]; else out[ci] = x[fi];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static VxDrop vx_mk_drop(const void* seed_ptr, unsigned long long stream, float p) {
+    VxDrop d;
+    d.seed_ptr = (p > 0.0f) ? (const uint64_t*)seed_ptr : nullptr;
+    d.stream = stream;
+    d.p = p;
+    return d;
+}
+
+extern "C" int vx_in_stats(const float* x, float* stats, long BC, long V, float eps, void* stream) {
+    VX_REQUIRE(x && stats && BC > 0 && V > 1, "vx_in_stats: bad args (InstanceNorm needs more than 1 spatial element; BC=%ld V=%ld)", BC, V);
+    hipLaunchKernelGGL(vx_in_stats_k, dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, stats, V, eps);
+    VX_LAUNCH_CHECK("vx_in_stats");
+    return 0;
+}
+
+extern "C" int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                               int nk, int act, const float* res, float* out, long BC, long V, void* stream) {
+    VX_REQUIRE(nk >= 1 && nk <= 3 && y0 && s0 && out && (nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)), "vx_in_apply_fwd: bad args");
+    hipLaunchKernelGGL(vx_in_apply_fwd_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, y0, y1, y2, s0, s1, s2, nk, act, res, out, V);
+    VX_LAUNCH_CHECK("vx_in_apply_fwd");
+    return 0;
+}
+
+extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, float* dy, long BC, long V, void* stream) {
+    VX_REQUIRE(dout && y && st && m_ws && dy, "vx_in_bwd: null pointer");
+    hipLaunchKernelGGL(vx_in_bwd_stats_k, dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, m_ws, V);
+    hipLaunchKernelGGL(vx_in_bwd_apply_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, m_ws, act, dy, V);
+    VX_LAUNCH_CHECK("vx_in_bwd");
+    return 0;
+}
+
+extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream) {
+    VX_REQUIRE(x && gamma && beta && out && B > 0 && C > 0 && V > 0, "vx_ln_cf_fwd: bad args");
+    hipLaunchKernelGGL(vx_ln_cf_fwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, C, V, eps);
+    VX_LAUNCH_CHECK("vx_ln_cf_fwd");
+    return 0;
+}
+
+extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,
+                            int B, int C, long V, float eps, void* stream) {
+    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta, "vx_ln_cf_bwd: null pointer");
+    hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, dgamma, dbeta, C, V, eps);
+    VX_LAUNCH_CHECK("vx_ln_cf_bwd");
+    return 0;
+}
+
+extern "C" int vx_gelu_drop_fwd(const float* a, float* h, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(a && h && n > 0, "vx_gelu_drop_fwd: bad args");
+    hipLaunchKernelGGL(vx_gelu_drop_fwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, h, n, vx_mk_drop(seed_ptr, dstream, p));
+    VX_LAUNCH_CHECK("vx_gelu_drop_fwd");
+    return 0;
+}
+extern "C" int vx_gelu_drop_bwd(const float* dh, const float* a, float* da, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(dh && a && da && n > 0, "vx_gelu_drop_bwd: bad args");
+    hipLaunchKernelGGL(vx_gelu_drop_bwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dh, a, da, n, vx_mk_drop(seed_ptr, dstream, p));
+    VX_LAUNCH_CHECK("vx_gelu_drop_bwd");
+    return 0;
+}
+extern "C" int vx_axpy_drop_fwd(const float* x, const float* z, float* out, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(z && out && n > 0, "vx_axpy_drop_fwd: bad args");
+    hipLaunchKernelGGL(vx_axpy_drop_fwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, z, out, alpha, n, vx_mk_drop(seed_ptr, dstream, p));
+    VX_LAUNCH_CHECK("vx_axpy_drop_fwd");
+    return 0;
+}
+extern "C" int vx_axpy_drop_bwd(const float* dout, float* dx, float* dz, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(dout && n > 0, "vx_axpy_drop_bwd: bad args");
+    hipLaunchKernelGGL(vx_axpy_drop_bwd_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, dz, alpha, n, vx_mk_drop(seed_ptr, dstream, p));
+    VX_LAUNCH_CHECK("vx_axpy_drop_bwd");
+    return 0;
+}
+extern "C" int vx_add(const float* a, const float* b, const float* c, float* out, long n, void* stream) {
+    VX_REQUIRE(a && b && out && n > 0, "vx_add: bad args");
+    hipLaunchKernelGGL(vx_add_k, dim3(vx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n);
+    VX_LAUNCH_CHECK("vx_add");
+    return 0;
+}
+extern "C" int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream) {
+    VX_REQUIRE(dy && db && B > 0 && C > 0 && V > 0, "vx_channel_sum: bad args");
+    hipLaunchKernelGGL(vx_channel_sum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, V);
+    VX_LAUNCH_CHECK("vx_channel_sum");
+    return 0;
+}
+extern "C" int vx_space_to_depth2(const float* x, float* out, int B, int C, int Dc, int Hc, int Wc, int inverse, void* stream) {
+    VX_REQUIRE(x && out && B > 0 && C > 0 && Dc > 0 && Hc > 0 && Wc > 0, "vx_space_to_depth2: bad args");
+    const long n = (long)8 * C * Dc * Hc * Wc;
+    hipLaunchKernelGGL(vx_s2d2_k, dim3(vx_cdiv(n, 256), B), dim3(256), 0, (hipStream_t)stream, x, out, C, Dc, Hc, Wc, inverse);
+    VX_LAUNCH_CHECK("vx_space_to_depth2");
+    return 0;
+}

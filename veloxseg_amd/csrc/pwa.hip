@@ -1,0 +1,450 @@
+// Paired-Window Attention kernels for gfx950 (fp32).
+// Reference: model/components/PWA.py:106-140 (gather), :308-327 (attention), :177-200 (scatter),
+//            model/components/attention_utils.py:83-125 (relative position bias).  Index maps: SURVEY.md A1.
+//
+// Token layout: tok[b, head a, window N (all scales concatenated), modality-major token T = m*l + t, lane c].
+// Attention: one WAVE (64 lanes) = 64 query rows of one (b, head, window); K/V rows are wave-uniform so
+// they travel on the scalar path (s_load) and feed v_fma as SGPR operands; the soft-max is an online
+// (flash-style) per-lane recurrence, scores never leave registers.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+__device__ __forceinline__ int vx_scale_of_window(const VxPwaPlan& P, int N) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < P.nb && N >= P.woff[k]) i = k;
+    return i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather: max-pool(s_i) of the scale-i channel slice, then window partition
+// grid: (ceil(V/256), nb*h*c channels, B); thread = one pooled cell of one channel
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_pwa_gather_fwd_k(const float* __restrict__ src, float* __restrict__ tok, VxPwaPlan P, int c, int m, int M) {
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
+    const int s0 = P.small[i][0], s1 = P.small[i][1], s2 = P.small[i][2];
+    const int p0n = P.grid[0] / s0, p1n = P.grid[1] / s1, p2n = P.grid[2] / s2;
+    const int pv = blockIdx.x * 256 + threadIdx.x;
+    if (pv >= p0n * p1n * p2n) return;
+    const int p2 = pv % p2n, p1 = (pv / p2n) % p1n, p0 = pv / (p2n * p1n);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const float* __restrict__ sc = src + ((long)b * (P.nb * P.heads * c) + ch) * V;
+    float best = -INFINITY;
+    for (int d = 0; d < s0; ++d)
+        for (int h = 0; h < s1; ++h)
+            for (int w = 0; w < s2; ++w) {
+                const float val = sc[((long)(p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w)];
+                if (val > best || val != val) best = val;
+            }
+    const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+    tok[((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc] = best;
+}
+
+// gradient goes to the first arg-max of each pooled cell (aten max_pool3d tie rule), zero elsewhere
+__global__ void __launch_bounds__(256) vx_pwa_gather_bwd_k(const float* __restrict__ src, const float* __restrict__ dtok, float* __restrict__ dsrc,
+                                                           VxPwaPlan P, int c, int m, int M) {
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
+    const int s0 = P.small[i][0], s1 = P.small[i][1], s2 = P.small[i][2];
+    const int p0n = P.grid[0] / s0, p1n = P.grid[1] / s1, p2n = P.grid[2] / s2;
+    const int pv = blockIdx.x * 256 + threadIdx.x;
+    if (pv >= p0n * p1n * p2n) return;
+    const int p2 = pv % p2n, p1 = (pv / p2n) % p1n, p0 = pv / (p2n * p1n);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const long cbase = ((long)b * (P.nb * P.heads * c) + ch) * V;
+    float best = -INFINITY;
+    long bidx = -1;
+    for (int d = 0; d < s0; ++d)
+        for (int h = 0; h < s1; ++h)
+            for (int w = 0; w < s2; ++w) {
+                const long idx = ((long)(p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w);
+                const float val = src[cbase + idx];
+                if (bidx < 0 || val > best || val != val) { best = val; bidx = idx; }
+            }
+    const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+    const float g = dtok[((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc];
+    for (int d = 0; d < s0; ++d)
+        for (int h = 0; h < s1; ++h)
+            for (int w = 0; w < s2; ++w) {
+                const long idx = ((long)(p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w);
+                dsrc[cbase + idx] = (idx == bidx) ? g : 0.0f;
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scatter: per-window trilinear up-sampling (align_corners=True) of the n^3 window outputs
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int& i1, float& lam) {
+    if (bw == n) { i0 = j; i1 = j; lam = 0.0f; return; }
+    const float ratio = (float)(n - 1) / (float)(bw - 1);
+    const float s = ratio * (float)j;
+    i0 = (int)s;
+    lam = s - (float)i0;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restrict__ tok, float* __restrict__ out, VxPwaPlan P, int c, int m, int M) {
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
+    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
+    const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
+    const int W0 = x0 / bw0, W1 = x1 / bw1, W2 = x2 / bw2;
+    int a0, b0, a1, b1, a2, b2;
+    float l0, l1, l2;
+    vx_src_coord(x0 % bw0, P.n[0], bw0, a0, b0, l0);
+    vx_src_coord(x1 % bw1, P.n[1], bw1, a1, b1, l1);
+    vx_src_coord(x2 % bw2, P.n[2], bw2, a2, b2, l2);
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const float* __restrict__ tw = tok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l) * c + cc;
+    auto T = [&](int t0, int t1, int t2) { return tw[(long)((t0 * P.n[1] + t1) * P.n[2] + t2) * c]; };
+    const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
+    const float val = k0 * (k1 * (k2 * T(a0, a1, a2) + l2 * T(a0, a1, b2)) + l1 * (k2 * T(a0, b1, a2) + l2 * T(a0, b1, b2))) +
+                      l0 * (k1 * (k2 * T(b0, a1, a2) + l2 * T(b0, a1, b2)) + l1 * (k2 * T(b0, b1, a2) + l2 * T(b0, b1, b2)));
+    out[((long)b * (P.nb * P.heads * c) + ch) * V + v] = val;
+}
+
+// adjoint: one thread per token element; loops over the output voxels of its window it contributes to
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M) {
+    const int b = blockIdx.z, a = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;          // over (N, t, cc)
+    if (e >= (long)P.Ntot * P.l * c) return;
+    const int cc = (int)(e % c);
+    const int t = (int)((e / c) % P.l);
+    const int N = (int)(e / ((long)c * P.l));
+    const int i = vx_scale_of_window(P, N);
+    const int Nl = N - P.woff[i];
+    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    const int t2 = t % P.n[2], t1 = (t / P.n[2]) % P.n[1], t0 = t / (P.n[2] * P.n[1]);
+    const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
+    const int ch = (i * P.heads + a) * c + cc;
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const float* __restrict__ dc = dout + ((long)b * (P.nb * P.heads * c) + ch) * V;
+    // support of token coordinate tk along an axis: output positions j whose i0 or i1 equals tk
+    auto range = [](int tk, int n, int bw, int& lo, int& hi) {
+        lo = bw; hi = -1;
+        for (int j = 0; j < bw; ++j) {
+            int i0, i1; float lam;
+            vx_src_coord(j, n, bw, i0, i1, lam);
+            if (i0 == tk || i1 == tk) { if (j < lo) lo = j; if (j > hi) hi = j; }
+        }
+    };
+    auto weight = [](int j, int tk, int n, int bw) {
+        int i0, i1; float lam;
+        vx_src_coord(j, n, bw, i0, i1, lam);
+        return (i0 == tk ? 1.0f - lam : 0.0f) + (i1 == tk ? lam : 0.0f);
+    };
+    int lo0, hi0, lo1, hi1, lo2, hi2;
+    range(t0, P.n[0], bw0, lo0, hi0);
+    range(t1, P.n[1], bw1, lo1, hi1);
+    range(t2, P.n[2], bw2, lo2, hi2);
+    float acc = 0.0f;
+    for (int j0 = lo0; j0 <= hi0; ++j0) {
+        const float w0 = weight(j0, t0, P.n[0], bw0);
+        for (int j1 = lo1; j1 <= hi1; ++j1) {
+            const float w01 = w0 * weight(j1, t1, P.n[1], bw1);
+            const long row = ((long)(W0 * bw0 + j0) * P.grid[1] + (W1 * bw1 + j1)) * P.grid[2] + W2 * bw2;
+            for (int j2 = lo2; j2 <= hi2; ++j2) acc = fmaf(w01 * weight(j2, t2, P.n[2], bw2), dc[row + j2], acc);
+        }
+    }
+    dtok[((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------
+struct VxAttn {
+    int BH;        // B*heads
+    int heads;
+    int Nt;        // windows
+    int ML, l, M;  // tokens per window (all modalities), per modality, modalities
+    int n[3];
+    int cq, cv;
+    float scale;
+    int lin_cst;   // (n0-1)(2n1-1)(2n2-1) + (n1-1)(2n2-1) + (n2-1)
+};
+
+__device__ __forceinline__ int vx_lin_of_token(const VxAttn& A, int T) {
+    const int t = T % A.l;
+    const int t2 = t % A.n[2], t1 = (t / A.n[2]) % A.n[1], t0 = t / (A.n[2] * A.n[1]);
+    return (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+}
+
+// unit = (bh, window, 64-query chunk); one wave per unit, 4 units per block
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                         const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
+                                                         VxAttn A, VxDrop drop) {
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    const long u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (u >= units) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = (int)(u % chunks);
+    const long win = u / chunks;                       // (bh*Nt + N)
+    const int a = (int)((win / A.Nt) % A.heads);
+    const int i = chunk * 64 + lane;
+    const bool ok = i < A.ML;
+    const int iq = ok ? i : A.ML - 1;
+    const float* __restrict__ qp = Q + (win * A.ML + iq) * CQ;
+    float q[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) q[c] = qp[c] * A.scale;
+    const int lin_i = vx_lin_of_token(A, iq) + A.lin_cst;
+    float acc[CV];
+#pragma unroll
+    for (int c = 0; c < CV; ++c) acc[c] = 0.0f;
+    float mrun = -INFINITY, lsum = 0.0f;
+    const float* __restrict__ kp = K + win * A.ML * CQ;
+    const float* __restrict__ vp = Vt + win * A.ML * CV;
+    const uint64_t drow = ((uint64_t)win * A.ML + iq) * (uint64_t)A.ML;
+    for (int j = 0; j < A.ML; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kp[(long)j * CQ + c], s);
+        s += table[(long)(lin_i - vx_lin_of_token(A, j)) * A.heads + a];
+        const float mn = fmaxf(mrun, s);
+        const float alpha = expf(mrun - mn);
+        const float p = expf(s - mn);
+        lsum = lsum * alpha + p;
+        const float pd = p * vx_drop(drop, drow + j);
+#pragma unroll
+        for (int c = 0; c < CV; ++c) acc[c] = fmaf(pd, vp[(long)j * CV + c], acc[c] * alpha);
+        mrun = mn;
+    }
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        float* __restrict__ op = O + (win * A.ML + i) * CV;
+#pragma unroll
+        for (int c = 0; c < CV; ++c) op[c] = acc[c] * inv;
+        LSE[win * A.ML + i] = mrun + logf(lsum);
+    }
+}
+
+// backward A: lane = query row.  dQ, delta = rowsum(dO*O), d(bias table) (LDS-staged atomics)
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                           const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                           const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
+                                                           float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop) {
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // [4][Tsz] private bias-gradient tables
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* __restrict__ stab = vx_sm + (long)wave * Tsz;
+    for (int k = lane; k < Tsz; k += 64) stab[k] = 0.0f;
+    __syncthreads();
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    const long u_raw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    const bool active = u_raw < units;
+    const long u = active ? u_raw : units - 1;
+    const int chunk = (int)(u % chunks);
+    const long win = u / chunks;
+    const int a = (int)((win / A.Nt) % A.heads);
+    const int i = chunk * 64 + lane;
+    const bool ok = active && i < A.ML;
+    const int iq = (i < A.ML) ? i : A.ML - 1;
+    const long row = win * A.ML + iq;
+    float q[CQ], dq[CQ], dov[CV];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) { q[c] = Q[row * CQ + c] * A.scale; dq[c] = 0.0f; }
+    float delta = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CV; ++c) { dov[c] = dO[row * CV + c]; delta = fmaf(dov[c], O[row * CV + c], delta); }
+    const float lse = LSE[row];
+    const int lin_i = vx_lin_of_token(A, iq) + A.lin_cst;
+    const float* __restrict__ kp = K + win * A.ML * CQ;
+    const float* __restrict__ vp = Vt + win * A.ML * CV;
+    const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
+    for (int j = 0; j < A.ML; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kp[(long)j * CQ + c], s);
+        const int bi = lin_i - vx_lin_of_token(A, j);
+        s += table[(long)bi * A.heads + a];
+        const float p = expf(s - lse);
+        float dp = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], vp[(long)j * CV + c], dp);
+        dp *= vx_drop(drop, drow + j);
+        const float ds = ok ? p * (dp - delta) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kp[(long)j * CQ + c], dq[c]);
+        atomicAdd(stab + bi, ds);
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) dQ[row * CQ + c] = dq[c] * A.scale;
+        Delta[row] = delta;
+    }
+    __syncthreads();
+    for (int k = lane; k < Tsz; k += 64) {
+        const float g = stab[k];
+        if (g != 0.0f) atomicAdd(dtable + (long)k * A.heads + a, g);
+    }
+}
+
+// backward B: lane = key row.  dK, dV
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                            const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                            const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
+                                                            VxAttn A, VxDrop drop) {
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    const long u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (u >= units) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = (int)(u % chunks);
+    const long win = u / chunks;
+    const int a = (int)((win / A.Nt) % A.heads);
+    const int j = chunk * 64 + lane;
+    const bool ok = j < A.ML;
+    const int jk = ok ? j : A.ML - 1;
+    const long krow = win * A.ML + jk;
+    float k[CQ], dk[CQ], v[CV], dv[CV];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) { k[c] = K[krow * CQ + c]; dk[c] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < CV; ++c) { v[c] = Vt[krow * CV + c]; dv[c] = 0.0f; }
+    const int lin_j = vx_lin_of_token(A, jk) - A.lin_cst;
+    const float* __restrict__ qp = Q + win * A.ML * CQ;
+    const float* __restrict__ dop = dO + win * A.ML * CV;
+    for (int i = 0; i < A.ML; ++i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) s = fmaf(qp[(long)i * CQ + c], k[c], s);
+        s = s * A.scale + table[(long)(vx_lin_of_token(A, i) - lin_j) * A.heads + a];
+        const float p = expf(s - LSE[win * A.ML + i]);
+        const float msk = vx_drop(drop, ((uint64_t)(win * A.ML + i)) * (uint64_t)A.ML + jk);
+        float dp = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CV; ++c) dp = fmaf(dop[(long)i * CV + c], v[c], dp);
+        const float pd = p * msk;
+#pragma unroll
+        for (int c = 0; c < CV; ++c) dv[c] = fmaf(pd, dop[(long)i * CV + c], dv[c]);
+        const float ds = p * (dp * msk - Delta[win * A.ML + i]) * A.scale;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) dk[c] = fmaf(ds, qp[(long)i * CQ + c], dk[c]);
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) dK[krow * CQ + c] = dk[c];
+#pragma unroll
+        for (int c = 0; c < CV; ++c) dV[krow * CV + c] = dv[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static int vx_plan_check(const VxPwaPlan* P, const char* who) {
+    if (!P) VX_FAIL(-1, "%s: null plan", who);
+    if (P->nb < 1 || P->nb > 4 || P->heads < 1 || P->l != P->n[0] * P->n[1] * P->n[2]) VX_FAIL(-1, "%s: bad plan (nb=%d heads=%d l=%d)", who, P->nb, P->heads, P->l);
+    for (int i = 0; i < P->nb; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (P->small[i][k] < 1 || P->nwin[i][k] < 1 || P->nwin[i][k] * P->n[k] * P->small[i][k] != P->grid[k])
+                VX_FAIL(-1, "%s: scale %d does not tile the grid on axis %d", who, i, k);
+    return 0;
+}
+
+extern "C" int vx_pwa_gather_fwd(const float* src, float* tok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_gather_fwd")) return e;
+    VX_REQUIRE(src && tok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_gather_fwd: bad args");
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    hipLaunchKernelGGL(vx_pwa_gather_fwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, src, tok, *plan, c, m, M);
+    VX_LAUNCH_CHECK("vx_pwa_gather_fwd");
+    return 0;
+}
+
+extern "C" int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsrc, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_gather_bwd")) return e;
+    VX_REQUIRE(src && dtok && dsrc && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_gather_bwd: bad args");
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    hipLaunchKernelGGL(vx_pwa_gather_bwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, src, dtok, dsrc, *plan, c, m, M);
+    VX_LAUNCH_CHECK("vx_pwa_gather_bwd");
+    return 0;
+}
+
+extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_fwd")) return e;
+    VX_REQUIRE(tok && out && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_fwd: bad args");
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    hipLaunchKernelGGL(vx_pwa_scatter_fwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
+    VX_LAUNCH_CHECK("vx_pwa_scatter_fwd");
+    return 0;
+}
+
+extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
+    VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
+    const long E = (long)plan->Ntot * plan->l * c;
+    hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(vx_cdiv(E, 256), plan->heads, B), dim3(256), 0, (hipStream_t)stream, dout, dtok, *plan, c, m, M);
+    VX_LAUNCH_CHECK("vx_pwa_scatter_bwd");
+    return 0;
+}
+
+static int vx_attn_fill(VxAttn& A, const VxPwaPlan* P, int B, int M, int cq, int cv, const char* who) {
+    if (int e = vx_plan_check(P, who)) return e;
+    if (B <= 0 || M <= 0) VX_FAIL(-1, "%s: bad B/M", who);
+    A.BH = B * P->heads; A.heads = P->heads; A.Nt = P->Ntot; A.l = P->l; A.M = M; A.ML = M * P->l;
+    A.n[0] = P->n[0]; A.n[1] = P->n[1]; A.n[2] = P->n[2];
+    A.cq = cq; A.cv = cv; A.scale = 1.0f / sqrtf((float)cq);
+    A.lin_cst = ((P->n[0] - 1) * (2 * P->n[1] - 1) + (P->n[1] - 1)) * (2 * P->n[2] - 1) + (P->n[2] - 1);
+    return 0;
+}
+
+template <int A_, int B_> struct vx_pair { static constexpr int a = A_, b = B_; };
+// returns false when the (c_qk, c_v) pair has no instantiation
+template <class F> static bool vx_attn_dispatch(int cq, int cv, F&& f) {
+#define VX_CASE(X, Y) if (cq == X && cv == Y) { f(vx_pair<X, Y>{}); return true; }
+    VX_CASE(4, 4) VX_CASE(8, 8) VX_CASE(8, 16) VX_CASE(16, 16) VX_CASE(16, 32) VX_CASE(4, 8) VX_CASE(2, 2) VX_CASE(2, 4)
+    VX_CASE(4, 16) VX_CASE(8, 32) VX_CASE(2, 8) VX_CASE(16, 64) VX_CASE(8, 64) VX_CASE(32, 32)
+#undef VX_CASE
+    return false;
+}
+
+extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
+                               const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, cq, cv, "vx_pwa_attn_fwd")) return e;
+    VX_REQUIRE(Q && K && V && table && O && LSE, "vx_pwa_attn_fwd: null pointer");
+    const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
+    VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
+    const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
+        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, A, d);
+    });
+    if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
+    VX_LAUNCH_CHECK("vx_pwa_attn_fwd");
+    return 0;
+}
+
+extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                               const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
+                               const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, cq, cv, "vx_pwa_attn_bwd")) return e;
+    VX_REQUIRE(Q && K && V && table && O && LSE && dO && dQ && dK && dV && dtable && delta_ws, "vx_pwa_attn_bwd: null pointer");
+    const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
+    const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+    const size_t shm = (size_t)4 * Tsz * sizeof(float);
+    VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
+    VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
+    const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
+        constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
+        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, dtable, Tsz, A, d);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, A, d);
+    });
+    if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
+    VX_LAUNCH_CHECK("vx_pwa_attn_bwd");
+    return 0;
+}

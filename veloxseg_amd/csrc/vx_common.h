@@ -1,0 +1,110 @@
+// Shared device/host helpers for the VeloxSeg gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define VX_WAVE 64
+
+extern thread_local char vx_err_buf[512];
+
+#define VX_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(vx_err_buf, sizeof(vx_err_buf), __VA_ARGS__); \
+        return (code);                                       \
+    } while (0)
+
+#define VX_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) VX_FAIL(-1, __VA_ARGS__); \
+    } while (0)
+
+// Launch check: hipGetLastError only (no sync; graph-capturable).
+#define VX_LAUNCH_CHECK(name)                                                            \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) VX_FAIL(-2, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int vx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions -------------------------------------------------------------
+__device__ __forceinline__ float vx_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double vx_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float vx_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over a 256-thread block (4 waves); result valid in thread 0.  `sm` needs >= 4 floats.
+__device__ __forceinline__ float vx_block_sum_256(float v, float* sm) {
+    v = vx_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ---- exact-erf GELU (nn.GELU() default) ---------------------------------------------------
+__device__ __forceinline__ float vx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float vx_gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- counter-based RNG for dropout: Philox4x32-10 ------------------------------------------
+struct VxPhilox {
+    uint32_t c[4];
+    uint32_t k[2];
+};
+__device__ __forceinline__ void vx_philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+// 4 x 32 random bits for (seed, stream id, counter)
+__device__ __forceinline__ void vx_philox4(uint64_t seed, uint64_t stream, uint64_t ctr, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        vx_philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+// keep-mask scale for element `idx` of dropout stream `stream`: returns 0 or 1/(1-p)
+__device__ __forceinline__ float vx_dropout_scale(uint64_t seed, uint64_t stream, uint64_t idx, float p, float inv_keep) {
+    uint32_t r[4];
+    vx_philox4(seed, stream, idx >> 2, r);
+    const uint32_t bits = r[idx & 3];
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);   // [0,1)
+    return u >= p ? inv_keep : 0.0f;
+}
+
+// Dropout descriptor passed by value to kernels.  `seed_ptr` points at a device uint64 pair
+// {seed, step}; the step is bumped by the host/optimizer so a captured graph replays new masks.
+struct VxDrop {
+    const uint64_t* seed_ptr;   // nullptr => dropout off
+    uint64_t stream;            // unique per dropout site
+    float p;
+};
+__device__ __forceinline__ float vx_drop(const VxDrop& d, uint64_t idx) {
+    if (d.seed_ptr == nullptr || d.p <= 0.0f) return 1.0f;
+    const uint64_t seed = d.seed_ptr[0] + 0x9E3779B97F4A7C15ull * d.seed_ptr[1];
+    return vx_dropout_scale(seed, d.stream, idx, d.p, 1.0f / (1.0f - d.p));
+}

@@ -1,0 +1,567 @@
+"""Autograd operators of the VeloxSeg hot path, each backed by hand-written HIP kernels (libveloxseg_hip.so).
+
+Every operator takes / returns contiguous fp32 NCDHW CUDA tensors and launches on the current PyTorch
+HIP stream, so a whole training step can be captured into one hipGraph.  Parameter gradients are
+ACCUMULATED IN PLACE into `param.grad` by the weight-gradient kernels (float atomics), and `None` is
+returned to autograd for them: no per-parameter AccumulateGrad kernels, one flat gradient buffer for
+the RCCL all-reduce and the fused AdamW (see veloxseg_amd/engine.py).
+
+There is no CPU implementation here on purpose (tier rule: the product path has no fallback).
+"""
+from __future__ import annotations
+
+import itertools
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _hip as H
+
+IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
+LN_EPS = 1e-6      # reference attention_utils.py:15
+
+# ------------------------------------------------------------------------------------------------
+# dropout RNG state: device int64[2] = {seed, step}; kernels hash (seed, step, site, element index)
+# ------------------------------------------------------------------------------------------------
+_site_counter = itertools.count(1)
+_rng_state = {}
+
+
+def new_dropout_site() -> int:
+    return next(_site_counter)
+
+
+def rng_state(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _rng_state:
+        _rng_state[key] = torch.tensor([12345, 0], dtype=torch.int64, device=device)
+    return _rng_state[key]
+
+
+def manual_seed(seed: int, device="cuda"):
+    st = rng_state(torch.device(device) if not isinstance(device, torch.device) else device)
+    st.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+
+
+def advance_rng(device):
+    rng_state(device)[1:2].add_(1)
+
+
+def grad_buf(p: torch.Tensor) -> torch.Tensor:
+    """Running gradient buffer of a parameter (created zeroed on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _check(x: torch.Tensor, what: str):
+    if not x.is_cuda:
+        raise RuntimeError(f"veloxseg_amd.{what}: input is on {x.device}; the VeloxSeg hot path runs only on an MI355X "
+                           "(HIP kernels, no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"veloxseg_amd.{what}: expected float32, got {x.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions
+# ------------------------------------------------------------------------------------------------
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x2, w, b, K, S, P, G, ps):
+        _check(x, "conv3d")
+        x = _c(x)
+        x2 = _c(x2) if x2 is not None else None
+        B, C1, D, Hh, W = x.shape
+        Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+        Cout = w.shape[0]
+        assert w.shape[1] * G == Cin and w.shape[2] == K, (tuple(w.shape), Cin, G, K)
+        Do, Ho, Wo = (D + 2 * P - K) // S + 1, (Hh + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
+        if ps == 1:
+            y = torch.empty((B, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+        else:
+            y = torch.empty((B, Cout // ps ** 3, Do * ps, Ho * ps, Wo * ps), device=x.device, dtype=torch.float32)
+        H.call("vx_conv3d_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, H.stream_ptr())
+        ctx.save_for_backward(x, x2)
+        ctx.w, ctx.b = w, b
+        ctx.meta = (B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2 = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps = ctx.meta
+        dy = _c(dy)
+        st = H.stream_ptr()
+        dx = dx2 = None
+        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        if need_x:
+            dx = torch.empty_like(x)
+            dx2 = torch.empty_like(x2) if x2 is not None else None
+            H.call("vx_conv3d_bwd_data", H.P(dy), H.P(w), None, H.P(dx), H.P(dx2), C1, B, Cin, D, Hh, W, Cout, K, S, P, G, ps, 0, st)
+        if w.requires_grad:
+            db = grad_buf(b) if (b is not None and b.requires_grad) else None
+            H.call("vx_conv3d_bwd_weight", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
+        return dx, dx2, None, None, None, None, None, None, None
+
+
+def conv3d(x, w, b=None, *, x2=None, stride=1, padding=0, groups=1, pixel_shuffle=1):
+    """Conv3d (+ optional channel-concat input, + optional PixelShuffle store)."""
+    return _Conv3dFn.apply(x, x2, w, b, int(w.shape[2]), int(stride), int(padding), int(groups), int(pixel_shuffle))
+
+
+class _ConvTransposeK2S2Fn(torch.autograd.Function):
+    """ConvTranspose3d(kernel=2, stride=2) run as the adjoint of a stride-2 conv (conv_blocks.py:29-35)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _check(x, "conv_transpose3d")
+        x = _c(x)
+        B, Ci, d, h, wd = x.shape
+        Co = w.shape[1]
+        assert w.shape[0] == Ci and tuple(w.shape[2:]) == (2, 2, 2)
+        y = torch.empty((B, Co, 2 * d, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
+        H.call("vx_conv3d_bwd_data", H.P(x), H.P(w), H.P(b), H.P(y), None, 0, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, 0, H.stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.w, ctx.b = w, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        dy = _c(dy)
+        B, Ci, d, h, wd = x.shape
+        Co = w.shape[1]
+        st = H.stream_ptr()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            H.call("vx_conv3d_fwd", H.P(dy), None, 0, H.P(w), None, H.P(dx), B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
+        if w.requires_grad:
+            H.call("vx_conv3d_bwd_weight", H.P(dy), None, 0, H.P(x), H.P(grad_buf(w)), None, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
+        if b is not None and b.requires_grad:
+            H.call("vx_channel_sum", H.P(dy), H.P(grad_buf(b)), B, Co, 8 * d * h * wd, st)
+        return dx, None, None
+
+
+def conv_transpose_k2s2(x, w, b):
+    return _ConvTransposeK2S2Fn.apply(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm (+ activation, + n-way sum, + residual)
+# ------------------------------------------------------------------------------------------------
+class _InstNormSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, res, act, *ys):
+        n = len(ys)
+        assert 1 <= n <= 3
+        ys = [_c(y) for y in ys]
+        _check(ys[0], "instance_norm")
+        B, C = ys[0].shape[:2]
+        V = ys[0][0, 0].numel()
+        st = H.stream_ptr()
+        stats = [torch.empty((B * C * 2,), device=ys[0].device, dtype=torch.float32) for _ in ys]
+        for y, s in zip(ys, stats):
+            H.call("vx_in_stats", H.P(y), H.P(s), B * C, V, IN_EPS, st)
+        out = torch.empty_like(ys[0])
+        res_c = _c(res) if res is not None else None
+        pp = [H.P(y) for y in ys] + [None] * (3 - n)
+        ss = [H.P(s) for s in stats] + [None] * (3 - n)
+        H.call("vx_in_apply_fwd", *pp, *ss, n, int(act), H.P(res_c), H.P(out), B * C, V, st)
+        ctx.save_for_backward(*ys, *stats)
+        ctx.n, ctx.act, ctx.has_res = n, int(act), res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n = ctx.n
+        ys, stats = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dout = _c(dout)
+        B, C = ys[0].shape[:2]
+        V = ys[0][0, 0].numel()
+        st = H.stream_ptr()
+        grads = []
+        for k in range(n):
+            if ctx.needs_input_grad[2 + k]:
+                dy = torch.empty_like(ys[k])
+                ws = torch.empty((B * C * 2,), device=dout.device, dtype=torch.float32)
+                H.call("vx_in_bwd", H.P(dout), H.P(ys[k]), H.P(stats[k]), ctx.act, H.P(ws), H.P(dy), B * C, V, st)
+                grads.append(dy)
+            else:
+                grads.append(None)
+        dres = dout if (ctx.has_res and ctx.needs_input_grad[0]) else None
+        return (dres, None, *grads)
+
+
+def instnorm_sum(ys: Sequence[torch.Tensor], act: bool = False, res: Optional[torch.Tensor] = None):
+    """(res) + sum_k act(InstanceNorm(y_k))."""
+    return _InstNormSumFn.apply(res, bool(act), *ys)
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-first LayerNorm
+# ------------------------------------------------------------------------------------------------
+class _LayerNormCFFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _check(x, "layer_norm")
+        x = _c(x)
+        B, C = x.shape[:2]
+        V = x[0, 0].numel()
+        out = torch.empty_like(x)
+        H.call("vx_ln_cf_fwd", H.P(x), H.P(gamma), H.P(beta), H.P(out), B, C, V, LN_EPS, H.stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.g, ctx.bt = gamma, beta
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dout = _c(dout)
+        B, C = x.shape[:2]
+        V = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        H.call("vx_ln_cf_bwd", H.P(x), H.P(ctx.g), H.P(dout), H.P(dx), H.P(grad_buf(ctx.g)), H.P(grad_buf(ctx.bt)), B, C, V, LN_EPS, H.stream_ptr())
+        return dx, None, None
+
+
+def layernorm_cf(x, gamma, beta):
+    return _LayerNormCFFn.apply(x, gamma, beta)
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise
+# ------------------------------------------------------------------------------------------------
+class _GeluDropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, p, site):
+        _check(a, "gelu")
+        a = _c(a)
+        h = torch.empty_like(a)
+        rs = rng_state(a.device) if p > 0 else None
+        H.call("vx_gelu_drop_fwd", H.P(a), H.P(h), a.numel(), H.P(rs, torch.int64), site, float(p), H.stream_ptr())
+        ctx.save_for_backward(a)
+        ctx.p, ctx.site = float(p), site
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (a,) = ctx.saved_tensors
+        dh = _c(dh)
+        da = torch.empty_like(a)
+        rs = rng_state(a.device) if ctx.p > 0 else None
+        H.call("vx_gelu_drop_bwd", H.P(dh), H.P(a), H.P(da), a.numel(), H.P(rs, torch.int64), ctx.site, ctx.p, H.stream_ptr())
+        return da, None, None
+
+
+def gelu_dropout(a, p: float = 0.0, site: int = 0):
+    return _GeluDropFn.apply(a, float(p), int(site))
+
+
+class _AxpyDropFn(torch.autograd.Function):
+    """out = alpha * x + dropout(z)  (x may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, z, alpha, p, site):
+        _check(z, "residual_dropout")
+        z = _c(z)
+        xc = _c(x) if x is not None else None
+        out = torch.empty_like(z)
+        rs = rng_state(z.device) if p > 0 else None
+        H.call("vx_axpy_drop_fwd", H.P(xc), H.P(z), H.P(out), float(alpha), z.numel(), H.P(rs, torch.int64), site, float(p), H.stream_ptr())
+        ctx.alpha, ctx.p, ctx.site, ctx.has_x = float(alpha), float(p), site, x is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        need_x = ctx.has_x and ctx.needs_input_grad[0]
+        dx = dz = None
+        if ctx.p == 0.0 and (ctx.alpha == 1.0 or not need_x):
+            return (dout if need_x else None), dout, None, None, None
+        if need_x:
+            dx = dout if ctx.alpha == 1.0 else torch.empty_like(dout)
+        dz = dout if ctx.p == 0.0 else torch.empty_like(dout)
+        rs = rng_state(dout.device) if ctx.p > 0 else None
+        H.call("vx_axpy_drop_bwd", H.P(dout), H.P(dx) if (need_x and ctx.alpha != 1.0) else None,
+               H.P(dz) if ctx.p > 0 else None, ctx.alpha, dout.numel(), H.P(rs, torch.int64), ctx.site, ctx.p, H.stream_ptr())
+        return dx, dz, None, None, None
+
+
+def residual_dropout(x, z, alpha: float = 1.0, p: float = 0.0, site: int = 0):
+    return _AxpyDropFn.apply(x, z, float(alpha), float(p), int(site))
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _check(a, "add")
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        H.call("vx_add", H.P(a), H.P(b), None, H.P(out), a.numel(), H.stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+class _SpaceToDepth2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check(x, "space_to_depth")
+        x = _c(x)
+        B, C, D, Hh, W = x.shape
+        assert D % 2 == 0 and Hh % 2 == 0 and W % 2 == 0
+        out = torch.empty((B, 8 * C, D // 2, Hh // 2, W // 2), device=x.device, dtype=torch.float32)
+        H.call("vx_space_to_depth2", H.P(x), H.P(out), B, C, D // 2, Hh // 2, W // 2, 0, H.stream_ptr())
+        ctx.shape = (B, C, D, Hh, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, D, Hh, W = ctx.shape
+        g = _c(g)
+        dx = torch.empty((B, C, D, Hh, W), device=g.device, dtype=torch.float32)
+        H.call("vx_space_to_depth2", H.P(g), H.P(dx), B, C, D // 2, Hh // 2, W // 2, 1, H.stream_ptr())
+        return dx
+
+
+def space_to_depth2(x):
+    return _SpaceToDepth2Fn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# Paired-Window Attention core: gather -> attention -> scatter for all modalities
+# ------------------------------------------------------------------------------------------------
+class _PwaCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, plan, cq, cv, M, p_attn, site, *qkv):
+        assert len(qkv) == 3 * M
+        qkv = [_c(t) for t in qkv]
+        _check(qkv[0], "pwa_attention")
+        B = qkv[0].shape[0]
+        dev = qkv[0].device
+        h, Nt, ML = plan.heads, plan.Ntot, M * plan.l
+        st = H.stream_ptr()
+        pp = H.ctypes.addressof(plan)
+        tq = torch.empty((B, h, Nt, ML, cq), device=dev, dtype=torch.float32)
+        tk = torch.empty_like(tq)
+        tv = torch.empty((B, h, Nt, ML, cv), device=dev, dtype=torch.float32)
+        for m in range(M):
+            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m]), H.P(tq), pp, cq, m, M, B, st)
+            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m + 1]), H.P(tk), pp, cq, m, M, B, st)
+            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m + 2]), H.P(tv), pp, cv, m, M, B, st)
+        O = torch.empty_like(tv)
+        lse = torch.empty((B, h, Nt, ML), device=dev, dtype=torch.float32)
+        rs = rng_state(dev) if p_attn > 0 else None
+        tbl = _c(table)
+        H.call("vx_pwa_attn_fwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), pp, B, M, cq, cv,
+               H.P(rs, torch.int64), site, float(p_attn), st)
+        g = (plan.grid[0], plan.grid[1], plan.grid[2])
+        outs = []
+        for m in range(M):
+            o = torch.empty((B, plan.nb * h * cv, *g), device=dev, dtype=torch.float32)
+            H.call("vx_pwa_scatter_fwd", H.P(O), H.P(o), pp, cv, m, M, B, st)
+            outs.append(o)
+        ctx.save_for_backward(tq, tk, tv, O, lse, tbl, *qkv)
+        ctx.table = table
+        ctx.plan, ctx.cq, ctx.cv, ctx.M, ctx.p, ctx.site = plan, cq, cv, M, float(p_attn), site
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        tq, tk, tv, O, lse, tbl = ctx.saved_tensors[:6]
+        qkv = ctx.saved_tensors[6:]
+        plan, cq, cv, M = ctx.plan, ctx.cq, ctx.cv, ctx.M
+        B = tq.shape[0]
+        dev = tq.device
+        st = H.stream_ptr()
+        pp = H.ctypes.addressof(plan)
+        dO = torch.empty_like(O)
+        for m in range(M):
+            H.call("vx_pwa_scatter_bwd", H.P(_c(douts[m])), H.P(dO), pp, cv, m, M, B, st)
+        dq, dk, dv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
+        delta = torch.empty_like(lse)
+        rs = rng_state(dev) if ctx.p > 0 else None
+        dtab = grad_buf(ctx.table) if ctx.table.requires_grad else torch.zeros_like(tbl)
+        H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
+               H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, st)
+        grads = []
+        for m in range(M):
+            for j, (dt, c) in enumerate(((dq, cq), (dk, cq), (dv, cv))):
+                src = qkv[3 * m + j]
+                d = torch.empty_like(src)
+                H.call("vx_pwa_gather_bwd", H.P(src), H.P(dt), H.P(d), pp, c, m, M, B, st)
+                grads.append(d)
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def pwa_core(table, plan, cq, cv, qkv: Sequence[torch.Tensor], p_attn: float = 0.0, site: int = 0) -> List[torch.Tensor]:
+    M = len(qkv) // 3
+    return list(_PwaCoreFn.apply(table, plan, int(cq), int(cv), M, float(p_attn), int(site), *qkv))
+
+
+# ------------------------------------------------------------------------------------------------
+# up-sampling, Gram
+# ------------------------------------------------------------------------------------------------
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        _check(x, "upsample_trilinear")
+        x = _c(x)
+        B, C, d, h, w = x.shape
+        D, Hh, W = size
+        out = torch.empty((B, C, D, Hh, W), device=x.device, dtype=torch.float32)
+        H.call("vx_upsample_trilinear_fwd", H.P(x), H.P(out), B * C, d, h, w, D, Hh, W, H.stream_ptr())
+        ctx.shape = (B, C, d, h, w, D, Hh, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, d, h, w, D, Hh, W = ctx.shape
+        g = _c(g)
+        dx = torch.empty((B, C, d, h, w), device=g.device, dtype=torch.float32)
+        H.call("vx_upsample_trilinear_bwd", H.P(g), H.P(dx), B * C, d, h, w, D, Hh, W, H.stream_ptr())
+        return dx, None
+
+
+def upsample_trilinear(x, size):
+    size = tuple(int(s) for s in size)
+    if tuple(x.shape[2:]) == size:
+        return x        # F.interpolate to the same size with align_corners=True is the identity (VeloxSeg.py:183)
+    return _UpsampleFn.apply(x, size)
+
+
+class _GramFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check(x, "gram")
+        x = _c(x)
+        B, C = x.shape[:2]
+        V = x[0, 0].numel()
+        G = torch.empty((B, C, C), device=x.device, dtype=torch.float32)
+        H.call("vx_gram_fwd", H.P(x), H.P(G), B, C, V, H.stream_ptr())
+        ctx.save_for_backward(x)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        (x,) = ctx.saved_tensors
+        dG = _c(dG)
+        B, C = x.shape[:2]
+        V = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        H.call("vx_gram_bwd", H.P(x), H.P(dG), H.P(dx), B, C, V, H.stream_ptr())
+        return dx
+
+
+def gram(x):
+    return _GramFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+_LAB_KIND = {torch.int64: 0, torch.int32: 1, torch.uint8: 2}
+_weight_cache = {}
+
+
+def _head_weights(ws, device):
+    key = (tuple(float(w) for w in ws), str(device))
+    if key not in _weight_cache:
+        _weight_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return _weight_cache[key]
+
+
+class _VeloxLossFn(torch.autograd.Function):
+    """sum_h w_h (CE + Dice)(logits_h) + w_rc MSE(rcs, x) + w_f/M sum_m MSE(G_seg, G_m)   (utils/loss.py:52-66)."""
+
+    @staticmethod
+    def forward(ctx, labels, sr, head_w, w_rc, w_f, nh, M, *outs):
+        logits = [_c(t) for t in outs[:nh]]
+        _check(logits[0], "loss")
+        B, C = logits[0].shape[:2]
+        V = logits[0][0, 0].numel()
+        dev = logits[0].device
+        st = H.stream_ptr()
+        if labels.dtype not in _LAB_KIND:
+            raise RuntimeError(f"labels must be int64/int32/uint8, got {labels.dtype}")
+        labels = _c(labels)
+        assert labels.numel() == B * V, (labels.shape, B, V)
+        hw = _head_weights(head_w, dev)
+        seg_acc = torch.empty((nh * (1 + B * C * 3),), device=dev, dtype=torch.float64)
+        lp = [H.P(t) for t in logits] + [None] * (4 - nh)
+        H.call("vx_seg_loss_fwd", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(seg_acc, torch.float64), B, C, V, st)
+        has_tail = M > 0
+        rcs = grams = None
+        rc_acc = None
+        if has_tail:
+            rcs, sr_c = _c(outs[nh]), _c(sr)
+            assert rcs.shape == sr_c.shape, (rcs.shape, sr_c.shape)
+            rc_acc = torch.empty((1,), device=dev, dtype=torch.float64)
+            H.call("vx_sqdiff_sum", H.P(rcs), H.P(sr_c), rcs.numel(), H.P(rc_acc, torch.float64), st)
+            grams = [_c(t) for t in outs[nh + 1: nh + 2 + M]]
+        coef = torch.empty((nh * (1 + B * C * 2) + 2,), device=dev, dtype=torch.float32)
+        loss = torch.empty((1,), device=dev, dtype=torch.float32)
+        gp = [H.P(g) for g in grams[1:]] + [None] * (4 - M) if has_tail else [None] * 4
+        H.call("vx_loss_finalize", H.P(seg_acc, torch.float64), nh, B, C, V, H.P(hw),
+               H.P(rc_acc, torch.float64) if has_tail else None, rcs.numel() if has_tail else 1, float(w_rc),
+               H.P(grams[0]) if has_tail else None, *gp, M if has_tail else 0, grams[0].shape[1] if has_tail else 0, float(w_f),
+               H.P(loss), H.P(coef), st)
+        ctx.save_for_backward(labels, coef, *logits, *( [rcs, sr_c] + grams if has_tail else []))
+        ctx.nh, ctx.M, ctx.has_tail, ctx.dims = nh, M, has_tail, (B, C, V)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        nh, M = ctx.nh, ctx.M
+        B, C, V = ctx.dims
+        labels, coef = ctx.saved_tensors[:2]
+        logits = ctx.saved_tensors[2:2 + nh]
+        st = H.stream_ptr()
+        go = _c(gout.reshape(1).to(torch.float32))
+        grads = []
+        stride = (1 + B * C * 2) * 4
+        for h in range(nh):
+            d = torch.empty_like(logits[h])
+            H.call("vx_seg_loss_bwd", H.P(logits[h]), H.P(labels, None), _LAB_KIND[labels.dtype], coef.data_ptr() + h * stride, H.P(go), H.P(d), B, C, V, st)
+            grads.append(d)
+        if ctx.has_tail:
+            rcs, sr = ctx.saved_tensors[2 + nh: 4 + nh]
+            grams = ctx.saved_tensors[4 + nh:]
+            misc = coef.data_ptr() + nh * stride
+            drc = torch.empty_like(rcs)
+            H.call("vx_mse_bwd", H.P(rcs), H.P(sr), misc, H.P(go), H.P(drc), rcs.numel(), st)
+            grads.append(drc)
+            dgs = torch.empty_like(grams[0])
+            dgm = [torch.empty_like(g) for g in grams[1:]]
+            gp = [H.P(g) for g in grams[1:]] + [None] * (4 - M)
+            dp = [H.P(g) for g in dgm] + [None] * (4 - M)
+            H.call("vx_gram_mse_bwd", H.P(grams[0]), *gp, M, misc + 4, H.P(go), H.P(dgs), *dp, grams[0].numel(), st)
+            grads.append(dgs)
+            grads.extend(dgm)
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def veloxseg_loss(outputs: Sequence[torch.Tensor], labels: torch.Tensor, sr_labels: Optional[torch.Tensor], head_weights: Sequence[float],
+                  w_rc: float, w_f: float, num_modal: int) -> torch.Tensor:
+    """outputs = nh logits [+ rcs, G_seg, G_rc x M]."""
+    tail = 2 + num_modal
+    nh = len(outputs) - tail
+    assert 1 <= nh <= 4, "1..4 deep-supervision heads supported"
+    return _VeloxLossFn.apply(labels, sr_labels, tuple(head_weights), float(w_rc), float(w_f), nh, num_modal, *outputs)
+
+
+def seg_only_loss(outputs: Sequence[torch.Tensor], labels: torch.Tensor, head_weights: Sequence[float]) -> torch.Tensor:
+    return _VeloxLossFn.apply(labels, None, tuple(head_weights), 0.0, 0.0, len(outputs), 0, *outputs)

@@ -1,0 +1,142 @@
+"""Dual-branch encoder (reference: model/Encoder.py)."""
+from typing import Sequence
+
+import torch
+from torch import nn
+
+from .. import functional as VF
+from .components.attention_utils import LayerNorm
+from .components.common_function import InstanceNormMarker, ParamConv3d
+from .components.conv_blocks import DownConv, JLCLayer
+from .components.PWA import Transformer_BasicLayer
+
+
+class PatchEmbed(nn.Module):
+    """MONAI PatchEmbed stand-in: proj = Conv3d(k = s = patch), no norm (Encoder.py:150-156)."""
+
+    def __init__(self, patch_size, in_chans, embed_dim, norm_layer=None, spatial_dims=3):
+        super().__init__()
+        if norm_layer is not None or spatial_dims != 3:
+            raise NotImplementedError("patch_norm=True / 2-D are not used by any shipped config")
+        self.patch_size = (patch_size,) * 3
+        self.proj = ParamConv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = None
+
+    def forward(self, x):
+        if any(s % p for s, p in zip(x.shape[2:], self.patch_size)):
+            raise ValueError(f"input {tuple(x.shape[2:])} must be a multiple of patch_size {self.patch_size}")
+        return self.proj(x)
+
+
+class Conv_Encoder(nn.Module):
+    """DownConv + JLC x4 (Encoder.py:13-85)."""
+
+    def __init__(self, patch_size=4, in_ch=1, base_ch=16, depths=(1, 1, 1, 1), kernel_sizes=(1, 3, 5), min_dim_group=(4, 8, 8, 16),
+                 expansion_factor=(3, 3, 2, 2), dropout=0.0, spatial_dim=3):
+        super().__init__()
+        self.down1 = DownConv(in_ch, base_ch, patch_size=patch_size, dim=spatial_dim)
+        self.down2 = DownConv(base_ch, base_ch * 2, patch_size=2, dim=spatial_dim)
+        self.down3 = DownConv(base_ch * 2, base_ch * 4, patch_size=2, dim=spatial_dim)
+        self.down4 = DownConv(base_ch * 4, base_ch * 8, patch_size=2, dim=spatial_dim)
+        groups = [base_ch * 2 ** i // min_dim_group[i] for i in range(4)]
+        for i in range(4):
+            setattr(self, f"layer{i + 1}", JLCLayer(base_ch * 2 ** i, depths[i], kernel_sizes, groups[i], expansion_factor[i],
+                                                     dropout=dropout, spatial_dim=spatial_dim))
+
+    def forward(self, x):
+        feats = []
+        for i in range(4):
+            x = getattr(self, f"layer{i + 1}")(getattr(self, f"down{i + 1}")(x))
+            feats.append(x)
+        return tuple(feats)
+
+
+class Transformer_Encoder(nn.Module):
+    """per-modality PatchEmbed -> 4 PWA layers with PatchMerging (Encoder.py:88-204)."""
+
+    def __init__(self, input_size, patch_size, in_channels, embed_dim=16, depths=(2, 2, 2, 2),
+                 min_big_window_sizes=((3, 3, 3), (6, 6, 6), (3, 3, 3), (3, 3, 3)), min_small_window_sizes=((1, 1, 1),) * 4,
+                 scale_factors=(2, 2, 2, 2), num_heads=(1, 2, 2, 4), min_dim_head=(4, 8, 8, 16), ffn_expansion_ratio=(3, 3, 2, 2),
+                 attn_drop=0.1, proj_drop=0.1, drop_path=0, act_layer="GELU", norm_layer=LayerNorm, patch_norm=False, qkv_bias=True, spatial_dim=3):
+        super().__init__()
+        self.in_channels = list(in_channels)
+        self.num_modalities = len(in_channels)
+        self.num_layers = len(depths)
+        self.patch_size = patch_size
+        self.patch_embeds = nn.ModuleList([PatchEmbed(patch_size=patch_size, in_chans=self.in_channels[m], embed_dim=embed_dim,
+                                                      norm_layer=norm_layer if patch_norm else None, spatial_dims=spatial_dim)
+                                           for m in range(self.num_modalities)])
+        self.pos_drop = nn.Dropout(p=proj_drop)
+        self.p_pos = proj_drop
+        self.sites_pos = [VF.new_dropout_site() for _ in range(self.num_modalities)]
+        if drop_path:
+            raise NotImplementedError("drop_path > 0 is not used by any shipped config")
+        self.layers = nn.ModuleList()
+        grid = [int(s) // patch_size for s in input_size]
+        for i in range(self.num_layers):
+            self.layers.append(Transformer_BasicLayer(
+                input_size=list(grid), in_channels=[int(embed_dim * 2 ** i)] * self.num_modalities, depth=depths[i],
+                min_big_window_size=min_big_window_sizes[i], min_small_window_size=min_small_window_sizes[i], scale_factor=scale_factors[i],
+                num_heads=num_heads[i], min_dim_head=min_dim_head[i], attn_drop=attn_drop, proj_drop=proj_drop, drop_path=0.0,
+                ffn_expansion_ratio=ffn_expansion_ratio[i], act_layer=act_layer, norm_layer=norm_layer, qkv_bias=qkv_bias,
+                do_downsample=i < self.num_layers - 1, dim=spatial_dim))
+            grid = [g // 2 for g in grid]
+
+    def forward(self, xs):
+        xs = torch.chunk(xs, self.num_modalities, dim=1)            # Encoder.py:192
+        p = self.p_pos if self.training else 0.0
+        cur = []
+        for m in range(self.num_modalities):
+            e = self.patch_embeds[m](xs[m].contiguous())
+            cur.append(VF.residual_dropout(None, e, 0.0, p, self.sites_pos[m]) if p > 0 else e)
+        feats = []
+        for i, layer in enumerate(self.layers):
+            attn, cur = layer(cur)
+            feats.append(attn)
+        return tuple(feats)
+
+
+class Encoder(nn.Module):
+    """PWA branch + conv branch, fused per level by a 1x1 modal mixer and an add (Encoder.py:207-367)."""
+
+    def __init__(self, input_size, patch_size, in_ch, base_ch=16, conv_depths=(1, 1, 1, 1), kernel_sizes=(1, 3, 5), min_dim_group=(4, 8, 8, 16),
+                 conv_expansion_factor=(4, 4, 4, 4), attn_base_ch=16, depths=(2, 2, 2, 2),
+                 min_big_window_sizes=((3, 3, 3), (6, 6, 6), (3, 3, 3), (3, 3, 3)), min_small_window_sizes=((1, 1, 1),) * 4,
+                 min_dim_head=(4, 8, 8, 16), scale_factors=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), attn_drop=0.1, proj_drop=0.1, drop_path=0,
+                 ffn_expansion_ratio=(4, 4, 4, 4), act_layer="GELU", norm_layer=LayerNorm, patch_norm=False, qkv_bias=True, conv_drop=0.0, spatial_dim=3):
+        super().__init__()
+        self.in_channels = list(in_ch)
+        self.num_modalities = len(in_ch)
+        self.encoder_attn = Transformer_Encoder(input_size=input_size, patch_size=patch_size, in_channels=in_ch, embed_dim=attn_base_ch, depths=depths,
+                                                min_big_window_sizes=min_big_window_sizes, min_small_window_sizes=min_small_window_sizes,
+                                                scale_factors=scale_factors, num_heads=num_heads, min_dim_head=min_dim_head, attn_drop=attn_drop,
+                                                proj_drop=proj_drop, drop_path=drop_path, ffn_expansion_ratio=ffn_expansion_ratio, act_layer=act_layer,
+                                                norm_layer=norm_layer, patch_norm=patch_norm, qkv_bias=qkv_bias, spatial_dim=spatial_dim)
+        self.encoder_conv = Conv_Encoder(patch_size=patch_size, in_ch=sum(in_ch), base_ch=base_ch, depths=conv_depths, kernel_sizes=kernel_sizes,
+                                         min_dim_group=min_dim_group, expansion_factor=conv_expansion_factor, dropout=conv_drop, spatial_dim=spatial_dim)
+        M = self.num_modalities
+        for i in range(4):
+            setattr(self, f"attn2conv_{i + 1}", nn.Sequential(ParamConv3d(attn_base_ch * 2 ** i * M, base_ch * 2 ** i, 1, 1), InstanceNormMarker(base_ch * 2 ** i)))
+
+    def _mix(self, level: int, attn_feats):
+        """1x1 conv over the channel-concatenated modalities (the concat is done inside the kernel for M = 2)."""
+        conv = getattr(self, f"attn2conv_{level + 1}")[0]
+        if len(attn_feats) == 1:
+            return conv(attn_feats[0])
+        if len(attn_feats) == 2:
+            return conv(attn_feats[0], x2=attn_feats[1])
+        return conv(torch.cat(list(attn_feats), dim=1))
+
+    def forward(self, x):
+        attn = self.encoder_attn(x)
+        encs = []
+        prev = x
+        for i in range(4):
+            a_raw = self._mix(i, attn[i])
+            d_raw = getattr(self.encoder_conv, f"down{i + 1}").raw(prev)
+            fused = VF.instnorm_sum([d_raw, a_raw])                  # IN(down) + IN(mix)  (Encoder.py:351-360)
+            prev = getattr(self.encoder_conv, f"layer{i + 1}")(fused)
+            encs.append(prev)
+        if self.training:
+            return [list(a) for a in attn], encs
+        return tuple(encs)

@@ -1,0 +1,152 @@
+"""Paired-Window Attention blocks (reference: model/components/PWA.py).
+
+Only the classes the VeloxSeg graph instantiates are provided (MultiModal_Paired_Windows_Attention,
+Paired_Windows_TransformerBlock, Transformer_BasicLayer); the reference's Cross_Channel_Attention is dead code.
+Geometry (window scales, channel split) is planned on the host once per layer and handed to the HIP
+kernels as a VxPwaPlan (include/veloxseg_hip.h).
+"""
+from math import ceil
+from typing import List, Sequence
+
+import torch
+from torch import nn
+
+from ... import _hip as H
+from ... import functional as VF
+from .attention_utils import FFN, LayerNorm, PatchMerging, PositionalEmbedding
+from .common_function import ParamConv3d
+
+
+def plan_windows(input_size, min_big, min_small, scale_factor, num_heads, min_dim_head, channels):
+    """Window scales `while (bw <= input).any()` and channel split (PWA.py:56-86)."""
+    big, small = [], []
+    bw, sw = [int(v) for v in min_big], [int(v) for v in min_small]
+    while any(b <= g for b, g in zip(bw, input_size)):
+        big.append(list(bw))
+        small.append(list(sw))
+        bw = [b * scale_factor for b in bw]
+        sw = [s * scale_factor for s in sw]
+    if not big:
+        raise ValueError(f"PWA: window {list(min_big)} is larger than the token grid {list(input_size)} on every axis")
+    need = len(big) * num_heads * min_dim_head
+    ch_qk = need
+    ch_v = ceil(channels / need) * need
+    n = [min_big[k] // min_small[k] for k in range(3)]
+    nwin = []
+    for b in big:
+        if any(g % x or g // x == 0 for g, x in zip(input_size, b)):
+            raise ValueError(f"PWA: window {b} does not tile the token grid {list(input_size)} "
+                             "(the reference fails inside einops.rearrange for the same configuration)")
+        nwin.append([g // x for g, x in zip(input_size, b)])
+    return dict(big=big, small=small, n=n, nwin=nwin, ch_qk=ch_qk, ch_v=ch_v)
+
+
+class MultiModal_Paired_Windows_Attention(nn.Module):
+    """LN -> q/k/v 1x1 -> window gather (max-pool + partition) -> multi-modal window attention with relative bias
+    -> per-window trilinear scatter -> 1x1 mix -> x + Drop(.)   (PWA.py:246-379)."""
+
+    def __init__(self, input_size: Sequence[int], in_channels: Sequence[int], min_big_window_size=(3, 3, 3), min_small_window_size=(1, 1, 1),
+                 scale_factor: int = 2, num_heads: int = 1, min_dim_head: int = 4, qkv_bias: bool = True, attn_drop: float = 0.1,
+                 proj_drop: float = 0.1, norm_layer=LayerNorm, dim: int = 3, use_pos_embed: bool = True):
+        super().__init__()
+        if dim != 3 or not use_pos_embed or num_heads < 1:
+            raise NotImplementedError("veloxseg_amd PWA: 3-D, positional bias on, num_heads >= 1")
+        self.input_size = list(input_size)
+        self.in_channels = list(in_channels)
+        self.num_modalities = len(in_channels)
+        self.num_heads, self.min_dim_head, self.dim = num_heads, min_dim_head, dim
+        self.mid_channels = max(in_channels)
+        g = plan_windows(self.input_size, min_big_window_size, min_small_window_size, scale_factor, num_heads, min_dim_head, self.mid_channels)
+        self.big_window_size, self.small_window_size = g["big"], g["small"]
+        self.n_hwd = g["n"]
+        self.num_bswin = len(g["big"])
+        self.channels_qk, self.channels_v = g["ch_qk"], g["ch_v"]
+        self.c_qk = self.channels_qk // (self.num_bswin * num_heads)
+        self.c_v = self.channels_v // (self.num_bswin * num_heads)
+        self.plan = H.make_plan(self.input_size, self.n_hwd, num_heads, g["small"], g["nwin"])
+        self.position_embedding = PositionalEmbedding(dim=dim, num_heads=num_heads, window_size=self.n_hwd)
+        self.attn_drop, self.proj_drop = attn_drop, proj_drop
+        input_norms, qkv_proj, mix_channels, dropout_attns = [], [], [], []
+        for m in range(self.num_modalities):
+            input_norms.append(norm_layer(self.in_channels[m], data_format="channels_first", dim=dim))
+            qkv_proj.append(nn.ModuleList([ParamConv3d(self.in_channels[m], self.channels_qk, kernel_size=1, bias=qkv_bias),
+                                           ParamConv3d(self.in_channels[m], self.channels_qk, kernel_size=1, bias=qkv_bias),
+                                           ParamConv3d(self.in_channels[m], self.channels_v, kernel_size=1, bias=qkv_bias)]))
+            mix_channels.append(ParamConv3d(self.channels_v, self.in_channels[m], kernel_size=1))
+            dropout_attns.append(nn.Dropout(proj_drop))
+        self.input_norms = nn.ModuleList(input_norms)
+        self.qkv_proj = nn.ModuleList(qkv_proj)
+        self.mix_channels = nn.ModuleList(mix_channels)
+        self.dropout_attns = nn.ModuleList(dropout_attns)
+        self.site_attn = VF.new_dropout_site()
+        self.sites_proj = [VF.new_dropout_site() for _ in range(self.num_modalities)]
+
+    def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0) -> List[torch.Tensor]:
+        """returns residual_scale * x_m + Drop(mix(attention)) ; the transformer block passes 2.0 (double residual)."""
+        assert len(inputs) == self.num_modalities, f"The number of modalities should be {self.num_modalities}, but got {len(inputs)}"
+        qkv = []
+        for m in range(self.num_modalities):
+            xn = self.input_norms[m](inputs[m])          # LN once (the reference evaluates the same LN three times)
+            qkv += [self.qkv_proj[m][j](xn) for j in range(3)]
+        train = self.training
+        scat = VF.pwa_core(self.position_embedding.relative_position_bias_table, self.plan, self.c_qk, self.c_v, qkv,
+                           self.attn_drop if train else 0.0, self.site_attn)
+        outs = []
+        for m in range(self.num_modalities):
+            mix = self.mix_channels[m](scat[m])
+            outs.append(VF.residual_dropout(inputs[m], mix, residual_scale, self.proj_drop if train else 0.0, self.sites_proj[m]))
+        return outs
+
+
+class Paired_Windows_TransformerBlock(nn.Module):
+    """y = x + attn(x) (attn already contains +x: double residual, PWA.py:377,436); z = y + FFN(LN(y)) (:437)."""
+
+    def __init__(self, input_size, in_channels, min_big_window_size=(3, 3, 3), min_small_window_size=(1, 1, 1), scale_factor=2, num_heads=1,
+                 min_dim_head=4, attn_drop=0.1, proj_drop=0.1, drop_path=0.0, ffn_expansion_ratio=4, act_layer="GELU", norm_layer=LayerNorm,
+                 qkv_bias=True, dim=3):
+        super().__init__()
+        if drop_path and drop_path > 0:
+            raise NotImplementedError("drop_path > 0 is not used by any shipped config")
+        self.input_size, self.in_channels = input_size, in_channels
+        self.num_modalities = len(in_channels)
+        self.attn = MultiModal_Paired_Windows_Attention(input_size=input_size, in_channels=in_channels, min_big_window_size=min_big_window_size,
+                                                        min_small_window_size=min_small_window_size, scale_factor=scale_factor, num_heads=num_heads,
+                                                        min_dim_head=min_dim_head, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=proj_drop,
+                                                        norm_layer=norm_layer, dim=dim, use_pos_embed=True)
+        self.drop_path = nn.Identity()
+        self.ffns = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        for m in range(self.num_modalities):
+            self.ffns.append(FFN(in_channels[m], expansion_ratio=ffn_expansion_ratio, dropout_rate=proj_drop, act=act_layer, dim=dim))
+            self.norms.append(norm_layer(in_channels[m], data_format="channels_first", dim=dim))
+
+    def forward(self, xs):
+        ys = self.attn(xs, residual_scale=2.0)
+        return [self.ffns[m](self.norms[m](ys[m]), residual=ys[m]) for m in range(self.num_modalities)]
+
+
+class Transformer_BasicLayer(nn.Module):
+    """depth x block, then optional PatchMerging per modality (PWA.py:444-511)."""
+
+    def __init__(self, input_size, in_channels, depth=2, min_big_window_size=(3, 3, 3), min_small_window_size=(1, 1, 1), scale_factor=2,
+                 num_heads=1, min_dim_head=4, attn_drop=0.1, proj_drop=0.1, drop_path=0, ffn_expansion_ratio=4, act_layer="GELU",
+                 norm_layer=LayerNorm, qkv_bias=True, do_downsample=True, dim=3):
+        super().__init__()
+        self.num_modalities = len(in_channels)
+        self.blocks = nn.ModuleList([
+            Paired_Windows_TransformerBlock(input_size=input_size, in_channels=in_channels, min_big_window_size=min_big_window_size,
+                                            min_small_window_size=min_small_window_size, scale_factor=scale_factor, num_heads=num_heads,
+                                            min_dim_head=min_dim_head, attn_drop=attn_drop, proj_drop=proj_drop,
+                                            drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                            ffn_expansion_ratio=ffn_expansion_ratio, act_layer=act_layer, norm_layer=norm_layer,
+                                            qkv_bias=qkv_bias, dim=dim)
+            for i in range(depth)])
+        self.downs = None
+        if do_downsample:
+            self.downs = nn.ModuleList([PatchMerging(in_ch=in_channels[m], norm_layer=norm_layer, dim=dim) for m in range(self.num_modalities)])
+
+    def forward(self, xs):
+        for blk in self.blocks:
+            xs = blk(xs)
+        down = [self.downs[m](xs[m]) for m in range(self.num_modalities)] if self.downs is not None else None
+        return xs, down
