@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VeloxSeg training patches/s on synthetic 128^3 2-modality volumes (BASELINE.json metric).
+
+One "step" = zero_grad + forward + Dice/CE/SDKT loss + backward + [RCCL gradient all-reduce] + AdamW on one batch
+of synthetic patches already resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 launch
+with torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+LOSS_CFG = {"deep_Loss_weight": [1, 1, 1, 1], "RC_Loss_weight": 0.5, "Feature_Loss_weight": 2.0}   # config/train_config_bs4.json:52-59
+
+BASE = dict(patch_size=4, base_ch=16, conv_depths=[1, 1, 1, 1], kernel_sizes=[1, 3, 5], min_dim_group=[4, 8, 8, 16],
+            conv_expansion_factor=[3, 3, 2, 2], attn_base_ch=16, depths=[1, 1, 1, 1], min_small_window_sizes=[[1, 1, 1]] * 4,
+            min_dim_head=[4, 8, 8, 16], ffn_expansion_ratio=[3, 3, 2, 2], num_heads=[1, 2, 2, 4], proj_drop=0.1, conv_drop=0.1, spatial_dim=3)
+W128 = [[4] * 3, [8] * 3, [4] * 3, [4] * 3]      # [3,6,3,3] does not tile the 32^3 token grid of a 128^3 patch
+W96 = [[3] * 3, [6] * 3, [3] * 3, [3] * 3]
+WORKLOADS = {
+    # name: (model kwargs, default per-GPU batch)
+    "autopet128": (dict(BASE, input_size=[128] * 3, in_ch=[1, 1], n_classes=2, min_big_window_sizes=W128), 2),
+    "autopet96": (dict(BASE, input_size=[96] * 3, in_ch=[1, 1], n_classes=2, min_big_window_sizes=W96), 4),
+    "brats128": (dict(BASE, input_size=[128] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W128), 2),
+    "brats96": (dict(BASE, input_size=[96] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W96), 2),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector / fp32-input MFMA peak
+
+
+def synth(cfg, B, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    S = cfg["input_size"]
+    x = torch.randn(B, sum(cfg["in_ch"]), *S, generator=g)
+    if cfg["n_classes"] == 2:
+        lab = (torch.rand(B, 1, *S, generator=g) > 0.97).long()
+    else:
+        lab = torch.randint(0, cfg["n_classes"], (B, 1, *[s // 8 for s in S]), generator=g)
+        lab = lab.repeat_interleave(8, 2).repeat_interleave(8, 3).repeat_interleave(8, 4)
+    return x.to(device), lab.to(device)
+
+
+def cpu_baseline(cfg, B, budget_s=25.0):
+    """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) on this host's cores: same workload,
+    bounded sample (1 warm-up step, then steps until ~budget_s)."""
+    from oracle import veloxseg_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipe import fill_state_dict
+    ocfg = O.OracleConfig(**{**cfg, "attn_drop": 0.1})
+    sd = fill_state_dict(O.state_dict_template(ocfg), seed=7)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(params)
+    opt = torch.optim.AdamW(list(params.values()), lr=2.5e-4, weight_decay=0.01)
+    x, lab = synth(cfg, B, "cpu", 12345)
+    cores = torch.get_num_threads()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        outs = O.forward(x, full, ocfg, training=True)
+        loss = O.loss(outs, lab, x, ocfg.M, LOSS_CFG)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()
+    t0, n = time.time(), 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of the same workload, batch {B}, fp32, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="autopet128", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: workload default)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-pass", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the VeloxSeg hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+
+    import types
+    from veloxseg_amd import _hip as H
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+
+    cfg, defB = WORKLOADS[args.workload]
+    B = args.batch or defB
+    torch.manual_seed(12345)                                   # reference seed (utils/seed.py:6)
+    model = VeloxSeg(**cfg).to(dev)
+    VF.manual_seed(12345 + rank, dev)
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, dev, num_modal=len(cfg["in_ch"]))
+    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.no_graph, overlap=not args.no_overlap)
+    x, lab = synth(cfg, B, dev, 12345 + rank)
+    eng.step(x, lab)                                           # capture (+ first step)
+    for _ in range(max(args.warmup - 1, 0)):
+        eng.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss = float(eng.loss)
+    assert loss == loss, "loss is NaN"
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {"metric": "training patches/s on 128^3 2-mod volumes (fwd+loss+bwd+allreduce+AdamW)" if args.workload == "autopet128"
+               else f"training patches/s ({args.workload})",
+               "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic (randn volumes, rand>0.97 labels, random-init weights, seed 12345)",
+               "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
+                                      f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
+                          "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "hip_graph": not args.no_graph, "final_loss": round(loss, 5)}}
+    # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
+    if rank == 0 and not args.no_kernel_pass:
+        eng.flat.reattach()
+        H.profile_begin()
+        eng._fwd_bwd_single()
+        prof = H.profile_end()
+        rows = sorted(((v[1], v[0], k) for k, v in prof.items()), reverse=True)
+        total = sum(r[0] for r in rows)
+        top = rows[0]
+        out["kernel_pass"] = {"total_ms": round(total, 3), "top": [{"entry": r[2][0], "key": list(r[2][1]), "launches": r[1], "ms": round(r[0], 4)} for r in rows[:8]]}
+        name, key = top[2]
+        out["roofline"] = roofline_for(name, key, top[0] / top[1])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, B)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline_for(name, key, ms_per_launch):
+    """Algorithmic bytes / flops of one launch of C-ABI entry `name` with integer arguments `key` (see include/veloxseg_hip.h)."""
+    r = {"kernel": name, "args": list(key), "avg_launch_ms": round(ms_per_launch, 5)}
+    if name.startswith("vx_conv3d"):
+        # (..., C1, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps[, accumulate])
+        ints = list(key)
+        if name == "vx_conv3d_bwd_data":
+            ints = ints[:-1]
+        B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps = ints[-11:]
+        Do, Ho, Wo = [(d + 2 * P - K) // S + 1 for d in (Di, Hi, Wi)]
+        vin, vout = B * Cin * Di * Hi * Wi, B * Cout * Do * Ho * Wo
+        nw = Cout * (Cin // G) * K ** 3
+        flops = 2.0 * vout * (Cin // G) * K ** 3
+        bytes_ = 4.0 * (vin + vout + nw)
+        ai = flops / bytes_
+        if ai > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):      # above the fp32 ridge: price against the fp32 ALU/MFMA peak
+            ach = flops / (ms_per_launch * 1e-3) / 1e12
+            r.update({"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                      "traffic": None, "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+                      "note": "fp32 conv with arithmetic intensity %.0f flop/B: priced against the fp32 (vector = f32-input MFMA) peak" % ai})
+            return r
+        ach = bytes_ / (ms_per_launch * 1e-3) / 1e9
+        r.update({"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                  "algorithmic_bytes": bytes_})
+        return r
+    r.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None})
+    return r
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,7 @@ def test_train_step_vs_oracle(golden_dir, name):
     for k, p in model.named_parameters():
         assert p.grad is not None, k
         g, r = p.grad.detach().cpu().double(), params[k].grad.double()
-        rel = float((g - r).norm() / r.norm().clamp(min=1e-6))
+        rel = float((g - r).norm() / (r.norm() + 1e-4))      # biases in front of an InstanceNorm / key biases have ~0 gradient
         if rel > 2e-3:
             bad.append((k, rel, float(r.norm())))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]

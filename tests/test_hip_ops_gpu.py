@@ -23,7 +23,7 @@ def dev():
 
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed + sum(shape))
-    return torch.randn(*shape, generator=g) * scale
+    return torch.randn(tuple(shape), generator=g) * scale
 
 
 def close(a, b, atol, rtol, what):

@@ -112,8 +112,37 @@ def P(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
     return t.data_ptr()
 
 
+_PROFILE = None   # when a list: (name, int-args key, start event, end event) per call -- bench.py's per-kernel timing pass
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """-> {(name, key): [launches, total_ms]} measured with HIP events on the launch stream."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, key, e0, e1 in rec:
+        d = out.setdefault((name, key), [0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+    return out
+
+
 def call(name: str, *args):
+    if _PROFILE is None:
+        LIB.call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     LIB.call(name, *args)
+    e1.record()
+    key = tuple(a for a in args[:-1] if isinstance(a, int) and not isinstance(a, bool) and abs(a) < (1 << 24))
+    _PROFILE.append((name, key, e0, e1))
 
 
 def make_plan(grid, n, heads, small, nwin) -> VxPwaPlan:
