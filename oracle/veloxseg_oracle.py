@@ -109,7 +109,7 @@ def upsample_trilinear(x: Tensor, size: Sequence[int]) -> Tensor:
     """F.interpolate(x, size, mode='trilinear', align_corners=True) (VeloxSeg.py:177-184)."""
     if list(x.shape[2:]) == list(size):
         return x
-    Ad, Ah, Aw = (interp_matrix(x.shape[2 + i], size[i]) for i in range(3))
+    Ad, Ah, Aw = (interp_matrix(x.shape[2 + i], size[i]).to(x.device) for i in range(3))
     x = torch.einsum("bcdhw,Dd->bcDhw", x, Ad)
     x = torch.einsum("bcdhw,Hh->bcdHw", x, Ah)
     x = torch.einsum("bcdhw,Ww->bcdhW", x, Aw)
@@ -147,7 +147,7 @@ def scatter_windows(tok: Tensor, plan: dict, c: int) -> Tensor:
         s = plan["small"][i]
         t = tok[:, :, off:off + N].reshape(B, h, N0, N1, N2, n[0], n[1], n[2], c)
         off += N
-        A0, A1, A2 = (interp_matrix(n[k], n[k] * s[k]) for k in range(3))
+        A0, A1, A2 = (interp_matrix(n[k], n[k] * s[k]).to(tok.device) for k in range(3))
         t = torch.einsum("bhxyzijkc,Ii->bhxyzIjkc", t, A0)
         t = torch.einsum("bhxyzijkc,Jj->bhxyziJkc", t, A1)
         t = torch.einsum("bhxyzijkc,Kk->bhxyzijKc", t, A2)
