@@ -45,6 +45,18 @@ int vx_conv3d_bwd_data(const float* dy, const float* w, const float* bias_like, 
 int vx_conv3d_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                          int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
 
+/* LDS-tiled weight gradient for spatial kernels (same contract as vx_conv3d_bwd_weight): x halo tile in LDS, dy on the scalar path */
+int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                               int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* 1x1x1 convolutions: thread-per-voxel with scalar-path weights (fwd / bwd_data; Cin % 4 == 0), fp32-MFMA GEMM over the voxel
+ * axis for the weight gradient.  w: (Cout, Cin).  Same concat / accumulate conventions as vx_conv3d_*. */
+int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
+                   int B, int Cin, int Cout, long V, void* stream);
+int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int C1,
+                        int B, int Cin, int Cout, long V, int accumulate, void* stream);
+int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                          int B, int Cin, int Cout, long V, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
  * Encoder.py:334-337, Decoder.py:54-57).  stats[2*bc] = mean, stats[2*bc+1] = rstd.
@@ -59,8 +71,8 @@ int vx_in_bwd(const float* dout, const float* y, const float* stats, int act, fl
 
 /* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
 int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);
-int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,
-                 int B, int C, long V, float eps, void* stream);   /* dgamma/dbeta: += */
+int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
+                 int B, int C, long V, float eps, void* stream);   /* dgamma/dbeta: += ; ws = 2*B*V floats of workspace */
 
 /* element-wise pieces: h = drop(gelu(a)) (attention_utils.py:64-66, conv_blocks.py:66); out = alpha*x + drop(z)
  * (PWA.py:377 + :436 double residual, attention_utils.py:68-70, conv_blocks.py:69,74, Encoder.py:196) */

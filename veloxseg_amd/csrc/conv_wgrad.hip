@@ -1,0 +1,217 @@
+// Tiled weight-gradient kernel for spatial convolutions (any cubic K, stride, groups, optional pixel-shuffled dy).
+//
+//   dw[co, ci, tap] += sum_{b, q} dy[b, co, q] * x[b, g*Cin_g + ci, q*S - P + tap]
+//
+// Mapping (MI355X): one 256-thread block = (batch b, group g, COT output channels, a run of output tiles).
+//   * the x halo tile of the block's output tile lives in LDS ([Cin_g][HD][HH][HW]);
+//   * a thread owns NP (ci, tap) pairs x COT output channels in registers (NP*COT accumulators);
+//   * dy[b, co, q] does not depend on the thread: it is read through the SCALAR path (s_load) and enters the
+//     v_fmac as an SGPR operand -> 1 LDS read feeds COT FMAs, no vector load of dy at all;
+//   * partial sums are flushed with one float atomic per (weight, block) after the block's last tile.
+// Replaces the weight-gradient half of aten::convolution_backward for conv_blocks.py:10-17,51-58 and
+// Decoder.py:73-76,150-153 (reference), and the ConvTranspose3d k2s2 weight gradient via the adjoint view.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+#include <type_traits>
+
+struct VxWg {
+    int B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, K, S, P, G, C1, ps;
+    int TD, TH, TW;            // output tile
+    int HD, HH, HW;            // halo tile = (T-1)*S + K
+    int nTd, nTh, nTw;         // tiles per axis
+    int tiles_per_block;
+};
+
+__device__ __forceinline__ long vx_wg_dy_index(const VxWg& p, int b, int co, int d, int h, int w) {
+    if (p.ps == 1) return ((((long)b * p.Cout + co) * p.Do + d) * p.Ho + h) * (long)p.Wo + w;
+    const int s = p.ps;
+    const int s3 = co % s;
+    int t = co / s;
+    const int s2 = t % s;
+    t /= s;
+    const int s1 = t % s;
+    const int c = t / s;
+    const int Cc = p.Cout / (s * s * s);
+    return ((((long)b * Cc + c) * (p.Do * s) + d * s + s1) * (long)(p.Ho * s) + h * s + s2) * (long)(p.Wo * s) + w * s + s3;
+}
+
+template <int KT, int COT, int NP>
+__global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict__ x, const float* __restrict__ x2,
+                                                        const float* __restrict__ dy, float* __restrict__ dw, VxWg p) {
+    extern __shared__ __attribute__((aligned(16))) float vx_halo[];
+    const int K = KT > 0 ? KT : p.K;
+    const int K3 = K * K * K;
+    const int Cin_g = p.Cin / p.G, Cout_g = p.Cout / p.G;
+    const int chunks_per_group = Cout_g / COT;
+    const int g = blockIdx.y / chunks_per_group;
+    const int co0 = g * Cout_g + (blockIdx.y % chunks_per_group) * COT;
+    const int b = blockIdx.z;
+    const int npairs = Cin_g * K3;
+    const int plane = p.HD * p.HH * p.HW;
+    const long Vi = (long)p.Di * p.Hi * p.Wi;
+    const int ntiles = p.nTd * p.nTh * p.nTw;
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, ntiles);
+
+    for (int pass0 = 0; pass0 < npairs; pass0 += 256 * NP) {
+        float acc[NP][COT];
+        int loff[NP];
+        bool pok[NP];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const int pi = pass0 + n * 256 + threadIdx.x;
+            pok[n] = pi < npairs;
+            const int pc = pok[n] ? pi : 0;
+            const int tap = pc % K3, ci = pc / K3;
+            const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+            loff[n] = ci * plane + (kd * p.HH + kh) * p.HW + kw;
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[n][j] = 0.0f;
+        }
+        for (int t = t_begin; t < t_end; ++t) {
+            const int tw = t % p.nTw, th = (t / p.nTw) % p.nTh, td = t / (p.nTw * p.nTh);
+            const int od0 = td * p.TD, oh0 = th * p.TH, ow0 = tw * p.TW;
+            const int id0 = od0 * p.S - p.P, ih0 = oh0 * p.S - p.P, iw0 = ow0 * p.S - p.P;
+            __syncthreads();
+            for (int e = threadIdx.x; e < Cin_g * plane; e += 256) {
+                const int ci = e / plane, r = e % plane;
+                const int hw = r % p.HW, hh = (r / p.HW) % p.HH, hd = r / (p.HW * p.HH);
+                const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+                float v = 0.0f;
+                if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                    const int c = g * Cin_g + ci;
+                    const float* src = (c < p.C1) ? x + ((long)b * p.C1 + c) * Vi : x2 + ((long)b * (p.Cin - p.C1) + (c - p.C1)) * Vi;
+                    v = src[((long)id * p.Hi + ih) * p.Wi + iw];
+                }
+                vx_halo[e] = v;
+            }
+            __syncthreads();
+            const int nd = min(p.TD, p.Do - od0), nh = min(p.TH, p.Ho - oh0), nw = min(p.TW, p.Wo - ow0);
+            for (int qd = 0; qd < nd; ++qd)
+                for (int qh = 0; qh < nh; ++qh) {
+                    const int rowoff = (qd * p.S * p.HH + qh * p.S) * p.HW;
+                    int qw = 0;
+                    for (; qw + 4 <= nw; qw += 4) {
+                        float xv[NP][4];
+#pragma unroll
+                        for (int n = 0; n < NP; ++n)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) xv[n][u] = vx_halo[loff[n] + rowoff + (qw + u) * p.S];
+#pragma unroll
+                        for (int j = 0; j < COT; ++j) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float dv = dy[vx_wg_dy_index(p, b, co0 + j, od0 + qd, oh0 + qh, ow0 + qw + u)];   // wave-uniform -> s_load
+#pragma unroll
+                                for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv, xv[n][u], acc[n][j]);
+                            }
+                        }
+                    }
+                    for (; qw < nw; ++qw) {
+                        float xv[NP];
+#pragma unroll
+                        for (int n = 0; n < NP; ++n) xv[n] = vx_halo[loff[n] + rowoff + qw * p.S];
+#pragma unroll
+                        for (int j = 0; j < COT; ++j) {
+                            const float dv = dy[vx_wg_dy_index(p, b, co0 + j, od0 + qd, oh0 + qh, ow0 + qw)];
+#pragma unroll
+                            for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv, xv[n], acc[n][j]);
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const int pi = pass0 + n * 256 + threadIdx.x;
+            if (pi < npairs) {
+#pragma unroll
+                for (int j = 0; j < COT; ++j) atomicAdd(dw + (long)(co0 + j) * npairs + pi, acc[n][j]);
+            }
+        }
+    }
+}
+
+// db[co] += sum_{b,q} dy[b,co,q]  (dy possibly pixel-shuffled); one block per output channel
+__global__ void __launch_bounds__(256) vx_bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, VxWg p) {
+    const int co = blockIdx.x;
+    const long Vo = (long)p.Do * p.Ho * p.Wo;
+    float s = 0.0f;
+    for (int b = 0; b < p.B; ++b)
+        for (long q = threadIdx.x; q < Vo; q += 256) {
+            const int w = (int)(q % p.Wo), h = (int)((q / p.Wo) % p.Ho), d = (int)(q / ((long)p.Wo * p.Ho));
+            s += dy[vx_wg_dy_index(p, b, co, d, h, w)];
+        }
+    __shared__ float sm[4];
+    s = vx_block_sum_256(s, sm);
+    if (threadIdx.x == 0) atomicAdd(db + co, s);
+}
+
+template <int N> using vx_ic2 = std::integral_constant<int, N>;
+
+extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                                          int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream) {
+    VX_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && S > 0 && G > 0 && ps > 0, "vx_conv3d_bwd_weight_tiled: bad args");
+    VX_REQUIRE(Cin % G == 0 && Cout % G == 0, "vx_conv3d_bwd_weight_tiled: channels not divisible by groups");
+    VxWg p;
+    p.B = B; p.Cin = Cin; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cout = Cout; p.K = K; p.S = S; p.P = P; p.G = G; p.ps = ps;
+    p.C1 = (C1 <= 0 || C1 > Cin) ? Cin : C1;
+    VX_REQUIRE(p.C1 == Cin || x2, "vx_conv3d_bwd_weight_tiled: x2 missing");
+    p.Do = (Di + 2 * P - K) / S + 1; p.Ho = (Hi + 2 * P - K) / S + 1; p.Wo = (Wi + 2 * P - K) / S + 1;
+    VX_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, "vx_conv3d_bwd_weight_tiled: empty output");
+    const int Cin_g = Cin / G, Cout_g = Cout / G;
+    // output tile: a W-run of up to 32 voxels, grown in H then D until the halo of all Cin_g channels fills ~64 KB of LDS
+    p.TW = p.Wo < 32 ? p.Wo : 32; p.TH = 1; p.TD = 1;
+    auto halo_bytes = [&](int td, int th, int tw) {
+        return (size_t)Cin_g * ((td - 1) * S + K) * ((th - 1) * S + K) * ((tw - 1) * S + K) * sizeof(float);
+    };
+    const size_t budget = 64 * 1024;
+    while (halo_bytes(p.TD, p.TH, p.TW) > budget && p.TW > 4) p.TW = (p.TW + 1) / 2;
+    VX_REQUIRE(halo_bytes(p.TD, p.TH, p.TW) <= 150 * 1024, "vx_conv3d_bwd_weight_tiled: halo tile does not fit LDS (Cin/G=%d K=%d)", Cin_g, K);
+    for (;;) {
+        bool grown = false;
+        if (p.TH < p.Ho && p.TH < 8 && halo_bytes(p.TD, p.TH * 2, p.TW) <= budget) { p.TH *= 2; grown = true; }
+        if (p.TD < p.Do && p.TD < 4 && halo_bytes(p.TD * 2, p.TH, p.TW) <= budget) { p.TD *= 2; grown = true; }
+        if (!grown) break;
+    }
+    if (p.TH > p.Ho) p.TH = p.Ho;
+    if (p.TD > p.Do) p.TD = p.Do;
+    p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
+    p.nTd = vx_cdiv(p.Do, p.TD); p.nTh = vx_cdiv(p.Ho, p.TH); p.nTw = vx_cdiv(p.Wo, p.TW);
+    const int ntiles = p.nTd * p.nTh * p.nTw;
+    const int COT = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
+    const int gy = G * (Cout_g / COT);
+    // enough blocks to fill 256 CUs a few times over, but several tiles per block to amortise the atomic flush
+    int tpb = (int)(((long)ntiles * gy * B + 2047) / 2048);
+    if (tpb < 1) tpb = 1;
+    if (tpb > 8) tpb = 8;
+    p.tiles_per_block = tpb;
+    const int npairs = Cin_g * K * K * K;
+    const int NP = npairs > 512 ? 4 : (npairs > 256 ? 2 : 1);
+    const size_t shm = halo_bytes(p.TD, p.TH, p.TW);
+    dim3 grid(vx_cdiv(ntiles, tpb), gy, B);
+    hipStream_t st = (hipStream_t)stream;
+    auto launch = [&](auto kt, auto cot, auto np) {
+        vx_wgrad_tiled_k<decltype(kt)::value, decltype(cot)::value, decltype(np)::value><<<grid, dim3(256), shm, st>>>(x, x2, dy, dw, p);
+    };
+    auto with_np = [&](auto kt, auto cot) {
+        if (NP == 4) launch(kt, cot, vx_ic2<4>{});
+        else if (NP == 2) launch(kt, cot, vx_ic2<2>{});
+        else launch(kt, cot, vx_ic2<1>{});
+    };
+    auto with_cot = [&](auto kt) {
+        switch (COT) {
+            case 8: with_np(kt, vx_ic2<8>{}); break;
+            case 4: with_np(kt, vx_ic2<4>{}); break;
+            case 2: with_np(kt, vx_ic2<2>{}); break;
+            default: with_np(kt, vx_ic2<1>{}); break;
+        }
+    };
+    switch (K) {
+        case 3: with_cot(vx_ic2<3>{}); break;
+        case 5: with_cot(vx_ic2<5>{}); break;
+        default: with_cot(vx_ic2<0>{}); break;
+    }
+    if (db) vx_bias_grad_k<<<dim3(Cout), dim3(256), 0, st>>>(dy, db, p);
+    VX_LAUNCH_CHECK("vx_conv3d_bwd_weight_tiled");
+    return 0;
+}

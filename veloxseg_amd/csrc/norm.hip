@@ -116,53 +116,54 @@ __global__ void __launch_bounds__(256) vx_ln_cf_fwd_k(const float* __restrict__ 
     for (int c = 0; c < C; ++c) ob[(long)c * V] = fmaf(gamma[c], (xb[(long)c * V] - u) * r, beta[c]);
 }
 
-// dx = r*(g - mean_c(g) - xhat*mean_c(g*xhat)), g = dout*gamma;  dgamma += sum dout*xhat, dbeta += sum dout
+// dx = r*(g - mean_c(g) - xhat*mean_c(g*xhat)), g = dout*gamma; per-voxel (mean, rstd) are saved to ws for the parameter pass
 __global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dout,
-                                                      float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int C, long V, float eps) {
+                                                      float* __restrict__ dx, float* __restrict__ ws, int C, long V, float eps) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = v < V;
-    const long base = (long)blockIdx.y * C * V + (ok ? v : 0);
+    if (v >= V) return;
+    const long base = (long)blockIdx.y * C * V + v;
     const float* __restrict__ xb = x + base;
     const float* __restrict__ db = dout + base;
-    float u = 0.0f, r = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    if (ok) {
-        float s = 0.0f;
-        for (int c = 0; c < C; ++c) s += xb[(long)c * V];
-        u = s / (float)C;
-        float q = 0.0f;
-        for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
-        r = 1.0f / sqrtf(q / (float)C + eps);
-        for (int c = 0; c < C; ++c) {
-            const float xh = (xb[(long)c * V] - u) * r;
-            const float g = db[(long)c * V] * gamma[c];
-            s1 += g;
-            s2 = fmaf(g, xh, s2);
-        }
-        s1 /= (float)C;
-        s2 /= (float)C;
-    }
-    __shared__ float sm[8];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xb[(long)c * V];
+    const float u = s / (float)C;
+    float q = 0.0f;
+    for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
+    const float r = 1.0f / sqrtf(q / (float)C + eps);
+    float s1 = 0.0f, s2 = 0.0f;
     for (int c = 0; c < C; ++c) {
-        float dg = 0.0f, dbt = 0.0f;
-        if (ok) {
-            const float xh = (xb[(long)c * V] - u) * r;
-            const float d = db[(long)c * V];
-            dx[base + (long)c * V] = r * (d * gamma[c] - s1 - xh * s2);
-            dg = d * xh;
-            dbt = d;
-        }
-        dg = vx_wave_sum(dg);
-        dbt = vx_wave_sum(dbt);
-        __syncthreads();
-        if (lane == 0) { sm[wid] = dg; sm[4 + wid] = dbt; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(dgamma + c, sm[0] + sm[1] + sm[2] + sm[3]);
-            atomicAdd(dbeta + c, sm[4] + sm[5] + sm[6] + sm[7]);
-        }
+        const float xh = (xb[(long)c * V] - u) * r;
+        const float g = db[(long)c * V] * gamma[c];
+        s1 += g;
+        s2 = fmaf(g, xh, s2);
     }
+    s1 /= (float)C;
+    s2 /= (float)C;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (xb[(long)c * V] - u) * r;
+        dx[base + (long)c * V] = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
+    }
+    ws[2 * ((long)blockIdx.y * V + v)] = u;
+    ws[2 * ((long)blockIdx.y * V + v) + 1] = r;
+}
+
+// dgamma[c] += sum_{b,v} dout*xhat ; dbeta[c] += sum dout.   grid (C, chunks)
+__global__ void __launch_bounds__(256) vx_ln_cf_bwd_param_k(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ ws,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, long V) {
+    const int c = blockIdx.x;
+    float dg = 0.0f, db = 0.0f;
+    const long n = (long)B * V;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long)gridDim.y * 256) {
+        const long b = i / V, v = i % V;
+        const long idx = (b * C + c) * V + v;
+        const float d = dout[idx];
+        dg = fmaf(d, (x[idx] - ws[2 * i]) * ws[2 * i + 1], dg);
+        db += d;
+    }
+    __shared__ float sm[4];
+    dg = vx_block_sum_256(dg, sm);
+    db = vx_block_sum_256(db, sm);
+    if (threadIdx.x == 0) { atomicAdd(dgamma + c, dg); atomicAdd(dbeta + c, db); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,10 +272,13 @@ extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* bet
     return 0;
 }
 
-extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,
+extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
                             int B, int C, long V, float eps, void* stream) {
-    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta, "vx_ln_cf_bwd: null pointer");
-    hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, dgamma, dbeta, C, V, eps);
+    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta && ws, "vx_ln_cf_bwd: null pointer");
+    hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps);
+    int chunks = vx_cdiv((long)B * V, 256 * 8);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(vx_ln_cf_bwd_param_k, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, x, dout, ws, dgamma, dbeta, B, C, V);
     VX_LAUNCH_CHECK("vx_ln_cf_bwd");
     return 0;
 }

@@ -1,0 +1,193 @@
+// 1x1x1 convolutions (channel mixers) for gfx950, fp32 NCDHW.
+//   reference call sites: PWA.py:291-298 (q/k/v, mix), attention_utils.py:56-57 (FFN), :141 (PatchMerging reduction),
+//   conv_blocks.py:64-68 (JLC channel stage), Encoder.py:334-337 (modal mixer, with the torch.cat of :344-347 folded in),
+//   Decoder.py:54-57 (enc2rc on cat(attn_m, enc)), :155-158 (deep-supervision heads).
+//
+// forward / input-gradient: one thread = one voxel, the weight row it needs is wave-uniform and is fetched with wide
+//   scalar loads (s_load_dwordx4) and consumed as SGPR operands of v_fmac -> zero LDS, zero vector weight traffic;
+//   activations are read coalesced along V (256 B per wave per channel).
+// weight-gradient: dW = dY . X^T is a GEMM whose reduction axis is the voxel axis -> fp32 MFMA (v_mfma_f32_16x16x4_f32,
+//   exact fp32 FMA chain), operands straight from global memory as 16-byte loads (the K axis may be permuted freely as
+//   long as A and B use the same permutation), one wave per (16 co x 16 ci) tile and voxel chunk, float atomics to flush.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+#include <type_traits>
+
+typedef float vx_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ const float* vx_pw_row(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin, int b, int c, long V) {
+    return (c < C1) ? x + ((long)b * C1 + c) * V : x2 + ((long)b * (Cin - C1) + (c - C1)) * V;
+}
+
+// y[b,co,v] = bias[co] + sum_ci w[co,ci] * x[b,ci,v]          (Cin % 4 == 0)
+template <int COT>
+__global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+                                                   const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                   int Cout, long V) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, b = blockIdx.z;
+    if (v >= V) return;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = bias ? bias[co0 + j] : 0.0f;
+    for (int ci = 0; ci < Cin; ci += 4) {
+        float xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = vx_pw_row(x, x2, C1, Cin, b, ci + u, V)[v];
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + (long)(co0 + j) * Cin + ci);   // uniform -> s_load_dwordx4
+            acc[j] = fmaf(wv.x, xv[0], acc[j]);
+            acc[j] = fmaf(wv.y, xv[1], acc[j]);
+            acc[j] = fmaf(wv.z, xv[2], acc[j]);
+            acc[j] = fmaf(wv.w, xv[3], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < COT; ++j) y[((long)b * Cout + co0 + j) * V + v] = acc[j];
+}
+
+// dx[b,ci,v] (=|+=) sum_co w[co,ci] * dy[b,co,v]              (CIT input channels per thread, CIT % 4 == 0)
+template <int CIT>
+__global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                        float* __restrict__ dx2, int C1, int Cin, int Cout, long V, int accumulate) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ci0 = blockIdx.y * CIT, b = blockIdx.z;
+    if (v >= V) return;
+    float acc[CIT];
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) acc[i] = 0.0f;
+    const float* __restrict__ dyb = dy + (long)b * Cout * V + v;
+    for (int co = 0; co < Cout; ++co) {
+        const float dv = dyb[(long)co * V];
+        const float* __restrict__ wr = w + (long)co * Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < CIT; i += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + i);
+            acc[i] = fmaf(wv.x, dv, acc[i]);
+            acc[i + 1] = fmaf(wv.y, dv, acc[i + 1]);
+            acc[i + 2] = fmaf(wv.z, dv, acc[i + 2]);
+            acc[i + 3] = fmaf(wv.w, dv, acc[i + 3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) {
+        const int c = ci0 + i;
+        float* dst = (c < C1) ? dx + ((long)b * C1 + c) * V + v : dx2 + ((long)b * (Cin - C1) + (c - C1)) * V + v;
+        if (accumulate) *dst += acc[i]; else *dst = acc[i];
+    }
+}
+
+// dW[co,ci] += sum_{b,v} dy[b,co,v] x[b,ci,v] ; db[co] += sum dy.   One wave = one (16 co x 16 ci) tile x one voxel chunk.
+__global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+                                                     const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
+                                                     float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long cw = (long)blockIdx.x * 4 + wave;
+    if (cw >= (long)B * chunks_per_b) return;
+    const int b = (int)(cw / chunks_per_b);
+    const long v0 = (cw % chunks_per_b) * (long)vox_per_wave;
+    const long v1 = (v0 + vox_per_wave < V) ? v0 + vox_per_wave : V;
+    const int mt = blockIdx.y / n_ci_tiles, nt = blockIdx.y % n_ci_tiles;
+    const int r = lane & 15, q = lane >> 4;
+    const int co = mt * 16 + r, ci = nt * 16 + r;
+    const bool co_ok = co < Cout, ci_ok = ci < Cin;
+    const float* __restrict__ arow = dy + ((long)b * Cout + (co_ok ? co : 0)) * V;
+    const float* __restrict__ brow = vx_pw_row(x, x2, C1, Cin, b, ci_ok ? ci : 0, V);
+    vx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const bool vec = (V & 3) == 0;
+    for (long vb = v0; vb < v1; vb += 16) {            // wave-uniform trip count (MFMA needs every lane); lane covers vb+4q .. vb+4q+3
+        const long v = vb + 4 * q;
+        float a4[4], b4[4];
+        if (vec && v + 3 < v1) {
+            const float4 av = co_ok ? *reinterpret_cast<const float4*>(arow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = ci_ok ? *reinterpret_cast<const float4*>(brow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a4[0] = av.x; a4[1] = av.y; a4[2] = av.z; a4[3] = av.w;
+            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = v + u < v1;
+                a4[u] = (in && co_ok) ? arow[v + u] : 0.0f;
+                b4[u] = (in && ci_ok) ? brow[v + u] : 0.0f;
+            }
+        }
+        bsum += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int m = mt * 16 + 4 * q + reg, n = nt * 16 + r;
+        if (m < Cout && n < Cin) atomicAdd(dw + (long)m * Cin + n, acc[reg]);
+    }
+    if (db != nullptr && nt == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0 && co_ok) atomicAdd(db + co, bsum);
+    }
+}
+
+template <int N> using vx_ic3 = std::integral_constant<int, N>;
+
+extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
+                              int B, int Cin, int Cout, long V, void* stream) {
+    VX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_fwd: bad args");
+    VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_fwd: Cin must be a multiple of 4 (got %d)", Cin);
+    if (C1 <= 0 || C1 > Cin) C1 = Cin;
+    VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_fwd: x2 missing");
+    VX_REQUIRE(C1 % 4 == 0, "vx_pw_conv_fwd: concat split must be a multiple of 4");
+    const int T = (Cout % 16 == 0) ? 16 : (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
+    dim3 grid(vx_cdiv(V, 256), Cout / T, B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (T) {
+        case 16: vx_pw_fwd_k<16><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+        case 8: vx_pw_fwd_k<8><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+        case 4: vx_pw_fwd_k<4><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+        case 2: vx_pw_fwd_k<2><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+        default: vx_pw_fwd_k<1><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+    }
+    VX_LAUNCH_CHECK("vx_pw_conv_fwd");
+    return 0;
+}
+
+extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int C1,
+                                   int B, int Cin, int Cout, long V, int accumulate, void* stream) {
+    VX_REQUIRE(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_data: bad args");
+    VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_bwd_data: Cin must be a multiple of 4 (got %d)", Cin);
+    if (C1 <= 0 || C1 > Cin) C1 = Cin;
+    VX_REQUIRE(C1 == Cin || dx2, "vx_pw_conv_bwd_data: dx2 missing");
+    int T = (Cin % 16 == 0) ? 16 : (Cin % 8 == 0) ? 8 : 4;
+    while (T > 4 && (C1 % T)) T >>= 1;
+    VX_REQUIRE(C1 % T == 0, "vx_pw_conv_bwd_data: concat split must be a multiple of 4");
+    dim3 grid(vx_cdiv(V, 256), Cin / T, B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (T) {
+        case 16: vx_pw_bwd_data_k<16><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
+        case 8: vx_pw_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
+        default: vx_pw_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
+    }
+    VX_LAUNCH_CHECK("vx_pw_conv_bwd_data");
+    return 0;
+}
+
+extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                                     int B, int Cin, int Cout, long V, void* stream) {
+    VX_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_weight: bad args");
+    if (C1 <= 0 || C1 > Cin) C1 = Cin;
+    VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_bwd_weight: x2 missing");
+    const int mt = vx_cdiv(Cout, 16), nt = vx_cdiv(Cin, 16);
+    // voxel chunk per wave: multiple of 16; aim at >= ~2048 waves in flight over all tiles
+    long waves_per_tile = 2048 / ((long)mt * nt);
+    if (waves_per_tile < 1) waves_per_tile = 1;
+    long vpw = ((long)B * V + waves_per_tile - 1) / waves_per_tile;
+    vpw = (vpw + 15) / 16 * 16;
+    if (vpw < 64) vpw = 64;
+    const int chunks_per_b = vx_cdiv(V, vpw);
+    dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), mt * nt);
+    vx_pw_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, x2, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);
+    VX_LAUNCH_CHECK("vx_pw_conv_bwd_weight");
+    return 0;
+}

@@ -17,6 +17,7 @@ import torch
 
 from . import _hip as H
 
+WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -84,7 +85,12 @@ class _Conv3dFn(torch.autograd.Function):
             y = torch.empty((B, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
         else:
             y = torch.empty((B, Cout // ps ** 3, Do * ps, Ho * ps, Wo * ps), device=x.device, dtype=torch.float32)
-        H.call("vx_conv3d_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, H.stream_ptr())
+        pw = (K == 1 and S == 1 and P == 0 and G == 1 and ps == 1 and Cin % 4 == 0 and C1 % 4 == 0)
+        if pw:
+            H.call("vx_pw_conv_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, Cout, D * Hh * W, H.stream_ptr())
+        else:
+            H.call("vx_conv3d_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, H.stream_ptr())
+        ctx.pw = pw
         ctx.save_for_backward(x, x2)
         ctx.w, ctx.b = w, b
         ctx.meta = (B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps)
@@ -102,10 +108,16 @@ class _Conv3dFn(torch.autograd.Function):
         if need_x:
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            H.call("vx_conv3d_bwd_data", H.P(dy), H.P(w), None, H.P(dx), H.P(dx2), C1, B, Cin, D, Hh, W, Cout, K, S, P, G, ps, 0, st)
+            if ctx.pw:
+                H.call("vx_pw_conv_bwd_data", H.P(dy), H.P(w), H.P(dx), H.P(dx2), C1, B, Cin, Cout, D * Hh * W, 0, st)
+            else:
+                H.call("vx_conv3d_bwd_data", H.P(dy), H.P(w), None, H.P(dx), H.P(dx2), C1, B, Cin, D, Hh, W, Cout, K, S, P, G, ps, 0, st)
         if w.requires_grad:
             db = grad_buf(b) if (b is not None and b.requires_grad) else None
-            H.call("vx_conv3d_bwd_weight", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
+            if K == 1 and S == 1 and P == 0 and G == 1 and ps == 1:
+                H.call("vx_pw_conv_bwd_weight", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, Cout, D * Hh * W, st)
+            else:
+                H.call(WGRAD_ENTRY, H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
         return dx, dx2, None, None, None, None, None, None, None
 
 
@@ -143,7 +155,7 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
             dx = torch.empty_like(x)
             H.call("vx_conv3d_fwd", H.P(dy), None, 0, H.P(w), None, H.P(dx), B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
         if w.requires_grad:
-            H.call("vx_conv3d_bwd_weight", H.P(dy), None, 0, H.P(x), H.P(grad_buf(w)), None, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
+            H.call(WGRAD_ENTRY, H.P(dy), None, 0, H.P(x), H.P(grad_buf(w)), None, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
         if b is not None and b.requires_grad:
             H.call("vx_channel_sum", H.P(dy), H.P(grad_buf(b)), B, Co, 8 * d * h * wd, st)
         return dx, None, None
@@ -227,7 +239,8 @@ class _LayerNormCFFn(torch.autograd.Function):
         B, C = x.shape[:2]
         V = x[0, 0].numel()
         dx = torch.empty_like(x)
-        H.call("vx_ln_cf_bwd", H.P(x), H.P(ctx.g), H.P(dout), H.P(dx), H.P(grad_buf(ctx.g)), H.P(grad_buf(ctx.bt)), B, C, V, LN_EPS, H.stream_ptr())
+        ws = torch.empty((2 * B * V,), device=x.device, dtype=torch.float32)
+        H.call("vx_ln_cf_bwd", H.P(x), H.P(ctx.g), H.P(dout), H.P(dx), H.P(grad_buf(ctx.g)), H.P(grad_buf(ctx.bt)), H.P(ws), B, C, V, LN_EPS, H.stream_ptr())
         return dx, None, None
 
 
