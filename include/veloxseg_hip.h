@@ -48,6 +48,11 @@ int vx_conv3d_bwd_weight(const float* x, const float* x2, int C1, const float* d
 /* LDS-tiled weight gradient for spatial kernels (same contract as vx_conv3d_bwd_weight): x halo tile in LDS, dy on the scalar path */
 int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                                int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* stride-1 "same" conv, K in {3,5}, register-blocked + LDS-staged (JLC grouped convs, patch-expand).  w is always the forward
+ * weight (Cf_out, Cf_in/G, K,K,K).  wmode 0 = forward (Cin=Cf_in, Cout=Cf_out); wmode 1 = input gradient (x:=dy, Cin=Cf_out, Cout=Cf_in).
+ * in_ps / out_ps: PixelShuffle factor of the input / output storage.  accumulate: y += . */
+int vx_conv_s1(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
+               int K, int G, int wmode, int in_ps, int out_ps, int accumulate, void* stream);
 /* 1x1x1 convolutions: thread-per-voxel with scalar-path weights (fwd / bwd_data; Cin % 4 == 0), fp32-MFMA GEMM over the voxel
  * axis for the weight gradient.  w: (Cout, Cin).  Same concat / accumulate conventions as vx_conv3d_*. */
 int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,

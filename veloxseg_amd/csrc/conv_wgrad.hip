@@ -35,7 +35,7 @@ __device__ __forceinline__ long vx_wg_dy_index(const VxWg& p, int b, int co, int
     return ((((long)b * Cc + c) * (p.Do * s) + d * s + s1) * (long)(p.Ho * s) + h * s + s2) * (long)(p.Wo * s) + w * s + s3;
 }
 
-template <int KT, int COT, int NP>
+template <int KT, int COT, int NP, int DYMODE>   // DYMODE 0: scalar dy loads, 1: 16-B loads along W (ps=1, Wo%4==0), 2: 16-B loads along co (ps=4)
 __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ dy, float* __restrict__ dw, VxWg p) {
     extern __shared__ __attribute__((aligned(16))) float vx_halo[];
@@ -97,13 +97,38 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
                         for (int n = 0; n < NP; ++n)
 #pragma unroll
                             for (int u = 0; u < 4; ++u) xv[n][u] = vx_halo[loff[n] + rowoff + (qw + u) * p.S];
+                        if (DYMODE == 1) {
 #pragma unroll
-                        for (int j = 0; j < COT; ++j) {
+                            for (int j = 0; j < COT; ++j) {
+                                const float4 d4 = *reinterpret_cast<const float4*>(dy + vx_wg_dy_index(p, b, co0 + j, od0 + qd, oh0 + qh, ow0 + qw));   // wave-uniform -> s_load_dwordx4
+                                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                    for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv[u], xv[n][u], acc[n][j]);
+                            }
+                        } else if (DYMODE == 2 && COT >= 4) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const float dv = dy[vx_wg_dy_index(p, b, co0 + j, od0 + qd, oh0 + qh, ow0 + qw + u)];   // wave-uniform -> s_load
 #pragma unroll
-                                for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv, xv[n][u], acc[n][j]);
+                                for (int j4 = 0; j4 < COT; j4 += 4) {
+                                    const float4 d4 = *reinterpret_cast<const float4*>(dy + vx_wg_dy_index(p, b, co0 + j4, od0 + qd, oh0 + qh, ow0 + qw + u));   // 4 consecutive co
+                                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                        for (int n = 0; n < NP; ++n) acc[n][(j4 + jj) < COT ? (j4 + jj) : 0] = fmaf(dv[jj], xv[n][u], acc[n][(j4 + jj) < COT ? (j4 + jj) : 0]);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < COT; ++j) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const float dv = dy[vx_wg_dy_index(p, b, co0 + j, od0 + qd, oh0 + qh, ow0 + qw + u)];   // wave-uniform -> s_load
+#pragma unroll
+                                    for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv, xv[n][u], acc[n][j]);
+                                }
                             }
                         }
                     }
@@ -131,16 +156,18 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
     }
 }
 
-// db[co] += sum_{b,q} dy[b,co,q]  (dy possibly pixel-shuffled); one block per output channel
+// db[co] += sum_{b,q} dy[b,co,q]  (dy possibly pixel-shuffled); grid (Cout, chunks)
 __global__ void __launch_bounds__(256) vx_bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, VxWg p) {
     const int co = blockIdx.x;
     const long Vo = (long)p.Do * p.Ho * p.Wo;
+    const long n = (long)p.B * Vo;
     float s = 0.0f;
-    for (int b = 0; b < p.B; ++b)
-        for (long q = threadIdx.x; q < Vo; q += 256) {
-            const int w = (int)(q % p.Wo), h = (int)((q / p.Wo) % p.Ho), d = (int)(q / ((long)p.Wo * p.Ho));
-            s += dy[vx_wg_dy_index(p, b, co, d, h, w)];
-        }
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long)gridDim.y * 256) {
+        const int b = (int)(i / Vo);
+        const long q = i % Vo;
+        const int w = (int)(q % p.Wo), h = (int)((q / p.Wo) % p.Ho), d = (int)(q / ((long)p.Wo * p.Ho));
+        s += dy[vx_wg_dy_index(p, b, co, d, h, w)];
+    }
     __shared__ float sm[4];
     s = vx_block_sum_256(s, sm);
     if (threadIdx.x == 0) atomicAdd(db + co, s);
@@ -190,8 +217,12 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
     const size_t shm = halo_bytes(p.TD, p.TH, p.TW);
     dim3 grid(vx_cdiv(ntiles, tpb), gy, B);
     hipStream_t st = (hipStream_t)stream;
+    const int dymode = (ps == 1 && p.Wo % 4 == 0 && p.TW % 4 == 0) ? 1 : ((ps == 4 && COT >= 4) ? 2 : 0);
     auto launch = [&](auto kt, auto cot, auto np) {
-        vx_wgrad_tiled_k<decltype(kt)::value, decltype(cot)::value, decltype(np)::value><<<grid, dim3(256), shm, st>>>(x, x2, dy, dw, p);
+        constexpr int KT_ = decltype(kt)::value, COT_ = decltype(cot)::value, NP_ = decltype(np)::value;
+        if (dymode == 1) vx_wgrad_tiled_k<KT_, COT_, NP_, 1><<<grid, dim3(256), shm, st>>>(x, x2, dy, dw, p);
+        else if (dymode == 2) vx_wgrad_tiled_k<KT_, COT_, NP_, 2><<<grid, dim3(256), shm, st>>>(x, x2, dy, dw, p);
+        else vx_wgrad_tiled_k<KT_, COT_, NP_, 0><<<grid, dim3(256), shm, st>>>(x, x2, dy, dw, p);
     };
     auto with_np = [&](auto kt, auto cot) {
         if (NP == 4) launch(kt, cot, vx_ic2<4>{});
@@ -211,7 +242,11 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
         case 5: with_cot(vx_ic2<5>{}); break;
         default: with_cot(vx_ic2<0>{}); break;
     }
-    if (db) vx_bias_grad_k<<<dim3(Cout), dim3(256), 0, st>>>(dy, db, p);
+    if (db) {
+        int chunks = vx_cdiv((long)B * p.Do * p.Ho * p.Wo, 256 * 16);
+        if (chunks > 32) chunks = 32;
+        vx_bias_grad_k<<<dim3(Cout, chunks), dim3(256), 0, st>>>(dy, db, p);
+    }
     VX_LAUNCH_CHECK("vx_conv3d_bwd_weight_tiled");
     return 0;
 }

@@ -18,6 +18,7 @@ import torch
 from . import _hip as H
 
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
+USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -86,8 +87,12 @@ class _Conv3dFn(torch.autograd.Function):
         else:
             y = torch.empty((B, Cout // ps ** 3, Do * ps, Ho * ps, Wo * ps), device=x.device, dtype=torch.float32)
         pw = (K == 1 and S == 1 and P == 0 and G == 1 and ps == 1 and Cin % 4 == 0 and C1 % 4 == 0)
+        s1 = (x2 is None and S == 1 and K in (3, 5) and P == K // 2 and (Cout // G) % 4 == 0 and (Cin // G) % 4 == 0 and USE_S1)
+        ctx.s1 = s1
         if pw:
             H.call("vx_pw_conv_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, Cout, D * Hh * W, H.stream_ptr())
+        elif s1:
+            H.call("vx_conv_s1", H.P(x), H.P(w), H.P(b), H.P(y), B, Cin, Cout, D, Hh, W, K, G, 0, 1, ps, 0, H.stream_ptr())
         else:
             H.call("vx_conv3d_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, H.stream_ptr())
         ctx.pw = pw
@@ -110,6 +115,8 @@ class _Conv3dFn(torch.autograd.Function):
             dx2 = torch.empty_like(x2) if x2 is not None else None
             if ctx.pw:
                 H.call("vx_pw_conv_bwd_data", H.P(dy), H.P(w), H.P(dx), H.P(dx2), C1, B, Cin, Cout, D * Hh * W, 0, st)
+            elif ctx.s1:
+                H.call("vx_conv_s1", H.P(dy), H.P(w), None, H.P(dx), B, Cout, Cin, D, Hh, W, K, G, 1, ps, 1, 0, st)
             else:
                 H.call("vx_conv3d_bwd_data", H.P(dy), H.P(w), None, H.P(dx), H.P(dx2), C1, B, Cin, D, Hh, W, Cout, K, S, P, G, ps, 0, st)
         if w.requires_grad:
