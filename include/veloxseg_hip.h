@@ -62,17 +62,23 @@ int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, 
 int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                           int B, int Cin, int Cout, long V, void* stream);
 
+/* small-volume variant (fp32 MFMA tiles of 16 channels x 16 voxels): dst[b,m,v] = bias[m] + sum_k Wt(m,k) src[b,k,v].
+ * forward: transpose_w=0, Mch=Cout, Kch=Cin; input gradient: transpose_w=1, Mch=Cin, Kch=Cout (src:=dy, dst:=dx).  Cin_of_w = row length of w.
+ * src may be a concat (S1 channels from src, rest from src2); dst may be split the same way (D1). */
+int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
+                    float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
  * Encoder.py:334-337, Decoder.py:54-57).  stats[2*bc] = mean, stats[2*bc+1] = rstd.
  *   vx_in_apply_fwd: out = (res?res:0) + sum_{k<nk} act((y_k-mean_k)*rstd_k), act 0=identity 1=exact GELU
  *                    (JLC spatial sum conv_blocks.py:73; DownConv+attn2conv add Encoder.py:351-360; UpConv+skip Decoder.py:85-87)
- *   vx_in_bwd:       dy = rstd*(dz - mean(dz) - z*mean(dz*z)), dz = dout*act'(z); m_ws = 2*BC floats of workspace
+ *   vx_in_bwd:       dy = rstd*(dz - mean(dz) - z*mean(dz*z)), dz = dout*act'(z); m_ws = 2*BC floats, part_ws = 32*BC doubles of workspace
  * --------------------------------------------------------------------------------------------- */
-int vx_in_stats(const float* x, float* stats, long BC, long V, float eps, void* stream);
+int vx_in_stats(const float* x, float* stats, double* part_ws, long BC, long V, float eps, void* stream);   /* part_ws: 32*BC doubles */
 int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                     int nk, int act, const float* res, float* out, long BC, long V, void* stream);
-int vx_in_bwd(const float* dout, const float* y, const float* stats, int act, float* m_ws, float* dy, long BC, long V, void* stream);
+int vx_in_bwd(const float* dout, const float* y, const float* stats, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream);
 
 /* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
 int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);
@@ -109,7 +115,7 @@ int vx_pwa_gather_fwd(const float* src, float* tok, const VxPwaPlan* plan, int c
 int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsrc, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
 /* window_scattering_3d (PWA.py:177-200): per-window trilinear, align_corners=True */
 int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
-int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);   /* dtok += (caller zeroes it once for all modalities) */
 /* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).
  * O: (B,heads,Ntot,M*l,cv); LSE: (B,heads,Ntot,M*l).  bwd: dtable += ; delta_ws = B*heads*Ntot*M*l floats. */
 int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
@@ -140,7 +146,12 @@ int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const flo
 int vx_gram_fwd(const float* x, float* G, int B, int C, long V, void* stream);
 int vx_gram_bwd(const float* x, const float* dG, float* dx, int B, int C, long V, void* stream);
 int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, int d, int h, int w, int D, int H, int W, void* stream);
-int vx_upsample_trilinear_bwd(const float* dout, float* dx, long BC, int d, int h, int w, int D, int H, int W, void* stream);
+/* adjoint as three separable 1-D passes (D, then H, then W); ws = BC*d*(H*W + h*W) floats */
+int vx_upsample_trilinear_bwd(const float* dout, float* dx, float* ws, long BC, int d, int h, int w, int D, int H, int W, void* stream);
+
+/* ConvTranspose3d(k=2, s=2) specialised (conv_blocks.py:29-35): w = (Ci, Co, 2,2,2); x: (B,Ci,d,h,w); y: (B,Co,2d,2h,2w) */
+int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream);
+int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream);
 
 /* fused AdamW on flat buffers (torch.optim.AdamW maths; config/train_config_bs4.json:66-72); g is scaled by grad_scale first */
 int vx_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

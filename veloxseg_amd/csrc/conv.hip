@@ -43,12 +43,15 @@ __device__ __forceinline__ const float* vx_in_chan(const VxConv& p, const float*
 }
 
 // ------------------------------------------------------------------------------------------
-// forward: one thread = one output voxel x COT output channels (same group)
+// forward: one thread = one output voxel x COT output channels (same group).  The weight slice of the block's
+// COT channels is staged in LDS as [ci][tap][COT] (CIC input channels per pass) and read back as broadcast
+// ds_read_b128, so strided / odd-sized kernels (DownConv k7s4, k3s2, PatchEmbed k=s) do not depend on scalar-load merging.
 // ------------------------------------------------------------------------------------------
 template <int KT, int COT>
 __global__ void __launch_bounds__(256) vx_conv3d_fwd_k(const float* __restrict__ x, const float* __restrict__ x2,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y, VxConv p) {
+                                                       float* __restrict__ y, VxConv p, int cic) {
+    extern __shared__ __attribute__((aligned(16))) float vx_wlds[];
     const int K = KT > 0 ? KT : p.K;
     const int K3 = K * K * K;
     const long Vo = (long)p.Do * p.Ho * p.Wo;
@@ -57,48 +60,61 @@ __global__ void __launch_bounds__(256) vx_conv3d_fwd_k(const float* __restrict__
     const int co0 = blockIdx.y * COT;
     const int Cin_g = p.Cin / p.G, Cout_g = p.Cout / p.G;
     const int g = co0 / Cout_g;
-    if (v >= Vo) return;
-    const int ow = (int)(v % p.Wo);
-    const int oh = (int)((v / p.Wo) % p.Ho);
-    const int od = (int)(v / ((long)p.Wo * p.Ho));
+    const bool valid = v < Vo;
+    const long vv = valid ? v : 0;
+    const int ow = (int)(vv % p.Wo);
+    const int oh = (int)((vv / p.Wo) % p.Ho);
+    const int od = (int)(vv / ((long)p.Wo * p.Ho));
     float acc[COT];
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = bias ? bias[co0 + j] : 0.0f;
     const int id0 = od * p.S - p.P, ih0 = oh * p.S - p.P, iw0 = ow * p.S - p.P;
-    const long wstride = (long)Cin_g * K3;
-    for (int ci = 0; ci < Cin_g; ++ci) {
-        const float* __restrict__ xc = vx_in_chan(p, x, x2, b, g * Cin_g + ci);
-        const float* __restrict__ wc = w + ((long)co0 * Cin_g + ci) * K3;
-        for (int kd = 0; kd < K; ++kd) {
-            const int id = id0 + kd;
-            const bool okd = (unsigned)id < (unsigned)p.Di;
-            for (int kh = 0; kh < K; ++kh) {
-                const int ih = ih0 + kh;
-                const bool okh = okd && (unsigned)ih < (unsigned)p.Hi;
-                const long rowoff = ((long)id * p.Hi + ih) * p.Wi;
+    for (int cc = 0; cc < Cin_g; cc += cic) {
+        const int ncc = min(cic, Cin_g - cc);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ncc * K3 * COT; e += 256) {
+            const int j = e % COT, t = (e / COT) % K3, cil = e / (COT * K3);
+            vx_wlds[e] = w[((long)(co0 + j) * Cin_g + cc + cil) * K3 + t];
+        }
+        __syncthreads();
+        if (valid) {
+            for (int cil = 0; cil < ncc; ++cil) {
+                const float* __restrict__ xc = vx_in_chan(p, x, x2, b, g * Cin_g + cc + cil);
+                const float* __restrict__ wc = vx_wlds + (long)cil * K3 * COT;
+                for (int kd = 0; kd < K; ++kd) {
+                    const int id = id0 + kd;
+                    const bool okd = (unsigned)id < (unsigned)p.Di;
+                    for (int kh = 0; kh < K; ++kh) {
+                        const int ih = ih0 + kh;
+                        const bool okh = okd && (unsigned)ih < (unsigned)p.Hi;
+                        const long rowoff = ((long)id * p.Hi + ih) * p.Wi;
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const int iw = iw0 + kw;
-                    const float xv = (okh && (unsigned)iw < (unsigned)p.Wi) ? xc[rowoff + iw] : 0.0f;
-                    const float* wp = wc + (kd * K + kh) * K + kw;
+                        for (int kw = 0; kw < K; ++kw) {
+                            const int iw = iw0 + kw;
+                            const float xv = (okh && (unsigned)iw < (unsigned)p.Wi) ? xc[rowoff + iw] : 0.0f;
+                            const float* wp = wc + ((kd * K + kh) * K + kw) * COT;
 #pragma unroll
-                    for (int j = 0; j < COT; ++j) acc[j] = fmaf(wp[j * wstride], xv, acc[j]);
+                            for (int j = 0; j < COT; ++j) acc[j] = fmaf(wp[j], xv, acc[j]);
+                        }
+                    }
                 }
             }
         }
     }
+    if (!valid) return;
 #pragma unroll
     for (int j = 0; j < COT; ++j) y[vx_y_index(p, b, co0 + j, od, oh, ow)] = acc[j];
 }
 
 // ------------------------------------------------------------------------------------------
-// backward-data: one thread = one input voxel x CIT input channels (same group)
+// backward-data: one thread = one input voxel x CIT input channels (same group); weights staged in LDS as [co][tap][CIT]
 //   dx[b,ci,pos] (+)= sum_{co in group} sum_t dy[b,co,q] * w[co,ci,t],   q*S - P + t = pos
 // ------------------------------------------------------------------------------------------
 template <int KT, int CIT>
 __global__ void __launch_bounds__(256) vx_conv3d_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
                                                             const float* __restrict__ bias_like,  // optional bias added (ConvTranspose fwd)
-                                                            float* __restrict__ dx, float* __restrict__ dx2, VxConv p, int accumulate) {
+                                                            float* __restrict__ dx, float* __restrict__ dx2, VxConv p, int accumulate, int coc) {
+    extern __shared__ __attribute__((aligned(16))) float vx_wlds[];
     const int K = KT > 0 ? KT : p.K;
     const int K3 = K * K * K;
     const long Vi = (long)p.Di * p.Hi * p.Wi;
@@ -108,36 +124,51 @@ __global__ void __launch_bounds__(256) vx_conv3d_bwd_data_k(const float* __restr
     const int Cin_g = p.Cin / p.G, Cout_g = p.Cout / p.G;
     const int g = ci0 / Cin_g;
     const int cil = ci0 - g * Cin_g;              // channel inside group
-    if (v >= Vi) return;
-    const int iw = (int)(v % p.Wi);
-    const int ih = (int)((v / p.Wi) % p.Hi);
-    const int id = (int)(v / ((long)p.Wi * p.Hi));
+    const bool valid = v < Vi;
+    const long vv = valid ? v : 0;
+    const int iw = (int)(vv % p.Wi);
+    const int ih = (int)((vv / p.Wi) % p.Hi);
+    const int id = (int)(vv / ((long)p.Wi * p.Hi));
     float acc[CIT];
 #pragma unroll
     for (int j = 0; j < CIT; ++j) acc[j] = bias_like ? bias_like[ci0 + j] : 0.0f;
-    for (int col = 0; col < Cout_g; ++col) {
-        const int co = g * Cout_g + col;
-        const float* __restrict__ wc = w + ((long)co * Cin_g + cil) * K3;
-        for (int kd = 0; kd < K; ++kd) {
-            const int nd = id + p.P - kd;
-            const int qd = nd / p.S;
-            const bool okd = nd >= 0 && qd * p.S == nd && qd < p.Do;
-            for (int kh = 0; kh < K; ++kh) {
-                const int nh = ih + p.P - kh;
-                const int qh = nh / p.S;
-                const bool okh = okd && nh >= 0 && qh * p.S == nh && qh < p.Ho;
-                for (int kw = 0; kw < K; ++kw) {
-                    const int nw = iw + p.P - kw;
-                    const int qw = nw / p.S;
-                    const bool ok = okh && nw >= 0 && qw * p.S == nw && qw < p.Wo;
-                    const float dv = ok ? dy[vx_y_index(p, b, co, qd, qh, qw)] : 0.0f;
-                    const float* wp = wc + (kd * K + kh) * K + kw;
+    for (int c0 = 0; c0 < Cout_g; c0 += coc) {
+        const int ncoc = min(coc, Cout_g - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ncoc * K3 * CIT; e += 256) {
+            const int j = e % CIT, t = (e / CIT) % K3, col = e / (CIT * K3);
+            vx_wlds[e] = w[((long)(g * Cout_g + c0 + col) * Cin_g + cil + j) * K3 + t];
+        }
+        __syncthreads();
+        if (valid) {
+            for (int col = 0; col < ncoc; ++col) {
+                const int co = g * Cout_g + c0 + col;
+                const float* __restrict__ wc = vx_wlds + (long)col * K3 * CIT;
+                for (int kd = 0; kd < K; ++kd) {
+                    const int nd = id + p.P - kd;
+                    const int qd = nd / p.S;
+                    const bool okd = nd >= 0 && qd * p.S == nd && qd < p.Do;
+                    for (int kh = 0; kh < K; ++kh) {
+                        const int nh = ih + p.P - kh;
+                        const int qh = nh / p.S;
+                        const bool okh = okd && nh >= 0 && qh * p.S == nh && qh < p.Ho;
+                        for (int kw = 0; kw < K; ++kw) {
+                            const int nw = iw + p.P - kw;
+                            const int qw = nw / p.S;
+                            const bool ok = okh && nw >= 0 && qw * p.S == nw && qw < p.Wo;
+                            if (ok) {
+                                const float dv = dy[vx_y_index(p, b, co, qd, qh, qw)];
+                                const float* wp = wc + ((kd * K + kh) * K + kw) * CIT;
 #pragma unroll
-                    for (int j = 0; j < CIT; ++j) acc[j] = fmaf(wp[j * K3], dv, acc[j]);
+                                for (int j = 0; j < CIT; ++j) acc[j] = fmaf(wp[j], dv, acc[j]);
+                            }
+                        }
+                    }
                 }
             }
         }
     }
+    if (!valid) return;
 #pragma unroll
     for (int j = 0; j < CIT; ++j) {
         const int c = ci0 + j;
@@ -235,12 +266,18 @@ extern "C" int vx_conv3d_fwd(const float* x, const float* x2, int C1, const floa
     if (int e = vx_conv_fill(p, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, C1, ps, "vx_conv3d_fwd")) return e;
     if (!x || !w || !y || (p.C1 < Cin && !x2)) VX_FAIL(-1, "vx_conv3d_fwd: null pointer");
     const long Vo = (long)p.Do * p.Ho * p.Wo;
-    const int T = vx_pick_tile(Cout / G);
+    int T = vx_pick_tile(Cout / G);
+    while (T > 1 && (long)vx_cdiv(Vo, 256) * (Cout / T) * B < 512) T >>= 1;        // small outputs: more blocks
+    const int K3 = K * K * K, Cin_g = Cin / G;
+    int cic = Cin_g;
+    while (cic > 1 && (size_t)cic * K3 * T * sizeof(float) > 32 * 1024) cic = (cic + 1) / 2;
+    const size_t shm = (size_t)cic * K3 * T * sizeof(float);
+    VX_REQUIRE(shm <= 150 * 1024, "vx_conv3d_fwd: weight slice does not fit LDS (K=%d)", K);
     dim3 grid(vx_cdiv(Vo, 256), Cout / T, B);
     hipStream_t st = (hipStream_t)stream;
     vx_dispatch_kt(K, [&](auto kt) {
         vx_dispatch_tile(T, [&](auto tt) {
-            vx_conv3d_fwd_k<decltype(kt)::value, decltype(tt)::value><<<grid, dim3(256), 0, st>>>(x, x2, w, bias, y, p);
+            vx_conv3d_fwd_k<decltype(kt)::value, decltype(tt)::value><<<grid, dim3(256), shm, st>>>(x, x2, w, bias, y, p, cic);
         });
     });
     VX_LAUNCH_CHECK("vx_conv3d_fwd");
@@ -256,11 +293,17 @@ extern "C" int vx_conv3d_bwd_data(const float* dy, const float* w, const float* 
     const long Vi = (long)Di * Hi * Wi;
     int T = vx_pick_tile(Cin / G);
     if (p.C1 < Cin) { while (T > 1 && (p.C1 % T)) T >>= 1; }   // a tile must not straddle the concat boundary
+    while (T > 1 && (long)vx_cdiv(Vi, 256) * (Cin / T) * B < 512) T >>= 1;
+    const int K3 = K * K * K, Cout_g = Cout / G;
+    int coc = Cout_g;
+    while (coc > 1 && (size_t)coc * K3 * T * sizeof(float) > 32 * 1024) coc = (coc + 1) / 2;
+    const size_t shm = (size_t)coc * K3 * T * sizeof(float);
+    VX_REQUIRE(shm <= 150 * 1024, "vx_conv3d_bwd_data: weight slice does not fit LDS (K=%d)", K);
     dim3 grid(vx_cdiv(Vi, 256), Cin / T, B);
     hipStream_t st = (hipStream_t)stream;
     vx_dispatch_kt(K, [&](auto kt) {
         vx_dispatch_tile(T, [&](auto tt) {
-            vx_conv3d_bwd_data_k<decltype(kt)::value, decltype(tt)::value><<<grid, dim3(256), 0, st>>>(dy, w, bias_like, dx, dx2, p, accumulate);
+            vx_conv3d_bwd_data_k<decltype(kt)::value, decltype(tt)::value><<<grid, dim3(256), shm, st>>>(dy, w, bias_like, dx, dx2, p, accumulate, coc);
         });
     });
     VX_LAUNCH_CHECK("vx_conv3d_bwd_data");

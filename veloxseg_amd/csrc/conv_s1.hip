@@ -66,13 +66,15 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
         __syncthreads();
         // stage the halo of `ncc` input channels
         for (int e = tid; e < ncc * plane; e += 256) {
-            const int cil = e / plane, r = e % plane;
+            int cil, r;
+            if (p.in_ps > 1) { cil = e % ncc; r = e / ncc; }      // pixel-shuffled source: consecutive channels are consecutive in memory
+            else { cil = e / plane; r = e % plane; }
             const int hw = r % p.HWp, hh = (r / p.HWp) % p.HH, hd = r / (p.HWp * p.HH);
             const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
             float v = 0.0f;
             if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                 v = x[vx_ps_index(p.Cin, p.D, p.H, p.W, p.in_ps, b, g * Cin_g + cc + cil, id, ih, iw)];
-            xs[e] = v;
+            xs[cil * plane + r] = v;
         }
         // stage the weight slice [ncc][K3][COT]
         for (int e = tid; e < ncc * K3 * COT; e += 256) {
@@ -164,7 +166,9 @@ extern "C" int vx_conv_s1(const float* x, const float* w, const float* bias, flo
     p.HD = p.TD + K - 1; p.HH = p.TH + K - 1; p.HWp = (p.TWq * 4 + K - 1 + 3) / 4 * 4;
     if (p.HWp < p.TWq * 4 + 4) p.HWp = p.TWq * 4 + 4;     // the 8-float row read of the last thread must stay inside the row
     p.nTd = vx_cdiv(D, p.TD); p.nTh = vx_cdiv(H, p.TH); p.nTw = vx_cdiv(W, p.TWq * 4);
-    const int COT = (Cout_g % 16 == 0) ? 16 : (Cout_g % 8 == 0) ? 8 : 4;
+    int COT = (Cout_g % 16 == 0) ? 16 : (Cout_g % 8 == 0) ? 8 : 4;
+    // few output channels (e.g. the 16-channel input gradient of a patch-expand conv): narrower register blocks, more blocks
+    while (COT > 4 && (long)p.nTd * p.nTh * p.nTw * (Cout / COT) * B < 512) COT >>= 1;
     const int plane = p.HD * p.HH * p.HWp;
     // input channels per pass: keep LDS (halo + weights) under ~48 KB so that 3 blocks share a CU
     int cic = Cin_g < 4 ? Cin_g : 4;

@@ -262,33 +262,37 @@ __global__ void __launch_bounds__(256) vx_upsample_fwd_k(const float* __restrict
                        l0 * (k1 * (k2 * T(b0, a1, a2) + l2 * T(b0, a1, b2)) + l1 * (k2 * T(b0, b1, a2) + l2 * T(b0, b1, b2)));
 }
 
-// adjoint with an LDS copy of one (b,c) low-res volume per block: grid (chunks, B*C); LDS atomics, then one global atomic per low-res voxel
-__global__ void __launch_bounds__(256) vx_upsample_bwd_k(const float* __restrict__ dout, float* __restrict__ dx, int d, int h, int w, int D, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float vx_lds[];
-    const long Vo = (long)D * H * W;
-    const int Vi = d * h * w;
+// adjoint as separable 1-D passes.  pass over axis `ax` of a (n0,n1,n2) volume: out[.., j_in, ..] = sum_J A[J][j_in] * in[.., J, ..]
+// one thread = one output element; threads run along the innermost axis, so reads are coalesced for ax = 0,1 (the big passes).
+__global__ void __launch_bounds__(256) vx_upsample_adj_axis_k(const float* __restrict__ in, float* __restrict__ out,
+                                                              int N0, int N1, int N2, int ax, int nin, int nout) {
+    // input dims (N0,N1,N2) with N[ax] == nout (fine); output dims equal except axis ax -> nin (coarse)
+    const int O0 = ax == 0 ? nin : N0, O1 = ax == 1 ? nin : N1, O2 = ax == 2 ? nin : N2;
+    const long Vo = (long)O0 * O1 * O2, Vin = (long)N0 * N1 * N2;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Vo) return;
     const long bc = blockIdx.y;
-    for (int k = threadIdx.x; k < Vi; k += 256) vx_lds[k] = 0.0f;
-    __syncthreads();
-    const float* __restrict__ db = dout + bc * Vo;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < Vo; v += (long)gridDim.x * 256) {
-        const int X = (int)(v % W), Y = (int)((v / W) % H), Z = (int)(v / ((long)W * H));
-        int a0, b0, a1, b1, a2, b2;
-        float l0, l1, l2;
-        vx_up_coord(Z, d, D, a0, b0, l0);
-        vx_up_coord(Y, h, H, a1, b1, l1);
-        vx_up_coord(X, w, W, a2, b2, l2);
-        const float g = db[v];
-        const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
-        auto A = [&](int z, int y, int xx, float wt) { if (wt != 0.0f) atomicAdd(&vx_lds[(z * h + y) * w + xx], wt * g); };
-        A(a0, a1, a2, k0 * k1 * k2); A(a0, a1, b2, k0 * k1 * l2); A(a0, b1, a2, k0 * l1 * k2); A(a0, b1, b2, k0 * l1 * l2);
-        A(b0, a1, a2, l0 * k1 * k2); A(b0, a1, b2, l0 * k1 * l2); A(b0, b1, a2, l0 * l1 * k2); A(b0, b1, b2, l0 * l1 * l2);
+    const int o2 = (int)(e % O2), o1 = (int)((e / O2) % O1), o0 = (int)(e / ((long)O2 * O1));
+    const int t = ax == 0 ? o0 : (ax == 1 ? o1 : o2);
+    const long stride = ax == 0 ? (long)N1 * N2 : (ax == 1 ? N2 : 1);
+    const long base = bc * Vin + ((long)(ax == 0 ? 0 : o0) * N1 + (ax == 1 ? 0 : o1)) * N2 + (ax == 2 ? 0 : o2);
+    // fine positions that touch coarse index t: src = ratio*J in (t-1, t+1)
+    int lo = 0, hi = nout - 1;
+    if (nout != nin && nout > 1 && nin > 1) {
+        const float inv = (float)(nout - 1) / (float)(nin - 1);
+        lo = (int)floorf((float)(t - 1) * inv);
+        hi = (int)ceilf((float)(t + 1) * inv);
+        if (lo < 0) lo = 0;
+        if (hi > nout - 1) hi = nout - 1;
+    } else if (nout == nin) { lo = t; hi = t; }
+    float acc = 0.0f;
+    for (int J = lo; J <= hi; ++J) {
+        int i0, i1; float lam;
+        vx_up_coord(J, nin, nout, i0, i1, lam);
+        const float wgt = (i0 == t ? 1.0f - lam : 0.0f) + (i1 == t ? lam : 0.0f);
+        if (wgt != 0.0f) acc = fmaf(wgt, in[base + (long)J * stride], acc);
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < Vi; k += 256) {
-        const float s = vx_lds[k];
-        if (s != 0.0f) atomicAdd(dx + bc * Vi + k, s);
-    }
+    out[bc * Vo + e] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,15 +399,14 @@ extern "C" int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, in
     return 0;
 }
 
-extern "C" int vx_upsample_trilinear_bwd(const float* dout, float* dx, long BC, int d, int h, int w, int D, int H, int W, void* stream) {
-    VX_REQUIRE(dout && dx && BC > 0 && d > 0 && h > 0 && w > 0, "vx_upsample_trilinear_bwd: bad args");
-    const size_t shm = sizeof(float) * (size_t)d * h * w;
-    VX_REQUIRE(shm <= 96 * 1024, "vx_upsample_trilinear_bwd: low-res volume %dx%dx%d does not fit the LDS accumulator", d, h, w);
+extern "C" int vx_upsample_trilinear_bwd(const float* dout, float* dx, float* ws, long BC, int d, int h, int w, int D, int H, int W, void* stream) {
+    VX_REQUIRE(dout && dx && ws && BC > 0 && d > 0 && h > 0 && w > 0 && D >= d && H >= h && W >= w, "vx_upsample_trilinear_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)BC * d * h * w, st) != hipSuccess) VX_FAIL(-2, "vx_upsample_trilinear_bwd: memset failed");
-    int chunks = vx_cdiv((long)D * H * W, 256 * 16);
-    if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(vx_upsample_bwd_k, dim3(chunks, (unsigned)BC), dim3(256), shm, st, dout, dx, d, h, w, D, H, W);
+    float* t1 = ws;                                   // (BC, d, H, W)
+    float* t2 = ws + BC * (long)d * H * W;            // (BC, d, h, W)
+    hipLaunchKernelGGL(vx_upsample_adj_axis_k, dim3(vx_cdiv((long)d * H * W, 256), (unsigned)BC), dim3(256), 0, st, dout, t1, D, H, W, 0, d, D);
+    hipLaunchKernelGGL(vx_upsample_adj_axis_k, dim3(vx_cdiv((long)d * h * W, 256), (unsigned)BC), dim3(256), 0, st, (const float*)t1, t2, d, H, W, 1, h, H);
+    hipLaunchKernelGGL(vx_upsample_adj_axis_k, dim3(vx_cdiv((long)d * h * w, 256), (unsigned)BC), dim3(256), 0, st, (const float*)t2, dx, d, h, W, 2, w, W);
     VX_LAUNCH_CHECK("vx_upsample_trilinear_bwd");
     return 0;
 }

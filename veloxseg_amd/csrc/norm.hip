@@ -10,11 +10,12 @@
 // InstanceNorm statistics: one 256-thread block per (b,c) row of V contiguous floats.
 // stats[2*bc] = mean, stats[2*bc+1] = rstd.  fp64 accumulation -> deterministic and cancellation-safe.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) vx_in_stats_k(const float* __restrict__ x, float* __restrict__ stats, long V, float eps) {
+__global__ void __launch_bounds__(256) vx_in_stats_part_k(const float* __restrict__ x, double* __restrict__ part, long V, int S) {
     const long bc = blockIdx.x;
+    const int sp = blockIdx.y;
     const float* __restrict__ row = x + bc * V;
     double s = 0.0, ss = 0.0;
-    for (long v = threadIdx.x; v < V; v += 256) {
+    for (long v = (long)sp * 256 + threadIdx.x; v < V; v += (long)S * 256) {
         const double t = (double)row[v];
         s += t;
         ss += t * t;
@@ -26,13 +27,20 @@ __global__ void __launch_bounds__(256) vx_in_stats_k(const float* __restrict__ x
     if (lane == 0) { sm[wid] = s; sm[4 + wid] = ss; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double S = sm[0] + sm[1] + sm[2] + sm[3], SS = sm[4] + sm[5] + sm[6] + sm[7];
-        const double m = S / (double)V;
-        double var = SS / (double)V - m * m;
-        if (var < 0.0) var = 0.0;
-        stats[2 * bc] = (float)m;
-        stats[2 * bc + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        part[(bc * S + sp) * 2] = sm[0] + sm[1] + sm[2] + sm[3];
+        part[(bc * S + sp) * 2 + 1] = sm[4] + sm[5] + sm[6] + sm[7];
     }
+}
+__global__ void __launch_bounds__(256) vx_in_stats_fin_k(const double* __restrict__ part, float* __restrict__ stats, long BC, long V, int S, float eps) {
+    const long bc = (long)blockIdx.x * 256 + threadIdx.x;
+    if (bc >= BC) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < S; ++k) { s += part[(bc * S + k) * 2]; ss += part[(bc * S + k) * 2 + 1]; }
+    const double m = s / (double)V;
+    double var = ss / (double)V - m * m;
+    if (var < 0.0) var = 0.0;
+    stats[2 * bc] = (float)m;
+    stats[2 * bc + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // out = (res ? res : 0) + sum_{k<nk} act((y_k - mean_k) * rstd_k)
@@ -60,12 +68,13 @@ __global__ void __launch_bounds__(256) vx_in_apply_fwd_k(const float* __restrict
 }
 
 // backward statistics for one branch: m[2bc] = mean(dz), m[2bc+1] = mean(dz*z), dz = dout*act'(z)
-__global__ void __launch_bounds__(256) vx_in_bwd_stats_k(const float* __restrict__ dout, const float* __restrict__ y,
-                                                         const float* __restrict__ st, int act, float* __restrict__ m, long V) {
+__global__ void __launch_bounds__(256) vx_in_bwd_stats_part_k(const float* __restrict__ dout, const float* __restrict__ y,
+                                                              const float* __restrict__ st, int act, double* __restrict__ part, long V, int S) {
     const long bc = blockIdx.x;
+    const int sp = blockIdx.y;
     const float mean = st[2 * bc], rstd = st[2 * bc + 1];
     double a = 0.0, c = 0.0;
-    for (long v = threadIdx.x; v < V; v += 256) {
+    for (long v = (long)sp * 256 + threadIdx.x; v < V; v += (long)S * 256) {
         const long i = bc * V + v;
         const float z = (y[i] - mean) * rstd;
         const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
@@ -79,9 +88,17 @@ __global__ void __launch_bounds__(256) vx_in_bwd_stats_k(const float* __restrict
     if (lane == 0) { sm[wid] = a; sm[4 + wid] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        m[2 * bc] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)V);
-        m[2 * bc + 1] = (float)((sm[4] + sm[5] + sm[6] + sm[7]) / (double)V);
+        part[(bc * S + sp) * 2] = sm[0] + sm[1] + sm[2] + sm[3];
+        part[(bc * S + sp) * 2 + 1] = sm[4] + sm[5] + sm[6] + sm[7];
     }
+}
+__global__ void __launch_bounds__(256) vx_in_bwd_stats_fin_k(const double* __restrict__ part, float* __restrict__ m, long BC, long V, int S) {
+    const long bc = (long)blockIdx.x * 256 + threadIdx.x;
+    if (bc >= BC) return;
+    double a = 0.0, c = 0.0;
+    for (int k = 0; k < S; ++k) { a += part[(bc * S + k) * 2]; c += part[(bc * S + k) * 2 + 1]; }
+    m[2 * bc] = (float)(a / (double)V);
+    m[2 * bc + 1] = (float)(c / (double)V);
 }
 
 // dy = rstd * (dz - m1 - z*m2)
@@ -101,18 +118,28 @@ __global__ void __launch_bounds__(256) vx_in_bwd_apply_k(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 // channels-first LayerNorm, one thread per voxel (coalesced along V for every channel).
 // ---------------------------------------------------------------------------------------------
+// per-voxel mean / rstd over C with a pivot-shifted single sweep (numerically equivalent to the two-pass form at fp32)
+__device__ __forceinline__ void vx_ln_stats(const float* __restrict__ xb, int C, long V, float eps, float& u, float& r) {
+    const float pivot = xb[0];
+    float s = 0.0f, q = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - pivot; s += d; q = fmaf(d, d, q); }
+    const float md = s / (float)C;
+    float var = q / (float)C - md * md;
+    var = var < 0.0f ? 0.0f : var;
+    u = pivot + md;
+    r = 1.0f / sqrtf(var + eps);
+}
+
 __global__ void __launch_bounds__(256) vx_ln_cf_fwd_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ out, int C, long V, float eps) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const float* __restrict__ xb = x + (long)blockIdx.y * C * V + v;
     float* __restrict__ ob = out + (long)blockIdx.y * C * V + v;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += xb[(long)c * V];
-    const float u = s / (float)C;
-    float q = 0.0f;
-    for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
-    const float r = 1.0f / sqrtf(q / (float)C + eps);
+    float u, r;
+    vx_ln_stats(xb, C, V, eps, u, r);
+#pragma unroll 8
     for (int c = 0; c < C; ++c) ob[(long)c * V] = fmaf(gamma[c], (xb[(long)c * V] - u) * r, beta[c]);
 }
 
@@ -124,13 +151,10 @@ __global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ 
     const long base = (long)blockIdx.y * C * V + v;
     const float* __restrict__ xb = x + base;
     const float* __restrict__ db = dout + base;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += xb[(long)c * V];
-    const float u = s / (float)C;
-    float q = 0.0f;
-    for (int c = 0; c < C; ++c) { const float d = xb[(long)c * V] - u; q = fmaf(d, d, q); }
-    const float r = 1.0f / sqrtf(q / (float)C + eps);
+    float u, r;
+    vx_ln_stats(xb, C, V, eps, u, r);
     float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const float xh = (xb[(long)c * V] - u) * r;
         const float g = db[(long)c * V] * gamma[c];
@@ -139,6 +163,7 @@ __global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ 
     }
     s1 /= (float)C;
     s2 /= (float)C;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const float xh = (xb[(long)c * V] - u) * r;
         dx[base + (long)c * V] = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
@@ -242,9 +267,19 @@ static VxDrop vx_mk_drop(const void* seed_ptr, unsigned long long stream, float 
     return d;
 }
 
-extern "C" int vx_in_stats(const float* x, float* stats, long BC, long V, float eps, void* stream) {
-    VX_REQUIRE(x && stats && BC > 0 && V > 1, "vx_in_stats: bad args (InstanceNorm needs more than 1 spatial element; BC=%ld V=%ld)", BC, V);
-    hipLaunchKernelGGL(vx_in_stats_k, dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, stats, V, eps);
+static int vx_in_split(long BC, long V) {      // row split so that ~1024 blocks are in flight, each with >= 2048 elements
+    long S = 1024 / (BC > 0 ? BC : 1);
+    if (S > V / 2048) S = V / 2048;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+extern "C" int vx_in_stats(const float* x, float* stats, double* part_ws, long BC, long V, float eps, void* stream) {
+    VX_REQUIRE(x && stats && part_ws && BC > 0 && V > 1, "vx_in_stats: bad args (InstanceNorm needs more than 1 spatial element; BC=%ld V=%ld)", BC, V);
+    const int S = vx_in_split(BC, V);
+    hipLaunchKernelGGL(vx_in_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, x, part_ws, V, S);
+    hipLaunchKernelGGL(vx_in_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, stats, BC, V, S, eps);
     VX_LAUNCH_CHECK("vx_in_stats");
     return 0;
 }
@@ -257,9 +292,11 @@ extern "C" int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2
     return 0;
 }
 
-extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, float* dy, long BC, long V, void* stream) {
-    VX_REQUIRE(dout && y && st && m_ws && dy, "vx_in_bwd: null pointer");
-    hipLaunchKernelGGL(vx_in_bwd_stats_k, dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, m_ws, V);
+extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream) {
+    VX_REQUIRE(dout && y && st && m_ws && part_ws && dy, "vx_in_bwd: null pointer");
+    const int S = vx_in_split(BC, V);
+    hipLaunchKernelGGL(vx_in_bwd_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, part_ws, V, S);
+    hipLaunchKernelGGL(vx_in_bwd_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, m_ws, BC, V, S);
     hipLaunchKernelGGL(vx_in_bwd_apply_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, m_ws, act, dy, V);
     VX_LAUNCH_CHECK("vx_in_bwd");
     return 0;

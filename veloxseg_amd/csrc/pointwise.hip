@@ -30,17 +30,23 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
     float acc[COT];
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = bias ? bias[co0 + j] : 0.0f;
-    for (int ci = 0; ci < Cin; ci += 4) {
-        float xv[4];
+    constexpr int CIB = 16;                       // input channels fetched per batch: 16 independent loads in flight per thread
+    for (int ci = 0; ci < Cin; ci += CIB) {
+        float xv[CIB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = vx_pw_row(x, x2, C1, Cin, b, ci + u, V)[v];
+        for (int u = 0; u < CIB; ++u) xv[u] = (ci + u < Cin) ? vx_pw_row(x, x2, C1, Cin, b, ci + u, V)[v] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < COT; ++j) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + (long)(co0 + j) * Cin + ci);   // uniform -> s_load_dwordx4
-            acc[j] = fmaf(wv.x, xv[0], acc[j]);
-            acc[j] = fmaf(wv.y, xv[1], acc[j]);
-            acc[j] = fmaf(wv.z, xv[2], acc[j]);
-            acc[j] = fmaf(wv.w, xv[3], acc[j]);
+        for (int u4 = 0; u4 < CIB; u4 += 4) {
+            if (ci + u4 < Cin) {                  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < COT; ++j) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + (long)(co0 + j) * Cin + ci + u4);   // uniform -> s_load_dwordx4
+                    acc[j] = fmaf(wv.x, xv[u4 + 0], acc[j]);
+                    acc[j] = fmaf(wv.y, xv[u4 + 1], acc[j]);
+                    acc[j] = fmaf(wv.z, xv[u4 + 2], acc[j]);
+                    acc[j] = fmaf(wv.w, xv[u4 + 3], acc[j]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -58,16 +64,24 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < CIT; ++i) acc[i] = 0.0f;
     const float* __restrict__ dyb = dy + (long)b * Cout * V + v;
-    for (int co = 0; co < Cout; ++co) {
-        const float dv = dyb[(long)co * V];
-        const float* __restrict__ wr = w + (long)co * Cin + ci0;
+    constexpr int COB = 8;                        // output channels fetched per batch
+    for (int co0 = 0; co0 < Cout; co0 += COB) {
+        float dv[COB];
 #pragma unroll
-        for (int i = 0; i < CIT; i += 4) {
-            const float4 wv = *reinterpret_cast<const float4*>(wr + i);
-            acc[i] = fmaf(wv.x, dv, acc[i]);
-            acc[i + 1] = fmaf(wv.y, dv, acc[i + 1]);
-            acc[i + 2] = fmaf(wv.z, dv, acc[i + 2]);
-            acc[i + 3] = fmaf(wv.w, dv, acc[i + 3]);
+        for (int u = 0; u < COB; ++u) dv[u] = (co0 + u < Cout) ? dyb[(long)(co0 + u) * V] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < COB; ++u) {
+            if (co0 + u < Cout) {                 // wave-uniform
+                const float* __restrict__ wr = w + (long)(co0 + u) * Cin + ci0;
+#pragma unroll
+                for (int i = 0; i < CIT; i += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wr + i);
+                    acc[i] = fmaf(wv.x, dv[u], acc[i]);
+                    acc[i + 1] = fmaf(wv.y, dv[u], acc[i + 1]);
+                    acc[i + 2] = fmaf(wv.z, dv[u], acc[i + 2]);
+                    acc[i + 3] = fmaf(wv.w, dv[u], acc[i + 3]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -139,7 +153,8 @@ extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const flo
     if (C1 <= 0 || C1 > Cin) C1 = Cin;
     VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_fwd: x2 missing");
     VX_REQUIRE(C1 % 4 == 0, "vx_pw_conv_fwd: concat split must be a multiple of 4");
-    const int T = (Cout % 16 == 0) ? 16 : (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
+    int T = (Cout % 16 == 0) ? 16 : (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
+    while (T > 1 && (long)vx_cdiv(V, 256) * (Cout / T) * B < 512) T >>= 1;     // small volumes: trade register blocking for more blocks
     dim3 grid(vx_cdiv(V, 256), Cout / T, B);
     hipStream_t st = (hipStream_t)stream;
     switch (T) {
@@ -161,6 +176,7 @@ extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, f
     VX_REQUIRE(C1 == Cin || dx2, "vx_pw_conv_bwd_data: dx2 missing");
     int T = (Cin % 16 == 0) ? 16 : (Cin % 8 == 0) ? 8 : 4;
     while (T > 4 && (C1 % T)) T >>= 1;
+    while (T > 4 && (long)vx_cdiv(V, 256) * (Cin / T) * B < 512) T >>= 1;
     VX_REQUIRE(C1 % T == 0, "vx_pw_conv_bwd_data: concat split must be a multiple of 4");
     dim3 grid(vx_cdiv(V, 256), Cin / T, B);
     hipStream_t st = (hipStream_t)stream;
@@ -189,5 +205,191 @@ extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, co
     dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), mt * nt);
     vx_pw_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, x2, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);
     VX_LAUNCH_CHECK("vx_pw_conv_bwd_weight");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k=2, s=2): every output voxel has exactly one (input voxel, tap) -> a pointwise conv to 8*Co channels
+// with a depth-to-space store.  One thread = one INPUT voxel x COT output channels x 8 taps.
+// ------------------------------------------------------------------------------------------------------------------
+template <int COT>
+__global__ void __launch_bounds__(256) vx_upconv_fwd_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int Ci, int Co, int d, int h, int wd) {
+    const long Vi = (long)d * h * wd;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, b = blockIdx.z;
+    if (v >= Vi) return;
+    float acc[COT][8];
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[j][t] = bias ? bias[co0 + j] : 0.0f;
+    const float* __restrict__ xb = x + (long)b * Ci * Vi + v;
+    constexpr int CIB = 8;
+    for (int ci = 0; ci < Ci; ci += CIB) {
+        float xv[CIB];
+#pragma unroll
+        for (int u = 0; u < CIB; ++u) xv[u] = (ci + u < Ci) ? xb[(long)(ci + u) * Vi] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < CIB; ++u) {
+            if (ci + u < Ci) {
+#pragma unroll
+                for (int j = 0; j < COT; ++j) {
+                    const float* wp = w + ((long)(ci + u) * Co + co0 + j) * 8;      // uniform -> 2 x s_load_dwordx4
+                    const float4 w0 = *reinterpret_cast<const float4*>(wp);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
+                    acc[j][0] = fmaf(w0.x, xv[u], acc[j][0]); acc[j][1] = fmaf(w0.y, xv[u], acc[j][1]);
+                    acc[j][2] = fmaf(w0.z, xv[u], acc[j][2]); acc[j][3] = fmaf(w0.w, xv[u], acc[j][3]);
+                    acc[j][4] = fmaf(w1.x, xv[u], acc[j][4]); acc[j][5] = fmaf(w1.y, xv[u], acc[j][5]);
+                    acc[j][6] = fmaf(w1.z, xv[u], acc[j][6]); acc[j][7] = fmaf(w1.w, xv[u], acc[j][7]);
+                }
+            }
+        }
+    }
+    const int xw = (int)(v % wd), xh = (int)((v / wd) % h), xd = (int)(v / ((long)wd * h));
+    const int H2 = 2 * h, W2 = 2 * wd;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        float* __restrict__ yb = y + (((long)b * Co + co0 + j) * (2 * d)) * (long)H2 * W2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float2* dst = reinterpret_cast<float2*>(yb + ((long)(2 * xd + i) * H2 + (2 * xh + k)) * W2 + 2 * xw);
+                *dst = make_float2(acc[j][(i * 2 + k) * 2], acc[j][(i * 2 + k) * 2 + 1]);
+            }
+    }
+}
+
+template <int CIT>
+__global__ void __launch_bounds__(256) vx_upconv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                            int Ci, int Co, int d, int h, int wd) {
+    const long Vi = (long)d * h * wd;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ci0 = blockIdx.y * CIT, b = blockIdx.z;
+    if (v >= Vi) return;
+    const int xw = (int)(v % wd), xh = (int)((v / wd) % h), xd = (int)(v / ((long)wd * h));
+    const int H2 = 2 * h, W2 = 2 * wd;
+    float acc[CIT];
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) acc[i] = 0.0f;
+    for (int co = 0; co < Co; ++co) {
+        const float* __restrict__ yb = dy + (((long)b * Co + co) * (2 * d)) * (long)H2 * W2;
+        float dv[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float2 t = *reinterpret_cast<const float2*>(yb + ((long)(2 * xd + i) * H2 + (2 * xh + k)) * W2 + 2 * xw);
+                dv[(i * 2 + k) * 2] = t.x;
+                dv[(i * 2 + k) * 2 + 1] = t.y;
+            }
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const float* wp = w + ((long)(ci0 + i) * Co + co) * 8;
+            const float4 w0 = *reinterpret_cast<const float4*>(wp);
+            const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
+            float s = acc[i];
+            s = fmaf(w0.x, dv[0], s); s = fmaf(w0.y, dv[1], s); s = fmaf(w0.z, dv[2], s); s = fmaf(w0.w, dv[3], s);
+            s = fmaf(w1.x, dv[4], s); s = fmaf(w1.y, dv[5], s); s = fmaf(w1.z, dv[6], s); s = fmaf(w1.w, dv[7], s);
+            acc[i] = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) dx[((long)b * Ci + ci0 + i) * Vi + v] = acc[i];
+}
+
+extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
+    VX_REQUIRE(x && w && y && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_fwd: bad args");
+    const int T = (Co % 8 == 0) ? 8 : (Co % 4 == 0) ? 4 : (Co % 2 == 0) ? 2 : 1;
+    dim3 grid(vx_cdiv((long)d * h * wd, 256), Co / T, B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (T) {
+        case 8: vx_upconv_fwd_k<8><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        case 4: vx_upconv_fwd_k<4><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        case 2: vx_upconv_fwd_k<2><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        default: vx_upconv_fwd_k<1><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+    }
+    VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
+    return 0;
+}
+
+extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
+    VX_REQUIRE(dy && w && dx && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_bwd_data: bad args");
+    const int T = (Ci % 8 == 0) ? 8 : (Ci % 4 == 0) ? 4 : (Ci % 2 == 0) ? 2 : 1;
+    dim3 grid(vx_cdiv((long)d * h * wd, 256), Ci / T, B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (T) {
+        case 8: vx_upconv_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        case 4: vx_upconv_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        case 2: vx_upconv_bwd_data_k<2><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        default: vx_upconv_bwd_data_k<1><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+    }
+    VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small-volume 1x1 convolution as an fp32-MFMA GEMM (levels 2-4: V <= 4096 voxels, 32..384 channels): the thread-per-voxel
+// kernels above are latency-bound there (one wave = 64 voxels walks the whole channel axis serially).  Here one wave owns a
+// 16 (out channels) x 16 (voxels) tile and walks the reduction axis with v_mfma_f32_16x16x4_f32, operands straight from global.
+//   dst[b, m, v] = bias[m] + sum_k Wt(m,k) * src[b, k, v],   Wt(m,k) = w[m*wsm + k*wsk]
+//   forward: m = co, k = ci, wsm = Cin, wsk = 1;   input gradient: m = ci, k = co, wsm = 1, wsk = Cin.
+// src (forward) or dst (input gradient) may be the channel concat of two tensors.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
+                                                    const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
+                                                    float* __restrict__ dst, float* __restrict__ dst2, int D1,
+                                                    int Mch, int Kch, long V, int B, int n_vt, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long tile = (long)blockIdx.x * 4 + wave;           // over (b, voxel tile)
+    if (tile >= (long)B * n_vt) return;
+    const int b = (int)(tile / n_vt);
+    const long v0 = (tile % n_vt) * 16;
+    const int mt = blockIdx.y;
+    const int r = lane & 15, q = lane >> 4;
+    const int m_a = mt * 16 + r;                              // A row owned by this lane
+    const bool m_ok = m_a < Mch;
+    const long v_b = v0 + r;                                  // B column owned by this lane
+    const bool v_ok = v_b < V;
+    vx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ wrow = w + (long)(m_ok ? m_a : 0) * wsm;
+    for (int k0 = 0; k0 < Kch; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * s + q;
+            const bool k_ok = k < Kch;
+            av[s] = (m_ok && k_ok) ? wrow[(long)k * wsk] : 0.0f;
+            const float* srow = (k < S1) ? src + ((long)b * S1 + k) * V : src2 + ((long)b * (Kch - S1) + (k - S1)) * V;
+            bv[s] = (v_ok && k_ok) ? srow[v_b] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+    if (!v_ok) return;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int m = mt * 16 + 4 * q + reg;
+        if (m < Mch) {
+            float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
+            const float o = acc[reg] + (bias ? bias[m] : 0.0f);
+            drow[v_b] = accumulate ? drow[v_b] + o : o;
+        }
+    }
+}
+
+extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
+                               float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream) {
+    VX_REQUIRE(src && w && dst && B > 0 && Mch > 0 && Kch > 0 && V > 0, "vx_pw_conv_mfma: bad args");
+    if (S1 <= 0 || S1 > Kch) S1 = Kch;
+    if (D1 <= 0 || D1 > Mch) D1 = Mch;
+    VX_REQUIRE((S1 == Kch || src2) && (D1 == Mch || dst2), "vx_pw_conv_mfma: second tensor of a concat is missing");
+    const int n_vt = vx_cdiv(V, 16);
+    const int wsm = transpose_w ? 1 : Cin_of_w, wsk = transpose_w ? Cin_of_w : 1;
+    dim3 grid(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
+    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate);
+    VX_LAUNCH_CHECK("vx_pw_conv_mfma");
     return 0;
 }

@@ -112,50 +112,46 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restr
     out[((long)b * (P.nb * P.heads * c) + ch) * V + v] = val;
 }
 
-// adjoint: one thread per token element; loops over the output voxels of its window it contributes to
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M) {
-    const int b = blockIdx.z, a = blockIdx.y;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;          // over (N, t, cc)
-    if (e >= (long)P.Ntot * P.l * c) return;
-    const int cc = (int)(e % c);
-    const int t = (int)((e / c) % P.l);
-    const int N = (int)(e / ((long)c * P.l));
+// adjoint of the scatter: one block = (b, head, window, voxel chunk); the window's l x c token gradients are accumulated in LDS
+// (ds_add_f32) from the block's output voxels (8 corners each), then flushed with one float atomic per token element.
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int max_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c]
+    const int b = blockIdx.z / P.heads, a = blockIdx.z % P.heads;
+    const int N = blockIdx.y;
     const int i = vx_scale_of_window(P, N);
+    const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
+    const int nv = bw0 * bw1 * bw2;
+    const int items = nv * c;
+    int chunks = (items + 4095) / 4096;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if ((int)blockIdx.x >= chunks) return;
+    for (int k = threadIdx.x; k < P.l * c; k += 256) vx_sacc[k] = 0.0f;
+    __syncthreads();
     const int Nl = N - P.woff[i];
     const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
-    const int t2 = t % P.n[2], t1 = (t / P.n[2]) % P.n[1], t0 = t / (P.n[2] * P.n[1]);
-    const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
-    const int ch = (i * P.heads + a) * c + cc;
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
-    const float* __restrict__ dc = dout + ((long)b * (P.nb * P.heads * c) + ch) * V;
-    // support of token coordinate tk along an axis: output positions j whose i0 or i1 equals tk
-    auto range = [](int tk, int n, int bw, int& lo, int& hi) {
-        lo = bw; hi = -1;
-        for (int j = 0; j < bw; ++j) {
-            int i0, i1; float lam;
-            vx_src_coord(j, n, bw, i0, i1, lam);
-            if (i0 == tk || i1 == tk) { if (j < lo) lo = j; if (j > hi) hi = j; }
-        }
-    };
-    auto weight = [](int j, int tk, int n, int bw) {
-        int i0, i1; float lam;
-        vx_src_coord(j, n, bw, i0, i1, lam);
-        return (i0 == tk ? 1.0f - lam : 0.0f) + (i1 == tk ? lam : 0.0f);
-    };
-    int lo0, hi0, lo1, hi1, lo2, hi2;
-    range(t0, P.n[0], bw0, lo0, hi0);
-    range(t1, P.n[1], bw1, lo1, hi1);
-    range(t2, P.n[2], bw2, lo2, hi2);
-    float acc = 0.0f;
-    for (int j0 = lo0; j0 <= hi0; ++j0) {
-        const float w0 = weight(j0, t0, P.n[0], bw0);
-        for (int j1 = lo1; j1 <= hi1; ++j1) {
-            const float w01 = w0 * weight(j1, t1, P.n[1], bw1);
-            const long row = ((long)(W0 * bw0 + j0) * P.grid[1] + (W1 * bw1 + j1)) * P.grid[2] + W2 * bw2;
-            for (int j2 = lo2; j2 <= hi2; ++j2) acc = fmaf(w01 * weight(j2, t2, P.n[2], bw2), dc[row + j2], acc);
-        }
+    const int chbase = (i * P.heads + a) * c;
+    const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + chbase) * V;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < items; e += chunks * 256) {
+        const int vox = e % nv, cc = e / nv;
+        const int j2 = vox % bw2, j1 = (vox / bw2) % bw1, j0 = vox / (bw2 * bw1);
+        int a0, b0, a1, b1, a2, b2;
+        float l0, l1, l2;
+        vx_src_coord(j0, P.n[0], bw0, a0, b0, l0);
+        vx_src_coord(j1, P.n[1], bw1, a1, b1, l1);
+        vx_src_coord(j2, P.n[2], bw2, a2, b2, l2);
+        const float g = db[(long)cc * V + ((long)(W0 * bw0 + j0) * P.grid[1] + (W1 * bw1 + j1)) * P.grid[2] + (W2 * bw2 + j2)];
+        const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
+        auto A = [&](int t0, int t1, int t2, float wt) { if (wt != 0.0f) atomicAdd(&vx_sacc[((t0 * P.n[1] + t1) * P.n[2] + t2) * c + cc], wt * g); };
+        A(a0, a1, a2, k0 * k1 * k2); A(a0, a1, b2, k0 * k1 * l2); A(a0, b1, a2, k0 * l1 * k2); A(a0, b1, b2, k0 * l1 * l2);
+        A(b0, a1, a2, l0 * k1 * k2); A(b0, a1, b2, l0 * k1 * l2); A(b0, b1, a2, l0 * l1 * k2); A(b0, b1, b2, l0 * l1 * l2);
     }
-    dtok[((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc] = acc;
+    __syncthreads();
+    float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l) * c;
+    for (int k = threadIdx.x; k < P.l * c; k += 256) {
+        const float sacc = vx_sacc[k];
+        if (sacc != 0.0f) atomicAdd(dt + k, sacc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,15 +174,21 @@ __device__ __forceinline__ int vx_lin_of_token(const VxAttn& A, int T) {
     return (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
 }
 
-// unit = (bh, window, 64-query chunk); one wave per unit, 4 units per block
+// unit = (bh, window, 64-query chunk); one wave per unit, 4 units per block.  Keys/values are staged 64 rows at a time
+// into a per-wave LDS slab (coalesced global read, one row per lane) and consumed as broadcast ds_read_b128.
+#define VX_KV_ROWS 64
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                          const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
                                                          VxAttn A, VxDrop drop) {
+    constexpr int RS = CQ + CV;
+    __shared__ __attribute__((aligned(16))) float kvs[4][VX_KV_ROWS * RS];
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    const long u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long u = (long)blockIdx.x * 4 + wave;
     if (u >= units) return;
+    float* __restrict__ slab = kvs[wave];
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;                       // (bh*Nt + N)
@@ -206,19 +208,31 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = ((uint64_t)win * A.ML + iq) * (uint64_t)A.ML;
-    for (int j = 0; j < A.ML; ++j) {
-        float s = 0.0f;
+    for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
+        const int nk = min(VX_KV_ROWS, A.ML - j0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nk) {
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kp[(long)j * CQ + c], s);
-        s += table[(long)(lin_i - vx_lin_of_token(A, j)) * A.heads + a];
-        const float mn = fmaxf(mrun, s);
-        const float alpha = expf(mrun - mn);
-        const float p = expf(s - mn);
-        lsum = lsum * alpha + p;
-        const float pd = p * vx_drop(drop, drow + j);
+            for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = kp[(long)(j0 + lane) * CQ + c];
 #pragma unroll
-        for (int c = 0; c < CV; ++c) acc[c] = fmaf(pd, vp[(long)j * CV + c], acc[c] * alpha);
-        mrun = mn;
+            for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int jj = 0; jj < nk; ++jj) {
+            const float* __restrict__ row = slab + jj * RS;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) s = fmaf(q[c], row[c], s);
+            s += table[(long)(lin_i - vx_lin_of_token(A, j0 + jj)) * A.heads + a];
+            const float mn = fmaxf(mrun, s);
+            const float alpha = expf(mrun - mn);
+            const float p = expf(s - mn);
+            lsum = lsum * alpha + p;
+            const float pd = p * vx_drop(drop, drow + j0 + jj);
+#pragma unroll
+            for (int c = 0; c < CV; ++c) acc[c] = fmaf(pd, row[CQ + c], acc[c] * alpha);
+            mrun = mn;
+        }
     }
     if (ok) {
         const float inv = 1.0f / lsum;
@@ -235,14 +249,17 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
                                                            float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop) {
-    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // [4][Tsz] private bias-gradient tables
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int RS = CQ + CV;
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // [4][Tsz] private bias-gradient tables, then [4][64*RS] K/V slabs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
     float* __restrict__ stab = vx_sm + (long)wave * Tsz;
+    float* __restrict__ slab = vx_sm + (long)4 * Tsz + (long)wave * VX_KV_ROWS * RS;
     for (int k = lane; k < Tsz; k += 64) stab[k] = 0.0f;
     __syncthreads();
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    const long u_raw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    const long u_raw = (long)blockIdx.x * 4 + wave;
     const bool active = u_raw < units;
     const long u = active ? u_raw : units - 1;
     const int chunk = (int)(u % chunks);
@@ -263,21 +280,33 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
-    for (int j = 0; j < A.ML; ++j) {
-        float s = 0.0f;
+    for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
+        const int nk = min(VX_KV_ROWS, A.ML - j0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nk) {
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kp[(long)j * CQ + c], s);
-        const int bi = lin_i - vx_lin_of_token(A, j);
-        s += table[(long)bi * A.heads + a];
-        const float p = expf(s - lse);
-        float dp = 0.0f;
+            for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = kp[(long)(j0 + lane) * CQ + c];
 #pragma unroll
-        for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], vp[(long)j * CV + c], dp);
-        dp *= vx_drop(drop, drow + j);
-        const float ds = ok ? p * (dp - delta) : 0.0f;
+            for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int jj = 0; jj < nk; ++jj) {
+            const float* __restrict__ kr = slab + jj * RS;
+            float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kp[(long)j * CQ + c], dq[c]);
-        atomicAdd(stab + bi, ds);
+            for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
+            const int bi = lin_i - vx_lin_of_token(A, j0 + jj);
+            s += table[(long)bi * A.heads + a];
+            const float p = expf(s - lse);
+            float dp = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
+            dp *= vx_drop(drop, drow + j0 + jj);
+            const float ds = ok ? p * (dp - delta) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
+            atomicAdd(stab + bi, ds);
+        }
     }
     if (ok) {
 #pragma unroll
@@ -291,16 +320,20 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     }
 }
 
-// backward B: lane = key row.  dK, dV
+// backward B: lane = key row.  dK, dV.  Query-side rows (q, dO, lse, delta) are staged per wave in LDS.
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
                                                             VxAttn A, VxDrop drop) {
+    constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
+    __shared__ __attribute__((aligned(16))) float qs[4][VX_KV_ROWS * RS];
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    const long u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long u = (long)blockIdx.x * 4 + wave;
     if (u >= units) return;
+    float* __restrict__ slab = qs[wave];
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;
@@ -317,22 +350,37 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     const int lin_j = vx_lin_of_token(A, jk) - A.lin_cst;
     const float* __restrict__ qp = Q + win * A.ML * CQ;
     const float* __restrict__ dop = dO + win * A.ML * CV;
-    for (int i = 0; i < A.ML; ++i) {
-        float s = 0.0f;
+    for (int i0 = 0; i0 < A.ML; i0 += VX_KV_ROWS) {
+        const int nq = min(VX_KV_ROWS, A.ML - i0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nq) {
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) s = fmaf(qp[(long)i * CQ + c], k[c], s);
-        s = s * A.scale + table[(long)(vx_lin_of_token(A, i) - lin_j) * A.heads + a];
-        const float p = expf(s - LSE[win * A.ML + i]);
-        const float msk = vx_drop(drop, ((uint64_t)(win * A.ML + i)) * (uint64_t)A.ML + jk);
-        float dp = 0.0f;
+            for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = qp[(long)(i0 + lane) * CQ + c];
 #pragma unroll
-        for (int c = 0; c < CV; ++c) dp = fmaf(dop[(long)i * CV + c], v[c], dp);
-        const float pd = p * msk;
+            for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = dop[(long)(i0 + lane) * CV + c];
+            slab[lane * RS + CQ + CV] = LSE[win * A.ML + i0 + lane];
+            slab[lane * RS + CQ + CV + 1] = Delta[win * A.ML + i0 + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int ii = 0; ii < nq; ++ii) {
+            const float* __restrict__ qr = slab + ii * RS;
+            const int i = i0 + ii;
+            float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CV; ++c) dv[c] = fmaf(pd, dop[(long)i * CV + c], dv[c]);
-        const float ds = p * (dp * msk - Delta[win * A.ML + i]) * A.scale;
+            for (int c = 0; c < CQ; ++c) s = fmaf(qr[c], k[c], s);
+            s = s * A.scale + table[(long)(vx_lin_of_token(A, i) - lin_j) * A.heads + a];
+            const float p = expf(s - qr[CQ + CV]);
+            const float msk = vx_drop(drop, ((uint64_t)(win * A.ML + i)) * (uint64_t)A.ML + jk);
+            float dp = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) dk[c] = fmaf(ds, qp[(long)i * CQ + c], dk[c]);
+            for (int c = 0; c < CV; ++c) dp = fmaf(qr[CQ + c], v[c], dp);
+            const float pd = p * msk;
+#pragma unroll
+            for (int c = 0; c < CV; ++c) dv[c] = fmaf(pd, qr[CQ + c], dv[c]);
+            const float ds = p * (dp * msk - qr[CQ + CV + 1]) * A.scale;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) dk[c] = fmaf(ds, qr[c], dk[c]);
+        }
     }
     if (ok) {
 #pragma unroll
@@ -345,6 +393,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+static inline int plane_l(const VxPwaPlan* P) { return P->l; }
 static int vx_plan_check(const VxPwaPlan* P, const char* who) {
     if (!P) VX_FAIL(-1, "%s: null plan", who);
     if (P->nb < 1 || P->nb > 4 || P->heads < 1 || P->l != P->n[0] * P->n[1] * P->n[2]) VX_FAIL(-1, "%s: bad plan (nb=%d heads=%d l=%d)", who, P->nb, P->heads, P->l);
@@ -385,8 +434,14 @@ extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan*
 extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
     VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
-    const long E = (long)plan->Ntot * plan->l * c;
-    hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(vx_cdiv(E, 256), plan->heads, B), dim3(256), 0, (hipStream_t)stream, dout, dtok, *plan, c, m, M);
+    const size_t shm = sizeof(float) * (size_t)plane_l(plan) * c;
+    VX_REQUIRE(shm <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
+    const int last = plan->nb - 1;
+    const long nv_max = (long)plan->n[0] * plan->small[last][0] * plan->n[1] * plan->small[last][1] * plan->n[2] * plan->small[last][2];
+    int max_chunks = (int)((nv_max * c + 4095) / 4096);
+    if (max_chunks > 64) max_chunks = 64;
+    if (max_chunks < 1) max_chunks = 1;
+    hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(max_chunks, plan->Ntot, B * plan->heads), dim3(256), shm, (hipStream_t)stream, dout, dtok, *plan, c, m, M, max_chunks);
     VX_LAUNCH_CHECK("vx_pwa_scatter_bwd");
     return 0;
 }
@@ -436,7 +491,7 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     VX_REQUIRE(Q && K && V && table && O && LSE && dO && dQ && dK && dV && dtable && delta_ws, "vx_pwa_attn_bwd: null pointer");
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
-    const size_t shm = (size_t)4 * Tsz * sizeof(float);
+    const size_t shm = ((size_t)4 * Tsz + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {

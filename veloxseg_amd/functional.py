@@ -19,6 +19,7 @@ from . import _hip as H
 
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
+PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -89,7 +90,9 @@ class _Conv3dFn(torch.autograd.Function):
         pw = (K == 1 and S == 1 and P == 0 and G == 1 and ps == 1 and Cin % 4 == 0 and C1 % 4 == 0)
         s1 = (x2 is None and S == 1 and K in (3, 5) and P == K // 2 and (Cout // G) % 4 == 0 and (Cin // G) % 4 == 0 and USE_S1)
         ctx.s1 = s1
-        if pw:
+        if pw and D * Hh * W <= PW_MFMA_MAX_V:
+            H.call("vx_pw_conv_mfma", H.P(x), H.P(x2), C1, H.P(w), 0, H.P(b), H.P(y), None, 0, B, Cout, Cin, Cin, D * Hh * W, 0, H.stream_ptr())
+        elif pw:
             H.call("vx_pw_conv_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, Cout, D * Hh * W, H.stream_ptr())
         elif s1:
             H.call("vx_conv_s1", H.P(x), H.P(w), H.P(b), H.P(y), B, Cin, Cout, D, Hh, W, K, G, 0, 1, ps, 0, H.stream_ptr())
@@ -113,7 +116,9 @@ class _Conv3dFn(torch.autograd.Function):
         if need_x:
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            if ctx.pw:
+            if ctx.pw and D * Hh * W <= PW_MFMA_MAX_V:
+                H.call("vx_pw_conv_mfma", H.P(dy), None, 0, H.P(w), 1, None, H.P(dx), H.P(dx2), C1, B, Cin, Cout, Cin, D * Hh * W, 0, st)
+            elif ctx.pw:
                 H.call("vx_pw_conv_bwd_data", H.P(dy), H.P(w), H.P(dx), H.P(dx2), C1, B, Cin, Cout, D * Hh * W, 0, st)
             elif ctx.s1:
                 H.call("vx_conv_s1", H.P(dy), H.P(w), None, H.P(dx), B, Cout, Cin, D, Hh, W, K, G, 1, ps, 1, 0, st)
@@ -144,7 +149,7 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
         Co = w.shape[1]
         assert w.shape[0] == Ci and tuple(w.shape[2:]) == (2, 2, 2)
         y = torch.empty((B, Co, 2 * d, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
-        H.call("vx_conv3d_bwd_data", H.P(x), H.P(w), H.P(b), H.P(y), None, 0, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, 0, H.stream_ptr())
+        H.call("vx_upconv_k2s2_fwd", H.P(x), H.P(w), H.P(b), H.P(y), B, Ci, Co, d, h, wd, H.stream_ptr())
         ctx.save_for_backward(x)
         ctx.w, ctx.b = w, b
         return y
@@ -160,7 +165,7 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            H.call("vx_conv3d_fwd", H.P(dy), None, 0, H.P(w), None, H.P(dx), B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
+            H.call("vx_upconv_k2s2_bwd_data", H.P(dy), H.P(w), H.P(dx), B, Ci, Co, d, h, wd, st)
         if w.requires_grad:
             H.call(WGRAD_ENTRY, H.P(dy), None, 0, H.P(x), H.P(grad_buf(w)), None, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, st)
         if b is not None and b.requires_grad:
@@ -187,7 +192,8 @@ class _InstNormSumFn(torch.autograd.Function):
         st = H.stream_ptr()
         stats = [torch.empty((B * C * 2,), device=ys[0].device, dtype=torch.float32) for _ in ys]
         for y, s in zip(ys, stats):
-            H.call("vx_in_stats", H.P(y), H.P(s), B * C, V, IN_EPS, st)
+            part = torch.empty((B * C * 32,), device=y.device, dtype=torch.float64)
+            H.call("vx_in_stats", H.P(y), H.P(s), H.P(part, torch.float64), B * C, V, IN_EPS, st)
         out = torch.empty_like(ys[0])
         res_c = _c(res) if res is not None else None
         pp = [H.P(y) for y in ys] + [None] * (3 - n)
@@ -210,7 +216,8 @@ class _InstNormSumFn(torch.autograd.Function):
             if ctx.needs_input_grad[2 + k]:
                 dy = torch.empty_like(ys[k])
                 ws = torch.empty((B * C * 2,), device=dout.device, dtype=torch.float32)
-                H.call("vx_in_bwd", H.P(dout), H.P(ys[k]), H.P(stats[k]), ctx.act, H.P(ws), H.P(dy), B * C, V, st)
+                part = torch.empty((B * C * 32,), device=dout.device, dtype=torch.float64)
+                H.call("vx_in_bwd", H.P(dout), H.P(ys[k]), H.P(stats[k]), ctx.act, H.P(ws), H.P(part, torch.float64), H.P(dy), B * C, V, st)
                 grads.append(dy)
             else:
                 grads.append(None)
@@ -408,7 +415,7 @@ class _PwaCoreFn(torch.autograd.Function):
         dev = tq.device
         st = H.stream_ptr()
         pp = H.ctypes.addressof(plan)
-        dO = torch.empty_like(O)
+        dO = torch.zeros_like(O)
         for m in range(M):
             H.call("vx_pwa_scatter_bwd", H.P(_c(douts[m])), H.P(dO), pp, cv, m, M, B, st)
         dq, dk, dv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
@@ -452,7 +459,8 @@ class _UpsampleFn(torch.autograd.Function):
         B, C, d, h, w, D, Hh, W = ctx.shape
         g = _c(g)
         dx = torch.empty((B, C, d, h, w), device=g.device, dtype=torch.float32)
-        H.call("vx_upsample_trilinear_bwd", H.P(g), H.P(dx), B * C, d, h, w, D, Hh, W, H.stream_ptr())
+        ws = torch.empty((B * C * d * (Hh * W + h * W),), device=g.device, dtype=torch.float32)
+        H.call("vx_upsample_trilinear_bwd", H.P(g), H.P(dx), H.P(ws), B * C, d, h, w, D, Hh, W, H.stream_ptr())
         return dx, None
 
 
