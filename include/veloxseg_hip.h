@@ -113,6 +113,12 @@ typedef struct VxPwaPlan {
 /* window_gathering_3d (PWA.py:106-140) of modality m into tok[B, heads, Ntot, M*l, c]; bwd routes to the first arg-max */
 int vx_pwa_gather_fwd(const float* src, float* tok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
 int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsrc, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
+/* the same gather for ALL 3*M tensors (q0,k0,v0,q1,...) in ONE launch; the arg-max voxel of every pooled cell is saved (int32, token layout) and
+ * drives the backward pass (srcs / dsrcs: host arrays of 3*M device pointers) */
+int vx_pwa_gather_all_fwd(const float* const* srcs, float* tq, float* tk, float* tv, int* iq, int* ik, int* iv,
+                          const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream);
+int vx_pwa_gather_all_bwd(const float* dtq, const float* dtk, const float* dtv, const int* iq, const int* ik, const int* iv, float* const* dsrcs,
+                          const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream);
 /* window_scattering_3d (PWA.py:177-200): per-window trilinear, align_corners=True */
 int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
 int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);   /* dtok += (caller zeroes it once for all modalities) */

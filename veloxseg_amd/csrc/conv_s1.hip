@@ -20,6 +20,7 @@ struct VxS1 {
     int in_ps, out_ps;        // pixel-shuffle factor of the input / output STORAGE (1 = plain NCDHW)
     int accumulate;           // y += result
     int cic;                  // input channels staged per pass
+    int st_hw, st_hh, st_hd, st_c;   // 256 decomposed in the staging index space (hw fastest): per-thread incremental addressing
 };
 
 __device__ __forceinline__ long vx_ps_index(int C, int D, int H, int W, int ps, int b, int c, int d, int h, int w) {
@@ -64,17 +65,36 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
     for (int cc = 0; cc < Cin_g; cc += p.cic) {
         const int ncc = min(p.cic, Cin_g - cc);
         __syncthreads();
-        // stage the halo of `ncc` input channels
-        for (int e = tid; e < ncc * plane; e += 256) {
-            int cil, r;
-            if (p.in_ps > 1) { cil = e % ncc; r = e / ncc; }      // pixel-shuffled source: consecutive channels are consecutive in memory
-            else { cil = e / plane; r = e % plane; }
-            const int hw = r % p.HWp, hh = (r / p.HWp) % p.HH, hd = r / (p.HWp * p.HH);
-            const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
-            float v = 0.0f;
-            if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                v = x[vx_ps_index(p.Cin, p.D, p.H, p.W, p.in_ps, b, g * Cin_g + cc + cil, id, ih, iw)];
-            xs[cil * plane + r] = v;
+        // stage the halo of `ncc` input channels: element index e = ((cil*HD + hd)*HH + hh)*HWp + hw, e = tid, tid+256, ...
+        // (hd,hh,hw,cil) advance incrementally by the host-decomposed stride: no integer division in the loop.
+        if (p.in_ps == 1) {
+            int hw = tid % p.HWp, t1 = tid / p.HWp;
+            int hh = t1 % p.HH, t2 = t1 / p.HH;
+            int hd = t2 % p.HD, cil = t2 / p.HD;
+            const long chan_stride = (long)p.D * p.H * p.W;
+            const float* __restrict__ xb = x + ((long)b * p.Cin + g * Cin_g + cc) * chan_stride;
+            for (int e = tid; e < ncc * plane; e += 256) {
+                const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
+                float v = 0.0f;
+                if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    v = xb[cil * chan_stride + ((long)id * p.H + ih) * p.W + iw];
+                xs[e] = v;
+                hw += p.st_hw; if (hw >= p.HWp) { hw -= p.HWp; ++hh; }
+                hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
+                hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++cil; }
+                cil += p.st_c;
+            }
+        } else {
+            // pixel-shuffled source: channel fastest (4 consecutive channels = 16 contiguous bytes)
+            for (int e = tid; e < ncc * plane; e += 256) {
+                const int cil = e % ncc, r = e / ncc;
+                const int hw = r % p.HWp, hh = (r / p.HWp) % p.HH, hd = r / (p.HWp * p.HH);
+                const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
+                float v = 0.0f;
+                if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    v = x[vx_ps_index(p.Cin, p.D, p.H, p.W, p.in_ps, b, g * Cin_g + cc + cil, id, ih, iw)];
+                xs[cil * plane + r] = v;
+            }
         }
         // stage the weight slice [ncc][K3][COT]
         for (int e = tid; e < ncc * K3 * COT; e += 256) {
@@ -176,6 +196,13 @@ extern "C" int vx_conv_s1(const float* x, const float* w, const float* bias, flo
     while (cic > 1 && lds_bytes(cic) > 48 * 1024) cic >>= 1;
     VX_REQUIRE(lds_bytes(cic) <= 150 * 1024, "vx_conv_s1: tile does not fit LDS");
     p.cic = cic;
+    {   // 256 = ((st_c*HD + st_hd)*HH + st_hh)*HWp + st_hw
+        int r = 256;
+        p.st_hw = r % p.HWp; r /= p.HWp;
+        p.st_hh = r % p.HH; r /= p.HH;
+        p.st_hd = r % p.HD; r /= p.HD;
+        p.st_c = r;
+    }
     dim3 grid(p.nTd * p.nTh * p.nTw, Cout / COT, B);
     hipStream_t st = (hipStream_t)stream;
     const size_t shm = lds_bytes(cic);

@@ -299,36 +299,6 @@ __global__ void __launch_bounds__(256) vx_upconv_bwd_data_k(const float* __restr
     for (int i = 0; i < CIT; ++i) dx[((long)b * Ci + ci0 + i) * Vi + v] = acc[i];
 }
 
-extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
-    VX_REQUIRE(x && w && y && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_fwd: bad args");
-    const int T = (Co % 8 == 0) ? 8 : (Co % 4 == 0) ? 4 : (Co % 2 == 0) ? 2 : 1;
-    dim3 grid(vx_cdiv((long)d * h * wd, 256), Co / T, B);
-    hipStream_t st = (hipStream_t)stream;
-    switch (T) {
-        case 8: vx_upconv_fwd_k<8><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
-        case 4: vx_upconv_fwd_k<4><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
-        case 2: vx_upconv_fwd_k<2><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
-        default: vx_upconv_fwd_k<1><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
-    }
-    VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
-    return 0;
-}
-
-extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
-    VX_REQUIRE(dy && w && dx && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_bwd_data: bad args");
-    const int T = (Ci % 8 == 0) ? 8 : (Ci % 4 == 0) ? 4 : (Ci % 2 == 0) ? 2 : 1;
-    dim3 grid(vx_cdiv((long)d * h * wd, 256), Ci / T, B);
-    hipStream_t st = (hipStream_t)stream;
-    switch (T) {
-        case 8: vx_upconv_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
-        case 4: vx_upconv_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
-        case 2: vx_upconv_bwd_data_k<2><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
-        default: vx_upconv_bwd_data_k<1><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
-    }
-    VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Small-volume 1x1 convolution as an fp32-MFMA GEMM (levels 2-4: V <= 4096 voxels, 32..384 channels): the thread-per-voxel
 // kernels above are latency-bound there (one wave = 64 voxels walks the whole channel axis serially).  Here one wave owns a
@@ -340,7 +310,10 @@ extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* d
 __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
                                                     const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
                                                     float* __restrict__ dst, float* __restrict__ dst2, int D1,
-                                                    int Mch, int Kch, long V, int B, int n_vt, int accumulate) {
+                                                    int Mch, int Kch, long V, int B, int n_vt, int accumulate,
+                                                    int mode, int cd, int ch, int cw) {
+    // mode 0: plain.  mode 1 (ConvTranspose k2s2 forward): row m = co*8 + tap is stored depth-to-space into y[b][co][2d+i][2h+j][2w+k].
+    // mode 2 (ConvTranspose k2s2 input gradient): reduction row k = co*8 + tap is gathered space-to-depth from dy.  (cd,ch,cw) = coarse dims.
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long tile = (long)blockIdx.x * 4 + wave;           // over (b, voxel tile)
@@ -362,8 +335,18 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
             const int k = k0 + 4 * s + q;
             const bool k_ok = k < Kch;
             av[s] = (m_ok && k_ok) ? wrow[(long)k * wsk] : 0.0f;
-            const float* srow = (k < S1) ? src + ((long)b * S1 + k) * V : src2 + ((long)b * (Kch - S1) + (k - S1)) * V;
-            bv[s] = (v_ok && k_ok) ? srow[v_b] : 0.0f;
+            if (mode == 2) {
+                float t = 0.0f;
+                if (v_ok && k_ok) {
+                    const int co = k >> 3, tp = k & 7;
+                    const int xw = (int)(v_b % cw), xh = (int)((v_b / cw) % ch), xd = (int)(v_b / ((long)cw * ch));
+                    t = src[((((long)b * (Kch >> 3) + co) * (2 * cd) + 2 * xd + (tp >> 2)) * (2 * ch) + 2 * xh + ((tp >> 1) & 1)) * (long)(2 * cw) + 2 * xw + (tp & 1)];
+                }
+                bv[s] = t;
+            } else {
+                const float* srow = (k < S1) ? src + ((long)b * S1 + k) * V : src2 + ((long)b * (Kch - S1) + (k - S1)) * V;
+                bv[s] = (v_ok && k_ok) ? srow[v_b] : 0.0f;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
@@ -373,9 +356,16 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
     for (int reg = 0; reg < 4; ++reg) {
         const int m = mt * 16 + 4 * q + reg;
         if (m < Mch) {
-            float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
-            const float o = acc[reg] + (bias ? bias[m] : 0.0f);
-            drow[v_b] = accumulate ? drow[v_b] + o : o;
+            if (mode == 1) {
+                const int co = m >> 3, tp = m & 7;
+                const int xw = (int)(v_b % cw), xh = (int)((v_b / cw) % ch), xd = (int)(v_b / ((long)cw * ch));
+                dst[((((long)b * (Mch >> 3) + co) * (2 * cd) + 2 * xd + (tp >> 2)) * (2 * ch) + 2 * xh + ((tp >> 1) & 1)) * (long)(2 * cw) + 2 * xw + (tp & 1)] =
+                    acc[reg] + (bias ? bias[co] : 0.0f);
+            } else {
+                float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
+                const float o = acc[reg] + (bias ? bias[m] : 0.0f);
+                drow[v_b] = accumulate ? drow[v_b] + o : o;
+            }
         }
     }
 }
@@ -389,7 +379,54 @@ extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, cons
     const int n_vt = vx_cdiv(V, 16);
     const int wsm = transpose_w ? 1 : Cin_of_w, wsk = transpose_w ? Cin_of_w : 1;
     dim3 grid(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
-    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate);
+    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0);
     VX_LAUNCH_CHECK("vx_pw_conv_mfma");
     return 0;
 }
+
+extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
+    VX_REQUIRE(x && w && y && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long Vc = (long)d * h * wd;
+    if (Vc <= 4096) {   // coarse levels: MFMA tiles, rows m = co*8 + tap stored depth-to-space
+        const int n_vt = vx_cdiv(Vc, 16);
+        dim3 g2(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Co * 8, 16));
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(x, nullptr, Ci, w, 1, Co * 8, bias, y, nullptr, Co * 8, Co * 8, Ci, Vc, B, n_vt, 0, 1, d, h, wd);
+        VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
+        return 0;
+    }
+    const int T = (Co % 8 == 0) ? 8 : (Co % 4 == 0) ? 4 : (Co % 2 == 0) ? 2 : 1;
+    dim3 grid(vx_cdiv((long)d * h * wd, 256), Co / T, B);
+    switch (T) {
+        case 8: vx_upconv_fwd_k<8><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        case 4: vx_upconv_fwd_k<4><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        case 2: vx_upconv_fwd_k<2><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+        default: vx_upconv_fwd_k<1><<<grid, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd); break;
+    }
+    VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
+    return 0;
+}
+
+extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
+    VX_REQUIRE(dy && w && dx && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_bwd_data: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long Vc = (long)d * h * wd;
+    if (Vc <= 4096) {   // coarse levels: MFMA tiles, reduction rows k = co*8 + tap gathered space-to-depth from dy
+        const int n_vt = vx_cdiv(Vc, 16);
+        dim3 g2(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Ci, 16));
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(dy, nullptr, Co * 8, w, Co * 8, 1, nullptr, dx, nullptr, Ci, Ci, Co * 8, Vc, B, n_vt, 0, 2, d, h, wd);
+        VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
+        return 0;
+    }
+    const int T = (Ci % 8 == 0) ? 8 : (Ci % 4 == 0) ? 4 : (Ci % 2 == 0) ? 2 : 1;
+    dim3 grid(vx_cdiv((long)d * h * wd, 256), Ci / T, B);
+    switch (T) {
+        case 8: vx_upconv_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        case 4: vx_upconv_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        case 2: vx_upconv_bwd_data_k<2><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+        default: vx_upconv_bwd_data_k<1><<<grid, 256, 0, st>>>(dy, w, dx, Ci, Co, d, h, wd); break;
+    }
+    VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
+    return 0;
+}
+

@@ -78,6 +78,95 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_bwd_k(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused gather of ALL q/k/v tensors of ALL modalities in one launch, arg-max saved for the backward pass.
+//   A pooled cell (s0*s1*s2 voxels) is reduced cooperatively by T = min(64, cell size) adjacent lanes (shuffle reduction with the
+//   aten tie rule: first index wins), so the coarse scales (8^3 = 512 voxels per cell) no longer serialise in one thread.
+// ---------------------------------------------------------------------------------------------
+struct VxGatherPtrs {
+    const float* src[12];   // q0,k0,v0,q1,k1,v1,...
+    float* dsrc[12];
+};
+
+__global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_k(VxGatherPtrs ptrs, float* __restrict__ tq, float* __restrict__ tk, float* __restrict__ tv,
+                                                               int* __restrict__ iq, int* __restrict__ ik, int* __restrict__ iv,
+                                                               VxPwaPlan P, int cq, int cv, int M) {
+    // blockIdx.y enumerates (tensor, channel): tensors of kind q,k have nb*h*cq channels, kind v has nb*h*cv
+    const int nq = P.nb * P.heads * cq, nv_ = P.nb * P.heads * cv;
+    const int per_m = 2 * nq + nv_;
+    const int m = blockIdx.y / per_m;
+    int rch = blockIdx.y % per_m;
+    int kind, c;
+    if (rch < nq) { kind = 0; c = cq; } else if (rch < 2 * nq) { kind = 1; c = cq; rch -= nq; } else { kind = 2; c = cv; rch -= 2 * nq; }
+    const int ch = rch, b = blockIdx.z;
+    const float* __restrict__ src = ptrs.src[3 * m + kind];
+    float* __restrict__ tok = kind == 0 ? tq : (kind == 1 ? tk : tv);
+    int* __restrict__ tix = kind == 0 ? iq : (kind == 1 ? ik : iv);
+    const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
+    const int s0 = P.small[i][0], s1 = P.small[i][1], s2 = P.small[i][2];
+    const int csz = s0 * s1 * s2;
+    int T = 1;
+    while (T < 64 && T < csz) T <<= 1;
+    const int p0n = P.grid[0] / s0, p1n = P.grid[1] / s1, p2n = P.grid[2] / s2;
+    const int ncell = p0n * p1n * p2n;
+    const int cells_per_block = 256 / T;
+    const int sub = threadIdx.x % T;
+    const int cell = blockIdx.x * cells_per_block + threadIdx.x / T;
+    const bool cok = cell < ncell;
+    const int cl = cok ? cell : 0;
+    const int p2 = cl % p2n, p1 = (cl / p2n) % p1n, p0 = cl / (p2n * p1n);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const float* __restrict__ sc = src + ((long)b * (P.nb * P.heads * c) + ch) * V;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int e = sub; e < csz; e += T) {
+        const int w = e % s2, h = (e / s2) % s1, d = e / (s2 * s1);
+        const int idx = ((p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w);
+        const float val = sc[idx];
+        if (val > best || bidx == 0x7fffffff) { best = val; bidx = idx; }     // increasing idx per lane: strict > keeps the first
+    }
+    for (int o = T >> 1; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (cok && sub == 0) {
+        const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+        const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+        const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+        const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc;
+        tok[ti] = best;
+        tix[ti] = bidx;
+    }
+}
+
+// backward: one thread per INPUT voxel: dsrc = (saved arg-max of my cell == me) ? dtok : 0   (no memset, no atomics, coalesced stores)
+__global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_k(VxGatherPtrs ptrs, const float* __restrict__ dtq, const float* __restrict__ dtk, const float* __restrict__ dtv,
+                                                               const int* __restrict__ iq, const int* __restrict__ ik, const int* __restrict__ iv,
+                                                               VxPwaPlan P, int cq, int cv, int M) {
+    const int nq = P.nb * P.heads * cq, nv_ = P.nb * P.heads * cv;
+    const int per_m = 2 * nq + nv_;
+    const int m = blockIdx.y / per_m;
+    int rch = blockIdx.y % per_m;
+    int kind, c;
+    if (rch < nq) { kind = 0; c = cq; } else if (rch < 2 * nq) { kind = 1; c = cq; rch -= nq; } else { kind = 2; c = cv; rch -= 2 * nq; }
+    const int ch = rch, b = blockIdx.z;
+    float* __restrict__ dsrc = ptrs.dsrc[3 * m + kind];
+    const float* __restrict__ dtok = kind == 0 ? dtq : (kind == 1 ? dtk : dtv);
+    const int* __restrict__ tix = kind == 0 ? iq : (kind == 1 ? ik : iv);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
+    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
+    const int p0 = x0 / P.small[i][0], p1 = x1 / P.small[i][1], p2 = x2 / P.small[i][2];
+    const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+    const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc;
+    dsrc[((long)b * (P.nb * P.heads * c) + ch) * V + v] = (tix[ti] == (int)v) ? dtok[ti] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // scatter: per-window trilinear up-sampling (align_corners=True) of the n^3 window outputs
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int& i1, float& lam) {
@@ -114,17 +203,15 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restr
 
 // adjoint of the scatter: one block = (b, head, window, voxel chunk); the window's l x c token gradients are accumulated in LDS
 // (ds_add_f32) from the block's output voxels (8 corners each), then flushed with one float atomic per token element.
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int max_chunks) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale) {
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c]
     const int b = blockIdx.z / P.heads, a = blockIdx.z % P.heads;
-    const int N = blockIdx.y;
-    const int i = vx_scale_of_window(P, N);
+    const int i = scale;
+    const int N = P.woff[i] + blockIdx.y;
     const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
     const int nv = bw0 * bw1 * bw2;
     const int items = nv * c;
-    int chunks = (items + 4095) / 4096;
-    if (chunks > max_chunks) chunks = max_chunks;
-    if ((int)blockIdx.x >= chunks) return;
+    const int chunks = gridDim.x;
     for (int k = threadIdx.x; k < P.l * c; k += 256) vx_sacc[k] = 0.0f;
     __syncthreads();
     const int Nl = N - P.woff[i];
@@ -422,6 +509,33 @@ extern "C" int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsr
     return 0;
 }
 
+extern "C" int vx_pwa_gather_all_fwd(const float* const* srcs, float* tq, float* tk, float* tv, int* iq, int* ik, int* iv,
+                                     const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_gather_all_fwd")) return e;
+    VX_REQUIRE(srcs && tq && tk && tv && iq && ik && iv && cq > 0 && cv > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_gather_all_fwd: bad args");
+    VxGatherPtrs ptrs;
+    for (int k = 0; k < 3 * M; ++k) { VX_REQUIRE(srcs[k], "vx_pwa_gather_all_fwd: null source %d", k); ptrs.src[k] = srcs[k]; ptrs.dsrc[k] = nullptr; }
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    const int per_m = plan->nb * plan->heads * (2 * cq + cv);
+    // grid.x covers the finest scale (one lane per cell, 256 cells per block); coarser scales use fewer cells but T lanes each
+    hipLaunchKernelGGL(vx_pwa_gather_all_fwd_k, dim3(vx_cdiv(V, 256), per_m * M, B), dim3(256), 0, (hipStream_t)stream, ptrs, tq, tk, tv, iq, ik, iv, *plan, cq, cv, M);
+    VX_LAUNCH_CHECK("vx_pwa_gather_all_fwd");
+    return 0;
+}
+
+extern "C" int vx_pwa_gather_all_bwd(const float* dtq, const float* dtk, const float* dtv, const int* iq, const int* ik, const int* iv, float* const* dsrcs,
+                                     const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_gather_all_bwd")) return e;
+    VX_REQUIRE(dsrcs && dtq && dtk && dtv && iq && ik && iv && cq > 0 && cv > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_gather_all_bwd: bad args");
+    VxGatherPtrs ptrs;
+    for (int k = 0; k < 3 * M; ++k) { VX_REQUIRE(dsrcs[k], "vx_pwa_gather_all_bwd: null destination %d", k); ptrs.dsrc[k] = dsrcs[k]; ptrs.src[k] = nullptr; }
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    const int per_m = plan->nb * plan->heads * (2 * cq + cv);
+    hipLaunchKernelGGL(vx_pwa_gather_all_bwd_k, dim3(vx_cdiv(V, 256), per_m * M, B), dim3(256), 0, (hipStream_t)stream, ptrs, dtq, dtk, dtv, iq, ik, iv, *plan, cq, cv, M);
+    VX_LAUNCH_CHECK("vx_pwa_gather_all_bwd");
+    return 0;
+}
+
 extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_fwd")) return e;
     VX_REQUIRE(tok && out && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_fwd: bad args");
@@ -436,12 +550,13 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
     VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
     const size_t shm = sizeof(float) * (size_t)plane_l(plan) * c;
     VX_REQUIRE(shm <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
-    const int last = plan->nb - 1;
-    const long nv_max = (long)plan->n[0] * plan->small[last][0] * plan->n[1] * plan->small[last][1] * plan->n[2] * plan->small[last][2];
-    int max_chunks = (int)((nv_max * c + 4095) / 4096);
-    if (max_chunks > 64) max_chunks = 64;
-    if (max_chunks < 1) max_chunks = 1;
-    hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(max_chunks, plan->Ntot, B * plan->heads), dim3(256), shm, (hipStream_t)stream, dout, dtok, *plan, c, m, M, max_chunks);
+    for (int i = 0; i < plan->nb; ++i) {
+        const long nv = (long)plan->n[0] * plan->small[i][0] * plan->n[1] * plan->small[i][1] * plan->n[2] * plan->small[i][2];
+        int chunks = (int)((nv * c + 4095) / 4096);
+        if (chunks > 64) chunks = 64;
+        const int nwin = plan->nwin[i][0] * plan->nwin[i][1] * plan->nwin[i][2];
+        hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(chunks, nwin, B * plan->heads), dim3(256), shm, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i);
+    }
     VX_LAUNCH_CHECK("vx_pwa_scatter_bwd");
     return 0;
 }

@@ -385,10 +385,12 @@ class _PwaCoreFn(torch.autograd.Function):
         tq = torch.empty((B, h, Nt, ML, cq), device=dev, dtype=torch.float32)
         tk = torch.empty_like(tq)
         tv = torch.empty((B, h, Nt, ML, cv), device=dev, dtype=torch.float32)
-        for m in range(M):
-            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m]), H.P(tq), pp, cq, m, M, B, st)
-            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m + 1]), H.P(tk), pp, cq, m, M, B, st)
-            H.call("vx_pwa_gather_fwd", H.P(qkv[3 * m + 2]), H.P(tv), pp, cv, m, M, B, st)
+        iq = torch.empty(tq.shape, device=dev, dtype=torch.int32)
+        ik = torch.empty(tq.shape, device=dev, dtype=torch.int32)
+        iv = torch.empty(tv.shape, device=dev, dtype=torch.int32)
+        srcs = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in qkv])
+        H.call("vx_pwa_gather_all_fwd", srcs, H.P(tq), H.P(tk), H.P(tv), H.P(iq, torch.int32), H.P(ik, torch.int32), H.P(iv, torch.int32),
+               pp, cq, cv, M, B, st)
         O = torch.empty_like(tv)
         lse = torch.empty((B, h, Nt, ML), device=dev, dtype=torch.float32)
         rs = rng_state(dev) if p_attn > 0 else None
@@ -401,15 +403,15 @@ class _PwaCoreFn(torch.autograd.Function):
             o = torch.empty((B, plan.nb * h * cv, *g), device=dev, dtype=torch.float32)
             H.call("vx_pwa_scatter_fwd", H.P(O), H.P(o), pp, cv, m, M, B, st)
             outs.append(o)
-        ctx.save_for_backward(tq, tk, tv, O, lse, tbl, *qkv)
+        ctx.save_for_backward(tq, tk, tv, O, lse, tbl, iq, ik, iv)
+        ctx.qkv_shapes = [tuple(t.shape) for t in qkv]
         ctx.table = table
         ctx.plan, ctx.cq, ctx.cv, ctx.M, ctx.p, ctx.site = plan, cq, cv, M, float(p_attn), site
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        tq, tk, tv, O, lse, tbl = ctx.saved_tensors[:6]
-        qkv = ctx.saved_tensors[6:]
+        tq, tk, tv, O, lse, tbl, iq, ik, iv = ctx.saved_tensors
         plan, cq, cv, M = ctx.plan, ctx.cq, ctx.cv, ctx.M
         B = tq.shape[0]
         dev = tq.device
@@ -424,13 +426,10 @@ class _PwaCoreFn(torch.autograd.Function):
         dtab = grad_buf(ctx.table) if ctx.table.requires_grad else torch.zeros_like(tbl)
         H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
                H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, st)
-        grads = []
-        for m in range(M):
-            for j, (dt, c) in enumerate(((dq, cq), (dk, cq), (dv, cv))):
-                src = qkv[3 * m + j]
-                d = torch.empty_like(src)
-                H.call("vx_pwa_gather_bwd", H.P(src), H.P(dt), H.P(d), pp, c, m, M, B, st)
-                grads.append(d)
+        grads = [torch.empty(shp, device=dev, dtype=torch.float32) for shp in ctx.qkv_shapes]
+        dsts = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in grads])
+        H.call("vx_pwa_gather_all_bwd", H.P(dq), H.P(dk), H.P(dv), H.P(iq, torch.int32), H.P(ik, torch.int32), H.P(iv, torch.int32), dsts,
+               pp, cq, cv, M, B, st)
         return (None, None, None, None, None, None, None, *grads)
 
 
