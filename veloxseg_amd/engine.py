@@ -33,8 +33,6 @@ class FlatParams:
         if not params:
             raise ValueError("model has no trainable parameters")
         dev = params[0][1].device
-        if dev.type != "cuda":
-            raise RuntimeError("FlatParams: move the model to the MI355X first (model.cuda())")
         head = [(n, p) for n, p in params if any(n.startswith(f) for f in first)]
         tail = [(n, p) for n, p in params if not any(n.startswith(f) for f in first)]
         self.names: List[str] = []
