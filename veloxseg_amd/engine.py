@@ -108,11 +108,16 @@ class TrainEngine:
         VF.advance_rng(self.dev)
         enc = self.model.encoder
         attn, encs = enc(self.x)
-        boundary = list(encs) + [t for lvl in attn for t in lvl]
-        self._boundary = boundary
-        outs = self._decode(attn, encs)
+        # cut the autograd graph at the encoder outputs: the decoders consume detached leaves, so this phase touches decoder nodes
+        # only; the leaves' .grad then seed the encoder backward (phase 2), which adds the encoder-internal paths (enc_i -> down_{i+1}).
+        encs_d = [e.detach().requires_grad_(True) for e in encs]
+        attn_d = [[t.detach().requires_grad_(True) for t in lvl] for lvl in attn]
+        self._boundary = list(encs) + [t for lvl in attn for t in lvl]
+        leaves = encs_d + [t for lvl in attn_d for t in lvl]
+        outs = self._decode(attn_d, encs_d)
         loss = self.criterion(outs, self.labels, sr_labels=self.x)
-        self._bgrads = torch.autograd.grad(loss, boundary, retain_graph=False, allow_unused=False)
+        loss.backward()
+        self._bgrads = [l.grad for l in leaves]
         self.loss.copy_(loss.detach())
 
     def _decode(self, attn, encs):
