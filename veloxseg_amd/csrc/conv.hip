@@ -144,24 +144,20 @@ __global__ void __launch_bounds__(256) vx_conv3d_bwd_data_k(const float* __restr
             for (int col = 0; col < ncoc; ++col) {
                 const int co = g * Cout_g + c0 + col;
                 const float* __restrict__ wc = vx_wlds + (long)col * K3 * CIT;
-                for (int kd = 0; kd < K; ++kd) {
-                    const int nd = id + p.P - kd;
-                    const int qd = nd / p.S;
-                    const bool okd = nd >= 0 && qd * p.S == nd && qd < p.Do;
-                    for (int kh = 0; kh < K; ++kh) {
-                        const int nh = ih + p.P - kh;
-                        const int qh = nh / p.S;
-                        const bool okh = okd && nh >= 0 && qh * p.S == nh && qh < p.Ho;
-                        for (int kw = 0; kw < K; ++kw) {
-                            const int nw = iw + p.P - kw;
-                            const int qw = nw / p.S;
-                            const bool ok = okh && nw >= 0 && qw * p.S == nw && qw < p.Wo;
-                            if (ok) {
-                                const float dv = dy[vx_y_index(p, b, co, qd, qh, qw)];
-                                const float* wp = wc + ((kd * K + kh) * K + kw) * CIT;
+                // only taps with (pos + P - k) divisible by the stride contribute: start at the right residue and step by S
+                for (int kd = (id + p.P) % p.S; kd < K; kd += p.S) {
+                    const int qd = (id + p.P - kd) / p.S;
+                    if (id + p.P - kd < 0 || qd >= p.Do) continue;
+                    for (int kh = (ih + p.P) % p.S; kh < K; kh += p.S) {
+                        const int qh = (ih + p.P - kh) / p.S;
+                        if (ih + p.P - kh < 0 || qh >= p.Ho) continue;
+                        for (int kw = (iw + p.P) % p.S; kw < K; kw += p.S) {
+                            const int qw = (iw + p.P - kw) / p.S;
+                            if (iw + p.P - kw < 0 || qw >= p.Wo) continue;
+                            const float dv = dy[vx_y_index(p, b, co, qd, qh, qw)];
+                            const float* wp = wc + ((kd * K + kh) * K + kw) * CIT;
 #pragma unroll
-                                for (int j = 0; j < CIT; ++j) acc[j] = fmaf(wp[j], dv, acc[j]);
-                            }
+                            for (int j = 0; j < CIT; ++j) acc[j] = fmaf(wp[j], dv, acc[j]);
                         }
                     }
                 }

@@ -202,6 +202,13 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
     }
     if (p.TH > p.Ho) p.TH = p.Ho;
     if (p.TD > p.Do) p.TD = p.Do;
+    {   // small volumes: prefer more, smaller tiles (>= ~512 blocks) over LDS-filling ones; the atomic flush stays cheap
+        const int COT0 = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
+        auto nblk = [&]() { return (long)vx_cdiv(p.Do, p.TD) * vx_cdiv(p.Ho, p.TH) * vx_cdiv(p.Wo, p.TW) * G * (Cout_g / COT0) * B; };
+        while (nblk() < 512 && p.TD > 1) p.TD = (p.TD + 1) / 2;
+        while (nblk() < 512 && p.TH > 1) p.TH = (p.TH + 1) / 2;
+        while (nblk() < 512 && p.TW > 8) p.TW = (p.TW + 1) / 2;
+    }
     p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
     p.nTd = vx_cdiv(p.Do, p.TD); p.nTh = vx_cdiv(p.Ho, p.TH); p.nTw = vx_cdiv(p.Wo, p.TW);
     const int ntiles = p.nTd * p.nTh * p.nTw;

@@ -261,25 +261,45 @@ __device__ __forceinline__ int vx_lin_of_token(const VxAttn& A, int T) {
     return (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
 }
 
+// Per-block LDS tables shared by the attention kernels: lin[t] (t < l) and the bias table of every head (Tsz x heads floats).
+// LDS layout (dynamic): [lin: l ints][bias: heads*Tsz floats][per-wave slabs ...]
+__device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __restrict__ table, int Tsz, int* lin, float* bias) {
+    for (int t = threadIdx.x; t < A.l; t += 256) {
+        const int t2 = t % A.n[2], t1 = (t / A.n[2]) % A.n[1], t0 = t / (A.n[2] * A.n[1]);
+        lin[t] = (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+    }
+    for (int e = threadIdx.x; e < Tsz * A.heads; e += 256) {       // transpose (Tsz, heads) -> [head][Tsz]
+        const int a = e / Tsz, k = e % Tsz;
+        bias[e] = table[(long)k * A.heads + a];
+    }
+}
+
 // unit = (bh, window, 64-query chunk); one wave per unit, 4 units per block.  Keys/values are staged 64 rows at a time
 // into a per-wave LDS slab (coalesced global read, one row per lane) and consumed as broadcast ds_read_b128.
 #define VX_KV_ROWS 64
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                          const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
-                                                         VxAttn A, VxDrop drop) {
+                                                         int Tsz, VxAttn A, VxDrop drop) {
     constexpr int RS = CQ + CV;
-    __shared__ __attribute__((aligned(16))) float kvs[4][VX_KV_ROWS * RS];
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];
+    int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
+    const int lin_pad = (A.l + 3) & ~3;
+    float* __restrict__ bias_all = vx_sm + lin_pad;
+    float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
+    vx_attn_tables(A, table, Tsz, lin, bias_all);
+    __syncthreads();
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long u = (long)blockIdx.x * 4 + wave;
     if (u >= units) return;
-    float* __restrict__ slab = kvs[wave];
+    float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;                       // (bh*Nt + N)
     const int a = (int)((win / A.Nt) % A.heads);
+    const float* __restrict__ bias = bias_all + (long)a * Tsz;
     const int i = chunk * 64 + lane;
     const bool ok = i < A.ML;
     const int iq = ok ? i : A.ML - 1;
@@ -287,7 +307,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     float q[CQ];
 #pragma unroll
     for (int c = 0; c < CQ; ++c) q[c] = qp[c] * A.scale;
-    const int lin_i = vx_lin_of_token(A, iq) + A.lin_cst;
+    const int lin_i = lin[iq % A.l] + A.lin_cst;
     float acc[CV];
 #pragma unroll
     for (int c = 0; c < CV; ++c) acc[c] = 0.0f;
@@ -295,6 +315,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = ((uint64_t)win * A.ML + iq) * (uint64_t)A.ML;
+    int tj = 0;                                        // key token index modulo l (keys are modality-major)
     for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
         const int nk = min(VX_KV_ROWS, A.ML - j0);
         __builtin_amdgcn_wave_barrier();
@@ -310,10 +331,11 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < CQ; ++c) s = fmaf(q[c], row[c], s);
-            s += table[(long)(lin_i - vx_lin_of_token(A, j0 + jj)) * A.heads + a];
+            s += bias[lin_i - lin[tj]];
+            if (++tj == A.l) tj = 0;
             const float mn = fmaxf(mrun, s);
-            const float alpha = expf(mrun - mn);
-            const float p = expf(s - mn);
+            const float alpha = __expf(mrun - mn);
+            const float p = __expf(s - mn);
             lsum = lsum * alpha + p;
             const float pd = p * vx_drop(drop, drow + j0 + jj);
 #pragma unroll
@@ -326,7 +348,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
         float* __restrict__ op = O + (win * A.ML + i) * CV;
 #pragma unroll
         for (int c = 0; c < CV; ++c) op[c] = acc[c] * inv;
-        LSE[win * A.ML + i] = mrun + logf(lsum);
+        LSE[win * A.ML + i] = mrun + __logf(lsum);
     }
 }
 
@@ -337,11 +359,17 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
                                                            float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop) {
     constexpr int RS = CQ + CV;
-    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // [4][Tsz] private bias-gradient tables, then [4][64*RS] K/V slabs
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // lin | bias tables | [4][Tsz] bias-gradient tables | [4] K/V slabs
+    int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
+    const int lin_pad = (A.l + 3) & ~3;
+    float* __restrict__ bias_all = vx_sm + lin_pad;
+    float* __restrict__ gtabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
+    float* __restrict__ slabs = gtabs + (((long)4 * Tsz + 3) & ~3);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    float* __restrict__ stab = vx_sm + (long)wave * Tsz;
-    float* __restrict__ slab = vx_sm + (long)4 * Tsz + (long)wave * VX_KV_ROWS * RS;
+    float* __restrict__ stab = gtabs + (long)wave * Tsz;
+    float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
+    vx_attn_tables(A, table, Tsz, lin, bias_all);
     for (int k = lane; k < Tsz; k += 64) stab[k] = 0.0f;
     __syncthreads();
     const int chunks = (A.ML + 63) / 64;
@@ -352,6 +380,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;
     const int a = (int)((win / A.Nt) % A.heads);
+    const float* __restrict__ bias = bias_all + (long)a * Tsz;
     const int i = chunk * 64 + lane;
     const bool ok = active && i < A.ML;
     const int iq = (i < A.ML) ? i : A.ML - 1;
@@ -363,10 +392,11 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
 #pragma unroll
     for (int c = 0; c < CV; ++c) { dov[c] = dO[row * CV + c]; delta = fmaf(dov[c], O[row * CV + c], delta); }
     const float lse = LSE[row];
-    const int lin_i = vx_lin_of_token(A, iq) + A.lin_cst;
+    const int lin_i = lin[iq % A.l] + A.lin_cst;
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
+    int tj = 0;
     for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
         const int nk = min(VX_KV_ROWS, A.ML - j0);
         __builtin_amdgcn_wave_barrier();
@@ -382,9 +412,10 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
-            const int bi = lin_i - vx_lin_of_token(A, j0 + jj);
-            s += table[(long)bi * A.heads + a];
-            const float p = expf(s - lse);
+            const int bi = lin_i - lin[tj];
+            if (++tj == A.l) tj = 0;
+            s += bias[bi];
+            const float p = __expf(s - lse);
             float dp = 0.0f;
 #pragma unroll
             for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
@@ -412,19 +443,26 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
-                                                            VxAttn A, VxDrop drop) {
+                                                            int Tsz, VxAttn A, VxDrop drop) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
-    __shared__ __attribute__((aligned(16))) float qs[4][VX_KV_ROWS * RS];
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];
+    int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
+    const int lin_pad = (A.l + 3) & ~3;
+    float* __restrict__ bias_all = vx_sm + lin_pad;
+    float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
+    vx_attn_tables(A, table, Tsz, lin, bias_all);
+    __syncthreads();
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long u = (long)blockIdx.x * 4 + wave;
     if (u >= units) return;
-    float* __restrict__ slab = qs[wave];
+    float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;
     const int a = (int)((win / A.Nt) % A.heads);
+    const float* __restrict__ bias = bias_all + (long)a * Tsz;
     const int j = chunk * 64 + lane;
     const bool ok = j < A.ML;
     const int jk = ok ? j : A.ML - 1;
@@ -434,9 +472,10 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     for (int c = 0; c < CQ; ++c) { k[c] = K[krow * CQ + c]; dk[c] = 0.0f; }
 #pragma unroll
     for (int c = 0; c < CV; ++c) { v[c] = Vt[krow * CV + c]; dv[c] = 0.0f; }
-    const int lin_j = vx_lin_of_token(A, jk) - A.lin_cst;
+    const int lin_j = lin[jk % A.l] - A.lin_cst;
     const float* __restrict__ qp = Q + win * A.ML * CQ;
     const float* __restrict__ dop = dO + win * A.ML * CV;
+    int ti = 0;
     for (int i0 = 0; i0 < A.ML; i0 += VX_KV_ROWS) {
         const int nq = min(VX_KV_ROWS, A.ML - i0);
         __builtin_amdgcn_wave_barrier();
@@ -455,8 +494,9 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < CQ; ++c) s = fmaf(qr[c], k[c], s);
-            s = s * A.scale + table[(long)(vx_lin_of_token(A, i) - lin_j) * A.heads + a];
-            const float p = expf(s - qr[CQ + CV]);
+            s = s * A.scale + bias[lin[ti] - lin_j];
+            if (++ti == A.l) ti = 0;
+            const float p = __expf(s - qr[CQ + CV]);
             const float msk = vx_drop(drop, ((uint64_t)(win * A.ML + i)) * (uint64_t)A.ML + jk);
             float dp = 0.0f;
 #pragma unroll
@@ -589,8 +629,12 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     VX_REQUIRE(Q && K && V && table && O && LSE, "vx_pwa_attn_fwd: null pointer");
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
+    const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+    const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
+    const size_t shm = (tab_f + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_fwd: tables do not fit LDS (%d entries x %d heads)", Tsz, A.heads);
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
-        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, A, d);
+        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_fwd");
@@ -606,13 +650,15 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     VX_REQUIRE(Q && K && V && table && O && LSE && dO && dQ && dK && dV && dtable && delta_ws, "vx_pwa_attn_bwd: null pointer");
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
-    const size_t shm = ((size_t)4 * Tsz + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
+    const size_t shm = (tab_f + (((size_t)4 * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    const size_t shm_kv = (tab_f + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
         vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, dtable, Tsz, A, d);
-        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, A, d);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, Tsz, A, d);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd");
