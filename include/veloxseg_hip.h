@@ -53,6 +53,13 @@ int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const fl
  * in_ps / out_ps: PixelShuffle factor of the input / output storage.  accumulate: y += . */
 int vx_conv_s1(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
                int K, int G, int wmode, int in_ps, int out_ps, int accumulate, void* stream);
+/* patch-expand (Conv3d 16 -> 64*Cc, k3 p1, PixelShuffle 4) input gradient as an fp32-MFMA implicit GEMM reading the fine gradient and the
+ * tap-major weights in 256-byte runs.  dy_fine: (B, Cc, 4D,4H,4W); w: (64*Cc, 16, 3,3,3); wt_ws: 64*Cc*16*27 floats; dx: (B,16,D,H,W) */
+int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
+                            int accumulate, void* stream);
+/* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
+ * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
+int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);
 /* 1x1x1 convolutions: thread-per-voxel with scalar-path weights (fwd / bwd_data; Cin % 4 == 0), fp32-MFMA GEMM over the voxel
  * axis for the weight gradient.  w: (Cout, Cin).  Same concat / accumulate conventions as vx_conv3d_*. */
 int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,

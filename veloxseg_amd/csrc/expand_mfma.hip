@@ -1,0 +1,240 @@
+// Patch-expand convolution (Conv3d 16 -> 64*Cc, k3 p1, + PixelShuffle(4); reference Decoder.py:73-76,150-153, superpixel.py:16)
+// as fp32-MFMA implicit GEMMs whose operands are read STRAIGHT FROM GLOBAL MEMORY in 256-byte runs.
+//
+// The pixel-shuffled tensor makes this possible: output channel co = ((c*4+s1)*4+s2)*4+s3 of coarse voxel (d,h,w) lives at
+// fine[c][4d+s1][4h+s2][4w+s3], so for 16 consecutive coarse voxels along W the 4 values s3 = 0..3 form 64 CONSECUTIVE floats.
+// With v_mfma_f32_16x16x4_f32 (A: lane(r,q) = A[row r][k q], B: lane(r,q) = B[k q][col r], D: lane(r,q), reg = D[row 4q+reg][col r]):
+//   input gradient  dx[p, ci] = sum_{t,co} dyf[co, p-t+1] W[co,ci,t]:   rows = 16 coarse voxels, cols = 16 ci, k = s3
+//        -> A is one coalesced 256-B load of the fine gradient, B one coalesced 256-B load of the tap-major weights WT[t][co][ci].
+// Exact fp32 (the MFMA is a k-ordered fmaf chain), so it is interchangeable with the VALU kernels within round-off.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+typedef float vx_f4 __attribute__((ext_vector_type(4)));
+
+// WT[t][co][ci] = W[co][ci][t]
+__global__ void __launch_bounds__(256) vx_weight_tap_major_k(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int K3) {
+    const long n = (long)Cout * Cin * K3;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int ci = (int)(e % Cin);
+    const int co = (int)((e / Cin) % Cout);
+    const int t = (int)(e / ((long)Cin * Cout));
+    wt[e] = w[((long)co * Cin + ci) * K3 + t];
+}
+
+// x_cl[b][voxel][c] = x[b][c][voxel]  (C = 16): lets the weight-gradient kernel read 4 voxels x 16 channels as ONE 256-byte run
+__global__ void __launch_bounds__(256) vx_to_channels_last16_k(const float* __restrict__ x, float* __restrict__ xcl, long V) {
+    __shared__ float tile[16][65];
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int c = e / 64, k = e % 64;
+        tile[c][k] = (v0 + k < V) ? x[((long)b * 16 + c) * V + v0 + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int k = e / 16, c = e % 16;
+        if (v0 + k < V) xcl[((long)b * V + v0 + k) * 16 + c] = tile[c][k];
+    }
+}
+
+// one wave = MT consecutive 16-voxel tiles of the coarse volume (flattened d,h,w), all 16 input channels
+template <int MT>
+__global__ void __launch_bounds__(256) vx_expand_bwd_data_mfma_k(const float* __restrict__ dyf, const float* __restrict__ wt, float* __restrict__ dx,
+                                                                 int B, int Cc, int D, int H, int W, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long V = (long)D * H * W;
+    const int tiles = (int)((V + 15) / 16);
+    const int groups = (tiles + MT - 1) / MT;
+    const long gw = (long)blockIdx.x * 4 + wave;
+    if (gw >= (long)B * groups) return;
+    const int b = (int)(gw / groups);
+    const int tile0 = (int)(gw % groups) * MT;
+    const int r = lane & 15, q = lane >> 4;
+    const int Cout = Cc * 64;
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;                       // one fine channel
+    int pd[MT], ph[MT], pw[MT];
+    bool pok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const long p = (long)(tile0 + m) * 16 + r;
+        pok[m] = (tile0 + m) < tiles && p < V;
+        const long pp = pok[m] ? p : 0;
+        pw[m] = (int)(pp % W);
+        ph[m] = (int)((pp / W) % H);
+        pd[m] = (int)(pp / ((long)W * H));
+    }
+    vx_f4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
+    for (int t = 0; t < 27; ++t) {
+        const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+        long abase[MT];
+        bool aok[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int qd = pd[m] - td + 1, qh = ph[m] - th + 1, qw = pw[m] - tw + 1;
+            aok[m] = pok[m] && (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+            abase[m] = ((long)(4 * qd) * FH + 4 * qh) * FW + 4 * qw + q;
+        }
+        const float* __restrict__ wtt = wt + ((long)t * Cout) * 16 + q * 16 + r;      // + co_base*16
+        for (int c = 0; c < Cc; ++c) {
+            for (int s1 = 0; s1 < 4; ++s1) {
+                const long coff = (long)c * fplane + (long)s1 * FH * FW;
+                const int co_base = ((c * 4 + s1) * 4) * 4;
+                float bv[4], av[MT][4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    bv[s2] = wtt[(long)(co_base + s2 * 4) * 16];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[m][s2] = aok[m] ? dyb[coff + abase[m] + (long)s2 * FW] : 0.0f;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][s2], bv[s2], acc[m], 0, 0, 0);
+            }
+        }
+    }
+    // D: row = voxel 4q+reg of the tile, col = ci r
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long p = (long)(tile0 + m) * 16 + 4 * q + reg;
+            if ((tile0 + m) < tiles && p < V) {
+                float* dst = dx + ((long)b * 16 + r) * V + p;
+                *dst = accumulate ? *dst + acc[m][reg] : acc[m][reg];
+            }
+        }
+    }
+}
+
+extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
+                                       int accumulate, void* stream) {
+    VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int Cout = Cc * 64;
+    const long nW = (long)Cout * 16 * 27;
+    vx_weight_tap_major_k<<<vx_cdiv(nW, 256), 256, 0, st>>>(w, wt_ws, Cout, 16, 27);
+    const long V = (long)D * H * W;
+    const int tiles = (int)((V + 15) / 16);
+    constexpr int MT = 4;
+    const int groups = (tiles + MT - 1) / MT;
+    vx_expand_bwd_data_mfma_k<MT><<<vx_cdiv((long)B * groups, 4), 256, 0, st>>>(dy_fine, wt_ws, dx, B, Cc, D, H, W, accumulate);
+    VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[co, ci, t] += sum_{b,p} dyf[co, p] * x[ci, p + t - 1]   (+ db[co] += sum dyf[co, p])
+//   rows = 16 output channels of one (c, s1) group (row r <-> s2 = r>>2, s3 = r&3), cols = 16 input channels, k = 4 coarse voxels along W.
+//   A (fine gradient): lane (r,q) reads fine[c][4d+s1][4h+s2][4(w4+q)+s3]  -> 4 fine rows x 64 contiguous bytes per load;
+//   B (coarse input, CHANNELS-LAST copy): lane (r,q) reads xcl[p + t - 1 (voxel w4+q+tw-1)][ci=r] -> one 256-byte run per tap.
+//   One wave = one (c,s1) group x a run of k-steps; 27 accumulator tiles (108 VGPRs); one float atomic per weight per wave at the end.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vx_expand_wgrad_mfma_k(const float* __restrict__ x, const float* __restrict__ dyf, float* __restrict__ dw,
+                                                              float* __restrict__ db, int B, int Cc, int D, int H, int W, int steps_per_wave, int chunks_per_b) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ float red[16 * 16 * 27];
+    for (int e = threadIdx.x; e < 16 * 16 * 27; e += 256) red[e] = 0.0f;
+    __syncthreads();
+    const long gw_raw = (long)blockIdx.x * 4 + wave;
+    const bool active = gw_raw < (long)B * chunks_per_b;
+    const long gw = active ? gw_raw : 0;
+    const int b = (int)(gw / chunks_per_b);
+    const int chunk = (int)(gw % chunks_per_b);
+    const int mt = blockIdx.y;                          // (c, s1)
+    const int c = mt >> 2, s1 = mt & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int W4 = (W + 3) / 4;                         // k-steps per coarse row
+    const long nsteps = (long)D * H * W4;
+    const long V = (long)D * H * W;
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    const float* __restrict__ dyb = dyf + ((long)b * Cc + c) * fplane + (long)s1 * FH * FW + (long)(r >> 2) * FW + (r & 3);
+    const float* __restrict__ xb = x + (long)b * V * 16 + r;       // channels-last: [voxel][16]
+    vx_f4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const long s_begin = (long)chunk * steps_per_wave;
+    const long s_end = !active ? s_begin : ((s_begin + steps_per_wave < nsteps) ? s_begin + steps_per_wave : nsteps);
+    // software pipeline: the 28 operand loads of step s+1 are issued before the 27 MFMAs of step s
+    auto load_step = [&](long s, float& av, float (&bv)[27]) {
+        const int w4 = (int)(s % W4);
+        const int h = (int)((s / W4) % H);
+        const int d = (int)(s / ((long)W4 * H));
+        const int pw = 4 * w4 + q;
+        const bool vok = pw < W && s < s_end;
+        av = vok ? dyb[((long)(4 * d) * FH + 4 * h) * FW + 4 * pw] : 0.0f;
+#pragma unroll
+        for (int td = 0; td < 3; ++td) {
+            const int id = d + td - 1;
+            const bool okd = (unsigned)id < (unsigned)D;
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int ih = h + th - 1;
+                const bool okh = okd && (unsigned)ih < (unsigned)H;
+                const long rowoff = ((long)id * H + ih) * W;
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    const int iw = pw + tw - 1;
+                    bv[(td * 3 + th) * 3 + tw] = (okh && vok && (unsigned)iw < (unsigned)W) ? xb[(rowoff + iw) * 16] : 0.0f;
+                }
+            }
+        }
+    };
+    float av0, bv0[27], av1, bv1[27];
+    load_step(s_begin, av0, bv0);
+    for (long s = s_begin; s < s_end; s += 2) {
+        load_step(s + 1, av1, bv1);
+        bsum += av0;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[t], acc[t], 0, 0, 0);
+        load_step(s + 2, av0, bv0);
+        bsum += av1;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[t], acc[t], 0, 0, 0);
+    }
+    // D: row = 4q+reg -> co = mt*16 + row, col = ci r.  The 4 waves of the block (same (c,s1) group, different voxel runs) are summed in LDS
+    // in the final [co][ci][t] order, then flushed as CONTIGUOUS float atomics (64 consecutive floats per wave instruction).
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[((4 * q + reg) * 16 + r) * 27 + t], acc[t][reg]);
+    }
+    __syncthreads();
+    float* __restrict__ dwg = dw + (long)mt * 16 * 16 * 27;
+    for (int e = threadIdx.x; e < 16 * 16 * 27; e += 256) atomicAdd(dwg + e, red[e]);
+    if (db != nullptr && active) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0) atomicAdd(db + mt * 16 + r, bsum);
+    }
+}
+
+extern "C" int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && xcl_ws && dy_fine && dw && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_wgrad_mfma: bad args");
+    {
+        const long Vx = (long)D * H * W;
+        vx_to_channels_last16_k<<<dim3(vx_cdiv(Vx, 64), B), 256, 0, (hipStream_t)stream>>>(x, xcl_ws, Vx);
+    }
+    const long nsteps = (long)D * H * ((W + 3) / 4);
+    const int groups = Cc * 4;
+    long waves_per_group = 2048 / groups;
+    if (waves_per_group < 1) waves_per_group = 1;
+    long spw = ((long)B * nsteps + waves_per_group - 1) / waves_per_group;
+    if (spw < 16) spw = 16;
+    const int chunks_per_b = vx_cdiv(nsteps, spw);
+    dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), groups);
+    vx_expand_wgrad_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(xcl_ws, dy_fine, dw, db, B, Cc, D, H, W, (int)spw, chunks_per_b);
+    VX_LAUNCH_CHECK("vx_expand_wgrad_mfma");
+    return 0;
+}

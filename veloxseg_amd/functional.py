@@ -18,6 +18,7 @@ import torch
 from . import _hip as H
 
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
+USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
@@ -120,6 +121,9 @@ class _Conv3dFn(torch.autograd.Function):
                 H.call("vx_pw_conv_mfma", H.P(dy), None, 0, H.P(w), 1, None, H.P(dx), H.P(dx2), C1, B, Cin, Cout, Cin, D * Hh * W, 0, st)
             elif ctx.pw:
                 H.call("vx_pw_conv_bwd_data", H.P(dy), H.P(w), H.P(dx), H.P(dx2), C1, B, Cin, Cout, D * Hh * W, 0, st)
+            elif ctx.s1 and ps == 4 and K == 3 and Cin == 16 and G == 1 and USE_EXPAND_MFMA:
+                wt = torch.empty((Cout * 16 * 27,), device=x.device, dtype=torch.float32)
+                H.call("vx_expand_bwd_data_mfma", H.P(dy), H.P(w), H.P(wt), H.P(dx), B, Cout // 64, D, Hh, W, 0, st)
             elif ctx.s1:
                 H.call("vx_conv_s1", H.P(dy), H.P(w), None, H.P(dx), B, Cout, Cin, D, Hh, W, K, G, 1, ps, 1, 0, st)
             else:
@@ -128,6 +132,9 @@ class _Conv3dFn(torch.autograd.Function):
             db = grad_buf(b) if (b is not None and b.requires_grad) else None
             if K == 1 and S == 1 and P == 0 and G == 1 and ps == 1:
                 H.call("vx_pw_conv_bwd_weight", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, Cout, D * Hh * W, st)
+            elif ctx.s1 and ps == 4 and K == 3 and Cin == 16 and G == 1 and USE_EXPAND_MFMA:
+                xcl = torch.empty((B * D * Hh * W * 16,), device=x.device, dtype=torch.float32)
+                H.call("vx_expand_wgrad_mfma", H.P(x), H.P(xcl), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cout // 64, D, Hh, W, st)
             else:
                 H.call(WGRAD_ENTRY, H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
         return dx, dx2, None, None, None, None, None, None, None
