@@ -266,3 +266,36 @@ def test_errors_are_python_exceptions():
     from veloxseg_amd import _hip as H
     with pytest.raises(RuntimeError, match="vx_conv3d_fwd"):
         H.call("vx_conv3d_fwd", None, None, 0, None, None, None, 1, 4, 4, 4, 4, 4, 1, 1, 0, 1, 1, 0)
+
+
+def test_kernel_variants_agree():
+    """A/B of alternative kernels for the same op: tiled vs untiled weight gradient, conv_s1 vs generic conv, MFMA vs VALU pointwise /
+    patch-expand paths.  They must agree to fp32 round-off (all are k-ordered fp32 FMA chains)."""
+    VF = _vf()
+    import veloxseg_amd.functional as F_
+    d = dev()
+
+    def run(cfg):
+        for k, v in cfg.items():
+            setattr(F_, k, v)
+        torch.manual_seed(0)
+        res = []
+        for (Cin, Cout, K, G, ps, sp) in [(16, 128, 3, 1, 4, (6, 5, 8)), (16, 16, 5, 4, 1, (8, 8, 8)), (32, 32, 3, 4, 1, (4, 6, 8)), (64, 32, 1, 1, 1, (4, 4, 4))]:
+            x = rnd(2, Cin, *sp, seed=Cin).to(d).requires_grad_(True)
+            w = (rnd(Cout, Cin // G, K, K, K, seed=K) * 0.1).to(d).requires_grad_(True)
+            b = rnd(Cout, seed=3).to(d).requires_grad_(True)
+            y = VF.conv3d(x, w, b, padding=K // 2, groups=G, pixel_shuffle=ps)
+            y.backward(rnd(*y.shape, seed=5).to(d))
+            res += [y.detach(), x.grad, w.grad, b.grad]
+        torch.cuda.synchronize()
+        return res
+
+    base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096)
+    ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0))
+    try:
+        for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0)):
+            got = run(variant)
+            for i, (a, b_) in enumerate(zip(got, ref)):
+                close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")
+    finally:
+        run(base)
