@@ -10,7 +10,8 @@
 // InstanceNorm statistics: one 256-thread block per (b,c) row of V contiguous floats.
 // stats[2*bc] = mean, stats[2*bc+1] = rstd.  fp64 accumulation -> deterministic and cancellation-safe.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) vx_in_stats_part_k(const float* __restrict__ x, double* __restrict__ part, long V, int S) {
+__global__ void __launch_bounds__(256) vx_in_stats_part_k(const float* __restrict__ x, double* __restrict__ part, long V, int S,
+                                                          float* __restrict__ stats, float eps) {
     const long bc = blockIdx.x;
     const int sp = blockIdx.y;
     const float* __restrict__ row = x + bc * V;
@@ -27,8 +28,17 @@ __global__ void __launch_bounds__(256) vx_in_stats_part_k(const float* __restric
     if (lane == 0) { sm[wid] = s; sm[4 + wid] = ss; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[(bc * S + sp) * 2] = sm[0] + sm[1] + sm[2] + sm[3];
-        part[(bc * S + sp) * 2 + 1] = sm[4] + sm[5] + sm[6] + sm[7];
+        const double S1 = sm[0] + sm[1] + sm[2] + sm[3], S2 = sm[4] + sm[5] + sm[6] + sm[7];
+        if (S == 1) {          // whole row in this block: finalize here, no second launch
+            const double m = S1 / (double)V;
+            double var = S2 / (double)V - m * m;
+            if (var < 0.0) var = 0.0;
+            stats[2 * bc] = (float)m;
+            stats[2 * bc + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            part[(bc * S + sp) * 2] = S1;
+            part[(bc * S + sp) * 2 + 1] = S2;
+        }
     }
 }
 __global__ void __launch_bounds__(256) vx_in_stats_fin_k(const double* __restrict__ part, float* __restrict__ stats, long BC, long V, int S, float eps) {
@@ -69,7 +79,8 @@ __global__ void __launch_bounds__(256) vx_in_apply_fwd_k(const float* __restrict
 
 // backward statistics for one branch: m[2bc] = mean(dz), m[2bc+1] = mean(dz*z), dz = dout*act'(z)
 __global__ void __launch_bounds__(256) vx_in_bwd_stats_part_k(const float* __restrict__ dout, const float* __restrict__ y,
-                                                              const float* __restrict__ st, int act, double* __restrict__ part, long V, int S) {
+                                                              const float* __restrict__ st, int act, double* __restrict__ part, long V, int S,
+                                                              float* __restrict__ m_out) {
     const long bc = blockIdx.x;
     const int sp = blockIdx.y;
     const float mean = st[2 * bc], rstd = st[2 * bc + 1];
@@ -88,8 +99,14 @@ __global__ void __launch_bounds__(256) vx_in_bwd_stats_part_k(const float* __res
     if (lane == 0) { sm[wid] = a; sm[4 + wid] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[(bc * S + sp) * 2] = sm[0] + sm[1] + sm[2] + sm[3];
-        part[(bc * S + sp) * 2 + 1] = sm[4] + sm[5] + sm[6] + sm[7];
+        const double S1 = sm[0] + sm[1] + sm[2] + sm[3], S2 = sm[4] + sm[5] + sm[6] + sm[7];
+        if (S == 1) {
+            m_out[2 * bc] = (float)(S1 / (double)V);
+            m_out[2 * bc + 1] = (float)(S2 / (double)V);
+        } else {
+            part[(bc * S + sp) * 2] = S1;
+            part[(bc * S + sp) * 2 + 1] = S2;
+        }
     }
 }
 __global__ void __launch_bounds__(256) vx_in_bwd_stats_fin_k(const double* __restrict__ part, float* __restrict__ m, long BC, long V, int S) {
@@ -229,9 +246,10 @@ __global__ void __launch_bounds__(256) vx_add_k(const float* __restrict__ a, con
 __global__ void __launch_bounds__(256) vx_channel_sum_k(const float* __restrict__ dy, float* __restrict__ db, int B, int C, long V) {
     const int c = blockIdx.x;
     float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const float* __restrict__ row = dy + ((long)b * C + c) * V;
-        for (long v = threadIdx.x; v < V; v += 256) s += row[v];
+    const long n = (long)B * V;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long)gridDim.y * 256) {
+        const long b = i / V, v = i % V;
+        s += dy[(b * C + c) * V + v];
     }
     __shared__ float sm[4];
     s = vx_block_sum_256(s, sm);
@@ -269,7 +287,7 @@ static VxDrop vx_mk_drop(const void* seed_ptr, unsigned long long stream, float 
 
 static int vx_in_split(long BC, long V) {      // row split so that ~1024 blocks are in flight, each with >= 2048 elements
     long S = 1024 / (BC > 0 ? BC : 1);
-    if (S > V / 2048) S = V / 2048;
+    if (S > V / 4096) S = V / 4096;
     if (S > 16) S = 16;
     if (S < 1) S = 1;
     return (int)S;
@@ -278,8 +296,8 @@ static int vx_in_split(long BC, long V) {      // row split so that ~1024 blocks
 extern "C" int vx_in_stats(const float* x, float* stats, double* part_ws, long BC, long V, float eps, void* stream) {
     VX_REQUIRE(x && stats && part_ws && BC > 0 && V > 1, "vx_in_stats: bad args (InstanceNorm needs more than 1 spatial element; BC=%ld V=%ld)", BC, V);
     const int S = vx_in_split(BC, V);
-    hipLaunchKernelGGL(vx_in_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, x, part_ws, V, S);
-    hipLaunchKernelGGL(vx_in_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, stats, BC, V, S, eps);
+    hipLaunchKernelGGL(vx_in_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, x, part_ws, V, S, stats, eps);
+    if (S > 1) hipLaunchKernelGGL(vx_in_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, stats, BC, V, S, eps);
     VX_LAUNCH_CHECK("vx_in_stats");
     return 0;
 }
@@ -295,8 +313,8 @@ extern "C" int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2
 extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y && st && m_ws && part_ws && dy, "vx_in_bwd: null pointer");
     const int S = vx_in_split(BC, V);
-    hipLaunchKernelGGL(vx_in_bwd_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, part_ws, V, S);
-    hipLaunchKernelGGL(vx_in_bwd_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, m_ws, BC, V, S);
+    hipLaunchKernelGGL(vx_in_bwd_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, part_ws, V, S, m_ws);
+    if (S > 1) hipLaunchKernelGGL(vx_in_bwd_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, m_ws, BC, V, S);
     hipLaunchKernelGGL(vx_in_bwd_apply_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, m_ws, act, dy, V);
     VX_LAUNCH_CHECK("vx_in_bwd");
     return 0;
@@ -352,7 +370,9 @@ extern "C" int vx_add(const float* a, const float* b, const float* c, float* out
 }
 extern "C" int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream) {
     VX_REQUIRE(dy && db && B > 0 && C > 0 && V > 0, "vx_channel_sum: bad args");
-    hipLaunchKernelGGL(vx_channel_sum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, V);
+    int chunks = vx_cdiv((long)B * V, 256 * 16);
+    if (chunks > 32) chunks = 32;
+    hipLaunchKernelGGL(vx_channel_sum_k, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, V);
     VX_LAUNCH_CHECK("vx_channel_sum");
     return 0;
 }
