@@ -14,6 +14,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import veloxseg_amd  # noqa: E402,F401  (first: configures the HIP runtime before anything initialises it)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -151,3 +151,37 @@ def test_engine_graph_and_two_phase_backward_match_plain_step(golden_dir):
     assert all(abs(a - b) <= 2e-4 * abs(a) for a, b in zip(la, lb)), (la, lb)
     assert la[2] < la[0], "three AdamW steps on a fixed batch must reduce the loss"
     assert float((ea.flat.param - eb.flat.param).abs().max()) < 5e-4
+
+
+def test_graph_replay_after_device_sync_matches_eager():
+    """Regression for the ROCm 7.2 graph-packet-capture fault (veloxseg_amd/__init__.py): replays separated by
+    hipDeviceSynchronize used to return garbage (loss 1e6 .. inf) from the second replay on at 128^3.  With the runtime
+    configured by the package the captured step must track the eager step, dropout streams included."""
+    import types
+    import veloxseg_amd
+    from bench import LOSS_CFG as BL, WORKLOADS, synth
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    assert veloxseg_amd.GRAPH_REPLAY_SAFE, "package must be imported before the HIP runtime initialises"
+    cfg, _ = WORKLOADS["autopet128"]
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), BL, None, num_modal=2)
+    x, lab = synth(cfg, 1, "cuda", 12345)
+    losses = {}
+    for use_graph in (False, True):
+        torch.manual_seed(12345)
+        model = VeloxSeg(**cfg).cuda()
+        VF.manual_seed(5, "cuda")
+        eng = TrainEngine(model, crit, (1, 2, 128, 128, 128), use_graph=use_graph, overlap=False)
+        assert eng.use_graph == use_graph
+        out = []
+        for it in range(5):
+            l = eng.step(x, lab) if it == 0 else eng.step()
+            torch.cuda.synchronize()
+            out.append(float(l))
+        losses[use_graph] = out
+        del eng, model
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 2e-3 * abs(a), losses
+    assert losses[True][-1] < losses[True][0]

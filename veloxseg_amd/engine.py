@@ -12,11 +12,13 @@ the encoder outputs: the decoder bucket's all-reduce runs on a side stream while
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+import veloxseg_amd as _pkg
 from . import _hip as H
 from . import functional as VF
 
@@ -80,6 +82,10 @@ class TrainEngine:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.overlap = overlap and self.world > 1
+        if use_graph and not _pkg.GRAPH_REPLAY_SAFE:
+            warnings.warn("veloxseg_amd was imported after the HIP runtime initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; "
+                          "hipGraph replay is unsafe on this ROCm (see veloxseg_amd/__init__.py) -- TrainEngine launches eagerly")
+            use_graph = False
         self.use_graph = use_graph
         B = batch_shape[0]
         self.x = torch.zeros(batch_shape, device=self.dev, dtype=torch.float32)
@@ -147,7 +153,7 @@ class TrainEngine:
     # ---- capture --------------------------------------------------------------------------------
     def _capture(self):
         self.model.train()
-        VF.rng_state(self.dev)
+        rng0 = VF.rng_state(self.dev).clone()
         self.flat.reattach()
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream())
@@ -159,6 +165,7 @@ class TrainEngine:
                 else:
                     self._fwd_bwd_single()
         torch.cuda.current_stream().wait_stream(s)
+        VF.rng_state(self.dev).copy_(rng0)        # the warm-up steps must not consume dropout streams: graph == eager run
         torch.cuda.synchronize()
         if self.overlap:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -35,7 +35,17 @@ def new_dropout_site() -> int:
     return next(_site_counter)
 
 
+def reset_dropout_sites():
+    """Called at the top of VeloxSeg.__init__: site ids are then a function of the architecture only, so two models built
+    from the same config draw the same dropout streams for the same (seed, step)."""
+    global _site_counter
+    _site_counter = itertools.count(1)
+
+
 def rng_state(device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())      # "cuda" and "cuda:0" must name the same state
     key = str(device)
     if key not in _rng_state:
         _rng_state[key] = torch.tensor([12345, 0], dtype=torch.int64, device=device)

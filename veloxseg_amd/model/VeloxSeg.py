@@ -24,6 +24,7 @@ class VeloxSeg(nn.Module):
         super().__init__()
         if spatial_dim != 3:
             raise NotImplementedError("veloxseg_amd implements the 3-D network (all shipped configs)")
+        VF.reset_dropout_sites()
         self.size = list(input_size)
         self.spatial_dim = spatial_dim
         self.patch_size = patch_size
