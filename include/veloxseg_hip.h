@@ -138,6 +138,9 @@ int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float*
                     const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
                     const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+/* tuning knob of the two entries above: key/query split per 64-row unit (0 = automatic from the unit count, else 1, 2 or 4; clamped to the
+ * number of 64-row slabs).  Results are identical up to fp32 summation order; the dropout mask does not depend on it. */
+int vx_pwa_attn_set_split(int S);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss side (utils/loss.py:30-66, common_function.py:8-14, VeloxSeg.py:177-184)

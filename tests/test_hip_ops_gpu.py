@@ -207,6 +207,79 @@ def test_pwa_core(case):
     run_pair(g, c, qkv, [table], atol=3e-5, rtol=3e-4, what=name)
 
 
+@pytest.mark.parametrize("grid,big,heads,mdh,C", [([12, 12, 12], [6, 6, 6], 2, 8, 32), ([6, 6, 6], [3, 3, 3], 1, 4, 16), ([16, 16, 16], [8, 8, 8], 2, 8, 32)],
+                         ids=["ML432", "ML54_unaligned", "ML1024"])
+def test_pwa_attention_dropout_and_key_splits(grid, big, heads, mdh, C):
+    """Attention dropout (p = 0.3) and the key/query split of the attention kernels.
+    (a) S = 1, 2, 4 give the same outputs and gradients (the mask is a function of (seed, step, site, element) only);
+    (b) forward and backward use the same mask: <O(V), G> == <V, dV(G)> (O is linear in V) and a central difference along a random
+        direction of q matches <dq, direction>;
+    (c) the mask keeps ~70 % of the pairs: with q = k = 0, v = 1 every output is the mean of its row's mask (expectation 1)."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    M = 2
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    n = pl["n"]
+    table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+    base = []
+    for m in range(M):
+        base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
+    gouts = None
+
+    def run(S, tensors=None, backward=True):
+        nonlocal gouts
+        H.call("vx_pwa_attn_set_split", S)
+        VF.manual_seed(77, d)
+        t = [b.clone().to(d).requires_grad_(True) for b in (tensors or base)]
+        table.grad = None
+        outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=0.3, site=9)
+        if gouts is None:
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) for i, o in enumerate(outs)]
+        if backward:
+            torch.autograd.backward(outs, gouts)
+        torch.cuda.synchronize()
+        return [o.detach() for o in outs], [x.grad for x in t] + [table.grad.clone()] if backward else None
+
+    try:
+        o1, g1 = run(1)
+        for S in (2, 4):
+            oS, gS = run(S)
+            for i, (a, b) in enumerate(zip(oS + gS, o1 + g1)):
+                close(a, b, 2e-5 * max(1.0, float(b.abs().max())), 1e-4, f"split {S} tensor {i}")
+        H.call("vx_pwa_attn_set_split", 0)
+        o0, g0 = run(0)
+        # (b) adjoint in v (modality 0) and directional derivative in q (modality 1)
+        zero_v = [b.clone() for b in base]
+        zero_v[5] = torch.zeros_like(base[5])                    # O = A(v0) + B(v1), both positively homogeneous (max-pool + linear maps)
+        oz, _ = run(0, zero_v, backward=False)                   # => <A(v0), G> = <v0, dv0> (Euler), A(v0) = O(v0, 0)
+        lhs0 = sum(float((o.double() * g.double()).sum()) for o, g in zip(oz, gouts))
+        rhs0 = float((base[2].to(d).double() * g0[2].double()).sum())
+        assert abs(lhs0 - rhs0) <= 2e-4 * max(1.0, abs(rhs0)), ("v adjoint", lhs0, rhs0)
+        dirq = rnd(*base[3].shape, seed=91)
+        eps = 1e-2
+        vals = []
+        for sgn in (+1, -1):
+            tt = [b.clone() for b in base]
+            tt[3] = base[3] + sgn * eps * dirq
+            oo, _ = run(0, tt, backward=False)
+            vals.append(sum(float((o.double() * g.double()).sum()) for o, g in zip(oo, gouts)))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((g0[3].double() * dirq.to(d).double()).sum())
+        assert abs(fd - an) <= 5e-2 * max(1.0, abs(an)), ("q directional derivative", fd, an)
+        # (c) mask statistics
+        flat = [torch.zeros_like(b) if i % 3 != 2 else torch.ones_like(b) for i, b in enumerate(base)]
+        table0 = table.detach() * 0
+        VF.manual_seed(78, d)
+        tq = VF.pwa_core(table0, plan, pl["c_qk"], pl["c_v"], [f.to(d) for f in flat], p_attn=0.3, site=9)
+        mean = float(torch.stack([t.mean() for t in tq]).mean())
+        assert abs(mean - 1.0) < 2e-2, mean
+        assert float(tq[0].std()) > 1e-3, "dropout must perturb the rows"
+    finally:
+        H.call("vx_pwa_attn_set_split", 0)
+
+
 def test_upsample_and_gram():
     VF = _vf()
     x = rnd(2, 3, 4, 6, 3)

@@ -274,14 +274,17 @@ __device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __r
     }
 }
 
-// unit = (bh, window, 64-query chunk); one wave per unit, 4 units per block.  Keys/values are staged 64 rows at a time
-// into a per-wave LDS slab (coalesced global read, one row per lane) and consumed as broadcast ds_read_b128.
+// unit = (bh, window, 64-query chunk).  A block is 4 waves = (4/S) units x S key splits: wave (u, s) walks the 64-row K/V slabs
+// s, s+S, s+2S, ... of its window (staged in a per-wave LDS slab: coalesced global read, one row per lane, consumed as broadcast
+// ds_read_b128) and the S partial soft-max states of a unit are merged through LDS.  S > 1 keeps the 1024-key windows of the 8^3
+// level from running one wave per SIMD.  Attention dropout: one Philox call per 4 consecutive keys (vx_drop4).
 #define VX_KV_ROWS 64
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                          const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
-                                                         int Tsz, VxAttn A, VxDrop drop) {
+                                                         int Tsz, VxAttn A, VxDrop drop, int S) {
     constexpr int RS = CQ + CV;
+    static_assert(RS >= CV + 2, "the merge reuses the slab rows");
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
@@ -289,11 +292,15 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
     vx_attn_tables(A, table, Tsz, lin, bias_all);
     __syncthreads();
+    const VxDropCtx dc = vx_drop_ctx(drop);
+    const bool al4 = (A.ML & 3) == 0;
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long u = (long)blockIdx.x * 4 + wave;
-    if (u >= units) return;
+    const int split = wave % S;
+    const long u_raw = (long)blockIdx.x * (4 / S) + wave / S;
+    const bool active = u_raw < units;
+    const long u = active ? u_raw : units - 1;
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
@@ -301,8 +308,8 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const int a = (int)((win / A.Nt) % A.heads);
     const float* __restrict__ bias = bias_all + (long)a * Tsz;
     const int i = chunk * 64 + lane;
-    const bool ok = i < A.ML;
-    const int iq = ok ? i : A.ML - 1;
+    const bool ok = active && i < A.ML;
+    const int iq = (i < A.ML) ? i : A.ML - 1;
     const float* __restrict__ qp = Q + (win * A.ML + iq) * CQ;
     float q[CQ];
 #pragma unroll
@@ -315,9 +322,9 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = ((uint64_t)win * A.ML + iq) * (uint64_t)A.ML;
-    int tj = 0;                                        // key token index modulo l (keys are modality-major)
-    for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
+    for (int j0 = split * VX_KV_ROWS; j0 < A.ML; j0 += S * VX_KV_ROWS) {
         const int nk = min(VX_KV_ROWS, A.ML - j0);
+        int tj = j0 % A.l;                             // key token index modulo l (keys are modality-major)
         __builtin_amdgcn_wave_barrier();
         if (lane < nk) {
 #pragma unroll
@@ -326,20 +333,46 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
             for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int jj = 0; jj < nk; ++jj) {
-            const float* __restrict__ row = slab + jj * RS;
-            float s = 0.0f;
+        for (int jj = 0; jj < nk; jj += 4) {
+            float m4[4];
+            vx_drop4(dc, drow + j0 + jj, al4, m4);
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) s = fmaf(q[c], row[c], s);
-            s += bias[lin_i - lin[tj]];
-            if (++tj == A.l) tj = 0;
-            const float mn = fmaxf(mrun, s);
-            const float alpha = __expf(mrun - mn);
-            const float p = __expf(s - mn);
-            lsum = lsum * alpha + p;
-            const float pd = p * vx_drop(drop, drow + j0 + jj);
+            for (int t = 0; t < 4; ++t) {
+                if (jj + t < nk) {
+                    const float* __restrict__ row = slab + (jj + t) * RS;
+                    float s = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CV; ++c) acc[c] = fmaf(pd, row[CQ + c], acc[c] * alpha);
+                    for (int c = 0; c < CQ; ++c) s = fmaf(q[c], row[c], s);
+                    s += bias[lin_i - lin[tj]];
+                    if (++tj == A.l) tj = 0;
+                    const float mn = fmaxf(mrun, s);
+                    const float alpha = __expf(mrun - mn);
+                    const float p = __expf(s - mn);
+                    lsum = lsum * alpha + p;
+                    const float pd = p * m4[t];
+#pragma unroll
+                    for (int c = 0; c < CV; ++c) acc[c] = fmaf(pd, row[CQ + c], acc[c] * alpha);
+                    mrun = mn;
+                }
+            }
+        }
+    }
+    if (S > 1) {                                       // merge the S partial states of a unit (every split saw >= 1 slab: launcher)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CV; ++c) slab[lane * RS + c] = acc[c];
+        slab[lane * RS + CV] = mrun;
+        slab[lane * RS + CV + 1] = lsum;
+        __syncthreads();
+        if (split != 0) return;
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float* __restrict__ o = slab + (long)s2 * VX_KV_ROWS * RS + lane * RS;
+            const float m2 = o[CV], l2 = o[CV + 1];
+            const float mn = fmaxf(mrun, m2);
+            const float a1 = __expf(mrun - mn), a2 = __expf(m2 - mn);
+            lsum = lsum * a1 + l2 * a2;
+#pragma unroll
+            for (int c = 0; c < CV; ++c) acc[c] = acc[c] * a1 + o[c] * a2;
             mrun = mn;
         }
     }
@@ -352,29 +385,34 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     }
 }
 
-// backward A: lane = query row.  dQ, delta = rowsum(dO*O), d(bias table) (LDS-staged atomics)
+// backward A: lane = query row.  dQ, delta = rowsum(dO*O), d(bias table).  Same (unit, key split) decomposition as the forward;
+// the d(bias) of a unit is accumulated in ONE LDS table shared by its S waves (ds_add_f32), then flushed with float atomics.
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                           float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop) {
+                                                           float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop, int S) {
     constexpr int RS = CQ + CV;
-    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // lin | bias tables | [4][Tsz] bias-gradient tables | [4] K/V slabs
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // lin | bias tables | [4/S][Tsz] bias-gradient tables | [4] K/V slabs
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
     float* __restrict__ bias_all = vx_sm + lin_pad;
     float* __restrict__ gtabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
-    float* __restrict__ slabs = gtabs + (((long)4 * Tsz + 3) & ~3);
+    const int upb = 4 / S;
+    float* __restrict__ slabs = gtabs + (((long)upb * Tsz + 3) & ~3);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    float* __restrict__ stab = gtabs + (long)wave * Tsz;
+    const int split = wave % S;
+    float* __restrict__ stab = gtabs + (long)(wave / S) * Tsz;
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     vx_attn_tables(A, table, Tsz, lin, bias_all);
-    for (int k = lane; k < Tsz; k += 64) stab[k] = 0.0f;
+    for (int k = threadIdx.x; k < upb * Tsz; k += 256) gtabs[k] = 0.0f;
     __syncthreads();
+    const VxDropCtx dc = vx_drop_ctx(drop);
+    const bool al4 = (A.ML & 3) == 0;
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    const long u_raw = (long)blockIdx.x * 4 + wave;
+    const long u_raw = (long)blockIdx.x * upb + wave / S;
     const bool active = u_raw < units;
     const long u = active ? u_raw : units - 1;
     const int chunk = (int)(u % chunks);
@@ -396,9 +434,9 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
-    int tj = 0;
-    for (int j0 = 0; j0 < A.ML; j0 += VX_KV_ROWS) {
+    for (int j0 = split * VX_KV_ROWS; j0 < A.ML; j0 += S * VX_KV_ROWS) {
         const int nk = min(VX_KV_ROWS, A.ML - j0);
+        int tj = j0 % A.l;
         __builtin_amdgcn_wave_barrier();
         if (lane < nk) {
 #pragma unroll
@@ -407,43 +445,66 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
             for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int jj = 0; jj < nk; ++jj) {
-            const float* __restrict__ kr = slab + jj * RS;
-            float s = 0.0f;
+        for (int jj = 0; jj < nk; jj += 4) {
+            float m4[4];
+            vx_drop4(dc, drow + j0 + jj, al4, m4);
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
-            const int bi = lin_i - lin[tj];
-            if (++tj == A.l) tj = 0;
-            s += bias[bi];
-            const float p = __expf(s - lse);
-            float dp = 0.0f;
+            for (int t = 0; t < 4; ++t) {
+                if (jj + t < nk) {
+                    const float* __restrict__ kr = slab + (jj + t) * RS;
+                    float s = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
-            dp *= vx_drop(drop, drow + j0 + jj);
-            const float ds = ok ? p * (dp - delta) : 0.0f;
+                    for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
+                    const int bi = lin_i - lin[tj];
+                    if (++tj == A.l) tj = 0;
+                    s += bias[bi];
+                    const float p = __expf(s - lse);
+                    float dp = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
-            atomicAdd(stab + bi, ds);
+                    for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
+                    dp *= m4[t];
+                    const float ds = ok ? p * (dp - delta) : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
+                    atomicAdd(stab + bi, ds);
+                }
+            }
         }
     }
-    if (ok) {
+    if (S > 1) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) dQ[row * CQ + c] = dq[c] * A.scale;
-        Delta[row] = delta;
+        for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = dq[c];
     }
     __syncthreads();
-    for (int k = lane; k < Tsz; k += 64) {
-        const float g = stab[k];
-        if (g != 0.0f) atomicAdd(dtable + (long)k * A.heads + a, g);
+    if (split == 0) {
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float* __restrict__ o = slab + (long)s2 * VX_KV_ROWS * RS + lane * RS;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) dq[c] += o[c];
+        }
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) dQ[row * CQ + c] = dq[c] * A.scale;
+            Delta[row] = delta;
+        }
+    }
+    if (active) {
+        for (int k = split * 64 + lane; k < Tsz; k += 64 * S) {
+            const float g = stab[k];
+            if (g != 0.0f) atomicAdd(dtable + (long)k * A.heads + a, g);
+        }
     }
 }
 
-// backward B: lane = key row.  dK, dV.  Query-side rows (q, dO, lse, delta) are staged per wave in LDS.
+// backward B: lane = key row.  dK, dV.  Query-side rows (q, dO, lse, delta) are staged per wave in LDS; the S splits of a unit walk
+// interleaved query slabs and are summed through LDS.  Dropout: lane (quad position t) draws the Philox counter of query row i+t
+// for its quad's 4 keys; a quad transpose (DPP) hands every lane its own key's word for the 4 rows -> one Philox call per 4 pairs.
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
-                                                            int Tsz, VxAttn A, VxDrop drop) {
+                                                            int Tsz, VxAttn A, VxDrop drop, int S) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
@@ -452,11 +513,15 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
     vx_attn_tables(A, table, Tsz, lin, bias_all);
     __syncthreads();
+    const VxDropCtx dc = vx_drop_ctx(drop);
+    const bool al4 = (A.ML & 3) == 0;
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long u = (long)blockIdx.x * 4 + wave;
-    if (u >= units) return;
+    const int split = wave % S;
+    const long u_raw = (long)blockIdx.x * (4 / S) + wave / S;
+    const bool active = u_raw < units;
+    const long u = active ? u_raw : units - 1;
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     const int lane = threadIdx.x & 63;
     const int chunk = (int)(u % chunks);
@@ -464,8 +529,8 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     const int a = (int)((win / A.Nt) % A.heads);
     const float* __restrict__ bias = bias_all + (long)a * Tsz;
     const int j = chunk * 64 + lane;
-    const bool ok = j < A.ML;
-    const int jk = ok ? j : A.ML - 1;
+    const bool ok = active && j < A.ML;
+    const int jk = (j < A.ML) ? j : A.ML - 1;
     const long krow = win * A.ML + jk;
     float k[CQ], dk[CQ], v[CV], dv[CV];
 #pragma unroll
@@ -475,9 +540,10 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     const int lin_j = lin[jk % A.l] - A.lin_cst;
     const float* __restrict__ qp = Q + win * A.ML * CQ;
     const float* __restrict__ dop = dO + win * A.ML * CV;
-    int ti = 0;
-    for (int i0 = 0; i0 < A.ML; i0 += VX_KV_ROWS) {
+    const int qt = lane & 3;
+    for (int i0 = split * VX_KV_ROWS; i0 < A.ML; i0 += S * VX_KV_ROWS) {
         const int nq = min(VX_KV_ROWS, A.ML - i0);
+        int ti = i0 % A.l;
         __builtin_amdgcn_wave_barrier();
         if (lane < nq) {
 #pragma unroll
@@ -488,25 +554,59 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
             slab[lane * RS + CQ + CV + 1] = Delta[win * A.ML + i0 + lane];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int ii = 0; ii < nq; ++ii) {
-            const float* __restrict__ qr = slab + ii * RS;
-            const int i = i0 + ii;
-            float s = 0.0f;
+        for (int ii = 0; ii < nq; ii += 4) {
+            float m4[4];
+            if (!dc.on) {
+                m4[0] = m4[1] = m4[2] = m4[3] = 1.0f;
+            } else if (al4) {                          // ML % 4 == 0: quads are counter-aligned for every row, nq % 4 == 0
+                uint32_t r[4], w[4];
+                const uint64_t idx = ((uint64_t)(win * A.ML + i0 + ii + qt)) * (uint64_t)A.ML + (uint64_t)(jk & ~3);
+                vx_philox4(dc.seed, dc.stream, idx >> 2, r);
+                vx_quad_transpose4(r, w);
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) s = fmaf(qr[c], k[c], s);
-            s = s * A.scale + bias[lin[ti] - lin_j];
-            if (++ti == A.l) ti = 0;
-            const float p = __expf(s - qr[CQ + CV]);
-            const float msk = vx_drop(drop, ((uint64_t)(win * A.ML + i)) * (uint64_t)A.ML + jk);
-            float dp = 0.0f;
+                for (int t = 0; t < 4; ++t) m4[t] = vx_mask_of_bits(dc, w[t]);
+            } else {
 #pragma unroll
-            for (int c = 0; c < CV; ++c) dp = fmaf(qr[CQ + c], v[c], dp);
-            const float pd = p * msk;
+                for (int t = 0; t < 4; ++t) m4[t] = vx_drop1(dc, ((uint64_t)(win * A.ML + min(i0 + ii + t, A.ML - 1))) * (uint64_t)A.ML + jk);
+            }
 #pragma unroll
-            for (int c = 0; c < CV; ++c) dv[c] = fmaf(pd, qr[CQ + c], dv[c]);
-            const float ds = p * (dp * msk - qr[CQ + CV + 1]) * A.scale;
+            for (int t = 0; t < 4; ++t) {
+                if (ii + t < nq) {
+                    const float* __restrict__ qr = slab + (ii + t) * RS;
+                    float s = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) dk[c] = fmaf(ds, qr[c], dk[c]);
+                    for (int c = 0; c < CQ; ++c) s = fmaf(qr[c], k[c], s);
+                    s = s * A.scale + bias[lin[ti] - lin_j];
+                    if (++ti == A.l) ti = 0;
+                    const float p = __expf(s - qr[CQ + CV]);
+                    const float msk = m4[t];
+                    float dp = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CV; ++c) dp = fmaf(qr[CQ + c], v[c], dp);
+                    const float pd = p * msk;
+#pragma unroll
+                    for (int c = 0; c < CV; ++c) dv[c] = fmaf(pd, qr[CQ + c], dv[c]);
+                    const float ds = p * (dp * msk - qr[CQ + CV + 1]) * A.scale;
+#pragma unroll
+                    for (int c = 0; c < CQ; ++c) dk[c] = fmaf(ds, qr[c], dk[c]);
+                }
+            }
+        }
+    }
+    if (S > 1) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = dk[c];
+#pragma unroll
+        for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = dv[c];
+        __syncthreads();
+        if (split != 0) return;
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float* __restrict__ o = slab + (long)s2 * VX_KV_ROWS * RS + lane * RS;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) dk[c] += o[c];
+#pragma unroll
+            for (int c = 0; c < CV; ++c) dv[c] += o[c + CQ];
         }
     }
     if (ok) {
@@ -611,6 +711,23 @@ static int vx_attn_fill(VxAttn& A, const VxPwaPlan* P, int B, int M, int cq, int
     return 0;
 }
 
+// key/query split S of the attention kernels: enough waves to fill 256 CUs x 4 SIMDs several times over, never more splits than slabs
+static int vx_attn_split_override = 0;
+extern "C" int vx_pwa_attn_set_split(int S) {
+    if (S != 0 && S != 1 && S != 2 && S != 4) VX_FAIL(-1, "vx_pwa_attn_set_split: S must be 0 (auto), 1, 2 or 4");
+    vx_attn_split_override = S;
+    return 0;
+}
+static int vx_attn_split(long units, int ML) {
+    const int nslabs = (ML + 63) / 64;
+    int S = 1;
+    if (vx_attn_split_override) S = vx_attn_split_override;
+    else if (units * 2 < 4096) S = 4;
+    else if (units < 4096) S = 2;
+    while (S > nslabs) S >>= 1;
+    return S;
+}
+
 template <int A_, int B_> struct vx_pair { static constexpr int a = A_, b = B_; };
 // returns false when the (c_qk, c_v) pair has no instantiation
 template <class F> static bool vx_attn_dispatch(int cq, int cv, F&& f) {
@@ -632,9 +749,10 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
     const size_t shm = (tab_f + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    const int S = vx_attn_split(units, A.ML);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_fwd: tables do not fit LDS (%d entries x %d heads)", Tsz, A.heads);
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
-        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d);
+        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_fwd");
@@ -651,14 +769,15 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
-    const size_t shm = (tab_f + (((size_t)4 * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    const int S = vx_attn_split(units, A.ML);
+    const size_t shm = (tab_f + (((size_t)(4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     const size_t shm_kv = (tab_f + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
-        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, dtable, Tsz, A, d);
-        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4)), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, Tsz, A, d);
+        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, dtable, Tsz, A, d, S);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, Tsz, A, d, S);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd");

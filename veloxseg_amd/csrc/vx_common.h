@@ -108,3 +108,58 @@ __device__ __forceinline__ float vx_drop(const VxDrop& d, uint64_t idx) {
     const uint64_t seed = d.seed_ptr[0] + 0x9E3779B97F4A7C15ull * d.seed_ptr[1];
     return vx_dropout_scale(seed, d.stream, idx, d.p, 1.0f / (1.0f - d.p));
 }
+
+// Dropout context hoisted out of inner loops: the {seed, step} pair is read once (scalar loads), masks are derived from raw Philox words.
+// Element idx always maps to word (idx & 3) of philox(seed, stream, idx >> 2), so any kernel may amortise one Philox call over the four
+// elements that share a counter without changing the mask.
+struct VxDropCtx {
+    uint64_t seed, stream;
+    float p, inv_keep;
+    bool on;
+};
+__device__ __forceinline__ VxDropCtx vx_drop_ctx(const VxDrop& d) {
+    VxDropCtx c;
+    c.on = d.seed_ptr != nullptr && d.p > 0.0f;
+    c.stream = d.stream;
+    c.p = d.p;
+    c.inv_keep = c.on ? 1.0f / (1.0f - d.p) : 1.0f;
+    c.seed = c.on ? d.seed_ptr[0] + 0x9E3779B97F4A7C15ull * d.seed_ptr[1] : 0ull;
+    return c;
+}
+__device__ __forceinline__ float vx_mask_of_bits(const VxDropCtx& c, uint32_t bits) {
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    return u >= c.p ? c.inv_keep : 0.0f;
+}
+__device__ __forceinline__ float vx_drop1(const VxDropCtx& c, uint64_t idx) {
+    if (!c.on) return 1.0f;
+    uint32_t r[4];
+    vx_philox4(c.seed, c.stream, idx >> 2, r);
+    return vx_mask_of_bits(c, r[idx & 3]);
+}
+// masks of elements idx0 .. idx0+3; one Philox call when idx0 is a multiple of 4 (`aligned`, wave-uniform), four otherwise
+__device__ __forceinline__ void vx_drop4(const VxDropCtx& c, uint64_t idx0, bool aligned, float (&m)[4]) {
+    if (!c.on) {
+        m[0] = m[1] = m[2] = m[3] = 1.0f;
+    } else if (aligned) {
+        uint32_t r[4];
+        vx_philox4(c.seed, c.stream, idx0 >> 2, r);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[t] = vx_mask_of_bits(c, r[t]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[t] = vx_drop1(c, idx0 + t);
+    }
+}
+// Quad transpose of Philox words: the 4 lanes of an aligned quad hold words r[0..3] of four different counters (lane t: counter t).
+// Returns in out[t] the word (lane & 3) of the quad's lane t, i.e. lane s ends with element s of each of the four counters.
+#define VX_QUAD_BCAST(v, T) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (T) * 0x55, 0xF, 0xF, true))
+__device__ __forceinline__ void vx_quad_transpose4(const uint32_t (&r)[4], uint32_t (&out)[4]) {
+    const int s = threadIdx.x & 3;
+#define VX_QT(T)                                                                                                   \
+    {                                                                                                              \
+        const uint32_t w0 = VX_QUAD_BCAST(r[0], T), w1 = VX_QUAD_BCAST(r[1], T), w2 = VX_QUAD_BCAST(r[2], T), w3 = VX_QUAD_BCAST(r[3], T); \
+        out[T] = s == 0 ? w0 : s == 1 ? w1 : s == 2 ? w2 : w3;                                                      \
+    }
+    VX_QT(0) VX_QT(1) VX_QT(2) VX_QT(3)
+#undef VX_QT
+}
