@@ -1,6 +1,6 @@
 """Data-parallel engine on real kernels: two processes (world_size 2, gloo backend so that both can share the one MI355X of the
-test box; the production backend is "nccl" = RCCL) run TrainEngine with the hipGraph two-phase backward and the two-bucket
-all-reduce; their averaged gradient and the parameters after the AdamW step must equal those of a single process trained on the concatenated batch."""
+test box; the production backend is "nccl" = RCCL) run TrainEngine -- eager launches and per-stage hipGraphs -- with the staged
+backward and the two-bucket all-reduce; their averaged gradient and the parameters after the AdamW step must equal those of a single process trained on the concatenated batch."""
 import os
 import socket
 import sys
@@ -39,13 +39,13 @@ def _setup():
     return cfg_d, crit, x, lab, model, TrainEngine
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, use_graph):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
-    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=True, overlap=True)
+    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True)
     assert eng.world == 2 and eng.overlap
     loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
     torch.cuda.synchronize()
@@ -56,12 +56,13 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_engine_equals_single_process(tmp_path):
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graphs"])
+def test_two_rank_engine_equals_single_process(tmp_path, use_graph):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
     dp = torch.load(os.path.join(str(tmp_path), "dp.pt"))
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
-    eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=True, overlap=True)     # world 1: overlap off automatically
+    eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=False, overlap=True)    # world 1: overlap off automatically
     eng.step(x.cuda(), lab.cuda())
     torch.cuda.synchronize()
     g_ref = eng.flat.grad.cpu()

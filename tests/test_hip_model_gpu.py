@@ -116,8 +116,8 @@ def test_full_size_properties_128():
 
 
 def test_engine_graph_and_two_phase_backward_match_plain_step(golden_dir):
-    """TrainEngine: (a) the two-phase backward used to overlap the decoder bucket's all-reduce gives the same gradients as one
-    backward; (b) the hipGraph-captured step reproduces the eager step; (c) the fused AdamW moves the flat parameters."""
+    """TrainEngine: (a) the staged pass (enc_fwd, dec_fwd[k], loss, dec_bwd[k], enc_bwd with detached leaves in between) that
+    the per-stage hipGraphs are captured from gives the same gradients as one plain backward; (b) the hipGraph-captured step reproduces the eager step; (c) the fused AdamW moves the flat parameters."""
     import types
     from veloxseg_amd import functional as VF
     from veloxseg_amd.engine import TrainEngine
@@ -140,9 +140,9 @@ def test_engine_graph_and_two_phase_backward_match_plain_step(golden_dir):
     e1._fwd_bwd_single()
     g_single = e1.flat.grad.clone()
     VF.manual_seed(99, "cuda")
-    e1._phase1(); e1._phase2()
+    e1._eager_pass()                       # the staged pass (detached leaves at the encoder and decoder outputs)
     torch.cuda.synchronize()
-    assert float((e1.flat.grad - g_single).abs().max()) <= 1e-5 * float(g_single.abs().max()), "two-phase backward differs"
+    assert float((e1.flat.grad - g_single).abs().max()) <= 1e-5 * float(g_single.abs().max()), "staged backward differs"
     assert e1.flat.split > 0 and e1.flat.split < e1.flat.numel
     # graph vs eager, 3 optimisation steps each (dropout p=0 in this config => deterministic)
     ea, eb = make(False), make(True)
@@ -154,17 +154,15 @@ def test_engine_graph_and_two_phase_backward_match_plain_step(golden_dir):
 
 
 def test_graph_replay_after_device_sync_matches_eager():
-    """Regression for the ROCm 7.2 graph-packet-capture fault (veloxseg_amd/__init__.py): replays separated by
-    hipDeviceSynchronize used to return garbage (loss 1e6 .. inf) from the second replay on at 128^3.  With the runtime
-    configured by the package the captured step must track the eager step, dropout streams included."""
+    """Regression for the ROCm 7.2 single-chain graph replay fault (veloxseg_amd/__init__.py): replays separated by
+    hipDeviceSynchronize used to return garbage (loss 1e6 .. inf) from the second replay on at 128^3.  The engine's multi-branch
+    capture must survive its own self-check (use_graph stays True) and track the eager step, dropout streams included."""
     import types
-    import veloxseg_amd
     from bench import LOSS_CFG as BL, WORKLOADS, synth
     from veloxseg_amd import functional as VF
     from veloxseg_amd.engine import TrainEngine
     from veloxseg_amd.model.VeloxSeg import VeloxSeg
     from veloxseg_amd.utils.loss import Loss
-    assert veloxseg_amd.GRAPH_REPLAY_SAFE, "package must be imported before the HIP runtime initialises"
     cfg, _ = WORKLOADS["autopet128"]
     crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), BL, None, num_modal=2)
     x, lab = synth(cfg, 1, "cuda", 12345)
@@ -180,6 +178,7 @@ def test_graph_replay_after_device_sync_matches_eager():
             l = eng.step(x, lab) if it == 0 else eng.step()
             torch.cuda.synchronize()
             out.append(float(l))
+        assert eng.use_graph == use_graph, "graph self-check failed: engine fell back to eager launches"
         losses[use_graph] = out
         del eng, model
     for a, b in zip(losses[False], losses[True]):

@@ -13,21 +13,25 @@ import sys as _sys
 
 
 def _configure_hip_runtime():
-    """ROCm 7.2 replays instantiated hipGraphs from pre-recorded AQL packets ("graph packet capture").  On gfx950 that path
-    intermittently replays this engine's ~1400-node training graph with corrupt results when the device was idle
-    (hipDeviceSynchronize) before the launch; the regular per-node dispatch path is correct and measures the same
-    (161.7 vs 162.4 patches/s).  The switch is read once, when the HIP runtime initialises, so it has to
-    be in the environment before the first HIP call of the process: importing this package first is enough.
-    Returns True when the setting is known to be in effect."""
-    want = "0"
-    cur = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
-    if cur is not None:
-        return cur == want
-    torch = _sys.modules.get("torch")
-    if torch is not None and torch.cuda.is_initialized():
-        return False                      # too late for this process; TrainEngine then launches eagerly instead of replaying
-    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = want
-    return True
+    """hipGraph dispatch mode of the HIP runtime (ROCm 7.2, gfx950).
+
+    Finding (tools/graph_replay_repro.py): an instantiated graph that is ONE chain of ~1400 kernel nodes is replayed
+    through a batched AQL-packet path (DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) that intermittently returns garbage for this
+    step when the device was idle (hipDeviceSynchronize) before the launch.  Graphs with more than one branch take the per-node path,
+    are correct in every trial, and run their branches concurrently.  TrainEngine therefore (1) always captures multi-branch
+    graphs (engine._forked + functional.run_branches), (2) verifies the replays against the eager pass after capture and falls
+    back to eager launches on any mismatch.  VELOXSEG_GRAPH_DISPATCH=nodes additionally turns the packet path off for the whole
+    process (slower: the per-node path then enqueues every kernel from the host, about 17 us each); it must be set before the
+    first HIP call, i.e. before or at `import veloxseg_amd`."""
+    mode = _os.environ.get("VELOXSEG_GRAPH_DISPATCH", "default")
+    if mode not in ("default", "nodes"):
+        raise ValueError("VELOXSEG_GRAPH_DISPATCH must be 'default' or 'nodes'")
+    if mode == "nodes" and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in _os.environ:
+        torch = _sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_initialized():
+            raise RuntimeError("VELOXSEG_GRAPH_DISPATCH=nodes: import veloxseg_amd before the first CUDA/HIP call of the process")
+        _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return mode
 
 
-GRAPH_REPLAY_SAFE = _configure_hip_runtime()
+GRAPH_DISPATCH = _configure_hip_runtime()

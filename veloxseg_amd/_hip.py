@@ -60,6 +60,7 @@ def _to_ctype(ty: str):
 class _Lib:
     def __init__(self):
         self._dll = None
+        self._fns = {}
         self.protos = parse_header()
 
     def load(self):
@@ -81,10 +82,12 @@ class _Lib:
         return dll
 
     def call(self, name: str, *args):
-        dll = self.load()
-        rc = getattr(dll, name)(*args)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = getattr(self.load(), name)
+        rc = fn(*args)
         if rc != 0:
-            msg = dll.vx_last_error()
+            msg = self._dll.vx_last_error()
             raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 
@@ -95,7 +98,14 @@ def available() -> bool:
     return os.path.exists(LIB_PATH)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of PyTorch's current stream on the current device (the raw getter is ~30x cheaper than building a Stream object;
+    this is called once per kernel launch)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -12,13 +12,13 @@ the encoder outputs: the decoder bucket's all-reduce runs on a side stream while
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
-import veloxseg_amd as _pkg
 from . import _hip as H
 from . import functional as VF
 
@@ -71,7 +71,7 @@ class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
-                 eps=1e-8, use_graph=True, overlap=True, process_group=None, warmup_steps=2):
+                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3):
         self.model, self.criterion = model, criterion
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
@@ -82,10 +82,6 @@ class TrainEngine:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.overlap = overlap and self.world > 1
-        if use_graph and not _pkg.GRAPH_REPLAY_SAFE:
-            warnings.warn("veloxseg_amd was imported after the HIP runtime initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; "
-                          "hipGraph replay is unsafe on this ROCm (see veloxseg_amd/__init__.py) -- TrainEngine launches eagerly")
-            use_graph = False
         self.use_graph = use_graph
         B = batch_shape[0]
         self.x = torch.zeros(batch_shape, device=self.dev, dtype=torch.float32)
@@ -94,6 +90,7 @@ class TrainEngine:
         self.graphs = None
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self._warm = warmup_steps
+        self.verify_replays = verify_replays
         if self.world > 1:
             dist.broadcast(self.flat.param, src=0, group=self.pg)      # identical replicas at start
 
@@ -103,44 +100,65 @@ class TrainEngine:
         return outs, self.criterion(outs, self.labels, sr_labels=self.x)
 
     def _fwd_bwd_single(self):
+        """plain eager step: model() runs the decoder branches on forked streams (functional.run_branches)"""
         self.flat.zero_grad()
         _, loss = self._forward_loss()
         loss.backward()
         self.loss.copy_(loss.detach())
 
-    def _phase1(self):
-        """forward + loss + backward through the decoders down to the encoder outputs"""
+    # ---- stages -------------------------------------------------------------------------------
+    # The step is cut at the encoder outputs and at the decoder outputs into stages that exchange DETACHED leaves:
+    #   enc_fwd -> { dec_fwd[k] } -> loss (+ its backward) -> { dec_bwd[k] } -> enc_bwd          k = 0..M (Seg decoder, M RC decoders)
+    # The braces run concurrently on one HIP stream per branch.  Eagerly the same functions run back to back (stage order is
+    # a valid serialisation), which is the reference the captured graphs are checked against.
+    def _s_enc_fwd(self):
         self.flat.zero_grad()
         VF.advance_rng(self.dev)
-        enc = self.model.encoder
-        attn, encs = enc(self.x)
-        # cut the autograd graph at the encoder outputs: the decoders consume detached leaves, so this phase touches decoder nodes
-        # only; the leaves' .grad then seed the encoder backward (phase 2), which adds the encoder-internal paths (enc_i -> down_{i+1}).
-        encs_d = [e.detach().requires_grad_(True) for e in encs]
-        attn_d = [[t.detach().requires_grad_(True) for t in lvl] for lvl in attn]
+        attn, encs = self.model.encoder(self.x)
         self._boundary = list(encs) + [t for lvl in attn for t in lvl]
-        leaves = encs_d + [t for lvl in attn_d for t in lvl]
-        outs = self._decode(attn_d, encs_d)
-        loss = self.criterion(outs, self.labels, sr_labels=self.x)
+
+    def _s_dec_fwd(self, k):
+        # every branch gets its own leaves (same storage, separate .grad), so concurrent branches never accumulate into one tensor
+        leaves = [t.detach().requires_grad_(True) for t in self._boundary]
+        M = self.model.num_modalities
+        encs, flat_attn = leaves[:4], leaves[4:]
+        attn = [flat_attn[L * M:(L + 1) * M] for L in range(4)]
+        self._leaves[k] = leaves
+        self._outs[k] = list(self.model.decode_branch(k, attn, encs))
+
+    def _s_loss(self):
+        outs_d = [[o.detach().requires_grad_(True) for o in outs] for outs in self._outs]
+        loss = self.criterion(self.model.assemble_train(outs_d), self.labels, sr_labels=self.x)
         loss.backward()
-        self._bgrads = [l.grad for l in leaves]
+        self._douts = [[o.grad for o in od] for od in outs_d]
         self.loss.copy_(loss.detach())
 
-    def _decode(self, attn, encs):
-        m = self.model
-        pred, dec_pram = m.decoder(*encs)
-        pred = [m.scale_prediction(p) for p in pred]
-        rcs, prams = [], []
-        for k in range(m.num_modalities):
-            rc, pr = m.rc_decoders[k]([attn[L][k] for L in range(4)], encs)
-            rcs.append(rc)
-            prams.append(pr)
-        rcs = rcs[0] if len(rcs) == 1 else torch.cat(rcs, dim=1)
-        return pred + [rcs] + [dec_pram] + prams
+    def _s_dec_bwd(self, k):
+        pairs = [(o, g) for o, g in zip(self._outs[k], self._douts[k]) if g is not None]
+        torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
-    def _phase2(self):
-        torch.autograd.backward(self._boundary, self._bgrads)
-        self._boundary = self._bgrads = None
+    def _s_enc_bwd(self):
+        bt, bg = [], []
+        for j, t in enumerate(self._boundary):
+            gs = [lv[j].grad for lv in self._leaves if lv[j].grad is not None]
+            if gs:
+                g = gs[0]
+                for h in gs[1:]:
+                    g = g + h
+                bt.append(t)
+                bg.append(g)
+        torch.autograd.backward(bt, bg)
+
+    def _eager_pass(self):
+        nb = self.model.num_branches
+        self._leaves, self._outs = [None] * nb, [None] * nb
+        self._s_enc_fwd()
+        for k in range(nb):
+            self._s_dec_fwd(k)
+        self._s_loss()
+        for k in range(nb):
+            self._s_dec_bwd(k)
+        self._s_enc_bwd()
 
     def _allreduce(self, lo, hi):
         dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
@@ -151,34 +169,102 @@ class TrainEngine:
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.t, 1.0 / self.world, H.stream_ptr())
 
     # ---- capture --------------------------------------------------------------------------------
+    def _forked(self, fn, *args):
+        """Run `fn` with a trivial side-stream branch alive around it, so that every captured graph has more than one branch.
+        ROCm 7.2 replays single-branch graphs through a batched AQL-packet path that intermittently corrupts this step after a
+        device synchronise (veloxseg_amd/__init__.py); multi-branch graphs take the ordinary per-node path."""
+        if os.environ.get("VX_NO_FORK") == "1":         # debugging only (tools/graph_replay_repro.py)
+            return fn(*args)
+        cur = torch.cuda.current_stream(self.dev)
+        self._fork_stream.wait_stream(cur)
+        with torch.cuda.stream(self._fork_stream):
+            self._fork_buf.add_(1.0)
+        fn(*args)
+        cur.wait_stream(self._fork_stream)
+
+    def _graph(self, pool, fn, *args):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            self._forked(fn, *args)
+        return g
+
     def _capture(self):
+        """One hipGraph per stage.  Branch graphs allocate from their own memory pool (a shared pool hands the blocks one capture freed
+        to the next capture, which is only safe when the graphs replay in capture order, not concurrently); tensors that cross
+        stages stay referenced by the engine for the lifetime of the graphs."""
         self.model.train()
-        rng0 = VF.rng_state(self.dev).clone()
+        rng = VF.rng_state(self.dev)
+        rng0 = rng.clone()
         self.flat.reattach()
+        nb = self.model.num_branches
+        self._fork_stream = torch.cuda.Stream(device=self.dev)
+        self._fork_buf = torch.zeros(64, device=self.dev)
+        self.branch_streams = [torch.cuda.Stream(device=self.dev) for _ in range(nb)]
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(self._warm):           # warm allocator / lazy inits outside the capture
-                if self.overlap:
-                    self._phase1()
-                    self._phase2()
-                else:
-                    self._fwd_bwd_single()
+            for _ in range(max(1, self._warm)):   # warm allocator / lazy inits outside the capture; the last pass is the reference
+                rng.copy_(rng0)
+                self._eager_pass()
+            ref = (self.loss.double().clone(), self.flat.grad.double().abs().sum())
         torch.cuda.current_stream().wait_stream(s)
-        VF.rng_state(self.dev).copy_(rng0)        # the warm-up steps must not consume dropout streams: graph == eager run
+        rng.copy_(rng0)                           # the warm-up steps must not consume dropout streams: graph == eager run
         torch.cuda.synchronize()
-        if self.overlap:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._phase1()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._phase2()
-            self.graphs = (g1, g2)
-        else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._fwd_bwd_single()
-            self.graphs = (g,)
+        self._leaves, self._outs = [None] * nb, [None] * nb
+        main_pool = torch.cuda.graph_pool_handle()
+        pools = [torch.cuda.graph_pool_handle() for _ in range(nb)]
+        G = {"enc_fwd": self._graph(main_pool, self._s_enc_fwd)}
+        G["dec_fwd"] = [self._graph(pools[k], self._s_dec_fwd, k) for k in range(nb)]
+        G["loss"] = self._graph(main_pool, self._s_loss)
+        G["dec_bwd"] = [self._graph(pools[k], self._s_dec_bwd, k) for k in range(nb)]
+        G["enc_bwd"] = self._graph(main_pool, self._s_enc_bwd)
+        self.graphs = G
+        # self-check: replays separated by device synchronisation must reproduce the eager pass (same dropout streams)
+        for k in range(self.verify_replays):
+            rng.copy_(rng0)
+            torch.cuda.synchronize()
+            self._replay(comm=False)
+            torch.cuda.synchronize()
+            got = (self.loss.double(), self.flat.grad.double().abs().sum())
+            bad = [not bool(torch.isfinite(a)) or abs(float(a) - float(b)) > 2e-3 * max(abs(float(b)), 1e-30) for a, b in zip(got, ref)]
+            if any(bad):
+                warnings.warn(f"hipGraph replay {k} does not reproduce the eager step (loss {float(got[0]):.6g} vs {float(ref[0]):.6g}, "
+                              f"|grad| {float(got[1]):.6g} vs {float(ref[1]):.6g}); TrainEngine falls back to eager launches")
+                self.graphs, self.use_graph = None, False
+                break
+        rng.copy_(rng0)
+
+    def _fan(self, graphs):
+        cur = torch.cuda.current_stream(self.dev)
+        for s_, g in zip(self.branch_streams, graphs):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                g.replay()
+        for s_ in self.branch_streams:
+            cur.wait_stream(s_)
+
+    def _replay(self, comm: bool):
+        """enc_fwd, {dec_fwd}, loss, {dec_bwd}, [decoder bucket all-reduce on the comm stream ||] enc_bwd, [encoder bucket all-reduce]"""
+        G = self.graphs
+        cur = torch.cuda.current_stream(self.dev)
+        G["enc_fwd"].replay()
+        self._fan(G["dec_fwd"])
+        G["loss"].replay()
+        self._fan(G["dec_bwd"])
+        split, n = self.flat.split, self.flat.numel
+        if comm and self.overlap:
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self._allreduce(split, n)                   # decoder bucket, overlapped with the encoder backward
+        G["enc_bwd"].replay()
+        if comm and self.world > 1:
+            if self.overlap:
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self._allreduce(0, split)               # encoder bucket
+                cur.wait_stream(self.comm_stream)
+            else:
+                self._allreduce(0, n)
 
     # ---- public ---------------------------------------------------------------------------------
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -187,41 +273,38 @@ class TrainEngine:
             self.x.copy_(x, non_blocking=True)
         if labels is not None:
             self.labels.copy_(labels, non_blocking=True)
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         if self.use_graph and self.graphs is None:
-            self._capture()
-        cur = torch.cuda.current_stream()
-        if self.world == 1:
-            if self.use_graph:
-                self.graphs[0].replay()
-            else:
-                self.flat.reattach()
-                self._fwd_bwd_single()
-        elif not self.overlap:
-            if self.use_graph:
-                self.graphs[0].replay()
-            else:
-                self.flat.reattach()
-                self._fwd_bwd_single()
-            self._allreduce(0, self.flat.numel)
+            self._capture()                                    # may clear use_graph (self-check)
+        if self.use_graph:
+            self._replay(comm=True)
         else:
+            cur = torch.cuda.current_stream(self.dev)
+            self.flat.reattach()
             split, n = self.flat.split, self.flat.numel
-            if self.use_graph:
-                self.graphs[0].replay()
+            if self.world == 1:
+                self._fwd_bwd_single()
+            elif not self.overlap:
+                self._fwd_bwd_single()
+                self._allreduce(0, n)
             else:
-                self.flat.reattach()
-                self._phase1()
-            self.comm_stream.wait_stream(cur)
-            with torch.cuda.stream(self.comm_stream):
-                self._allreduce(split, n)                   # decoder bucket, overlapped with the encoder backward
-            if self.use_graph:
-                self.graphs[1].replay()
-            else:
-                self._phase2()
-            self.comm_stream.wait_stream(cur)
-            with torch.cuda.stream(self.comm_stream):
-                self._allreduce(0, split)                   # encoder bucket
-            cur.wait_stream(self.comm_stream)
+                nb = self.model.num_branches
+                self._leaves, self._outs = [None] * nb, [None] * nb
+                self._s_enc_fwd()
+                for k in range(nb):
+                    self._s_dec_fwd(k)
+                self._s_loss()
+                for k in range(nb):
+                    self._s_dec_bwd(k)
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self._allreduce(split, n)
+                self._s_enc_bwd()
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self._allreduce(0, split)
+                cur.wait_stream(self.comm_stream)
         self._adamw()
         return self.loss
 

@@ -21,6 +21,7 @@ WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
+BRANCH_STREAMS = True                         # independent sub-networks (the M+1 decoders) run on forked HIP streams in training
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -29,6 +30,34 @@ LN_EPS = 1e-6      # reference attention_utils.py:15
 # ------------------------------------------------------------------------------------------------
 _site_counter = itertools.count(1)
 _rng_state = {}
+
+
+_branch_streams = {}
+
+
+def run_branches(fns, device):
+    """Run independent closures `fns` (each returns a tensor or a tuple/list of tensors) on forked HIP streams and join them on
+    the current stream.  The autograd engine replays every backward node on the stream its forward ran on, so the backward
+    passes of the branches overlap too; under hipGraph capture the fork/join becomes parallel branches of the graph.  The branches
+    are chains of small kernels (a 4^3 .. 32^3 decoder level rarely fills 256 CUs), which is what makes the overlap pay."""
+    if not BRANCH_STREAMS or len(fns) < 2:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream(device)
+    key = (str(device), len(fns))
+    if key not in _branch_streams:
+        _branch_streams[key] = [torch.cuda.Stream(device=device) for _ in fns]
+    outs = []
+    for s_, f in zip(_branch_streams[key], fns):
+        s_.wait_stream(cur)
+        with torch.cuda.stream(s_):
+            outs.append(f())
+    for s_, o in zip(_branch_streams[key], outs):
+        cur.wait_stream(s_)
+        for t in (o if isinstance(o, (tuple, list)) else (o,)):
+            for u in (t if isinstance(t, (tuple, list)) else (t,)):
+                if torch.is_tensor(u):
+                    u.record_stream(cur)
+    return outs
 
 
 def new_dropout_site() -> int:

@@ -54,6 +54,32 @@ class VeloxSeg(nn.Module):
         """trilinear, align_corners=True, to self.size (VeloxSeg.py:177-184)."""
         return VF.upsample_trilinear(pred, self.size)
 
+    # Training-mode heads (VeloxSeg.py:199-221): Seg_Decoder + deep-supervision up-sampling (branch 0) and the M reconstruction
+    # decoders (branches 1..M).  The branches only share their inputs, so they can run concurrently (functional.run_branches in the
+    # eager path, one hipGraph per branch in engine.TrainEngine).
+    @property
+    def num_branches(self) -> int:
+        return 1 + self.num_modalities
+
+    def decode_branch(self, k: int, attn, encs):
+        """branch 0 -> (pred_0..pred_3, dec_pram); branch m+1 -> (rc_m, rc_pram_m).  attn[L][m] / encs[L] as returned by the encoder."""
+        if k == 0:
+            pred, dec_pram = self.decoder(*encs)
+            return tuple(self.scale_prediction(p) for p in pred) + (dec_pram,)
+        m = k - 1
+        return tuple(self.rc_decoders[m]([attn[L][m] for L in range(4)], encs))
+
+    def assemble_train(self, branch_outs):
+        """list of decode_branch results -> the reference's training output list [pred x4, rcs, dec_pram, rc_pram x M] (VeloxSeg.py:221)"""
+        seg = list(branch_outs[0])
+        rcs = [o[0] for o in branch_outs[1:]]
+        rcs = rcs[0] if len(rcs) == 1 else torch.cat(rcs, dim=1)
+        return seg[:-1] + [rcs, seg[-1]] + [o[1] for o in branch_outs[1:]]
+
+    def decode_train(self, attn, encs):
+        outs = VF.run_branches([(lambda k=k: self.decode_branch(k, attn, encs)) for k in range(self.num_branches)], encs[0].device)
+        return self.assemble_train(outs)
+
     def forward(self, x) -> Union[torch.Tensor, Sequence[torch.Tensor]]:
         if not x.is_cuda:
             raise RuntimeError("veloxseg_amd.VeloxSeg runs on MI355X only: move the model and the input to a cuda device "
@@ -62,14 +88,6 @@ class VeloxSeg(nn.Module):
         if self.training:
             VF.advance_rng(x.device)
             attn, encs = self.encoder(x)
-            pred, dec_pram = self.decoder(*encs)
-            pred = [self.scale_prediction(p) for p in pred]
-            rcs, rc_prams = [], []
-            for m in range(self.num_modalities):
-                rc, pram = self.rc_decoders[m]([attn[L][m] for L in range(4)], encs)
-                rcs.append(rc)
-                rc_prams.append(pram)
-            rcs = rcs[0] if len(rcs) == 1 else torch.cat(rcs, dim=1)
-            return pred + [rcs] + [dec_pram] + rc_prams
+            return self.decode_train(attn, encs)
         encs = self.encoder(x)
         return self.decoder(*encs)
