@@ -173,6 +173,21 @@ int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, i
 int vx_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, long step, float grad_scale, void* stream);
 
+/* ---- sliding-window inference + label metrics -------------------------------------------------------
+ * Replaces monai.inferers.sliding_window_inference as called from utils/inference_runtime.py:4-19 (constant blending) and the
+ * argmax + Dice of utils/inference_brats.py:216-217.  Volumes are one batch item, (C, D, H, W) fp32 contiguous. */
+int vx_sw_extract(const float* vol, float* win, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0, int x0, void* stream);
+/* acc[:, window] += weight * win; windows must be accumulated in the reference's window order (one call each) */
+int vx_sw_accumulate(const float* win, float* acc, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0, int x0, float weight, void* stream);
+/* out = acc / (cz[z]*cy[y]*cx[x]) (per-axis window counts; out may alias acc or be NULL), labels = uint8 argmax over C (may be NULL) */
+int vx_sw_finalize(const float* acc, float* out, unsigned char* labels, const float* cz, const float* cy, const float* cx,
+                   int C, int D, int H, int W, void* stream);
+/* labels[b, v] = argmax_c logits[b, c, v] (first maximum, uint8): `outputs[0].argmax(dim=1)` of utils/metric/metrics.py:16 */
+int vx_argmax_channels(const float* logits, unsigned char* labels, int B, int C, long V, void* stream);
+/* conf[b, g, p] += #voxels with ground truth g and prediction p (uint64, NC*NC per sample; caller zeroes it): the sufficient statistic of
+ * metrics_tensor (utils/metric/metrics.py:44-91) and cal_dice (utils/metric/metrics_brats.py:31-35); label widths 1, 4 or 8 bytes */
+int vx_confusion(const void* pred, int pred_bytes, const void* gt, int gt_bytes, unsigned long long* conf, int B, long V, int NC, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+"""GPU: sliding-window inference and label metrics through the C ABI (csrc/infer.hip) against the oracle / the reference goldens."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sliding_window_oracle as SO  # noqa: E402  (checker only)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _pointwise(w):
+    # a deterministic per-window function that also depends on the position INSIDE the window, so blending really averages different values
+    ramp = torch.linspace(0, 1, w.shape[-1], device=w.device).view(1, 1, 1, 1, -1)
+    return torch.cat([w[:, :1] * 2.0 + ramp, w[:, -1:] - 1.0, w.mean(1, keepdim=True) * ramp], 1)
+
+
+@pytest.mark.parametrize("shape,roi,swb,overlap", [((2, 3, 20, 17, 9), (8, 8, 8), 3, 0.5), ((1, 2, 5, 6, 7), (8, 4, 16), 2, 0.25),
+                                                   ((1, 4, 40, 33, 21), (16, 16, 16), 2, 0.5), ((3, 1, 12, 12, 12), (12, 12, 12), 4, 0.5)])
+def test_sliding_window_matches_oracle_bit_exactly(shape, roi, swb, overlap):
+    from veloxseg_amd.utils import inference_runtime as IR
+    d = dev()
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(3)).to(d)
+    want = SO.sliding_window_inference(x, roi, swb, _pointwise, overlap)          # oracle driver, same predictor, same device arithmetic
+    got, labels = IR.sliding_window_inference(x, roi, swb, _pointwise, overlap=overlap, return_labels=True)
+    assert got.shape == want.shape
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert labels.dtype == torch.uint8 and torch.equal(labels.long(), want.argmax(1, keepdim=True))
+    cfgd = {"sliding_window": {"overlap": overlap}}
+    assert torch.equal(IR.sliding_window_predict(x, _pointwise, roi, swb, cfgd), want)
+    with pytest.raises(NotImplementedError):
+        IR.sliding_window_inference(x, roi, swb, _pointwise, overlap=overlap, mode="gaussian")
+    with pytest.raises(RuntimeError):
+        IR.sliding_window_inference(x.cpu(), roi, swb, _pointwise, overlap=overlap)
+
+
+def test_sliding_window_with_the_hip_model(golden_dir):
+    """end to end: HIP VeloxSeg (eval) as the predictor of both drivers -> identical blended logits; and against the CPU oracle model
+    within the logits tolerance of the model parity tests, argmax equal wherever the top-2 margin exceeds that tolerance."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from recipe import CASES, fill_state_dict
+    from oracle import veloxseg_oracle as O
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils import inference_runtime as IR
+    cfg, _ = CASES["g2_32_m2"]
+    d = dev()
+    model = VeloxSeg(**cfg)
+    sd = model.state_dict()
+    fill_state_dict(sd)
+    model.load_state_dict(sd)
+    model = model.to(d).eval()
+    x = torch.randn((1, 2, 48, 40, 36), generator=torch.Generator().manual_seed(5))
+    with torch.inference_mode():
+        got, labels = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5)
+        want = SO.sliding_window_inference(x.to(d), (32, 32, 32), 2, IR.Net(model), 0.5)
+    assert torch.equal(got, want)
+    ocfg = O.OracleConfig(**cfg)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = SO.sliding_window_inference(x, (32, 32, 32), 2, lambda w: O.forward(w, sd_cpu, ocfg, training=False), 0.5)
+    err = (got.cpu() - ref).abs()
+    tol = 1e-4 * ref.abs().clamp(min=1.0)
+    assert bool((err <= tol).all()), float(err.max())
+    top2 = ref.topk(2, dim=1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2e-4
+    assert bool((labels.cpu()[:, 0][sure] == ref.argmax(1)[sure]).all())
+    assert float(sure.float().mean()) > 0.99
+
+
+def test_metrics_match_reference_goldens(golden_dir):
+    from veloxseg_amd.utils.metric import metrics as M, metrics_brats as MB
+    d = dev()
+    G = torch.load(os.path.join(golden_dir, "metrics.pt"))
+    for case in G["binary"]:
+        for dt in (torch.uint8, torch.int64):
+            got = M.metrics_tensor(case["gt"].to(d).to(dt), case["pred"].to(d).to(dt))
+            for a, b in zip(got, case["metrics_tensor"]):
+                assert abs(a - b) <= 1e-7 * max(1.0, abs(b)), (got, case["metrics_tensor"])
+        res, string = M.show_deep_metrics([case["logits"].to(d)], case["gt"].to(d).long(), True)
+        assert string == case["show"][1], (string, case["show"][1])
+        assert all(abs(a - b) <= 1e-7 for a, b in zip(res, case["show"][0]))
+    for case in G["brats"]:
+        got = MB.cal_dice(case["pred"].to(d), case["gt"].to(d).long())
+        for a, b in zip(got, case["cal_dice"]):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got, case["cal_dice"])
+        d1 = float(MB.Dice((case["pred"] == 1).float().to(d), (case["gt"] == 1).float().to(d)))
+        assert abs(d1 - case["dice_class1"]) <= 1e-6
+        res, string = MB.show_deep_metrics([case["logits"].to(d), -case["logits"].to(d)], case["gt"].to(d).long(), True)
+        assert string == case["show"][1], (string, case["show"][1])
