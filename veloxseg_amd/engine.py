@@ -71,7 +71,7 @@ class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
-                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3):
+                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None):
         self.model, self.criterion = model, criterion
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
@@ -79,6 +79,9 @@ class TrainEngine:
         self.v = torch.zeros_like(self.flat.param)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.t = 0
+        self.optimizer = None
+        if optimizer is not None:
+            self.bind_optimizer(optimizer)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.overlap = overlap and self.world > 1
@@ -88,6 +91,7 @@ class TrainEngine:
         self.labels = torch.zeros((B, 1, *batch_shape[2:]), device=self.dev, dtype=label_dtype)
         self.loss = torch.zeros((), device=self.dev, dtype=torch.float32)
         self.graphs = None
+        self.last_outputs = None
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self._warm = warmup_steps
         self.verify_replays = verify_replays
@@ -102,9 +106,10 @@ class TrainEngine:
     def _fwd_bwd_single(self):
         """plain eager step: model() runs the decoder branches on forked streams (functional.run_branches)"""
         self.flat.zero_grad()
-        _, loss = self._forward_loss()
+        outs, loss = self._forward_loss()
         loss.backward()
         self.loss.copy_(loss.detach())
+        self.last_outputs = [o.detach() for o in outs]
 
     # ---- stages -------------------------------------------------------------------------------
     # The step is cut at the encoder outputs and at the decoder outputs into stages that exchange DETACHED leaves:
@@ -128,7 +133,8 @@ class TrainEngine:
 
     def _s_loss(self):
         outs_d = [[o.detach().requires_grad_(True) for o in outs] for outs in self._outs]
-        loss = self.criterion(self.model.assemble_train(outs_d), self.labels, sr_labels=self.x)
+        self.last_outputs = self.model.assemble_train(outs_d)      # detached leaves: what the per-step metrics read
+        loss = self.criterion(self.last_outputs, self.labels, sr_labels=self.x)
         loss.backward()
         self._douts = [[o.grad for o in od] for od in outs_d]
         self.loss.copy_(loss.detach())
@@ -163,7 +169,48 @@ class TrainEngine:
     def _allreduce(self, lo, hi):
         dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
 
+    # ---- torch.optim.AdamW as the state carrier (reference checkpoints, LR schedulers) ---------------
+    def bind_optimizer(self, optimizer):
+        """`optimizer` = torch.optim.AdamW over model.parameters() (utils/optimizers/optimizers.py:27-34).  Its param_groups[0] becomes the
+        source of lr / betas / eps / weight_decay (so the reference's per-epoch LR schedulers drive the fused HIP update), and its
+        per-parameter state is made to alias the engine's flat moment buffers, so optimizer.state_dict() / load_state_dict() read and
+        write the reference's checkpoint format (utils/load_model.py:90-109).  Call again (or load_optimizer_state) after
+        optimizer.load_state_dict()."""
+        if not isinstance(optimizer, torch.optim.AdamW):
+            raise TypeError("TrainEngine drives torch.optim.AdamW only (the optimizer of every shipped train_config)")
+        if len(optimizer.param_groups) != 1 or [id(p) for p in optimizer.param_groups[0]["params"]] != [id(p) for p in self.flat.params]:
+            raise ValueError("optimizer must hold exactly model.parameters() in one param group")
+        if optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
+            raise NotImplementedError("amsgrad / maximize are not supported by the fused AdamW")
+        self.optimizer = optimizer
+        self.load_optimizer_state()
+
+    def load_optimizer_state(self):
+        """copy whatever state the bound optimizer holds (e.g. after load_state_dict) into the flat buffers, then alias it back"""
+        opt = self.optimizer
+        steps = []
+        for n, p in zip(self.flat.names, self.flat.params):
+            o, k = self.flat.slices[n]
+            st = opt.state.get(p, {})
+            if "exp_avg" in st:
+                self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(float(st["step"])))
+        if steps:
+            if len(set(steps)) != 1 or len(steps) != len(self.flat.params):
+                raise ValueError("optimizer state has differing per-parameter step counts; the fused AdamW keeps one")
+            self.t = steps[0]
+        self._step_tensor = torch.tensor(float(self.t), dtype=torch.float32)
+        for n, p in zip(self.flat.names, self.flat.params):
+            o, k = self.flat.slices[n]
+            opt.state[p] = {"step": self._step_tensor, "exp_avg": self.m[o:o + k].view(p.shape), "exp_avg_sq": self.v[o:o + k].view(p.shape)}
+
     def _adamw(self):
+        if self.optimizer is not None:
+            g = self.optimizer.param_groups[0]
+            self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], g["betas"], g["eps"]
+            self._step_tensor += 1
+            self.optimizer._opt_called = True        # the fused kernel below IS optimizer.step(); keeps LR schedulers from warning
         self.t += 1
         H.call("vx_adamw_step", H.P(self.flat.param), H.P(self.flat.grad), H.P(self.m), H.P(self.v), self.flat.numel, float(self.lr),
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.t, 1.0 / self.world, H.stream_ptr())
