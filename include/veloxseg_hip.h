@@ -48,6 +48,9 @@ int vx_conv3d_bwd_weight(const float* x, const float* x2, int C1, const float* d
 /* LDS-tiled weight gradient for spatial kernels (same contract as vx_conv3d_bwd_weight): x halo tile in LDS, dy on the scalar path */
 int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                                int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* weight + bias gradient of a 1x1x1 GROUPED conv with Cin == Cout == C (JLC k = 1 branch, conv_blocks.py:51-58): dw (C, C/G) +=, db (C) += (may be NULL).
+ * Needs V % 4 == 0 and a group width of 4, 8 or 16; other shapes go through vx_conv3d_bwd_weight_tiled. */
+int vx_gconv1_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int G, long V, void* stream);
 /* stride-1 "same" conv, K in {3,5}, register-blocked + LDS-staged (JLC grouped convs, patch-expand).  w is always the forward
  * weight (Cf_out, Cf_in/G, K,K,K).  wmode 0 = forward (Cin=Cf_in, Cout=Cf_out); wmode 1 = input gradient (x:=dy, Cin=Cf_out, Cout=Cf_in).
  * in_ps / out_ps: PixelShuffle factor of the input / output storage.  accumulate: y += . */

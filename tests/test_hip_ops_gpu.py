@@ -353,7 +353,8 @@ def test_kernel_variants_agree():
             setattr(F_, k, v)
         torch.manual_seed(0)
         res = []
-        for (Cin, Cout, K, G, ps, sp) in [(16, 128, 3, 1, 4, (6, 5, 8)), (16, 16, 5, 4, 1, (8, 8, 8)), (32, 32, 3, 4, 1, (4, 6, 8)), (64, 32, 1, 1, 1, (4, 4, 4))]:
+        for (Cin, Cout, K, G, ps, sp) in [(16, 128, 3, 1, 4, (6, 5, 8)), (16, 16, 5, 4, 1, (8, 8, 8)), (32, 32, 3, 4, 1, (4, 6, 8)), (64, 32, 1, 1, 1, (4, 4, 4)),
+                                          (16, 16, 1, 4, 1, (8, 8, 8)), (32, 32, 1, 4, 1, (6, 5, 8)), (128, 128, 1, 8, 1, (4, 4, 4))]:
             x = rnd(2, Cin, *sp, seed=Cin).to(d).requires_grad_(True)
             w = (rnd(Cout, Cin // G, K, K, K, seed=K) * 0.1).to(d).requires_grad_(True)
             b = rnd(Cout, seed=3).to(d).requires_grad_(True)
@@ -363,10 +364,10 @@ def test_kernel_variants_agree():
         torch.cuda.synchronize()
         return res
 
-    base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096)
-    ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0))
+    base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096, USE_GCONV1=True)
+    ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0, USE_GCONV1=False))
     try:
-        for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0)):
+        for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0), dict(base, USE_GCONV1=False)):
             got = run(variant)
             for i, (a, b_) in enumerate(zip(got, ref)):
                 close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")

@@ -63,6 +63,92 @@ __global__ void __launch_bounds__(256) vx_seg_loss_fwd_k(const float* __restrict
     }
 }
 
+// Vectorised variant (V % 4 == 0, C compile-time): 4 voxels per thread and iteration as float4 rows, all heads in ONE sweep so the labels
+// are read once, wave-shuffle + LDS block reduction of the nh*(1+2C)+C sums, one fp64 atomic per sum and block.
+template <int C>
+__global__ void __launch_bounds__(256) vx_seg_loss_fwd4_k(const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
+                                                          const float* __restrict__ l3, int nh, const void* __restrict__ lab, int lab_kind,
+                                                          double* __restrict__ acc, int B, long V) {
+    constexpr int NS = 1 + 2 * C;                       // per head: ce, I[C], P[C]
+    const int b = blockIdx.y;
+    const float* heads[4] = {l0, l1, l2, l3};
+    float S[4][NS], T[C];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) S[h][k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) T[c] = 0.0f;
+    const long V4 = V >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < V4; q += (long)gridDim.x * 256) {
+        int y[4];
+        if (lab_kind == 0) {
+            const longlong2 a = ((const longlong2*)lab)[((long)b * V >> 1) + 2 * q], c2 = ((const longlong2*)lab)[((long)b * V >> 1) + 2 * q + 1];
+            y[0] = (int)a.x; y[1] = (int)a.y; y[2] = (int)c2.x; y[3] = (int)c2.y;
+        } else if (lab_kind == 1) {
+            const int4 a = ((const int4*)lab)[((long)b * V >> 2) + q];
+            y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+        } else {
+            const uchar4 a = ((const uchar4*)lab)[((long)b * V >> 2) + q];
+            y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[c] += (y[j] == c) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (h < nh) {
+                const float4* __restrict__ lg = (const float4*)(heads[h] + (long)b * C * V);
+                float z[C][4];
+#pragma unroll
+                for (int c = 0; c < C; ++c) { const float4 t = lg[(long)c * V4 + q]; z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mx = z[0][j];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                    float e[C], se = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { e[c] = expf(z[c][j] - mx); se += e[c]; }
+                    const float inv = 1.0f / se;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float pc = e[c] * inv;
+                        S[h][1 + C + c] += pc;
+                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] -= logf(fmaxf(pc, 1e-38f)); }
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float red[4][4 * NS + C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { const float v = vx_wave_sum(S[h][k]); if (lane == 0) red[wid][h * NS + k] = v; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = vx_wave_sum(T[c]); if (lane == 0) red[wid][4 * NS + c] = v; }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 4 * NS + C) {
+        const double v = (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k];
+        if (k < 4 * NS) {
+            const int h = k / NS, r = k % NS;
+            if (h < nh) {
+                double* __restrict__ ah = acc + (long)h * (1 + (long)B * C * 3);
+                if (r == 0) atomicAdd(ah, v);
+                else if (r <= C) atomicAdd(ah + 1 + ((long)b * C + (r - 1)) * 3, v);            // I
+                else atomicAdd(ah + 1 + ((long)b * C + (r - 1 - C)) * 3 + 1, v);                // P
+            }
+        } else {
+            const int c = k - 4 * NS;
+            for (int h = 0; h < nh; ++h) atomicAdd(acc + (long)h * (1 + (long)B * C * 3) + 1 + ((long)b * C + c) * 3 + 2, v);   // T (same for every head)
+        }
+    }
+}
+
 // squared-difference sum -> acc[0] (double)
 __global__ void __launch_bounds__(256) vx_sqdiff_sum_k(const float* __restrict__ a, const float* __restrict__ b, long n, double* __restrict__ acc) {
     float s = 0.0f;
@@ -80,6 +166,17 @@ __global__ void vx_loss_finalize_k(const double* __restrict__ acc, int nh, int B
                                    const float* __restrict__ gs, const float* __restrict__ g0, const float* __restrict__ g1,
                                    const float* __restrict__ g2, const float* __restrict__ g3, int M, int Cg, float w_f,
                                    float* __restrict__ loss_out, float* __restrict__ coef) {
+    // Gram (SDKT) term: the only O(B*Cg*Cg) part -- all 64 lanes share it, lane 0 then does the scalar bookkeeping
+    double feat = 0.0;
+    const long ng = (long)B * Cg * Cg;
+    if (gs && M > 0) {
+        const float* gm_[4] = {g0, g1, g2, g3};
+        for (int m = 0; m < M; ++m) {
+            double s_ = 0.0;
+            for (long i = threadIdx.x; i < ng; i += 64) { const double d = (double)gs[i] - (double)gm_[m][i]; s_ += d * d; }
+            feat += vx_wave_sum(s_) / (double)ng;
+        }
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double eps = 1e-5;
     double total = 0.0;
@@ -113,14 +210,6 @@ __global__ void vx_loss_finalize_k(const double* __restrict__ acc, int nh, int B
         misc[0] = (float)(2.0 * (double)w_rc / (double)n_rc);
     } else misc[0] = 0.0f;
     if (gs && M > 0) {
-        const float* gm[4] = {g0, g1, g2, g3};
-        const long ng = (long)B * Cg * Cg;
-        double feat = 0.0;
-        for (int m = 0; m < M; ++m) {
-            double s = 0.0;
-            for (long i = 0; i < ng; ++i) { const double d = (double)gs[i] - (double)gm[m][i]; s += d * d; }
-            feat += s / (double)ng;
-        }
         total += (double)w_f * feat / (double)M;
         misc[1] = (float)(2.0 * (double)w_f / ((double)M * (double)ng));
     } else misc[1] = 0.0f;
@@ -262,6 +351,37 @@ __global__ void __launch_bounds__(256) vx_upsample_fwd_k(const float* __restrict
                        l0 * (k1 * (k2 * T(b0, a1, a2) + l2 * T(b0, a1, b2)) + l1 * (k2 * T(b0, b1, a2) + l2 * T(b0, b1, b2)));
 }
 
+// same arithmetic, 4 consecutive outputs of a row per thread (W % 4 == 0): the z/y coordinates and the 4 source rows are shared, 16-byte stores
+__global__ void __launch_bounds__(256) vx_upsample_fwd4_k(const float* __restrict__ x, float* __restrict__ out, int d, int h, int w, int D, int H, int W) {
+    const int W4 = W >> 2;
+    const long Vo4 = (long)D * H * W4, Vi = (long)d * h * w;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= Vo4) return;
+    const long bc = blockIdx.y;
+    const int X0 = (int)(q % W4) * 4, Y = (int)((q / W4) % H), Z = (int)(q / ((long)W4 * H));
+    int a0, b0, a1, b1;
+    float l0, l1;
+    vx_up_coord(Z, d, D, a0, b0, l0);
+    vx_up_coord(Y, h, H, a1, b1, l1);
+    const float* __restrict__ xb = x + bc * Vi;
+    const float* __restrict__ r00 = xb + ((long)a0 * h + a1) * w;
+    const float* __restrict__ r01 = xb + ((long)a0 * h + b1) * w;
+    const float* __restrict__ r10 = xb + ((long)b0 * h + a1) * w;
+    const float* __restrict__ r11 = xb + ((long)b0 * h + b1) * w;
+    const float k0 = 1.0f - l0, k1 = 1.0f - l1;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int a2, b2;
+        float l2;
+        vx_up_coord(X0 + j, w, W, a2, b2, l2);
+        const float k2 = 1.0f - l2;
+        o[j] = k0 * (k1 * (k2 * r00[a2] + l2 * r00[b2]) + l1 * (k2 * r01[a2] + l2 * r01[b2])) +
+               l0 * (k1 * (k2 * r10[a2] + l2 * r10[b2]) + l1 * (k2 * r11[a2] + l2 * r11[b2]));
+    }
+    *(float4*)(out + (bc * (long)D * H + ((long)Z * H + Y)) * W + X0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // adjoint as separable 1-D passes.  pass over axis `ax` of a (n0,n1,n2) volume: out[.., j_in, ..] = sum_J A[J][j_in] * in[.., J, ..]
 // one thread = one output element; threads run along the innermost axis, so reads are coalesced for ax = 0,1 (the big passes).
 __global__ void __launch_bounds__(256) vx_upsample_adj_axis_k(const float* __restrict__ in, float* __restrict__ out,
@@ -321,6 +441,17 @@ extern "C" int vx_seg_loss_fwd(const float* l0, const float* l1, const float* l2
     VX_REQUIRE(lab_kind >= 0 && lab_kind <= 2, "vx_seg_loss_fwd: label kind must be 0(int64) 1(int32) 2(uint8)");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_fwd: memset failed");
+    if ((V & 3) == 0 && C <= 4) {
+        int chunks = vx_cdiv(V >> 2, 256 * 4);
+        const int cap = B >= 4 ? 256 : 512;
+        if (chunks > cap) chunks = cap;
+        const dim3 grid(chunks, B), blk(256);
+        if (C == 2) vx_seg_loss_fwd4_k<2><<<grid, blk, 0, st>>>(l0, l1, l2, l3, nh, labels, lab_kind, acc, B, V);
+        else if (C == 3) vx_seg_loss_fwd4_k<3><<<grid, blk, 0, st>>>(l0, l1, l2, l3, nh, labels, lab_kind, acc, B, V);
+        else vx_seg_loss_fwd4_k<4><<<grid, blk, 0, st>>>(l0, l1, l2, l3, nh, labels, lab_kind, acc, B, V);
+        VX_LAUNCH_CHECK("vx_seg_loss_fwd");
+        return 0;
+    }
     int chunks = vx_cdiv(V, 256 * 8);
     if (chunks > 1024) chunks = 1024;
     hipLaunchKernelGGL(vx_seg_loss_fwd_k, dim3(chunks, B), dim3(256), 0, st, l0, l1, l2, l3, nh, labels, lab_kind, acc, B, C, V);
@@ -394,7 +525,10 @@ extern "C" int vx_gram_bwd(const float* x, const float* dG, float* dx, int B, in
 
 extern "C" int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, int d, int h, int w, int D, int H, int W, void* stream) {
     VX_REQUIRE(x && out && BC > 0 && d > 0 && h > 0 && w > 0 && D >= d && H >= h && W >= w, "vx_upsample_trilinear_fwd: bad args");
-    hipLaunchKernelGGL(vx_upsample_fwd_k, dim3(vx_cdiv((long)D * H * W, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, d, h, w, D, H, W);
+    if ((W & 3) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(vx_upsample_fwd4_k, dim3(vx_cdiv((long)D * H * (W >> 2), 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, d, h, w, D, H, W);
+    else
+        hipLaunchKernelGGL(vx_upsample_fwd_k, dim3(vx_cdiv((long)D * H * W, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, x, out, d, h, w, D, H, W);
     VX_LAUNCH_CHECK("vx_upsample_trilinear_fwd");
     return 0;
 }

@@ -20,6 +20,7 @@ from . import _hip as H
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
+USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 BRANCH_STREAMS = True                         # independent sub-networks (the M+1 decoders) run on forked HIP streams in training
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
@@ -171,6 +172,9 @@ class _Conv3dFn(torch.autograd.Function):
             db = grad_buf(b) if (b is not None and b.requires_grad) else None
             if K == 1 and S == 1 and P == 0 and G == 1 and ps == 1:
                 H.call("vx_pw_conv_bwd_weight", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, Cout, D * Hh * W, st)
+            elif (USE_GCONV1 and K == 1 and S == 1 and P == 0 and G > 1 and ps == 1 and x2 is None and Cin == Cout and (Cin // G) in (4, 8, 16)
+                  and (D * Hh * W) % 4 == 0):
+                H.call("vx_gconv1_bwd_weight", H.P(x), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, G, D * Hh * W, st)
             elif ctx.s1 and ps == 4 and K == 3 and Cin == 16 and G == 1 and USE_EXPAND_MFMA:
                 xcl = torch.empty((B * D * Hh * W * 16,), device=x.device, dtype=torch.float32)
                 H.call("vx_expand_wgrad_mfma", H.P(x), H.P(xcl), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cout // 64, D, Hh, W, st)
