@@ -169,10 +169,14 @@ def main():
                           "hip_graph": bool(eng.use_graph), "launch": "hipGraph per stage" if eng.use_graph else "eager, decoder branches on forked HIP streams", "final_loss": round(loss, 5)}}
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
+        from veloxseg_amd import functional as VF
         eng.flat.reattach()
+        VF.BRANCH_STREAMS = False          # one stream: HIP-event intervals are then the kernels' own durations, not shared-GPU time
+        eng._fwd_bwd_single()
         H.profile_begin()
         eng._fwd_bwd_single()
         prof = H.profile_end()
+        VF.BRANCH_STREAMS = True
         rows = sorted(((v[1], v[0], k) for k, v in prof.items()), reverse=True)
         total = sum(r[0] for r in rows)
         top = rows[0]

@@ -22,7 +22,7 @@ USE_EXPAND_MFMA = True                        # patch-expand input gradient on f
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
-BRANCH_STREAMS = True                         # independent sub-networks (the M+1 decoders) run on forked HIP streams in training
+BRANCH_STREAMS = True                         # independent sub-networks (M+1 decoders; encoder conv chain vs PWA chain) run on forked HIP streams
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -59,6 +59,17 @@ def run_branches(fns, device):
                 if torch.is_tensor(u):
                     u.record_stream(cur)
     return outs
+
+
+def side_stream(device, name: str) -> "torch.cuda.Stream":
+    """a named, cached side stream of `device` (one per role, e.g. the conv chain of the encoder)"""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (str(device), name)
+    if key not in _branch_streams:
+        _branch_streams[key] = torch.cuda.Stream(device=device)
+    return _branch_streams[key]
 
 
 def new_dropout_site() -> int:

@@ -82,13 +82,17 @@ class Transformer_Encoder(nn.Module):
                 do_downsample=i < self.num_layers - 1, dim=spatial_dim))
             grid = [g // 2 for g in grid]
 
-    def forward(self, xs):
+    def embed(self, xs):
         xs = torch.chunk(xs, self.num_modalities, dim=1)            # Encoder.py:192
         p = self.p_pos if self.training else 0.0
         cur = []
         for m in range(self.num_modalities):
             e = self.patch_embeds[m](xs[m].contiguous())
             cur.append(VF.residual_dropout(None, e, 0.0, p, self.sites_pos[m]) if p > 0 else e)
+        return cur
+
+    def forward(self, xs):
+        cur = self.embed(xs)
         feats = []
         for i, layer in enumerate(self.layers):
             attn, cur = layer(cur)
@@ -128,15 +132,37 @@ class Encoder(nn.Module):
         return conv(torch.cat(list(attn_feats), dim=1))
 
     def forward(self, x):
-        attn = self.encoder_attn(x)
-        encs = []
+        """The PWA chain (transformer levels 1..4) and the conv chain only meet at the per-level mixers, conv level L needing attn_L
+        (Encoder.py:351-360).  With functional.BRANCH_STREAMS the conv chain runs on a second HIP stream, one level behind the
+        transformer: conv level L overlaps transformer level L+1, forward and (autograd replays nodes on their forward stream) backward."""
+        ta = self.encoder_attn
+        cur_feats = ta.embed(x)
+        side = VF.side_stream(x.device, "encoder_conv") if VF.BRANCH_STREAMS else None
+        main = torch.cuda.current_stream(x.device) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
+        attn, encs = [], []
         prev = x
         for i in range(4):
-            a_raw = self._mix(i, attn[i])
-            d_raw = getattr(self.encoder_conv, f"down{i + 1}").raw(prev)
-            fused = VF.instnorm_sum([d_raw, a_raw])                  # IN(down) + IN(mix)  (Encoder.py:351-360)
-            prev = getattr(self.encoder_conv, f"layer{i + 1}")(fused)
+            a_i, cur_feats = ta.layers[i](cur_feats)
+            attn.append(a_i)
+            if side is not None:
+                side.wait_stream(main)
+                ctx = torch.cuda.stream(side)
+                ctx.__enter__()
+            try:
+                a_raw = self._mix(i, a_i)
+                d_raw = getattr(self.encoder_conv, f"down{i + 1}").raw(prev)
+                fused = VF.instnorm_sum([d_raw, a_raw])                  # IN(down) + IN(mix)  (Encoder.py:351-360)
+                prev = getattr(self.encoder_conv, f"layer{i + 1}")(fused)
+            finally:
+                if side is not None:
+                    ctx.__exit__(None, None, None)
             encs.append(prev)
+        if side is not None:
+            main.wait_stream(side)
+            for e in encs:
+                e.record_stream(main)
         if self.training:
             return [list(a) for a in attn], encs
         return tuple(encs)
