@@ -105,6 +105,9 @@ int vx_add(const float* a, const float* b, const float* c, float* out, long n, v
 int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream);                  /* db[c] += sum_{b,v} dy */
 /* PatchMerging.faeture_sample (attention_utils.py:144-159); Dc,Hc,Wc = coarse dims; inverse=1 is the adjoint */
 int vx_space_to_depth2(const float* x, float* out, int B, int C, int Dc, int Hc, int Wc, int inverse, void* stream);
+/* out[b, c*K^3 + (kd*K+kh)*K + kw, z,y,x] = x[b, c, z*K+kd, y*K+kh, x*K+kw] (K = 2, 3, 4; d,h,w = OUTPUT grid): turns a kernel == stride conv
+ * (PatchEmbed, Encoder.py:150-156) into a 1x1 conv over C*K^3 channels with the conv weight viewed as (Cout, C*K^3) */
+int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Paired-Window Attention (model/components/PWA.py).  Geometry of one layer:

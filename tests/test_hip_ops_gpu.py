@@ -373,3 +373,35 @@ def test_kernel_variants_agree():
                 close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")
     finally:
         run(base)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,sp", [(1, 16, 4, (16, 16, 8)), (2, 8, 2, (8, 12, 16)), (1, 16, 4, (32, 32, 32))])
+def test_patch_conv_via_patchify_matches_direct_conv_and_oracle(Cin, Cout, K, sp):
+    """PatchEmbed (kernel == stride): patchify + 1x1 conv (MFMA / VALU by volume) vs the generic direct conv vs aten on the CPU"""
+    VF = _vf()
+    import veloxseg_amd.functional as F_
+    d = dev()
+    x = rnd(2, Cin, *sp, seed=1)
+    w0 = rnd(Cout, Cin, K, K, K, seed=2) * 0.2
+    b0 = rnd(Cout, seed=3)
+    gy = None
+    res = {}
+    try:
+        for flag in (True, False):
+            F_.USE_PATCHIFY = flag
+            w = w0.clone().to(d).requires_grad_(True)
+            b = b0.clone().to(d).requires_grad_(True)
+            y = VF.conv3d(x.to(d), w, b, stride=K, padding=0)
+            gy = rnd(*y.shape, seed=4) if gy is None else gy
+            y.backward(gy.to(d))
+            torch.cuda.synchronize()
+            res[flag] = (y.detach().cpu(), w.grad.cpu(), b.grad.cpu())
+    finally:
+        F_.USE_PATCHIFY = True
+    wc, bc = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yc = F.conv3d(x, wc, bc, stride=K)
+    yc.backward(gy)
+    for flag in (True, False):
+        close(res[flag][0], yc, 2e-5, 2e-4, f"patchify={flag} y")
+        close(res[flag][1], wc.grad, 1e-4 * float(wc.grad.abs().max()), 5e-4, f"patchify={flag} dw")
+        close(res[flag][2], bc.grad, 1e-4 * float(bc.grad.abs().max()), 5e-4, f"patchify={flag} db")

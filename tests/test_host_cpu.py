@@ -106,3 +106,21 @@ def test_no_cpu_fallback_and_no_oracle_import_in_product():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"
+
+
+def test_fastcall_extension_wraps_every_entry_point():
+    """the generated CPython wrappers (csrc/_vxfast.c) cover every int-returning prototype of the header and sit on the same library"""
+    from veloxseg_amd import _hip as H
+    fast = H.fast_module()
+    assert fast is not None, "run `python -c 'import __graft_entry__ as g; g.build()'`"
+    protos = H.parse_header()
+    missing = [n for n, (ret, _) in protos.items() if not ret.startswith("const char") and not hasattr(fast, n)]
+    assert not missing, missing
+    assert fast.vx_abi_version() == H.ABI_VERSION
+    import pytest
+    with pytest.raises(TypeError):
+        fast.vx_add(0, 0, 0)                          # wrong arity: nothing is launched
+    with pytest.raises(TypeError):
+        fast.vx_pwa_attn_set_split("two")             # wrong type: nothing is launched
+    assert fast.vx_pwa_attn_set_split(3) != 0 and b"must be" in H.LIB.load().vx_last_error()
+    assert fast.vx_pwa_attn_set_split(0) == 0

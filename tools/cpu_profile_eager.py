@@ -15,6 +15,8 @@ model = VeloxSeg(**cfg).cuda()
 crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)
 eng = TrainEngine(model, crit, (B, 2, S, S, S), use_graph=False, overlap=False)
 x, lab = synth(cfg, B, "cuda", 1)
+from veloxseg_amd import functional as VF
+VF.BRANCH_STREAMS = os.environ.get("VX_BRANCH_STREAMS", "1") == "1"
 for _ in range(3):
     eng.step(x, lab)
 torch.cuda.synchronize()
@@ -25,6 +27,8 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("host ms/step (launch only) %.2f, incl. final sync %.2f" % ((t1 - t0) * 100, (t2 - t0) * 100))
+if os.environ.get("VX_NO_CPROFILE") == "1":
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):

@@ -84,7 +84,12 @@ class _Lib:
     def call(self, name: str, *args):
         fn = self._fns.get(name)
         if fn is None:
-            fn = self._fns[name] = getattr(self.load(), name)
+            dll = self.load()
+            fast = fast_module()
+            fn = getattr(fast, name, None) if fast is not None else None      # generated METH_FASTCALL wrapper (same library underneath)
+            if fn is None:
+                fn = getattr(dll, name)                                       # ctypes binding
+            self._fns[name] = fn
         rc = fn(*args)
         if rc != 0:
             msg = self._dll.vx_last_error()
@@ -92,6 +97,25 @@ class _Lib:
 
 
 LIB = _Lib()
+_FAST = [False, None]
+
+
+def fast_module(reload: bool = False):
+    """veloxseg_amd._vxfast (built by __graft_entry__.build from the generated csrc/_vxfast.c) or None: the ctypes path is then used;
+    both are bindings of the same libveloxseg_hip.so, neither is a fallback implementation."""
+    if reload:
+        _FAST[0] = False
+        LIB._fns.clear()
+    if not _FAST[0]:
+        _FAST[0] = True
+        if os.environ.get("VELOXSEG_NO_FASTCALL") != "1":
+            try:
+                LIB.load()                      # the extension links against the library: make sure it is resident first
+                from . import _vxfast
+                _FAST[1] = _vxfast
+            except ImportError:
+                _FAST[1] = None
+    return _FAST[1]
 
 
 def available() -> bool:

@@ -92,17 +92,21 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
     }
 }
 
-// dW[co,ci] += sum_{b,v} dy[b,co,v] x[b,ci,v] ; db[co] += sum dy.   One wave = one (16 co x 16 ci) tile x one voxel chunk.
+// dW[co,ci] += sum_{b,v} dy[b,co,v] x[b,ci,v] ; db[co] += sum dy.   One wave = one (16 co x 16 ci) tile x one voxel chunk; 64 voxels per
+// iteration with all eight 16-byte operand loads issued before the 16 MFMAs; the 4 waves of a block (same tile, adjacent chunks) are
+// summed through LDS so that a block issues 256 float atomics, not 1024 (with ~2 k waves on one 16x16 tile the atomics on its 256
+// addresses, not the loads, were the cost: 56 us for 17 MB).
 __global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
                                                      const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
                                                      float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
+    __shared__ float red[4][4 * 64 + 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long cw = (long)blockIdx.x * 4 + wave;
-    if (cw >= (long)B * chunks_per_b) return;
-    const int b = (int)(cw / chunks_per_b);
-    const long v0 = (cw % chunks_per_b) * (long)vox_per_wave;
-    const long v1 = (v0 + vox_per_wave < V) ? v0 + vox_per_wave : V;
+    const bool live = cw < (long)B * chunks_per_b;
+    const int b = live ? (int)(cw / chunks_per_b) : 0;
+    const long v0 = live ? (cw % chunks_per_b) * (long)vox_per_wave : 0;
+    const long v1 = live ? ((v0 + vox_per_wave < V) ? v0 + vox_per_wave : V) : 0;
     const int mt = blockIdx.y / n_ci_tiles, nt = blockIdx.y % n_ci_tiles;
     const int r = lane & 15, q = lane >> 4;
     const int co = mt * 16 + r, ci = nt * 16 + r;
@@ -112,36 +116,54 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x
     vx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     const bool vec = (V & 3) == 0;
-    for (long vb = v0; vb < v1; vb += 16) {            // wave-uniform trip count (MFMA needs every lane); lane covers vb+4q .. vb+4q+3
+    long vb = v0;
+    if (vec) {
+        for (; vb + 64 <= v1; vb += 64) {              // wave-uniform trip count; lane covers vb + 16 s + 4 q .. + 3, s = 0..3
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const long v = vb + 16 * s4 + 4 * q;
+                av[s4] = co_ok ? *reinterpret_cast<const float4*>(arow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[s4] = ci_ok ? *reinterpret_cast<const float4*>(brow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                bsum += (av[s4].x + av[s4].y) + (av[s4].z + av[s4].w);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].x, bv[s4].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].y, bv[s4].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].z, bv[s4].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].w, bv[s4].w, acc, 0, 0, 0);
+            }
+        }
+    }
+    for (; vb < v1; vb += 16) {                        // tail / unaligned volumes
         const long v = vb + 4 * q;
         float a4[4], b4[4];
-        if (vec && v + 3 < v1) {
-            const float4 av = co_ok ? *reinterpret_cast<const float4*>(arow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 bv = ci_ok ? *reinterpret_cast<const float4*>(brow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            a4[0] = av.x; a4[1] = av.y; a4[2] = av.z; a4[3] = av.w;
-            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
-        } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = v + u < v1;
-                a4[u] = (in && co_ok) ? arow[v + u] : 0.0f;
-                b4[u] = (in && ci_ok) ? brow[v + u] : 0.0f;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const bool in = v + u < v1;
+            a4[u] = (in && co_ok) ? arow[v + u] : 0.0f;
+            b4[u] = (in && ci_ok) ? brow[v + u] : 0.0f;
         }
         bsum += (a4[0] + a4[1]) + (a4[2] + a4[3]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], acc, 0, 0, 0);
     }
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[wave][reg * 64 + lane] = acc[reg];
+    if (q == 0) red[wave][256 + r] = bsum;
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
+        const float s_ = (red[0][reg * 64 + lane] + red[1][reg * 64 + lane]) + (red[2][reg * 64 + lane] + red[3][reg * 64 + lane]);
         const int m = mt * 16 + 4 * q + reg, n = nt * 16 + r;
-        if (m < Cout && n < Cin) atomicAdd(dw + (long)m * Cin + n, acc[reg]);
+        if (m < Cout && n < Cin) atomicAdd(dw + (long)m * Cin + n, s_);
     }
-    if (db != nullptr && nt == 0) {
-        bsum += __shfl_xor(bsum, 16, 64);
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (q == 0 && co_ok) atomicAdd(db + co, bsum);
-    }
+    if (db != nullptr && nt == 0 && q == 0 && co_ok)
+        atomicAdd(db + co, (red[0][256 + r] + red[1][256 + r]) + (red[2][256 + r] + red[3][256 + r]));
 }
 
 template <int N> using vx_ic3 = std::integral_constant<int, N>;
@@ -196,11 +218,11 @@ extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, co
     VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_bwd_weight: x2 missing");
     const int mt = vx_cdiv(Cout, 16), nt = vx_cdiv(Cin, 16);
     // voxel chunk per wave: multiple of 16; aim at >= ~2048 waves in flight over all tiles
-    long waves_per_tile = 2048 / ((long)mt * nt);
-    if (waves_per_tile < 1) waves_per_tile = 1;
+    long waves_per_tile = 1024 / ((long)mt * nt);
+    if (waves_per_tile < 4) waves_per_tile = 4;
     long vpw = ((long)B * V + waves_per_tile - 1) / waves_per_tile;
-    vpw = (vpw + 15) / 16 * 16;
-    if (vpw < 64) vpw = 64;
+    vpw = (vpw + 63) / 64 * 64;
+    if (vpw < 256) vpw = 256;
     const int chunks_per_b = vx_cdiv(V, vpw);
     dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), mt * nt);
     vx_pw_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, x2, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);

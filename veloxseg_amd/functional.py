@@ -20,6 +20,7 @@ from . import _hip as H
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
+USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 BRANCH_STREAMS = True                         # independent sub-networks (M+1 decoders; encoder conv chain vs PWA chain) run on forked HIP streams
@@ -142,6 +143,24 @@ class _Conv3dFn(torch.autograd.Function):
         pw = (K == 1 and S == 1 and P == 0 and G == 1 and ps == 1 and Cin % 4 == 0 and C1 % 4 == 0)
         s1 = (x2 is None and S == 1 and K in (3, 5) and P == K // 2 and (Cout // G) % 4 == 0 and (Cin // G) % 4 == 0 and USE_S1)
         ctx.s1 = s1
+        # kernel == stride, no padding, input needs no gradient (PatchEmbed on the image): patchify once, then it is a 1x1 conv
+        patch = (USE_PATCHIFY and K == S and K in (2, 4) and P == 0 and G == 1 and ps == 1 and x2 is None and not x.requires_grad
+                 and D % K == 0 and Hh % K == 0 and W % K == 0 and (Cin * K ** 3) % 4 == 0)
+        ctx.patch = patch
+        if patch:
+            Ck, Vo = Cin * K ** 3, Do * Ho * Wo
+            xs = torch.empty((B, Ck, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+            st = H.stream_ptr()
+            H.call("vx_patchify", H.P(x), H.P(xs), B, Cin, Do, Ho, Wo, K, st)
+            if Vo <= PW_MFMA_MAX_V:
+                H.call("vx_pw_conv_mfma", H.P(xs), None, Ck, H.P(w), 0, H.P(b), H.P(y), None, 0, B, Cout, Ck, Ck, Vo, 0, st)
+            else:
+                H.call("vx_pw_conv_fwd", H.P(xs), None, Ck, H.P(w), H.P(b), H.P(y), B, Ck, Cout, Vo, st)
+            ctx.save_for_backward(xs, None)
+            ctx.w, ctx.b = w, b
+            ctx.meta = (B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps)
+            ctx.pw = False
+            return y
         if pw and D * Hh * W <= PW_MFMA_MAX_V:
             H.call("vx_pw_conv_mfma", H.P(x), H.P(x2), C1, H.P(w), 0, H.P(b), H.P(y), None, 0, B, Cout, Cin, Cin, D * Hh * W, 0, H.stream_ptr())
         elif pw:
@@ -163,6 +182,12 @@ class _Conv3dFn(torch.autograd.Function):
         B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps = ctx.meta
         dy = _c(dy)
         st = H.stream_ptr()
+        if ctx.patch:                           # x is the patchified input (B, Cin*K^3, Do, Ho, Wo); the image itself needs no gradient
+            if w.requires_grad:
+                db = grad_buf(b) if (b is not None and b.requires_grad) else None
+                H.call("vx_pw_conv_bwd_weight", H.P(x), None, Cin * K ** 3, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin * K ** 3, Cout,
+                       (D // K) * (Hh // K) * (W // K), st)
+            return None, None, None, None, None, None, None, None, None
         dx = dx2 = None
         need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         if need_x:
@@ -449,7 +474,8 @@ class _PwaCoreFn(torch.autograd.Function):
         iq = torch.empty(tq.shape, device=dev, dtype=torch.int32)
         ik = torch.empty(tq.shape, device=dev, dtype=torch.int32)
         iv = torch.empty(tv.shape, device=dev, dtype=torch.int32)
-        srcs = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in qkv])
+        srcs_arr = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in qkv])
+        srcs = H.ctypes.addressof(srcs_arr)
         H.call("vx_pwa_gather_all_fwd", srcs, H.P(tq), H.P(tk), H.P(tv), H.P(iq, torch.int32), H.P(ik, torch.int32), H.P(iv, torch.int32),
                pp, cq, cv, M, B, st)
         O = torch.empty_like(tv)
@@ -488,7 +514,8 @@ class _PwaCoreFn(torch.autograd.Function):
         H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
                H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, st)
         grads = [torch.empty(shp, device=dev, dtype=torch.float32) for shp in ctx.qkv_shapes]
-        dsts = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in grads])
+        dsts_arr = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in grads])
+        dsts = H.ctypes.addressof(dsts_arr)
         H.call("vx_pwa_gather_all_bwd", H.P(dq), H.P(dk), H.P(dv), H.P(iq, torch.int32), H.P(ik, torch.int32), H.P(iv, torch.int32), dsts,
                pp, cq, cv, M, B, st)
         return (None, None, None, None, None, None, None, *grads)
