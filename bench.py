@@ -184,7 +184,7 @@ def main():
         # dominant kernel = largest total time among the launches whose algorithmic work we can state
         out["roofline"] = None
         for tot_ms, n, (name, key) in rows:
-            rf = roofline_for(name, key, tot_ms / n)
+            rf = roofline_for(name, key, tot_ms / n, model)
             if rf.get("achieved") is not None:
                 rf["launches_per_step"], rf["share_of_step"] = n, round(tot_ms / total, 4)
                 out["roofline"] = rf
@@ -197,11 +197,27 @@ def main():
         dist.destroy_process_group()
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r01q_pmc_traffic.json")
+
+
+def _pmc_traffic(kernels, B):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
+    correction applied: profiles/r01q_pmc_traffic.json).  Counters cannot be read from inside bench.py; the figure is valid for the workload
+    and batch it was collected on (autopet128, B = 4) and null otherwise."""
+    try:
+        d = json.load(open(PMC_FILE))["kernels"]
+        if B != 4:
+            return None, None
+        return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), "profiles/r01q_pmc_traffic.json"
+    except Exception:
+        return None, None
+
+
 def _conv_out(d, K, S, P):
     return (d + 2 * P - K) // S + 1
 
 
-def roofline_for(name, key, ms_per_launch):
+def roofline_for(name, key, ms_per_launch, model=None):
     """Algorithmic flops / bytes of ONE launch of C-ABI entry `name` with integer arguments `key` (argument order: include/veloxseg_hip.h).
     Convolutions and attention sit above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B) -> priced against the fp32 vector = f32-MFMA peak;
     everything else against HBM."""
@@ -209,7 +225,7 @@ def roofline_for(name, key, ms_per_launch):
     flops = bytes_ = None
     k = list(key)
     try:
-        if name in ("vx_conv3d_fwd", "vx_conv3d_bwd_weight", "vx_conv3d_bwd_weight_tiled", "vx_conv3d_bwd_data"):
+        if name in ("vx_conv3d_fwd", "vx_conv3d_bwd_weight", "vx_conv3d_bwd_weight_tiled", "vx_conv3d_bwd_weight_tiled_ws", "vx_conv3d_bwd_data"):
             if name == "vx_conv3d_bwd_data":
                 k = k[:-1]
             B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps = k[-11:]
@@ -225,8 +241,17 @@ def roofline_for(name, key, ms_per_launch):
             v = B * D * H * W
             flops, bytes_ = 2.0 * v * 64 * Cc * 16 * 27, 4.0 * (v * (16 + 64 * Cc) + 64 * Cc * 16 * 27)
         elif name in ("vx_pwa_attn_fwd", "vx_pwa_attn_bwd"):
-            B, M, cq, cv = k[-4:]          # (..., B, M, cq, cv) after the plan pointer; windows/tokens are not in the int key
-            flops = None
+            B, M, cq, cv = k[:4]           # (B, M, cq, cv[, dropout site]); windows / tokens come from the model's PWA plan with these head widths
+            plan = next((m.plan for m in model.modules() if hasattr(m, "plan") and getattr(m, "c_qk", None) == cq and getattr(m, "c_v", None) == cv), None)
+            if plan is not None:
+                rows = B * plan.heads * plan.Ntot * M * plan.l
+                pairs = rows * M * plan.l
+                # forward: QK^T + PV.  backward (two kernels, P recomputed from the saved LSE): dQ pass QK^T, dP, dQ; dK/dV pass QK^T, dP, dV, dK
+                flops = pairs * (2.0 * cq + 2.0 * cv) if name == "vx_pwa_attn_fwd" else pairs * (8.0 * cq + 6.0 * cv)
+                bytes_ = 4.0 * rows * ((2 * cq + 2 * cv + 1) if name == "vx_pwa_attn_fwd" else (4 * cq + 4 * cv + 3))
+                r["pairs"], r["kernels"] = pairs, 1 if name == "vx_pwa_attn_fwd" else 2
+                r["traffic"], r["traffic_source"] = _pmc_traffic([f"vx_pwa_attn_fwd_k<{cq}, {cv}>"] if name == "vx_pwa_attn_fwd" else
+                                                                 [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"], B)
         elif name in ("vx_pw_conv_fwd", "vx_pw_conv_bwd_data", "vx_pw_conv_bwd_weight"):
             B, Cin, Cout, V = k[-4:] if name != "vx_pw_conv_bwd_data" else k[-5:-1]
             flops, bytes_ = 2.0 * B * V * Cin * Cout, 4.0 * (B * V * (Cin + Cout) + Cin * Cout)

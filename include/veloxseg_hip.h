@@ -48,6 +48,11 @@ int vx_conv3d_bwd_weight(const float* x, const float* x2, int C1, const float* d
 /* LDS-tiled weight gradient for spatial kernels (same contract as vx_conv3d_bwd_weight): x halo tile in LDS, dy on the scalar path */
 int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                                int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* the same with a caller-owned workspace: blocks store partial sums (no float atomics on dw from ~1 k blocks), a second kernel folds them.
+ * vx_conv3d_bwd_weight_ws_floats returns the workspace size in floats (0 = the plain entry is the better path, < 0 = error). */
+int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps);
+int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
 /* weight + bias gradient of a 1x1x1 GROUPED conv with Cin == Cout == C (JLC k = 1 branch, conv_blocks.py:51-58): dw (C, C/G) +=, db (C) += (may be NULL).
  * Needs V % 4 == 0 and a group width of 4, 8 or 16; other shapes go through vx_conv3d_bwd_weight_tiled. */
 int vx_gconv1_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int G, long V, void* stream);

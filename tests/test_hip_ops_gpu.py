@@ -364,10 +364,10 @@ def test_kernel_variants_agree():
         torch.cuda.synchronize()
         return res
 
-    base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096, USE_GCONV1=True)
-    ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0, USE_GCONV1=False))
+    base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096, USE_GCONV1=True, USE_WGRAD_WS=True)
+    ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0, USE_GCONV1=False, USE_WGRAD_WS=False))
     try:
-        for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0), dict(base, USE_GCONV1=False)):
+        for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0), dict(base, USE_GCONV1=False), dict(base, USE_WGRAD_WS=False)):
             got = run(variant)
             for i, (a, b_) in enumerate(zip(got, ref)):
                 close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")

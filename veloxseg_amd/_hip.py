@@ -167,6 +167,20 @@ def profile_end():
     return out
 
 
+def query(name: str, *args) -> int:
+    """entries whose int return value is an answer, not a status (negative = error)"""
+    LIB.load()
+    fn = LIB._fns.get(name)
+    if fn is None:
+        fast = fast_module()
+        fn = LIB._fns[name] = getattr(fast, name, None) if fast is not None and hasattr(fast, name) else getattr(LIB._dll, name)
+    rc = fn(*args)
+    if rc < 0:
+        msg = LIB._dll.vx_last_error()
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else '?'}")
+    return rc
+
+
 def call(name: str, *args):
     if _PROFILE is None:
         LIB.call(name, *args)

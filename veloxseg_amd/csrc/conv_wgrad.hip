@@ -20,6 +20,7 @@ struct VxWg {
     int HD, HH, HW;            // halo tile = (T-1)*S + K
     int nTd, nTh, nTw;         // tiles per axis
     int tiles_per_block;
+    float* part;               // optional partial-sum workspace [slices][Cout * Cin_g * K^3]; nullptr -> float atomics into dw
 };
 
 __device__ __forceinline__ long vx_wg_dy_index(const VxWg& p, int b, int co, int d, int h, int w) {
@@ -149,8 +150,14 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
         for (int n = 0; n < NP; ++n) {
             const int pi = pass0 + n * 256 + threadIdx.x;
             if (pi < npairs) {
+                if (p.part) {                  // every (slice, weight) is written by exactly one block: plain coalesced stores
+                    float* __restrict__ pd = p.part + ((long)blockIdx.z * gridDim.x + blockIdx.x) * ((long)p.Cout * npairs);
 #pragma unroll
-                for (int j = 0; j < COT; ++j) atomicAdd(dw + (long)(co0 + j) * npairs + pi, acc[n][j]);
+                    for (int j = 0; j < COT; ++j) pd[(long)(co0 + j) * npairs + pi] = acc[n][j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < COT; ++j) atomicAdd(dw + (long)(co0 + j) * npairs + pi, acc[n][j]);
+                }
             }
         }
     }
@@ -173,10 +180,28 @@ __global__ void __launch_bounds__(256) vx_bias_grad_k(const float* __restrict__ 
     if (threadIdx.x == 0) atomicAdd(db + co, s);
 }
 
-template <int N> using vx_ic2 = std::integral_constant<int, N>;
+// dw[i] += sum over slices of part[s][i]; grid (cdiv(n,256), slice chunks): coalesced reads, one float atomic per (weight, chunk)
+__global__ void __launch_bounds__(256) vx_wg_reduce_k(const float* __restrict__ part, float* __restrict__ dw, long n, int slices) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int per = (slices + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(s0 + per, slices);
+    float a0 = 0.0f, a1 = 0.0f;
+    int s_ = s0;
+    for (; s_ + 1 < s1; s_ += 2) { a0 += part[(long)s_ * n + i]; a1 += part[(long)(s_ + 1) * n + i]; }
+    if (s_ < s1) a0 += part[(long)s_ * n + i];
+    if (s0 < s1) atomicAdd(dw + i, a0 + a1);
+}
 
-extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
-                                          int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream) {
+template <int N> using vx_ic2 = std::integral_constant<int, N>;
+#ifndef VX_WG_MIN_BLOCKS
+#define VX_WG_MIN_BLOCKS 2048   // the inner loop is latency-bound (scalar dy loads + LDS reads feed few FMAs per thread): 8 waves per SIMD beat big tiles
+#endif
+
+// ws == nullptr: float atomics straight into dw.  ws != nullptr (>= *need floats): blocks store partial sums, vx_wg_reduce_k folds them.
+// query: only compute *need (0 when the atomic path is the better one: few blocks per weight).
+static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats, long* need, bool query,
+                     int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream) {
     VX_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && S > 0 && G > 0 && ps > 0, "vx_conv3d_bwd_weight_tiled: bad args");
     VX_REQUIRE(Cin % G == 0 && Cout % G == 0, "vx_conv3d_bwd_weight_tiled: channels not divisible by groups");
     VxWg p;
@@ -205,9 +230,9 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
     {   // small volumes: prefer more, smaller tiles (>= ~512 blocks) over LDS-filling ones; the atomic flush stays cheap
         const int COT0 = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
         auto nblk = [&]() { return (long)vx_cdiv(p.Do, p.TD) * vx_cdiv(p.Ho, p.TH) * vx_cdiv(p.Wo, p.TW) * G * (Cout_g / COT0) * B; };
-        while (nblk() < 512 && p.TD > 1) p.TD = (p.TD + 1) / 2;
-        while (nblk() < 512 && p.TH > 1) p.TH = (p.TH + 1) / 2;
-        while (nblk() < 512 && p.TW > 8) p.TW = (p.TW + 1) / 2;
+        while (nblk() < VX_WG_MIN_BLOCKS && p.TD > 1) p.TD = (p.TD + 1) / 2;
+        while (nblk() < VX_WG_MIN_BLOCKS && p.TH > 1) p.TH = (p.TH + 1) / 2;
+        while (nblk() < VX_WG_MIN_BLOCKS && p.TW > 8) p.TW = (p.TW + 1) / 2;
     }
     p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
     p.nTd = vx_cdiv(p.Do, p.TD); p.nTh = vx_cdiv(p.Ho, p.TH); p.nTw = vx_cdiv(p.Wo, p.TW);
@@ -224,6 +249,14 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
     const size_t shm = halo_bytes(p.TD, p.TH, p.TW);
     dim3 grid(vx_cdiv(ntiles, tpb), gy, B);
     hipStream_t st = (hipStream_t)stream;
+    const long nw = (long)Cout * npairs;
+    const int slices = (int)grid.x * B;
+    // partial-sum path pays off when many blocks hit every weight (float atomics on one address serialise in L2: the 7^3 stride-4
+    // DownConv issued 11 M atomics on 11 k addresses = 0.5 ms) and the workspace stays small
+    const long want = (slices >= 16 && (long)slices * nw <= (64l << 20)) ? (long)slices * nw : 0;
+    if (need) *need = want;
+    if (query) return 0;
+    p.part = (ws && want > 0 && ws_floats >= want) ? ws : nullptr;
     const int dymode = (ps == 1 && p.Wo % 4 == 0 && p.TW % 4 == 0) ? 1 : ((ps == 4 && COT >= 4) ? 2 : 0);
     auto launch = [&](auto kt, auto cot, auto np) {
         constexpr int KT_ = decltype(kt)::value, COT_ = decltype(cot)::value, NP_ = decltype(np)::value;
@@ -249,6 +282,12 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
         case 5: with_cot(vx_ic2<5>{}); break;
         default: with_cot(vx_ic2<0>{}); break;
     }
+    if (p.part) {
+        int sc = slices / 32;
+        if (sc < 1) sc = 1;
+        if (sc > 32) sc = 32;
+        vx_wg_reduce_k<<<dim3(vx_cdiv(nw, 256), sc), dim3(256), 0, st>>>(p.part, dw, nw, slices);
+    }
     if (db) {
         int chunks = vx_cdiv((long)B * p.Do * p.Ho * p.Wo, 256 * 16);
         if (chunks > 32) chunks = 32;
@@ -256,6 +295,24 @@ extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C
     }
     VX_LAUNCH_CHECK("vx_conv3d_bwd_weight_tiled");
     return 0;
+}
+
+extern "C" int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                                          int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream) {
+    return vx_wg_run(x, x2, C1, dy, dw, db, nullptr, 0, nullptr, false, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps, stream);
+}
+
+extern "C" int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps) {
+    long need = 0;
+    static const float dummy = 0.0f;
+    const int rc = vx_wg_run(&dummy, &dummy, 0, &dummy, const_cast<float*>(&dummy), nullptr, nullptr, 0, &need, true, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps, nullptr);
+    if (rc != 0) return rc;
+    return need > 0x7fffffffl ? 0 : (int)need;
+}
+
+extern "C" int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                             int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream) {
+    return vx_wg_run(x, x2, C1, dy, dw, db, ws, ws_floats, nullptr, false, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps, stream);
 }
 
 

@@ -20,6 +20,8 @@ from . import _hip as H
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
+USE_WGRAD_WS = True                           # tiled weight gradient through a partial-sum workspace instead of float atomics
+_wgrad_ws = {}
 USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
@@ -214,6 +216,14 @@ class _Conv3dFn(torch.autograd.Function):
             elif ctx.s1 and ps == 4 and K == 3 and Cin == 16 and G == 1 and USE_EXPAND_MFMA:
                 xcl = torch.empty((B * D * Hh * W * 16,), device=x.device, dtype=torch.float32)
                 H.call("vx_expand_wgrad_mfma", H.P(x), H.P(xcl), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cout // 64, D, Hh, W, st)
+            elif WGRAD_ENTRY == "vx_conv3d_bwd_weight_tiled" and USE_WGRAD_WS:
+                key = (B, Cin, D, Hh, W, Cout, K, S, P, G, ps)
+                nws = _wgrad_ws.get(key)
+                if nws is None:
+                    nws = _wgrad_ws[key] = H.query("vx_conv3d_bwd_weight_ws_floats", *key)
+                ws = torch.empty((nws,), device=x.device, dtype=torch.float32) if nws > 0 else None
+                H.call("vx_conv3d_bwd_weight_tiled_ws", H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), H.P(ws), nws,
+                       B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
             else:
                 H.call(WGRAD_ENTRY, H.P(x), H.P(x2), C1, H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, st)
         return dx, dx2, None, None, None, None, None, None, None
