@@ -94,6 +94,13 @@ int vx_in_stats(const float* x, float* stats, double* part_ws, long BC, long V, 
 int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                     int nk, int act, const float* res, float* out, long BC, long V, void* stream);
 int vx_in_bwd(const float* dout, const float* y, const float* stats, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream);
+/* short rows (V <= vx_in_row_max() = 4096): statistics + application of up to 3 inputs in ONE launch (block = one (b,c) row held in registers);
+ * s_k (BC,2) receive (mean, rstd); bwd writes dy_k for every non-NULL d_k.  Same arithmetic as the split kernels above. */
+int vx_in_row_max(void);
+int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, float* s0, float* s1, float* s2, int nk, int act, const float* res,
+                  float* out, long BC, long V, float eps, void* stream);
+int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                  int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream);
 
 /* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
 int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);

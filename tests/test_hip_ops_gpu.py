@@ -116,11 +116,13 @@ def test_conv_transpose():
     run_pair(lambda x, w, b: VF.conv_transpose_k2s2(x, w, b), lambda x, w, b: F.conv_transpose3d(x, w, b, stride=2), [x], [w, b], what="convT")
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 5, 4, 3), (2, 4, 16, 16, 16), (1, 3, 20, 20, 12)], ids=["V60_row", "V4096_row", "V4800_split"])
 @pytest.mark.parametrize("n,act,res", [(1, False, False), (1, False, True), (2, False, False), (3, True, True)])
-def test_instnorm_sum(n, act, res):
+def test_instnorm_sum(n, act, res, shape):
+    """short rows (V <= 4096) run the one-launch row kernels, longer ones the split statistics + apply kernels; same oracle"""
     VF = _vf()
-    ys = [rnd(2, 8, 5, 4, 3, seed=i) * (1 + i) + i for i in range(n)]
-    r = [rnd(2, 8, 5, 4, 3, seed=9)] if res else []
+    ys = [rnd(*shape, seed=i) * (1 + i) + i for i in range(n)]
+    r = [rnd(*shape, seed=9)] if res else []
 
     def g(*t):
         return VF.instnorm_sum(list(t[:n]), act=act, res=t[n] if res else None)
@@ -133,6 +135,21 @@ def test_instnorm_sum(n, act, res):
         return out
 
     run_pair(g, c, ys + r, what=f"in{n}")
+    if shape[2] * shape[3] * shape[4] <= 4096:          # and the two kernel families agree with each other
+        import veloxseg_amd.functional as F_
+        d = dev()
+        outs = {}
+        try:
+            for flag in (True, False):
+                F_.USE_IN_ROW = flag
+                t = [y.clone().to(d).requires_grad_(True) for y in ys + r]
+                o = g(*t)
+                o.backward(rnd(*shape, seed=77).to(d))
+                outs[flag] = [o.detach()] + [x.grad for x in t]
+        finally:
+            F_.USE_IN_ROW = True
+        for a, b in zip(outs[True], outs[False]):
+            close(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, "row vs split")
 
 
 def test_layernorm_and_s2d():

@@ -434,3 +434,115 @@ extern "C" int vx_patchify(const float* x, float* out, int B, int C, int d, int 
     VX_LAUNCH_CHECK("vx_patchify");
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// InstanceNorm on SHORT rows (V <= VX_IN_ROW_MAX): statistics and application in ONE launch.  One 256-thread block owns one (b,c) row of
+// every input, keeps it in registers (<= 16 floats per thread and input), reduces in fp64 exactly like vx_in_stats_part_k, then applies.
+// Levels 2-4 of the 128^3 pyramid (16^3, 8^3, 4^3 voxels) take this path: 1 launch instead of n+1 forward and of 2n backward.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define VX_IN_ROW_MAX 4096
+__device__ __forceinline__ void vx_block_sum2_f64(double& a, double& c, double* sm) {
+    a = vx_wave_sum(a);
+    c = vx_wave_sum(c);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sm[wid] = a; sm[4 + wid] = c; }
+    __syncthreads();
+    a = sm[0] + sm[1] + sm[2] + sm[3];
+    c = sm[4] + sm[5] + sm[6] + sm[7];
+}
+
+__global__ void __launch_bounds__(256) vx_in_row_fwd_k(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
+                                                       float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2,
+                                                       int nk, int act, const float* __restrict__ res, float* __restrict__ out, int V, float eps) {
+    __shared__ double sm[8];
+    const long bc = blockIdx.x;
+    const float* ys[3] = {y0, y1, y2};
+    float* ss[3] = {s0, s1, s2};
+    constexpr int R = VX_IN_ROW_MAX / 256;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; acc[r] = (res && v < V) ? res[bc * V + v] : 0.0f; }
+    for (int k = 0; k < nk; ++k) {
+        const float* __restrict__ row = ys[k] + bc * V;
+        float x[R];
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = r * 256 + threadIdx.x;
+            x[r] = v < V ? row[v] : 0.0f;
+            const double t = (double)x[r];
+            a += t;
+            c += t * t;
+        }
+        vx_block_sum2_f64(a, c, sm);
+        const double m = a / (double)V;
+        double var = c / (double)V - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (threadIdx.x == 0) { ss[k][2 * bc] = mean; ss[k][2 * bc + 1] = rstd; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float z = (x[r] - mean) * rstd;
+            acc[r] += act ? vx_gelu(z) : z;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; if (v < V) out[bc * V + v] = acc[r]; }
+}
+
+__global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__ dout, const float* __restrict__ y0, const float* __restrict__ y1,
+                                                       const float* __restrict__ y2, const float* __restrict__ s0, const float* __restrict__ s1,
+                                                       const float* __restrict__ s2, int nk, int act, float* __restrict__ d0, float* __restrict__ d1,
+                                                       float* __restrict__ d2, int V) {
+    __shared__ double sm[8];
+    const long bc = blockIdx.x;
+    const float* ys[3] = {y0, y1, y2};
+    const float* ss[3] = {s0, s1, s2};
+    float* ds[3] = {d0, d1, d2};
+    constexpr int R = VX_IN_ROW_MAX / 256;
+    float g[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; g[r] = v < V ? dout[bc * V + v] : 0.0f; }
+    for (int k = 0; k < nk; ++k) {
+        if (ds[k] == nullptr) continue;                 // this input needs no gradient (block-uniform)
+        const float* __restrict__ row = ys[k] + bc * V;
+        const float mean = ss[k][2 * bc], rstd = ss[k][2 * bc + 1];
+        float z[R], dz[R];
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = r * 256 + threadIdx.x;
+            z[r] = v < V ? (row[v] - mean) * rstd : 0.0f;
+            dz[r] = v < V ? (act ? g[r] * vx_gelu_grad(z[r]) : g[r]) : 0.0f;
+            a += (double)dz[r];
+            c += (double)dz[r] * (double)z[r];
+        }
+        vx_block_sum2_f64(a, c, sm);
+        const float m1 = (float)(a / (double)V), m2 = (float)(c / (double)V);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; if (v < V) ds[k][bc * V + v] = rstd * (dz[r] - m1 - z[r] * m2); }
+    }
+}
+
+extern "C" int vx_in_row_max(void) { return VX_IN_ROW_MAX; }
+
+extern "C" int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, float* s0, float* s1, float* s2, int nk, int act, const float* res,
+                             float* out, long BC, long V, float eps, void* stream) {
+    VX_REQUIRE(y0 && s0 && out && nk >= 1 && nk <= 3 && BC > 0, "vx_in_row_fwd: bad args");
+    VX_REQUIRE(V > 1, "vx_in_row_fwd: InstanceNorm needs more than 1 spatial element per channel (got %ld), as nn.InstanceNorm3d does", V);
+    VX_REQUIRE(V <= VX_IN_ROW_MAX, "vx_in_row_fwd: rows of at most %d elements (got %ld): use vx_in_stats + vx_in_apply_fwd", VX_IN_ROW_MAX, V);
+    VX_REQUIRE((nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)), "vx_in_row_fwd: missing input");
+    vx_in_row_fwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(y0, y1, y2, s0, s1, s2, nk, act, res, out, (int)V, eps);
+    VX_LAUNCH_CHECK("vx_in_row_fwd");
+    return 0;
+}
+
+extern "C" int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                             int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream) {
+    VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd: bad args");
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V);
+    VX_LAUNCH_CHECK("vx_in_row_bwd");
+    return 0;
+}

@@ -20,6 +20,8 @@ from . import _hip as H
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
+USE_IN_ROW = True                             # InstanceNorm of short rows (V <= 4096): statistics + application in one launch
+IN_ROW_MAX = 4096
 USE_WGRAD_WS = True                           # tiled weight gradient through a partial-sum workspace instead of float atomics
 _wgrad_ws = {}
 USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
@@ -286,15 +288,21 @@ class _InstNormSumFn(torch.autograd.Function):
         B, C = ys[0].shape[:2]
         V = ys[0][0, 0].numel()
         st = H.stream_ptr()
-        stats = [torch.empty((B * C * 2,), device=ys[0].device, dtype=torch.float32) for _ in ys]
-        for y, s in zip(ys, stats):
-            part = torch.empty((B * C * 32,), device=y.device, dtype=torch.float64)
-            H.call("vx_in_stats", H.P(y), H.P(s), H.P(part, torch.float64), B * C, V, IN_EPS, st)
         out = torch.empty_like(ys[0])
         res_c = _c(res) if res is not None else None
         pp = [H.P(y) for y in ys] + [None] * (3 - n)
-        ss = [H.P(s) for s in stats] + [None] * (3 - n)
-        H.call("vx_in_apply_fwd", *pp, *ss, n, int(act), H.P(res_c), H.P(out), B * C, V, st)
+        if USE_IN_ROW and V <= IN_ROW_MAX:                      # short rows: statistics + application in one launch
+            sbuf = torch.empty((n, B * C * 2), device=ys[0].device, dtype=torch.float32)
+            stats = [sbuf[k] for k in range(n)]
+            ss = [H.P(s) for s in stats] + [None] * (3 - n)
+            H.call("vx_in_row_fwd", *pp, *ss, n, int(act), H.P(res_c), H.P(out), B * C, V, IN_EPS, st)
+        else:
+            stats = [torch.empty((B * C * 2,), device=ys[0].device, dtype=torch.float32) for _ in ys]
+            for y, s in zip(ys, stats):
+                part = torch.empty((B * C * 32,), device=y.device, dtype=torch.float64)
+                H.call("vx_in_stats", H.P(y), H.P(s), H.P(part, torch.float64), B * C, V, IN_EPS, st)
+            ss = [H.P(s) for s in stats] + [None] * (3 - n)
+            H.call("vx_in_apply_fwd", *pp, *ss, n, int(act), H.P(res_c), H.P(out), B * C, V, st)
         ctx.save_for_backward(*ys, *stats)
         ctx.n, ctx.act, ctx.has_res = n, int(act), res is not None
         return out
@@ -307,6 +315,14 @@ class _InstNormSumFn(torch.autograd.Function):
         B, C = ys[0].shape[:2]
         V = ys[0][0, 0].numel()
         st = H.stream_ptr()
+        if USE_IN_ROW and V <= IN_ROW_MAX:
+            need = [bool(ctx.needs_input_grad[2 + k]) for k in range(n)]
+            grads = [torch.empty_like(ys[k]) if need[k] else None for k in range(n)]
+            if any(need):
+                H.call("vx_in_row_bwd", H.P(dout), *([H.P(y) for y in ys] + [None] * (3 - n)), *([H.P(s_) for s_ in stats] + [None] * (3 - n)),
+                       n, ctx.act, *([H.P(g) for g in grads] + [None] * (3 - n)), B * C, V, st)
+            dres = dout if (ctx.has_res and ctx.needs_input_grad[0]) else None
+            return (dres, None, *grads)
         grads = []
         for k in range(n):
             if ctx.needs_input_grad[2 + k]:
