@@ -155,16 +155,21 @@ class TrainEngine:
                 bg.append(g)
         torch.autograd.backward(bt, bg)
 
-    def _eager_pass(self):
+    def _eager_stages(self, between=None):
+        """the staged pass launched eagerly: decoder stages on forked HIP streams (functional.run_branches; autograd replays each branch's
+        backward on the stream of its forward), `between()` is called once the decoder gradients are complete (decoder-bucket all-reduce)"""
         nb = self.model.num_branches
         self._leaves, self._outs = [None] * nb, [None] * nb
         self._s_enc_fwd()
-        for k in range(nb):
-            self._s_dec_fwd(k)
+        VF.run_branches([(lambda k=k: self._s_dec_fwd(k)) for k in range(nb)], self.dev)
         self._s_loss()
-        for k in range(nb):
-            self._s_dec_bwd(k)
+        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev)
+        if between is not None:
+            between()
         self._s_enc_bwd()
+
+    def _eager_pass(self):
+        self._eager_stages()
 
     def _allreduce(self, lo, hi):
         dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
@@ -336,18 +341,11 @@ class TrainEngine:
                 self._fwd_bwd_single()
                 self._allreduce(0, n)
             else:
-                nb = self.model.num_branches
-                self._leaves, self._outs = [None] * nb, [None] * nb
-                self._s_enc_fwd()
-                for k in range(nb):
-                    self._s_dec_fwd(k)
-                self._s_loss()
-                for k in range(nb):
-                    self._s_dec_bwd(k)
-                self.comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self.comm_stream):
-                    self._allreduce(split, n)
-                self._s_enc_bwd()
+                def decoder_bucket():
+                    self.comm_stream.wait_stream(cur)
+                    with torch.cuda.stream(self.comm_stream):
+                        self._allreduce(split, n)               # overlaps the encoder backward
+                self._eager_stages(between=decoder_bucket)
                 self.comm_stream.wait_stream(cur)
                 with torch.cuda.stream(self.comm_stream):
                     self._allreduce(0, split)
