@@ -40,6 +40,16 @@ def test_eval_logits_vs_oracle_and_golden(golden_dir, name):
     check_compact(logits, fix["eval_logits"], 2e-4, 2e-4, "eval logits vs reference golden")
     mism = float((am.to(torch.uint8) != fix["argmax"]).float().mean())
     assert mism <= 1e-5, f"argmax vs reference golden differs on {mism:.2e} of voxels"
+    # Dice delta vs the reference (north-star bar: < 1e-3): Dice of our mask and of the reference's golden mask against the same labels,
+    # computed by the on-device metrics (utils/metric): the masks are equal, so the delta is 0 up to the <= 1e-5 voxel allowance above
+    from veloxseg_amd.utils.metric import metrics as M, metrics_brats as MB
+    lab = labels.cuda()
+    ours, theirs = am.to(torch.uint8).unsqueeze(1).cuda(), fix["argmax"].unsqueeze(1).cuda()
+    if cfg_d["n_classes"] == 2:
+        d_ours, d_ref = M.metrics_tensor(lab, ours)[-1], M.metrics_tensor(lab, theirs)[-1]
+    else:
+        d_ours, d_ref = MB.cal_dice(ours, lab)[0], MB.cal_dice(theirs, lab)[0]
+    assert abs(d_ours - d_ref) < 1e-3, (d_ours, d_ref)
 
 
 @pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2"])
@@ -184,3 +194,40 @@ def test_graph_replay_after_device_sync_matches_eager():
     for a, b in zip(losses[False], losses[True]):
         assert abs(a - b) <= 2e-3 * abs(a), losses
     assert losses[True][-1] < losses[True][0]
+
+
+def test_composite_blocks_equal_the_fine_grained_operators():
+    """functional.USE_COMPOSITE (one autograd node per JLC block / FFN tail) runs the same kernels in the same order as the per-operator
+    graph: outputs, loss and every gradient agree to summation-order noise, with dropout active (same Philox streams)."""
+    import types
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg_d, _ = CASES["g2_32_m2"]
+    cfg_d = dict(cfg_d, proj_drop=0.1, conv_drop=0.1, attn_drop=0.1)
+    x, labels = make_inputs(cfg_d, 2)
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)
+    res = {}
+    try:
+        for flag in (True, False):
+            VF.USE_COMPOSITE = flag
+            torch.manual_seed(11)
+            model = VeloxSeg(**cfg_d).cuda().train()
+            VF.manual_seed(123, "cuda")
+            out = model(x.cuda())
+            loss = crit(out, labels.cuda(), sr_labels=x.cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            res[flag] = (float(loss), [o.detach().clone() for o in out], {n: p.grad.clone() for n, p in model.named_parameters()})
+            with torch.no_grad():
+                model.eval()
+                res[flag] += (model(x.cuda()).clone(),)
+    finally:
+        VF.USE_COMPOSITE = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):        # (the Gram outputs are float-atomic sums: equal to round-off, not bit for bit)
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    assert torch.equal(res[True][3], res[False][3])
+    for n, g in res[False][2].items():
+        d_ = float((res[True][2][n] - g).abs().max())
+        assert d_ <= 1e-5 * max(1e-3, float(g.abs().max())), (n, d_)

@@ -17,6 +17,7 @@ eng = TrainEngine(model, crit, (B, 2, S, S, S), use_graph=False, overlap=False)
 x, lab = synth(cfg, B, "cuda", 1)
 from veloxseg_amd import functional as VF
 VF.BRANCH_STREAMS = os.environ.get("VX_BRANCH_STREAMS", "1") == "1"
+VF.USE_COMPOSITE = os.environ.get("VX_COMPOSITE", "1") == "1"
 for _ in range(3):
     eng.step(x, lab)
 torch.cuda.synchronize()

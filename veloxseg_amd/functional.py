@@ -455,6 +455,126 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
+# ------------------------------------------------------------------------------------------------
+# composite blocks: ONE autograd node for a whole JLC block / transformer FFN tail
+# ------------------------------------------------------------------------------------------------
+# The fine-grained operators above cost ~45 us of host time each per step (autograd node + python + allocations), and the step is
+# host-bound once the GPU side overlaps on several streams.  A composite runs the SAME forward / backward code of
+# those operators (their staticmethods, on a light context object instead of an autograd ctx) in a fixed order, so the kernels, the
+# arithmetic and the dropout streams are identical; only the 8 (JLC) / 4 (FFN) inner autograd nodes and their bookkeeping disappear.
+USE_COMPOSITE = True
+
+
+class _Ctx:
+    """stand-in for the autograd ctx when an operator's forward/backward staticmethods are called directly"""
+    __slots__ = ("saved_tensors", "needs_input_grad", "__dict__")
+
+    def __init__(self):
+        self.saved_tensors = ()
+        self.needs_input_grad = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+
+def _sum3(a, b, c=None):
+    out = torch.empty_like(a)
+    H.call("vx_add", H.P(a), H.P(_c(b)), H.P(_c(c)) if c is not None else None, H.P(out), a.numel(), H.stream_ptr())
+    return out
+
+
+class _JLCFn(torch.autograd.Function):
+    """x + sum_k GELU(IN(gconv_k(x))) =: o ;  out = o + Drop(conv2(GELU(conv1(IN(o)))))   (reference conv_blocks.py:41-75)"""
+
+    @staticmethod
+    def forward(ctx, x, mod, p, site):
+        cs, ys = [], []
+        for seq in mod.spatial_convs:
+            conv = seq[0]
+            c = _Ctx()
+            K = conv.kernel_size[0]
+            ys.append(_Conv3dFn.forward(c, x, None, conv.weight, conv.bias, K, 1, K // 2, conv.groups, 1))
+            cs.append(c)
+        c_in1, c_in2, c1, cg, c2, cr = _Ctx(), _Ctx(), _Ctx(), _Ctx(), _Ctx(), _Ctx()
+        o = _InstNormSumFn.forward(c_in1, x, True, *ys)
+        n = _InstNormSumFn.forward(c_in2, None, False, o)
+        l1, l2 = mod.channel_conv[1], mod.channel_conv[3]
+        a = _Conv3dFn.forward(c1, n, None, l1.weight, l1.bias, 1, 1, 0, 1, 1)
+        h = _GeluDropFn.forward(cg, a, 0.0, 0)
+        z = _Conv3dFn.forward(c2, h, None, l2.weight, l2.bias, 1, 1, 0, 1, 1)
+        out = _AxpyDropFn.forward(cr, o, z, 1.0, float(p), int(site))
+        ctx.tape = (cs, c_in1, c_in2, c1, cg, c2, cr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cs, c_in1, c_in2, c1, cg, c2, cr = ctx.tape
+        ctx.tape = None
+        cr.needs_input_grad = (True, True, False, False, False)
+        do_res, dz = _AxpyDropFn.backward(cr, dout)[:2]
+        c2.needs_input_grad = (True,) + (False,) * 8
+        dh = _Conv3dFn.backward(c2, dz)[0]
+        cg.needs_input_grad = (True, False, False)
+        da = _GeluDropFn.backward(cg, dh)[0]
+        c1.needs_input_grad = (True,) + (False,) * 8
+        dn = _Conv3dFn.backward(c1, da)[0]
+        c_in2.needs_input_grad = (False, False, True)
+        do2 = _InstNormSumFn.backward(c_in2, dn)[2]
+        do = _sum3(_c(do_res), do2)
+        n = len(cs)
+        c_in1.needs_input_grad = (True, False) + (True,) * n
+        g = _InstNormSumFn.backward(c_in1, do)
+        dxs = []
+        for k, c in enumerate(cs):
+            c.needs_input_grad = (True,) + (False,) * 8
+            dxs.append(_Conv3dFn.backward(c, g[2 + k])[0])
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        dx = _sum3(do, dxs[0], dxs[1] if n > 1 else None)
+        if n > 2:
+            dx = _sum3(dx, dxs[2])
+        return dx, None, None, None
+
+
+def jlc_block(x, mod, p: float, site: int):
+    return _JLCFn.apply(x, mod, float(p), int(site))
+
+
+class _FFNTailFn(torch.autograd.Function):
+    """out = y + Drop(linear2(Drop(GELU(linear1(LN(y))))))   (reference PWA.py:437 with attention_utils.py:45-71)"""
+
+    @staticmethod
+    def forward(ctx, y, norm, ffn, p):
+        cl, c1, cg, c2, cr = _Ctx(), _Ctx(), _Ctx(), _Ctx(), _Ctx()
+        n = _LayerNormCFFn.forward(cl, y, norm.weight, norm.bias)
+        a = _Conv3dFn.forward(c1, n, None, ffn.linear1.weight, ffn.linear1.bias, 1, 1, 0, 1, 1)
+        h = _GeluDropFn.forward(cg, a, float(p), int(ffn.site1))
+        z = _Conv3dFn.forward(c2, h, None, ffn.linear2.weight, ffn.linear2.bias, 1, 1, 0, 1, 1)
+        out = _AxpyDropFn.forward(cr, y, z, 1.0, float(p), int(ffn.site2))
+        ctx.tape = (cl, c1, cg, c2, cr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cl, c1, cg, c2, cr = ctx.tape
+        ctx.tape = None
+        cr.needs_input_grad = (True, True, False, False, False)
+        dy_res, dz = _AxpyDropFn.backward(cr, dout)[:2]
+        c2.needs_input_grad = (True,) + (False,) * 8
+        dh = _Conv3dFn.backward(c2, dz)[0]
+        cg.needs_input_grad = (True, False, False)
+        da = _GeluDropFn.backward(cg, dh)[0]
+        c1.needs_input_grad = (True,) + (False,) * 8
+        dn = _Conv3dFn.backward(c1, da)[0]
+        cl.needs_input_grad = (True, False, False)
+        dy_ln = _LayerNormCFFn.backward(cl, dn)[0]
+        return _sum3(_c(dy_res), dy_ln), None, None, None
+
+
+def ffn_tail(y, norm, ffn, p: float):
+    return _FFNTailFn.apply(y, norm, ffn, float(p))
+
+
 class _SpaceToDepth2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -122,6 +122,8 @@ class Paired_Windows_TransformerBlock(nn.Module):
 
     def forward(self, xs):
         ys = self.attn(xs, residual_scale=2.0)
+        if VF.USE_COMPOSITE:
+            return [VF.ffn_tail(ys[m], self.norms[m], self.ffns[m], self.ffns[m].p if self.training else 0.0) for m in range(self.num_modalities)]
         return [self.ffns[m](self.norms[m](ys[m]), residual=ys[m]) for m in range(self.num_modalities)]
 
 

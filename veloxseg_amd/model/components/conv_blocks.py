@@ -58,6 +58,8 @@ class JLC(nn.Module):
         self.site = VF.new_dropout_site()
 
     def forward(self, x):
+        if VF.USE_COMPOSITE and x.is_cuda:
+            return VF.jlc_block(x, self, self.p if self.training else 0.0, self.site)       # same kernels, one autograd node
         ys = [seq[0](x) for seq in self.spatial_convs]
         o = VF.instnorm_sum(ys, act=True, res=x)
         h = VF.gelu_dropout(self.channel_conv[1](VF.instnorm_sum([o])), 0.0, 0)
