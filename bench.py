@@ -166,10 +166,11 @@ def main():
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "hip_graph": bool(eng.use_graph), "launch": "hipGraph per stage" if eng.use_graph else "eager, decoder branches on forked HIP streams", "final_loss": round(loss, 5)}}
+                          "hip_graph": bool(eng.use_graph), "launch": "hipGraph per stage" if eng.use_graph else "eager; decoder branches and the encoder conv chain on forked HIP streams", "final_loss": round(loss, 5)}}
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
         from veloxseg_amd import functional as VF
+        _pmc_traffic.workload = args.workload
         eng.flat.reattach()
         VF.BRANCH_STREAMS = False          # one stream: HIP-event intervals are then the kernels' own durations, not shared-GPU time
         eng._fwd_bwd_single()
@@ -206,11 +207,14 @@ def _pmc_traffic(kernels, B):
     and batch it was collected on (autopet128, B = 4) and null otherwise."""
     try:
         d = json.load(open(PMC_FILE))["kernels"]
-        if B != 4:
+        if B != 4 or _pmc_traffic.workload != "autopet128":
             return None, None
         return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), "profiles/r01q_pmc_traffic.json"
     except Exception:
         return None, None
+
+
+_pmc_traffic.workload = None
 
 
 def _conv_out(d, K, S, P):
