@@ -124,3 +124,16 @@ def test_fastcall_extension_wraps_every_entry_point():
         fast.vx_pwa_attn_set_split("two")             # wrong type: nothing is launched
     assert fast.vx_pwa_attn_set_split(3) != 0 and b"must be" in H.LIB.load().vx_last_error()
     assert fast.vx_pwa_attn_set_split(0) == 0
+
+
+def test_cpp_operator_module_builds_and_loads():
+    """veloxseg_amd._vxops (C++ operator bodies) imports on a CPU-only box and refuses CPU tensors like the python bodies do"""
+    import pytest
+    import torch
+    from veloxseg_amd import functional as VF
+    m = VF.cpp_module()
+    assert m is not None, "run `python -c 'import __graft_entry__ as g; g.build()'`"
+    for name in ("conv_fwd", "conv_bwd", "in_fwd", "in_bwd", "ln_fwd", "ln_bwd", "gelu_fwd", "gelu_bwd", "axpy_fwd", "axpy_bwd", "jlc_fwd", "jlc_bwd", "ffn_fwd", "ffn_bwd"):
+        assert hasattr(m, name), name
+    with pytest.raises(RuntimeError, match="no CPU"):
+        VF.conv3d(torch.zeros(1, 4, 4, 4, 4), torch.zeros(4, 4, 1, 1, 1))

@@ -1,0 +1,400 @@
+// veloxseg_amd._vxops -- the host-side operator bodies in C++ (pybind11 + ATen for allocation only).
+//
+// Why: one eager training step makes ~300 operator calls and ~1050 kernel launches; with the operator bodies in Python the host needs
+// 14-16 ms per step, more than the GPU.  This module runs the SAME sequences of C-ABI calls (include/veloxseg_hip.h) that
+// veloxseg_amd/functional.py runs -- routing, workspace allocation, launches -- without the interpreter in between.  Autograd stays in
+// Python: every entry here is a plain forward or backward function returning tensors plus an opaque state object; functional.py keeps one
+// torch.autograd.Function per operator / composite block and calls these from its forward / backward.  The arithmetic lives in
+// libveloxseg_hip.so either way; this file contains no kernels and no CPU implementation.
+//
+// Reference call sites mirrored by the composites: JLC block conv_blocks.py:41-75; FFN tail PWA.py:437 + attention_utils.py:45-71.
+#include <torch/extension.h>
+#include <memory>
+#include <vector>
+#include "../../include/veloxseg_hip.h"
+
+using at::Tensor;
+typedef c10::optional<Tensor> OptT;
+
+namespace {
+
+struct Flags {
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = true, use_patchify = true, use_in_row = true;
+    int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    double in_eps = 1e-5, ln_eps = 1e-6;
+} F;
+
+inline void chk(int rc, const char* what) {
+    if (rc != 0) {
+        const char* m = vx_last_error();
+        throw std::runtime_error(std::string(what) + " failed (rc=" + std::to_string(rc) + "): " + (m ? m : "?"));
+    }
+}
+inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline float* mp(Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline Tensor contig(const Tensor& t) { return t.is_contiguous() ? t : t.contiguous(); }
+inline void check_in(const Tensor& x, const char* what) {
+    TORCH_CHECK(x.is_cuda(), "veloxseg_amd.", what, ": input is on ", x.device(), "; the VeloxSeg hot path runs only on an MI355X (HIP kernels, no CPU fallback)");
+    TORCH_CHECK(x.scalar_type() == at::kFloat, "veloxseg_amd.", what, ": expected float32");
+}
+inline float* grad_ptr(const Tensor& p) {          // running gradient buffer of a parameter (created zeroed on first use), as functional.grad_buf
+    if (!p.defined() || !p.requires_grad()) return nullptr;
+    if (!p.grad().defined()) const_cast<Tensor&>(p).mutable_grad() = at::zeros_like(p);
+    return p.grad().data_ptr<float>();
+}
+
+// ------------------------------------------------------------------------------------------------------------------- convolution
+struct ConvState {
+    Tensor x, x2, w, b;
+    int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
+    bool pw = false, s1 = false, patch = false;
+};
+
+Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
+                     bool x_requires_grad, void* stream) {
+    check_in(x_in, "conv3d");
+    Tensor x = contig(x_in), x2 = x2_in.defined() ? contig(x2_in) : Tensor();
+    const int B = x.size(0), C1 = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4);
+    const int Cin = C1 + (x2.defined() ? (int)x2.size(1) : 0), Cout = w.size(0);
+    TORCH_CHECK(w.size(1) * G == Cin && w.size(2) == K, "conv3d: weight shape does not match the input");
+    const int Do = (D + 2 * P - K) / S + 1, Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+    Tensor y = ps == 1 ? at::empty({B, Cout, Do, Ho, Wo}, x.options()) : at::empty({B, Cout / (ps * ps * ps), Do * ps, Ho * ps, Wo * ps}, x.options());
+    const long V = (long)D * H * W;
+    st.pw = (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1 && Cin % 4 == 0 && C1 % 4 == 0);
+    st.s1 = (!x2.defined() && S == 1 && (K == 3 || K == 5) && P == K / 2 && (Cout / G) % 4 == 0 && (Cin / G) % 4 == 0 && F.use_s1);
+    st.patch = (F.use_patchify && K == S && (K == 2 || K == 4) && P == 0 && G == 1 && ps == 1 && !x2.defined() && !x_requires_grad &&
+                D % K == 0 && H % K == 0 && W % K == 0 && (Cin * K * K * K) % 4 == 0);
+    st.w = w; st.b = b;
+    st.B = B; st.C1 = C1; st.Cin = Cin; st.D = D; st.H = H; st.W = W; st.Cout = Cout; st.K = K; st.S = S; st.P = P; st.G = G; st.ps = ps;
+    if (st.patch) {
+        const int Ck = Cin * K * K * K;
+        const long Vo = (long)Do * Ho * Wo;
+        Tensor xs = at::empty({B, Ck, Do, Ho, Wo}, x.options());
+        chk(vx_patchify(fp(x), mp(xs), B, Cin, Do, Ho, Wo, K, stream), "vx_patchify");
+        if (Vo <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(xs), nullptr, Ck, fp(w), 0, fp(b), mp(y), nullptr, 0, B, Cout, Ck, Ck, Vo, 0, stream), "vx_pw_conv_mfma");
+        else chk(vx_pw_conv_fwd(fp(xs), nullptr, Ck, fp(w), fp(b), mp(y), B, Ck, Cout, Vo, stream), "vx_pw_conv_fwd");
+        st.x = xs;
+        st.pw = false;
+        return y;
+    }
+    if (st.pw && V <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(x), fp(x2), C1, fp(w), 0, fp(b), mp(y), nullptr, 0, B, Cout, Cin, Cin, V, 0, stream), "vx_pw_conv_mfma");
+    else if (st.pw) chk(vx_pw_conv_fwd(fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, Cout, V, stream), "vx_pw_conv_fwd");
+    else if (st.s1) chk(vx_conv_s1(fp(x), fp(w), fp(b), mp(y), B, Cin, Cout, D, H, W, K, G, 0, 1, ps, 0, stream), "vx_conv_s1");
+    else chk(vx_conv3d_fwd(fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_fwd");
+    st.x = x; st.x2 = x2;
+    return y;
+}
+
+// dx / dx2 are returned undefined when need_x is false; parameter gradients are accumulated into w.grad / b.grad
+void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, Tensor& dx2, void* stream) {
+    Tensor dy = contig(dy_in);
+    const int B = st.B, C1 = st.C1, Cin = st.Cin, D = st.D, H = st.H, W = st.W, Cout = st.Cout, K = st.K, S = st.S, P = st.P, G = st.G, ps = st.ps;
+    const long V = (long)D * H * W;
+    const Tensor& x = st.x; const Tensor& x2 = st.x2; const Tensor& w = st.w; const Tensor& b = st.b;
+    if (st.patch) {
+        if (w.requires_grad())
+            chk(vx_pw_conv_bwd_weight(fp(x), nullptr, Cin * K * K * K, fp(dy), grad_ptr(w), grad_ptr(b), B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), stream),
+                "vx_pw_conv_bwd_weight");
+        return;
+    }
+    if (need_x) {
+        dx = at::empty_like(x);
+        if (x2.defined()) dx2 = at::empty_like(x2);
+        if (st.pw && V <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(dy), nullptr, 0, fp(w), 1, nullptr, mp(dx), mp(dx2), C1, B, Cin, Cout, Cin, V, 0, stream), "vx_pw_conv_mfma");
+        else if (st.pw) chk(vx_pw_conv_bwd_data(fp(dy), fp(w), mp(dx), mp(dx2), C1, B, Cin, Cout, V, 0, stream), "vx_pw_conv_bwd_data");
+        else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
+            Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
+            chk(vx_expand_bwd_data_mfma(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, 0, stream), "vx_expand_bwd_data_mfma");
+        } else if (st.s1) chk(vx_conv_s1(fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, 0, stream), "vx_conv_s1");
+        else chk(vx_conv3d_bwd_data(fp(dy), fp(w), nullptr, mp(dx), mp(dx2), C1, B, Cin, D, H, W, Cout, K, S, P, G, ps, 0, stream), "vx_conv3d_bwd_data");
+    }
+    if (w.requires_grad()) {
+        float* dw = grad_ptr(w);
+        float* db = grad_ptr(b);
+        if (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1) chk(vx_pw_conv_bwd_weight(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, Cout, V, stream), "vx_pw_conv_bwd_weight");
+        else if (F.use_gconv1 && K == 1 && S == 1 && P == 0 && G > 1 && ps == 1 && !x2.defined() && Cin == Cout && (Cin / G == 4 || Cin / G == 8 || Cin / G == 16) && V % 4 == 0)
+            chk(vx_gconv1_bwd_weight(fp(x), fp(dy), dw, db, B, Cin, G, V, stream), "vx_gconv1_bwd_weight");
+        else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
+            Tensor xcl = at::empty({(long)B * V * 16}, x.options());
+            chk(vx_expand_wgrad_mfma(fp(x), mp(xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, stream), "vx_expand_wgrad_mfma");
+        } else if (F.use_wgrad_ws) {
+            const int nws = vx_conv3d_bwd_weight_ws_floats(B, Cin, D, H, W, Cout, K, S, P, G, ps);
+            TORCH_CHECK(nws >= 0, "vx_conv3d_bwd_weight_ws_floats failed");
+            Tensor ws = nws > 0 ? at::empty({(long)nws}, x.options()) : Tensor();
+            chk(vx_conv3d_bwd_weight_tiled_ws(fp(x), fp(x2), C1, fp(dy), dw, db, mp(ws), nws, B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_bwd_weight_tiled_ws");
+        } else chk(vx_conv3d_bwd_weight_tiled(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_bwd_weight_tiled");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- InstanceNorm
+struct INState {
+    std::vector<Tensor> ys, stats;
+    int n = 0, act = 0;
+    bool has_res = false;
+    long BC = 0, V = 0;
+};
+
+Tensor in_fwd_impl(INState& st, const Tensor& res, bool act, const std::vector<Tensor>& ys_in, void* stream) {
+    const int n = (int)ys_in.size();
+    TORCH_CHECK(n >= 1 && n <= 3, "instance_norm: 1..3 inputs");
+    check_in(ys_in[0], "instance_norm");
+    st.ys.clear();
+    for (auto& y : ys_in) st.ys.push_back(contig(y));
+    const long BC = st.ys[0].size(0) * st.ys[0].size(1), V = st.ys[0].numel() / BC;
+    st.n = n; st.act = act ? 1 : 0; st.has_res = res.defined(); st.BC = BC; st.V = V;
+    Tensor out = at::empty_like(st.ys[0]);
+    Tensor res_c = res.defined() ? contig(res) : Tensor();
+    const float* yp[3] = {fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr};
+    st.stats.clear();
+    if (F.use_in_row && V <= F.in_row_max) {
+        Tensor sbuf = at::empty({n, BC * 2}, st.ys[0].options());
+        for (int k = 0; k < n; ++k) st.stats.push_back(sbuf[k]);
+        float* sp[3] = {mp(st.stats[0]), n > 1 ? mp(st.stats[1]) : nullptr, n > 2 ? mp(st.stats[2]) : nullptr};
+        chk(vx_in_row_fwd(yp[0], yp[1], yp[2], sp[0], sp[1], sp[2], n, st.act, fp(res_c), mp(out), BC, V, (float)F.in_eps, stream), "vx_in_row_fwd");
+    } else {
+        for (int k = 0; k < n; ++k) {
+            Tensor s = at::empty({BC * 2}, st.ys[0].options());
+            Tensor part = at::empty({BC * 32}, st.ys[0].options().dtype(at::kDouble));
+            chk(vx_in_stats(yp[k], mp(s), part.data_ptr<double>(), BC, V, (float)F.in_eps, stream), "vx_in_stats");
+            st.stats.push_back(s);
+        }
+        chk(vx_in_apply_fwd(yp[0], yp[1], yp[2], fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr, n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, fp(res_c),
+                            mp(out), BC, V, stream), "vx_in_apply_fwd");
+    }
+    return out;
+}
+
+// grads[k] defined for every k with need[k]; the residual gradient is dout itself
+std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::vector<bool>& need, void* stream) {
+    Tensor dout = contig(dout_in);
+    const int n = st.n;
+    std::vector<Tensor> grads(n);
+    bool any = false;
+    for (int k = 0; k < n; ++k) if (need[k]) { grads[k] = at::empty_like(st.ys[k]); any = true; }
+    if (!any) return grads;
+    if (F.use_in_row && st.V <= F.in_row_max) {
+        chk(vx_in_row_bwd(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
+                          n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr, n > 2 ? mp(grads[2]) : nullptr, st.BC, st.V, stream),
+            "vx_in_row_bwd");
+    } else {
+        for (int k = 0; k < n; ++k) {
+            if (!need[k]) continue;
+            Tensor ws = at::empty({st.BC * 2}, dout.options());
+            Tensor part = at::empty({st.BC * 32}, dout.options().dtype(at::kDouble));
+            chk(vx_in_bwd(fp(dout), fp(st.ys[k]), fp(st.stats[k]), st.act, mp(ws), part.data_ptr<double>(), mp(grads[k]), st.BC, st.V, stream), "vx_in_bwd");
+        }
+    }
+    return grads;
+}
+
+// ------------------------------------------------------------------------------------------------------------------- LayerNorm, GELU, residual
+struct LNState { Tensor x, g, bt; };
+
+Tensor ln_fwd_impl(LNState& st, const Tensor& x_in, const Tensor& g, const Tensor& bt, void* stream) {
+    check_in(x_in, "layer_norm");
+    st.x = contig(x_in); st.g = g; st.bt = bt;
+    Tensor out = at::empty_like(st.x);
+    const int B = st.x.size(0), C = st.x.size(1);
+    chk(vx_ln_cf_fwd(fp(st.x), fp(g), fp(bt), mp(out), B, C, st.x.numel() / ((long)B * C), (float)F.ln_eps, stream), "vx_ln_cf_fwd");
+    return out;
+}
+Tensor ln_bwd_impl(LNState& st, const Tensor& dout_in, void* stream) {
+    Tensor dout = contig(dout_in);
+    const int B = st.x.size(0), C = st.x.size(1);
+    const long V = st.x.numel() / ((long)B * C);
+    Tensor dx = at::empty_like(st.x);
+    Tensor ws = at::empty({2 * (long)B * V}, st.x.options());
+    chk(vx_ln_cf_bwd(fp(st.x), fp(st.g), fp(dout), mp(dx), grad_ptr(st.g), grad_ptr(st.bt), mp(ws), B, C, V, (float)F.ln_eps, stream), "vx_ln_cf_bwd");
+    return dx;
+}
+
+struct GeluState { Tensor a; double p = 0; int64_t site = 0; const void* rs = nullptr; };
+Tensor gelu_fwd_impl(GeluState& st, const Tensor& a_in, double p, int64_t site, const void* rs, void* stream) {
+    check_in(a_in, "gelu");
+    st.a = contig(a_in); st.p = p; st.site = site; st.rs = p > 0 ? rs : nullptr;
+    Tensor h = at::empty_like(st.a);
+    chk(vx_gelu_drop_fwd(fp(st.a), mp(h), st.a.numel(), st.rs, (unsigned long long)site, (float)p, stream), "vx_gelu_drop_fwd");
+    return h;
+}
+Tensor gelu_bwd_impl(GeluState& st, const Tensor& dh_in, void* stream) {
+    Tensor dh = contig(dh_in);
+    Tensor da = at::empty_like(st.a);
+    chk(vx_gelu_drop_bwd(fp(dh), fp(st.a), mp(da), st.a.numel(), st.rs, (unsigned long long)st.site, (float)st.p, stream), "vx_gelu_drop_bwd");
+    return da;
+}
+
+struct AxpyState { double alpha = 1, p = 0; int64_t site = 0; const void* rs = nullptr; bool has_x = false; };
+Tensor axpy_fwd_impl(AxpyState& st, const Tensor& x, const Tensor& z_in, double alpha, double p, int64_t site, const void* rs, void* stream) {
+    check_in(z_in, "residual_dropout");
+    Tensor z = contig(z_in), xc = x.defined() ? contig(x) : Tensor();
+    st.alpha = alpha; st.p = p; st.site = site; st.rs = p > 0 ? rs : nullptr; st.has_x = x.defined();
+    Tensor out = at::empty_like(z);
+    chk(vx_axpy_drop_fwd(fp(xc), fp(z), mp(out), (float)alpha, z.numel(), st.rs, (unsigned long long)site, (float)p, stream), "vx_axpy_drop_fwd");
+    return out;
+}
+// -> (dx or undefined, dz)
+void axpy_bwd_impl(AxpyState& st, const Tensor& dout_in, bool need_x_in, Tensor& dx, Tensor& dz, void* stream) {
+    Tensor dout = contig(dout_in);
+    const bool need_x = st.has_x && need_x_in;
+    if (st.p == 0.0 && (st.alpha == 1.0 || !need_x)) { if (need_x) dx = dout; dz = dout; return; }
+    if (need_x) dx = st.alpha == 1.0 ? dout : at::empty_like(dout);
+    dz = st.p == 0.0 ? dout : at::empty_like(dout);
+    chk(vx_axpy_drop_bwd(fp(dout), (need_x && st.alpha != 1.0) ? mp(dx) : nullptr, st.p > 0 ? mp(dz) : nullptr, (float)st.alpha, dout.numel(), st.rs,
+                         (unsigned long long)st.site, (float)st.p, stream), "vx_axpy_drop_bwd");
+}
+
+inline Tensor sum3(const Tensor& a, const Tensor& b, const Tensor& c, void* stream) {
+    Tensor ac = contig(a), bc = contig(b), cc = c.defined() ? contig(c) : Tensor();
+    Tensor out = at::empty_like(ac);
+    chk(vx_add(fp(ac), fp(bc), fp(cc), mp(out), ac.numel(), stream), "vx_add");
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------- composites
+struct JLCState {
+    std::vector<ConvState> convs;
+    INState in1, in2;
+    ConvState c1, c2;
+    GeluState g;
+    AxpyState r;
+};
+
+struct FFNState {
+    LNState ln;
+    ConvState c1, c2;
+    GeluState g;
+    AxpyState r;
+};
+
+inline void* sp(int64_t v) { return reinterpret_cast<void*>(v); }
+
+}  // namespace
+
+// =================================================================================================================== python surface
+PYBIND11_MODULE(_vxops, m) {
+    m.doc() = "C++ operator bodies of veloxseg_amd.functional (same C-ABI calls, no interpreter in between)";
+    py::class_<ConvState, std::shared_ptr<ConvState>>(m, "ConvState");
+    py::class_<INState, std::shared_ptr<INState>>(m, "INState");
+    py::class_<LNState, std::shared_ptr<LNState>>(m, "LNState");
+    py::class_<GeluState, std::shared_ptr<GeluState>>(m, "GeluState");
+    py::class_<AxpyState, std::shared_ptr<AxpyState>>(m, "AxpyState");
+    py::class_<JLCState, std::shared_ptr<JLCState>>(m, "JLCState");
+    py::class_<FFNState, std::shared_ptr<FFNState>>(m, "FFNState");
+
+    m.def("set_flags", [](bool s1, bool expand_mfma, bool gconv1, bool wgrad_ws, bool patchify, bool in_row, int64_t pw_mfma_max_v, int64_t in_row_max, double in_eps,
+                          double ln_eps) {
+        F.use_s1 = s1; F.use_expand_mfma = expand_mfma; F.use_gconv1 = gconv1; F.use_wgrad_ws = wgrad_ws; F.use_patchify = patchify; F.use_in_row = in_row;
+        F.pw_mfma_max_v = pw_mfma_max_v; F.in_row_max = in_row_max; F.in_eps = in_eps; F.ln_eps = ln_eps;
+    });
+
+    m.def("conv_fwd", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int K, int S, int P, int G, int ps, int64_t stream) {
+        auto st = std::make_shared<ConvState>();
+        Tensor y = conv_fwd_impl(*st, x, x2.value_or(Tensor()), w, b.value_or(Tensor()), K, S, P, G, ps, x.requires_grad(), sp(stream));
+        return py::make_tuple(y, st);
+    });
+    m.def("conv_bwd", [](std::shared_ptr<ConvState> st, const Tensor& dy, bool need_x, int64_t stream) {
+        Tensor dx, dx2;
+        conv_bwd_impl(*st, dy, need_x, dx, dx2, sp(stream));
+        return py::make_tuple(dx.defined() ? py::cast(dx) : py::none(), dx2.defined() ? py::cast(dx2) : py::none());
+    });
+
+    m.def("in_fwd", [](const OptT& res, bool act, const std::vector<Tensor>& ys, int64_t stream) {
+        auto st = std::make_shared<INState>();
+        Tensor out = in_fwd_impl(*st, res.value_or(Tensor()), act, ys, sp(stream));
+        return py::make_tuple(out, st);
+    });
+    m.def("in_bwd", [](std::shared_ptr<INState> st, const Tensor& dout, const std::vector<bool>& need, int64_t stream) {
+        auto g = in_bwd_impl(*st, dout, need, sp(stream));
+        py::list out;
+        for (auto& t : g) out.append(t.defined() ? py::cast(t) : py::none());
+        return out;
+    });
+
+    m.def("ln_fwd", [](const Tensor& x, const Tensor& g, const Tensor& bt, int64_t stream) {
+        auto st = std::make_shared<LNState>();
+        Tensor out = ln_fwd_impl(*st, x, g, bt, sp(stream));
+        return py::make_tuple(out, st);
+    });
+    m.def("ln_bwd", [](std::shared_ptr<LNState> st, const Tensor& dout, int64_t stream) { return ln_bwd_impl(*st, dout, sp(stream)); });
+
+    m.def("gelu_fwd", [](const Tensor& a, double p, int64_t site, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<GeluState>();
+        Tensor h = gelu_fwd_impl(*st, a, p, site, sp(rs), sp(stream));
+        return py::make_tuple(h, st);
+    });
+    m.def("gelu_bwd", [](std::shared_ptr<GeluState> st, const Tensor& dh, int64_t stream) { return gelu_bwd_impl(*st, dh, sp(stream)); });
+
+    m.def("axpy_fwd", [](const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<AxpyState>();
+        Tensor out = axpy_fwd_impl(*st, x.value_or(Tensor()), z, alpha, p, site, sp(rs), sp(stream));
+        return py::make_tuple(out, st);
+    });
+    m.def("axpy_bwd", [](std::shared_ptr<AxpyState> st, const Tensor& dout, bool need_x, int64_t stream) {
+        Tensor dx, dz;
+        axpy_bwd_impl(*st, dout, need_x, dx, dz, sp(stream));
+        return py::make_tuple(dx.defined() ? py::cast(dx) : py::none(), dz);
+    });
+
+    // JLC block: ws/bs = the spatial convs' weights / biases (kernel sizes from the weight shapes), groups G; l1/l2 = the channel MLP
+    m.def("jlc_fwd", [](const Tensor& x, const std::vector<Tensor>& ws, const std::vector<Tensor>& bs, int G, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w,
+                        const Tensor& l2b, double p, int64_t site, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<JLCState>();
+        void* s_ = sp(stream);
+        const int n = (int)ws.size();
+        st->convs.resize(n);
+        std::vector<Tensor> ys;
+        for (int k = 0; k < n; ++k) {
+            const int K = ws[k].size(2);
+            ys.push_back(conv_fwd_impl(st->convs[k], x, Tensor(), ws[k], bs[k], K, 1, K / 2, G, 1, x.requires_grad(), s_));
+        }
+        Tensor o = in_fwd_impl(st->in1, x, true, ys, s_);
+        Tensor nrm = in_fwd_impl(st->in2, Tensor(), false, {o}, s_);
+        Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
+        Tensor h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
+        Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
+        Tensor out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
+        return py::make_tuple(out, st);
+    });
+    m.def("jlc_bwd", [](std::shared_ptr<JLCState> st, const Tensor& dout, bool need_x, int64_t stream) -> py::object {
+        void* s_ = sp(stream);
+        Tensor do_res, dz, dh, dh2, da, dn, dn2;
+        axpy_bwd_impl(st->r, dout, true, do_res, dz, s_);
+        conv_bwd_impl(st->c2, dz, true, dh, dh2, s_);
+        da = gelu_bwd_impl(st->g, dh, s_);
+        conv_bwd_impl(st->c1, da, true, dn, dn2, s_);
+        Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
+        Tensor d_o = sum3(do_res, do2, Tensor(), s_);
+        const int n = (int)st->convs.size();
+        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_);
+        std::vector<Tensor> dxs(n);
+        for (int k = 0; k < n; ++k) { Tensor t2; conv_bwd_impl(st->convs[k], g[k], true, dxs[k], t2, s_); }
+        st.reset();
+        if (!need_x) return py::none();
+        Tensor dx = sum3(d_o, dxs[0], n > 1 ? dxs[1] : Tensor(), s_);
+        if (n > 2) dx = sum3(dx, dxs[2], Tensor(), s_);
+        return py::cast(dx);
+    });
+
+    // FFN tail: out = y + Drop(linear2(Drop(GELU(linear1(LN(y))))))
+    m.def("ffn_fwd", [](const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p,
+                        int64_t site1, int64_t site2, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<FFNState>();
+        void* s_ = sp(stream);
+        Tensor n = ln_fwd_impl(st->ln, y, gamma, beta, s_);
+        Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
+        Tensor h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
+        Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
+        Tensor out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
+        return py::make_tuple(out, st);
+    });
+    m.def("ffn_bwd", [](std::shared_ptr<FFNState> st, const Tensor& dout, int64_t stream) {
+        void* s_ = sp(stream);
+        Tensor dy_res, dz, dh, t2, dn, t3;
+        axpy_bwd_impl(st->r, dout, true, dy_res, dz, s_);
+        conv_bwd_impl(st->c2, dz, true, dh, t2, s_);
+        Tensor da = gelu_bwd_impl(st->g, dh, s_);
+        conv_bwd_impl(st->c1, da, true, dn, t3, s_);
+        Tensor dy_ln = ln_bwd_impl(st->ln, dn, s_);
+        return sum3(dy_res, dy_ln, Tensor(), s_);
+    });
+}

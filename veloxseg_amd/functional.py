@@ -11,6 +11,7 @@ There is no CPU implementation here on purpose (tier rule: the product path has 
 from __future__ import annotations
 
 import itertools
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -114,6 +115,54 @@ def grad_buf(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+USE_CPP = True                                # operator bodies in C++ (veloxseg_amd._vxops) instead of the python code below; same C-ABI calls
+_CPP = [False, None]
+_CPP_DEFAULTS = None
+
+
+def cpp_module(reload: bool = False):
+    """veloxseg_amd._vxops (csrc/_vxops.cpp, built by __graft_entry__.build) or None: then the python bodies below run (same kernels)."""
+    if reload:
+        _CPP[0] = False
+    if not _CPP[0]:
+        _CPP[0] = True
+        if os.environ.get("VELOXSEG_NO_CPP") != "1":
+            try:
+                H.LIB.load()
+                from . import _vxops
+                _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
+                _CPP[1] = _vxops
+            except ImportError:
+                _CPP[1] = None
+    return _CPP[1]
+
+
+def _flag_tuple():
+    return (WGRAD_ENTRY, USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX)
+
+
+def _cpp():
+    """the C++ module when it may be used: built, enabled, and every A/B flag at the default it was configured with (tests that flip a
+    flag run the python bodies)"""
+    global _CPP_DEFAULTS
+    if not USE_CPP:
+        return None
+    m = _CPP[1] if _CPP[0] else cpp_module()
+    if m is None:
+        return None
+    if _CPP_DEFAULTS is None:
+        _CPP_DEFAULTS = _flag_tuple()
+    return m if _flag_tuple() == _CPP_DEFAULTS and H._PROFILE is None else None
+
+
+def _cpp_mod():
+    return _CPP[1]
+
+
+def _rs_ptr(device, p):
+    return rng_state(device).data_ptr() if p > 0 else 0
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -132,6 +181,11 @@ def _check(x: torch.Tensor, what: str):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, b, K, S, P, G, ps):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            y, ctx.cst = m.conv_fwd(x, x2, w, b, K, S, P, G, ps, H.stream_ptr())
+            return y
         _check(x, "conv3d")
         x = _c(x)
         x2 = _c(x2) if x2 is not None else None
@@ -181,6 +235,10 @@ class _Conv3dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.cst is not None:
+            dx, dx2 = _cpp_mod().conv_bwd(ctx.cst, dy, bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]), H.stream_ptr())
+            ctx.cst = None
+            return dx, dx2, None, None, None, None, None, None, None
         x, x2 = ctx.saved_tensors
         w, b = ctx.w, ctx.b
         B, C1, Cin, D, Hh, W, Cout, K, S, P, G, ps = ctx.meta
@@ -281,6 +339,12 @@ def conv_transpose_k2s2(x, w, b):
 class _InstNormSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, act, *ys):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            out, ctx.cst = m.in_fwd(res, bool(act), list(ys), H.stream_ptr())
+            ctx.n, ctx.has_res = len(ys), res is not None
+            return out
         n = len(ys)
         assert 1 <= n <= 3
         ys = [_c(y) for y in ys]
@@ -310,6 +374,11 @@ class _InstNormSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         n = ctx.n
+        if ctx.cst is not None:
+            grads = _cpp_mod().in_bwd(ctx.cst, dout, [bool(ctx.needs_input_grad[2 + k]) for k in range(n)], H.stream_ptr())
+            ctx.cst = None
+            dres = (dout if dout.is_contiguous() else dout.contiguous()) if (ctx.has_res and ctx.needs_input_grad[0]) else None
+            return (dres, None, *grads)
         ys, stats = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         dout = _c(dout)
         B, C = ys[0].shape[:2]
@@ -348,6 +417,11 @@ def instnorm_sum(ys: Sequence[torch.Tensor], act: bool = False, res: Optional[to
 class _LayerNormCFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            out, ctx.cst = m.ln_fwd(x, gamma, beta, H.stream_ptr())
+            return out
         _check(x, "layer_norm")
         x = _c(x)
         B, C = x.shape[:2]
@@ -360,6 +434,10 @@ class _LayerNormCFFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.cst is not None:
+            dx = _cpp_mod().ln_bwd(ctx.cst, dout, H.stream_ptr())
+            ctx.cst = None
+            return dx, None, None
         (x,) = ctx.saved_tensors
         dout = _c(dout)
         B, C = x.shape[:2]
@@ -380,6 +458,11 @@ def layernorm_cf(x, gamma, beta):
 class _GeluDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, p, site):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            h, ctx.cst = m.gelu_fwd(a, float(p), int(site), _rs_ptr(a.device, p), H.stream_ptr())
+            return h
         _check(a, "gelu")
         a = _c(a)
         h = torch.empty_like(a)
@@ -391,6 +474,10 @@ class _GeluDropFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh):
+        if ctx.cst is not None:
+            da = _cpp_mod().gelu_bwd(ctx.cst, dh, H.stream_ptr())
+            ctx.cst = None
+            return da, None, None
         (a,) = ctx.saved_tensors
         dh = _c(dh)
         da = torch.empty_like(a)
@@ -408,6 +495,11 @@ class _AxpyDropFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, z, alpha, p, site):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            out, ctx.cst = m.axpy_fwd(x, z, float(alpha), float(p), int(site), _rs_ptr(z.device, p), H.stream_ptr())
+            return out
         _check(z, "residual_dropout")
         z = _c(z)
         xc = _c(x) if x is not None else None
@@ -419,6 +511,10 @@ class _AxpyDropFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.cst is not None:
+            dx, dz = _cpp_mod().axpy_bwd(ctx.cst, dout, bool(ctx.needs_input_grad[0]), H.stream_ptr())
+            ctx.cst = None
+            return dx, dz, None, None, None
         dout = _c(dout)
         need_x = ctx.has_x and ctx.needs_input_grad[0]
         dx = dz = None
@@ -488,6 +584,14 @@ class _JLCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, p, site):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            convs = [seq[0] for seq in mod.spatial_convs]
+            l1, l2 = mod.channel_conv[1], mod.channel_conv[3]
+            out, ctx.cst = m.jlc_fwd(x, [c.weight for c in convs], [c.bias for c in convs], convs[0].groups, l1.weight, l1.bias, l2.weight, l2.bias,
+                                     float(p), int(site), _rs_ptr(x.device, p), H.stream_ptr())
+            return out
         cs, ys = [], []
         for seq in mod.spatial_convs:
             conv = seq[0]
@@ -508,6 +612,10 @@ class _JLCFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.cst is not None:
+            dx = _cpp_mod().jlc_bwd(ctx.cst, dout, bool(ctx.needs_input_grad[0]), H.stream_ptr())
+            ctx.cst = None
+            return dx, None, None, None
         cs, c_in1, c_in2, c1, cg, c2, cr = ctx.tape
         ctx.tape = None
         cr.needs_input_grad = (True, True, False, False, False)
@@ -545,6 +653,12 @@ class _FFNTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, norm, ffn, p):
+        m = _cpp()
+        ctx.cst = None
+        if m is not None:
+            out, ctx.cst = m.ffn_fwd(y, norm.weight, norm.bias, ffn.linear1.weight, ffn.linear1.bias, ffn.linear2.weight, ffn.linear2.bias, float(p),
+                                     int(ffn.site1), int(ffn.site2), _rs_ptr(y.device, p), H.stream_ptr())
+            return out
         cl, c1, cg, c2, cr = _Ctx(), _Ctx(), _Ctx(), _Ctx(), _Ctx()
         n = _LayerNormCFFn.forward(cl, y, norm.weight, norm.bias)
         a = _Conv3dFn.forward(c1, n, None, ffn.linear1.weight, ffn.linear1.bias, 1, 1, 0, 1, 1)
@@ -556,6 +670,10 @@ class _FFNTailFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.cst is not None:
+            dy = _cpp_mod().ffn_bwd(ctx.cst, dout, H.stream_ptr())
+            ctx.cst = None
+            return dy, None, None, None
         cl, c1, cg, c2, cr = ctx.tape
         ctx.tape = None
         cr.needs_input_grad = (True, True, False, False, False)
