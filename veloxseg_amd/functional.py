@@ -181,7 +181,7 @@ def _check(x: torch.Tensor, what: str):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, b, K, S, P, G, ps):
-        m = _cpp()
+        m = _cpp() if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             y, ctx.cst = m.conv_fwd(x, x2, w, b, K, S, P, G, ps, H.stream_ptr())
@@ -339,7 +339,7 @@ def conv_transpose_k2s2(x, w, b):
 class _InstNormSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, act, *ys):
-        m = _cpp()
+        m = _cpp() if ys[0].is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.in_fwd(res, bool(act), list(ys), H.stream_ptr())
@@ -417,7 +417,7 @@ def instnorm_sum(ys: Sequence[torch.Tensor], act: bool = False, res: Optional[to
 class _LayerNormCFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta):
-        m = _cpp()
+        m = _cpp() if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.ln_fwd(x, gamma, beta, H.stream_ptr())
@@ -458,7 +458,7 @@ def layernorm_cf(x, gamma, beta):
 class _GeluDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, p, site):
-        m = _cpp()
+        m = _cpp() if a.is_cuda else None
         ctx.cst = None
         if m is not None:
             h, ctx.cst = m.gelu_fwd(a, float(p), int(site), _rs_ptr(a.device, p), H.stream_ptr())
@@ -495,7 +495,7 @@ class _AxpyDropFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, z, alpha, p, site):
-        m = _cpp()
+        m = _cpp() if z.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.axpy_fwd(x, z, float(alpha), float(p), int(site), _rs_ptr(z.device, p), H.stream_ptr())
@@ -584,7 +584,7 @@ class _JLCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, p, site):
-        m = _cpp()
+        m = _cpp() if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             convs = [seq[0] for seq in mod.spatial_convs]
@@ -653,7 +653,7 @@ class _FFNTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, norm, ffn, p):
-        m = _cpp()
+        m = _cpp() if y.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.ffn_fwd(y, norm.weight, norm.bias, ffn.linear1.weight, ffn.linear1.bias, ffn.linear2.weight, ffn.linear2.bias, float(p),
