@@ -65,6 +65,8 @@ int vx_conv_s1(const float* x, const float* w, const float* bias, float* y, int 
  * tap-major weights in 256-byte runs.  dy_fine: (B, Cc, 4D,4H,4W); w: (64*Cc, 16, 3,3,3); wt_ws: 64*Cc*16*27 floats; dx: (B,16,D,H,W) */
 int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
                             int accumulate, void* stream);
+/* A/B knob of the entry above: 1 (default) = LDS-tiled kernel when D%4 == H%4 == W%16 == 0, 0 = every operand straight from global */
+int vx_expand_set_lds(int on);
 /* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
  * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
 int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);

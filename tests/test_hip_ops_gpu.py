@@ -371,7 +371,8 @@ def test_kernel_variants_agree():
         torch.manual_seed(0)
         res = []
         for (Cin, Cout, K, G, ps, sp) in [(16, 128, 3, 1, 4, (6, 5, 8)), (16, 16, 5, 4, 1, (8, 8, 8)), (32, 32, 3, 4, 1, (4, 6, 8)), (64, 32, 1, 1, 1, (4, 4, 4)),
-                                          (16, 16, 1, 4, 1, (8, 8, 8)), (32, 32, 1, 4, 1, (6, 5, 8)), (128, 128, 1, 8, 1, (4, 4, 4))]:
+                                          (16, 16, 1, 4, 1, (8, 8, 8)), (32, 32, 1, 4, 1, (6, 5, 8)), (128, 128, 1, 8, 1, (4, 4, 4)),
+                                          (16, 64, 3, 1, 4, (4, 8, 16)), (16, 128, 3, 1, 4, (8, 4, 32))]:     # the last two hit the LDS-tiled expand kernel
             x = rnd(2, Cin, *sp, seed=Cin).to(d).requires_grad_(True)
             w = (rnd(Cout, Cin // G, K, K, K, seed=K) * 0.1).to(d).requires_grad_(True)
             b = rnd(Cout, seed=3).to(d).requires_grad_(True)
