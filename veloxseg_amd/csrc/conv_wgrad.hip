@@ -20,6 +20,7 @@ struct VxWg {
     int HD, HH, HW;            // halo tile = (T-1)*S + K
     int nTd, nTh, nTw;         // tiles per axis
     int tiles_per_block;
+    int st_hw, st_hh, st_hd, st_c;   // 256 = ((st_c*HD + st_hd)*HH + st_hh)*HW + st_hw: per-iteration advance of the halo staging loop
     float* part;               // optional partial-sum workspace [slices][Cout * Cin_g * K^3]; nullptr -> float atomics into dw
 };
 
@@ -54,6 +55,9 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
     const int t_begin = blockIdx.x * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, ntiles);
 
+    const int st_hw0 = threadIdx.x % p.HW, st_t1 = threadIdx.x / p.HW;
+    const int st_hh0 = st_t1 % p.HH, st_t2 = st_t1 / p.HH;
+    const int st_hd0 = st_t2 % p.HD, st_c0 = st_t2 / p.HD;
     for (int pass0 = 0; pass0 < npairs; pass0 += 256 * NP) {
         float acc[NP][COT];
         int loff[NP];
@@ -74,17 +78,23 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
             const int od0 = td * p.TD, oh0 = th * p.TH, ow0 = tw * p.TW;
             const int id0 = od0 * p.S - p.P, ih0 = oh0 * p.S - p.P, iw0 = ow0 * p.S - p.P;
             __syncthreads();
-            for (int e = threadIdx.x; e < Cin_g * plane; e += 256) {
-                const int ci = e / plane, r = e % plane;
-                const int hw = r % p.HW, hh = (r / p.HW) % p.HH, hd = r / (p.HW * p.HH);
-                const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-                float v = 0.0f;
-                if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
-                    const int c = g * Cin_g + ci;
-                    const float* src = (c < p.C1) ? x + ((long)b * p.C1 + c) * Vi : x2 + ((long)b * (p.Cin - p.C1) + (c - p.C1)) * Vi;
-                    v = src[((long)id * p.Hi + ih) * p.Wi + iw];
+            {   // element e = ((ci*HD + hd)*HH + hh)*HW + hw for e = tid, tid+256, ...: (hw, hh, hd, ci) advance by the host-decomposed
+                // stride of 256, so the loop body has no integer division (4 per element used to cost as much as the FMA phase)
+                int hw = st_hw0, hh = st_hh0, hd = st_hd0, ci = st_c0;
+                for (int e = threadIdx.x; e < Cin_g * plane; e += 256) {
+                    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+                    float v = 0.0f;
+                    if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                        const int c = g * Cin_g + ci;
+                        const float* src = (c < p.C1) ? x + ((long)b * p.C1 + c) * Vi : x2 + ((long)b * (p.Cin - p.C1) + (c - p.C1)) * Vi;
+                        v = src[((long)id * p.Hi + ih) * p.Wi + iw];
+                    }
+                    vx_halo[e] = v;
+                    hw += p.st_hw; if (hw >= p.HW) { hw -= p.HW; ++hh; }
+                    hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
+                    hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++ci; }
+                    ci += p.st_c;
                 }
-                vx_halo[e] = v;
             }
             __syncthreads();
             const int nd = min(p.TD, p.Do - od0), nh = min(p.TH, p.Ho - oh0), nw = min(p.TW, p.Wo - ow0);
@@ -235,6 +245,13 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
         while (nblk() < VX_WG_MIN_BLOCKS && p.TW > 8) p.TW = (p.TW + 1) / 2;
     }
     p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
+    {
+        int r_ = 256;
+        p.st_hw = r_ % p.HW; r_ /= p.HW;
+        p.st_hh = r_ % p.HH; r_ /= p.HH;
+        p.st_hd = r_ % p.HD; r_ /= p.HD;
+        p.st_c = r_;
+    }
     p.nTd = vx_cdiv(p.Do, p.TD); p.nTh = vx_cdiv(p.Ho, p.TH); p.nTw = vx_cdiv(p.Wo, p.TW);
     const int ntiles = p.nTd * p.nTh * p.nTw;
     const int COT = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
