@@ -333,16 +333,24 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
                                                     const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
                                                     float* __restrict__ dst, float* __restrict__ dst2, int D1,
                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate,
-                                                    int mode, int cd, int ch, int cw) {
+                                                    int mode, int cd, int ch, int cw, int ksplit) {
     // mode 0: plain.  mode 1 (ConvTranspose k2s2 forward): row m = co*8 + tap is stored depth-to-space into y[b][co][2d+i][2h+j][2w+k].
     // mode 2 (ConvTranspose k2s2 input gradient): reduction row k = co*8 + tap is gathered space-to-depth from dy.  (cd,ch,cw) = coarse dims.
+    // ksplit = 1: the 4 waves of a block own 4 voxel tiles.  ksplit = 4 (small problems: too few tiles to fill the chip and a long,
+    // latency-bound reduction chain per wave): the 4 waves share ONE tile, each walks a quarter of the reduction axis, LDS sums them.
+    __shared__ float vx_ksum[4][256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long tile = (long)blockIdx.x * 4 + wave;           // over (b, voxel tile)
-    if (tile >= (long)B * n_vt) return;
+    const int ks = ksplit > 1 ? wave : 0;
+    const long tile_raw = ksplit > 1 ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;           // over (b, voxel tile)
+    const bool live = tile_raw < (long)B * n_vt;
+    if (!live && ksplit == 1) return;
+    const long tile = live ? tile_raw : 0;
     const int b = (int)(tile / n_vt);
     const long v0 = (tile % n_vt) * 16;
     const int mt = blockIdx.y;
+    const int kper = ksplit > 1 ? ((Kch + 4 * 16 - 1) / (4 * 16)) * 16 : Kch;
+    const int kbeg = ks * kper, kend = min(Kch, kbeg + kper);
     const int r = lane & 15, q = lane >> 4;
     const int m_a = mt * 16 + r;                              // A row owned by this lane
     const bool m_ok = m_a < Mch;
@@ -350,12 +358,12 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
     const bool v_ok = v_b < V;
     vx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ wrow = w + (long)(m_ok ? m_a : 0) * wsm;
-    for (int k0 = 0; k0 < Kch; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         float av[4], bv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = k0 + 4 * s + q;
-            const bool k_ok = k < Kch;
+            const bool k_ok = k < kend;
             av[s] = (m_ok && k_ok) ? wrow[(long)k * wsk] : 0.0f;
             if (mode == 2) {
                 float t = 0.0f;
@@ -372,6 +380,15 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+    if (ksplit > 1) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) vx_ksum[wave][reg * 64 + lane] = acc[reg];
+        __syncthreads();
+        if (wave != 0 || !live) return;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            acc[reg] = (vx_ksum[0][reg * 64 + lane] + vx_ksum[1][reg * 64 + lane]) + (vx_ksum[2][reg * 64 + lane] + vx_ksum[3][reg * 64 + lane]);
     }
     if (!v_ok) return;
 #pragma unroll
@@ -392,6 +409,9 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
     }
 }
 
+// split the reduction axis over the 4 waves of a block when there are too few (tile, wave) pairs to fill 256 CUs x 4 SIMDs and the chain is long
+static inline int vx_pw_ksplit(long wave_tiles, int Kch) { return (wave_tiles < 2048 && Kch >= 64) ? 4 : 1; }
+
 extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
                                float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream) {
     VX_REQUIRE(src && w && dst && B > 0 && Mch > 0 && Kch > 0 && V > 0, "vx_pw_conv_mfma: bad args");
@@ -400,8 +420,9 @@ extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, cons
     VX_REQUIRE((S1 == Kch || src2) && (D1 == Mch || dst2), "vx_pw_conv_mfma: second tensor of a concat is missing");
     const int n_vt = vx_cdiv(V, 16);
     const int wsm = transpose_w ? 1 : Cin_of_w, wsk = transpose_w ? Cin_of_w : 1;
-    dim3 grid(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
-    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0);
+    const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Mch, 16), Kch);
+    dim3 grid(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
+    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0, ksplit);
     VX_LAUNCH_CHECK("vx_pw_conv_mfma");
     return 0;
 }
@@ -412,8 +433,9 @@ extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* b
     const long Vc = (long)d * h * wd;
     if (Vc <= 4096) {   // coarse levels: MFMA tiles, rows m = co*8 + tap stored depth-to-space
         const int n_vt = vx_cdiv(Vc, 16);
-        dim3 g2(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Co * 8, 16));
-        vx_pw_mfma_k<<<g2, 256, 0, st>>>(x, nullptr, Ci, w, 1, Co * 8, bias, y, nullptr, Co * 8, Co * 8, Ci, Vc, B, n_vt, 0, 1, d, h, wd);
+        const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Co * 8, 16), Ci);
+        dim3 g2(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Co * 8, 16));
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(x, nullptr, Ci, w, 1, Co * 8, bias, y, nullptr, Co * 8, Co * 8, Ci, Vc, B, n_vt, 0, 1, d, h, wd, ksplit);
         VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
         return 0;
     }
@@ -435,8 +457,9 @@ extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* d
     const long Vc = (long)d * h * wd;
     if (Vc <= 4096) {   // coarse levels: MFMA tiles, reduction rows k = co*8 + tap gathered space-to-depth from dy
         const int n_vt = vx_cdiv(Vc, 16);
-        dim3 g2(vx_cdiv((long)B * n_vt, 4), vx_cdiv(Ci, 16));
-        vx_pw_mfma_k<<<g2, 256, 0, st>>>(dy, nullptr, Co * 8, w, Co * 8, 1, nullptr, dx, nullptr, Ci, Ci, Co * 8, Vc, B, n_vt, 0, 2, d, h, wd);
+        const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Ci, 16), Co * 8);
+        dim3 g2(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Ci, 16));
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(dy, nullptr, Co * 8, w, Co * 8, 1, nullptr, dx, nullptr, Ci, Ci, Co * 8, Vc, B, n_vt, 0, 2, d, h, wd, ksplit);
         VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
         return 0;
     }
