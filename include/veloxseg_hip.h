@@ -84,6 +84,8 @@ int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* 
  * src may be a concat (S1 channels from src, rest from src2); dst may be split the same way (D1). */
 int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
                     float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream);
+/* A/B knob: 1 (default) = 16 x 64 tiles with 16-byte operand loads when V % 4 == 0, 0 = 16 x 16 tiles */
+int vx_pw_mfma_set_wide(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,

@@ -409,6 +409,88 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
     }
 }
 
+// Plain mode, V % 4 == 0: one wave = 16 rows x 64 voxels as FOUR interleaved n-tiles (column r of n-tile j = voxel v0 + 4r + j), so the B
+// operands of the four MFMAs of a k-step are ONE 16-byte load per lane (256 contiguous bytes per reduction row and wave instead of 64) and
+// the results leave as 16-byte stores; the A operand (weights) is shared by the four MFMAs.  Same ksplit scheme as vx_pw_mfma_k.
+__global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
+                                                     const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
+                                                     float* __restrict__ dst, float* __restrict__ dst2, int D1,
+                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate, int ksplit) {
+    __shared__ float vx_ksum4[4][16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ks = ksplit > 1 ? wave : 0;
+    const long tile_raw = ksplit > 1 ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;           // over (b, 64-voxel tile)
+    const bool live = tile_raw < (long)B * n_vt;
+    if (!live && ksplit == 1) return;
+    const long tile = live ? tile_raw : 0;
+    const int b = (int)(tile / n_vt);
+    const long v0 = (tile % n_vt) * 64;
+    const int mt = blockIdx.y;
+    const int r = lane & 15, q = lane >> 4;
+    const int m_a = mt * 16 + r;
+    const bool m_ok = m_a < Mch;
+    const long v_b = v0 + 4 * r;                               // this lane's 4 voxels: v_b .. v_b + 3
+    const bool v_ok = v_b < V;                                 // V % 4 == 0: all four or none
+    const int kper = ksplit > 1 ? ((Kch + 4 * 16 - 1) / (4 * 16)) * 16 : Kch;
+    const int kbeg = ks * kper, kend = min(Kch, kbeg + kper);
+    vx_f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ wrow = w + (long)(m_ok ? m_a : 0) * wsm;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        float av[4];
+        float4 bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * s + q;
+            const bool k_ok = k < kend;
+            av[s] = (m_ok && k_ok) ? wrow[(long)k * wsk] : 0.0f;
+            const float* srow = (k < S1) ? src + ((long)b * S1 + k) * V : src2 + ((long)b * (Kch - S1) + (k - S1)) * V;
+            bv[s] = (v_ok && k_ok) ? *reinterpret_cast<const float4*>(srow + v_b) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+        }
+    }
+    if (ksplit > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) vx_ksum4[wave][(j * 4 + reg) * 64 + lane] = acc[j][reg];
+        __syncthreads();
+        if (wave != 0 || !live) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int e = (j * 4 + reg) * 64 + lane;
+                acc[j][reg] = (vx_ksum4[0][e] + vx_ksum4[1][e]) + (vx_ksum4[2][e] + vx_ksum4[3][e]);
+            }
+    }
+    if (!v_ok) return;
+    // D_j: row = 4q + reg, col = r  ->  out[m = mt*16 + 4q + reg][voxels v_b .. v_b+3] = (acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg])
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int m = mt * 16 + 4 * q + reg;
+        if (m < Mch) {
+            float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
+            const float bb = bias ? bias[m] : 0.0f;
+            float4 o = make_float4(acc[0][reg] + bb, acc[1][reg] + bb, acc[2][reg] + bb, acc[3][reg] + bb);
+            float4* dp = reinterpret_cast<float4*>(drow + v_b);
+            if (accumulate) { const float4 old = *dp; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            *dp = o;
+        }
+    }
+}
+
+static int vx_pw_mfma4_enabled = 1;
+extern "C" int vx_pw_mfma_set_wide(int on) { vx_pw_mfma4_enabled = on ? 1 : 0; return 0; }
+
 // split the reduction axis over the 4 waves of a block when there are too few (tile, wave) pairs to fill 256 CUs x 4 SIMDs and the chain is long
 static inline int vx_pw_ksplit(long wave_tiles, int Kch) { return (wave_tiles < 2048 && Kch >= 64) ? 4 : 1; }
 
@@ -418,8 +500,16 @@ extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, cons
     if (S1 <= 0 || S1 > Kch) S1 = Kch;
     if (D1 <= 0 || D1 > Mch) D1 = Mch;
     VX_REQUIRE((S1 == Kch || src2) && (D1 == Mch || dst2), "vx_pw_conv_mfma: second tensor of a concat is missing");
-    const int n_vt = vx_cdiv(V, 16);
     const int wsm = transpose_w ? 1 : Cin_of_w, wsk = transpose_w ? Cin_of_w : 1;
+    if ((V & 3) == 0 && vx_pw_mfma4_enabled) {
+        const int n_vt4 = vx_cdiv(V, 64);
+        const int ks4 = vx_pw_ksplit((long)B * n_vt4 * vx_cdiv(Mch, 16), Kch);
+        dim3 g4(ks4 > 1 ? (unsigned)((long)B * n_vt4) : vx_cdiv((long)B * n_vt4, 4), vx_cdiv(Mch, 16));
+        vx_pw_mfma4_k<<<g4, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt4, accumulate, ks4);
+        VX_LAUNCH_CHECK("vx_pw_conv_mfma");
+        return 0;
+    }
+    const int n_vt = vx_cdiv(V, 16);
     const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Mch, 16), Kch);
     dim3 grid(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
     vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0, ksplit);
