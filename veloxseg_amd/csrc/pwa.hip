@@ -434,41 +434,56 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
-    for (int j0 = split * VX_KV_ROWS; j0 < A.ML; j0 += S * VX_KV_ROWS) {
-        const int nk = min(VX_KV_ROWS, A.ML - j0);
-        int tj = j0 % A.l;
+    // Keys are walked TOKEN-major: a slab holds TS tokens x M modalities (row m*TS + tt <-> key m*l + t0 + tt).  The M keys of a token share
+    // the relative-position bin, so their ds are summed in registers and ONE ds_add_f32 per token reaches the bias-gradient table instead
+    // of one per key (LDS float atomics retire ~1 lane per clock: they were 70 % of this kernel).
+    const int TS = A.M == 1 ? 64 : A.M == 2 ? 32 : A.M == 4 ? 16 : (64 / A.M) & ~3;
+    for (int t0 = split * TS; t0 < A.l; t0 += S * TS) {
+        const int nt = min(TS, A.l - t0);
         __builtin_amdgcn_wave_barrier();
-        if (lane < nk) {
+        {
+            const int mrow = lane / TS, tt = lane - mrow * TS;
+            if (mrow < A.M && tt < nt) {
+                const long j = (long)mrow * A.l + t0 + tt;
 #pragma unroll
-            for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = kp[(long)(j0 + lane) * CQ + c];
+                for (int c = 0; c < CQ; ++c) slab[lane * RS + c] = kp[j * CQ + c];
 #pragma unroll
-            for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
+                for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[j * CV + c];
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int jj = 0; jj < nk; jj += 4) {
-            float m4[4];
-            vx_drop4(dc, drow + j0 + jj, al4, m4);
+        for (int tt = 0; tt < nt; tt += 4) {
+            float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+            int bi[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (jj + t < nk) {
-                    const float* __restrict__ kr = slab + (jj + t) * RS;
-                    float s = 0.0f;
+            for (int t = 0; t < 4; ++t) bi[t] = lin_i - lin[min(t0 + tt + t, A.l - 1)];
+            for (int mk = 0; mk < A.M; ++mk) {
+                float m4[4];
+                const uint64_t kidx = drow + (uint64_t)mk * A.l + t0 + tt;
+                vx_drop4(dc, kidx, al4 && ((A.l & 3) == 0), m4);
 #pragma unroll
-                    for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
-                    const int bi = lin_i - lin[tj];
-                    if (++tj == A.l) tj = 0;
-                    s += bias[bi];
-                    const float p = __expf(s - lse);
-                    float dp = 0.0f;
+                for (int t = 0; t < 4; ++t) {
+                    if (tt + t < nt) {
+                        const float* __restrict__ kr = slab + (mk * TS + tt + t) * RS;
+                        float s = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
-                    dp *= m4[t];
-                    const float ds = ok ? p * (dp - delta) : 0.0f;
+                        for (int c = 0; c < CQ; ++c) s = fmaf(q[c], kr[c], s);
+                        s += bias[bi[t]];
+                        const float p = __expf(s - lse);
+                        float dp = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
-                    atomicAdd(stab + bi, ds);
+                        for (int c = 0; c < CV; ++c) dp = fmaf(dov[c], kr[CQ + c], dp);
+                        dp *= m4[t];
+                        const float ds = ok ? p * (dp - delta) : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < CQ; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
+                        dsum[t] += ds;
+                    }
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (tt + t < nt) atomicAdd(stab + bi[t], dsum[t]);
         }
     }
     if (S > 1) {
@@ -703,7 +718,7 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
 
 static int vx_attn_fill(VxAttn& A, const VxPwaPlan* P, int B, int M, int cq, int cv, const char* who) {
     if (int e = vx_plan_check(P, who)) return e;
-    if (B <= 0 || M <= 0) VX_FAIL(-1, "%s: bad B/M", who);
+    if (B <= 0 || M <= 0 || M > 16) VX_FAIL(-1, "%s: bad B/M (1..16 modalities)", who);
     A.BH = B * P->heads; A.heads = P->heads; A.Nt = P->Ntot; A.l = P->l; A.M = M; A.ML = M * P->l;
     A.n[0] = P->n[0]; A.n[1] = P->n[1]; A.n[2] = P->n[2];
     A.cq = cq; A.cv = cv; A.scale = 1.0f / sqrtf((float)cq);
@@ -718,8 +733,11 @@ extern "C" int vx_pwa_attn_set_split(int S) {
     vx_attn_split_override = S;
     return 0;
 }
-static int vx_attn_split(long units, int ML) {
-    const int nslabs = (ML + 63) / 64;
+static int vx_attn_split(long units, int ML, int M) {
+    const int TS = M == 1 ? 64 : M == 2 ? 32 : M == 4 ? 16 : (64 / M) & ~3;
+    const int l = ML / M;
+    const int nslabs_q = (l + TS - 1) / TS;                     // token-major slabs of the dQ kernel
+    const int nslabs = ((ML + 63) / 64) < nslabs_q ? (ML + 63) / 64 : nslabs_q;
     int S = 1;
     if (vx_attn_split_override) S = vx_attn_split_override;
     else if (units * 2 < 4096) S = 4;
@@ -749,7 +767,7 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
     const size_t shm = (tab_f + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
-    const int S = vx_attn_split(units, A.ML);
+    const int S = vx_attn_split(units, A.ML, A.M);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_fwd: tables do not fit LDS (%d entries x %d heads)", Tsz, A.heads);
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S);
@@ -769,7 +787,7 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
-    const int S = vx_attn_split(units, A.ML);
+    const int S = vx_attn_split(units, A.ML, A.M);
     const size_t shm = (tab_f + (((size_t)(4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     const size_t shm_kv = (tab_f + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
