@@ -247,38 +247,37 @@ __global__ void __launch_bounds__(256) vx_expand_wgrad_mfma_k(const float* __res
     const long s_begin = (long)chunk * steps_per_wave;
     const long s_end = !active ? s_begin : ((s_begin + steps_per_wave < nsteps) ? s_begin + steps_per_wave : nsteps);
     // software pipeline: the 28 operand loads of step s+1 are issued before the 27 MFMAs of step s
-    auto load_step = [&](long s, float& av, float (&bv)[27]) {
-        const int w4 = (int)(s % W4);
-        const int h = (int)((s / W4) % H);
-        const int d = (int)(s / ((long)W4 * H));
-        const int pw = 4 * w4 + q;
-        const bool vok = pw < W && s < s_end;
-        av = vok ? dyb[((long)(4 * d) * FH + 4 * h) * FW + 4 * pw] : 0.0f;
+    // position of the NEXT step to load, advanced incrementally (three run-time integer divisions per step used to cost about as many issue
+    // cycles as the 27 MFMAs they fed); tap addresses = one base pointer + constant offsets, validity = per-axis flags
+    int nw4 = (int)(s_begin % W4), nh = (int)((s_begin / W4) % H), nd = (int)(s_begin / ((long)W4 * H));
+    long ns = s_begin;
+    const long HW16 = (long)H * W * 16, W16 = (long)W * 16;
+    auto load_step = [&](float& av, float (&bv)[27]) {
+        const int pw = 4 * nw4 + q;
+        const bool vok = pw < W && ns < s_end;
+        av = vok ? dyb[((long)(4 * nd) * FH + 4 * nh) * FW + 4 * pw] : 0.0f;
+        const float* __restrict__ xp = xb + (((long)nd * H + nh) * W + pw) * 16;
+        const bool okd[3] = {vok && nd > 0, vok, vok && nd < D - 1};
+        const bool okh[3] = {nh > 0, true, nh < H - 1};
+        const bool okw[3] = {pw > 0, true, pw < W - 1};
 #pragma unroll
-        for (int td = 0; td < 3; ++td) {
-            const int id = d + td - 1;
-            const bool okd = (unsigned)id < (unsigned)D;
+        for (int td = 0; td < 3; ++td)
 #pragma unroll
-            for (int th = 0; th < 3; ++th) {
-                const int ih = h + th - 1;
-                const bool okh = okd && (unsigned)ih < (unsigned)H;
-                const long rowoff = ((long)id * H + ih) * W;
+            for (int th = 0; th < 3; ++th)
 #pragma unroll
-                for (int tw = 0; tw < 3; ++tw) {
-                    const int iw = pw + tw - 1;
-                    bv[(td * 3 + th) * 3 + tw] = (okh && vok && (unsigned)iw < (unsigned)W) ? xb[(rowoff + iw) * 16] : 0.0f;
-                }
-            }
-        }
+                for (int tw = 0; tw < 3; ++tw)
+                    bv[(td * 3 + th) * 3 + tw] = (okd[td] && okh[th] && okw[tw]) ? xp[(td - 1) * HW16 + (th - 1) * W16 + (tw - 1) * 16] : 0.0f;
+        ++ns;
+        if (++nw4 == W4) { nw4 = 0; if (++nh == H) { nh = 0; ++nd; } }
     };
     float av0, bv0[27], av1, bv1[27];
-    load_step(s_begin, av0, bv0);
+    load_step(av0, bv0);
     for (long s = s_begin; s < s_end; s += 2) {
-        load_step(s + 1, av1, bv1);
+        load_step(av1, bv1);
         bsum += av0;
 #pragma unroll
         for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[t], acc[t], 0, 0, 0);
-        load_step(s + 2, av0, bv0);
+        load_step(av0, bv0);
         bsum += av1;
 #pragma unroll
         for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[t], acc[t], 0, 0, 0);
