@@ -105,6 +105,10 @@ int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, float* s0, 
                   float* out, long BC, long V, float eps, void* stream);
 int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                   int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream);
+/* the two backward entries with the bias gradient of the producing conv fused in: db_k[c] += sum_{b,v} dy_k (NULL = skip); BC = B*C */
+int vx_in_bwd_db(const float* dout, const float* y, const float* stats, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, float* db, int C, void* stream);
+int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                     int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream);
 
 /* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
 int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);

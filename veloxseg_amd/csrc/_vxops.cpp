@@ -86,7 +86,8 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
 }
 
 // dx / dx2 are returned undefined when need_x is false; parameter gradients are accumulated into w.grad / b.grad
-void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, Tensor& dx2, void* stream) {
+// acc_into (optional, only without a concat input): the input gradient is ADDED to this tensor in place and returned as dx
+void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, Tensor& dx2, void* stream, const Tensor& acc_into = Tensor(), bool skip_bias = false) {
     Tensor dy = contig(dy_in);
     const int B = st.B, C1 = st.C1, Cin = st.Cin, D = st.D, H = st.H, W = st.W, Cout = st.Cout, K = st.K, S = st.S, P = st.P, G = st.G, ps = st.ps;
     const long V = (long)D * H * W;
@@ -98,19 +99,20 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         return;
     }
     if (need_x) {
-        dx = at::empty_like(x);
+        const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
+        dx = acc ? acc_into : at::empty_like(x);
         if (x2.defined()) dx2 = at::empty_like(x2);
-        if (st.pw && V <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(dy), nullptr, 0, fp(w), 1, nullptr, mp(dx), mp(dx2), C1, B, Cin, Cout, Cin, V, 0, stream), "vx_pw_conv_mfma");
-        else if (st.pw) chk(vx_pw_conv_bwd_data(fp(dy), fp(w), mp(dx), mp(dx2), C1, B, Cin, Cout, V, 0, stream), "vx_pw_conv_bwd_data");
+        if (st.pw && V <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(dy), nullptr, 0, fp(w), 1, nullptr, mp(dx), mp(dx2), C1, B, Cin, Cout, Cin, V, acc, stream), "vx_pw_conv_mfma");
+        else if (st.pw) chk(vx_pw_conv_bwd_data(fp(dy), fp(w), mp(dx), mp(dx2), C1, B, Cin, Cout, V, acc, stream), "vx_pw_conv_bwd_data");
         else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
             Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
-            chk(vx_expand_bwd_data_mfma(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, 0, stream), "vx_expand_bwd_data_mfma");
-        } else if (st.s1) chk(vx_conv_s1(fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, 0, stream), "vx_conv_s1");
-        else chk(vx_conv3d_bwd_data(fp(dy), fp(w), nullptr, mp(dx), mp(dx2), C1, B, Cin, D, H, W, Cout, K, S, P, G, ps, 0, stream), "vx_conv3d_bwd_data");
+            chk(vx_expand_bwd_data_mfma(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream), "vx_expand_bwd_data_mfma");
+        } else if (st.s1) chk(vx_conv_s1(fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream), "vx_conv_s1");
+        else chk(vx_conv3d_bwd_data(fp(dy), fp(w), nullptr, mp(dx), mp(dx2), C1, B, Cin, D, H, W, Cout, K, S, P, G, ps, acc, stream), "vx_conv3d_bwd_data");
     }
     if (w.requires_grad()) {
         float* dw = grad_ptr(w);
-        float* db = grad_ptr(b);
+        float* db = skip_bias ? nullptr : grad_ptr(b);       // skip_bias: the caller fused the bias gradient into the InstanceNorm backward
         if (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1) chk(vx_pw_conv_bwd_weight(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, Cout, V, stream), "vx_pw_conv_bwd_weight");
         else if (F.use_gconv1 && K == 1 && S == 1 && P == 0 && G > 1 && ps == 1 && !x2.defined() && Cin == Cout && (Cin / G == 4 || Cin / G == 8 || Cin / G == 16) && V % 4 == 0)
             chk(vx_gconv1_bwd_weight(fp(x), fp(dy), dw, db, B, Cin, G, V, stream), "vx_gconv1_bwd_weight");
@@ -165,7 +167,7 @@ Tensor in_fwd_impl(INState& st, const Tensor& res, bool act, const std::vector<T
 }
 
 // grads[k] defined for every k with need[k]; the residual gradient is dout itself
-std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::vector<bool>& need, void* stream) {
+std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::vector<bool>& need, void* stream, float* const* dbs = nullptr, int C = 1) {
     Tensor dout = contig(dout_in);
     const int n = st.n;
     std::vector<Tensor> grads(n);
@@ -173,15 +175,17 @@ std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::v
     for (int k = 0; k < n; ++k) if (need[k]) { grads[k] = at::empty_like(st.ys[k]); any = true; }
     if (!any) return grads;
     if (F.use_in_row && st.V <= F.in_row_max) {
-        chk(vx_in_row_bwd(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
-                          n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr, n > 2 ? mp(grads[2]) : nullptr, st.BC, st.V, stream),
-            "vx_in_row_bwd");
+        chk(vx_in_row_bwd_db(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
+                             n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr, n > 2 ? mp(grads[2]) : nullptr,
+                             dbs ? dbs[0] : nullptr, (dbs && n > 1) ? dbs[1] : nullptr, (dbs && n > 2) ? dbs[2] : nullptr, C, st.BC, st.V, stream),
+            "vx_in_row_bwd_db");
     } else {
         for (int k = 0; k < n; ++k) {
             if (!need[k]) continue;
             Tensor ws = at::empty({st.BC * 2}, dout.options());
             Tensor part = at::empty({st.BC * 32}, dout.options().dtype(at::kDouble));
-            chk(vx_in_bwd(fp(dout), fp(st.ys[k]), fp(st.stats[k]), st.act, mp(ws), part.data_ptr<double>(), mp(grads[k]), st.BC, st.V, stream), "vx_in_bwd");
+            chk(vx_in_bwd_db(fp(dout), fp(st.ys[k]), fp(st.stats[k]), st.act, mp(ws), part.data_ptr<double>(), mp(grads[k]), st.BC, st.V, dbs ? dbs[k] : nullptr, C, stream),
+                "vx_in_bwd_db");
         }
     }
     return grads;
@@ -365,14 +369,19 @@ PYBIND11_MODULE(_vxops, m) {
         Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
         Tensor d_o = sum3(do_res, do2, Tensor(), s_);
         const int n = (int)st->convs.size();
-        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_);
-        std::vector<Tensor> dxs(n);
-        for (int k = 0; k < n; ++k) { Tensor t2; conv_bwd_impl(st->convs[k], g[k], true, dxs[k], t2, s_); }
+        // short rows: the bias gradients of the spatial convs ride on the one-launch InstanceNorm backward (one atomic per (b,c) row).  Long rows
+        // keep the separate reduction: fused into the per-256-voxel apply blocks it would be thousands of atomics on C addresses.
+        const bool fuse_db = F.use_in_row && st->in1.V <= F.in_row_max;
+        float* dbs[3] = {nullptr, nullptr, nullptr};
+        if (fuse_db)
+            for (int k = 0; k < n; ++k) dbs[k] = st->convs[k].w.requires_grad() ? grad_ptr(st->convs[k].b) : nullptr;
+        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_, fuse_db ? dbs : nullptr, (int)st->convs[0].Cout);
+        // dx = d_o + sum_k conv_k^T(g_k): d_o is this function's own temporary (its last reader was in_bwd above), so the three input gradients
+        // are accumulated into it in place by the kernels' `accumulate` mode -- no extra add launches
+        for (int k = 0; k < n; ++k) { Tensor t1, t2; conv_bwd_impl(st->convs[k], g[k], true, t1, t2, s_, d_o, fuse_db); }
         st.reset();
         if (!need_x) return py::none();
-        Tensor dx = sum3(d_o, dxs[0], n > 1 ? dxs[1] : Tensor(), s_);
-        if (n > 2) dx = sum3(dx, dxs[2], Tensor(), s_);
-        return py::cast(dx);
+        return py::cast(d_o);
     });
 
     // FFN tail: out = y + Drop(linear2(Drop(GELU(linear1(LN(y))))))

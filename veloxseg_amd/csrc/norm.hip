@@ -119,17 +119,27 @@ __global__ void __launch_bounds__(256) vx_in_bwd_stats_fin_k(const double* __res
 }
 
 // dy = rstd * (dz - m1 - z*m2)
+// db (optional): bias gradient of the conv that produced y, db[c] += sum_{b,v} dy -- mathematically zero behind an InstanceNorm, numerically the
+// same round-off residue a separate reduction of dy yields; fused here it costs one block reduction instead of a launch per conv
 __global__ void __launch_bounds__(256) vx_in_bwd_apply_k(const float* __restrict__ dout, const float* __restrict__ y,
                                                          const float* __restrict__ st, const float* __restrict__ m, int act,
-                                                         float* __restrict__ dy, long V) {
+                                                         float* __restrict__ dy, long V, float* __restrict__ db, int C) {
+    __shared__ float sm[4];
     const long bc = blockIdx.y;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    const long i = bc * V + v;
-    const float mean = st[2 * bc], rstd = st[2 * bc + 1];
-    const float z = (y[i] - mean) * rstd;
-    const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
-    dy[i] = rstd * (dz - m[2 * bc] - z * m[2 * bc + 1]);
+    float o = 0.0f;
+    if (v < V) {
+        const long i = bc * V + v;
+        const float mean = st[2 * bc], rstd = st[2 * bc + 1];
+        const float z = (y[i] - mean) * rstd;
+        const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
+        o = rstd * (dz - m[2 * bc] - z * m[2 * bc + 1]);
+        dy[i] = o;
+    }
+    if (db != nullptr) {
+        const float s_ = vx_block_sum_256(o, sm);
+        if (threadIdx.x == 0) atomicAdd(db + (int)(bc % C), s_);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,14 +320,23 @@ extern "C" int vx_in_apply_fwd(const float* y0, const float* y1, const float* y2
     return 0;
 }
 
-extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream) {
+static int vx_in_bwd_run(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, float* db, int C,
+                         void* stream) {
     VX_REQUIRE(dout && y && st && m_ws && part_ws && dy, "vx_in_bwd: null pointer");
+    VX_REQUIRE(db == nullptr || (C > 0 && BC % C == 0), "vx_in_bwd_db: BC must be a multiple of C");
     const int S = vx_in_split(BC, V);
     hipLaunchKernelGGL(vx_in_bwd_stats_part_k, dim3((unsigned)BC, S), dim3(256), 0, (hipStream_t)stream, dout, y, st, act, part_ws, V, S, m_ws);
     if (S > 1) hipLaunchKernelGGL(vx_in_bwd_stats_fin_k, dim3(vx_cdiv(BC, 256)), dim3(256), 0, (hipStream_t)stream, part_ws, m_ws, BC, V, S);
-    hipLaunchKernelGGL(vx_in_bwd_apply_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, m_ws, act, dy, V);
+    hipLaunchKernelGGL(vx_in_bwd_apply_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, dout, y, st, m_ws, act, dy, V, db, C);
     VX_LAUNCH_CHECK("vx_in_bwd");
     return 0;
+}
+extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, void* stream) {
+    return vx_in_bwd_run(dout, y, st, act, m_ws, part_ws, dy, BC, V, nullptr, 1, stream);
+}
+extern "C" int vx_in_bwd_db(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, float* db, int C,
+                            void* stream) {
+    return vx_in_bwd_run(dout, y, st, act, m_ws, part_ws, dy, BC, V, db, C, stream);
 }
 
 extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream) {
@@ -495,12 +514,14 @@ __global__ void __launch_bounds__(256) vx_in_row_fwd_k(const float* __restrict__
 __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__ dout, const float* __restrict__ y0, const float* __restrict__ y1,
                                                        const float* __restrict__ y2, const float* __restrict__ s0, const float* __restrict__ s1,
                                                        const float* __restrict__ s2, int nk, int act, float* __restrict__ d0, float* __restrict__ d1,
-                                                       float* __restrict__ d2, int V) {
+                                                       float* __restrict__ d2, int V, float* __restrict__ b0, float* __restrict__ b1, float* __restrict__ b2, int C) {
     __shared__ double sm[8];
+    __shared__ float smf[4];
     const long bc = blockIdx.x;
     const float* ys[3] = {y0, y1, y2};
     const float* ss[3] = {s0, s1, s2};
     float* ds[3] = {d0, d1, d2};
+    float* dbs[3] = {b0, b1, b2};
     constexpr int R = VX_IN_ROW_MAX / 256;
     float g[R];
 #pragma unroll
@@ -521,8 +542,16 @@ __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__
         }
         vx_block_sum2_f64(a, c, sm);
         const float m1 = (float)(a / (double)V), m2 = (float)(c / (double)V);
+        float osum = 0.0f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; if (v < V) ds[k][bc * V + v] = rstd * (dz[r] - m1 - z[r] * m2); }
+        for (int r = 0; r < R; ++r) {
+            const int v = r * 256 + threadIdx.x;
+            if (v < V) { const float o = rstd * (dz[r] - m1 - z[r] * m2); ds[k][bc * V + v] = o; osum += o; }
+        }
+        if (dbs[k] != nullptr) {              // bias gradient of the producing conv (see vx_in_bwd_apply_k)
+            const float s_ = vx_block_sum_256(osum, smf);
+            if (threadIdx.x == 0) atomicAdd(dbs[k] + (int)(bc % C), s_);
+        }
     }
 }
 
@@ -542,7 +571,14 @@ extern "C" int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, 
 extern "C" int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                              int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V);
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, nullptr, nullptr, nullptr, 1);
     VX_LAUNCH_CHECK("vx_in_row_bwd");
+    return 0;
+}
+extern "C" int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                                int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream) {
+    VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX && C > 0 && BC % C == 0, "vx_in_row_bwd_db: bad args");
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, db0, db1, db2, C);
+    VX_LAUNCH_CHECK("vx_in_row_bwd_db");
     return 0;
 }
