@@ -102,6 +102,36 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
                 for (int qh = 0; qh < nh; ++qh) {
                     const int rowoff = (qd * p.S * p.HH + qh * p.S) * p.HW;
                     int qw = 0;
+                    if (DYMODE == 1) {
+                        // ps == 1: one row pointer per output channel, hoisted out of the voxel loop (the generic index function re-derived it -- with
+                        // a branch on ps -- for every channel and 4-voxel group), and 8 voxels per iteration so that the 2*COT scalar loads and the
+                        // 8*NP LDS reads of an iteration are all in flight before its 8*NP*COT FMAs
+                        const float* dyr[COT];
+#pragma unroll
+                        for (int j = 0; j < COT; ++j)
+                            dyr[j] = dy + ((((long)b * p.Cout + co0 + j) * p.Do + od0 + qd) * p.Ho + oh0 + qh) * (long)p.Wo + ow0;
+                        for (; qw + 8 <= nw; qw += 8) {
+                            float xv[NP][8];
+#pragma unroll
+                            for (int n = 0; n < NP; ++n)
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) xv[n][u] = vx_halo[loff[n] + rowoff + (qw + u) * p.S];
+                            float4 da[COT], dbv[COT];
+#pragma unroll
+                            for (int j = 0; j < COT; ++j) {
+                                da[j] = *reinterpret_cast<const float4*>(dyr[j] + qw);
+                                dbv[j] = *reinterpret_cast<const float4*>(dyr[j] + qw + 4);
+                            }
+#pragma unroll
+                            for (int j = 0; j < COT; ++j) {
+                                const float dv[8] = {da[j].x, da[j].y, da[j].z, da[j].w, dbv[j].x, dbv[j].y, dbv[j].z, dbv[j].w};
+#pragma unroll
+                                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                                    for (int n = 0; n < NP; ++n) acc[n][j] = fmaf(dv[u], xv[n][u], acc[n][j]);
+                            }
+                        }
+                    }
                     for (; qw + 4 <= nw; qw += 4) {
                         float xv[NP][4];
 #pragma unroll
