@@ -230,4 +230,6 @@ def test_composite_blocks_equal_the_fine_grained_operators():
     assert torch.equal(res[True][3], res[False][3])
     for n, g in res[False][2].items():
         d_ = float((res[True][2][n] - g).abs().max())
-        assert d_ <= 1e-5 * max(1e-3, float(g.abs().max())), (n, d_)
+        # floor 1e-6: biases in front of an InstanceNorm have a mathematically zero gradient; what both paths compute for them is ~1e-8 of
+        # summation-order noise (float atomics), which differs from run to run
+        assert d_ <= 1e-5 * max(0.1, float(g.abs().max())), (n, d_)

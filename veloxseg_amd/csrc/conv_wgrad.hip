@@ -234,6 +234,9 @@ __global__ void __launch_bounds__(256) vx_wg_reduce_k(const float* __restrict__ 
 }
 
 template <int N> using vx_ic2 = std::integral_constant<int, N>;
+#ifndef VX_WG_MIN_BLOCKS_SMALL
+#define VX_WG_MIN_BLOCKS_SMALL 384
+#endif
 #ifndef VX_WG_MIN_BLOCKS
 #define VX_WG_MIN_BLOCKS 2048   // the inner loop is latency-bound (scalar dy loads + LDS reads feed few FMAs per thread): 8 waves per SIMD beat big tiles
 #endif
@@ -270,9 +273,11 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
     {   // small volumes: prefer more, smaller tiles (>= ~512 blocks) over LDS-filling ones; the atomic flush stays cheap
         const int COT0 = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
         auto nblk = [&]() { return (long)vx_cdiv(p.Do, p.TD) * vx_cdiv(p.Ho, p.TH) * vx_cdiv(p.Wo, p.TW) * G * (Cout_g / COT0) * B; };
-        while (nblk() < VX_WG_MIN_BLOCKS && p.TD > 1) p.TD = (p.TD + 1) / 2;
-        while (nblk() < VX_WG_MIN_BLOCKS && p.TH > 1) p.TH = (p.TH + 1) / 2;
-        while (nblk() < VX_WG_MIN_BLOCKS && p.TW > 8) p.TW = (p.TW + 1) / 2;
+        // small volumes (<= 16^3): every extra tile re-stages a halo that is mostly border, so aim lower
+        const long want = ((long)p.Do * p.Ho * p.Wo <= 4096) ? VX_WG_MIN_BLOCKS_SMALL : VX_WG_MIN_BLOCKS;
+        while (nblk() < want && p.TD > 1) p.TD = (p.TD + 1) / 2;
+        while (nblk() < want && p.TH > 1) p.TH = (p.TH + 1) / 2;
+        while (nblk() < want && p.TW > 8) p.TW = (p.TW + 1) / 2;
     }
     p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
     {
