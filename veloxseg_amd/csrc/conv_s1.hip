@@ -20,6 +20,7 @@ struct VxS1 {
     int in_ps, out_ps;        // pixel-shuffle factor of the input / output STORAGE (1 = plain NCDHW)
     int accumulate;           // y += result
     int cic;                  // input channels staged per pass
+    int parts;                // input-channel split: the block's 256 threads = SP spatial slots x `parts` channel parts (small tiles), LDS-reduced
     int st_hw, st_hh, st_hd, st_c;   // 256 decomposed in the staging index space (hw fastest): per-thread incremental addressing
 };
 
@@ -50,8 +51,12 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
     const int tw_i = tile % p.nTw, th_i = (tile / p.nTw) % p.nTh, td_i = tile / (p.nTw * p.nTh);
     const int d0 = td_i * p.TD, h0 = th_i * p.TH, w0 = tw_i * p.TWq * 4;
     const int tid = threadIdx.x;
-    const int tq = tid % p.TWq, th = (tid / p.TWq) % p.TH, td = tid / (p.TWq * p.TH);
-    const bool active = td < p.TD;
+    // small tiles (8^3, 4^3 volumes) leave most of the 256 threads without a spatial slot; they take a share of the input channels instead
+    const int SP = p.TWq * p.TH * p.TD;
+    const int part = p.parts > 1 ? tid / SP : 0;
+    const int sp = p.parts > 1 ? tid - part * SP : tid;
+    const int tq = sp % p.TWq, th = (sp / p.TWq) % p.TH, td = sp / (p.TWq * p.TH);
+    const bool active = td < p.TD && part < p.parts;
     const int plane = p.HD * p.HH * p.HWp;
     float* __restrict__ xs = vx_s1_lds;
     float* __restrict__ ws = vx_s1_lds + p.cic * plane;
@@ -106,7 +111,7 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
         }
         __syncthreads();
         if (active) {
-            for (int cil = 0; cil < ncc; ++cil) {
+            for (int cil = part; cil < ncc; cil += p.parts) {
 #pragma unroll
                 for (int kd = 0; kd < K; ++kd) {
 #pragma unroll
@@ -134,6 +139,22 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
                 }
             }
         }
+    }
+    if (p.parts > 1) {             // sum the channel parts: [part][slot][4*COT] through LDS (the halo / weight tiles are dead by now)
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) vx_s1_lds[(part * SP + sp) * (4 * COT) + u * COT + j] = acc[u][j];
+        }
+        __syncthreads();
+        if (!active || part != 0) return;
+        for (int q = 1; q < p.parts; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) acc[u][j] += vx_s1_lds[(q * SP + sp) * (4 * COT) + u * COT + j];
     }
     if (!active) return;
     const int od = d0 + td, oh = h0 + th, ow = w0 + 4 * tq;
@@ -189,13 +210,29 @@ extern "C" int vx_conv_s1(const float* x, const float* w, const float* bias, flo
     int COT = (Cout_g % 16 == 0) ? 16 : (Cout_g % 8 == 0) ? 8 : 4;
     // few output channels (e.g. the 16-channel input gradient of a patch-expand conv): narrower register blocks, more blocks
     while (COT > 4 && (long)p.nTd * p.nTh * p.nTw * (Cout / COT) * B < 512) COT >>= 1;
+    // small volumes (16^3, 8^3): still too few blocks for 256 CUs -> thinner tiles in D (more halo planes staged per output plane, but the
+    // kernel is latency-bound at one wave per SIMD); keep at least one full wave of active threads
+    while (p.TD > 1 && (long)p.nTd * p.nTh * p.nTw * (Cout / COT) * B < 768 && (p.TD / 2) * p.TWq * p.TH >= 64) {
+        p.TD /= 2;
+        p.HD = p.TD + K - 1;
+        p.nTd = vx_cdiv(D, p.TD);
+    }
     const int plane = p.HD * p.HH * p.HWp;
     // input channels per pass: keep LDS (halo + weights) under ~48 KB so that 3 blocks share a CU
+    // input-channel parts for tiles with fewer than 256 spatial slots
+    int parts = 1;
+    {
+        const int SP = p.TWq * p.TH * p.TD;
+        while (parts * 2 * SP <= 256 && parts * 2 <= Cin_g && Cin_g % (parts * 2) == 0) parts *= 2;
+    }
     int cic = Cin_g < 4 ? Cin_g : 4;
+    if (cic < parts) cic = parts;
     auto lds_bytes = [&](int c) { return (size_t)c * (plane + K * K * K * COT) * sizeof(float); };
-    while (cic > 1 && lds_bytes(cic) > 48 * 1024) cic >>= 1;
+    while (cic > 1 && cic > parts && lds_bytes(cic) > 48 * 1024) cic >>= 1;
+    while (parts > 1 && lds_bytes(cic) > 64 * 1024) { parts >>= 1; if (cic > 4 && cic > parts) cic = parts > 4 ? parts : 4; }
     VX_REQUIRE(lds_bytes(cic) <= 150 * 1024, "vx_conv_s1: tile does not fit LDS");
     p.cic = cic;
+    p.parts = parts;
     {   // 256 = ((st_c*HD + st_hd)*HH + st_hh)*HWp + st_hw
         int r = 256;
         p.st_hw = r % p.HWp; r /= p.HWp;
@@ -205,7 +242,11 @@ extern "C" int vx_conv_s1(const float* x, const float* w, const float* bias, flo
     }
     dim3 grid(p.nTd * p.nTh * p.nTw, Cout / COT, B);
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = lds_bytes(cic);
+    size_t shm = lds_bytes(cic);
+    if (parts > 1) {
+        const size_t red = (size_t)parts * (p.TWq * p.TH * p.TD) * 4 * COT * sizeof(float);
+        if (red > shm) shm = red;
+    }
 #define VX_S1_LAUNCH(KK, CC) vx_conv_s1_k<KK, CC><<<grid, dim3(256), shm, st>>>(x, w, bias, y, p)
     if (K == 3) {
         if (COT == 16) VX_S1_LAUNCH(3, 16); else if (COT == 8) VX_S1_LAUNCH(3, 8); else VX_S1_LAUNCH(3, 4);
