@@ -27,7 +27,7 @@ USE_WGRAD_WS = True                           # tiled weight gradient through a 
 _wgrad_ws = {}
 USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
-PW_MFMA_MAX_V = 4096                          # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
+PW_MFMA_MAX_V = int(os.environ.get("VELOXSEG_PW_MFMA_MAX_V", "4096"))   # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 BRANCH_STREAMS = True                         # independent sub-networks (M+1 decoders; encoder conv chain vs PWA chain) run on forked HIP streams
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
