@@ -29,6 +29,7 @@ USE_PATCHIFY = True                           # kernel == stride convs (PatchEmb
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = int(os.environ.get("VELOXSEG_PW_MFMA_MAX_V", "4096"))   # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 BRANCH_STREAMS = True                         # independent sub-networks (M+1 decoders; encoder conv chain vs PWA chain) run on forked HIP streams
+MODALITY_STREAMS = int(os.environ.get("VELOXSEG_MODALITY_STREAMS", "1"))   # 1: per-modality halves of a PWA block on forked streams; 2: + PatchEmbed / PatchMerging
 IN_EPS = 1e-5      # nn.InstanceNorm3d default (reference common_function.py:63-66)
 LN_EPS = 1e-6      # reference attention_utils.py:15
 
@@ -42,7 +43,7 @@ _rng_state = {}
 _branch_streams = {}
 
 
-def run_branches(fns, device):
+def run_branches(fns, device, tag: str = "branches"):
     """Run independent closures `fns` (each returns a tensor or a tuple/list of tensors) on forked HIP streams and join them on
     the current stream.  The autograd engine replays every backward node on the stream its forward ran on, so the backward
     passes of the branches overlap too; under hipGraph capture the fork/join becomes parallel branches of the graph.  The branches
@@ -50,7 +51,7 @@ def run_branches(fns, device):
     if not BRANCH_STREAMS or len(fns) < 2:
         return [f() for f in fns]
     cur = torch.cuda.current_stream(device)
-    key = (str(device), len(fns))
+    key = (str(device), len(fns), tag)
     if key not in _branch_streams:
         _branch_streams[key] = [torch.cuda.Stream(device=device) for _ in fns]
     outs = []

@@ -85,11 +85,14 @@ class Transformer_Encoder(nn.Module):
     def embed(self, xs):
         xs = torch.chunk(xs, self.num_modalities, dim=1)            # Encoder.py:192
         p = self.p_pos if self.training else 0.0
-        cur = []
-        for m in range(self.num_modalities):
+        def one(m):
             e = self.patch_embeds[m](xs[m].contiguous())
-            cur.append(VF.residual_dropout(None, e, 0.0, p, self.sites_pos[m]) if p > 0 else e)
-        return cur
+            return VF.residual_dropout(None, e, 0.0, p, self.sites_pos[m]) if p > 0 else e
+
+        M = self.num_modalities
+        if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:
+            return VF.run_branches([(lambda m=m: one(m)) for m in range(M)], xs[0].device, tag="modalities")
+        return [one(m) for m in range(M)]
 
     def forward(self, xs):
         cur = self.embed(xs)

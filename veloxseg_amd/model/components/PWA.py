@@ -81,21 +81,33 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
         self.site_attn = VF.new_dropout_site()
         self.sites_proj = [VF.new_dropout_site() for _ in range(self.num_modalities)]
 
-    def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0) -> List[torch.Tensor]:
-        """returns residual_scale * x_m + Drop(mix(attention)) ; the transformer block passes 2.0 (double residual)."""
-        assert len(inputs) == self.num_modalities, f"The number of modalities should be {self.num_modalities}, but got {len(inputs)}"
-        qkv = []
-        for m in range(self.num_modalities):
-            xn = self.input_norms[m](inputs[m])          # LN once (the reference evaluates the same LN three times)
-            qkv += [self.qkv_proj[m][j](xn) for j in range(3)]
-        train = self.training
+    def _qkv(self, m: int, x):
+        xn = self.input_norms[m](x)                      # LN once (the reference evaluates the same LN three times)
+        return [self.qkv_proj[m][j](xn) for j in range(3)]
+
+    def _post(self, m: int, x, s, residual_scale: float, tail):
+        mix = self.mix_channels[m](s)
+        y = VF.residual_dropout(x, mix, residual_scale, self.proj_drop if self.training else 0.0, self.sites_proj[m])
+        return tail(m, y) if tail is not None else y
+
+    def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0, tail=None) -> List[torch.Tensor]:
+        """returns residual_scale * x_m + Drop(mix(attention)) ; the transformer block passes 2.0 (double residual).
+        Everything except the joint attention is per modality and independent: with functional.MODALITY_STREAMS the M modalities run on
+        forked HIP streams before and after the attention (`tail(m, y)`, e.g. the block's FFN, rides on the same branch)."""
+        M = self.num_modalities
+        assert len(inputs) == M, f"The number of modalities should be {M}, but got {len(inputs)}"
+        par = VF.MODALITY_STREAMS and VF.BRANCH_STREAMS and M > 1 and inputs[0].is_cuda
+        if par:
+            parts = VF.run_branches([(lambda m=m: self._qkv(m, inputs[m])) for m in range(M)], inputs[0].device, tag="modalities")
+        else:
+            parts = [self._qkv(m, inputs[m]) for m in range(M)]
+        qkv = [t for p in parts for t in p]
         scat = VF.pwa_core(self.position_embedding.relative_position_bias_table, self.plan, self.c_qk, self.c_v, qkv,
-                           self.attn_drop if train else 0.0, self.site_attn)
-        outs = []
-        for m in range(self.num_modalities):
-            mix = self.mix_channels[m](scat[m])
-            outs.append(VF.residual_dropout(inputs[m], mix, residual_scale, self.proj_drop if train else 0.0, self.sites_proj[m]))
-        return outs
+                           self.attn_drop if self.training else 0.0, self.site_attn)
+        if par:
+            return VF.run_branches([(lambda m=m: self._post(m, inputs[m], scat[m], residual_scale, tail)) for m in range(M)], inputs[0].device,
+                                   tag="modalities")
+        return [self._post(m, inputs[m], scat[m], residual_scale, tail) for m in range(M)]
 
 
 class Paired_Windows_TransformerBlock(nn.Module):
@@ -121,10 +133,11 @@ class Paired_Windows_TransformerBlock(nn.Module):
             self.norms.append(norm_layer(in_channels[m], data_format="channels_first", dim=dim))
 
     def forward(self, xs):
-        ys = self.attn(xs, residual_scale=2.0)
         if VF.USE_COMPOSITE:
-            return [VF.ffn_tail(ys[m], self.norms[m], self.ffns[m], self.ffns[m].p if self.training else 0.0) for m in range(self.num_modalities)]
-        return [self.ffns[m](self.norms[m](ys[m]), residual=ys[m]) for m in range(self.num_modalities)]
+            tail = lambda m, y: VF.ffn_tail(y, self.norms[m], self.ffns[m], self.ffns[m].p if self.training else 0.0)      # noqa: E731
+        else:
+            tail = lambda m, y: self.ffns[m](self.norms[m](y), residual=y)      # noqa: E731
+        return self.attn(xs, residual_scale=2.0, tail=tail)
 
 
 class Transformer_BasicLayer(nn.Module):
@@ -150,5 +163,11 @@ class Transformer_BasicLayer(nn.Module):
     def forward(self, xs):
         for blk in self.blocks:
             xs = blk(xs)
-        down = [self.downs[m](xs[m]) for m in range(self.num_modalities)] if self.downs is not None else None
+        if self.downs is None:
+            return xs, None
+        M = self.num_modalities
+        if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:       # PatchMerging is per modality too
+            down = VF.run_branches([(lambda m=m: self.downs[m](xs[m])) for m in range(M)], xs[0].device, tag="modalities")
+        else:
+            down = [self.downs[m](xs[m]) for m in range(M)]
         return xs, down
