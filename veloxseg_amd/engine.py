@@ -161,9 +161,9 @@ class TrainEngine:
         nb = self.model.num_branches
         self._leaves, self._outs = [None] * nb, [None] * nb
         self._s_enc_fwd()
-        VF.run_branches([(lambda k=k: self._s_dec_fwd(k)) for k in range(nb)], self.dev)
+        VF.run_branches([(lambda k=k: self._s_dec_fwd(k)) for k in range(nb)], self.dev, uses=[self._boundary] * nb)
         self._s_loss()
-        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev)
+        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev, uses=[self._douts[k] for k in range(nb)])
         if between is not None:
             between()
         self._s_enc_bwd()

@@ -43,20 +43,36 @@ _rng_state = {}
 _branch_streams = {}
 
 
-def run_branches(fns, device, tag: str = "branches"):
+def _record(ts, stream):
+    for t in ts:
+        if isinstance(t, (list, tuple)):
+            _record(t, stream)
+        elif torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(stream)
+
+
+def run_branches(fns, device, tag: str = "branches", uses=None):
     """Run independent closures `fns` (each returns a tensor or a tuple/list of tensors) on forked HIP streams and join them on
-    the current stream.  The autograd engine replays every backward node on the stream its forward ran on, so the backward
+    the current stream.  `uses[k]` = the tensors branch k reads that were allocated on another stream: they are `record_stream`-ed on
+    the branch's stream, otherwise the caching allocator may hand their memory to a new tensor as soon as the host drops the last
+    reference -- in the backward pass that is while the branch's (saved-tensor-reading) kernels are still queued, and the first training
+    step then computes a gradient from recycled memory.  The autograd engine replays every backward node on the stream its forward ran on, so the backward
     passes of the branches overlap too; under hipGraph capture the fork/join becomes parallel branches of the graph.  The branches
     are chains of small kernels (a 4^3 .. 32^3 decoder level rarely fills 256 CUs), which is what makes the overlap pay."""
     if not BRANCH_STREAMS or len(fns) < 2:
         return [f() for f in fns]
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(device)
     key = (str(device), len(fns), tag)
     if key not in _branch_streams:
         _branch_streams[key] = [torch.cuda.Stream(device=device) for _ in fns]
     outs = []
-    for s_, f in zip(_branch_streams[key], fns):
+    for k_, (s_, f) in enumerate(zip(_branch_streams[key], fns)):
         s_.wait_stream(cur)
+        if uses is not None:
+            _record(uses[k_], s_)
         with torch.cuda.stream(s_):
             outs.append(f())
     for s_, o in zip(_branch_streams[key], outs):
@@ -66,6 +82,29 @@ def run_branches(fns, device, tag: str = "branches"):
                 if torch.is_tensor(u):
                     u.record_stream(cur)
     return outs
+
+
+_streams_ready = set()
+
+
+def ensure_streams(device, n_modalities: int):
+    """Create every side stream the model uses (encoder conv chain, M modality branches, M+1 decoder branches) BEFORE the first kernel of the
+    first forward, then synchronise once.  Streams created lazily in the middle of the first forward gave a wrong first-iteration gradient
+    for the last node of the encoder conv chain (a cross-stream ordering the runtime only honoured once all queues existed;
+    AMD_SERIALIZE_KERNEL=3 or this eager creation make the first step equal to the later ones: tests/test_hip_model_gpu.py)."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (str(device), n_modalities)
+    if key in _streams_ready or not BRANCH_STREAMS:
+        return
+    side_stream(device, "encoder_conv")
+    for n, tag in ((n_modalities, "modalities"), (n_modalities + 1, "branches")):
+        k = (str(device), n, tag)
+        if n >= 2 and k not in _branch_streams:
+            _branch_streams[k] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    torch.cuda.synchronize(device)
+    _streams_ready.add(key)
 
 
 def side_stream(device, name: str) -> "torch.cuda.Stream":
@@ -142,6 +181,13 @@ def _flag_tuple():
     return (WGRAD_ENTRY, USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX)
 
 
+_CPP_OPS = set(os.environ.get("VELOXSEG_CPP_OPS", "conv,in,ln,gelu,axpy,jlc,ffn").split(","))      # debugging: which operators may take the C++ path
+
+
+def _cpp_op(name):
+    return _cpp() if name in _CPP_OPS else None
+
+
 def _cpp():
     """the C++ module when it may be used: built, enabled, and every A/B flag at the default it was configured with (tests that flip a
     flag run the python bodies)"""
@@ -182,7 +228,7 @@ def _check(x: torch.Tensor, what: str):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, b, K, S, P, G, ps):
-        m = _cpp() if x.is_cuda else None
+        m = _cpp_op("conv") if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             y, ctx.cst = m.conv_fwd(x, x2, w, b, K, S, P, G, ps, H.stream_ptr())
@@ -340,7 +386,7 @@ def conv_transpose_k2s2(x, w, b):
 class _InstNormSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, act, *ys):
-        m = _cpp() if ys[0].is_cuda else None
+        m = _cpp_op("in") if ys[0].is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.in_fwd(res, bool(act), list(ys), H.stream_ptr())
@@ -418,7 +464,7 @@ def instnorm_sum(ys: Sequence[torch.Tensor], act: bool = False, res: Optional[to
 class _LayerNormCFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta):
-        m = _cpp() if x.is_cuda else None
+        m = _cpp_op("ln") if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.ln_fwd(x, gamma, beta, H.stream_ptr())
@@ -459,7 +505,7 @@ def layernorm_cf(x, gamma, beta):
 class _GeluDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, p, site):
-        m = _cpp() if a.is_cuda else None
+        m = _cpp_op("gelu") if a.is_cuda else None
         ctx.cst = None
         if m is not None:
             h, ctx.cst = m.gelu_fwd(a, float(p), int(site), _rs_ptr(a.device, p), H.stream_ptr())
@@ -496,7 +542,7 @@ class _AxpyDropFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, z, alpha, p, site):
-        m = _cpp() if z.is_cuda else None
+        m = _cpp_op("axpy") if z.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.axpy_fwd(x, z, float(alpha), float(p), int(site), _rs_ptr(z.device, p), H.stream_ptr())
@@ -585,7 +631,7 @@ class _JLCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, p, site):
-        m = _cpp() if x.is_cuda else None
+        m = _cpp_op("jlc") if x.is_cuda else None
         ctx.cst = None
         if m is not None:
             convs = [seq[0] for seq in mod.spatial_convs]
@@ -654,7 +700,7 @@ class _FFNTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, norm, ffn, p):
-        m = _cpp() if y.is_cuda else None
+        m = _cpp_op("ffn") if y.is_cuda else None
         ctx.cst = None
         if m is not None:
             out, ctx.cst = m.ffn_fwd(y, norm.weight, norm.bias, ffn.linear1.weight, ffn.linear1.bias, ffn.linear2.weight, ffn.linear2.bias, float(p),

@@ -91,7 +91,7 @@ class Transformer_Encoder(nn.Module):
 
         M = self.num_modalities
         if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:
-            return VF.run_branches([(lambda m=m: one(m)) for m in range(M)], xs[0].device, tag="modalities")
+            return VF.run_branches([(lambda m=m: one(m)) for m in range(M)], xs[0].device, tag="modalities", uses=[[xs[m]] for m in range(M)])
         return [one(m) for m in range(M)]
 
     def forward(self, xs):
@@ -144,6 +144,7 @@ class Encoder(nn.Module):
         main = torch.cuda.current_stream(x.device) if side is not None else None
         if side is not None:
             side.wait_stream(main)
+            x.record_stream(side)            # read by down1 on the side stream, forward and (weight gradient) backward
         attn, encs = [], []
         prev = x
         for i in range(4):
@@ -151,6 +152,8 @@ class Encoder(nn.Module):
             attn.append(a_i)
             if side is not None:
                 side.wait_stream(main)
+                for t_ in a_i:
+                    t_.record_stream(side)   # the mixer reads them on the side stream
                 ctx = torch.cuda.stream(side)
                 ctx.__enter__()
             try:

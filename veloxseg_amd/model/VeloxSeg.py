@@ -77,7 +77,8 @@ class VeloxSeg(nn.Module):
         return seg[:-1] + [rcs, seg[-1]] + [o[1] for o in branch_outs[1:]]
 
     def decode_train(self, attn, encs):
-        outs = VF.run_branches([(lambda k=k: self.decode_branch(k, attn, encs)) for k in range(self.num_branches)], encs[0].device)
+        outs = VF.run_branches([(lambda k=k: self.decode_branch(k, attn, encs)) for k in range(self.num_branches)], encs[0].device,
+                               uses=[[encs] if k == 0 else [encs, [attn[L][k - 1] for L in range(4)]] for k in range(self.num_branches)])
         return self.assemble_train(outs)
 
     def forward(self, x) -> Union[torch.Tensor, Sequence[torch.Tensor]]:
@@ -85,6 +86,7 @@ class VeloxSeg(nn.Module):
             raise RuntimeError("veloxseg_amd.VeloxSeg runs on MI355X only: move the model and the input to a cuda device "
                                "(there is deliberately no CPU fallback; the CPU oracle lives under oracle/ for tests)")
         x = x.contiguous()
+        VF.ensure_streams(x.device, self.num_modalities)
         if self.training:
             VF.advance_rng(x.device)
             attn, encs = self.encoder(x)

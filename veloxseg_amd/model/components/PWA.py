@@ -98,7 +98,8 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
         assert len(inputs) == M, f"The number of modalities should be {M}, but got {len(inputs)}"
         par = VF.MODALITY_STREAMS and VF.BRANCH_STREAMS and M > 1 and inputs[0].is_cuda
         if par:
-            parts = VF.run_branches([(lambda m=m: self._qkv(m, inputs[m])) for m in range(M)], inputs[0].device, tag="modalities")
+            parts = VF.run_branches([(lambda m=m: self._qkv(m, inputs[m])) for m in range(M)], inputs[0].device, tag="modalities",
+                                    uses=[[inputs[m]] for m in range(M)])
         else:
             parts = [self._qkv(m, inputs[m]) for m in range(M)]
         qkv = [t for p in parts for t in p]
@@ -106,7 +107,7 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
                            self.attn_drop if self.training else 0.0, self.site_attn)
         if par:
             return VF.run_branches([(lambda m=m: self._post(m, inputs[m], scat[m], residual_scale, tail)) for m in range(M)], inputs[0].device,
-                                   tag="modalities")
+                                   tag="modalities", uses=[[inputs[m], scat[m]] for m in range(M)])
         return [self._post(m, inputs[m], scat[m], residual_scale, tail) for m in range(M)]
 
 
@@ -167,7 +168,7 @@ class Transformer_BasicLayer(nn.Module):
             return xs, None
         M = self.num_modalities
         if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:       # PatchMerging is per modality too
-            down = VF.run_branches([(lambda m=m: self.downs[m](xs[m])) for m in range(M)], xs[0].device, tag="modalities")
+            down = VF.run_branches([(lambda m=m: self.downs[m](xs[m])) for m in range(M)], xs[0].device, tag="modalities", uses=[[xs[m]] for m in range(M)])
         else:
             down = [self.downs[m](xs[m]) for m in range(M)]
         return xs, down
