@@ -233,3 +233,22 @@ def test_composite_blocks_equal_the_fine_grained_operators():
         # floor 1e-6: biases in front of an InstanceNorm have a mathematically zero gradient; what both paths compute for them is ~1e-8 of
         # summation-order noise (float atomics), which differs from run to run
         assert d_ <= 1e-5 * max(0.1, float(g.abs().max())), (n, d_)
+
+
+@pytest.mark.timeout(600)
+def test_first_step_of_a_fresh_process_matches_serialised_kernels(tmp_path):
+    """Multi-stream safety: the very first training step of a fresh process (cold caching allocator, streams just created) must give the
+    same loss and gradients as the same step with AMD_SERIALIZE_KERNEL=3.  A tensor read on a forked stream without record_stream used to
+    be recycled by the allocator while its reader was still queued: one weight gradient came out ~0 in the first step only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "dbg_first_iter.py")
+    ref = str(tmp_path / "ref.pt")
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, tool, "save", ref], env=dict(env, AMD_SERIALIZE_KERNEL="3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for _ in range(3):
+        r = subprocess.run([sys.executable, tool, "cmp", ref], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "\n0 bad params" in r.stdout, r.stdout[-800:]
