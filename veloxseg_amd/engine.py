@@ -111,6 +111,37 @@ class TrainEngine:
         self.loss.copy_(loss.detach())
         self.last_outputs = [o.detach() for o in outs]
 
+    def _fwd_bwd_overlapped(self):
+        """plain eager step + the decoder-bucket all-reduce started from INSIDE the backward pass: every decoder consumes the deepest
+        encoder output enc4 in its first layer, so the gradient of enc4 is complete exactly when the three decoders have finished
+        their backward (all their weight-gradient kernels are queued); a multi-grad hook on enc4 then launches the all-reduce of the
+        decoder bucket on the communication stream, where it overlaps the whole encoder backward.  No staging, no detached leaves."""
+        self.flat.zero_grad()
+        handles = []
+        split, n = self.flat.split, self.flat.numel
+
+        def decoders_done(_grads):
+            cur = torch.cuda.current_stream(self.dev)
+            self.comm_stream.wait_stream(cur)
+            for s_ in VF.branch_stream_list(self.dev, self.model.num_branches, "branches"):
+                self.comm_stream.wait_stream(s_)
+            with torch.cuda.stream(self.comm_stream):
+                self._allreduce(split, n)
+
+        def on_enc(attn, encs):
+            handles.append(torch.autograd.graph.register_multi_grad_hook([encs[-1]], decoders_done, mode="all"))
+
+        self.model._on_encoder_outputs = on_enc
+        try:
+            outs, loss = self._forward_loss()
+            loss.backward()
+        finally:
+            self.model._on_encoder_outputs = None
+            for h in handles:
+                h.remove()
+        self.loss.copy_(loss.detach())
+        self.last_outputs = [o.detach() for o in outs]
+
     # ---- stages -------------------------------------------------------------------------------
     # The step is cut at the encoder outputs and at the decoder outputs into stages that exchange DETACHED leaves:
     #   enc_fwd -> { dec_fwd[k] } -> loss (+ its backward) -> { dec_bwd[k] } -> enc_bwd          k = 0..M (Seg decoder, M RC decoders)
@@ -341,11 +372,7 @@ class TrainEngine:
                 self._fwd_bwd_single()
                 self._allreduce(0, n)
             else:
-                def decoder_bucket():
-                    self.comm_stream.wait_stream(cur)
-                    with torch.cuda.stream(self.comm_stream):
-                        self._allreduce(split, n)               # overlaps the encoder backward
-                self._eager_stages(between=decoder_bucket)
+                self._fwd_bwd_overlapped()                      # decoder bucket is reduced while the encoder backward runs
                 self.comm_stream.wait_stream(cur)
                 with torch.cuda.stream(self.comm_stream):
                     self._allreduce(0, split)

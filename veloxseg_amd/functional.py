@@ -107,6 +107,14 @@ def ensure_streams(device, n_modalities: int):
     _streams_ready.add(key)
 
 
+def branch_stream_list(device, n: int, tag: str = "branches"):
+    """the streams run_branches uses for `n` branches with this tag (empty when branch streams are off or not created yet)"""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return list(_branch_streams.get((str(device), n, tag), [])) if BRANCH_STREAMS else []
+
+
 def side_stream(device, name: str) -> "torch.cuda.Stream":
     """a named, cached side stream of `device` (one per role, e.g. the conv chain of the encoder)"""
     device = torch.device(device)

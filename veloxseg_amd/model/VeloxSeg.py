@@ -25,6 +25,7 @@ class VeloxSeg(nn.Module):
         if spatial_dim != 3:
             raise NotImplementedError("veloxseg_amd implements the 3-D network (all shipped configs)")
         VF.reset_dropout_sites()
+        self._on_encoder_outputs = None
         self.size = list(input_size)
         self.spatial_dim = spatial_dim
         self.patch_size = patch_size
@@ -90,6 +91,8 @@ class VeloxSeg(nn.Module):
         if self.training:
             VF.advance_rng(x.device)
             attn, encs = self.encoder(x)
+            if self._on_encoder_outputs is not None:          # engine hook: lets the data-parallel step see where the decoders' backward ends
+                self._on_encoder_outputs(attn, encs)
             return self.decode_train(attn, encs)
         encs = self.encoder(x)
         return self.decoder(*encs)
