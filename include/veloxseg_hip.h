@@ -214,6 +214,15 @@ int vx_argmax_channels(const float* logits, unsigned char* labels, int B, int C,
  * metrics_tensor (utils/metric/metrics.py:44-91) and cal_dice (utils/metric/metrics_brats.py:31-35); label widths 1, 4 or 8 bytes */
 int vx_confusion(const void* pred, int pred_bytes, const void* gt, int gt_bytes, unsigned long long* conf, int B, long V, int NC, void* stream);
 
+/* ---- training-input stand-in: MONAI CropForegroundd / RandCropByPosNegLabeld / RandRotated of utils/train_autopet.py:132-152 ----
+ * x: one sample (C, D, H, W) fp32; labels uint8 / int32 / int64 / fp32 (lab_bytes 1 / 4 / 8 / -4). */
+int vx_min_value(const float* x, long n, float* out_init_inf, void* stream);                       /* out[0] = min(out[0], min x); caller presets +inf */
+int vx_bbox_gt(const float* x, float thr, int C, int D, int H, int W, int* out6, void* stream);     /* (min d,h,w, max d,h,w) of {x > thr}; caller presets (INT_MAX x3, -1 x3) */
+int vx_label_chunk_count(const void* labels, int lab_bytes, long n, int chunk, int fg, int* counts, void* stream);   /* per-chunk counts of label > 0 (fg) or == 0 */
+int vx_label_kth_in_chunk(const void* labels, int lab_bytes, long n, long chunk_start, int chunk, int fg, int k, long* out_index, void* stream);
+/* rotation about the last spatial axis (the (D,H) plane turns), centre (n-1)/2, border padding; mode 0 bilinear, 1 nearest */
+int vx_rotate_z(const float* x, float* out, int C, int D, int H, int W, float cos_a, float sin_a, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

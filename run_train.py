@@ -30,6 +30,7 @@ if __name__ == "__main__":
     parser.add_argument("--model_index", type=str, default=None, help="Markdown index of the model")
     parser.add_argument("--select_modal", type=int, default=None)
     parser.add_argument("--synthetic", type=int, default=8, dest="synthetic_steps", help="synthetic batches per epoch")
+    parser.add_argument("--augment", action="store_true", help="synthetic whole cases through the GPU transform chain (crop foreground, pos/neg crop, z-rotation) instead of ready-made patches")
     parser.add_argument("--data_module", type=str, default=None, help="python module with build_loaders(args, train_config, model_config)")
     parser.add_argument("--save_path", type=str, default=None, help="checkpoint directory (default ./checkpoints/<date>_<dataset>)")
     parser.add_argument("--graph", action="store_true", dest="use_graph", help="per-stage hipGraph replay instead of eager launches")

@@ -106,3 +106,20 @@ def test_entrypoints_run_with_the_reference_command_line(tmp_path):
                         "--synthetic", "1", "--volume_shape", "48", "40", "36", "--out_csv", str(tmp_path / "res.csv")], capture_output=True, text=True, env=env, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(tmp_path / "res.csv") and "synthetic_0" in r.stdout
+
+
+def test_train_on_whole_cases_through_the_gpu_transform_chain(tmp_path):
+    """--augment: synthetic whole cases -> crop foreground -> pos/neg label crops -> z-rotation, all on the GPU, feeding the step loop"""
+    from veloxseg_amd.utils.train_loop import SyntheticVolumes, run_train
+    cfg, _ = CASES["g2_32_m2"]
+    src = SyntheticVolumes(cfg, 2, 2, torch.device("cuda", 0), volume=(72, 64, 56))
+    batches = list(src)
+    assert len(batches) == 2
+    for x, y in batches:
+        assert x.shape == (2, 2, 32, 32, 32) and y.shape == (2, 1, 32, 32, 32) and y.dtype == torch.long
+        assert set(y.unique().tolist()) <= {0, 1}
+    assert any(int(y.sum()) > 0 for _, y in batches)                  # pos/neg sampling found lesion voxels
+    again = list(SyntheticVolumes(cfg, 2, 2, torch.device("cuda", 0), volume=(72, 64, 56)))
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(batches, again))      # seeded: reproducible
+    h = run_train(_args(augment=True), dict(TRAIN_CFG, epochs=2), {"VeloxSeg": cfg}, save_path=str(tmp_path / "aug"))
+    assert len(h["loss"]) == 2 and all(l == l for l in h["loss"])

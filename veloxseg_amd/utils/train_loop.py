@@ -48,6 +48,55 @@ class SyntheticPatches:
             yield x.to(self.device), y.to(self.device)
 
 
+class SyntheticVolumes:
+    """whole synthetic cases (padded background + a foreground body + lesion blobs) pushed through the reference's transform chain on the GPU
+    (utils/augment.py: CropForegroundd -> RandCropByPosNegLabeld(num_samples) -> RandRotated): `batch` patches per step, batch / num_samples cases per step"""
+
+    def __init__(self, model_cfg, batch, steps, device, volume=(160, 160, 144), num_samples=2, seed=12345, rotate_degrees=15.0):
+        from . import augment as A
+        if batch % num_samples:
+            raise ValueError("batch must be a multiple of num_samples")
+        self.cfg, self.batch, self.steps, self.device, self.volume, self.seed, self.ns = model_cfg, batch, steps, device, tuple(volume), seed, num_samples
+        self.M = sum(model_cfg["in_ch"])
+        self.keys = [f"img{m}" for m in range(self.M)] + ["seg"]
+        self.pipe = A.Compose([
+            A.CropForegroundd(self.keys, "img0"),
+            A.RandCropByPosNegLabeld(self.keys, "seg", model_cfg["input_size"], pos=1, neg=1, num_samples=num_samples),
+            A.RandRotated(self.keys, range_z=A.rotation_range_from_degrees(rotate_degrees), mode=A.image_label_modes(self.M), prob=0.5),
+        ]).set_random_state(seed)
+
+    def __len__(self):
+        return self.steps
+
+    def case(self, g):
+        D, Hh, W = self.volume
+        pad = 8
+        body = (slice(None), slice(pad, D - pad), slice(pad, Hh - pad), slice(pad, W - pad))
+        data = {}
+        for m in range(self.M):
+            x = torch.full((1, D, Hh, W), -2.0, device=self.device)
+            x[body] = torch.randn((1, D - 2 * pad, Hh - 2 * pad, W - 2 * pad), generator=g, device=self.device).abs() - 1.9
+            data[f"img{m}"] = x
+        seg = torch.zeros((1, D, Hh, W), device=self.device)
+        ncls = self.cfg["n_classes"]
+        for _ in range(6):
+            c = [int(torch.randint(pad + 6, n - pad - 6, (1,), generator=g, device=self.device)) for n in (D, Hh, W)]
+            cls = 1 if ncls == 2 else int(torch.randint(1, ncls, (1,), generator=g, device=self.device))
+            seg[:, c[0] - 5:c[0] + 5, c[1] - 5:c[1] + 5, c[2] - 5:c[2] + 5] = float(cls)
+        data["seg"] = seg
+        return data
+
+    def __iter__(self):
+        g = torch.Generator(device=self.device).manual_seed(self.seed)
+        for _ in range(self.steps):
+            xs, ys = [], []
+            for _ in range(self.batch // self.ns):
+                for d in self.pipe(self.case(g)):
+                    xs.append(torch.cat([d[k] for k in self.keys[:-1]], 0))
+                    ys.append(d["seg"].long())
+            yield torch.stack(xs), torch.stack(ys)
+
+
 def _metric_fns(dataset_name):
     if dataset_name == "BraTS2021":
         from .metric.metrics_brats import show_deep_metrics
@@ -76,7 +125,8 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
         log.info("Load Checkpoint, Continue to Train!!!!")
     batch = train_config["batch_size"]
     if train_loader is None:
-        train_loader = SyntheticPatches(mcfg, batch, getattr(args, "synthetic_steps", 4), device)
+        source = SyntheticVolumes if getattr(args, "augment", False) else SyntheticPatches
+        train_loader = source(mcfg, batch, getattr(args, "synthetic_steps", 4), device)
     x0, y0 = next(iter(train_loader))
     engine = TrainEngine(model, criterion, tuple(x0.shape), label_dtype=y0.dtype, optimizer=optimizer, use_graph=getattr(args, "use_graph", False))
     show_deep_metrics = _metric_fns(args.dataset_name)
