@@ -198,18 +198,18 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01q_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01z_pmc_traffic.json")
 
 
 def _pmc_traffic(kernels, B):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
-    correction applied: profiles/r01q_pmc_traffic.json).  Counters cannot be read from inside bench.py; the figure is valid for the workload
+    correction applied: profiles/r01z_pmc_traffic.json).  Counters cannot be read from inside bench.py; the figure is valid for the workload
     and batch it was collected on (autopet128, B = 4) and null otherwise."""
     try:
         d = json.load(open(PMC_FILE))["kernels"]
         if B != 4 or _pmc_traffic.workload != "autopet128":
             return None, None
-        return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), "profiles/r01q_pmc_traffic.json"
+        return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), "profiles/r01z_pmc_traffic.json"
     except Exception:
         return None, None
 
