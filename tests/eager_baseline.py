@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc measurement (NOT part of the product or of bench.py): the oracle's plain PyTorch formulation run with
 aten/MIOpen kernels on the MI355X = "PyTorch-ROCm eager" training step, the reference point of BASELINE.json's
-">= 5x eager" target.  Usage: python tools/eager_baseline.py [workload] [batch] [steps]"""
+">= 5x eager" target.  Usage: python tests/eager_baseline.py [workload] [batch] [steps]"""
 import os
 import sys
 import time
