@@ -156,10 +156,12 @@ int vx_pwa_gather_all_bwd(const float* dtq, const float* dtk, const float* dtv, 
 int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);
 int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream);   /* dtok += (caller zeroes it once for all modalities) */
 /* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).
- * O: (B,heads,Ntot,M*l,cv); LSE: (B,heads,Ntot,M*l).  bwd: dtable += ; delta_ws = B*heads*Ntot*M*l floats. */
+ * O: (B,heads,Ntot,M*l,cv); LSE: (B,heads,Ntot,M*l).  bwd: dtable += ; delta_ws = vx_pwa_attn_bwd_ws_floats(plan, B, M) floats
+ * (row-sum workspace + replicated bias-gradient tables; contents need not be initialised). */
 int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
                     const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M);   /* answer, not a status; negative = error */
 int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                     const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,

@@ -10,6 +10,8 @@ from veloxseg_amd.model.VeloxSeg import VeloxSeg
 from veloxseg_amd.utils.loss import Loss
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 cfg, B = WORKLOADS["autopet128"]
+if os.environ.get("VX_ATTN_DROP"):
+    cfg = dict(cfg, attn_drop=float(os.environ["VX_ATTN_DROP"]))
 torch.manual_seed(12345)
 model = VeloxSeg(**cfg).cuda()
 crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)

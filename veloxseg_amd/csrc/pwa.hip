@@ -387,11 +387,13 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
 
 // backward A: lane = query row.  dQ, delta = rowsum(dO*O), d(bias table).  Same (unit, key split) decomposition as the forward;
 // the d(bias) of a unit is accumulated in ONE LDS table shared by its S waves (ds_add_f32), then flushed with float atomics.
+#define VX_PRIV_BINS 256
+#define VX_DTABLE_REPLICAS 16
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                           float* __restrict__ dtable, int Tsz, VxAttn A, VxDrop drop, int S) {
+                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S) {
     constexpr int RS = CQ + CV;
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // lin | bias tables | [4/S][Tsz] bias-gradient tables | [4] K/V slabs
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
@@ -438,8 +440,22 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     // the relative-position bin, so their ds are summed in registers and ONE ds_add_f32 per token reaches the bias-gradient table instead
     // of one per key (LDS float atomics retire ~1 lane per clock: they were 70 % of this kernel).
     const int TS = A.M == 1 ? 64 : A.M == 2 ? 32 : A.M == 4 ? 16 : (64 / A.M) & ~3;
+    // Bias-gradient bins of one slab: the wave's 64 queries x TS tokens touch the bin range [li_min - lin(t_last), li_max - lin(t0)].  When it fits
+    // VX_PRIV_BINS entries and the wave's rows are distinct positions of ONE modality (=> distinct bins per instruction), the sums go through a
+    // wave-private LDS window with plain read-add-write (LDS executes a wave's instructions in order) and only the window is flushed with
+    // ds_add_f32 -- float LDS atomics with 64 scattered addresses were 40-65 % of this kernel.
+    volatile float* __restrict__ priv = slabs + (long)4 * VX_KV_ROWS * RS + wave * VX_PRIV_BINS;
+    int li_min = ok ? lin_i : 0x7fffffff, li_max = ok ? lin_i : -0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { li_min = min(li_min, __shfl_xor(li_min, o, 64)); li_max = max(li_max, __shfl_xor(li_max, o, 64)); }
+    const int row_first = chunk * 64, row_last = min(chunk * 64 + 63, A.ML - 1);
+    const bool one_modality = active && (row_first / A.l == row_last / A.l);
+    for (int k = lane; k < VX_PRIV_BINS; k += 64) priv[k] = 0.0f;
     for (int t0 = split * TS; t0 < A.l; t0 += S * TS) {
         const int nt = min(TS, A.l - t0);
+        const int base = li_min - lin[t0 + nt - 1];
+        const int range = li_max - li_min + lin[t0 + nt - 1] - lin[t0] + 1;
+        const bool use_priv = one_modality && range <= VX_PRIV_BINS;
         __builtin_amdgcn_wave_barrier();
         {
             const int mrow = lane / TS, tt = lane - mrow * TS;
@@ -481,9 +497,23 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
                     }
                 }
             }
+            if (use_priv) {
+                if (ok) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (tt + t < nt) atomicAdd(stab + bi[t], dsum[t]);
+                    for (int t = 0; t < 4; ++t)
+                        if (tt + t < nt) { const int k = bi[t] - base; priv[k] = priv[k] + dsum[t]; }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (tt + t < nt) atomicAdd(stab + bi[t], dsum[t]);
+            }
+        }
+        if (use_priv) {
+            for (int k = lane; k < range; k += 64) {
+                const float g = priv[k];
+                if (g != 0.0f) { atomicAdd(stab + base + k, g); priv[k] = 0.0f; }
+            }
         }
     }
     if (S > 1) {
@@ -504,10 +534,11 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
             Delta[row] = delta;
         }
     }
-    if (active) {
+    if (active) {      // one of VX_DTABLE_REPLICAS copies per block: thousands of blocks adding into the same few hundred addresses serialise in L2
+        float* __restrict__ dst = dtable_rep + (long)(blockIdx.x % VX_DTABLE_REPLICAS) * Tsz * A.heads;
         for (int k = split * 64 + lane; k < Tsz; k += 64 * S) {
             const float g = stab[k];
-            if (g != 0.0f) atomicAdd(dtable + (long)k * A.heads + a, g);
+            if (g != 0.0f) atomicAdd(dst + (long)k * A.heads + a, g);
         }
     }
 }
@@ -519,8 +550,17 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
+                                                            const float* __restrict__ dtable_rep, float* __restrict__ dtable,
                                                             int Tsz, VxAttn A, VxDrop drop, int S) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
+    {   // fold the dQ kernel's replicated bias-gradient tables into dtable (it ran before this kernel on the same stream): one owner thread per entry
+        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < (long)Tsz * A.heads; k += (long)gridDim.x * 256) {
+            float g = 0.0f;
+#pragma unroll
+            for (int r = 0; r < VX_DTABLE_REPLICAS; ++r) g += dtable_rep[(long)r * Tsz * A.heads + k];
+            dtable[k] += g;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
@@ -777,6 +817,21 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     return 0;
 }
 
+__global__ void __launch_bounds__(256) vx_zero4_k(float4* __restrict__ p, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, 4, 4, "vx_pwa_attn_bwd_ws_floats")) return e;
+    const long Tsz = (long)(2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+    const long rows = (long)A.BH * A.Nt * A.ML;
+    const long n = ((rows + 3) & ~3L) + (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
+    VX_REQUIRE(n < 0x7fffffffL, "vx_pwa_attn_bwd_ws_floats: workspace too large");
+    return (int)n;
+}
+
 extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
@@ -788,14 +843,20 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
     const int S = vx_attn_split(units, A.ML, A.M);
-    const size_t shm = (tab_f + (((size_t)(4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
+    const size_t shm = (tab_f + (((size_t)(4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv) + (size_t)4 * VX_PRIV_BINS) * sizeof(float);
     const size_t shm_kv = (tab_f + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
+    // workspace: [rows] delta | [VX_DTABLE_REPLICAS][Tsz*heads] bias-gradient replicas (zeroed here, folded into dtable by the dK/dV kernel)
+    const long rows = (long)A.BH * A.Nt * A.ML;
+    float* rep = delta_ws + ((rows + 3) & ~3L);
+    const long rep_floats = (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
+    const unsigned nblk = (unsigned)vx_cdiv(units, 4 / S);
+    vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
-        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, dtable, Tsz, A, d, S);
-        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, Tsz, A, d, S);
+        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd");

@@ -827,7 +827,11 @@ class _PwaCoreFn(torch.autograd.Function):
         for m in range(M):
             H.call("vx_pwa_scatter_bwd", H.P(_c(douts[m])), H.P(dO), pp, cv, m, M, B, st)
         dq, dk, dv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
-        delta = torch.empty_like(lse)
+        cache = plan.__dict__.setdefault("_ws_floats", {})          # python-side attribute of the ctypes plan object
+        nws = cache.get((B, M))
+        if nws is None:
+            nws = cache[(B, M)] = H.query("vx_pwa_attn_bwd_ws_floats", pp, B, M)
+        delta = torch.empty(nws, device=dev, dtype=torch.float32)
         rs = rng_state(dev) if ctx.p > 0 else None
         dtab = grad_buf(ctx.table) if ctx.table.requires_grad else torch.zeros_like(tbl)
         H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
