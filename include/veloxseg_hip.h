@@ -84,6 +84,13 @@ int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* 
  * src may be a concat (S1 channels from src, rest from src2); dst may be split the same way (D1). */
 int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
                     float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream);
+/* "1x1 conv -> GELU -> dropout -> 1x1 conv" stage of the JLC / FFN blocks (conv_blocks.py:64-68, attention_utils.py:56-66) with the element-wise
+ * part in the conv epilogues: fwd writes the pre-activation a and h = drop(gelu(a)); bwd_data writes da = (W2^T dy) * mask * gelu'(a).
+ * Same masks as vx_gelu_drop_fwd/_bwd on the same (seed_ptr, dstream, p).  mfma != 0: MFMA tile kernels (small volumes). */
+int vx_pw_conv_gelu_fwd(const float* x, const float* w, const float* bias, float* a, float* h, int B, int Cin, int Cout, long V, int mfma,
+                        const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+int vx_pw_conv_gelu_bwd_data(const float* dy, const float* w, const float* a, float* da, int B, int Cin, int Cout, long V, int mfma,
+                             const void* seed_ptr, unsigned long long dstream, float p, void* stream);
 /* A/B knob: 1 (default) = 16 x 64 tiles with 16-byte operand loads when V % 4 == 0, 0 = 16 x 16 tiles */
 int vx_pw_mfma_set_wide(int on);
 

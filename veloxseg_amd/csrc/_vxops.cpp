@@ -9,6 +9,12 @@
 //
 // Reference call sites mirrored by the composites: JLC block conv_blocks.py:41-75; FFN tail PWA.py:437 + attention_utils.py:45-71.
 #include <torch/extension.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/custom_class.h>
+#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <hip/hip_runtime_api.h>
+#include <functional>
 #include <memory>
 #include <vector>
 #include "../../include/veloxseg_hip.h"
@@ -19,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = true, use_patchify = true, use_in_row = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -41,6 +47,54 @@ inline float* grad_ptr(const Tensor& p) {          // running gradient buffer of
     if (!p.defined() || !p.requires_grad()) return nullptr;
     if (!p.grad().defined()) const_cast<Tensor&>(p).mutable_grad() = at::zeros_like(p);
     return p.grad().data_ptr<float>();
+}
+
+// ------------------------------------------------------------------------------------------------------------------- weight-gradient side stream
+// In the backward pass only the INPUT gradient of a convolution is on the critical path (the previous layer waits for it); its weight gradient
+// is needed by the optimizer alone.  When enabled (TrainEngine turns it on around loss.backward() and joins before the all-reduce / AdamW),
+// the weight-gradient launches are DEFERRED: each is queued as a closure that keeps its tensors alive; every VX_WG_FLUSH closures the queue is
+// launched on one side stream behind a single event per launching stream (an event record + wait pair costs ~10 us of host time on this runtime,
+// a pair per convolution made the step slower), so the next layers' backward no longer queues behind ~4 ms of weight-gradient kernels.  The
+// closures (and with them dy, x and the temporaries) are released only after the final join, i.e. after the joining stream waits for the side
+// stream, which is what makes the caching allocator's reuse of that memory safe without record_stream.
+#define VX_WG_FLUSH 8
+struct WgradSide {
+    bool enabled = false;
+    c10::optional<c10::hip::HIPStreamMasqueradingAsCUDA> stream;      // torch on ROCm presents HIP streams with the CUDA device type
+    hipEvent_t ev[64];
+    unsigned next = 0;
+    std::vector<std::pair<void*, std::function<void(void*)>>> pending;      // (stream the operands were produced on, launch closure)
+    std::vector<std::function<void(void*)>> done;                            // launched, kept alive until the final join
+} WG;
+
+inline hipStream_t wg_stream(int dev) {
+    if (!WG.stream.has_value()) {
+        WG.stream = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, (c10::DeviceIndex)dev);
+        for (auto& e : WG.ev) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    }
+    return WG.stream->stream();
+}
+inline void wg_order(hipStream_t after, hipStream_t waiter) {           // `waiter` waits for everything enqueued on `after` so far
+    hipEvent_t e = WG.ev[WG.next++ & 63];
+    TORCH_CHECK(hipEventRecord(e, after) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess, "wgrad stream ordering failed");
+}
+inline void wg_flush(int dev) {
+    if (WG.pending.empty()) return;
+    hipStream_t side = wg_stream(dev);
+    void* seen[8]; int ns = 0;
+    for (auto& p : WG.pending) {                                         // one event per distinct producing stream
+        bool dup = false;
+        for (int i = 0; i < ns; ++i) dup = dup || seen[i] == p.first;
+        if (!dup) { wg_order((hipStream_t)p.first, side); if (ns < 8) seen[ns++] = p.first; }
+    }
+    for (auto& p : WG.pending) { p.second((void*)side); WG.done.push_back(std::move(p.second)); }
+    WG.pending.clear();
+}
+// run `launch(stream)` now on `cur`, or queue it for the side stream
+inline void wgrad_submit(void* cur, int dev, std::function<void(void*)> launch) {
+    if (!WG.enabled) { launch(cur); return; }
+    WG.pending.emplace_back(cur, std::move(launch));
+    if (WG.pending.size() >= VX_WG_FLUSH) wg_flush(dev);
 }
 
 // ------------------------------------------------------------------------------------------------------------------- convolution
@@ -92,10 +146,14 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
     const int B = st.B, C1 = st.C1, Cin = st.Cin, D = st.D, H = st.H, W = st.W, Cout = st.Cout, K = st.K, S = st.S, P = st.P, G = st.G, ps = st.ps;
     const long V = (long)D * H * W;
     const Tensor& x = st.x; const Tensor& x2 = st.x2; const Tensor& w = st.w; const Tensor& b = st.b;
+    const int dev = dy.device().index();
     if (st.patch) {
-        if (w.requires_grad())
-            chk(vx_pw_conv_bwd_weight(fp(x), nullptr, Cin * K * K * K, fp(dy), grad_ptr(w), grad_ptr(b), B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), stream),
-                "vx_pw_conv_bwd_weight");
+        if (w.requires_grad()) {
+            float* dw = grad_ptr(w); float* db = grad_ptr(b);
+            wgrad_submit(stream, dev, [=](void* s) {
+                chk(vx_pw_conv_bwd_weight(fp(x), nullptr, Cin * K * K * K, fp(dy), dw, db, B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), s), "vx_pw_conv_bwd_weight");
+            });
+        }
         return;
     }
     if (need_x) {
@@ -113,19 +171,26 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
     if (w.requires_grad()) {
         float* dw = grad_ptr(w);
         float* db = skip_bias ? nullptr : grad_ptr(b);       // skip_bias: the caller fused the bias gradient into the InstanceNorm backward
-        if (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1) chk(vx_pw_conv_bwd_weight(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, Cout, V, stream), "vx_pw_conv_bwd_weight");
-        else if (F.use_gconv1 && K == 1 && S == 1 && P == 0 && G > 1 && ps == 1 && !x2.defined() && Cin == Cout && (Cin / G == 4 || Cin / G == 8 || Cin / G == 16) && V % 4 == 0)
-            chk(vx_gconv1_bwd_weight(fp(x), fp(dy), dw, db, B, Cin, G, V, stream), "vx_gconv1_bwd_weight");
-        else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
-            Tensor xcl = at::empty({(long)B * V * 16}, x.options());
-            chk(vx_expand_wgrad_mfma(fp(x), mp(xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, stream), "vx_expand_wgrad_mfma");
-        } else if (F.use_wgrad_ws) {
-            const int nws = vx_conv3d_bwd_weight_ws_floats(B, Cin, D, H, W, Cout, K, S, P, G, ps);
-            TORCH_CHECK(nws >= 0, "vx_conv3d_bwd_weight_ws_floats failed");
-            Tensor ws = nws > 0 ? at::empty({(long)nws}, x.options()) : Tensor();
-            chk(vx_conv3d_bwd_weight_tiled_ws(fp(x), fp(x2), C1, fp(dy), dw, db, mp(ws), nws, B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_bwd_weight_tiled_ws");
-        } else chk(vx_conv3d_bwd_weight_tiled(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_bwd_weight_tiled");
+        const bool s1 = st.s1;
+        // the closure owns dy, x, x2 (by value) and its temporaries: with the side stream on, it is released only after the final join
+        wgrad_submit(stream, dev, [=](void* s) {
+            if (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1) chk(vx_pw_conv_bwd_weight(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, Cout, V, s), "vx_pw_conv_bwd_weight");
+            else if (F.use_gconv1 && K == 1 && S == 1 && P == 0 && G > 1 && ps == 1 && !x2.defined() && Cin == Cout && (Cin / G == 4 || Cin / G == 8 || Cin / G == 16) && V % 4 == 0)
+                chk(vx_gconv1_bwd_weight(fp(x), fp(dy), dw, db, B, Cin, G, V, s), "vx_gconv1_bwd_weight");
+            else if (s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
+                auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
+                WG.done.push_back([xcl](void*) {});          // keeps the temporary alive as long as the launches of this pass
+                chk(vx_expand_wgrad_mfma(fp(x), mp(*xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, s), "vx_expand_wgrad_mfma");
+            } else if (F.use_wgrad_ws) {
+                const int nws = vx_conv3d_bwd_weight_ws_floats(B, Cin, D, H, W, Cout, K, S, P, G, ps);
+                TORCH_CHECK(nws >= 0, "vx_conv3d_bwd_weight_ws_floats failed");
+                auto ws = std::make_shared<Tensor>(nws > 0 ? at::empty({(long)nws}, x.options()) : Tensor());
+                WG.done.push_back([ws](void*) {});
+                chk(vx_conv3d_bwd_weight_tiled_ws(fp(x), fp(x2), C1, fp(dy), dw, db, mp(*ws), nws, B, Cin, D, H, W, Cout, K, S, P, G, ps, s), "vx_conv3d_bwd_weight_tiled_ws");
+            } else chk(vx_conv3d_bwd_weight_tiled(fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, D, H, W, Cout, K, S, P, G, ps, s), "vx_conv3d_bwd_weight_tiled");
+        });
     }
+    if (!WG.enabled) WG.done.clear();                        // immediate launches: nothing to keep
 }
 
 // ------------------------------------------------------------------------------------------------------------------- InstanceNorm
@@ -227,6 +292,37 @@ Tensor gelu_bwd_impl(GeluState& st, const Tensor& dh_in, void* stream) {
     return da;
 }
 
+// "1x1 conv -> GELU -> dropout" in one launch (GELU in the conv epilogue) and its mirror "input gradient of the next 1x1 conv -> GELU backward";
+// fills the same ConvState / GeluState as the two separate operators, so the weight gradients go through conv_bwd_impl unchanged.
+bool pw_gelu_fusable(const Tensor& x, const Tensor& w) {
+    return x.dim() == 5 && w.size(2) == 1 && w.size(1) == x.size(1) && x.size(1) % 4 == 0 && (x.numel() / (x.size(0) * x.size(1))) % 4 == 0;
+}
+Tensor pw_gelu_fwd_impl(ConvState& c, GeluState& g, const Tensor& x_in, const Tensor& w, const Tensor& b, double p, int64_t site, const void* rs, void* stream) {
+    check_in(x_in, "conv3d");
+    Tensor x = contig(x_in);
+    const int B = x.size(0), Cin = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4), Cout = w.size(0);
+    const long V = (long)D * H * W;
+    c.x = x; c.x2 = Tensor(); c.w = w; c.b = b;
+    c.B = B; c.C1 = Cin; c.Cin = Cin; c.D = D; c.H = H; c.W = W; c.Cout = Cout; c.K = 1; c.S = 1; c.P = 0; c.G = 1; c.ps = 1;
+    c.pw = true; c.s1 = false; c.patch = false;
+    Tensor a = at::empty({B, Cout, D, H, W}, x.options()), h = at::empty({B, Cout, D, H, W}, x.options());
+    g.a = a; g.p = p; g.site = site; g.rs = p > 0 ? rs : nullptr;
+    chk(vx_pw_conv_gelu_fwd(fp(x), fp(w), fp(b), mp(a), mp(h), B, Cin, Cout, V, V <= F.pw_mfma_max_v ? 1 : 0, g.rs, (unsigned long long)site, (float)p, stream),
+        "vx_pw_conv_gelu_fwd");
+    return h;
+}
+// c2: the conv that consumed h; returns da (gradient at the pre-activation) and accumulates c2's weight / bias gradients
+Tensor pw_gelu_bwd_impl(ConvState& c2, GeluState& g, const Tensor& dz_in, void* stream) {
+    Tensor dz = contig(dz_in);
+    const long V = (long)c2.D * c2.H * c2.W;
+    Tensor da = at::empty_like(g.a);
+    chk(vx_pw_conv_gelu_bwd_data(fp(dz), fp(c2.w), fp(g.a), mp(da), c2.B, c2.Cin, c2.Cout, V, V <= F.pw_mfma_max_v ? 1 : 0, g.rs, (unsigned long long)g.site,
+                                 (float)g.p, stream), "vx_pw_conv_gelu_bwd_data");
+    Tensor t1, t2;
+    conv_bwd_impl(c2, dz, false, t1, t2, stream);          // parameter gradients only
+    return da;
+}
+
 struct AxpyState { double alpha = 1, p = 0; int64_t site = 0; const void* rs = nullptr; bool has_x = false; };
 Tensor axpy_fwd_impl(AxpyState& st, const Tensor& x, const Tensor& z_in, double alpha, double p, int64_t site, const void* rs, void* stream) {
     check_in(z_in, "residual_dropout");
@@ -261,6 +357,7 @@ struct JLCState {
     ConvState c1, c2;
     GeluState g;
     AxpyState r;
+    bool fused = false;
 };
 
 struct FFNState {
@@ -268,9 +365,103 @@ struct FFNState {
     ConvState c1, c2;
     GeluState g;
     AxpyState r;
+    bool fused = false;
 };
 
 inline void* sp(int64_t v) { return reinterpret_cast<void*>(v); }
+
+// ------------------------------------------------------------------------------------------------------------------- C++ autograd nodes
+// The frequent single operators as torch::autograd::Function: forward and backward run without the interpreter (a python autograd.Function
+// costs ~10 us per apply and ~12 us per backward call, on ~120 operators per step).  State travels in an IValue capsule on the node; the
+// HIP stream is torch's current stream (the engine restores the forward's stream before it calls backward).
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+template <class S> struct Holder : torch::CustomClassHolder { S s; };
+template <class S> c10::intrusive_ptr<Holder<S>> put_state(AutogradContext* ctx) {
+    auto h = c10::make_intrusive<Holder<S>>();
+    ctx->saved_data["st"] = c10::IValue::make_capsule(h);
+    return h;
+}
+template <class S> S& get_state(AutogradContext* ctx) {
+    return c10::static_intrusive_pointer_cast<Holder<S>>(ctx->saved_data["st"].toCapsule())->s;
+}
+inline void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+struct ConvFn : public torch::autograd::Function<ConvFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int64_t K, int64_t S, int64_t P, int64_t G, int64_t ps) {
+        auto h = put_state<ConvState>(ctx);
+        return conv_fwd_impl(h->s, x, x2.value_or(Tensor()), w, b.value_or(Tensor()), (int)K, (int)S, (int)P, (int)G, (int)ps, x.requires_grad(), cur_stream(x));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        ConvState& st = get_state<ConvState>(ctx);
+        Tensor dx, dx2;
+        // needs_input_grad indexes the tensor arguments that were present (x, [x2], w, [b])
+        conv_bwd_impl(st, g[0], ctx->needs_input_grad(0) || (st.x2.defined() && ctx->needs_input_grad(1)), dx, dx2, cur_stream(g[0]));
+        ctx->saved_data.clear();
+        return {dx, dx2, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+struct InstNormFn : public torch::autograd::Function<InstNormFn> {
+    static Tensor forward(AutogradContext* ctx, const OptT& res, bool act, const Tensor& y0, const OptT& y1, const OptT& y2) {
+        auto h = put_state<INState>(ctx);
+        std::vector<Tensor> ys{y0};
+        if (y1.has_value() && y1->defined()) ys.push_back(*y1);
+        if (y2.has_value() && y2->defined()) ys.push_back(*y2);
+        ctx->saved_data["has_res"] = res.has_value() && res->defined();
+        return in_fwd_impl(h->s, res.value_or(Tensor()), act, ys, cur_stream(y0));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        INState& st = get_state<INState>(ctx);
+        const bool has_res = ctx->saved_data["has_res"].toBool();
+        const int off = has_res ? 1 : 0;                      // edges: [res], y0, [y1], [y2]
+        std::vector<bool> need(st.n);
+        for (int k = 0; k < st.n; ++k) need[k] = ctx->needs_input_grad(off + k);
+        auto grads = in_bwd_impl(st, g[0], need, cur_stream(g[0]));
+        grads.resize(3);
+        Tensor dres = (has_res && ctx->needs_input_grad(0)) ? contig(g[0]) : Tensor();
+        ctx->saved_data.clear();
+        return {dres, Tensor(), grads[0], grads[1], grads[2]};
+    }
+};
+
+struct LayerNormFn : public torch::autograd::Function<LayerNormFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& gamma, const Tensor& beta) {
+        auto h = put_state<LNState>(ctx);
+        return ln_fwd_impl(h->s, x, gamma, beta, cur_stream(x));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        Tensor dx = ln_bwd_impl(get_state<LNState>(ctx), g[0], cur_stream(g[0]));
+        ctx->saved_data.clear();
+        return {dx, Tensor(), Tensor()};
+    }
+};
+
+struct GeluFn : public torch::autograd::Function<GeluFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& a, double p, int64_t site, int64_t rs) {
+        auto h = put_state<GeluState>(ctx);
+        return gelu_fwd_impl(h->s, a, p, site, sp(rs), cur_stream(a));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        Tensor da = gelu_bwd_impl(get_state<GeluState>(ctx), g[0], cur_stream(g[0]));
+        ctx->saved_data.clear();
+        return {da, Tensor(), Tensor(), Tensor()};
+    }
+};
+
+struct AxpyFn : public torch::autograd::Function<AxpyFn> {
+    static Tensor forward(AutogradContext* ctx, const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) {
+        auto h = put_state<AxpyState>(ctx);
+        return axpy_fwd_impl(h->s, x.value_or(Tensor()), z, alpha, p, site, sp(rs), cur_stream(z));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        Tensor dx, dz;
+        AxpyState& st = get_state<AxpyState>(ctx);
+        axpy_bwd_impl(st, g[0], st.has_x && ctx->needs_input_grad(0), dx, dz, cur_stream(g[0]));
+        ctx->saved_data.clear();
+        return {dx, dz, Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
 
 }  // namespace
 
@@ -290,6 +481,25 @@ PYBIND11_MODULE(_vxops, m) {
         F.use_s1 = s1; F.use_expand_mfma = expand_mfma; F.use_gconv1 = gconv1; F.use_wgrad_ws = wgrad_ws; F.use_patchify = patchify; F.use_in_row = in_row;
         F.pw_mfma_max_v = pw_mfma_max_v; F.in_row_max = in_row_max; F.in_eps = in_eps; F.ln_eps = ln_eps;
     });
+
+    // C++ autograd nodes: return tensors that already carry their grad_fn
+    m.def("conv", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int64_t K, int64_t S, int64_t P, int64_t G, int64_t ps) {
+        return ConvFn::apply(x, x2, w, b, K, S, P, G, ps);
+    });
+    m.def("instnorm", [](const OptT& res, bool act, const Tensor& y0, const OptT& y1, const OptT& y2) { return InstNormFn::apply(res, act, y0, y1, y2); });
+    m.def("layernorm", [](const Tensor& x, const Tensor& g, const Tensor& bt) { return LayerNormFn::apply(x, g, bt); });
+    m.def("gelu", [](const Tensor& a, double p, int64_t site, int64_t rs) { return GeluFn::apply(a, p, site, rs); });
+    m.def("axpy", [](const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) { return AxpyFn::apply(x, z, alpha, p, site, rs); });
+
+    // weight-gradient side stream: enable around the backward pass, join (make `stream` wait for it) before anything reads the parameter gradients
+    m.def("set_wgrad_stream", [](bool on) { WG.enabled = on; });
+    m.def("wgrad_join", [](int64_t stream, int64_t device, bool final) {
+        wg_flush((int)device);
+        if (WG.stream.has_value() && !WG.done.empty()) wg_order(WG.stream->stream(), (hipStream_t)sp(stream));
+        if (final) WG.done.clear();          // after the wait above: the memory may be reused by the joining stream
+    });
+
+    m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites
 
     m.def("conv_fwd", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int K, int S, int P, int G, int ps, int64_t stream) {
         auto st = std::make_shared<ConvState>();
@@ -353,8 +563,13 @@ PYBIND11_MODULE(_vxops, m) {
         }
         Tensor o = in_fwd_impl(st->in1, x, true, ys, s_);
         Tensor nrm = in_fwd_impl(st->in2, Tensor(), false, {o}, s_);
-        Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
-        Tensor h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
+        st->fused = F.fuse_gelu && pw_gelu_fusable(nrm, l1w) && l2w.size(1) % 4 == 0;
+        Tensor h;
+        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, nrm, l1w, l1b, 0.0, 0, nullptr, s_);
+        else {
+            Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
+            h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
+        }
         Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
         Tensor out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
         return py::make_tuple(out, st);
@@ -363,8 +578,11 @@ PYBIND11_MODULE(_vxops, m) {
         void* s_ = sp(stream);
         Tensor do_res, dz, dh, dh2, da, dn, dn2;
         axpy_bwd_impl(st->r, dout, true, do_res, dz, s_);
-        conv_bwd_impl(st->c2, dz, true, dh, dh2, s_);
-        da = gelu_bwd_impl(st->g, dh, s_);
+        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
+        else {
+            conv_bwd_impl(st->c2, dz, true, dh, dh2, s_);
+            da = gelu_bwd_impl(st->g, dh, s_);
+        }
         conv_bwd_impl(st->c1, da, true, dn, dn2, s_);
         Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
         Tensor d_o = sum3(do_res, do2, Tensor(), s_);
@@ -390,8 +608,13 @@ PYBIND11_MODULE(_vxops, m) {
         auto st = std::make_shared<FFNState>();
         void* s_ = sp(stream);
         Tensor n = ln_fwd_impl(st->ln, y, gamma, beta, s_);
-        Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
-        Tensor h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
+        st->fused = F.fuse_gelu && pw_gelu_fusable(n, w1) && w2.size(1) % 4 == 0;
+        Tensor h;
+        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, n, w1, b1, p, site1, sp(rs), s_);
+        else {
+            Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
+            h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
+        }
         Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
         Tensor out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
         return py::make_tuple(out, st);
@@ -400,8 +623,12 @@ PYBIND11_MODULE(_vxops, m) {
         void* s_ = sp(stream);
         Tensor dy_res, dz, dh, t2, dn, t3;
         axpy_bwd_impl(st->r, dout, true, dy_res, dz, s_);
-        conv_bwd_impl(st->c2, dz, true, dh, t2, s_);
-        Tensor da = gelu_bwd_impl(st->g, dh, s_);
+        Tensor da;
+        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
+        else {
+            conv_bwd_impl(st->c2, dz, true, dh, t2, s_);
+            da = gelu_bwd_impl(st->g, dh, s_);
+        }
         conv_bwd_impl(st->c1, da, true, dn, t3, s_);
         Tensor dy_ln = ln_bwd_impl(st->ln, dn, s_);
         return sum3(dy_res, dy_ln, Tensor(), s_);

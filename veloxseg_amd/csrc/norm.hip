@@ -287,13 +287,6 @@ __global__ void __launch_bounds__(256) vx_s2d2_k(const float* __restrict__ x, fl
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static VxDrop vx_mk_drop(const void* seed_ptr, unsigned long long stream, float p) {
-    VxDrop d;
-    d.seed_ptr = (p > 0.0f) ? (const uint64_t*)seed_ptr : nullptr;
-    d.stream = stream;
-    d.p = p;
-    return d;
-}
 
 static int vx_in_split(long BC, long V) {      // row split so that ~1024 blocks are in flight, each with >= 2048 elements
     long S = 1024 / (BC > 0 ? BC : 1);

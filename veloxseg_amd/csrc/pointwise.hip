@@ -19,11 +19,26 @@ __device__ __forceinline__ const float* vx_pw_row(const float* __restrict__ x, c
     return (c < C1) ? x + ((long)b * C1 + c) * V : x2 + ((long)b * (Cin - C1) + (c - C1)) * V;
 }
 
+// Optional epilogue of the forward / input-gradient kernels, for the "1x1 conv -> GELU (+ dropout) -> 1x1 conv" stage of the JLC and FFN blocks
+// (conv_blocks.py:64-68, attention_utils.py:56-66): mode 1 stores the pre-activation in aux and writes drop(gelu(.)); mode 2 multiplies the input
+// gradient by mask * gelu'(aux).  idx = flat NCDHW index of the destination element = the element index of vx_gelu_drop_fwd / _bwd (same masks).
+struct VxPwEpi {
+    int mode;
+    float* aux;
+    VxDrop drop;
+};
+__device__ __forceinline__ float vx_pw_epi(const VxPwEpi& e, float val, long idx) {
+    if (e.mode == 1) { e.aux[idx] = val; return vx_gelu(val) * vx_drop(e.drop, (uint64_t)idx); }
+    if (e.mode == 2) return val * vx_drop(e.drop, (uint64_t)idx) * vx_gelu_grad(e.aux[idx]);
+    return val;
+}
+static inline VxPwEpi vx_no_epi() { VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; return e; }
+
 // y[b,co,v] = bias[co] + sum_ci w[co,ci] * x[b,ci,v]          (Cin % 4 == 0)
 template <int COT>
 __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
                                                    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-                                                   int Cout, long V) {
+                                                   int Cout, long V, VxPwEpi epi) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     const int co0 = blockIdx.y * COT, b = blockIdx.z;
     if (v >= V) return;
@@ -50,13 +65,16 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
         }
     }
 #pragma unroll
-    for (int j = 0; j < COT; ++j) y[((long)b * Cout + co0 + j) * V + v] = acc[j];
+    for (int j = 0; j < COT; ++j) {
+        const long idx = ((long)b * Cout + co0 + j) * V + v;
+        y[idx] = vx_pw_epi(epi, acc[j], idx);
+    }
 }
 
 // dx[b,ci,v] (=|+=) sum_co w[co,ci] * dy[b,co,v]              (CIT input channels per thread, CIT % 4 == 0)
 template <int CIT>
 __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                        float* __restrict__ dx2, int C1, int Cin, int Cout, long V, int accumulate) {
+                                                        float* __restrict__ dx2, int C1, int Cin, int Cout, long V, int accumulate, VxPwEpi epi) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     const int ci0 = blockIdx.y * CIT, b = blockIdx.z;
     if (v >= V) return;
@@ -88,7 +106,8 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
     for (int i = 0; i < CIT; ++i) {
         const int c = ci0 + i;
         float* dst = (c < C1) ? dx + ((long)b * C1 + c) * V + v : dx2 + ((long)b * (Cin - C1) + (c - C1)) * V + v;
-        if (accumulate) *dst += acc[i]; else *dst = acc[i];
+        const float o = vx_pw_epi(epi, acc[i], ((long)b * Cin + c) * V + v);          // epilogue only without a concat destination (C1 == Cin)
+        if (accumulate) *dst += o; else *dst = o;
     }
 }
 
@@ -168,8 +187,8 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x
 
 template <int N> using vx_ic3 = std::integral_constant<int, N>;
 
-extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
-                              int B, int Cin, int Cout, long V, void* stream) {
+static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
+                               int B, int Cin, int Cout, long V, void* stream, const VxPwEpi& epi) {
     VX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_fwd: bad args");
     VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_fwd: Cin must be a multiple of 4 (got %d)", Cin);
     if (C1 <= 0 || C1 > Cin) C1 = Cin;
@@ -180,18 +199,23 @@ extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const flo
     dim3 grid(vx_cdiv(V, 256), Cout / T, B);
     hipStream_t st = (hipStream_t)stream;
     switch (T) {
-        case 16: vx_pw_fwd_k<16><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
-        case 8: vx_pw_fwd_k<8><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
-        case 4: vx_pw_fwd_k<4><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
-        case 2: vx_pw_fwd_k<2><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
-        default: vx_pw_fwd_k<1><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V); break;
+        case 16: vx_pw_fwd_k<16><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
+        case 8: vx_pw_fwd_k<8><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
+        case 4: vx_pw_fwd_k<4><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
+        case 2: vx_pw_fwd_k<2><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
+        default: vx_pw_fwd_k<1><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
     }
     VX_LAUNCH_CHECK("vx_pw_conv_fwd");
     return 0;
 }
 
-extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int C1,
-                                   int B, int Cin, int Cout, long V, int accumulate, void* stream) {
+extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
+                              int B, int Cin, int Cout, long V, void* stream) {
+    return vx_pw_conv_fwd_impl(x, x2, C1, w, bias, y, B, Cin, Cout, V, stream, vx_no_epi());
+}
+
+static int vx_pw_conv_bwd_data_impl(const float* dy, const float* w, float* dx, float* dx2, int C1,
+                                    int B, int Cin, int Cout, long V, int accumulate, void* stream, const VxPwEpi& epi) {
     VX_REQUIRE(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_data: bad args");
     VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_bwd_data: Cin must be a multiple of 4 (got %d)", Cin);
     if (C1 <= 0 || C1 > Cin) C1 = Cin;
@@ -203,12 +227,17 @@ extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, f
     dim3 grid(vx_cdiv(V, 256), Cin / T, B);
     hipStream_t st = (hipStream_t)stream;
     switch (T) {
-        case 16: vx_pw_bwd_data_k<16><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
-        case 8: vx_pw_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
-        default: vx_pw_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate); break;
+        case 16: vx_pw_bwd_data_k<16><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate, epi); break;
+        case 8: vx_pw_bwd_data_k<8><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate, epi); break;
+        default: vx_pw_bwd_data_k<4><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, accumulate, epi); break;
     }
     VX_LAUNCH_CHECK("vx_pw_conv_bwd_data");
     return 0;
+}
+
+extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int C1,
+                                   int B, int Cin, int Cout, long V, int accumulate, void* stream) {
+    return vx_pw_conv_bwd_data_impl(dy, w, dx, dx2, C1, B, Cin, Cout, V, accumulate, stream, vx_no_epi());
 }
 
 extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
@@ -333,7 +362,7 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
                                                     const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
                                                     float* __restrict__ dst, float* __restrict__ dst2, int D1,
                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate,
-                                                    int mode, int cd, int ch, int cw, int ksplit) {
+                                                    int mode, int cd, int ch, int cw, int ksplit, VxPwEpi epi) {
     // mode 0: plain.  mode 1 (ConvTranspose k2s2 forward): row m = co*8 + tap is stored depth-to-space into y[b][co][2d+i][2h+j][2w+k].
     // mode 2 (ConvTranspose k2s2 input gradient): reduction row k = co*8 + tap is gathered space-to-depth from dy.  (cd,ch,cw) = coarse dims.
     // ksplit = 1: the 4 waves of a block own 4 voxel tiles.  ksplit = 4 (small problems: too few tiles to fill the chip and a long,
@@ -402,7 +431,7 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
                     acc[reg] + (bias ? bias[co] : 0.0f);
             } else {
                 float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
-                const float o = acc[reg] + (bias ? bias[m] : 0.0f);
+                const float o = vx_pw_epi(epi, acc[reg] + (bias ? bias[m] : 0.0f), ((long)b * Mch + m) * V + v_b);      // epilogue: D1 == Mch only
                 drow[v_b] = accumulate ? drow[v_b] + o : o;
             }
         }
@@ -415,7 +444,7 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
 __global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
                                                      const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
                                                      float* __restrict__ dst, float* __restrict__ dst2, int D1,
-                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate, int ksplit) {
+                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate, int ksplit, VxPwEpi epi) {
     __shared__ float vx_ksum4[4][16 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -481,6 +510,22 @@ __global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ s
             float* drow = (m < D1) ? dst + ((long)b * D1 + m) * V : dst2 + ((long)b * (Mch - D1) + (m - D1)) * V;
             const float bb = bias ? bias[m] : 0.0f;
             float4 o = make_float4(acc[0][reg] + bb, acc[1][reg] + bb, acc[2][reg] + bb, acc[3][reg] + bb);
+            if (epi.mode) {                                   // D1 == Mch
+                const long idx = ((long)b * Mch + m) * V + v_b;
+                if (epi.mode == 1) *reinterpret_cast<float4*>(epi.aux + idx) = o;
+                const float4 ax = epi.mode == 2 ? *reinterpret_cast<const float4*>(epi.aux + idx) : o;
+                if (epi.mode == 1) {
+                    o.x = vx_gelu(ax.x) * vx_drop(epi.drop, (uint64_t)idx);
+                    o.y = vx_gelu(ax.y) * vx_drop(epi.drop, (uint64_t)idx + 1);
+                    o.z = vx_gelu(ax.z) * vx_drop(epi.drop, (uint64_t)idx + 2);
+                    o.w = vx_gelu(ax.w) * vx_drop(epi.drop, (uint64_t)idx + 3);
+                } else {
+                    o.x = o.x * vx_drop(epi.drop, (uint64_t)idx) * vx_gelu_grad(ax.x);
+                    o.y = o.y * vx_drop(epi.drop, (uint64_t)idx + 1) * vx_gelu_grad(ax.y);
+                    o.z = o.z * vx_drop(epi.drop, (uint64_t)idx + 2) * vx_gelu_grad(ax.z);
+                    o.w = o.w * vx_drop(epi.drop, (uint64_t)idx + 3) * vx_gelu_grad(ax.w);
+                }
+            }
             float4* dp = reinterpret_cast<float4*>(drow + v_b);
             if (accumulate) { const float4 old = *dp; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
             *dp = o;
@@ -494,8 +539,8 @@ extern "C" int vx_pw_mfma_set_wide(int on) { vx_pw_mfma4_enabled = on ? 1 : 0; r
 // split the reduction axis over the 4 waves of a block when there are too few (tile, wave) pairs to fill 256 CUs x 4 SIMDs and the chain is long
 static inline int vx_pw_ksplit(long wave_tiles, int Kch) { return (wave_tiles < 2048 && Kch >= 64) ? 4 : 1; }
 
-extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
-                               float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream) {
+static int vx_pw_conv_mfma_impl(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
+                                float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream, const VxPwEpi& epi) {
     VX_REQUIRE(src && w && dst && B > 0 && Mch > 0 && Kch > 0 && V > 0, "vx_pw_conv_mfma: bad args");
     if (S1 <= 0 || S1 > Kch) S1 = Kch;
     if (D1 <= 0 || D1 > Mch) D1 = Mch;
@@ -505,16 +550,40 @@ extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, cons
         const int n_vt4 = vx_cdiv(V, 64);
         const int ks4 = vx_pw_ksplit((long)B * n_vt4 * vx_cdiv(Mch, 16), Kch);
         dim3 g4(ks4 > 1 ? (unsigned)((long)B * n_vt4) : vx_cdiv((long)B * n_vt4, 4), vx_cdiv(Mch, 16));
-        vx_pw_mfma4_k<<<g4, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt4, accumulate, ks4);
+        vx_pw_mfma4_k<<<g4, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt4, accumulate, ks4, epi);
         VX_LAUNCH_CHECK("vx_pw_conv_mfma");
         return 0;
     }
     const int n_vt = vx_cdiv(V, 16);
     const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Mch, 16), Kch);
     dim3 grid(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Mch, 16));
-    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0, ksplit);
+    vx_pw_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, 0, 0, 0, 0, ksplit, epi);
     VX_LAUNCH_CHECK("vx_pw_conv_mfma");
     return 0;
+}
+
+extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
+                               float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream) {
+    return vx_pw_conv_mfma_impl(src, src2, S1, w, transpose_w, bias, dst, dst2, D1, B, Mch, Kch, Cin_of_w, V, accumulate, stream, vx_no_epi());
+}
+
+// a = W x + bias (kept for the backward), h = drop(gelu(a)): the first half of "1x1 conv -> GELU -> dropout -> 1x1 conv" in one launch.
+// mfma != 0 routes to the MFMA tile kernels (small volumes), else to the one-voxel-per-thread kernel (Cin % 4 == 0).
+extern "C" int vx_pw_conv_gelu_fwd(const float* x, const float* w, const float* bias, float* a, float* h, int B, int Cin, int Cout, long V, int mfma,
+                                   const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(x && w && a && h && a != h, "vx_pw_conv_gelu_fwd: bad args");
+    VxPwEpi e; e.mode = 1; e.aux = a; e.drop = vx_mk_drop(seed_ptr, dstream, p);
+    if (mfma) return vx_pw_conv_mfma_impl(x, nullptr, Cin, w, 0, bias, h, nullptr, 0, B, Cout, Cin, Cin, V, 0, stream, e);
+    return vx_pw_conv_fwd_impl(x, nullptr, Cin, w, bias, h, B, Cin, Cout, V, stream, e);
+}
+// da = (W^T dy) * mask * gelu'(a): the input gradient of the SECOND 1x1 conv (w: Cout x Cin, dy: B x Cout x V) with the GELU/dropout backward of
+// the stage in its epilogue; a, da: B x Cin x V.
+extern "C" int vx_pw_conv_gelu_bwd_data(const float* dy, const float* w, const float* a, float* da, int B, int Cin, int Cout, long V, int mfma,
+                                        const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(dy && w && a && da && a != da, "vx_pw_conv_gelu_bwd_data: bad args");
+    VxPwEpi e; e.mode = 2; e.aux = const_cast<float*>(a); e.drop = vx_mk_drop(seed_ptr, dstream, p);
+    if (mfma) return vx_pw_conv_mfma_impl(dy, nullptr, 0, w, 1, nullptr, da, nullptr, Cin, B, Cin, Cout, Cin, V, 0, stream, e);
+    return vx_pw_conv_bwd_data_impl(dy, w, da, nullptr, Cin, B, Cin, Cout, V, 0, stream, e);
 }
 
 extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
@@ -525,7 +594,7 @@ extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* b
         const int n_vt = vx_cdiv(Vc, 16);
         const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Co * 8, 16), Ci);
         dim3 g2(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Co * 8, 16));
-        vx_pw_mfma_k<<<g2, 256, 0, st>>>(x, nullptr, Ci, w, 1, Co * 8, bias, y, nullptr, Co * 8, Co * 8, Ci, Vc, B, n_vt, 0, 1, d, h, wd, ksplit);
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(x, nullptr, Ci, w, 1, Co * 8, bias, y, nullptr, Co * 8, Co * 8, Ci, Vc, B, n_vt, 0, 1, d, h, wd, ksplit, vx_no_epi());
         VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
         return 0;
     }
@@ -549,7 +618,7 @@ extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* d
         const int n_vt = vx_cdiv(Vc, 16);
         const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Ci, 16), Co * 8);
         dim3 g2(ksplit > 1 ? (unsigned)((long)B * n_vt) : vx_cdiv((long)B * n_vt, 4), vx_cdiv(Ci, 16));
-        vx_pw_mfma_k<<<g2, 256, 0, st>>>(dy, nullptr, Co * 8, w, Co * 8, 1, nullptr, dx, nullptr, Ci, Ci, Co * 8, Vc, B, n_vt, 0, 2, d, h, wd, ksplit);
+        vx_pw_mfma_k<<<g2, 256, 0, st>>>(dy, nullptr, Co * 8, w, Co * 8, 1, nullptr, dx, nullptr, Ci, Ci, Co * 8, Vc, B, n_vt, 0, 2, d, h, wd, ksplit, vx_no_epi());
         VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
         return 0;
     }

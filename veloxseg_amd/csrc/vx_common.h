@@ -112,6 +112,13 @@ __device__ __forceinline__ float vx_drop(const VxDrop& d, uint64_t idx) {
 // Dropout context hoisted out of inner loops: the {seed, step} pair is read once (scalar loads), masks are derived from raw Philox words.
 // Element idx always maps to word (idx & 3) of philox(seed, stream, idx >> 2), so any kernel may amortise one Philox call over the four
 // elements that share a counter without changing the mask.
+static inline VxDrop vx_mk_drop(const void* seed_ptr, unsigned long long stream, float p) {
+    VxDrop d;
+    d.seed_ptr = (p > 0.0f) ? (const uint64_t*)seed_ptr : nullptr;
+    d.stream = stream;
+    d.p = p;
+    return d;
+}
 struct VxDropCtx {
     uint64_t seed, stream;
     float p, inv_keep;

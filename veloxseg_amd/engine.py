@@ -22,6 +22,8 @@ import torch.distributed as dist
 from . import _hip as H
 from . import functional as VF
 
+WGRAD_STREAM = os.environ.get("VELOXSEG_WGRAD_STREAM", "0") != "0"      # experiment (off): weight-gradient kernels deferred to a side stream -- measured 13.5 vs 12.0 ms/step, they steal CUs from the critical path
+
 
 def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
@@ -107,9 +109,23 @@ class TrainEngine:
         """plain eager step: model() runs the decoder branches on forked streams (functional.run_branches)"""
         self.flat.zero_grad()
         outs, loss = self._forward_loss()
-        loss.backward()
+        self._backward(loss)
         self.loss.copy_(loss.detach())
         self.last_outputs = [o.detach() for o in outs]
+
+    def _backward(self, loss):
+        """loss.backward() with the weight-gradient kernels of the convolutions on a side stream (csrc/_vxops.cpp WgradSide): only the input
+        gradients stay on the critical path; the launching stream is re-joined before anything reads the parameter gradients"""
+        m = VF.cpp_module() if (WGRAD_STREAM and not self.use_graph) else None
+        if m is None:
+            loss.backward()
+            return
+        m.set_wgrad_stream(True)
+        try:
+            loss.backward()
+        finally:
+            m.set_wgrad_stream(False)
+            m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
 
     def _fwd_bwd_overlapped(self):
         """plain eager step + the decoder-bucket all-reduce started from INSIDE the backward pass: every decoder consumes the deepest
@@ -123,6 +139,9 @@ class TrainEngine:
         def decoders_done(_grads):
             cur = torch.cuda.current_stream(self.dev)
             self.comm_stream.wait_stream(cur)
+            m = VF.cpp_module() if WGRAD_STREAM else None
+            if m is not None:
+                m.wgrad_join(self.comm_stream.cuda_stream, self.dev.index or 0, False)      # the decoders' weight gradients run on the side stream
             for s_ in VF.branch_stream_list(self.dev, self.model.num_branches, "branches"):
                 self.comm_stream.wait_stream(s_)
             with torch.cuda.stream(self.comm_stream):
@@ -134,7 +153,7 @@ class TrainEngine:
         self.model._on_encoder_outputs = on_enc
         try:
             outs, loss = self._forward_loss()
-            loss.backward()
+            self._backward(loss)
         finally:
             self.model._on_encoder_outputs = None
             for h in handles:
