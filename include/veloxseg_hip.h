@@ -84,6 +84,10 @@ int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* 
  * src may be a concat (S1 channels from src, rest from src2); dst may be split the same way (D1). */
 int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
                     float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream);
+/* input gradient (=|+= into dx / dx2) and weight / bias gradient (+= into dw, db; db may be NULL) of a 1x1 conv in one launch; same results as
+ * vx_pw_conv_mfma(transpose_w = 1) followed by vx_pw_conv_bwd_weight */
+int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float* x, const float* x2, int C1, float* dx, float* dx2, float* dw, float* db,
+                         int B, int Cin, int Cout, long V, int accumulate, void* stream);
 /* "1x1 conv -> GELU -> dropout -> 1x1 conv" stage of the JLC / FFN blocks (conv_blocks.py:64-68, attention_utils.py:56-66) with the element-wise
  * part in the conv epilogues: fwd writes the pre-activation a and h = drop(gelu(a)); bwd_data writes da = (W2^T dy) * mask * gelu'(a).
  * Same masks as vx_gelu_drop_fwd/_bwd on the same (seed_ptr, dstream, p).  mfma != 0: MFMA tile kernels (small volumes). */

@@ -437,3 +437,30 @@ def test_patch_conv_via_patchify_matches_direct_conv_and_oracle(Cin, Cout, K, sp
         close(res[flag][0], yc, 2e-5, 2e-4, f"patchify={flag} y")
         close(res[flag][1], wc.grad, 1e-4 * float(wc.grad.abs().max()), 5e-4, f"patchify={flag} dw")
         close(res[flag][2], bc.grad, 1e-4 * float(bc.grad.abs().max()), 5e-4, f"patchify={flag} db")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,V,C1", [(2, 32, 48, 512, 0), (1, 16, 64, 4096, 0), (2, 24, 20, 64, 8), (2, 32, 16, 216, 0)],
+                         ids=["V512", "V4096_ksplit", "concat_V64", "V216"])
+def test_pw_conv_bwd_fused_equals_two_launches(B, Cin, Cout, V, C1):
+    """vx_pw_conv_bwd_fused == vx_pw_conv_mfma(transpose) + vx_pw_conv_bwd_weight, incl. accumulate mode, concat inputs and a null bias gradient"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    dy, w = rnd(B, Cout, V, seed=1).to(d), rnd(Cout, Cin, seed=2).to(d)
+    c1 = C1 or Cin
+    x, x2 = rnd(B, c1, V, seed=3).to(d), (rnd(B, Cin - c1, V, seed=4).to(d) if C1 else None)
+    st = H.stream_ptr()
+    for acc in (0, 1):
+        ref_dx, ref_dx2 = torch.full((B, c1, V), 0.5, device=d), (torch.full((B, Cin - c1, V), 0.25, device=d) if C1 else None)
+        got_dx, got_dx2 = ref_dx.clone(), (ref_dx2.clone() if C1 else None)
+        ref_dw, ref_db, got_dw, got_db = (torch.zeros(Cout, Cin, device=d), torch.zeros(Cout, device=d), torch.zeros(Cout, Cin, device=d), torch.zeros(Cout, device=d))
+        H.call("vx_pw_conv_mfma", H.P(dy), None, 0, H.P(w), 1, None, H.P(ref_dx), H.P(ref_dx2), c1, B, Cin, Cout, Cin, V, acc, st)
+        H.call("vx_pw_conv_bwd_weight", H.P(x), H.P(x2), c1, H.P(dy), H.P(ref_dw), H.P(ref_db), B, Cin, Cout, V, st)
+        H.call("vx_pw_conv_bwd_fused", H.P(dy), H.P(w), H.P(x), H.P(x2), c1, H.P(got_dx), H.P(got_dx2), H.P(got_dw), H.P(got_db) if acc == 0 else None,
+               B, Cin, Cout, V, acc, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got_dx, ref_dx) and (not C1 or torch.equal(got_dx2, ref_dx2))
+        close(got_dw, ref_dw, 1e-5 * max(1.0, float(ref_dw.abs().max())), 1e-5, "dw")            # float atomics: summation order only
+        if acc == 0:
+            close(got_db, ref_db, 1e-5 * max(1.0, float(ref_db.abs().max())), 1e-5, "db")
+        else:
+            assert float(got_db.abs().max()) == 0.0

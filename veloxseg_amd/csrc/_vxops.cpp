@@ -25,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -154,6 +154,14 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 chk(vx_pw_conv_bwd_weight(fp(x), nullptr, Cin * K * K * K, fp(dy), dw, db, B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), s), "vx_pw_conv_bwd_weight");
             });
         }
+        return;
+    }
+    if (need_x && st.pw && V <= F.pw_mfma_max_v && w.requires_grad() && !WG.enabled && F.fuse_pw_bwd) {      // both gradients of a small 1x1 conv in one launch
+        const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
+        dx = acc ? acc_into : at::empty_like(x);
+        if (x2.defined()) dx2 = at::empty_like(x2);
+        chk(vx_pw_conv_bwd_fused(fp(dy), fp(w), fp(x), fp(x2), C1, mp(dx), mp(dx2), grad_ptr(w), skip_bias ? nullptr : grad_ptr(b), B, Cin, Cout, V, acc, stream),
+            "vx_pw_conv_bwd_fused");
         return;
     }
     if (need_x) {
@@ -499,7 +507,8 @@ PYBIND11_MODULE(_vxops, m) {
         if (final) WG.done.clear();          // after the wait above: the memory may be reused by the joining stream
     });
 
-    m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites
+    m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
+    m.def("set_fuse_pw_bwd", [](bool on) { F.fuse_pw_bwd = on; });  // A/B: input + weight gradient of small 1x1 convs in one launch      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites
 
     m.def("conv_fwd", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int K, int S, int P, int G, int ps, int64_t stream) {
         auto st = std::make_shared<ConvState>();

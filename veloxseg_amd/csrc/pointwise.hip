@@ -115,18 +115,18 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
 // iteration with all eight 16-byte operand loads issued before the 16 MFMAs; the 4 waves of a block (same tile, adjacent chunks) are
 // summed through LDS so that a block issues 256 float atomics, not 1024 (with ~2 k waves on one 16x16 tile the atomics on its 256
 // addresses, not the loads, were the cost: 56 us for 17 MB).
-__global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+__device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
                                                      const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
                                                      float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
     __shared__ float red[4][4 * 64 + 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long cw = (long)blockIdx.x * 4 + wave;
+    const long cw = (long)vbx * 4 + wave;
     const bool live = cw < (long)B * chunks_per_b;
     const int b = live ? (int)(cw / chunks_per_b) : 0;
     const long v0 = live ? (cw % chunks_per_b) * (long)vox_per_wave : 0;
     const long v1 = live ? ((v0 + vox_per_wave < V) ? v0 + vox_per_wave : V) : 0;
-    const int mt = blockIdx.y / n_ci_tiles, nt = blockIdx.y % n_ci_tiles;
+    const int mt = vby / n_ci_tiles, nt = vby % n_ci_tiles;
     const int r = lane & 15, q = lane >> 4;
     const int co = mt * 16 + r, ci = nt * 16 + r;
     const bool co_ok = co < Cout, ci_ok = ci < Cin;
@@ -183,6 +183,11 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x
     }
     if (db != nullptr && nt == 0 && q == 0 && co_ok)
         atomicAdd(db + co, (red[0][256 + r] + red[1][256 + r]) + (red[2][256 + r] + red[3][256 + r]));
+}
+__global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+                                                     const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
+                                                     float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
+    vx_pw_wgrad_body(blockIdx.x, blockIdx.y, x, x2, C1, Cin, dy, Cout, V, B, dw, db, vox_per_wave, chunks_per_b, n_ci_tiles);
 }
 
 template <int N> using vx_ic3 = std::integral_constant<int, N>;
@@ -441,7 +446,7 @@ __global__ void __launch_bounds__(256) vx_pw_mfma_k(const float* __restrict__ sr
 // Plain mode, V % 4 == 0: one wave = 16 rows x 64 voxels as FOUR interleaved n-tiles (column r of n-tile j = voxel v0 + 4r + j), so the B
 // operands of the four MFMAs of a k-step are ONE 16-byte load per lane (256 contiguous bytes per reduction row and wave instead of 64) and
 // the results leave as 16-byte stores; the A operand (weights) is shared by the four MFMAs.  Same ksplit scheme as vx_pw_mfma_k.
-__global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
+__device__ __forceinline__ void vx_pw_mfma4_body(const int vbx, const int vby, const float* __restrict__ src, const float* __restrict__ src2, int S1,
                                                      const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
                                                      float* __restrict__ dst, float* __restrict__ dst2, int D1,
                                                      int Mch, int Kch, long V, int B, int n_vt, int accumulate, int ksplit, VxPwEpi epi) {
@@ -449,13 +454,13 @@ __global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ s
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ks = ksplit > 1 ? wave : 0;
-    const long tile_raw = ksplit > 1 ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;           // over (b, 64-voxel tile)
+    const long tile_raw = ksplit > 1 ? (long)vbx : (long)vbx * 4 + wave;           // over (b, 64-voxel tile)
     const bool live = tile_raw < (long)B * n_vt;
     if (!live && ksplit == 1) return;
     const long tile = live ? tile_raw : 0;
     const int b = (int)(tile / n_vt);
     const long v0 = (tile % n_vt) * 64;
-    const int mt = blockIdx.y;
+    const int mt = vby;
     const int r = lane & 15, q = lane >> 4;
     const int m_a = mt * 16 + r;
     const bool m_ok = m_a < Mch;
@@ -532,6 +537,12 @@ __global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ s
         }
     }
 }
+__global__ void __launch_bounds__(256) vx_pw_mfma4_k(const float* __restrict__ src, const float* __restrict__ src2, int S1,
+                                                     const float* __restrict__ w, int wsm, int wsk, const float* __restrict__ bias,
+                                                     float* __restrict__ dst, float* __restrict__ dst2, int D1,
+                                                     int Mch, int Kch, long V, int B, int n_vt, int accumulate, int ksplit, VxPwEpi epi) {
+    vx_pw_mfma4_body(blockIdx.x, blockIdx.y, src, src2, S1, w, wsm, wsk, bias, dst, dst2, D1, Mch, Kch, V, B, n_vt, accumulate, ksplit, epi);
+}
 
 static int vx_pw_mfma4_enabled = 1;
 extern "C" int vx_pw_mfma_set_wide(int on) { vx_pw_mfma4_enabled = on ? 1 : 0; return 0; }
@@ -565,6 +576,51 @@ static int vx_pw_conv_mfma_impl(const float* src, const float* src2, int S1, con
 extern "C" int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w, int transpose_w, const float* bias,
                                float* dst, float* dst2, int D1, int B, int Mch, int Kch, int Cin_of_w, long V, int accumulate, void* stream) {
     return vx_pw_conv_mfma_impl(src, src2, S1, w, transpose_w, bias, dst, dst2, D1, B, Mch, Kch, Cin_of_w, V, accumulate, stream, vx_no_epi());
+}
+
+// Backward of a 1x1 conv in ONE launch: blocks [0, n1) compute the input gradient (the 16 x 64 MFMA tiles of vx_pw_mfma4_body on w^T), blocks
+// [n1, n1 + n2) the weight / bias gradient (vx_pw_wgrad_body).  The two halves are independent; at the 16^3 .. 4^3 levels each is a 7-11 us
+// launch, and ~70 such pairs per step ran back to back on one stream.
+__global__ void __launch_bounds__(256) vx_pw_bwd_fused_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ dx2,
+                                                         int C1, int Cin, int Cout, long V, int B, int n_vt, int accumulate, int ksplit, int n1, int gx1,
+                                                         const float* __restrict__ x, const float* __restrict__ x2, float* __restrict__ dw, float* __restrict__ db,
+                                                         int vox_per_wave, int chunks_per_b, int n_ci_tiles, int gx2) {
+    const int id = blockIdx.x;
+    if (id < n1) {
+        VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f;
+        vx_pw_mfma4_body(id % gx1, id / gx1, dy, nullptr, Cout, w, 1, Cin, nullptr, dx, dx2, C1, Cin, Cout, V, B, n_vt, accumulate, ksplit, e);
+    } else {
+        const int j = id - n1;
+        vx_pw_wgrad_body(j % gx2, j / gx2, x, x2, C1, Cin, dy, Cout, V, B, dw, db, vox_per_wave, chunks_per_b, n_ci_tiles);
+    }
+}
+
+extern "C" int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float* x, const float* x2, int C1, float* dx, float* dx2, float* dw, float* db,
+                                    int B, int Cin, int Cout, long V, int accumulate, void* stream) {
+    VX_REQUIRE(dy && w && x && dx && dw && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_fused: bad args");
+    if (C1 <= 0 || C1 > Cin) C1 = Cin;
+    VX_REQUIRE(C1 == Cin || (x2 && dx2), "vx_pw_conv_bwd_fused: second tensor of a concat is missing");
+    if ((V & 3) != 0 || !vx_pw_mfma4_enabled) {          // no wide tiles: the two separate launches
+        if (int e = vx_pw_conv_mfma_impl(dy, nullptr, 0, w, 1, nullptr, dx, dx2, C1, B, Cin, Cout, Cin, V, accumulate, stream, vx_no_epi())) return e;
+        return vx_pw_conv_bwd_weight(x, x2, C1, dy, dw, db, B, Cin, Cout, V, stream);
+    }
+    const int n_vt4 = vx_cdiv(V, 64);
+    const int ks4 = vx_pw_ksplit((long)B * n_vt4 * vx_cdiv(Cin, 16), Cout);
+    const int gx1 = ks4 > 1 ? (int)((long)B * n_vt4) : vx_cdiv((long)B * n_vt4, 4), gy1 = vx_cdiv(Cin, 16);
+    const int mt = vx_cdiv(Cout, 16), nt = vx_cdiv(Cin, 16);
+    long waves_per_tile = 1024 / ((long)mt * nt);
+    if (waves_per_tile < 4) waves_per_tile = 4;
+    long vpw = ((long)B * V + waves_per_tile - 1) / waves_per_tile;
+    vpw = (vpw + 63) / 64 * 64;
+    if (vpw < 256) vpw = 256;
+    const int chunks_per_b = vx_cdiv(V, vpw);
+    const int gx2 = vx_cdiv((long)B * chunks_per_b, 4), gy2 = mt * nt;
+    const long n1 = (long)gx1 * gy1, n2 = (long)gx2 * gy2;
+    VX_REQUIRE(n1 + n2 < 0x7fffffffL, "vx_pw_conv_bwd_fused: grid too large");
+    vx_pw_bwd_fused_k<<<dim3((unsigned)(n1 + n2)), 256, 0, (hipStream_t)stream>>>(dy, w, dx, dx2, C1, Cin, Cout, V, B, n_vt4, accumulate, ks4, (int)n1, gx1,
+                                                                               x, x2, dw, db, (int)vpw, chunks_per_b, nt, gx2);
+    VX_LAUNCH_CHECK("vx_pw_conv_bwd_fused");
+    return 0;
 }
 
 // a = W x + bias (kept for the backward), h = drop(gelu(a)): the first half of "1x1 conv -> GELU -> dropout -> 1x1 conv" in one launch.

@@ -179,6 +179,7 @@ def cpp_module(reload: bool = False):
                 H.LIB.load()
                 from . import _vxops
                 _vxops.set_fuse_gelu(os.environ.get("VELOXSEG_FUSE_GELU", "1") != "0")
+                _vxops.set_fuse_pw_bwd(os.environ.get("VELOXSEG_FUSE_PW_BWD", "1") != "0")
                 _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
                 _CPP[1] = _vxops
             except ImportError:
