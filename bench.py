@@ -188,6 +188,11 @@ def main():
             rf = roofline_for(name, key, tot_ms / n, model)
             if rf.get("achieved") is not None:
                 rf["launches_per_step"], rf["share_of_step"] = n, round(tot_ms / total, 4)
+                if rf.get("traffic") is None and name in ("vx_expand_wgrad_mfma", "vx_expand_bwd_data_mfma"):
+                    kern = "vx_expand_wgrad_mfma_k" if name == "vx_expand_wgrad_mfma" else "vx_expand_bwd_data_lds_k"
+                    rf["traffic"], src = _pmc_traffic_by_launches(kern, B, n)
+                    if src:
+                        rf["traffic_source"] = src
                 out["roofline"] = rf
                 break
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -199,6 +204,23 @@ def main():
 
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r01z_pmc_traffic.json")
+
+
+def _pmc_traffic_by_launches(kernel, B, launches_per_step, trace_steps=5):
+    """as _pmc_traffic for a kernel that runs with several shapes per step: the entry of the grid size that was launched launches_per_step times per step"""
+    try:
+        d = json.load(open(PMC_FILE))["kernels"][kernel]
+        if B != 4 or _pmc_traffic.workload != "autopet128":
+            return None, None
+        hits = [g for g in d.get("by_grid", {}).values() if g["launches_in_trace"] == launches_per_step * trace_steps]
+        if len(hits) == 1:
+            return float(hits[0]["hbm_bytes_per_launch_corrected"]), "profiles/r01z_pmc_traffic.json (by grid size)"
+        if "by_grid" in d:
+            return None, None
+        note = "" if d["launches_in_trace"] == launches_per_step * trace_steps else f" (mean over all {d['launches_in_trace'] // trace_steps} launches of this kernel per step, more than one shape)"
+        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r01z_pmc_traffic.json" + note
+    except Exception:
+        return None, None
 
 
 def _pmc_traffic(kernels, B):

@@ -25,13 +25,14 @@ def short(name):
     return "".join(out).strip()
 
 
-def collect(path, counter):
+def collect(path, counter, by_grid=False):
     acc = defaultdict(lambda: [0, 0.0])
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row.get("Counter_Name") != counter:
                 continue
-            a = acc[short(row["Kernel_Name"])]
+            key = short(row["Kernel_Name"])
+            a = acc[(key, int(row["Grid_Size"])) if by_grid else key]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
     return acc
@@ -48,6 +49,13 @@ def main():
         fk, wk = f[k][1] / f[k][0], w[k][1] / w[k][0]
         kernels[k] = {"launches_in_trace": f[k][0], "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
                       "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024)}
+    # the same kernel launched with several grid sizes (different shapes): one entry per grid
+    fg, wg = collect(fetch, "FETCH_SIZE", True), collect(write, "WRITE_SIZE", True)
+    for k in kernels:
+        grids = sorted(g for (n, g) in fg if n == k and (n, g) in wg)
+        if len(grids) > 1:
+            kernels[k]["by_grid"] = {str(g): {"launches_in_trace": fg[(k, g)][0],
+                                              "hbm_bytes_per_launch_corrected": int((2 * fg[(k, g)][1] / fg[(k, g)][0] + wg[(k, g)][1] / wg[(k, g)][0]) * 1024)} for g in grids}
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2`, B=4 autopet128; traffic = "
                      "2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), KB -> bytes",
            "kernels": kernels}
