@@ -464,3 +464,28 @@ def test_pw_conv_bwd_fused_equals_two_launches(B, Cin, Cout, V, C1):
             close(got_db, ref_db, 1e-5 * max(1.0, float(ref_db.abs().max())), 1e-5, "db")
         else:
             assert float(got_db.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("grid,big,heads,c", [([16, 16, 16], [8, 8, 8], 2, 8), ([16, 16, 16], [4, 4, 4], 1, 16), ([8, 8, 8], [4, 4, 4], 4, 32)])
+def test_scatter_adjoint_transpose_kernel_equals_general_adjoint(grid, big, heads, c):
+    """1x1x1 small windows: the LDS-transpose adjoint of window_scattering_3d writes exactly what the general (LDS-atomic) adjoint accumulates"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, c, heads * c * 2)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    B, M = 2, 2
+    pp = H.ctypes.addressof(plan)
+    dout = [rnd(B, plan.nb * heads * c, *grid, seed=60 + m).to(d) for m in range(M)]
+    res = []
+    try:
+        for knob in (1, 0):
+            H.call("vx_pwa_scatter_set_ident", knob)
+            dtok = torch.zeros(B, heads, plan.Ntot, M * plan.l, c, device=d)
+            for m in range(M):
+                H.call("vx_pwa_scatter_bwd", H.P(dout[m]), H.P(dtok), pp, c, m, M, B, H.stream_ptr())
+            torch.cuda.synchronize()
+            res.append(dtok)
+    finally:
+        H.call("vx_pwa_scatter_set_ident", 1)
+    assert float(res[0].abs().max()) > 0
+    close(res[0], res[1], 2e-6 * max(1.0, float(res[1].abs().max())), 1e-5, "scatter adjoint")       # the general adjoint sums with float atomics

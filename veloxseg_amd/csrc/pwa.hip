@@ -241,6 +241,29 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restr
     }
 }
 
+// small window 1x1x1 (every shipped config: min_small_window_sizes = [[1,1,1]] * 4): the per-window resampling is the identity, so the adjoint
+// is a transpose of the window's (c, voxels) slab into its (tokens, c) rows -- staged through LDS (pitch c + 1), coalesced on both sides, no atomics.
+// One block = one (b, head, window); every element of the destination rows is written exactly once, which equals "+=" on the zeroed buffer.
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale) {
+    extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c + 1]
+    const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
+    const int i = scale;
+    const int Nl = blockIdx.x, N = P.woff[i] + Nl;
+    const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
+    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c) * V;
+    const int l = P.l, pitch = c + 1;
+    for (int e = threadIdx.x; e < l * c; e += 256) {
+        const int vox = e % l, cc = e / l;
+        const int j2 = vox % n2, j1 = (vox / n2) % n1, j0 = vox / (n2 * n1);
+        vx_sacc[vox * pitch + cc] = db[(long)cc * V + ((long)(W0 * n0 + j0) * P.grid[1] + (W1 * n1 + j1)) * P.grid[2] + (W2 * n2 + j2)];
+    }
+    __syncthreads();
+    float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * l) + (long)m * l) * c;
+    for (int k = threadIdx.x; k < l * c; k += 256) dt[k] += vx_sacc[(k / c) * pitch + (k % c)];       // sole owner of these rows: "+=" without atomics
+}
+
 // ---------------------------------------------------------------------------------------------
 // attention
 // ---------------------------------------------------------------------------------------------
@@ -740,6 +763,8 @@ extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan*
     return 0;
 }
 
+static int vx_scatter_ident_enabled = 1;
+extern "C" int vx_pwa_scatter_set_ident(int on) { vx_scatter_ident_enabled = on ? 1 : 0; return 0; }      // A/B knob: 0 = always the general (LDS-atomic) adjoint
 extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
     VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
@@ -750,6 +775,12 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
         int chunks = (int)((nv * c + 4095) / 4096);
         if (chunks > 64) chunks = 64;
         const int nwin = plan->nwin[i][0] * plan->nwin[i][1] * plan->nwin[i][2];
+        if (plan->small[i][0] == 1 && plan->small[i][1] == 1 && plan->small[i][2] == 1 && vx_scatter_ident_enabled) {
+            const size_t shm1 = sizeof(float) * (size_t)plane_l(plan) * (c + 1);
+            VX_REQUIRE(shm1 <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
+            hipLaunchKernelGGL(vx_pwa_scatter_bwd_ident_k, dim3(nwin, B * plan->heads), dim3(256), shm1, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i);
+            continue;
+        }
         hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(chunks, nwin, B * plan->heads), dim3(256), shm, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i);
     }
     VX_LAUNCH_CHECK("vx_pwa_scatter_bwd");
