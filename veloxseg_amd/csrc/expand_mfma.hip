@@ -218,44 +218,52 @@ extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, flo
 //   B (coarse input, CHANNELS-LAST copy): lane (r,q) reads xcl[p + t - 1 (voxel w4+q+tw-1)][ci=r] -> one 256-byte run per tap.
 //   One wave = one (c,s1) group x a run of k-steps; 27 accumulator tiles (108 VGPRs); one float atomic per weight per wave at the end.
 // ------------------------------------------------------------------------------------------------------------------
+template <int GS>
 __global__ void __launch_bounds__(256) vx_expand_wgrad_mfma_k(const float* __restrict__ x, const float* __restrict__ dyf, float* __restrict__ dw,
                                                               float* __restrict__ db, int B, int Cc, int D, int H, int W, int steps_per_wave, int chunks_per_b) {
+    // One wave = TWO (c, s1) groups (s1 = 2 sp, 2 sp + 1) sharing the 27 coarse-input operands of every k-step: 29 operand loads feed 54 MFMAs
+    // (was 28 for 27; the kernel ran at the L2 read rate, not at the MFMA rate: every group re-reads all of x once per tap).  2 x 108 accumulator
+    // registers + the double-buffered operands fit the 512-register file of a wave that owns its SIMD (launch bounds 256 = 1 wave per SIMD).
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __shared__ float red[16 * 16 * 27];
-    for (int e = threadIdx.x; e < 16 * 16 * 27; e += 256) red[e] = 0.0f;
-    __syncthreads();
     const long gw_raw = (long)blockIdx.x * 4 + wave;
     const bool active = gw_raw < (long)B * chunks_per_b;
     const long gw = active ? gw_raw : 0;
     const int b = (int)(gw / chunks_per_b);
     const int chunk = (int)(gw % chunks_per_b);
-    const int mt = blockIdx.y;                          // (c, s1)
-    const int c = mt >> 2, s1 = mt & 3;
+    const int mt = blockIdx.y;                          // (c, s1 pair)
+    const int c = mt / (4 / GS), sp = mt % (4 / GS);
     const int r = lane & 15, q = lane >> 4;
     const int W4 = (W + 3) / 4;                         // k-steps per coarse row
     const long nsteps = (long)D * H * W4;
     const long V = (long)D * H * W;
     const long FH = 4L * H, FW = 4L * W;
     const long fplane = (4L * D) * FH * FW;
-    const float* __restrict__ dyb = dyf + ((long)b * Cc + c) * fplane + (long)s1 * FH * FW + (long)(r >> 2) * FW + (r & 3);
+    const long gstride = FH * FW;                       // s1 -> s1 + 1
+    const float* __restrict__ dyb = dyf + ((long)b * Cc + c) * fplane + (long)(GS * sp) * gstride + (long)(r >> 2) * FW + (r & 3);
     const float* __restrict__ xb = x + (long)b * V * 16 + r;       // channels-last: [voxel][16]
-    vx_f4 acc[27];
+    vx_f4 acc[GS][27];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = (vx_f4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.0f;
+    for (int g = 0; g < GS; ++g)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[g][t] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    float bsum[GS];
+#pragma unroll
+    for (int g = 0; g < GS; ++g) bsum[g] = 0.0f;
     const long s_begin = (long)chunk * steps_per_wave;
     const long s_end = !active ? s_begin : ((s_begin + steps_per_wave < nsteps) ? s_begin + steps_per_wave : nsteps);
-    // software pipeline: the 28 operand loads of step s+1 are issued before the 27 MFMAs of step s
-    // position of the NEXT step to load, advanced incrementally (three run-time integer divisions per step used to cost about as many issue
-    // cycles as the 27 MFMAs they fed); tap addresses = one base pointer + constant offsets, validity = per-axis flags
+    // software pipeline: the operand loads of step s+1 are issued before the MFMAs of step s; the position of the NEXT step to load is advanced
+    // incrementally (three run-time integer divisions per step used to cost about as many issue cycles as the MFMAs they fed)
     int nw4 = (int)(s_begin % W4), nh = (int)((s_begin / W4) % H), nd = (int)(s_begin / ((long)W4 * H));
     long ns = s_begin;
     const long HW16 = (long)H * W * 16, W16 = (long)W * 16;
-    auto load_step = [&](float& av, float (&bv)[27]) {
+    auto load_step = [&](float (&av)[GS], float (&bv)[27]) {
         const int pw = 4 * nw4 + q;
         const bool vok = pw < W && ns < s_end;
-        av = vok ? dyb[((long)(4 * nd) * FH + 4 * nh) * FW + 4 * pw] : 0.0f;
+        const long fo = ((long)(4 * nd) * FH + 4 * nh) * FW + 4 * pw;
+#pragma unroll
+        for (int g = 0; g < GS; ++g) av[g] = vok ? dyb[fo + g * gstride] : 0.0f;
         const float* __restrict__ xp = xb + (((long)nd * H + nh) * W + pw) * 16;
         const bool okd[3] = {vok && nd > 0, vok, vok && nd < D - 1};
         const bool okh[3] = {nh > 0, true, nh < H - 1};
@@ -270,33 +278,53 @@ __global__ void __launch_bounds__(256) vx_expand_wgrad_mfma_k(const float* __res
         ++ns;
         if (++nw4 == W4) { nw4 = 0; if (++nh == H) { nh = 0; ++nd; } }
     };
-    float av0, bv0[27], av1, bv1[27];
+    float av0[GS], bv0[27], av1[GS], bv1[27];
     load_step(av0, bv0);
     for (long s = s_begin; s < s_end; s += 2) {
         load_step(av1, bv1);
-        bsum += av0;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[t], acc[t], 0, 0, 0);
+        for (int g = 0; g < GS; ++g) {
+            bsum[g] += av0[g];
+#pragma unroll
+            for (int t = 0; t < 27; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g], bv0[t], acc[g][t], 0, 0, 0);
+        }
         load_step(av0, bv0);
-        bsum += av1;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[t], acc[t], 0, 0, 0);
+        for (int g = 0; g < GS; ++g) {
+            bsum[g] += av1[g];
+#pragma unroll
+            for (int t = 0; t < 27; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[g], bv1[t], acc[g][t], 0, 0, 0);
+        }
     }
-    // D: row = 4q+reg -> co = mt*16 + row, col = ci r.  The 4 waves of the block (same (c,s1) group, different voxel runs) are summed in LDS
-    // in the final [co][ci][t] order, then flushed as CONTIGUOUS float atomics (64 consecutive floats per wave instruction).
-    if (active) {
+    // D: row = 4q+reg -> co = group*16 + row, col = ci r.  The 4 waves of the block (same groups, different voxel runs) are summed in LDS in the
+    // final [co][ci][t] order, one group after the other, then flushed as CONTIGUOUS float atomics (64 consecutive floats per wave instruction).
 #pragma unroll
-        for (int t = 0; t < 27; ++t)
+    for (int g = 0; g < GS; ++g) {
+        // the four waves hold the same (lane -> element) map: they add their tiles into `red` one after the other with plain LDS read-add-write
+        // (scattered ds_add_f32 retire a few lanes per clock: 108 of them per wave cost as much as the 64 k-steps of MFMAs they concluded)
+        for (int wv = 0; wv < 4; ++wv) {
+            __syncthreads();
+            if (wave == wv) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[((4 * q + reg) * 16 + r) * 27 + t], acc[t][reg]);
-    }
-    __syncthreads();
-    float* __restrict__ dwg = dw + (long)mt * 16 * 16 * 27;
-    for (int e = threadIdx.x; e < 16 * 16 * 27; e += 256) atomicAdd(dwg + e, red[e]);
-    if (db != nullptr && active) {
-        bsum += __shfl_xor(bsum, 16, 64);
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (q == 0) atomicAdd(db + mt * 16 + r, bsum);
+                for (int t = 0; t < 27; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        float* __restrict__ e = &red[((4 * q + reg) * 16 + r) * 27 + t];
+                        const float v = active ? acc[g][t][reg] : 0.0f;
+                        *e = (wv == 0) ? v : *e + v;
+                    }
+            }
+        }
+        __syncthreads();
+        const int grp = c * 4 + GS * sp + g;
+        float* __restrict__ dwg = dw + (long)grp * 16 * 16 * 27;
+        for (int e = threadIdx.x; e < 16 * 16 * 27; e += 256) atomicAdd(dwg + e, red[e]);
+        if (db != nullptr && active) {
+            float bs = bsum[g];
+            bs += __shfl_xor(bs, 16, 64);
+            bs += __shfl_xor(bs, 32, 64);
+            if (q == 0) atomicAdd(db + grp * 16 + r, bs);
+        }
     }
 }
 
@@ -307,14 +335,15 @@ extern "C" int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* 
         vx_to_channels_last16_k<<<dim3(vx_cdiv(Vx, 64), B), 256, 0, (hipStream_t)stream>>>(x, xcl_ws, Vx);
     }
     const long nsteps = (long)D * H * ((W + 3) / 4);
-    const int groups = Cc * 4;
-    long waves_per_group = 2048 / groups;
+    constexpr int gs = 2;                            // one wave carries two of the four s1 groups of a channel block
+    const int groups = Cc * 4 / gs;
+    long waves_per_group = 1024 / groups;            // one resident wave per SIMD (508 registers): one round of 1024 waves, the flush amortised over >= 128 k-steps
     if (waves_per_group < 1) waves_per_group = 1;
     long spw = ((long)B * nsteps + waves_per_group - 1) / waves_per_group;
     if (spw < 16) spw = 16;
     const int chunks_per_b = vx_cdiv(nsteps, spw);
     dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), groups);
-    vx_expand_wgrad_mfma_k<<<grid, 256, 0, (hipStream_t)stream>>>(xcl_ws, dy_fine, dw, db, B, Cc, D, H, W, (int)spw, chunks_per_b);
+    vx_expand_wgrad_mfma_k<gs><<<grid, 256, 0, (hipStream_t)stream>>>(xcl_ws, dy_fine, dw, db, B, Cc, D, H, W, (int)spw, chunks_per_b);
     VX_LAUNCH_CHECK("vx_expand_wgrad_mfma");
     return 0;
 }
