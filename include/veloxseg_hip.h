@@ -67,6 +67,9 @@ int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, 
                             int accumulate, void* stream);
 /* A/B knob of the entry above: 1 (default) = LDS-tiled kernel when D%4 == H%4 == W%16 == 0, 0 = every operand straight from global */
 int vx_expand_set_lds(int on);
+/* forward of the same layer (conv 16 -> 64*Cc, k3 p1, PixelShuffle(4) store) as MFMA tiles over an LDS halo; wt_ws: Cout*16*27 floats.
+ * Needs D % 4 == 0, H % 4 == 0, W % 16 == 0: returns 1 (and launches nothing) otherwise -- the caller then uses vx_conv_s1. */
+int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream);
 /* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
  * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
 int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);

@@ -133,7 +133,15 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     }
     if (st.pw && V <= F.pw_mfma_max_v) chk(vx_pw_conv_mfma(fp(x), fp(x2), C1, fp(w), 0, fp(b), mp(y), nullptr, 0, B, Cout, Cin, Cin, V, 0, stream), "vx_pw_conv_mfma");
     else if (st.pw) chk(vx_pw_conv_fwd(fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, Cout, V, stream), "vx_pw_conv_fwd");
-    else if (st.s1) chk(vx_conv_s1(fp(x), fp(w), fp(b), mp(y), B, Cin, Cout, D, H, W, K, G, 0, 1, ps, 0, stream), "vx_conv_s1");
+    else if (st.s1) {
+        int rc = 1;
+        if (ps == 4 && K == 3 && Cin == 16 && G == 1 && Cout % 64 == 0 && F.use_expand_mfma) {       // patch-expand layer: MFMA tiles over an LDS halo
+            Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
+            rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
+            if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
+        }
+        if (rc == 1) chk(vx_conv_s1(fp(x), fp(w), fp(b), mp(y), B, Cin, Cout, D, H, W, K, G, 0, 1, ps, 0, stream), "vx_conv_s1");
+    }
     else chk(vx_conv3d_fwd(fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, D, H, W, Cout, K, S, P, G, ps, stream), "vx_conv3d_fwd");
     st.x = x; st.x2 = x2;
     return y;

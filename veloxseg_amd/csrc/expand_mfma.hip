@@ -212,6 +212,88 @@ extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, flo
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward: y_fine[c][4d+s1][4h+s2][4w+s3] = bias[co] + sum_{ci,t} W[co][ci][t] x[ci][(d,h,w) + t - 1],  co = ((c*4+s1)*4+s2)*4+s3
+//   D tile: rows = the 16 output channels (s2, s3) of one (c, s1) group, cols = 16 coarse voxels along W  ->  lane (r, q) ends with
+//   (s2 = q, s3 = 0..3) of voxel w0 + r = ONE float4 of the fine row 4h+q, and the 16 lanes r write 256 contiguous bytes.
+//   k = (tap t, channel quad j): A[row][k q] = WT[t][co_base+row][4j+q] (tap-major weights, 1 KB contiguous per load),
+//   B[k q][col r] = x[4j+q][voxel r + tap] from the block's LDS halo ([ci][6*6*18 voxels], plane pitch 656 = 16 mod 32 banks: 2 lanes per bank,
+//   the minimum for 64 lanes).  Block = 4 x 4 x 16 coarse tile, wave = d-slice, 4 N-tiles (h rows) per wave share every A operand.
+//   The VALU kernel this replaces (vx_conv_s1_k<3,16>) ran the same 7.2 GFLOP at 29 TFLOP/s.
+// ------------------------------------------------------------------------------------------------------------------
+#define VX_EF_PITCH 656
+__global__ void __launch_bounds__(256) vx_expand_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float vx_xh[];          // [16][VX_EF_PITCH]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const int Cout = Cc * 64;
+    const float* __restrict__ xb = x + (long)b * 16 * V;
+    for (int e = threadIdx.x; e < 16 * 648; e += 256) {                    // halo: 6 x 6 x 18 voxels x 16 channels, zero outside the volume
+        const int hv = e % 648, ci = e / 648;
+        const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+        float v = 0.0f;
+        if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W) v = xb[(long)ci * V + ((long)qd * H + qh) * W + qw];
+        vx_xh[ci * VX_EF_PITCH + hv] = v;
+    }
+    __syncthreads();
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    for (int g = 0; g < Cc * 4; ++g) {                                     // (c, s1) groups
+        const int c = g >> 2, s1 = g & 3;
+        const int co_base = g * 16;
+        vx_f4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 27; ++t) {
+            const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+            const float* __restrict__ wtt = wt + ((long)t * Cout + co_base + r) * 16 + q;
+            const float* __restrict__ xt = vx_xh + q * VX_EF_PITCH + ((wave + td) * 6 + th) * 18 + r + tw;
+            float av[4], bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[j] = wtt[4 * j];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bv[j][m] = xt[4 * j * VX_EF_PITCH + m * 18];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j][m], acc[m], 0, 0, 0);
+        }
+        // D: row 4q+reg = (s2 = q, s3 = reg), col r = voxel w0 + r
+        const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+    }
+}
+
+// returns 1 when the shape is not covered (caller uses the direct convolution), 0 on success
+extern "C" int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cout = Cc * 64;
+    const long nW = (long)Cout * 16 * 27;
+    vx_weight_tap_major_k<<<vx_cdiv(nW, 256), 256, 0, st>>>(w, wt_ws, Cout, 16, 27);
+    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    vx_expand_fwd_mfma_k<<<dim3((unsigned)nblk), 256, 16 * VX_EF_PITCH * sizeof(float), st>>>(x, wt_ws, bias, y, B, Cc, D, H, W);
+    VX_LAUNCH_CHECK("vx_expand_fwd_mfma");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weight gradient: dW[co, ci, t] += sum_{b,p} dyf[co, p] * x[ci, p + t - 1]   (+ db[co] += sum dyf[co, p])
 //   rows = 16 output channels of one (c, s1) group (row r <-> s2 = r>>2, s3 = r&3), cols = 16 input channels, k = 4 coarse voxels along W.
 //   A (fine gradient): lane (r,q) reads fine[c][4d+s1][4h+s2][4(w4+q)+s3]  -> 4 fine rows x 64 contiguous bytes per load;

@@ -288,7 +288,12 @@ class _Conv3dFn(torch.autograd.Function):
         elif pw:
             H.call("vx_pw_conv_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, Cout, D * Hh * W, H.stream_ptr())
         elif s1:
-            H.call("vx_conv_s1", H.P(x), H.P(w), H.P(b), H.P(y), B, Cin, Cout, D, Hh, W, K, G, 0, 1, ps, 0, H.stream_ptr())
+            rc = 1
+            if ps == 4 and K == 3 and Cin == 16 and G == 1 and Cout % 64 == 0 and USE_EXPAND_MFMA:      # patch-expand layer: MFMA tiles over an LDS halo
+                wt = torch.empty((Cout * 16 * 27,), device=x.device, dtype=torch.float32)
+                rc = H.query("vx_expand_fwd_mfma", H.P(x), H.P(w), H.P(b), H.P(wt), H.P(y), B, Cout // 64, D, Hh, W, H.stream_ptr())
+            if rc == 1:
+                H.call("vx_conv_s1", H.P(x), H.P(w), H.P(b), H.P(y), B, Cin, Cout, D, Hh, W, K, G, 0, 1, ps, 0, H.stream_ptr())
         else:
             H.call("vx_conv3d_fwd", H.P(x), H.P(x2), C1, H.P(w), H.P(b), H.P(y), B, Cin, D, Hh, W, Cout, K, S, P, G, ps, H.stream_ptr())
         ctx.pw = pw
