@@ -50,6 +50,11 @@ int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const fl
                                int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
 /* the same with a caller-owned workspace: blocks store partial sums (no float atomics on dw from ~1 k blocks), a second kernel folds them.
  * vx_conv3d_bwd_weight_ws_floats returns the workspace size in floats (0 = the plain entry is the better path, < 0 = error). */
+/* stem DownConv (Conv3d k7 s4 p3, Encoder.py conv-chain stem): weight + bias gradient as fp32-MFMA tiles over an LDS halo; ws from
+ * vx_down_wgrad_ws_floats (0 = shape not covered).  vx_down_wgrad_mfma returns 1 and launches nothing when the shape is not covered. */
+int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout);
+int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                       int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
 int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps);
 int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);

@@ -25,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -197,6 +197,11 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
                 WG.done.push_back([xcl](void*) {});          // keeps the temporary alive as long as the launches of this pass
                 chk(vx_expand_wgrad_mfma(fp(x), mp(*xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, s), "vx_expand_wgrad_mfma");
+            } else if (K == 7 && S == 4 && P == 3 && G == 1 && ps == 1 && !x2.defined() && F.use_down_mfma && vx_down_wgrad_ws_floats(B, Cin, D, H, W, Cout) > 0) {
+                const int nws = vx_down_wgrad_ws_floats(B, Cin, D, H, W, Cout);          // stem DownConv: MFMA tiles + partial-sum slices
+                auto ws = std::make_shared<Tensor>(at::empty({(long)nws}, x.options()));
+                WG.done.push_back([ws](void*) {});
+                chk(vx_down_wgrad_mfma(fp(x), fp(dy), dw, db, mp(*ws), nws, B, Cin, D, H, W, Cout, s), "vx_down_wgrad_mfma");
             } else if (F.use_wgrad_ws) {
                 const int nws = vx_conv3d_bwd_weight_ws_floats(B, Cin, D, H, W, Cout, K, S, P, G, ps);
                 TORCH_CHECK(nws >= 0, "vx_conv3d_bwd_weight_ws_floats failed");
@@ -516,6 +521,7 @@ PYBIND11_MODULE(_vxops, m) {
     });
 
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
+    m.def("set_down_mfma", [](bool on) { F.use_down_mfma = on; });  // A/B: MFMA weight gradient of the k7 s4 stem conv
     m.def("set_fuse_pw_bwd", [](bool on) { F.fuse_pw_bwd = on; });  // A/B: input + weight gradient of small 1x1 convs in one launch      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites
 
     m.def("conv_fwd", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int K, int S, int P, int G, int ps, int64_t stream) {

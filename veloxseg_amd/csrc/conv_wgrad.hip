@@ -80,20 +80,28 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
             __syncthreads();
             {   // element e = ((ci*HD + hd)*HH + hh)*HW + hw for e = tid, tid+256, ...: (hw, hh, hd, ci) advance by the host-decomposed
                 // stride of 256, so the loop body has no integer division (4 per element used to cost as much as the FMA phase)
+                // 4 elements per iteration with UNCONDITIONAL loads (clamped address, value selected afterwards): with a branch around each load
+                // the loop ran one memory latency per element
                 int hw = st_hw0, hh = st_hh0, hd = st_hd0, ci = st_c0;
-                for (int e = threadIdx.x; e < Cin_g * plane; e += 256) {
-                    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-                    float v = 0.0f;
-                    if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
-                        const int c = g * Cin_g + ci;
+                const int total = Cin_g * plane;
+                for (int e = threadIdx.x; e < total; e += 256 * 4) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+                        const bool ok = (e + u * 256 < total) && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                        const int c = ok ? g * Cin_g + ci : g * Cin_g;
                         const float* src = (c < p.C1) ? x + ((long)b * p.C1 + c) * Vi : x2 + ((long)b * (p.Cin - p.C1) + (c - p.C1)) * Vi;
-                        v = src[((long)id * p.Hi + ih) * p.Wi + iw];
+                        const float t_ = src[ok ? ((long)id * p.Hi + ih) * p.Wi + iw : 0];
+                        v[u] = ok ? t_ : 0.0f;
+                        hw += p.st_hw; if (hw >= p.HW) { hw -= p.HW; ++hh; }
+                        hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
+                        hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++ci; }
+                        ci += p.st_c;
                     }
-                    vx_halo[e] = v;
-                    hw += p.st_hw; if (hw >= p.HW) { hw -= p.HW; ++hh; }
-                    hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
-                    hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++ci; }
-                    ci += p.st_c;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e + u * 256 < total) vx_halo[e + u * 256] = v[u];
                 }
             }
             __syncthreads();
@@ -367,6 +375,164 @@ extern "C" int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, in
     return vx_wg_run(x, x2, C1, dy, dw, db, ws, ws_floats, nullptr, false, B, Cin, Di, Hi, Wi, Cout, K, S, P, G, ps, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stem DownConv (Conv3d k7 s4 p3, 1..4 modalities -> 16 channels; reference Encoder.py conv-chain stem): weight gradient as an fp32-MFMA GEMM.
+//   dW[co][n] = sum_{b,q} dy[b,co,q] * patch[b,q][n],   n = (ci, kd, kh, kw),  M = 16 co, N = CB*343 pairs (NT tiles of 16), K = B*Vout voxels.
+// The tiled VALU kernel above needs 0.44 ms for these 2.9 GFLOP (4 % of the fp32 peak: 686 pairs on 1024 thread slots, one LDS read per 8 FMAs
+// with stride-4 addresses).  Here a block stages the x halo of a 1 x 4 x 16 output tile ([CB][7][19][67] floats) in LDS; wave = one output
+// row = 4 k-steps of 4 voxels; per k-step ONE A operand (dy, lane (co r, voxel q)) feeds NT MFMAs whose B operands are LDS gathers at
+// per-lane pair offsets; the NT accumulator tiles stay in registers across the block's tiles; the four waves are then added in LDS (plain
+// phased read-add-write) and stored as one partial slice; vx_wg_reduce_k folds the slices into dw.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float vx_wf4 __attribute__((ext_vector_type(4)));
+#define VX_DW_HD 7
+#define VX_DW_HH 19
+#define VX_DW_HW 67
+#define VX_DW_PLANE (VX_DW_HD * VX_DW_HH * VX_DW_HW)
+template <int NT>
+__global__ void __launch_bounds__(256, 2) vx_down_wgrad_mfma_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                            float* __restrict__ db, int B, int Cin, int Di, int Hi, int Wi, int Cout, int Do, int Ho,
+                                                            int Wo, int CB, int tiles_per_block, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float vx_halo[];          // [CB][7][19][67]; reused as [16][NT*16] for the final reduction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * 16, cib = blockIdx.z * CB;
+    const int npairs = CB * 343;
+    // per-pair LDS offsets in an LDS table behind the halo (43 more live registers would push the kernel past 256 = one wave per SIMD)
+    int* __restrict__ offtab = reinterpret_cast<int*>(vx_halo + ((CB * VX_DW_PLANE + 3) & ~3));
+    for (int n = threadIdx.x; n < NT * 16; n += 256) {
+        const int tap = n % 343, ci = n / 343;
+        const int kw = tap % 7, kh = (tap / 7) % 7, kd = tap / 49;
+        offtab[n] = n < npairs ? ci * VX_DW_PLANE + (kd * VX_DW_HH + kh) * VX_DW_HW + kw : -1;
+    }
+    vx_wf4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (vx_wf4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int nTw = Wo / 16, nTh = Ho / 4;
+    const long Vi = (long)Di * Hi * Wi, Vo = (long)Do * Ho * Wo;
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    for (int t = t_begin; t < t_end; ++t) {
+        int tt = t;
+        const int tw = tt % nTw; tt /= nTw;
+        const int th = tt % nTh; tt /= nTh;
+        const int d = tt % Do;
+        const int b = tt / Do;
+        const int h0 = th * 4, w0 = tw * 16;
+        const int id0 = 4 * d - 3, ih0 = 4 * h0 - 3, iw0 = 4 * w0 - 3;
+        __syncthreads();
+        // halo staging, 8 elements per thread and iteration: the loads are unconditional (clamped address, value selected afterwards) so that all
+        // eight are in flight together -- with a branch around each load the loop ran one memory latency per element (250 of the kernel's 400 us)
+        {
+            const float* __restrict__ xb = x + ((long)b * Cin + cib) * Vi;
+            const int total = CB * VX_DW_PLANE;
+            for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, total - 1);
+                    const int hw = e % VX_DW_HW, row = e / VX_DW_HW;
+                    const int hh = row % VX_DW_HH, r2 = row / VX_DW_HH;
+                    const int hd = r2 % VX_DW_HD, ci = r2 / VX_DW_HD;
+                    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+                    const bool ok = (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+                    const long idx = ok ? (long)ci * Vi + ((long)id * Hi + ih) * Wi + iw : 0;
+                    const float t_ = xb[idx];
+                    v[u] = ok ? t_ : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < total) vx_halo[e0 + u * 256] = v[u];
+            }
+        }
+        __syncthreads();
+        const float* __restrict__ dyr = dy + ((long)b * Cout + co0 + r) * Vo + ((long)d * Ho + h0 + wave) * Wo + w0 + q;
+        float av[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) av[s4] = dyr[4 * s4];
+#pragma unroll 1
+        for (int s4 = 0; s4 < 4; ++s4) {          // not unrolled: 4 x 43 operand prefetches would not fit 256 registers
+            bsum += av[s4];
+            const int base = (4 * wave) * VX_DW_HW + 4 * (4 * s4 + q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int o = offtab[nt * 16 + r];
+                const float bv = o >= 0 ? vx_halo[o + base] : 0.0f;
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // block reduction: D row 4q+reg = co, col r = pair n of tile nt
+    float* __restrict__ red = vx_halo;                                      // [16][NT*16]
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float* __restrict__ e = &red[(4 * q + reg) * (NT * 16) + nt * 16 + r];
+                    *e = (wv == 0) ? acc[nt][reg] : *e + acc[nt][reg];
+                }
+        }
+    }
+    __syncthreads();
+    const long nw = (long)Cout * Cin * 343;
+    float* __restrict__ pd = part + (long)blockIdx.x * nw;
+    for (int e = threadIdx.x; e < 16 * NT * 16; e += 256) {
+        const int co = e / (NT * 16), n = e % (NT * 16);
+        if (n < npairs) pd[((long)(co0 + co) * Cin + cib) * 343 + n] = red[e];
+    }
+    if (db != nullptr && blockIdx.z == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0) atomicAdd(db + co0 + r, bsum);
+    }
+}
+
+static int vx_down_cfg(int B, int Cin, int Di, int Hi, int Wi, int Cout, int& CB, int& Do, int& Ho, int& Wo, int& ntiles, int& tpb, int& nblk) {
+    Do = (Di + 6 - 7) / 4 + 1; Ho = (Hi + 6 - 7) / 4 + 1; Wo = (Wi + 6 - 7) / 4 + 1;
+    if (Cout % 16 != 0 || Wo % 16 != 0 || Ho % 4 != 0 || Do < 1) return 1;
+    CB = (Cin % 2 == 0) ? 2 : 1;
+    if (Cin % CB != 0) return 1;
+    ntiles = B * Do * (Ho / 4) * (Wo / 16);
+    const int per_slice = (Cout / 16) * (Cin / CB);
+    int want = 512 / per_slice;                       // 2 blocks per CU = 2 waves per SIMD (<= 256 registers, 2 x 72 KB of LDS): one stages while the other runs MFMAs
+    if (want < 1) want = 1;
+    tpb = (ntiles + want - 1) / want;
+    if (tpb < 1) tpb = 1;
+    nblk = (ntiles + tpb - 1) / tpb;
+    return 0;
+}
+// workspace floats of vx_down_wgrad_mfma (0: shape not covered -> use vx_conv3d_bwd_weight_tiled)
+extern "C" int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout) {
+    int CB, Do, Ho, Wo, ntiles, tpb, nblk;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || vx_down_cfg(B, Cin, Di, Hi, Wi, Cout, CB, Do, Ho, Wo, ntiles, tpb, nblk)) return 0;
+    const long n = (long)nblk * Cout * Cin * 343;
+    return n > 0x7fffffffL ? 0 : (int)n;
+}
+// Conv3d(k7, s4, p3) weight + bias gradient (dw +=, db += ; db may be NULL).  Returns 1 (nothing launched) when the shape is not covered.
+extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream) {
+    VX_REQUIRE(x && dy && dw && ws && B > 0 && Cin > 0 && Cout > 0, "vx_down_wgrad_mfma: bad args");
+    int CB, Do, Ho, Wo, ntiles, tpb, nblk;
+    if (vx_down_cfg(B, Cin, Di, Hi, Wi, Cout, CB, Do, Ho, Wo, ntiles, tpb, nblk)) return 1;
+    const long nw = (long)Cout * Cin * 343;
+    VX_REQUIRE(ws_floats >= (long)nblk * nw, "vx_down_wgrad_mfma: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = sizeof(float) * ((((size_t)CB * VX_DW_PLANE + 3) & ~(size_t)3) + (size_t)(CB == 2 ? 43 : 22) * 16);
+    dim3 grid(nblk, Cout / 16, Cin / CB);
+    if (CB == 2) vx_down_wgrad_mfma_k<43><<<grid, 256, shm, st>>>(x, dy, ws, db, B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, CB, tpb, ntiles);
+    else vx_down_wgrad_mfma_k<22><<<grid, 256, shm, st>>>(x, dy, ws, db, B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, CB, tpb, ntiles);
+    int sc = nblk / 32;
+    if (sc < 1) sc = 1;
+    if (sc > 32) sc = 32;
+    vx_wg_reduce_k<<<dim3(vx_cdiv(nw, 256), sc), dim3(256), 0, st>>>(ws, dw, nw, nblk);
+    VX_LAUNCH_CHECK("vx_down_wgrad_mfma");
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1x1x1 GROUPED conv (the k = 1 member of the JLC spatial convs, conv_blocks.py:51-58): weight + bias gradient in one pass.

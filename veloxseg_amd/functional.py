@@ -26,6 +26,7 @@ IN_ROW_MAX = 4096
 USE_WGRAD_WS = os.environ.get("VELOXSEG_WGRAD_WS", "0") != "0"   # tiled weight gradient through a partial-sum workspace (deterministic order) instead of float atomics (30 fewer launches per step: +2 %)
 _wgrad_ws = {}
 USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
+USE_DOWN_MFMA = os.environ.get("VELOXSEG_DOWN_MFMA", "1") != "0"   # MFMA weight gradient of the k7 s4 p3 stem conv (False = tiled VALU kernel)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = int(os.environ.get("VELOXSEG_PW_MFMA_MAX_V", "4096"))   # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
 BRANCH_STREAMS = True                         # independent sub-networks (M+1 decoders; encoder conv chain vs PWA chain) run on forked HIP streams
@@ -179,6 +180,7 @@ def cpp_module(reload: bool = False):
                 H.LIB.load()
                 from . import _vxops
                 _vxops.set_fuse_gelu(os.environ.get("VELOXSEG_FUSE_GELU", "1") != "0")
+                _vxops.set_down_mfma(USE_DOWN_MFMA)
                 _vxops.set_fuse_pw_bwd(os.environ.get("VELOXSEG_FUSE_PW_BWD", "1") != "0")
                 _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
                 _CPP[1] = _vxops
@@ -345,6 +347,11 @@ class _Conv3dFn(torch.autograd.Function):
             elif ctx.s1 and ps == 4 and K == 3 and Cin == 16 and G == 1 and USE_EXPAND_MFMA:
                 xcl = torch.empty((B * D * Hh * W * 16,), device=x.device, dtype=torch.float32)
                 H.call("vx_expand_wgrad_mfma", H.P(x), H.P(xcl), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cout // 64, D, Hh, W, st)
+            elif (USE_DOWN_MFMA and K == 7 and S == 4 and P == 3 and G == 1 and ps == 1 and x2 is None
+                  and H.query("vx_down_wgrad_ws_floats", B, Cin, D, Hh, W, Cout) > 0):
+                nws = H.query("vx_down_wgrad_ws_floats", B, Cin, D, Hh, W, Cout)
+                ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
+                H.call("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(grad_buf(w)), H.P(db), H.P(ws), nws, B, Cin, D, Hh, W, Cout, st)
             elif WGRAD_ENTRY == "vx_conv3d_bwd_weight_tiled" and USE_WGRAD_WS:
                 key = (B, Cin, D, Hh, W, Cout, K, S, P, G, ps)
                 nws = _wgrad_ws.get(key)
