@@ -78,16 +78,25 @@ __global__ void __launch_bounds__(256) vx_conv_s1_k(const float* __restrict__ x,
             int hd = t2 % p.HD, cil = t2 / p.HD;
             const long chan_stride = (long)p.D * p.H * p.W;
             const float* __restrict__ xb = x + ((long)b * p.Cin + g * Cin_g + cc) * chan_stride;
-            for (int e = tid; e < ncc * plane; e += 256) {
-                const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
-                float v = 0.0f;
-                if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                    v = xb[cil * chan_stride + ((long)id * p.H + ih) * p.W + iw];
-                xs[e] = v;
-                hw += p.st_hw; if (hw >= p.HWp) { hw -= p.HWp; ++hh; }
-                hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
-                hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++cil; }
-                cil += p.st_c;
+            // 4 elements per iteration, loads unconditional (clamped address, value selected afterwards) so that they are all in flight together:
+            // with a branch around each load the loop paid one memory latency per element
+            const int total = ncc * plane;
+            for (int e = tid; e < total; e += 256 * 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
+                    const bool ok = (e + u * 256 < total) && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    const float t_ = xb[ok ? cil * chan_stride + ((long)id * p.H + ih) * p.W + iw : 0];
+                    v[u] = ok ? t_ : 0.0f;
+                    hw += p.st_hw; if (hw >= p.HWp) { hw -= p.HWp; ++hh; }
+                    hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
+                    hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++cil; }
+                    cil += p.st_c;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e + u * 256 < total) xs[e + u * 256] = v[u];
             }
         } else {
             // pixel-shuffled source: channel fastest (4 consecutive channels = 16 contiguous bytes)

@@ -148,14 +148,24 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_k(const float* __r
         for (int s1 = 0; s1 < 4; ++s1) {
             __syncthreads();
             // stage: 144 rows (hd, hh, s2) x 18 float4
-            for (int e = threadIdx.x; e < 144 * 18; e += 256) {
-                const int f4 = e % 18, row = e / 18;
-                const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
-                const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
-                    v = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw);
-                *reinterpret_cast<float4*>(vx_halo_t + row * 72 + f4 * 4) = v;
+            // 144 * 18 = 2592 float4 = 10.1 per thread: up to 11 unconditional loads in flight per thread (clamped address, value selected afterwards)
+            {
+                float4 v[11];
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+                    const int f4 = e % 18, row = e / 18;
+                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = (int)threadIdx.x + u * 256;
+                    if (e < 144 * 18) *reinterpret_cast<float4*>(vx_halo_t + (e / 18) * 72 + (e % 18) * 4) = v[u];
+                }
             }
             __syncthreads();
             const int co_base = ((c * 4 + s1) * 4) * 4;
@@ -237,13 +247,24 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_k(const float* __restr
     const long V = (long)D * H * W;
     const int Cout = Cc * 64;
     const float* __restrict__ xb = x + (long)b * 16 * V;
-    for (int e = threadIdx.x; e < 16 * 648; e += 256) {                    // halo: 6 x 6 x 18 voxels x 16 channels, zero outside the volume
-        const int hv = e % 648, ci = e / 648;
-        const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
-        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
-        float v = 0.0f;
-        if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W) v = xb[(long)ci * V + ((long)qd * H + qh) * W + qw];
-        vx_xh[ci * VX_EF_PITCH + hv] = v;
+    // halo: 6 x 6 x 18 voxels x 16 channels, zero outside the volume; 8 unconditional loads in flight per thread (clamped address, value selected afterwards)
+    for (int e0 = threadIdx.x; e0 < 16 * 648; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * 256, 16 * 648 - 1);
+            const int hv = e % 648, ci = e / 648;
+            const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+            const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+            const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+            const float t_ = xb[ok ? (long)ci * V + ((long)qd * H + qh) * W + qw : 0];
+            v[u] = ok ? t_ : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            if (e < 16 * 648) vx_xh[(e / 648) * VX_EF_PITCH + (e % 648)] = v[u];
+        }
     }
     __syncthreads();
     const long FH = 4L * H, FW = 4L * W;
