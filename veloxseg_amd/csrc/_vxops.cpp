@@ -25,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -521,6 +521,7 @@ PYBIND11_MODULE(_vxops, m) {
     });
 
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
+    m.def("set_skip_in_bias", [](bool on) { F.skip_in_bias = on; });   // A/B: 0 = compute the (mathematically zero) bias gradients of convs that feed an InstanceNorm
     m.def("set_down_mfma", [](bool on) { F.use_down_mfma = on; });  // A/B: MFMA weight gradient of the k7 s4 stem conv
     m.def("set_fuse_pw_bwd", [](bool on) { F.fuse_pw_bwd = on; });  // A/B: input + weight gradient of small 1x1 convs in one launch      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites
 
@@ -610,16 +611,17 @@ PYBIND11_MODULE(_vxops, m) {
         Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
         Tensor d_o = sum3(do_res, do2, Tensor(), s_);
         const int n = (int)st->convs.size();
-        // short rows: the bias gradients of the spatial convs ride on the one-launch InstanceNorm backward (one atomic per (b,c) row).  Long rows
-        // keep the separate reduction: fused into the per-256-voxel apply blocks it would be thousands of atomics on C addresses.
-        const bool fuse_db = F.use_in_row && st->in1.V <= F.in_row_max;
-        float* dbs[3] = {nullptr, nullptr, nullptr};
-        if (fuse_db)
-            for (int k = 0; k < n; ++k) dbs[k] = st->convs[k].w.requires_grad() ? grad_ptr(st->convs[k].b) : nullptr;
-        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_, fuse_db ? dbs : nullptr, (int)st->convs[0].Cout);
+        // The spatial convs feed an InstanceNorm directly: its backward removes the per-(b, c) mean, so the sum of g[k] over every row -- the bias
+        // gradient -- is zero up to round-off (the reference's value is ~1e-8 noise).  It is not computed: no reduction launch on the long rows,
+        // no per-row atomics on the short ones; the bias entries of the flat gradient stay at the zero they were cleared to.
+        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_);
         // dx = d_o + sum_k conv_k^T(g_k): d_o is this function's own temporary (its last reader was in_bwd above), so the three input gradients
         // are accumulated into it in place by the kernels' `accumulate` mode -- no extra add launches
-        for (int k = 0; k < n; ++k) { Tensor t1, t2; conv_bwd_impl(st->convs[k], g[k], true, t1, t2, s_, d_o, fuse_db); }
+        for (int k = 0; k < n; ++k) {
+            Tensor t1, t2;
+            if (F.skip_in_bias) grad_ptr(st->convs[k].b);         // the (zero) gradient tensor still exists for optimizers that walk p.grad
+            conv_bwd_impl(st->convs[k], g[k], true, t1, t2, s_, d_o, /*skip_bias=*/F.skip_in_bias);
+        }
         st.reset();
         if (!need_x) return py::none();
         return py::cast(d_o);
