@@ -126,6 +126,12 @@ int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const flo
                   int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream);
 /* the two backward entries with the bias gradient of the producing conv fused in: db_k[c] += sum_{b,v} dy_k (NULL = skip); BC = B*C */
 int vx_in_bwd_db(const float* dout, const float* y, const float* stats, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, float* db, int C, void* stream);
+/* the same InstanceNorm-sum on long rows in two launches per direction: one partial-sum launch for all nk inputs, and an apply launch whose
+ * blocks fold their row's partials themselves (no finalisation launches).  part_ws: nk * BC * 32 doubles.  dy_k may be NULL. */
+int vx_in_fwd_split(const float* y0, const float* y1, const float* y2, float* s0, float* s1, float* s2, double* part_ws,
+                    int nk, int act, const float* res, float* out, long BC, long V, float eps, void* stream);
+int vx_in_bwd_split(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                    double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, long BC, long V, void* stream);
 int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                      int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream);
 

@@ -518,3 +518,41 @@ def test_stem_weight_gradient_mfma_equals_tiled_kernel(B, Cin, sp):
     # shapes the tile geometry does not cover: the query says 0 and the entry declines without launching
     assert H.query("vx_down_wgrad_ws_floats", 1, 2, 96, 96, 96, 16) == 0
     assert H.query("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, 1, 2, 96, 96, 96, 16, st) == 1
+
+
+@pytest.mark.parametrize("nk,act,V,BC", [(3, 1, 32768, 8), (1, 0, 8192, 6), (2, 1, 5000, 3)])
+def test_instance_norm_long_rows_two_launch_path_equals_separate_launches(nk, act, V, BC):
+    """vx_in_fwd_split / vx_in_bwd_split (partials of all inputs in one launch, consumers fold them) vs vx_in_stats + vx_in_apply_fwd / vx_in_bwd"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    ys = [(rnd(BC, V, seed=10 + k) * (1.0 + k) + 0.3 * k).to(d) for k in range(nk)]
+    res, dout = rnd(BC, V, seed=5).to(d), rnd(BC, V, seed=6).to(d)
+    st = H.stream_ptr()
+    pad = [None] * (3 - nk)
+    # separate launches
+    stats = [torch.empty(BC * 2, device=d) for _ in range(nk)]
+    for y, s in zip(ys, stats):
+        part = torch.empty(BC * 32, device=d, dtype=torch.float64)
+        H.call("vx_in_stats", H.P(y), H.P(s), H.P(part, torch.float64), BC, V, 1e-5, st)
+    ref = torch.empty(BC, V, device=d)
+    H.call("vx_in_apply_fwd", *([H.P(y) for y in ys] + pad), *([H.P(s) for s in stats] + pad), nk, act, H.P(res), H.P(ref), BC, V, st)
+    rgrads = []
+    for y, s in zip(ys, stats):
+        g, ws, part = torch.empty(BC, V, device=d), torch.empty(BC * 2, device=d), torch.empty(BC * 32, device=d, dtype=torch.float64)
+        H.call("vx_in_bwd", H.P(dout), H.P(y), H.P(s), act, H.P(ws), H.P(part, torch.float64), H.P(g), BC, V, st)
+        rgrads.append(g)
+    # two launches per direction
+    stats2 = [torch.empty(BC * 2, device=d) for _ in range(nk)]
+    part = torch.empty(nk * BC * 32, device=d, dtype=torch.float64)
+    out = torch.empty(BC, V, device=d)
+    H.call("vx_in_fwd_split", *([H.P(y) for y in ys] + pad), *([H.P(s) for s in stats2] + pad), H.P(part, torch.float64), nk, act, H.P(res), H.P(out), BC, V, 1e-5, st)
+    grads = [torch.empty(BC, V, device=d) if k != 1 else None for k in range(nk)]          # input 1 (when present) needs no gradient
+    H.call("vx_in_bwd_split", H.P(dout), *([H.P(y) for y in ys] + pad), *([H.P(s) for s in stats2] + pad), H.P(part, torch.float64), nk, act,
+           *([H.P(g) for g in grads] + pad), BC, V, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    for s2, s in zip(stats2, stats):
+        assert torch.equal(s2, s)
+    for k in range(nk):
+        if grads[k] is not None:
+            assert torch.equal(grads[k], rgrads[k]), k

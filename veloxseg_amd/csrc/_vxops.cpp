@@ -25,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -239,6 +239,12 @@ Tensor in_fwd_impl(INState& st, const Tensor& res, bool act, const std::vector<T
         for (int k = 0; k < n; ++k) st.stats.push_back(sbuf[k]);
         float* sp[3] = {mp(st.stats[0]), n > 1 ? mp(st.stats[1]) : nullptr, n > 2 ? mp(st.stats[2]) : nullptr};
         chk(vx_in_row_fwd(yp[0], yp[1], yp[2], sp[0], sp[1], sp[2], n, st.act, fp(res_c), mp(out), BC, V, (float)F.in_eps, stream), "vx_in_row_fwd");
+    } else if (F.in_split2) {      // long rows: one partial-sum launch for all inputs + one apply launch that folds the partials itself
+        Tensor sbuf = at::empty({n, BC * 2}, st.ys[0].options());
+        for (int k = 0; k < n; ++k) st.stats.push_back(sbuf[k]);
+        Tensor part = at::empty({(long)n * BC * 32}, st.ys[0].options().dtype(at::kDouble));
+        chk(vx_in_fwd_split(yp[0], yp[1], yp[2], mp(st.stats[0]), n > 1 ? mp(st.stats[1]) : nullptr, n > 2 ? mp(st.stats[2]) : nullptr, part.data_ptr<double>(),
+                            n, st.act, fp(res_c), mp(out), BC, V, (float)F.in_eps, stream), "vx_in_fwd_split");
     } else {
         for (int k = 0; k < n; ++k) {
             Tensor s = at::empty({BC * 2}, st.ys[0].options());
@@ -265,6 +271,11 @@ std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::v
                              n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr, n > 2 ? mp(grads[2]) : nullptr,
                              dbs ? dbs[0] : nullptr, (dbs && n > 1) ? dbs[1] : nullptr, (dbs && n > 2) ? dbs[2] : nullptr, C, st.BC, st.V, stream),
             "vx_in_row_bwd_db");
+    } else if (F.in_split2 && !dbs) {
+        Tensor part = at::empty({(long)n * st.BC * 32}, dout.options().dtype(at::kDouble));
+        chk(vx_in_bwd_split(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
+                            n > 2 ? fp(st.stats[2]) : nullptr, part.data_ptr<double>(), n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr,
+                            n > 2 ? mp(grads[2]) : nullptr, st.BC, st.V, stream), "vx_in_bwd_split");
     } else {
         for (int k = 0; k < n; ++k) {
             if (!need[k]) continue;
@@ -521,6 +532,7 @@ PYBIND11_MODULE(_vxops, m) {
     });
 
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
+    m.def("set_in_split2", [](bool on) { F.in_split2 = on; });         // A/B: long-row InstanceNorm in 2 launches per direction (0 = separate stats / finalise / apply launches)
     m.def("set_skip_in_bias", [](bool on) { F.skip_in_bias = on; });   // A/B: 0 = compute the (mathematically zero) bias gradients of convs that feed an InstanceNorm
     m.def("set_down_mfma", [](bool on) { F.use_down_mfma = on; });  // A/B: MFMA weight gradient of the k7 s4 stem conv
     m.def("set_fuse_pw_bwd", [](bool on) { F.fuse_pw_bwd = on; });  // A/B: input + weight gradient of small 1x1 convs in one launch      // A/B: GELU (+ dropout) in the 1x1 conv epilogues of the JLC / FFN composites

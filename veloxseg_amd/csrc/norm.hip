@@ -285,6 +285,112 @@ __global__ void __launch_bounds__(256) vx_s2d2_k(const float* __restrict__ x, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long rows in TWO launches per direction (was 2 nk + 1 forward, 3 nk backward): the partial sums of all nk inputs come from one launch
+// (grid.z = input) and the consumer kernels fold the S partials of their row themselves (S <= 16 doubles per quantity) instead of waiting
+// for a finalisation launch; the forward's first block of every row also stores (mean, rstd) for the backward.
+// ---------------------------------------------------------------------------------------------
+struct VxIn3 { const float* y[3]; float* st[3]; float* dy[3]; };
+
+__global__ void __launch_bounds__(256) vx_in_stats_part3_k(VxIn3 P, double* __restrict__ part, long BC, long V, int S) {
+    const long bc = blockIdx.x;
+    const int sp = blockIdx.y, k = blockIdx.z;
+    const float* __restrict__ row = P.y[k] + bc * V;
+    double s = 0.0, ss = 0.0;
+    for (long v = (long)sp * 256 + threadIdx.x; v < V; v += (long)S * 256) {
+        const double t = (double)row[v];
+        s += t;
+        ss += t * t;
+    }
+    s = vx_wave_sum(s);
+    ss = vx_wave_sum(ss);
+    __shared__ double sm[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm[wid] = s; sm[4 + wid] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* __restrict__ pp = part + (((long)k * BC + bc) * S + sp) * 2;
+        pp[0] = sm[0] + sm[1] + sm[2] + sm[3];
+        pp[1] = sm[4] + sm[5] + sm[6] + sm[7];
+    }
+}
+
+__global__ void __launch_bounds__(256) vx_in_apply_fwd_fin_k(VxIn3 P, const double* __restrict__ part, int S, float eps, int nk, int act,
+                                                             const float* __restrict__ res, float* __restrict__ out, long BC, long V) {
+    __shared__ float ms[6];
+    const long bc = blockIdx.y;
+    if ((int)threadIdx.x < nk) {
+        const int k = threadIdx.x;
+        const double* __restrict__ pp = part + (((long)k * BC + bc) * S) * 2;
+        double s = 0.0, ss = 0.0;
+        for (int j = 0; j < S; ++j) { s += pp[2 * j]; ss += pp[2 * j + 1]; }
+        const double m = s / (double)V;
+        double var = ss / (double)V - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        ms[2 * k] = mean; ms[2 * k + 1] = rstd;
+        if (blockIdx.x == 0) { P.st[k][2 * bc] = mean; P.st[k][2 * bc + 1] = rstd; }
+    }
+    __syncthreads();
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const long i = bc * V + v;
+    float acc = res ? res[i] : 0.0f;
+    for (int k = 0; k < nk; ++k) {
+        const float z = (P.y[k][i] - ms[2 * k]) * ms[2 * k + 1];
+        acc += act ? vx_gelu(z) : z;
+    }
+    out[i] = acc;
+}
+
+__global__ void __launch_bounds__(256) vx_in_bwd_stats_part3_k(const float* __restrict__ dout, VxIn3 P, int act, double* __restrict__ part, long BC, long V, int S) {
+    const long bc = blockIdx.x;
+    const int sp = blockIdx.y, k = blockIdx.z;
+    if (P.dy[k] == nullptr) return;
+    const float mean = P.st[k][2 * bc], rstd = P.st[k][2 * bc + 1];
+    const float* __restrict__ y = P.y[k];
+    double a = 0.0, c = 0.0;
+    for (long v = (long)sp * 256 + threadIdx.x; v < V; v += (long)S * 256) {
+        const long i = bc * V + v;
+        const float z = (y[i] - mean) * rstd;
+        const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
+        a += (double)dz;
+        c += (double)dz * (double)z;
+    }
+    a = vx_wave_sum(a);
+    c = vx_wave_sum(c);
+    __shared__ double sm[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm[wid] = a; sm[4 + wid] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* __restrict__ pp = part + (((long)k * BC + bc) * S + sp) * 2;
+        pp[0] = sm[0] + sm[1] + sm[2] + sm[3];
+        pp[1] = sm[4] + sm[5] + sm[6] + sm[7];
+    }
+}
+
+__global__ void __launch_bounds__(256) vx_in_bwd_apply_fin_k(const float* __restrict__ dout, VxIn3 P, const double* __restrict__ part, int S, int act, long BC, long V) {
+    __shared__ float mm[2];
+    const long bc = blockIdx.y;
+    const int k = blockIdx.z;
+    if (P.dy[k] == nullptr) return;
+    if (threadIdx.x == 0) {
+        const double* __restrict__ pp = part + (((long)k * BC + bc) * S) * 2;
+        double a = 0.0, c = 0.0;
+        for (int j = 0; j < S; ++j) { a += pp[2 * j]; c += pp[2 * j + 1]; }
+        mm[0] = (float)(a / (double)V); mm[1] = (float)(c / (double)V);
+    }
+    __syncthreads();
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const long i = bc * V + v;
+    const float mean = P.st[k][2 * bc], rstd = P.st[k][2 * bc + 1];
+    const float z = (P.y[k][i] - mean) * rstd;
+    const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
+    P.dy[k][i] = rstd * (dz - mm[0] - z * mm[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 
@@ -330,6 +436,31 @@ extern "C" int vx_in_bwd(const float* dout, const float* y, const float* st, int
 extern "C" int vx_in_bwd_db(const float* dout, const float* y, const float* st, int act, float* m_ws, double* part_ws, float* dy, long BC, long V, float* db, int C,
                             void* stream) {
     return vx_in_bwd_run(dout, y, st, act, m_ws, part_ws, dy, BC, V, db, C, stream);
+}
+
+// Long-row InstanceNorm-sum in two launches.  part_ws: nk * BC * 16 * 2 doubles.  st_k receive (mean, rstd) per row for the backward.
+extern "C" int vx_in_fwd_split(const float* y0, const float* y1, const float* y2, float* s0, float* s1, float* s2, double* part_ws,
+                               int nk, int act, const float* res, float* out, long BC, long V, float eps, void* stream) {
+    VX_REQUIRE(nk >= 1 && nk <= 3 && y0 && s0 && out && part_ws && (nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)) && BC > 0 && V > 1, "vx_in_fwd_split: bad args");
+    const int S = vx_in_split(BC, V);
+    VxIn3 P; P.y[0] = y0; P.y[1] = y1; P.y[2] = y2; P.st[0] = s0; P.st[1] = s1; P.st[2] = s2; P.dy[0] = P.dy[1] = P.dy[2] = nullptr;
+    hipLaunchKernelGGL(vx_in_stats_part3_k, dim3((unsigned)BC, S, nk), dim3(256), 0, (hipStream_t)stream, P, part_ws, BC, V, S);
+    hipLaunchKernelGGL(vx_in_apply_fwd_fin_k, dim3(vx_cdiv(V, 256), (unsigned)BC), dim3(256), 0, (hipStream_t)stream, P, (const double*)part_ws, S, eps, nk, act, res, out, BC, V);
+    VX_LAUNCH_CHECK("vx_in_fwd_split");
+    return 0;
+}
+// backward of the same: dy_k may be NULL (no gradient needed for that input)
+extern "C" int vx_in_bwd_split(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
+                               double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, long BC, long V, void* stream) {
+    VX_REQUIRE(nk >= 1 && nk <= 3 && dout && y0 && s0 && part_ws && (nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)) && BC > 0 && V > 1, "vx_in_bwd_split: bad args");
+    if (!dy0 && !dy1 && !dy2) return 0;
+    const int S = vx_in_split(BC, V);
+    VxIn3 P; P.y[0] = y0; P.y[1] = y1; P.y[2] = y2; P.st[0] = const_cast<float*>(s0); P.st[1] = const_cast<float*>(s1); P.st[2] = const_cast<float*>(s2);
+    P.dy[0] = dy0; P.dy[1] = nk > 1 ? dy1 : nullptr; P.dy[2] = nk > 2 ? dy2 : nullptr;
+    hipLaunchKernelGGL(vx_in_bwd_stats_part3_k, dim3((unsigned)BC, S, nk), dim3(256), 0, (hipStream_t)stream, dout, P, act, part_ws, BC, V, S);
+    hipLaunchKernelGGL(vx_in_bwd_apply_fin_k, dim3(vx_cdiv(V, 256), (unsigned)BC, nk), dim3(256), 0, (hipStream_t)stream, dout, P, (const double*)part_ws, S, act, BC, V);
+    VX_LAUNCH_CHECK("vx_in_bwd_split");
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
