@@ -103,6 +103,9 @@ int vx_pw_conv_gelu_fwd(const float* x, const float* w, const float* bias, float
                         const void* seed_ptr, unsigned long long dstream, float p, void* stream);
 int vx_pw_conv_gelu_bwd_data(const float* dy, const float* w, const float* a, float* da, int B, int Cin, int Cout, long V, int mfma,
                              const void* seed_ptr, unsigned long long dstream, float p, void* stream);
+/* out = alpha * res + drop(W x + bias): residual + dropout (vx_axpy_drop_fwd's mask) in the epilogue of the 1x1 conv that feeds it; res != out */
+int vx_pw_conv_res_fwd(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int Cout, long V, int mfma,
+                       float alpha, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
 /* A/B knob: 1 (default) = 16 x 64 tiles with 16-byte operand loads when V % 4 == 0, 0 = 16 x 16 tiles */
 int vx_pw_mfma_set_wide(int on);
 
@@ -131,14 +134,17 @@ int vx_in_bwd_db(const float* dout, const float* y, const float* stats, int act,
 int vx_in_fwd_split(const float* y0, const float* y1, const float* y2, float* s0, float* s1, float* s2, double* part_ws,
                     int nk, int act, const float* res, float* out, long BC, long V, float eps, void* stream);
 int vx_in_bwd_split(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
-                    double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, long BC, long V, void* stream);
+                    double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, const float* add0, long BC, long V, void* stream);   /* add0 (optional): dy0 = add0 + gradient */
+int vx_in_row_bwd_add(const float* dout, const float* y0, const float* stats0, int act, const float* add0, float* d0, long BC, long V, void* stream);   /* short rows, single input: d0 = add0 + gradient */
 int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                      int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream);
 
 /* channels-first LayerNorm over C per voxel, biased variance (attention_utils.py:29-43) */
 int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream);
 int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
-                 int B, int C, long V, float eps, void* stream);   /* dgamma/dbeta: += ; ws = 2*B*V floats of workspace */
+                 int B, int C, long V, float eps, void* stream);
+int vx_ln_cf_bwd_add(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* dgamma, float* dbeta, float* ws,
+                     int B, int C, long V, float eps, void* stream);   /* dx = add + LayerNorm backward (add != dx) */   /* dgamma/dbeta: += ; ws = 2*B*V floats of workspace */
 
 /* element-wise pieces: h = drop(gelu(a)) (attention_utils.py:64-66, conv_blocks.py:66); out = alpha*x + drop(z)
  * (PWA.py:377 + :436 double residual, attention_utils.py:68-70, conv_blocks.py:69,74, Encoder.py:196) */

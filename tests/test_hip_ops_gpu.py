@@ -548,7 +548,7 @@ def test_instance_norm_long_rows_two_launch_path_equals_separate_launches(nk, ac
     H.call("vx_in_fwd_split", *([H.P(y) for y in ys] + pad), *([H.P(s) for s in stats2] + pad), H.P(part, torch.float64), nk, act, H.P(res), H.P(out), BC, V, 1e-5, st)
     grads = [torch.empty(BC, V, device=d) if k != 1 else None for k in range(nk)]          # input 1 (when present) needs no gradient
     H.call("vx_in_bwd_split", H.P(dout), *([H.P(y) for y in ys] + pad), *([H.P(s) for s in stats2] + pad), H.P(part, torch.float64), nk, act,
-           *([H.P(g) for g in grads] + pad), BC, V, st)
+           *([H.P(g) for g in grads] + pad), None, BC, V, st)
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     for s2, s in zip(stats2, stats):

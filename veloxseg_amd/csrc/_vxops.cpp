@@ -25,7 +25,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true;
+    bool use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -259,14 +259,21 @@ Tensor in_fwd_impl(INState& st, const Tensor& res, bool act, const std::vector<T
 }
 
 // grads[k] defined for every k with need[k]; the residual gradient is dout itself
-std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::vector<bool>& need, void* stream, float* const* dbs = nullptr, int C = 1) {
+inline Tensor sum3(const Tensor& a, const Tensor& b, const Tensor& c, void* stream);
+// add0 (optional, single-input norms only): grads[0] = add0 + gradient (the sum with a residual-branch gradient of the same tensor, in the kernel's store)
+std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::vector<bool>& need, void* stream, float* const* dbs = nullptr, int C = 1,
+                                const Tensor& add0 = Tensor()) {
     Tensor dout = contig(dout_in);
+    Tensor addc = add0.defined() ? contig(add0) : Tensor();
+    TORCH_CHECK(!addc.defined() || (st.n == 1 && !dbs), "in_bwd_impl: add0 only for single-input norms");
     const int n = st.n;
     std::vector<Tensor> grads(n);
     bool any = false;
     for (int k = 0; k < n; ++k) if (need[k]) { grads[k] = at::empty_like(st.ys[k]); any = true; }
     if (!any) return grads;
-    if (F.use_in_row && st.V <= F.in_row_max) {
+    if (addc.defined() && F.use_in_row && st.V <= F.in_row_max) {
+        chk(vx_in_row_bwd_add(fp(dout), fp(st.ys[0]), fp(st.stats[0]), st.act, fp(addc), mp(grads[0]), st.BC, st.V, stream), "vx_in_row_bwd_add");
+    } else if (F.use_in_row && st.V <= F.in_row_max) {
         chk(vx_in_row_bwd_db(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
                              n > 2 ? fp(st.stats[2]) : nullptr, n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr, n > 2 ? mp(grads[2]) : nullptr,
                              dbs ? dbs[0] : nullptr, (dbs && n > 1) ? dbs[1] : nullptr, (dbs && n > 2) ? dbs[2] : nullptr, C, st.BC, st.V, stream),
@@ -275,7 +282,7 @@ std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::v
         Tensor part = at::empty({(long)n * st.BC * 32}, dout.options().dtype(at::kDouble));
         chk(vx_in_bwd_split(fp(dout), fp(st.ys[0]), n > 1 ? fp(st.ys[1]) : nullptr, n > 2 ? fp(st.ys[2]) : nullptr, fp(st.stats[0]), n > 1 ? fp(st.stats[1]) : nullptr,
                             n > 2 ? fp(st.stats[2]) : nullptr, part.data_ptr<double>(), n, st.act, mp(grads[0]), n > 1 ? mp(grads[1]) : nullptr,
-                            n > 2 ? mp(grads[2]) : nullptr, st.BC, st.V, stream), "vx_in_bwd_split");
+                            n > 2 ? mp(grads[2]) : nullptr, fp(addc), st.BC, st.V, stream), "vx_in_bwd_split");
     } else {
         for (int k = 0; k < n; ++k) {
             if (!need[k]) continue;
@@ -284,6 +291,7 @@ std::vector<Tensor> in_bwd_impl(INState& st, const Tensor& dout_in, const std::v
             chk(vx_in_bwd_db(fp(dout), fp(st.ys[k]), fp(st.stats[k]), st.act, mp(ws), part.data_ptr<double>(), mp(grads[k]), st.BC, st.V, dbs ? dbs[k] : nullptr, C, stream),
                 "vx_in_bwd_db");
         }
+        if (addc.defined()) grads[0] = sum3(addc, grads[0], Tensor(), stream);
     }
     return grads;
 }
@@ -299,13 +307,16 @@ Tensor ln_fwd_impl(LNState& st, const Tensor& x_in, const Tensor& g, const Tenso
     chk(vx_ln_cf_fwd(fp(st.x), fp(g), fp(bt), mp(out), B, C, st.x.numel() / ((long)B * C), (float)F.ln_eps, stream), "vx_ln_cf_fwd");
     return out;
 }
-Tensor ln_bwd_impl(LNState& st, const Tensor& dout_in, void* stream) {
+Tensor ln_bwd_impl(LNState& st, const Tensor& dout_in, void* stream, const Tensor& add = Tensor()) {
     Tensor dout = contig(dout_in);
     const int B = st.x.size(0), C = st.x.size(1);
     const long V = st.x.numel() / ((long)B * C);
     Tensor dx = at::empty_like(st.x);
     Tensor ws = at::empty({2 * (long)B * V}, st.x.options());
-    chk(vx_ln_cf_bwd(fp(st.x), fp(st.g), fp(dout), mp(dx), grad_ptr(st.g), grad_ptr(st.bt), mp(ws), B, C, V, (float)F.ln_eps, stream), "vx_ln_cf_bwd");
+    if (add.defined()) {
+        Tensor addc = contig(add);
+        chk(vx_ln_cf_bwd_add(fp(st.x), fp(st.g), fp(dout), fp(addc), mp(dx), grad_ptr(st.g), grad_ptr(st.bt), mp(ws), B, C, V, (float)F.ln_eps, stream), "vx_ln_cf_bwd_add");
+    } else chk(vx_ln_cf_bwd(fp(st.x), fp(st.g), fp(dout), mp(dx), grad_ptr(st.g), grad_ptr(st.bt), mp(ws), B, C, V, (float)F.ln_eps, stream), "vx_ln_cf_bwd");
     return dx;
 }
 
@@ -364,6 +375,24 @@ Tensor axpy_fwd_impl(AxpyState& st, const Tensor& x, const Tensor& z_in, double 
     chk(vx_axpy_drop_fwd(fp(xc), fp(z), mp(out), (float)alpha, z.numel(), st.rs, (unsigned long long)site, (float)p, stream), "vx_axpy_drop_fwd");
     return out;
 }
+// out = alpha * res + drop(conv1x1(x)) in one launch (residual + dropout in the conv epilogue); fills the ConvState / AxpyState of the two operators
+Tensor pw_res_fwd_impl(ConvState& c, AxpyState& r, const Tensor& x_in, const Tensor& w, const Tensor& b, const Tensor& res_in, double alpha, double p, int64_t site,
+                       const void* rs, void* stream) {
+    check_in(x_in, "conv3d");
+    Tensor x = contig(x_in), res = contig(res_in);
+    const int B = x.size(0), Cin = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4), Cout = w.size(0);
+    const long V = (long)D * H * W;
+    c.x = x; c.x2 = Tensor(); c.w = w; c.b = b;
+    c.B = B; c.C1 = Cin; c.Cin = Cin; c.D = D; c.H = H; c.W = W; c.Cout = Cout; c.K = 1; c.S = 1; c.P = 0; c.G = 1; c.ps = 1;
+    c.pw = true; c.s1 = false; c.patch = false;
+    r.alpha = alpha; r.p = p; r.site = site; r.rs = p > 0 ? rs : nullptr; r.has_x = true;
+    Tensor out = at::empty({B, Cout, D, H, W}, x.options());
+    TORCH_CHECK(res.numel() == out.numel(), "residual shape does not match the conv output");
+    chk(vx_pw_conv_res_fwd(fp(x), fp(w), fp(b), fp(res), mp(out), B, Cin, Cout, V, V <= F.pw_mfma_max_v ? 1 : 0, (float)alpha, r.rs, (unsigned long long)site, (float)p,
+                           stream), "vx_pw_conv_res_fwd");
+    return out;
+}
+
 // -> (dx or undefined, dz)
 void axpy_bwd_impl(AxpyState& st, const Tensor& dout_in, bool need_x_in, Tensor& dx, Tensor& dz, void* stream) {
     Tensor dout = contig(dout_in);
@@ -532,6 +561,8 @@ PYBIND11_MODULE(_vxops, m) {
     });
 
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
+    m.def("set_fuse_bwd_add", [](bool on) { F.fuse_bwd_add = on; });   // A/B: residual-gradient sums in the stores of the InstanceNorm / LayerNorm backward kernels
+    m.def("set_fuse_res", [](bool on) { F.fuse_res = on; });           // A/B: residual + dropout in the epilogue of the second 1x1 conv of the JLC / FFN stage
     m.def("set_in_split2", [](bool on) { F.in_split2 = on; });         // A/B: long-row InstanceNorm in 2 launches per direction (0 = separate stats / finalise / apply launches)
     m.def("set_skip_in_bias", [](bool on) { F.skip_in_bias = on; });   // A/B: 0 = compute the (mathematically zero) bias gradients of convs that feed an InstanceNorm
     m.def("set_down_mfma", [](bool on) { F.use_down_mfma = on; });  // A/B: MFMA weight gradient of the k7 s4 stem conv
@@ -606,8 +637,12 @@ PYBIND11_MODULE(_vxops, m) {
             Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
             h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
         }
-        Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
-        Tensor out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
+        Tensor out;
+        if (F.fuse_res && pw_gelu_fusable(h, l2w)) out = pw_res_fwd_impl(st->c2, st->r, h, l2w, l2b, o, 1.0, p, site, sp(rs), s_);
+        else {
+            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
+            out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
+        }
         return py::make_tuple(out, st);
     });
     m.def("jlc_bwd", [](std::shared_ptr<JLCState> st, const Tensor& dout, bool need_x, int64_t stream) -> py::object {
@@ -620,8 +655,12 @@ PYBIND11_MODULE(_vxops, m) {
             da = gelu_bwd_impl(st->g, dh, s_);
         }
         conv_bwd_impl(st->c1, da, true, dn, dn2, s_);
-        Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
-        Tensor d_o = sum3(do_res, do2, Tensor(), s_);
+        Tensor d_o;                                            // = do_res + InstanceNorm backward of the channel stage's input
+        if (F.fuse_bwd_add) d_o = in_bwd_impl(st->in2, dn, {true}, s_, nullptr, 1, do_res)[0];
+        else {
+            Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
+            d_o = sum3(do_res, do2, Tensor(), s_);
+        }
         const int n = (int)st->convs.size();
         // The spatial convs feed an InstanceNorm directly: its backward removes the per-(b, c) mean, so the sum of g[k] over every row -- the bias
         // gradient -- is zero up to round-off (the reference's value is ~1e-8 noise).  It is not computed: no reduction launch on the long rows,
@@ -652,8 +691,12 @@ PYBIND11_MODULE(_vxops, m) {
             Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
             h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
         }
-        Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
-        Tensor out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
+        Tensor out;
+        if (F.fuse_res && pw_gelu_fusable(h, w2)) out = pw_res_fwd_impl(st->c2, st->r, h, w2, b2, y, 1.0, p, site2, sp(rs), s_);
+        else {
+            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
+            out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
+        }
         return py::make_tuple(out, st);
     });
     m.def("ffn_bwd", [](std::shared_ptr<FFNState> st, const Tensor& dout, int64_t stream) {
@@ -667,6 +710,7 @@ PYBIND11_MODULE(_vxops, m) {
             da = gelu_bwd_impl(st->g, dh, s_);
         }
         conv_bwd_impl(st->c1, da, true, dn, t3, s_);
+        if (F.fuse_bwd_add) return ln_bwd_impl(st->ln, dn, s_, dy_res);      // dy_res + LayerNorm backward in one store
         Tensor dy_ln = ln_bwd_impl(st->ln, dn, s_);
         return sum3(dy_res, dy_ln, Tensor(), s_);
     });

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) vx_ln_cf_fwd_k(const float* __restrict__ 
 
 // dx = r*(g - mean_c(g) - xhat*mean_c(g*xhat)), g = dout*gamma; per-voxel (mean, rstd) are saved to ws for the parameter pass
 __global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dout,
-                                                      float* __restrict__ dx, float* __restrict__ ws, int C, long V, float eps) {
+                                                      float* __restrict__ dx, float* __restrict__ ws, int C, long V, float eps, const float* __restrict__ add) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const long base = (long)blockIdx.y * C * V + v;
@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(256) vx_ln_cf_bwd_k(const float* __restrict__ 
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const float xh = (xb[(long)c * V] - u) * r;
-        dx[base + (long)c * V] = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
+        const float o = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
+        dx[base + (long)c * V] = add ? add[base + (long)c * V] + o : o;
     }
     ws[2 * ((long)blockIdx.y * V + v)] = u;
     ws[2 * ((long)blockIdx.y * V + v) + 1] = r;
@@ -369,7 +370,8 @@ __global__ void __launch_bounds__(256) vx_in_bwd_stats_part3_k(const float* __re
     }
 }
 
-__global__ void __launch_bounds__(256) vx_in_bwd_apply_fin_k(const float* __restrict__ dout, VxIn3 P, const double* __restrict__ part, int S, int act, long BC, long V) {
+__global__ void __launch_bounds__(256) vx_in_bwd_apply_fin_k(const float* __restrict__ dout, VxIn3 P, const double* __restrict__ part, int S, int act, long BC, long V,
+                                                             const float* __restrict__ add0) {
     __shared__ float mm[2];
     const long bc = blockIdx.y;
     const int k = blockIdx.z;
@@ -387,7 +389,8 @@ __global__ void __launch_bounds__(256) vx_in_bwd_apply_fin_k(const float* __rest
     const float mean = P.st[k][2 * bc], rstd = P.st[k][2 * bc + 1];
     const float z = (P.y[k][i] - mean) * rstd;
     const float dz = act ? dout[i] * vx_gelu_grad(z) : dout[i];
-    P.dy[k][i] = rstd * (dz - mm[0] - z * mm[1]);
+    const float o = rstd * (dz - mm[0] - z * mm[1]);
+    P.dy[k][i] = (k == 0 && add0) ? add0[i] + o : o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,14 +454,15 @@ extern "C" int vx_in_fwd_split(const float* y0, const float* y1, const float* y2
 }
 // backward of the same: dy_k may be NULL (no gradient needed for that input)
 extern "C" int vx_in_bwd_split(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
-                               double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, long BC, long V, void* stream) {
+                               double* part_ws, int nk, int act, float* dy0, float* dy1, float* dy2, const float* add0, long BC, long V, void* stream) {
+    VX_REQUIRE(add0 == nullptr || (dy0 && add0 != dy0), "vx_in_bwd_split: add0 needs a distinct dy0");
     VX_REQUIRE(nk >= 1 && nk <= 3 && dout && y0 && s0 && part_ws && (nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)) && BC > 0 && V > 1, "vx_in_bwd_split: bad args");
     if (!dy0 && !dy1 && !dy2) return 0;
     const int S = vx_in_split(BC, V);
     VxIn3 P; P.y[0] = y0; P.y[1] = y1; P.y[2] = y2; P.st[0] = const_cast<float*>(s0); P.st[1] = const_cast<float*>(s1); P.st[2] = const_cast<float*>(s2);
     P.dy[0] = dy0; P.dy[1] = nk > 1 ? dy1 : nullptr; P.dy[2] = nk > 2 ? dy2 : nullptr;
     hipLaunchKernelGGL(vx_in_bwd_stats_part3_k, dim3((unsigned)BC, S, nk), dim3(256), 0, (hipStream_t)stream, dout, P, act, part_ws, BC, V, S);
-    hipLaunchKernelGGL(vx_in_bwd_apply_fin_k, dim3(vx_cdiv(V, 256), (unsigned)BC, nk), dim3(256), 0, (hipStream_t)stream, dout, P, (const double*)part_ws, S, act, BC, V);
+    hipLaunchKernelGGL(vx_in_bwd_apply_fin_k, dim3(vx_cdiv(V, 256), (unsigned)BC, nk), dim3(256), 0, (hipStream_t)stream, dout, P, (const double*)part_ws, S, act, BC, V, add0);
     VX_LAUNCH_CHECK("vx_in_bwd_split");
     return 0;
 }
@@ -511,9 +515,11 @@ __global__ void __launch_bounds__(256) vx_ln_cf_lanes_k(const float* __restrict_
         s2 = vx_sum16(s2) / (float)C;
         if (live) {
             float* __restrict__ ob = out + b * C * V + v;
+            const float* __restrict__ ab = beta ? beta + b * C * V + v : nullptr;      // backward: `beta` carries the optional gradient to add (same layout as out)
             for (int c = sub; c < C; c += 16) {
                 const float xh = (xb[(long)c * V] - u) * r;
-                ob[(long)c * V] = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
+                const float o = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
+                ob[(long)c * V] = ab ? ab[(long)c * V] + o : o;
             }
             if (sub == 0) { ws[2 * vv] = u; ws[2 * vv + 1] = r; }
         }
@@ -533,18 +539,28 @@ extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* bet
     return 0;
 }
 
-extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
+static int vx_ln_cf_bwd_run(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* dgamma, float* dbeta, float* ws,
                             int B, int C, long V, float eps, void* stream) {
-    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta && ws, "vx_ln_cf_bwd: null pointer");
+    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta && ws && add != dx, "vx_ln_cf_bwd: bad pointers");
     if (vx_ln_use_lanes(B, C, V))
-        vx_ln_cf_lanes_k<true><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, nullptr, dout, dx, ws, C, V, (long)B * V, eps);
+        vx_ln_cf_lanes_k<true><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, add, dout, dx, ws, C, V, (long)B * V, eps);
     else
-        hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps);
+        hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps, add);
     int chunks = vx_cdiv((long)B * V, 256 * 8);
     if (chunks > 64) chunks = 64;
     hipLaunchKernelGGL(vx_ln_cf_bwd_param_k, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, x, dout, ws, dgamma, dbeta, B, C, V);
     VX_LAUNCH_CHECK("vx_ln_cf_bwd");
     return 0;
+}
+extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
+                            int B, int C, long V, float eps, void* stream) {
+    return vx_ln_cf_bwd_run(x, gamma, dout, nullptr, dx, dgamma, dbeta, ws, B, C, V, eps, stream);
+}
+// dx = add + LayerNorm backward: the sum with the residual-branch gradient of the same tensor in the kernel's store
+extern "C" int vx_ln_cf_bwd_add(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* dgamma, float* dbeta, float* ws,
+                                int B, int C, long V, float eps, void* stream) {
+    VX_REQUIRE(add, "vx_ln_cf_bwd_add: add is null");
+    return vx_ln_cf_bwd_run(x, gamma, dout, add, dx, dgamma, dbeta, ws, B, C, V, eps, stream);
 }
 
 extern "C" int vx_gelu_drop_fwd(const float* a, float* h, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
@@ -704,7 +720,8 @@ __global__ void __launch_bounds__(256) vx_in_row_fwd_k(const float* __restrict__
 __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__ dout, const float* __restrict__ y0, const float* __restrict__ y1,
                                                        const float* __restrict__ y2, const float* __restrict__ s0, const float* __restrict__ s1,
                                                        const float* __restrict__ s2, int nk, int act, float* __restrict__ d0, float* __restrict__ d1,
-                                                       float* __restrict__ d2, int V, float* __restrict__ b0, float* __restrict__ b1, float* __restrict__ b2, int C) {
+                                                       float* __restrict__ d2, int V, float* __restrict__ b0, float* __restrict__ b1, float* __restrict__ b2, int C,
+                                                       const float* __restrict__ add0) {
     __shared__ double sm[8];
     __shared__ float smf[4];
     const long bc = blockIdx.x;
@@ -736,13 +753,26 @@ __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int v = r * 256 + threadIdx.x;
-            if (v < V) { const float o = rstd * (dz[r] - m1 - z[r] * m2); ds[k][bc * V + v] = o; osum += o; }
+            if (v < V) {
+                const float o = rstd * (dz[r] - m1 - z[r] * m2);
+                ds[k][bc * V + v] = (k == 0 && add0) ? add0[bc * V + v] + o : o;        // add0: another gradient of the same tensor (residual branch), summed here
+                osum += o;
+            }
         }
         if (dbs[k] != nullptr) {              // bias gradient of the producing conv (see vx_in_bwd_apply_k)
             const float s_ = vx_block_sum_256(osum, smf);
             if (threadIdx.x == 0) atomicAdd(dbs[k] + (int)(bc % C), s_);
         }
     }
+}
+
+// d0 = add0 + InstanceNorm backward (single input): folds the add of a residual-branch gradient into the row kernel
+extern "C" int vx_in_row_bwd_add(const float* dout, const float* y0, const float* s0, int act, const float* add0, float* d0, long BC, long V, void* stream) {
+    VX_REQUIRE(dout && y0 && s0 && add0 && d0 && add0 != d0 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd_add: bad args");
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, nullptr, nullptr, s0, nullptr, nullptr, 1, act, d0, nullptr, nullptr, (int)V, nullptr,
+                                                                                nullptr, nullptr, 1, add0);
+    VX_LAUNCH_CHECK("vx_in_row_bwd_add");
+    return 0;
 }
 
 extern "C" int vx_in_row_max(void) { return VX_IN_ROW_MAX; }
@@ -761,14 +791,14 @@ extern "C" int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, 
 extern "C" int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                              int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, nullptr, nullptr, nullptr, 1);
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, nullptr, nullptr, nullptr, 1, nullptr);
     VX_LAUNCH_CHECK("vx_in_row_bwd");
     return 0;
 }
 extern "C" int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                                 int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX && C > 0 && BC % C == 0, "vx_in_row_bwd_db: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, db0, db1, db2, C);
+    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, db0, db1, db2, C, nullptr);
     VX_LAUNCH_CHECK("vx_in_row_bwd_db");
     return 0;
 }

@@ -26,13 +26,15 @@ struct VxPwEpi {
     int mode;
     float* aux;
     VxDrop drop;
+    float alpha;
 };
 __device__ __forceinline__ float vx_pw_epi(const VxPwEpi& e, float val, long idx) {
     if (e.mode == 1) { e.aux[idx] = val; return vx_gelu(val) * vx_drop(e.drop, (uint64_t)idx); }
     if (e.mode == 2) return val * vx_drop(e.drop, (uint64_t)idx) * vx_gelu_grad(e.aux[idx]);
+    if (e.mode == 3) return fmaf(e.alpha, e.aux[idx], val * vx_drop(e.drop, (uint64_t)idx));       // residual: alpha * res + drop(conv)
     return val;
 }
-static inline VxPwEpi vx_no_epi() { VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; return e; }
+static inline VxPwEpi vx_no_epi() { VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; e.alpha = 1.0f; return e; }
 
 // y[b,co,v] = bias[co] + sum_ci w[co,ci] * x[b,ci,v]          (Cin % 4 == 0)
 template <int COT>
@@ -518,8 +520,13 @@ __device__ __forceinline__ void vx_pw_mfma4_body(const int vbx, const int vby, c
             if (epi.mode) {                                   // D1 == Mch
                 const long idx = ((long)b * Mch + m) * V + v_b;
                 if (epi.mode == 1) *reinterpret_cast<float4*>(epi.aux + idx) = o;
-                const float4 ax = epi.mode == 2 ? *reinterpret_cast<const float4*>(epi.aux + idx) : o;
-                if (epi.mode == 1) {
+                const float4 ax = epi.mode >= 2 ? *reinterpret_cast<const float4*>(epi.aux + idx) : o;
+                if (epi.mode == 3) {
+                    o.x = fmaf(epi.alpha, ax.x, o.x * vx_drop(epi.drop, (uint64_t)idx));
+                    o.y = fmaf(epi.alpha, ax.y, o.y * vx_drop(epi.drop, (uint64_t)idx + 1));
+                    o.z = fmaf(epi.alpha, ax.z, o.z * vx_drop(epi.drop, (uint64_t)idx + 2));
+                    o.w = fmaf(epi.alpha, ax.w, o.w * vx_drop(epi.drop, (uint64_t)idx + 3));
+                } else if (epi.mode == 1) {
                     o.x = vx_gelu(ax.x) * vx_drop(epi.drop, (uint64_t)idx);
                     o.y = vx_gelu(ax.y) * vx_drop(epi.drop, (uint64_t)idx + 1);
                     o.z = vx_gelu(ax.z) * vx_drop(epi.drop, (uint64_t)idx + 2);
@@ -587,7 +594,7 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_fused_k(const float* __restrict
                                                          int vox_per_wave, int chunks_per_b, int n_ci_tiles, int gx2) {
     const int id = blockIdx.x;
     if (id < n1) {
-        VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f;
+        VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; e.alpha = 1.0f;
         vx_pw_mfma4_body(id % gx1, id / gx1, dy, nullptr, Cout, w, 1, Cin, nullptr, dx, dx2, C1, Cin, Cout, V, B, n_vt, accumulate, ksplit, e);
     } else {
         const int j = id - n1;
@@ -628,7 +635,7 @@ extern "C" int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float
 extern "C" int vx_pw_conv_gelu_fwd(const float* x, const float* w, const float* bias, float* a, float* h, int B, int Cin, int Cout, long V, int mfma,
                                    const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
     VX_REQUIRE(x && w && a && h && a != h, "vx_pw_conv_gelu_fwd: bad args");
-    VxPwEpi e; e.mode = 1; e.aux = a; e.drop = vx_mk_drop(seed_ptr, dstream, p);
+    VxPwEpi e; e.mode = 1; e.aux = a; e.drop = vx_mk_drop(seed_ptr, dstream, p); e.alpha = 1.0f;
     if (mfma) return vx_pw_conv_mfma_impl(x, nullptr, Cin, w, 0, bias, h, nullptr, 0, B, Cout, Cin, Cin, V, 0, stream, e);
     return vx_pw_conv_fwd_impl(x, nullptr, Cin, w, bias, h, B, Cin, Cout, V, stream, e);
 }
@@ -637,9 +644,19 @@ extern "C" int vx_pw_conv_gelu_fwd(const float* x, const float* w, const float* 
 extern "C" int vx_pw_conv_gelu_bwd_data(const float* dy, const float* w, const float* a, float* da, int B, int Cin, int Cout, long V, int mfma,
                                         const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
     VX_REQUIRE(dy && w && a && da && a != da, "vx_pw_conv_gelu_bwd_data: bad args");
-    VxPwEpi e; e.mode = 2; e.aux = const_cast<float*>(a); e.drop = vx_mk_drop(seed_ptr, dstream, p);
+    VxPwEpi e; e.mode = 2; e.aux = const_cast<float*>(a); e.drop = vx_mk_drop(seed_ptr, dstream, p); e.alpha = 1.0f;
     if (mfma) return vx_pw_conv_mfma_impl(dy, nullptr, 0, w, 1, nullptr, da, nullptr, Cin, B, Cin, Cout, Cin, V, 0, stream, e);
     return vx_pw_conv_bwd_data_impl(dy, w, da, nullptr, Cin, B, Cin, Cout, V, 0, stream, e);
+}
+
+// out = alpha * res + drop(W x + bias): the residual + dropout that follows the second 1x1 conv of the JLC / FFN stage in the conv epilogue.
+// The mask is the one vx_axpy_drop_fwd / _bwd generate for the same (seed_ptr, dstream, p) over the same element indices.
+extern "C" int vx_pw_conv_res_fwd(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int Cout, long V, int mfma,
+                                  float alpha, const void* seed_ptr, unsigned long long dstream, float p, void* stream) {
+    VX_REQUIRE(x && w && res && out, "vx_pw_conv_res_fwd: bad args");
+    VxPwEpi e; e.mode = 3; e.aux = const_cast<float*>(res); e.drop = vx_mk_drop(seed_ptr, dstream, p); e.alpha = alpha;
+    if (mfma) return vx_pw_conv_mfma_impl(x, nullptr, Cin, w, 0, bias, out, nullptr, 0, B, Cout, Cin, Cin, V, 0, stream, e);
+    return vx_pw_conv_fwd_impl(x, nullptr, Cin, w, bias, out, B, Cin, Cout, V, stream, e);
 }
 
 extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
