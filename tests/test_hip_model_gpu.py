@@ -225,14 +225,15 @@ def test_composite_blocks_equal_the_fine_grained_operators():
     finally:
         VF.USE_COMPOSITE = True
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
-    for a, b in zip(res[True][1], res[False][1]):        # (the Gram outputs are float-atomic sums: equal to round-off, not bit for bit)
-        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(res[True][1], res[False][1]):        # (the Gram outputs are float-atomic sums: equal to round-off, not bit for bit; the fused
+        # epilogues -- GELU, residual + dropout inside the 1x1 convs -- round alpha*res + mask*conv in a different order than the separate kernels: 1-2 ulp)
+        assert float((a - b).abs().max()) <= 4e-6 * max(1.0, float(b.abs().max()))
     assert torch.equal(res[True][3], res[False][3])
     for n, g in res[False][2].items():
         d_ = float((res[True][2][n] - g).abs().max())
         # floor 1e-6: biases in front of an InstanceNorm have a mathematically zero gradient; what both paths compute for them is ~1e-8 of
         # summation-order noise (float atomics), which differs from run to run
-        assert d_ <= 1e-5 * max(0.1, float(g.abs().max())), (n, d_)
+        assert d_ <= 3e-5 * max(0.1, float(g.abs().max())), (n, d_)          # fused epilogues: 1-2 ulp differences in the forward, amplified at the 4^3 level
 
 
 @pytest.mark.timeout(600)

@@ -510,6 +510,55 @@ struct GeluFn : public torch::autograd::Function<GeluFn> {
     }
 };
 
+// out = alpha * res + drop(conv1x1(x)) as ONE node (PWA mix conv + residual dropout, PWA.py:377): forward one launch, backward = mask the incoming
+// gradient once, then the fused 1x1 backward
+struct PwResState { ConvState c; AxpyState r; };
+struct PwResFn : public torch::autograd::Function<PwResFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const OptT& b, const Tensor& res, double alpha, double p, int64_t site, int64_t rs) {
+        auto h = put_state<PwResState>(ctx);
+        return pw_res_fwd_impl(h->s.c, h->s.r, x, w, b.value_or(Tensor()), res, alpha, p, site, sp(rs), cur_stream(x));
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        PwResState& st = get_state<PwResState>(ctx);
+        void* s_ = cur_stream(g[0]);
+        const bool has_b = st.c.b.defined();
+        const int res_edge = has_b ? 3 : 2;                              // edges: x, w, [b], res
+        Tensor dres, dz, dx, dx2;
+        axpy_bwd_impl(st.r, g[0], ctx->needs_input_grad(res_edge), dres, dz, s_);
+        conv_bwd_impl(st.c, dz, ctx->needs_input_grad(0), dx, dx2, s_);
+        ctx->saved_data.clear();
+        return {dx, Tensor(), Tensor(), dres, Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+// q, k, v = three 1x1 convs of the same input as ONE node (PWA.py:291-298): the three input gradients are accumulated into one tensor by the kernels'
+// accumulate mode instead of two autograd add launches per modality and level
+struct QKVState { ConvState c[3]; };
+struct QKVFn : public torch::autograd::Function<QKVFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& x, const Tensor& wq, const OptT& bq, const Tensor& wk, const OptT& bk, const Tensor& wv, const OptT& bv) {
+        auto h = put_state<QKVState>(ctx);
+        void* s_ = cur_stream(x);
+        const Tensor* ws[3] = {&wq, &wk, &wv};
+        const OptT* bs[3] = {&bq, &bk, &bv};
+        variable_list out;
+        for (int j = 0; j < 3; ++j) out.push_back(conv_fwd_impl(h->s.c[j], x, Tensor(), *ws[j], bs[j]->value_or(Tensor()), 1, 1, 0, 1, 1, x.requires_grad(), s_));
+        return out;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        QKVState& st = get_state<QKVState>(ctx);
+        const bool need_x = ctx->needs_input_grad(0);
+        Tensor dx;
+        for (int j = 0; j < 3; ++j) {
+            if (!g[j].defined()) continue;
+            Tensor t1, t2;
+            conv_bwd_impl(st.c[j], g[j], need_x, t1, t2, cur_stream(g[j]), dx);        // first defined gradient creates dx, the others accumulate into it
+            if (need_x && !dx.defined()) dx = t1;
+        }
+        ctx->saved_data.clear();
+        return {dx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
 struct AxpyFn : public torch::autograd::Function<AxpyFn> {
     static Tensor forward(AutogradContext* ctx, const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) {
         auto h = put_state<AxpyState>(ctx);
@@ -548,6 +597,13 @@ PYBIND11_MODULE(_vxops, m) {
         return ConvFn::apply(x, x2, w, b, K, S, P, G, ps);
     });
     m.def("instnorm", [](const OptT& res, bool act, const Tensor& y0, const OptT& y1, const OptT& y2) { return InstNormFn::apply(res, act, y0, y1, y2); });
+    m.def("pw_res", [](const Tensor& x, const Tensor& w, const OptT& b, const Tensor& res, double alpha, double p, int64_t site, int64_t rs) {
+        return PwResFn::apply(x, w, b, res, alpha, p, site, rs);
+    });
+    m.def("pw_res_ok", [](const Tensor& x, const Tensor& w) { return pw_gelu_fusable(x, w); });
+    m.def("qkv", [](const Tensor& x, const Tensor& wq, const OptT& bq, const Tensor& wk, const OptT& bk, const Tensor& wv, const OptT& bv) {
+        return QKVFn::apply(x, wq, bq, wk, bk, wv, bv);
+    });
     m.def("layernorm", [](const Tensor& x, const Tensor& g, const Tensor& bt) { return LayerNormFn::apply(x, g, bt); });
     m.def("gelu", [](const Tensor& a, double p, int64_t site, int64_t rs) { return GeluFn::apply(a, p, site, rs); });
     m.def("axpy", [](const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) { return AxpyFn::apply(x, z, alpha, p, site, rs); });

@@ -207,6 +207,15 @@ def _cpp_node(name):
     return _cpp_op(name) if USE_CPP_NODES else None
 
 
+def cpp_node(name):
+    """the C++ module when single operators may run as C++ autograd nodes (model code that builds multi-operator nodes asks here), else None"""
+    return _cpp_node(name)
+
+
+def rs_ptr(device, p):
+    return _rs_ptr(device, p)
+
+
 def _cpp():
     """the C++ module when it may be used: built, enabled, and every A/B flag at the default it was configured with (tests that flip a
     flag run the python bodies)"""

@@ -83,11 +83,21 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
 
     def _qkv(self, m: int, x):
         xn = self.input_norms[m](x)                      # LN once (the reference evaluates the same LN three times)
+        cm = VF.cpp_node("conv") if xn.is_cuda else None
+        if cm is not None:                               # one autograd node for the three projections: their input gradients accumulate in the kernels
+            pq, pk, pv = self.qkv_proj[m]
+            return list(cm.qkv(xn, pq.weight, pq.bias, pk.weight, pk.bias, pv.weight, pv.bias))
         return [self.qkv_proj[m][j](xn) for j in range(3)]
 
     def _post(self, m: int, x, s, residual_scale: float, tail):
-        mix = self.mix_channels[m](s)
-        y = VF.residual_dropout(x, mix, residual_scale, self.proj_drop if self.training else 0.0, self.sites_proj[m])
+        p = self.proj_drop if self.training else 0.0
+        cm = VF.cpp_node("conv") if s.is_cuda else None
+        mc = self.mix_channels[m]
+        if cm is not None and cm.pw_res_ok(s, mc.weight):      # mix conv + residual + dropout: one launch, one autograd node
+            y = cm.pw_res(s, mc.weight, mc.bias, x, float(residual_scale), float(p), int(self.sites_proj[m]), VF.rs_ptr(s.device, p))
+        else:
+            mix = mc(s)
+            y = VF.residual_dropout(x, mix, residual_scale, p, self.sites_proj[m])
         return tail(m, y) if tail is not None else y
 
     def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0, tail=None) -> List[torch.Tensor]:
