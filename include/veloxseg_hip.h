@@ -96,6 +96,9 @@ int vx_pw_conv_mfma(const float* src, const float* src2, int S1, const float* w,
  * vx_pw_conv_mfma(transpose_w = 1) followed by vx_pw_conv_bwd_weight */
 int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float* x, const float* x2, int C1, float* dx, float* dx2, float* dw, float* db,
                          int B, int Cin, int Cout, long V, int accumulate, void* stream);
+/* the same for large volumes (one voxel per thread for the input gradient: the vx_pw_conv_bwd_data kernel + vx_pw_conv_bwd_weight in one launch); Cin % 4 == 0 */
+int vx_pw_conv_bwd_fused_big(const float* dy, const float* w, const float* x, const float* x2, int C1, float* dx, float* dx2, float* dw, float* db,
+                             int B, int Cin, int Cout, long V, int accumulate, void* stream);
 /* "1x1 conv -> GELU -> dropout -> 1x1 conv" stage of the JLC / FFN blocks (conv_blocks.py:64-68, attention_utils.py:56-66) with the element-wise
  * part in the conv epilogues: fwd writes the pre-activation a and h = drop(gelu(a)); bwd_data writes da = (W2^T dy) * mask * gelu'(a).
  * Same masks as vx_gelu_drop_fwd/_bwd on the same (seed_ptr, dstream, p).  mfma != 0: MFMA tile kernels (small volumes). */

@@ -556,3 +556,25 @@ def test_instance_norm_long_rows_two_launch_path_equals_separate_launches(nk, ac
     for k in range(nk):
         if grads[k] is not None:
             assert torch.equal(grads[k], rgrads[k]), k
+
+
+@pytest.mark.parametrize("B,Cin,Cout,V,C1", [(2, 16, 48, 32768, 0), (1, 48, 16, 8192, 0), (2, 24, 20, 5000, 8)], ids=["V32768", "V8192", "concat_unaligned"])
+def test_pw_conv_bwd_fused_big_equals_two_launches(B, Cin, Cout, V, C1):
+    """vx_pw_conv_bwd_fused_big == vx_pw_conv_bwd_data + vx_pw_conv_bwd_weight (large volumes), incl. accumulate mode and concat inputs"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    dy, w = rnd(B, Cout, V, seed=1).to(d), rnd(Cout, Cin, seed=2).to(d)
+    c1 = C1 or Cin
+    x, x2 = rnd(B, c1, V, seed=3).to(d), (rnd(B, Cin - c1, V, seed=4).to(d) if C1 else None)
+    st = H.stream_ptr()
+    for acc in (0, 1):
+        ref_dx, ref_dx2 = torch.full((B, c1, V), 0.5, device=d), (torch.full((B, Cin - c1, V), 0.25, device=d) if C1 else None)
+        got_dx, got_dx2 = ref_dx.clone(), (ref_dx2.clone() if C1 else None)
+        ref_dw, ref_db, got_dw, got_db = (torch.zeros(Cout, Cin, device=d), torch.zeros(Cout, device=d), torch.zeros(Cout, Cin, device=d), torch.zeros(Cout, device=d))
+        H.call("vx_pw_conv_bwd_data", H.P(dy), H.P(w), H.P(ref_dx), H.P(ref_dx2), c1, B, Cin, Cout, V, acc, st)
+        H.call("vx_pw_conv_bwd_weight", H.P(x), H.P(x2), c1, H.P(dy), H.P(ref_dw), H.P(ref_db), B, Cin, Cout, V, st)
+        H.call("vx_pw_conv_bwd_fused_big", H.P(dy), H.P(w), H.P(x), H.P(x2), c1, H.P(got_dx), H.P(got_dx2), H.P(got_dw), H.P(got_db), B, Cin, Cout, V, acc, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got_dx, ref_dx) and (not C1 or torch.equal(got_dx2, ref_dx2))
+        close(got_dw, ref_dw, 1e-5 * max(1.0, float(ref_dw.abs().max())), 1e-5, "dw")
+        close(got_db, ref_db, 1e-5 * max(1.0, float(ref_db.abs().max())), 1e-5, "db")

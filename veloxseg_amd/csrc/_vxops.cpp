@@ -172,6 +172,14 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
             "vx_pw_conv_bwd_fused");
         return;
     }
+    if (need_x && st.pw && V > F.pw_mfma_max_v && w.requires_grad() && !WG.enabled && F.fuse_pw_bwd) {     // the same at the large levels
+        const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
+        dx = acc ? acc_into : at::empty_like(x);
+        if (x2.defined()) dx2 = at::empty_like(x2);
+        chk(vx_pw_conv_bwd_fused_big(fp(dy), fp(w), fp(x), fp(x2), C1, mp(dx), mp(dx2), grad_ptr(w), skip_bias ? nullptr : grad_ptr(b), B, Cin, Cout, V, acc, stream),
+            "vx_pw_conv_bwd_fused_big");
+        return;
+    }
     if (need_x) {
         const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
         dx = acc ? acc_into : at::empty_like(x);

@@ -75,10 +75,10 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
 
 // dx[b,ci,v] (=|+=) sum_co w[co,ci] * dy[b,co,v]              (CIT input channels per thread, CIT % 4 == 0)
 template <int CIT>
-__global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+__device__ __forceinline__ void vx_pw_bwd_data_body(const int vbx, const int vby, const int vbz, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                                         float* __restrict__ dx2, int C1, int Cin, int Cout, long V, int accumulate, VxPwEpi epi) {
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ci0 = blockIdx.y * CIT, b = blockIdx.z;
+    const long v = (long)vbx * 256 + threadIdx.x;
+    const int ci0 = vby * CIT, b = vbz;
     if (v >= V) return;
     float acc[CIT];
 #pragma unroll
@@ -111,6 +111,11 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
         const float o = vx_pw_epi(epi, acc[i], ((long)b * Cin + c) * V + v);          // epilogue only without a concat destination (C1 == Cin)
         if (accumulate) *dst += o; else *dst = o;
     }
+}
+template <int CIT>
+__global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                        float* __restrict__ dx2, int C1, int Cin, int Cout, long V, int accumulate, VxPwEpi epi) {
+    vx_pw_bwd_data_body<CIT>(blockIdx.x, blockIdx.y, blockIdx.z, dy, w, dx, dx2, C1, Cin, Cout, V, accumulate, epi);
 }
 
 // dW[co,ci] += sum_{b,v} dy[b,co,v] x[b,ci,v] ; db[co] += sum dy.   One wave = one (16 co x 16 ci) tile x one voxel chunk; 64 voxels per
@@ -627,6 +632,57 @@ extern "C" int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float
     vx_pw_bwd_fused_k<<<dim3((unsigned)(n1 + n2)), 256, 0, (hipStream_t)stream>>>(dy, w, dx, dx2, C1, Cin, Cout, V, B, n_vt4, accumulate, ks4, (int)n1, gx1,
                                                                                x, x2, dw, db, (int)vpw, chunks_per_b, nt, gx2);
     VX_LAUNCH_CHECK("vx_pw_conv_bwd_fused");
+    return 0;
+}
+
+// The same one-launch backward for LARGE volumes (one voxel per thread for the input gradient): blocks [0, n1) run vx_pw_bwd_data_body, the rest the
+// MFMA weight-gradient body.
+template <int CIT>
+__global__ void __launch_bounds__(256) vx_pw_bwd_fused_big_k(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ dx2,
+                                                             int C1, int Cin, int Cout, long V, int B, int accumulate, int n1, int gx1, int gy1,
+                                                             const float* __restrict__ x, const float* __restrict__ x2, float* __restrict__ dw, float* __restrict__ db,
+                                                             int vox_per_wave, int chunks_per_b, int n_ci_tiles, int gx2) {
+    const int id = blockIdx.x;
+    if (id < n1) {
+        VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; e.alpha = 1.0f;
+        const int bx = id % gx1, t = id / gx1;
+        vx_pw_bwd_data_body<CIT>(bx, t % gy1, t / gy1, dy, w, dx, dx2, C1, Cin, Cout, V, accumulate, e);
+    } else {
+        const int j = id - n1;
+        vx_pw_wgrad_body(j % gx2, j / gx2, x, x2, C1, Cin, dy, Cout, V, B, dw, db, vox_per_wave, chunks_per_b, n_ci_tiles);
+    }
+}
+
+extern "C" int vx_pw_conv_bwd_fused_big(const float* dy, const float* w, const float* x, const float* x2, int C1, float* dx, float* dx2, float* dw, float* db,
+                                        int B, int Cin, int Cout, long V, int accumulate, void* stream) {
+    VX_REQUIRE(dy && w && x && dx && dw && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_fused_big: bad args");
+    VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_bwd_fused_big: Cin must be a multiple of 4 (got %d)", Cin);
+    if (C1 <= 0 || C1 > Cin) C1 = Cin;
+    VX_REQUIRE(C1 == Cin || (x2 && dx2), "vx_pw_conv_bwd_fused_big: second tensor of a concat is missing");
+    int T = (Cin % 16 == 0) ? 16 : (Cin % 8 == 0) ? 8 : 4;
+    while (T > 4 && (C1 % T)) T >>= 1;
+    while (T > 4 && (long)vx_cdiv(V, 256) * (Cin / T) * B < 512) T >>= 1;
+    VX_REQUIRE(C1 % T == 0, "vx_pw_conv_bwd_fused_big: concat split must be a multiple of 4");
+    const int gx1 = vx_cdiv(V, 256), gy1 = Cin / T;
+    const long n1 = (long)gx1 * gy1 * B;
+    const int mt = vx_cdiv(Cout, 16), nt = vx_cdiv(Cin, 16);
+    long waves_per_tile = 1024 / ((long)mt * nt);
+    if (waves_per_tile < 4) waves_per_tile = 4;
+    long vpw = ((long)B * V + waves_per_tile - 1) / waves_per_tile;
+    vpw = (vpw + 63) / 64 * 64;
+    if (vpw < 256) vpw = 256;
+    const int chunks_per_b = vx_cdiv(V, vpw);
+    const int gx2 = vx_cdiv((long)B * chunks_per_b, 4);
+    const long n2 = (long)gx2 * mt * nt;
+    VX_REQUIRE(n1 + n2 < 0x7fffffffL, "vx_pw_conv_bwd_fused_big: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(n1 + n2));
+    switch (T) {
+        case 16: vx_pw_bwd_fused_big_k<16><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, B, accumulate, (int)n1, gx1, gy1, x, x2, dw, db, (int)vpw, chunks_per_b, nt, gx2); break;
+        case 8: vx_pw_bwd_fused_big_k<8><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, B, accumulate, (int)n1, gx1, gy1, x, x2, dw, db, (int)vpw, chunks_per_b, nt, gx2); break;
+        default: vx_pw_bwd_fused_big_k<4><<<grid, 256, 0, st>>>(dy, w, dx, dx2, C1, Cin, Cout, V, B, accumulate, (int)n1, gx1, gy1, x, x2, dw, db, (int)vpw, chunks_per_b, nt, gx2); break;
+    }
+    VX_LAUNCH_CHECK("vx_pw_conv_bwd_fused_big");
     return 0;
 }
 
