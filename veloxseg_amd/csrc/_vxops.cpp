@@ -581,6 +581,143 @@ struct AxpyFn : public torch::autograd::Function<AxpyFn> {
     }
 };
 
+static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, const std::vector<Tensor>& ws, const std::vector<Tensor>& bs, int G, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w,
+                        const Tensor& l2b, double p, int64_t site, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<JLCState>();
+        void* s_ = sp(stream);
+        const int n = (int)ws.size();
+        st->convs.resize(n);
+        std::vector<Tensor> ys;
+        for (int k = 0; k < n; ++k) {
+            const int K = ws[k].size(2);
+            ys.push_back(conv_fwd_impl(st->convs[k], x, Tensor(), ws[k], bs[k], K, 1, K / 2, G, 1, x.requires_grad(), s_));
+        }
+        Tensor o = in_fwd_impl(st->in1, x, true, ys, s_);
+        Tensor nrm = in_fwd_impl(st->in2, Tensor(), false, {o}, s_);
+        st->fused = F.fuse_gelu && pw_gelu_fusable(nrm, l1w) && l2w.size(1) % 4 == 0;
+        Tensor h;
+        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, nrm, l1w, l1b, 0.0, 0, nullptr, s_);
+        else {
+            Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
+            h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
+        }
+        Tensor out;
+        if (F.fuse_res && pw_gelu_fusable(h, l2w)) out = pw_res_fwd_impl(st->c2, st->r, h, l2w, l2b, o, 1.0, p, site, sp(rs), s_);
+        else {
+            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
+            out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
+        }
+        return {out, st};
+    }
+
+static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout, bool need_x, int64_t stream) {
+        void* s_ = sp(stream);
+        Tensor do_res, dz, dh, dh2, da, dn, dn2;
+        axpy_bwd_impl(st->r, dout, true, do_res, dz, s_);
+        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
+        else {
+            conv_bwd_impl(st->c2, dz, true, dh, dh2, s_);
+            da = gelu_bwd_impl(st->g, dh, s_);
+        }
+        conv_bwd_impl(st->c1, da, true, dn, dn2, s_);
+        Tensor d_o;                                            // = do_res + InstanceNorm backward of the channel stage's input
+        if (F.fuse_bwd_add) d_o = in_bwd_impl(st->in2, dn, {true}, s_, nullptr, 1, do_res)[0];
+        else {
+            Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
+            d_o = sum3(do_res, do2, Tensor(), s_);
+        }
+        const int n = (int)st->convs.size();
+        // The spatial convs feed an InstanceNorm directly: its backward removes the per-(b, c) mean, so the sum of g[k] over every row -- the bias
+        // gradient -- is zero up to round-off (the reference's value is ~1e-8 noise).  It is not computed: no reduction launch on the long rows,
+        // no per-row atomics on the short ones; the bias entries of the flat gradient stay at the zero they were cleared to.
+        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_);
+        // dx = d_o + sum_k conv_k^T(g_k): d_o is this function's own temporary (its last reader was in_bwd above), so the three input gradients
+        // are accumulated into it in place by the kernels' `accumulate` mode -- no extra add launches
+        for (int k = 0; k < n; ++k) {
+            Tensor t1, t2;
+            if (F.skip_in_bias) grad_ptr(st->convs[k].b);         // the (zero) gradient tensor still exists for optimizers that walk p.grad
+            conv_bwd_impl(st->convs[k], g[k], true, t1, t2, s_, d_o, /*skip_bias=*/F.skip_in_bias);
+        }
+        st.reset();
+        if (!need_x) return Tensor();
+        return d_o;
+    }
+
+static std::pair<Tensor, std::shared_ptr<FFNState>> ffn_fwd_f(const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p,
+                        int64_t site1, int64_t site2, int64_t rs, int64_t stream) {
+        auto st = std::make_shared<FFNState>();
+        void* s_ = sp(stream);
+        Tensor n = ln_fwd_impl(st->ln, y, gamma, beta, s_);
+        st->fused = F.fuse_gelu && pw_gelu_fusable(n, w1) && w2.size(1) % 4 == 0;
+        Tensor h;
+        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, n, w1, b1, p, site1, sp(rs), s_);
+        else {
+            Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
+            h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
+        }
+        Tensor out;
+        if (F.fuse_res && pw_gelu_fusable(h, w2)) out = pw_res_fwd_impl(st->c2, st->r, h, w2, b2, y, 1.0, p, site2, sp(rs), s_);
+        else {
+            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
+            out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
+        }
+        return {out, st};
+    }
+
+static Tensor ffn_bwd_f(std::shared_ptr<FFNState> st, const Tensor& dout, int64_t stream) {
+        void* s_ = sp(stream);
+        Tensor dy_res, dz, dh, t2, dn, t3;
+        axpy_bwd_impl(st->r, dout, true, dy_res, dz, s_);
+        Tensor da;
+        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
+        else {
+            conv_bwd_impl(st->c2, dz, true, dh, t2, s_);
+            da = gelu_bwd_impl(st->g, dh, s_);
+        }
+        conv_bwd_impl(st->c1, da, true, dn, t3, s_);
+        if (F.fuse_bwd_add) return ln_bwd_impl(st->ln, dn, s_, dy_res);      // dy_res + LayerNorm backward in one store
+        Tensor dy_ln = ln_bwd_impl(st->ln, dn, s_);
+        return sum3(dy_res, dy_ln, Tensor(), s_);
+    }
+
+// JLC block / FFN tail as C++ autograd nodes (the parameters are passed so that the node exists even when only they require a gradient;
+// their gradients are accumulated into .grad by the kernels, as everywhere)
+struct JLCFn : public torch::autograd::Function<JLCFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w0, const OptT& w1, const OptT& w2, const Tensor& b0, const OptT& b1, const OptT& b2, int64_t G,
+                          const Tensor& l1w, const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site, int64_t rs) {
+        std::vector<Tensor> ws{w0}, bs{b0};
+        if (w1.has_value() && w1->defined()) { ws.push_back(*w1); bs.push_back(b1.value()); }
+        if (w2.has_value() && w2->defined()) { ws.push_back(*w2); bs.push_back(b2.value()); }
+        auto r = jlc_fwd_f(x, ws, bs, (int)G, l1w, l1b, l2w, l2b, p, site, rs, (int64_t)cur_stream(x));
+        put_state<std::shared_ptr<JLCState>>(ctx)->s = r.second;
+        return r.first;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto st = get_state<std::shared_ptr<JLCState>>(ctx);
+        Tensor dx = jlc_bwd_f(st, g[0], ctx->needs_input_grad(0), (int64_t)cur_stream(g[0]));
+        ctx->saved_data.clear();
+        variable_list out(15);
+        out[0] = dx;
+        return out;
+    }
+};
+struct FFNFn : public torch::autograd::Function<FFNFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2,
+                          double p, int64_t site1, int64_t site2, int64_t rs) {
+        auto r = ffn_fwd_f(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs, (int64_t)cur_stream(y));
+        put_state<std::shared_ptr<FFNState>>(ctx)->s = r.second;
+        return r.first;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto st = get_state<std::shared_ptr<FFNState>>(ctx);
+        Tensor dy = ffn_bwd_f(st, g[0], (int64_t)cur_stream(g[0]));
+        ctx->saved_data.clear();
+        variable_list out(11);
+        out[0] = dy;
+        return out;
+    }
+};
+
 }  // namespace
 
 // =================================================================================================================== python surface
@@ -612,6 +749,12 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("qkv", [](const Tensor& x, const Tensor& wq, const OptT& bq, const Tensor& wk, const OptT& bk, const Tensor& wv, const OptT& bv) {
         return QKVFn::apply(x, wq, bq, wk, bk, wv, bv);
     });
+    m.def("jlc", [](const Tensor& x, const Tensor& w0, const OptT& w1, const OptT& w2, const Tensor& b0, const OptT& b1, const OptT& b2, int64_t G, const Tensor& l1w,
+                    const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site, int64_t rs) {
+        return JLCFn::apply(x, w0, w1, w2, b0, b1, b2, G, l1w, l1b, l2w, l2b, p, site, rs);
+    });
+    m.def("ffn", [](const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p, int64_t site1,
+                    int64_t site2, int64_t rs) { return FFNFn::apply(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs); });
     m.def("layernorm", [](const Tensor& x, const Tensor& g, const Tensor& bt) { return LayerNormFn::apply(x, g, bt); });
     m.def("gelu", [](const Tensor& a, double p, int64_t site, int64_t rs) { return GeluFn::apply(a, p, site, rs); });
     m.def("axpy", [](const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) { return AxpyFn::apply(x, z, alpha, p, site, rs); });
@@ -683,99 +826,19 @@ PYBIND11_MODULE(_vxops, m) {
     // JLC block: ws/bs = the spatial convs' weights / biases (kernel sizes from the weight shapes), groups G; l1/l2 = the channel MLP
     m.def("jlc_fwd", [](const Tensor& x, const std::vector<Tensor>& ws, const std::vector<Tensor>& bs, int G, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w,
                         const Tensor& l2b, double p, int64_t site, int64_t rs, int64_t stream) {
-        auto st = std::make_shared<JLCState>();
-        void* s_ = sp(stream);
-        const int n = (int)ws.size();
-        st->convs.resize(n);
-        std::vector<Tensor> ys;
-        for (int k = 0; k < n; ++k) {
-            const int K = ws[k].size(2);
-            ys.push_back(conv_fwd_impl(st->convs[k], x, Tensor(), ws[k], bs[k], K, 1, K / 2, G, 1, x.requires_grad(), s_));
-        }
-        Tensor o = in_fwd_impl(st->in1, x, true, ys, s_);
-        Tensor nrm = in_fwd_impl(st->in2, Tensor(), false, {o}, s_);
-        st->fused = F.fuse_gelu && pw_gelu_fusable(nrm, l1w) && l2w.size(1) % 4 == 0;
-        Tensor h;
-        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, nrm, l1w, l1b, 0.0, 0, nullptr, s_);
-        else {
-            Tensor a = conv_fwd_impl(st->c1, nrm, Tensor(), l1w, l1b, 1, 1, 0, 1, 1, true, s_);
-            h = gelu_fwd_impl(st->g, a, 0.0, 0, nullptr, s_);
-        }
-        Tensor out;
-        if (F.fuse_res && pw_gelu_fusable(h, l2w)) out = pw_res_fwd_impl(st->c2, st->r, h, l2w, l2b, o, 1.0, p, site, sp(rs), s_);
-        else {
-            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), l2w, l2b, 1, 1, 0, 1, 1, true, s_);
-            out = axpy_fwd_impl(st->r, o, z, 1.0, p, site, sp(rs), s_);
-        }
-        return py::make_tuple(out, st);
+        auto r = jlc_fwd_f(x, ws, bs, G, l1w, l1b, l2w, l2b, p, site, rs, stream);
+        return py::make_tuple(r.first, r.second);
     });
     m.def("jlc_bwd", [](std::shared_ptr<JLCState> st, const Tensor& dout, bool need_x, int64_t stream) -> py::object {
-        void* s_ = sp(stream);
-        Tensor do_res, dz, dh, dh2, da, dn, dn2;
-        axpy_bwd_impl(st->r, dout, true, do_res, dz, s_);
-        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
-        else {
-            conv_bwd_impl(st->c2, dz, true, dh, dh2, s_);
-            da = gelu_bwd_impl(st->g, dh, s_);
-        }
-        conv_bwd_impl(st->c1, da, true, dn, dn2, s_);
-        Tensor d_o;                                            // = do_res + InstanceNorm backward of the channel stage's input
-        if (F.fuse_bwd_add) d_o = in_bwd_impl(st->in2, dn, {true}, s_, nullptr, 1, do_res)[0];
-        else {
-            Tensor do2 = in_bwd_impl(st->in2, dn, {true}, s_)[0];
-            d_o = sum3(do_res, do2, Tensor(), s_);
-        }
-        const int n = (int)st->convs.size();
-        // The spatial convs feed an InstanceNorm directly: its backward removes the per-(b, c) mean, so the sum of g[k] over every row -- the bias
-        // gradient -- is zero up to round-off (the reference's value is ~1e-8 noise).  It is not computed: no reduction launch on the long rows,
-        // no per-row atomics on the short ones; the bias entries of the flat gradient stay at the zero they were cleared to.
-        auto g = in_bwd_impl(st->in1, d_o, std::vector<bool>(n, true), s_);
-        // dx = d_o + sum_k conv_k^T(g_k): d_o is this function's own temporary (its last reader was in_bwd above), so the three input gradients
-        // are accumulated into it in place by the kernels' `accumulate` mode -- no extra add launches
-        for (int k = 0; k < n; ++k) {
-            Tensor t1, t2;
-            if (F.skip_in_bias) grad_ptr(st->convs[k].b);         // the (zero) gradient tensor still exists for optimizers that walk p.grad
-            conv_bwd_impl(st->convs[k], g[k], true, t1, t2, s_, d_o, /*skip_bias=*/F.skip_in_bias);
-        }
-        st.reset();
-        if (!need_x) return py::none();
-        return py::cast(d_o);
+        Tensor d = jlc_bwd_f(st, dout, need_x, stream);
+        return d.defined() ? py::cast(d) : py::none();
     });
 
     // FFN tail: out = y + Drop(linear2(Drop(GELU(linear1(LN(y))))))
     m.def("ffn_fwd", [](const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p,
                         int64_t site1, int64_t site2, int64_t rs, int64_t stream) {
-        auto st = std::make_shared<FFNState>();
-        void* s_ = sp(stream);
-        Tensor n = ln_fwd_impl(st->ln, y, gamma, beta, s_);
-        st->fused = F.fuse_gelu && pw_gelu_fusable(n, w1) && w2.size(1) % 4 == 0;
-        Tensor h;
-        if (st->fused) h = pw_gelu_fwd_impl(st->c1, st->g, n, w1, b1, p, site1, sp(rs), s_);
-        else {
-            Tensor a = conv_fwd_impl(st->c1, n, Tensor(), w1, b1, 1, 1, 0, 1, 1, true, s_);
-            h = gelu_fwd_impl(st->g, a, p, site1, sp(rs), s_);
-        }
-        Tensor out;
-        if (F.fuse_res && pw_gelu_fusable(h, w2)) out = pw_res_fwd_impl(st->c2, st->r, h, w2, b2, y, 1.0, p, site2, sp(rs), s_);
-        else {
-            Tensor z = conv_fwd_impl(st->c2, h, Tensor(), w2, b2, 1, 1, 0, 1, 1, true, s_);
-            out = axpy_fwd_impl(st->r, y, z, 1.0, p, site2, sp(rs), s_);
-        }
-        return py::make_tuple(out, st);
+        auto r = ffn_fwd_f(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs, stream);
+        return py::make_tuple(r.first, r.second);
     });
-    m.def("ffn_bwd", [](std::shared_ptr<FFNState> st, const Tensor& dout, int64_t stream) {
-        void* s_ = sp(stream);
-        Tensor dy_res, dz, dh, t2, dn, t3;
-        axpy_bwd_impl(st->r, dout, true, dy_res, dz, s_);
-        Tensor da;
-        if (st->fused) da = pw_gelu_bwd_impl(st->c2, st->g, dz, s_);
-        else {
-            conv_bwd_impl(st->c2, dz, true, dh, t2, s_);
-            da = gelu_bwd_impl(st->g, dh, s_);
-        }
-        conv_bwd_impl(st->c1, da, true, dn, t3, s_);
-        if (F.fuse_bwd_add) return ln_bwd_impl(st->ln, dn, s_, dy_res);      // dy_res + LayerNorm backward in one store
-        Tensor dy_ln = ln_bwd_impl(st->ln, dn, s_);
-        return sum3(dy_res, dy_ln, Tensor(), s_);
-    });
+    m.def("ffn_bwd", [](std::shared_ptr<FFNState> st, const Tensor& dout, int64_t stream) { return ffn_bwd_f(st, dout, stream); });
 }

@@ -745,6 +745,13 @@ class _JLCFn(torch.autograd.Function):
 
 
 def jlc_block(x, mod, p: float, site: int):
+    m = _cpp_node("jlc") if x.is_cuda else None
+    if m is not None and len(mod.spatial_convs) <= 3:          # the whole block as one C++ autograd node
+        convs = [seq[0] for seq in mod.spatial_convs]
+        l1, l2 = mod.channel_conv[1], mod.channel_conv[3]
+        w = [c.weight for c in convs] + [None] * (3 - len(convs))
+        b = [c.bias for c in convs] + [None] * (3 - len(convs))
+        return m.jlc(x, w[0], w[1], w[2], b[0], b[1], b[2], convs[0].groups, l1.weight, l1.bias, l2.weight, l2.bias, float(p), int(site), _rs_ptr(x.device, p))
     return _JLCFn.apply(x, mod, float(p), int(site))
 
 
@@ -790,6 +797,10 @@ class _FFNTailFn(torch.autograd.Function):
 
 
 def ffn_tail(y, norm, ffn, p: float):
+    m = _cpp_node("ffn") if y.is_cuda else None
+    if m is not None:                                          # the whole tail as one C++ autograd node
+        return m.ffn(y, norm.weight, norm.bias, ffn.linear1.weight, ffn.linear1.bias, ffn.linear2.weight, ffn.linear2.bias, float(p), int(ffn.site1), int(ffn.site2),
+                     _rs_ptr(y.device, p))
     return _FFNTailFn.apply(y, norm, ffn, float(p))
 
 
