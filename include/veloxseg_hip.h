@@ -219,6 +219,9 @@ int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const 
                      float* loss_out, float* coef, void* stream);
 int vx_seg_loss_bwd(const float* logits, const void* labels, int lab_kind, const float* coef_head, const float* gout,
                     float* dlogits, int B, int C, long V, void* stream);
+/* all nh <= 4 heads in one launch (labels read once); head h reads its coefficients at coef + h * coef_stride floats */
+int vx_seg_loss_bwd4(const float* lg0, const float* lg1, const float* lg2, const float* lg3, int nh, const void* labels, int lab_kind, const float* coef,
+                     int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, int B, int C, long V, void* stream);
 int vx_mse_bwd(const float* a, const float* b, const float* coef, const float* gout, float* da, long n, void* stream);
 int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const float* g2, const float* g3, int M, const float* coef,
                     const float* gout, float* dgs, float* d0, float* d1, float* d2, float* d3, long n, void* stream);

@@ -578,3 +578,25 @@ def test_pw_conv_bwd_fused_big_equals_two_launches(B, Cin, Cout, V, C1):
         assert torch.equal(got_dx, ref_dx) and (not C1 or torch.equal(got_dx2, ref_dx2))
         close(got_dw, ref_dw, 1e-5 * max(1.0, float(ref_dw.abs().max())), 1e-5, "dw")
         close(got_db, ref_db, 1e-5 * max(1.0, float(ref_db.abs().max())), 1e-5, "db")
+
+
+def test_loss_backward_one_launch_for_all_heads_equals_per_head_launches():
+    VF = _vf()
+    d = dev()
+    B, S, ncls, M = 2, 12, 3, 2
+    g = torch.Generator().manual_seed(5)
+    base = [rnd(B, ncls, S, S, S, seed=i) for i in range(4)] + [rnd(B, M, S, S, S, seed=7)] + [rnd(B, 16, 16, seed=8 + i, scale=0.1) for i in range(1 + M)]
+    lab = torch.randint(0, ncls, (B, 1, S, S, S), generator=g).to(d)
+    sr = rnd(B, M, S, S, S, seed=99).to(d)
+    res = []
+    try:
+        for flag in (True, False):
+            VF.USE_LOSS_BWD4 = flag
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            VF.veloxseg_loss(t, lab, sr, [0.4, 0.3, 0.2, 0.1], 0.5, 2.0, M).backward()
+            torch.cuda.synchronize()
+            res.append([x.grad.clone() for x in t])
+    finally:
+        VF.USE_LOSS_BWD4 = True
+    for i, (a, b) in enumerate(zip(*res)):          # the 4-voxel kernel contracts / rounds the soft-max normalisation differently: a few ulp
+        close(a, b, 2e-6 * max(1e-3, float(b.abs().max())), 1e-5, f"grad {i}")

@@ -247,6 +247,62 @@ __global__ void __launch_bounds__(256) vx_seg_loss_bwd_k(const float* __restrict
     for (int c = 0; c < VX_MAXC; ++c) if (c < C) dl[(long)c * V + v] = go * (wce * (z[c] - (c == y ? 1.0f : 0.0f)) + z[c] * (g[c] - dot));
 }
 
+// all deep-supervision heads in one launch: the label (8 bytes per voxel as int64) is read once instead of once per head
+struct VxLoss4 { const float* lg[4]; float* dl[4]; };
+template <int VEC>      // VEC = 4: four consecutive voxels per thread, 16-byte loads and stores (V % 4 == 0)
+__global__ void __launch_bounds__(256) vx_seg_loss_bwd4_k(VxLoss4 P, int nh, const void* __restrict__ lab, int lab_kind, const float* __restrict__ coef, int coef_stride,
+                                                          const float* __restrict__ gout, int B, int C, long V) {
+    const int b = blockIdx.y;
+    const long v = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (v >= V) return;
+    const float go = gout ? gout[0] : 1.0f;
+    int y[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) y[u] = vx_label(lab, lab_kind, (long)b * V + v + u);
+    for (int h = 0; h < nh; ++h) {
+        const float* __restrict__ lg = P.lg[h] + (long)b * C * V;
+        float* __restrict__ dl = P.dl[h] + (long)b * C * V;
+        const float* __restrict__ coef_h = coef + (long)h * coef_stride;
+        const float wce = coef_h[0];
+        float z[VX_MAXC][VEC], mx[VEC], se[VEC], dot[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { mx[u] = -INFINITY; se[u] = 0.0f; dot[u] = 0.0f; }
+#pragma unroll
+        for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+            if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(lg + (long)c * V + v); z[c][0] = t.x; z[c][1 % VEC] = t.y; z[c][2 % VEC] = t.z; z[c][3 % VEC] = t.w; }
+            else z[c][0] = lg[(long)c * V + v];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) mx[u] = fmaxf(mx[u], z[c][u]);
+        }
+#pragma unroll
+        for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) { z[c][u] = expf(z[c][u] - mx[u]); se[u] += z[c][u]; }
+        }
+        float al[VX_MAXC], be[VX_MAXC];
+#pragma unroll
+        for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+            al[c] = coef_h[1 + ((long)b * C + c) * 2]; be[c] = coef_h[2 + ((long)b * C + c) * 2];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                z[c][u] *= 1.0f / se[u];
+                dot[u] = fmaf(z[c][u], (c == y[u] ? al[c] : 0.0f) + be[c], dot[u]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
+            float o[VEC];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                const float g = (c == y[u] ? al[c] : 0.0f) + be[c];
+                o[u] = go * (wce * (z[c][u] - (c == y[u] ? 1.0f : 0.0f)) + z[c][u] * (g - dot[u]));
+            }
+            if (VEC == 4) *reinterpret_cast<float4*>(dl + (long)c * V + v) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+            else dl[(long)c * V + v] = o[0];
+        }
+    }
+}
+
 // da = gout * coef * (a - b)
 __global__ void __launch_bounds__(256) vx_mse_bwd_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ coef,
                                                     const float* __restrict__ gout, float* __restrict__ da, long n) {
@@ -486,6 +542,18 @@ extern "C" int vx_seg_loss_bwd(const float* logits, const void* labels, int lab_
     VX_REQUIRE(logits && labels && coef_head && dlogits && C >= 2 && C <= VX_MAXC, "vx_seg_loss_bwd: bad args");
     hipLaunchKernelGGL(vx_seg_loss_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, logits, labels, lab_kind, coef_head, gout, dlogits, B, C, V);
     VX_LAUNCH_CHECK("vx_seg_loss_bwd");
+    return 0;
+}
+
+// the nh <= 4 heads of vx_seg_loss_fwd in one launch; coef = the forward's coefficient block, head h at coef + h * coef_stride floats
+extern "C" int vx_seg_loss_bwd4(const float* lg0, const float* lg1, const float* lg2, const float* lg3, int nh, const void* labels, int lab_kind, const float* coef,
+                                int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, int B, int C, long V, void* stream) {
+    VX_REQUIRE(nh >= 1 && nh <= 4 && lg0 && dl0 && labels && coef && C >= 2 && C <= VX_MAXC && B > 0 && V > 0, "vx_seg_loss_bwd4: bad args");
+    VxLoss4 P; P.lg[0] = lg0; P.lg[1] = lg1; P.lg[2] = lg2; P.lg[3] = lg3; P.dl[0] = dl0; P.dl[1] = dl1; P.dl[2] = dl2; P.dl[3] = dl3;
+    for (int h = 0; h < nh; ++h) VX_REQUIRE(P.lg[h] && P.dl[h], "vx_seg_loss_bwd4: head %d is missing", h);
+    if ((V & 3) == 0) hipLaunchKernelGGL(vx_seg_loss_bwd4_k<4>, dim3(vx_cdiv(V / 4, 256), B), dim3(256), 0, (hipStream_t)stream, P, nh, labels, lab_kind, coef, coef_stride, gout, B, C, V);
+    else hipLaunchKernelGGL(vx_seg_loss_bwd4_k<1>, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, P, nh, labels, lab_kind, coef, coef_stride, gout, B, C, V);
+    VX_LAUNCH_CHECK("vx_seg_loss_bwd4");
     return 0;
 }
 

@@ -26,6 +26,7 @@ IN_ROW_MAX = 4096
 USE_WGRAD_WS = os.environ.get("VELOXSEG_WGRAD_WS", "0") != "0"   # tiled weight gradient through a partial-sum workspace (deterministic order) instead of float atomics (30 fewer launches per step: +2 %)
 _wgrad_ws = {}
 USE_PATCHIFY = True                           # kernel == stride convs (PatchEmbed) as patchify + 1x1 conv (False = generic direct conv)
+USE_LOSS_BWD4 = True                          # loss backward of all deep-supervision heads in one launch (False = one launch per head)
 USE_DOWN_MFMA = os.environ.get("VELOXSEG_DOWN_MFMA", "1") != "0"   # MFMA weight gradient of the k7 s4 p3 stem conv (False = tiled VALU kernel)
 USE_GCONV1 = True                             # dedicated weight-gradient kernel of the 1x1x1 grouped JLC conv (False = tiled kernel)
 PW_MFMA_MAX_V = int(os.environ.get("VELOXSEG_PW_MFMA_MAX_V", "4096"))   # 1x1 convs on volumes up to this many voxels use the MFMA tile kernel
@@ -1027,10 +1028,15 @@ class _VeloxLossFn(torch.autograd.Function):
         go = _c(gout.reshape(1).to(torch.float32))
         grads = []
         stride = (1 + B * C * 2) * 4
-        for h in range(nh):
-            d = torch.empty_like(logits[h])
-            H.call("vx_seg_loss_bwd", H.P(logits[h]), H.P(labels, None), _LAB_KIND[labels.dtype], coef.data_ptr() + h * stride, H.P(go), H.P(d), B, C, V, st)
-            grads.append(d)
+        if USE_LOSS_BWD4 and nh <= 4:             # every head in one launch: the labels are read once
+            grads = [torch.empty_like(logits[h]) for h in range(nh)]
+            H.call("vx_seg_loss_bwd4", *([H.P(t) for t in logits] + [None] * (4 - nh)), nh, H.P(labels, None), _LAB_KIND[labels.dtype], coef.data_ptr(), stride // 4,
+                   H.P(go), *([H.P(d) for d in grads] + [None] * (4 - nh)), B, C, V, st)
+        else:
+            for h in range(nh):
+                d = torch.empty_like(logits[h])
+                H.call("vx_seg_loss_bwd", H.P(logits[h]), H.P(labels, None), _LAB_KIND[labels.dtype], coef.data_ptr() + h * stride, H.P(go), H.P(d), B, C, V, st)
+                grads.append(d)
         if ctx.has_tail:
             rcs, sr = ctx.saved_tensors[2 + nh: 4 + nh]
             grams = ctx.saved_tensors[4 + nh:]
