@@ -14,9 +14,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import veloxseg_amd  # noqa: E402,F401  (first: configures the HIP runtime before anything initialises it)
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+torch = dist = None      # imported in _imports(): the self-launcher for --gpus N > 1 must not touch HIP before it has started its children
+
+
+def _imports():
+    global torch, dist
+    import veloxseg_amd  # noqa: F401  (first: configures the HIP runtime before anything initialises it)
+    import torch as _t
+    import torch.distributed as _d
+    torch, dist = _t, _d
 
 LOSS_CFG = {"deep_Loss_weight": [1, 1, 1, 1], "RC_Loss_weight": 0.5, "Feature_Loss_weight": 2.0}   # config/train_config_bs4.json:52-59
 
@@ -33,11 +39,16 @@ WORKLOADS = {
     "brats128": (dict(BASE, input_size=[128] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W128), 2),
     "brats96": (dict(BASE, input_size=[96] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W96), 2),
 }
+# Algorithmic work per PATCH of a full training step (FlopCounterMode fwd+bwd; block-boundary activation traffic, fp32),
+# and optimizer traffic per STEP (32 B per parameter): (GFLOP / patch, MB / patch, MB optimizer / step)
+STEP_WORK = {"autopet128": (58.50, 569.1, 73.0), "autopet96": (24.11, 240.1, 73.0), "brats128": (71.55, 916.5, 60.0), "brats96": (30.04, 386.6, 60.0)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector / fp32-input MFMA peak
 
 
 def synth(cfg, B, device, seed):
+    if torch is None:
+        _imports()
     g = torch.Generator().manual_seed(seed)
     S = cfg["input_size"]
     x = torch.randn(B, sum(cfg["in_ch"]), *S, generator=g)
@@ -81,8 +92,89 @@ def cpu_baseline(cfg, B, budget_s=25.0):
         if time.time() - t0 > budget_s or n >= 20:
             break
     dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of the same workload, batch {B}, fp32, after 1 warm-up step"}
+    out = {"value": round(B / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
+           "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of the same workload, batch {B}, fp32, after 1 warm-up step",
+           "host_cores": os.cpu_count(), "cpu_model": _cpu_model()}
+    # the reference's own CPU protocol (speed_test.py:64-70,102-115): eval forward, ONE thread, batch 1 (README.md:216 quotes 6.67 patches/s at 96^3)
+    try:
+        torch.set_num_threads(1)
+        with torch.no_grad():
+            x1 = x[:1]
+            O.forward(x1, sd, ocfg, training=False)
+            t0, n1 = time.time(), 0
+            while n1 < 5 and time.time() - t0 < 12.0:
+                O.forward(x1, sd, ocfg, training=False)
+                n1 += 1
+        out["eval_1thread_bs1"] = {"value": round(n1 / (time.time() - t0), 4), "unit": "patches/s", "sample": f"{n1} eval forwards, 1 thread, batch 1 (speed_test.py protocol)"}
+    except Exception as e:      # a reported extra, never a reason to lose the line
+        out["eval_1thread_bs1"] = {"error": str(e)[:200]}
+    finally:
+        torch.set_num_threads(cores)
+    return out
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def eager_rocm_baseline(cfg, B, dev, budget_s=8.0):
+    """PyTorch-ROCm EAGER training step = the oracle's plain aten formulation run on the MI355X (aten / MIOpen / rocBLAS kernels), the
+    denominator of north_star's '>= 5x eager' target.  Bounded sample outside the timed region; the oracle is used as a baseline here exactly
+    as in cpu_baseline, never as the product."""
+    from oracle import veloxseg_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipe import fill_state_dict
+    ocfg = O.OracleConfig(**{**cfg, "attn_drop": 0.1})
+    sd = {k: v.to(dev) for k, v in fill_state_dict(O.state_dict_template(ocfg), seed=7).items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(params)
+    opt = torch.optim.AdamW(list(params.values()), lr=2.5e-4, weight_decay=0.01)
+    x, lab = synth(cfg, B, dev, 12345)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        outs = O.forward(x, full, ocfg, training=True)
+        loss = O.loss(outs, lab, x, ocfg.M, LOSS_CFG)
+        loss.backward()
+        opt.step()
+
+    step()
+    step()
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    while n < 10 and time.perf_counter() - t0 < budget_s:
+        step()
+        n += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "patches/s", "ms_per_step": round(dt * 1e3, 2),
+            "sample": f"{n} eager steps (aten ops, fp32, same workload / batch / optimizer) after 2 warm-up steps"}
+
+
+def _self_launch(n):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them) and wait; rank 0 prints the
+    JSON line on the inherited stdout.  The parent never initialises the GPU (no exec of an initialised process, no torch import here)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = p_.wait() or rc
+    return rc
 
 
 def main():
@@ -98,8 +190,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, production) or gloo (debug: lets several ranks share one GPU)")
+    ap.add_argument("--no-eager-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))          # plain `python bench.py --gpus N`: one child process per GPU, started before anything touches HIP
+    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,6 +291,22 @@ def main():
                         rf["traffic_source"] = src
                 out["roofline"] = rf
                 break
+    if rank == 0:
+        gf, mb, opt_mb = STEP_WORK[args.workload]
+        flops = gf * 1e9 * B * world
+        byts = (mb * B + opt_mb) * 1e6 * world
+        sec = out["ms_per_step"] * 1e-3
+        out["step_roofline"] = {"algorithmic_flops": flops, "algorithmic_bytes": byts,
+                                "achieved_tflops": round(flops / sec / 1e12, 2), "frac_fp32": round(flops / sec / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
+                                "achieved_gbs": round(byts / sec / 1e9, 1), "frac_hbm": round(byts / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                "note": "whole step against the fp32 vector/MFMA peak and the HBM peak of the GPUs used (SURVEY.md 8d work model)"}
+    if rank == 0 and world == 1 and not args.no_eager_baseline:
+        try:
+            torch.cuda.empty_cache()
+            out["eager_rocm_baseline"] = eager_rocm_baseline(cfg, B, dev)
+            out["eager_rocm_baseline"]["speedup"] = round(out["value"] / out["eager_rocm_baseline"]["value"], 1)
+        except Exception as e:
+            out["eager_rocm_baseline"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B)
     if rank == 0:

@@ -113,6 +113,49 @@ int vx_pw_conv_res_fwd(const float* x, const float* w, const float* bias, const 
 int vx_pw_mfma_set_wide(int on);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused blocks (round 2): the JLC block in 3 + 4 launches (+ 3 weight-gradient launches) and the channel MLP of the JLC / FFN stages in one
+ * launch per direction.  Statistics travel as per-block PARTIAL SUMS that the consumer folds (no atomics, no zero-fill launches).
+ *
+ * vx_mlp_*: out = x + Drop2(W2 . Drop1(GELU(W1 . norm(x) + b1)) + b2), w1 (R, C), w2 (C, R)
+ *   norm 0 = InstanceNorm3d(eps): JLC channel stage, conv_blocks.py:64-69 + the residual of :74.  Forward: `part` != NULL = (sum, sumsq)
+ *            partials of x, [B*C][nparts][2] doubles (from vx_jlc_mid_fwd), folded here and written to `stats` (B*C, 2) = (mean, rstd);
+ *            part == NULL = stats is an input.  Backward: stats is an input; dx receives dn = the gradient at the NORMALISED input and
+ *            part_out [B*C][vx_mlp_bwd_nparts][2] floats receives the partials (sum dn, sum dn*nhat) of the InstanceNorm backward.
+ *   norm 1 = channels-first LayerNorm(gamma, beta, eps): FFN tail of a PWA block, PWA.py:437 with attention_utils.py:45-71.  Backward: dx is the
+ *            complete input gradient INCLUDING the residual branch (dout + ...); dgamma / dbeta are accumulated.
+ *   dw1, db1, dw2, db2 are accumulated (float atomics, one per element and block).  Dropout: site1 / p1 on the hidden activation (masks of
+ *   vx_gelu_drop_*), site2 / p2 on the output (masks of vx_axpy_drop_*).  vx_mlp_supported: (C, R) in {(16,48), (32,96), (16,32), (32,64)}, V % 4 == 0.
+ * --------------------------------------------------------------------------------------------- */
+int vx_mlp_supported(int C, int R, long V);
+int vx_mlp_bwd_nparts(int B, int C, long V);
+int vx_mlp_fwd(const float* x, int norm, const double* part, int nparts, float* stats, const float* gamma, const float* beta,
+               const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int C, int R, long V, float eps,
+               const void* seed_ptr, unsigned long long site1, float p1, unsigned long long site2, float p2, void* stream);
+int vx_mlp_bwd(const float* x, int norm, const float* stats, const float* gamma, const float* beta, const float* w1, const float* b1,
+               const float* w2, const float* dout, float* dx, float* part_out, float* dgamma, float* dbeta, float* dw1, float* db1,
+               float* dw2, float* db2, int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site1, float p1,
+               unsigned long long site2, float p2, void* stream);
+/* JLC spatial stage o = x + sum_{k=1,3,5} GELU(IN(gconv_k(x))) (conv_blocks.py:51-58,72-73); group width C/G a multiple of 4, V % 4 == 0.
+ *   vx_jlc_conv_fwd: y1, y3, y5 = the three grouped convs from one LDS halo tile; part [3][B*C][vx_jlc_ntiles][2] doubles = (sum, sumsq) per tile
+ *   vx_jlc_mid_fwd : stats_y [3][B*C][2] = (mean, rstd) of y_k (written); o; part_o [B*C][vx_jlc_nchunks][2] doubles = (sum, sumsq) of o per chunk
+ *   vx_jlc_mid_bwd : d_o = dout + IN-backward(dn; part_dn from vx_mlp_bwd); part_t [3][B*C][vx_jlc_nchunks][2] floats = (sum t_k, sum t_k*yhat_k),
+ *                    t_k = d_o * GELU'(yhat_k)
+ *   vx_jlc_gk      : g_k = rstd_k (t_k - mean t_k - yhat_k mean(t_k yhat_k)), the gradients at the conv outputs
+ *   vx_jlc_conv_bwd: dx = d_o + sum_k conv_k^T(g_k) */
+int vx_jlc_ntiles(int B, int C, int G, int D, int H, int W);
+int vx_jlc_nchunks(long BC, long V);
+int vx_jlc_conv_fwd(const float* x, const float* w1, const float* w3, const float* w5, const float* b1, const float* b3, const float* b5,
+                    float* y1, float* y3, float* y5, double* part, int B, int C, int G, int D, int H, int W, void* stream);
+int vx_jlc_mid_fwd(const float* x, const float* y1, const float* y3, const float* y5, const double* part_y, int nty, float* stats_y, float* o,
+                   double* part_o, long BC, long V, float eps, void* stream);
+int vx_jlc_mid_bwd(const float* dout, const float* dn, const float* part_dn, int npd, const float* o, const float* stats_o, const float* y1,
+                   const float* y3, const float* y5, const float* stats_y, float* d_o, float* part_t, long BC, long V, void* stream);
+int vx_jlc_gk(const float* d_o, const float* y1, const float* y3, const float* y5, const float* stats_y, const float* part_t, float* g1, float* g3,
+              float* g5, long BC, long V, void* stream);
+int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5, const float* w1, const float* w3, const float* w5, const float* d_o,
+                    float* dx, int B, int C, int G, int D, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
  * Encoder.py:334-337, Decoder.py:54-57).  stats[2*bc] = mean, stats[2*bc+1] = rstd.
  *   vx_in_apply_fwd: out = (res?res:0) + sum_{k<nk} act((y_k-mean_k)*rstd_k), act 0=identity 1=exact GELU

@@ -1,0 +1,175 @@
+"""GPU parity of the fused block kernels (csrc/jlc.hip, csrc/mlp.hip): the JLC block (reference conv_blocks.py:41-75) and the FFN tail
+(PWA.py:437 + attention_utils.py:45-71), forward + every gradient,
+  (a) against the CPU oracle with dropout off (tolerances stated per test, fp32), and
+  (b) against the per-operator kernels of the same library with dropout ON (same Philox masks: outputs equal to summation-order noise)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import veloxseg_oracle as O  # noqa: E402  (checker only)
+
+
+def _close(a, b, atol, rtol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    if not bool((err <= tol).all()):
+        i = int((err - tol).argmax())
+        raise AssertionError(f"{what}: max abs err {float(err.max()):.3e} (ref max {float(b.abs().max()):.3e}); worst idx {i}: got {float(a.flatten()[i]):.6e} "
+                             f"want {float(b.flatten()[i]):.6e}; bad frac {float((err > tol).double().mean()):.3e}")
+
+
+def _jlc_module(C, groups, r, p, seed):
+    from veloxseg_amd.model.components.conv_blocks import JLC
+    from veloxseg_amd import functional as VF
+    torch.manual_seed(seed)
+    VF.reset_dropout_sites()          # the same dropout stream for every module built by this helper
+    m = JLC(C, kernel_sizes=(1, 3, 5), groups=groups, epansion_factor=r, dropout=p)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.copy_(torch.randn_like(q) * (0.3 if q.dim() > 1 else 0.1))
+    return m
+
+
+def _oracle_sd(m, pre="blk."):
+    return {pre + k: v.detach().clone().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+
+
+JLC_CASES = [
+    # name, B, C, groups, expansion, spatial
+    ("L1_w4_32cube", 2, 16, 4, 3, (32, 32, 32)),
+    ("L2_w8_16cube", 2, 32, 4, 3, (16, 16, 16)),
+    ("L1_aniso", 1, 16, 4, 3, (8, 12, 20)),
+    ("L2_small", 2, 32, 4, 3, (8, 8, 8)),
+    ("w16", 1, 32, 2, 3, (8, 8, 16)),
+]
+
+
+@pytest.mark.parametrize("case", JLC_CASES, ids=[c[0] for c in JLC_CASES])
+def test_fused_jlc_block_vs_oracle(case):
+    """fused path == oracle.jlc (p = 0): output 2e-4 abs / 2e-4 rel, gradients 1e-3 relative to the gradient's scale"""
+    from veloxseg_amd import functional as VF
+    _, B, C, G, r, sp = case
+    cm = VF.cpp_module()
+    assert cm is not None
+    m = _jlc_module(C, G, r, 0.0, 3).cuda().train()
+    x = torch.randn(B, C, *sp, generator=torch.Generator().manual_seed(5))
+    xg = x.cuda().requires_grad_(True)
+    cm.set_fuse_blocks(True)
+    out = m(xg)
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(6))
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    sd = _oracle_sd(m)
+    xc = x.clone().requires_grad_(True)
+    ref = O.jlc(xc, sd, "blk.", G, 0.0, True)
+    ref.backward(gy)
+    _close(out, ref, 2e-4, 2e-4, "jlc out")
+    _close(xg.grad, xc.grad, 1e-3 * float(xc.grad.abs().max()), 1e-3, "jlc dx")
+    for k, p in m.named_parameters():
+        g_ref = sd["blk." + k].grad
+        if "spatial_convs" in k and k.endswith("bias"):
+            continue       # behind an InstanceNorm: zero by construction (the reference's value is round-off); not computed
+        _close(p.grad, g_ref, 2e-3 * float(g_ref.abs().max()) + 1e-6, 2e-3, f"jlc d{k}")
+
+
+@pytest.mark.parametrize("case", JLC_CASES[:3], ids=[c[0] for c in JLC_CASES[:3]])
+def test_fused_jlc_block_equals_per_operator_kernels_with_dropout(case):
+    from veloxseg_amd import functional as VF
+    _, B, C, G, r, sp = case
+    cm = VF.cpp_module()
+    res = {}
+    try:
+        for fused in (True, False):
+            cm.set_fuse_blocks(fused)
+            m = _jlc_module(C, G, r, 0.1, 3).cuda().train()
+            VF.manual_seed(77, "cuda")
+            x = torch.randn(B, C, *sp, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+            out = m(x)
+            gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).cuda()
+            out.backward(gy)
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        cm.set_fuse_blocks(True)
+    _close(res[True][0], res[False][0], 1e-4, 1e-4, "out")
+    _close(res[True][1], res[False][1], 1e-3 * float(res[False][1].abs().max()), 1e-3, "dx")
+    for k in res[True][2]:
+        if "spatial_convs" in k and k.endswith("bias"):
+            continue
+        g = res[False][2][k]
+        _close(res[True][2][k], g, 2e-3 * float(g.abs().max()) + 1e-6, 2e-3, f"d{k}")
+
+
+FFN_CASES = [("L1", 2, 16, 3, (16, 16, 32)), ("L2", 2, 32, 3, (8, 16, 16)), ("ragged", 1, 16, 3, (6, 6, 7 * 4))]
+
+
+def _ffn_modules(C, r, p, seed):
+    from veloxseg_amd.model.components.attention_utils import FFN, LayerNorm
+    from veloxseg_amd import functional as VF
+    torch.manual_seed(seed)
+    VF.reset_dropout_sites()
+    ffn = FFN(C, expansion_ratio=r, dropout_rate=p)
+    ln = LayerNorm(C)
+    with torch.no_grad():
+        for q in list(ffn.parameters()) + list(ln.parameters()):
+            q.copy_(torch.randn_like(q) * 0.3 + (1.0 if q is ln.weight else 0.0))
+    return ffn, ln
+
+
+@pytest.mark.parametrize("case", FFN_CASES, ids=[c[0] for c in FFN_CASES])
+def test_fused_ffn_tail_vs_oracle(case):
+    """y + FFN(LN(y)) fused == oracle (p = 0)"""
+    from veloxseg_amd import functional as VF
+    _, B, C, r, sp = case
+    cm = VF.cpp_module()
+    cm.set_fuse_blocks(True)
+    ffn, ln = _ffn_modules(C, r, 0.0, 4)
+    ffn, ln = ffn.cuda().train(), ln.cuda().train()
+    y = torch.randn(B, C, *sp, generator=torch.Generator().manual_seed(8))
+    yg = y.cuda().requires_grad_(True)
+    out = VF.ffn_tail(yg, ln, ffn, 0.0)
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    sd = {"f." + k: v.detach().clone().cpu().requires_grad_(True) for k, v in ffn.state_dict().items()}
+    lw, lb = ln.weight.detach().clone().cpu().requires_grad_(True), ln.bias.detach().clone().cpu().requires_grad_(True)
+    yc = y.clone().requires_grad_(True)
+    ref = yc + O.ffn(O.layernorm_cf(yc, lw, lb), sd, "f.", 0.0, True)
+    ref.backward(gy)
+    _close(out, ref, 2e-4, 2e-4, "ffn out")
+    _close(yg.grad, yc.grad, 1e-3 * float(yc.grad.abs().max()), 1e-3, "ffn dy")
+    for k, p in ffn.named_parameters():
+        g = sd["f." + k].grad
+        _close(p.grad, g, 2e-3 * float(g.abs().max()) + 1e-6, 2e-3, f"ffn d{k}")
+    _close(ln.weight.grad, lw.grad, 2e-3 * float(lw.grad.abs().max()), 2e-3, "dgamma")
+    _close(ln.bias.grad, lb.grad, 2e-3 * float(lb.grad.abs().max()), 2e-3, "dbeta")
+
+
+@pytest.mark.parametrize("case", FFN_CASES[:2], ids=[c[0] for c in FFN_CASES[:2]])
+def test_fused_ffn_tail_equals_per_operator_kernels_with_dropout(case):
+    from veloxseg_amd import functional as VF
+    _, B, C, r, sp = case
+    cm = VF.cpp_module()
+    res = {}
+    try:
+        for fused in (True, False):
+            cm.set_fuse_blocks(fused)
+            ffn, ln = _ffn_modules(C, r, 0.1, 4)
+            ffn, ln = ffn.cuda().train(), ln.cuda().train()
+            VF.manual_seed(91, "cuda")
+            y = torch.randn(B, C, *sp, generator=torch.Generator().manual_seed(8)).cuda().requires_grad_(True)
+            out = VF.ffn_tail(y, ln, ffn, 0.1)
+            gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).cuda()
+            out.backward(gy)
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().clone(), y.grad.clone(), {k: p.grad.clone() for k, p in list(ffn.named_parameters()) + [("ln." + n, q) for n, q in ln.named_parameters()]})
+    finally:
+        cm.set_fuse_blocks(True)
+    _close(res[True][0], res[False][0], 1e-4, 1e-4, "out")
+    _close(res[True][1], res[False][1], 1e-3 * float(res[False][1].abs().max()), 1e-3, "dy")
+    for k in res[True][2]:
+        g = res[False][2][k]
+        _close(res[True][2][k], g, 2e-3 * float(g.abs().max()) + 1e-6, 2e-3, f"d{k}")

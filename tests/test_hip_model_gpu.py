@@ -227,13 +227,15 @@ def test_composite_blocks_equal_the_fine_grained_operators():
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
     for a, b in zip(res[True][1], res[False][1]):        # (the Gram outputs are float-atomic sums: equal to round-off, not bit for bit; the fused
         # epilogues -- GELU, residual + dropout inside the 1x1 convs -- round alpha*res + mask*conv in a different order than the separate kernels: 1-2 ulp)
-        assert float((a - b).abs().max()) <= 4e-6 * max(1.0, float(b.abs().max()))
-    assert torch.equal(res[True][3], res[False][3])
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    # eval logits: the composite path runs the fused block kernels (csrc/jlc.hip, csrc/mlp.hip: other summation order, GELU through the
+    # A&S 7.1.26 erf with <= 3e-7 absolute error), the per-operator path erff and separate kernels: equal to fp32 noise, not bit for bit
+    assert float((res[True][3] - res[False][3]).abs().max()) <= 2e-5 * max(1.0, float(res[False][3].abs().max()))
     for n, g in res[False][2].items():
         d_ = float((res[True][2][n] - g).abs().max())
         # floor 1e-6: biases in front of an InstanceNorm have a mathematically zero gradient; what both paths compute for them is ~1e-8 of
         # summation-order noise (float atomics), which differs from run to run
-        assert d_ <= 3e-5 * max(0.1, float(g.abs().max())), (n, d_)          # fused epilogues: 1-2 ulp differences in the forward, amplified at the 4^3 level
+        assert d_ <= 2e-4 * max(0.1, float(g.abs().max())), (n, d_)          # fused blocks: fp32-noise differences in the forward, amplified at the 4^3 level
 
 
 @pytest.mark.timeout(600)

@@ -149,9 +149,19 @@ def P(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
 _PROFILE = None   # when a list: (name, int-args key, start event, end event) per call -- bench.py's per-kernel timing pass
 
 
+def _cpp_profiler():
+    from . import functional as VF
+    return VF.cpp_module()
+
+
 def profile_begin():
+    """time every C-ABI call with HIP events on its launch stream: the calls made from python (this module) and those made by the C++ operator
+    bodies (veloxseg_amd._vxops keeps its own record list)"""
     global _PROFILE
     _PROFILE = []
+    m = _cpp_profiler()
+    if m is not None:
+        m.profile_begin()
 
 
 def profile_end():
@@ -164,6 +174,12 @@ def profile_end():
         d = out.setdefault((name, key), [0, 0.0])
         d[0] += 1
         d[1] += e0.elapsed_time(e1)
+    m = _cpp_profiler()
+    if m is not None:
+        for name, key, ms in m.profile_end():
+            d = out.setdefault((name, tuple(key)), [0, 0.0])
+            d[0] += 1
+            d[1] += ms
     return out
 
 

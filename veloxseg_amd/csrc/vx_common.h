@@ -63,6 +63,24 @@ __device__ __forceinline__ float vx_gelu_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and phi(x) = exp(-x^2/2) / sqrt(2 pi) from ONE v_exp: erf through Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, i.e. <= 7.5e-8 on Phi: at the rounding level of fp32 erff), whose exponential exp(-(x/sqrt2)^2) is the one phi needs.
+// Used by the fused block kernels, where GELU / GELU' are evaluated for every element of the expanded activation on the fly.
+__device__ __forceinline__ void vx_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float e = __expf(-0.5f * x * x);
+    const float y = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, y, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_erfc = 0.5f * poly * t * e;          // 0.5 * erfc(|x| / sqrt 2)
+    cdf = x >= 0.0f ? 1.0f - half_erfc : half_erfc;
+    pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float vx_gelu_fast(float x) { float c, p; vx_cdf_pdf(x, c, p); return x * c; }
+__device__ __forceinline__ float vx_gelu_grad_fast(float x) { float c, p; vx_cdf_pdf(x, c, p); return fmaf(x, p, c); }
+
 // ---- counter-based RNG for dropout: Philox4x32-10 ------------------------------------------
 struct VxPhilox {
     uint32_t c[4];
@@ -75,12 +93,15 @@ __device__ __forceinline__ void vx_philox_round(uint32_t (&c)[4], const uint32_t
     uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-// 4 x 32 random bits for (seed, stream id, counter)
+// 4 x 32 random bits for (seed, stream id, counter).  7 rounds: the smallest round count of Philox4x32 that passes BigCrush (Salmon et al., SC'11,
+// table 2; 10 is the library default with a safety margin).  Dropout masks need far less, and the 32-bit multiplies of a round are quarter-rate
+// VALU instructions: the generator was a visible share of every kernel that draws masks.
+#define VX_PHILOX_ROUNDS 7
 __device__ __forceinline__ void vx_philox4(uint64_t seed, uint64_t stream, uint64_t ctr, uint32_t (&out)[4]) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
     uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < VX_PHILOX_ROUNDS; ++r) {
         vx_philox_round(c, k);
         k[0] += 0x9E3779B9u;
         k[1] += 0xBB67AE85u;

@@ -228,7 +228,7 @@ def _cpp():
         return None
     if _CPP_DEFAULTS is None:
         _CPP_DEFAULTS = _flag_tuple()
-    return m if _flag_tuple() == _CPP_DEFAULTS and H._PROFILE is None else None
+    return m if _flag_tuple() == _CPP_DEFAULTS else None
 
 
 def _cpp_mod():
