@@ -14,7 +14,7 @@ Fixtures (all fp32, CPU, torch.manual_seed-ed; see CASES below):
                    grads_sample{param->tensor for a few small params})
   ops.pt    : per-op micro goldens (LayerNorm, gather/scatter, attention w/ bias M=2, PatchMerging,
               JLC, DownConv, UpConv, PixelShuffle, Gram, DiceLoss/CE, full Loss)
-Usage: python tests/golden/make_golden.py
+Usage: python tests/golden/make_golden.py [case ...]      (no argument = every case + ops.pt)
 """
 import os
 import sys
@@ -103,7 +103,7 @@ def install_stub():
 
 
 sys.path.insert(0, HERE)
-from recipe import CASES, LOSS_CFG, fill_state_dict, make_inputs, tensor_sha, sd_sha, compact  # noqa: E402
+from recipe import BIG_CASES, CASES, LOSS_CFG, fill_state_dict, make_inputs, tensor_sha, sd_sha, compact, pack_mask  # noqa: E402
 
 
 def make_case(name, cfg, B):
@@ -138,7 +138,7 @@ def make_case(name, cfg, B):
     small = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.numel() <= 600}
     fix = dict(config=cfg, batch=B, init_seed=12345, init_sha256=init_sha, sd_seed=7, sd_sha256=sd_sha(sd), sd_keys=list(sd.keys()),
                sd_shapes={k: list(v.shape) for k, v in sd.items()}, x_sha256=tensor_sha(x), labels_sha256=tensor_sha(labels),
-               eval_logits=compact(logits), argmax=logits.argmax(1).to(torch.uint8),
+               eval_logits=compact(logits), argmax=(pack_mask(logits.argmax(1).to(torch.uint8), cfg["n_classes"]) if name in BIG_CASES else logits.argmax(1).to(torch.uint8)),
                train_outputs=[compact(o) for o in outs], loss=float(loss),
                loss_cfg=LOSS_CFG, grad_norms=grad_norms, grads_small=small)
     torch.save(fix, os.path.join(HERE, name + ".pt"))
@@ -274,6 +274,9 @@ if __name__ == "__main__":
     install_stub()
     atexit.register(lambda: shutil.rmtree(sys.path[1], ignore_errors=True) if "monai_stub_" in sys.path[1] else None)
     torch.set_num_threads(8)
-    make_ops()
+    only = sys.argv[1:]                      # optional: case names to (re)generate; default = everything
+    if not only:
+        make_ops()
     for name, (cfg, B) in CASES.items():
-        make_case(name, cfg, B)
+        if not only or name in only:
+            make_case(name, cfg, B)

@@ -64,12 +64,40 @@ def sd_sha(sd: dict) -> str:
 
 
 def compact(t: torch.Tensor, limit: int = 70000) -> dict:
-    """Small tensors in full; big ones as shape + sums + a stride-3 spatial subsample."""
+    """Small tensors in full; big ones as shape + sums + a strided spatial subsample (stride 3; coarser -- recorded as "stride" -- for the
+    128^3 cases so that a fixture stays well under 2 MB)."""
     t = t.detach()
     if t.numel() <= limit:
         return {"full": t.clone()}
-    return {"shape": list(t.shape), "sum": float(t.double().sum()), "abs_sum": float(t.double().abs().sum()),
-            "strided": t[..., ::3, ::3, ::3].clone()}
+    st = 3
+    while t[..., ::st, ::st, ::st].numel() > 45000:
+        st += 1
+    out = {"shape": list(t.shape), "sum": float(t.double().sum()), "abs_sum": float(t.double().abs().sum()),
+           "strided": t[..., ::st, ::st, ::st].clone()}
+    if st != 3:
+        out["stride"] = st
+    return out
+
+
+def pack_mask(am: torch.Tensor, ncls: int) -> dict:
+    """arg-max mask (uint8, values < ncls <= 4) as bit planes: 1/8 (2 classes) or 1/4 (<= 4 classes) of a byte per voxel"""
+    import numpy as np
+    a = am.detach().cpu().numpy().astype(np.uint8)
+    planes = [np.packbits((a >> k) & 1) for k in range(1 if ncls <= 2 else 2)]
+    return {"shape": list(a.shape), "planes": [torch.from_numpy(p.copy()) for p in planes]}
+
+
+def unpack_mask(d) -> torch.Tensor:
+    import numpy as np
+    if torch.is_tensor(d):
+        return d
+    n = 1
+    for s in d["shape"]:
+        n *= s
+    out = np.zeros(n, dtype=np.uint8)
+    for k, p in enumerate(d["planes"]):
+        out |= (np.unpackbits(p.numpy())[:n] << k).astype(np.uint8)
+    return torch.from_numpy(out.reshape(d["shape"]))
 
 
 def check_compact(t: torch.Tensor, ref: dict, atol: float, rtol: float, what: str = ""):
@@ -78,7 +106,8 @@ def check_compact(t: torch.Tensor, ref: dict, atol: float, rtol: float, what: st
         torch.testing.assert_close(t, ref["full"], atol=atol, rtol=rtol, msg=lambda m: f"{what}: {m}")
         return
     assert list(t.shape) == ref["shape"], (what, t.shape, ref["shape"])
-    torch.testing.assert_close(t[..., ::3, ::3, ::3], ref["strided"], atol=atol, rtol=rtol, msg=lambda m: f"{what}: {m}")
+    st = ref.get("stride", 3)
+    torch.testing.assert_close(t[..., ::st, ::st, ::st], ref["strided"], atol=atol, rtol=rtol, msg=lambda m: f"{what}: {m}")
     s = float(t.double().abs().sum())
     assert abs(s - ref["abs_sum"]) <= rtol * 10 * ref["abs_sum"] + atol, (what, s, ref["abs_sum"])
 
@@ -102,5 +131,11 @@ CASES = {
     # G4: anisotropic Hecktor-style windows (config/models_config_hecktor2022.json), 64x64x32, patch 2
     "g4_aniso_m2": (dict(BASE, input_size=[64, 64, 32], patch_size=2, in_ch=[1, 1],
                          min_big_window_sizes=[[4, 4, 2], [8, 8, 4], [4, 4, 2], [4, 4, 2]]), 2),
+    # G5 / G6: the HEADLINE shapes (BASELINE.json configs[2] / configs[1]): 128^3 patches, patch 4, windows [4,8,4,4], batch 1
+    "g5_128_m2": (dict(BASE, input_size=[128, 128, 128], patch_size=4, in_ch=[1, 1],
+                       min_big_window_sizes=[[4] * 3, [8] * 3, [4] * 3, [4] * 3]), 1),
+    "g6_128_brats": (dict(BASE, input_size=[128, 128, 128], patch_size=4, in_ch=[4], n_classes=4,
+                          min_big_window_sizes=[[4] * 3, [8] * 3, [4] * 3, [4] * 3]), 1),
 }
+BIG_CASES = ("g5_128_m2", "g6_128_brats")      # fixtures store the arg-max mask bit-packed and coarser subsamples
 LOSS_CFG = {"deep_Loss_weight": [1, 1, 1, 1], "RC_Loss_weight": 0.5, "Feature_Loss_weight": 2.0}

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import veloxseg_oracle as O  # noqa: E402
-from recipe import CASES, LOSS_CFG, check_compact, fill_state_dict, make_inputs  # noqa: E402
+from recipe import CASES, LOSS_CFG, check_compact, fill_state_dict, make_inputs, unpack_mask  # noqa: E402
 
 
 def _build(name):
@@ -38,6 +38,7 @@ def test_eval_logits_vs_oracle_and_golden(golden_dir, name):
     assert bool((am == amr)[confident].all()), "argmax differs on a voxel whose margin exceeds the tolerance"
     fix = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
     check_compact(logits, fix["eval_logits"], 2e-4, 2e-4, "eval logits vs reference golden")
+    fix["argmax"] = unpack_mask(fix["argmax"])
     mism = float((am.to(torch.uint8) != fix["argmax"]).float().mean())
     assert mism <= 1e-5, f"argmax vs reference golden differs on {mism:.2e} of voxels"
     # Dice delta vs the reference (north-star bar: < 1e-3): Dice of our mask and of the reference's golden mask against the same labels,
@@ -52,7 +53,7 @@ def test_eval_logits_vs_oracle_and_golden(golden_dir, name):
     assert abs(d_ours - d_ref) < 1e-3, (d_ours, d_ref)
 
 
-@pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2"])
+@pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2", "g6_128_brats"])
 def test_train_step_vs_oracle(golden_dir, name):
     from veloxseg_amd.utils.loss import Loss
     import types

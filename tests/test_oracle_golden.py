@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import veloxseg_oracle as O
-from recipe import CASES, LOSS_CFG, check_compact, fill_state_dict, make_inputs, sd_sha, tensor_sha
+from recipe import CASES, LOSS_CFG, check_compact, fill_state_dict, make_inputs, sd_sha, tensor_sha, unpack_mask
 
 ATOL, RTOL = 2e-4, 2e-4
 
@@ -40,11 +40,11 @@ def test_eval_logits_and_argmax(golden_dir, name):
         logits = O.forward(x, sd, cfg, training=False)
     check_compact(logits, fix["eval_logits"], ATOL, RTOL, "eval logits")
     am = logits.argmax(1).to(torch.uint8)
-    mism = (am != fix["argmax"]).float().mean().item()
+    mism = (am != unpack_mask(fix["argmax"])).float().mean().item()
     assert mism == 0.0, f"argmax differs on {mism:.2e} of voxels"
 
 
-@pytest.mark.parametrize("name", ["g1_48_m2", "g3_64_brats", "g4_aniso_m2"])
+@pytest.mark.parametrize("name", ["g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2"])
 def test_train_outputs_loss_grads(golden_dir, name):
     fix, cfg, sd, x, labels = _case(golden_dir, name)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}

@@ -34,15 +34,18 @@ __global__ void __launch_bounds__(256) vx_seg_loss_fwd_k(const float* __restrict
             float z[VX_MAXC], mx = -INFINITY;
 #pragma unroll
             for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = lg[(long)c * V + v]; mx = fmaxf(mx, z[c]); }
-            float se = 0.0f;
+            float se = 0.0f, zy = 0.0f;
 #pragma unroll
-            for (int c = 0; c < VX_MAXC; ++c) if (c < C) { z[c] = expf(z[c] - mx); se += z[c]; }
+            for (int c = 0; c < VX_MAXC; ++c) if (c < C) { if (c == y) zy = z[c]; z[c] = expf(z[c] - mx); se += z[c]; }
             const float inv = 1.0f / se;
+            // cross entropy through log-sum-exp, as nn.CrossEntropyLoss computes it: grows linearly with the logit gap instead of saturating at
+            // -log(FLT_MIN) like -log(softmax) does (labels outside [0, C) contribute nothing; the python surface validates the range)
+            if ((unsigned)y < (unsigned)C) ce += (mx + logf(se)) - zy;
 #pragma unroll
             for (int c = 0; c < VX_MAXC; ++c) if (c < C) {
                 const float p = z[c] * inv;
                 P[c] += p;
-                if (c == y) { I[c] += p; T[c] += 1.0f; ce -= logf(fmaxf(p, 1e-38f)); }
+                if (c == y) { I[c] += p; T[c] += 1.0f; }
             }
         }
         double* __restrict__ ah = acc + (long)h * (1 + (long)B * C * 3);
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_fwd4_k(const float* __restric
                     for (int c = 0; c < C; ++c) {
                         const float pc = e[c] * inv;
                         S[h][1 + C + c] += pc;
-                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] -= logf(fmaxf(pc, 1e-38f)); }
+                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + logf(se)) - z[c][j]; }     // CE = logsumexp - z_y (nn.CrossEntropyLoss)
                     }
                 }
             }
