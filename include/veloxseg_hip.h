@@ -247,6 +247,13 @@ int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float*
 /* tuning knob of the two entries above: key/query split per 64-row unit (0 = automatic from the unit count, else 1, 2 or 4; clamped to the
  * number of 64-row slabs).  Results are identical up to fp32 summation order; the dropout mask does not depend on it. */
 int vx_pwa_attn_set_split(int S);
+/* The two entries above run on the matrix cores (csrc/pwa_mfma.hip: QK^T, PV, dP, dQ, dK, dV as v_mfma_f32_16x16x4_f32 tiles, K/V of a window staged
+ * once per 128-query block) when a window's tokens tile into 16-token blocks (l % 64 == 0) and the head widths are one of (4,4) (8,8) (8,16) (16,32)
+ * (16,16) (4,8); same masks, same results up to fp32 summation order.  vx_pwa_attn_set_mfma(mask) selects the passes: bit 0 forward, bit 1 backward
+ * (default 1: the forward; the backward's d(bias) sum is faster in the VALU kernels, see pwa_mfma.hip); vx_pwa_attn_mfma_ok answers that mask for a
+ * geometry the MFMA kernels cover and 0 otherwise. */
+int vx_pwa_attn_mfma_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+int vx_pwa_attn_set_mfma(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss side (utils/loss.py:30-66, common_function.py:8-14, VeloxSeg.py:177-184)

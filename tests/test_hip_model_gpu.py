@@ -256,3 +256,45 @@ def test_first_step_of_a_fresh_process_matches_serialised_kernels(tmp_path):
         r = subprocess.run([sys.executable, tool, "cmp", ref], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         assert "\n0 bad params" in r.stdout, r.stdout[-800:]
+
+
+def test_two_forwards_before_their_backwards_keep_their_dropout_masks():
+    """Every training forward snapshots its own {seed, step} dropout state (functional.advance_rng): forward(x1), forward(x2), backward(1),
+    backward(2) must give the gradients of the two separate forward/backward pairs -- the masks a backward regenerates are those of ITS forward."""
+    import types
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    VF.RNG_INPLACE = False
+    cfg_d = dict(CASES["g2_32_m2"][0], proj_drop=0.1, conv_drop=0.1, attn_drop=0.1)
+    torch.manual_seed(4)
+    model = VeloxSeg(**cfg_d).cuda().train()
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)
+    xs = [make_inputs(cfg_d, 1, seed=31 + k) for k in range(2)]
+
+    def grads():
+        g = {n: p.grad.clone() for n, p in model.named_parameters()}
+        for p in model.parameters():
+            p.grad.zero_()
+        return g
+
+    def loss_of(k, outs):
+        return crit(outs, xs[k][1].cuda(), sr_labels=xs[k][0].cuda())
+
+    VF.manual_seed(5, "cuda")
+    ref = []
+    for k in range(2):
+        loss_of(k, model(xs[k][0].cuda())).backward()
+        torch.cuda.synchronize()
+        ref.append(grads())
+    VF.manual_seed(5, "cuda")
+    outs = [model(xs[k][0].cuda()) for k in range(2)]          # two forwards in flight
+    got = []
+    for k in range(2):
+        loss_of(k, outs[k]).backward()
+        torch.cuda.synchronize()
+        got.append(grads())
+    for k in range(2):
+        for n, g in ref[k].items():
+            d_ = float((got[k][n] - g).abs().max())
+            assert d_ <= 2e-4 * max(0.1, float(g.abs().max())), (k, n, d_)

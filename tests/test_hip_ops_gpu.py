@@ -280,7 +280,7 @@ def test_pwa_attention_dropout_and_key_splits(grid, big, heads, mdh, C):
         rhs0 = float((base[2].to(d).double() * g0[2].double()).sum())
         assert abs(lhs0 - rhs0) <= 2e-4 * max(1.0, abs(rhs0)), ("v adjoint", lhs0, rhs0)
         dirq = rnd(*base[3].shape, seed=91)
-        eps = 1e-2
+        eps = 3e-3          # small: every arg-max switch of the max-pooled window scales that the step crosses is a kink of the forward map
         vals = []
         for sgn in (+1, -1):
             tt = [b.clone() for b in base]
@@ -289,7 +289,7 @@ def test_pwa_attention_dropout_and_key_splits(grid, big, heads, mdh, C):
             vals.append(sum(float((o.double() * g.double()).sum()) for o, g in zip(oo, gouts)))
         fd = (vals[0] - vals[1]) / (2 * eps)
         an = float((g0[3].double() * dirq.to(d).double()).sum())
-        assert abs(fd - an) <= 5e-2 * max(1.0, abs(an)), ("q directional derivative", fd, an)
+        assert abs(fd - an) <= 1e-1 * max(1.0, abs(an)), ("q directional derivative", fd, an)     # (a mask mismatch between forward and dQ pass shows as an O(1) error)
         # (c) mask statistics
         flat = [torch.zeros_like(b) if i % 3 != 2 else torch.ones_like(b) for i, b in enumerate(base)]
         table0 = table.detach() * 0
@@ -600,3 +600,38 @@ def test_loss_backward_one_launch_for_all_heads_equals_per_head_launches():
         VF.USE_LOSS_BWD4 = True
     for i, (a, b) in enumerate(zip(*res)):          # the 4-voxel kernel contracts / rounds the soft-max normalisation differently: a few ulp
         close(a, b, 2e-6 * max(1e-3, float(b.abs().max())), 1e-5, f"grad {i}")
+
+
+@pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),
+                                                    ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 1), ([16, 16, 16], [8, 8, 8], 2, 8, 32, 1)],
+                         ids=["c8v8_ML1024", "c8v16", "c16v32", "c4v8", "c4v4_M1", "c8v8_M1"])
+def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh, C, M):
+    """The MFMA attention kernels (csrc/pwa_mfma.hip) against the fp32-VALU kernels of the same library on the same inputs, dropout ON (p = 0.2: both
+    draw the same Philox words for the same (query, key) element): outputs, dq / dk / dv and the bias-table gradient agree to fp32 summation noise."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    H.call("vx_pwa_attn_set_mfma", 3)
+    assert H.query("vx_pwa_attn_mfma_ok", H.ctypes.addressof(plan), 2, M, pl["c_qk"], pl["c_v"]) == 3, "geometry is expected to take the MFMA path"
+    n = pl["n"]
+    base = []
+    for m in range(M):
+        base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
+    res = {}
+    try:
+        for on in (3, 0):            # 3 = forward AND backward on the MFMA kernels, 0 = the VALU kernels
+            H.call("vx_pwa_attn_set_mfma", on)
+            VF.manual_seed(77, d)
+            table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=0.2, site=9)
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gouts)
+            torch.cuda.synchronize()
+            res[on] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
+    finally:
+        H.call("vx_pwa_attn_set_mfma", 1)
+    for i, (a, b) in enumerate(zip(res[3], res[0])):
+        close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma vs valu tensor {i}")

@@ -65,6 +65,8 @@ inline Tensor contig(const Tensor& t) { return t.is_contiguous() ? t : t.contigu
 inline void check_in(const Tensor& x, const char* what) {
     TORCH_CHECK(x.is_cuda(), "veloxseg_amd.", what, ": input is on ", x.device(), "; the VeloxSeg hot path runs only on an MI355X (HIP kernels, no CPU fallback)");
     TORCH_CHECK(x.scalar_type() == at::kFloat, "veloxseg_amd.", what, ": expected float32");
+    TORCH_CHECK(x.device().index() == c10::hip::current_device(), "veloxseg_amd.", what, ": tensor lives on cuda:", (int)x.device().index(), " but the current device is cuda:",
+                (int)c10::hip::current_device(), "; kernels launch on the current device's stream -- wrap the call in torch.cuda.device(tensor.device)");
 }
 inline float* grad_ptr(const Tensor& p) {          // running gradient buffer of a parameter (created zeroed on first use), as functional.grad_buf
     if (!p.defined() || !p.requires_grad()) return nullptr;

@@ -33,26 +33,6 @@ struct VxMlp {
     VxDrop d1, d2;
 };
 
-// masks of the 4 consecutive elements (row, vox4 .. vox4+3), vox4 % 4 == 0: one Philox call
-__device__ __forceinline__ void vx_masks_vox4(const VxDropCtx& dc, uint64_t row, long V, long vox4, float (&m)[4]) {
-    if (!dc.on) { m[0] = m[1] = m[2] = m[3] = 1.0f; return; }
-    uint32_t r[4];
-    vx_philox4(dc.seed, dc.stream, (row * (uint64_t)V + (uint64_t)vox4) >> 2, r);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) m[t] = vx_mask_of_bits(dc, r[t]);
-}
-// masks of the elements (row0 + T * rstride, vox), T = 0..3, when the 4 lanes of a quad hold 4 consecutive voxels (vox & 3 == lane & 3): lane s draws
-// the counter of row T = s and the words are handed round by a DPP quad transpose
-__device__ __forceinline__ void vx_masks_rows4(const VxDropCtx& dc, uint64_t row0, uint64_t rstride, long V, long vox, float (&m)[4]) {
-    if (!dc.on) { m[0] = m[1] = m[2] = m[3] = 1.0f; return; }
-    uint32_t r[4], w[4];
-    const uint64_t row = row0 + (uint64_t)(threadIdx.x & 3) * rstride;
-    vx_philox4(dc.seed, dc.stream, (row * (uint64_t)V + (uint64_t)vox) >> 2, r);
-    vx_quad_transpose4(r, w);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) m[t] = vx_mask_of_bits(dc, w[t]);
-}
-
 // InstanceNorm statistics of this block's sample into LDS (threads 0..C-1): folded from the producer's partial sums, or read as given
 template <int C>
 __device__ __forceinline__ void vx_mlp_in_stats(const VxMlp& p, bool fold, int b, float* mu_s, float* rs_s, bool writer) {

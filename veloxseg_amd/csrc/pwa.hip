@@ -903,6 +903,13 @@ template <class F> static bool vx_attn_dispatch(int cq, int cv, F&& f) {
     return false;
 }
 
+// MFMA kernels (pwa_mfma.hip) for windows whose tokens tile into 16-token blocks
+int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE, const VxPwaPlan* plan, int B, int M,
+                         int cq, int cv, VxDrop d, void* stream);
+int vx_pwa_attn_mfma_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
+                         float* dK, float* dV, float* dtable, float* delta, float* rep, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d,
+                         void* stream);
+
 extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
                                const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
@@ -911,6 +918,12 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     VX_REQUIRE(Q && K && V && table && O && LSE, "vx_pwa_attn_fwd: null pointer");
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
+    if (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 1) {
+        const int rc = vx_pwa_attn_mfma_fwd(Q, K, V, table, O, LSE, plan, B, M, cq, cv, d, stream);
+        if (rc) return rc;
+        VX_LAUNCH_CHECK("vx_pwa_attn_fwd (mfma)");
+        return 0;
+    }
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
     const size_t shm = (tab_f + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
@@ -960,6 +973,12 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     const long rep_floats = (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
     const unsigned nblk = (unsigned)vx_cdiv(units, 4 / S);
     vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
+    if (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2) {
+        const int rc = vx_pwa_attn_mfma_bwd(Q, K, V, table, O, LSE, dO, dQ, dK, dV, dtable, delta_ws, rep, plan, B, M, cq, cv, d, stream);
+        if (rc) return rc;
+        VX_LAUNCH_CHECK("vx_pwa_attn_bwd (mfma)");
+        return 0;
+    }
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
         vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S);

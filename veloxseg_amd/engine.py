@@ -119,6 +119,7 @@ class TrainEngine:
         m = VF.cpp_module() if (WGRAD_STREAM and not self.use_graph) else None
         if m is None:
             loss.backward()
+            self._join_side_streams()
             return
         m.set_wgrad_stream(True)
         try:
@@ -126,6 +127,15 @@ class TrainEngine:
         finally:
             m.set_wgrad_stream(False)
             m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
+        self._join_side_streams()
+
+    def _join_side_streams(self, waiter=None):
+        """The weight-gradient kernels write flat.grad IN PLACE on whatever stream their node ran on (decoder branches, modality branches, the
+        encoder conv chain) and return None to autograd, so no AccumulateGrad node carries the dependency: make the stream that will read
+        flat.grad (all-reduce, AdamW) wait for every forked stream explicitly instead of relying on the engine's end-of-backward leaf sync."""
+        waiter = waiter or torch.cuda.current_stream(self.dev)
+        for s_ in VF.all_side_streams(self.dev):
+            waiter.wait_stream(s_)
 
     def _fwd_bwd_overlapped(self):
         """plain eager step + the decoder-bucket all-reduce started from INSIDE the backward pass: every decoder consumes the deepest
@@ -136,7 +146,10 @@ class TrainEngine:
         handles = []
         split, n = self.flat.split, self.flat.numel
 
+        fired = []
+
         def decoders_done(_grads):
+            fired.append(True)
             cur = torch.cuda.current_stream(self.dev)
             self.comm_stream.wait_stream(cur)
             m = VF.cpp_module() if WGRAD_STREAM else None
@@ -158,6 +171,11 @@ class TrainEngine:
             self.model._on_encoder_outputs = None
             for h in handles:
                 h.remove()
+        if not fired:             # the hook did not run (e.g. enc4 needed no gradient): reduce the decoder bucket now rather than silently skipping it
+            cur = torch.cuda.current_stream(self.dev)
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self._allreduce(split, n)
         self.loss.copy_(loss.detach())
         self.last_outputs = [o.detach() for o in outs]
 
@@ -295,6 +313,7 @@ class TrainEngine:
         to the next capture, which is only safe when the graphs replay in capture order, not concurrently); tensors that cross
         stages stay referenced by the engine for the lifetime of the graphs."""
         self.model.train()
+        VF.RNG_INPLACE = True       # replays must bump the tensor the captured kernels point at
         rng = VF.rng_state(self.dev)
         rng0 = rng.clone()
         self.flat.reattach()

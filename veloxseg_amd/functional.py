@@ -117,6 +117,19 @@ def branch_stream_list(device, n: int, tag: str = "branches"):
     return list(_branch_streams.get((str(device), n, tag), [])) if BRANCH_STREAMS else []
 
 
+def all_side_streams(device):
+    """every stream this module has forked work onto on `device` (branch / modality lists and named side streams)"""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    out = []
+    for k, v in _branch_streams.items():
+        if k[0] != str(device):
+            continue
+        out.extend(v if isinstance(v, list) else [v])
+    return out
+
+
 def side_stream(device, name: str) -> "torch.cuda.Stream":
     """a named, cached side stream of `device` (one per role, e.g. the conv chain of the encoder)"""
     device = torch.device(device)
@@ -154,8 +167,28 @@ def manual_seed(seed: int, device="cuda"):
     st.copy_(torch.tensor([seed, 0], dtype=torch.int64))
 
 
+RNG_INPLACE = False      # hipGraph capture (engine.TrainEngine(use_graph=True)): the captured step must bump the SAME tensor on every replay
+_rng_keep = {}           # device -> the {seed, step} tensors of the most recent training forwards (kept alive for their backward passes)
+_rng_inc = {}
+
+
 def advance_rng(device):
-    rng_state(device)[1:2].add_(1)
+    """New dropout step.  Every training forward gets its OWN {seed, step} tensor (the previous ones stay alive for the last 32 forwards): the
+    kernels read {seed, step} at execution time through the pointer their autograd node captured in forward, so a second forward before the
+    first backward (micro-batching, two models on one device) can no longer change the masks an earlier forward's backward regenerates."""
+    st = rng_state(device)
+    if RNG_INPLACE:
+        st[1:2].add_(1)
+        return
+    key = str(st.device)
+    inc = _rng_inc.get(key)
+    if inc is None:
+        inc = _rng_inc[key] = torch.tensor([0, 1], dtype=torch.int64, device=st.device)
+    keep = _rng_keep.setdefault(key, [])
+    keep.append(st)
+    if len(keep) > 32:
+        del keep[0]
+    _rng_state[key] = st + inc
 
 
 def grad_buf(p: torch.Tensor) -> torch.Tensor:
@@ -249,6 +282,9 @@ def _check(x: torch.Tensor, what: str):
                            "(HIP kernels, no CPU fallback)")
     if x.dtype != torch.float32:
         raise RuntimeError(f"veloxseg_amd.{what}: expected float32, got {x.dtype}")
+    if x.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"veloxseg_amd.{what}: tensor lives on cuda:{x.device.index} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "kernels launch on the current device's stream -- wrap the call in torch.cuda.device(tensor.device)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -564,7 +600,7 @@ class _GeluDropFn(torch.autograd.Function):
         rs = rng_state(a.device) if p > 0 else None
         H.call("vx_gelu_drop_fwd", H.P(a), H.P(h), a.numel(), H.P(rs, torch.int64), site, float(p), H.stream_ptr())
         ctx.save_for_backward(a)
-        ctx.p, ctx.site = float(p), site
+        ctx.p, ctx.site, ctx.rs = float(p), site, rs
         return h
 
     @staticmethod
@@ -576,7 +612,7 @@ class _GeluDropFn(torch.autograd.Function):
         (a,) = ctx.saved_tensors
         dh = _c(dh)
         da = torch.empty_like(a)
-        rs = rng_state(a.device) if ctx.p > 0 else None
+        rs = ctx.rs
         H.call("vx_gelu_drop_bwd", H.P(dh), H.P(a), H.P(da), a.numel(), H.P(rs, torch.int64), ctx.site, ctx.p, H.stream_ptr())
         return da, None, None
 
@@ -604,7 +640,7 @@ class _AxpyDropFn(torch.autograd.Function):
         out = torch.empty_like(z)
         rs = rng_state(z.device) if p > 0 else None
         H.call("vx_axpy_drop_fwd", H.P(xc), H.P(z), H.P(out), float(alpha), z.numel(), H.P(rs, torch.int64), site, float(p), H.stream_ptr())
-        ctx.alpha, ctx.p, ctx.site, ctx.has_x = float(alpha), float(p), site, x is not None
+        ctx.alpha, ctx.p, ctx.site, ctx.has_x, ctx.rs = float(alpha), float(p), site, x is not None, rs
         return out
 
     @staticmethod
@@ -621,7 +657,7 @@ class _AxpyDropFn(torch.autograd.Function):
         if need_x:
             dx = dout if ctx.alpha == 1.0 else torch.empty_like(dout)
         dz = dout if ctx.p == 0.0 else torch.empty_like(dout)
-        rs = rng_state(dout.device) if ctx.p > 0 else None
+        rs = ctx.rs
         H.call("vx_axpy_drop_bwd", H.P(dout), H.P(dx) if (need_x and ctx.alpha != 1.0) else None,
                H.P(dz) if ctx.p > 0 else None, ctx.alpha, dout.numel(), H.P(rs, torch.int64), ctx.site, ctx.p, H.stream_ptr())
         return dx, dz, None, None, None
@@ -869,7 +905,7 @@ class _PwaCoreFn(torch.autograd.Function):
         ctx.save_for_backward(tq, tk, tv, O, lse, tbl, iq, ik, iv)
         ctx.qkv_shapes = [tuple(t.shape) for t in qkv]
         ctx.table = table
-        ctx.plan, ctx.cq, ctx.cv, ctx.M, ctx.p, ctx.site = plan, cq, cv, M, float(p_attn), site
+        ctx.plan, ctx.cq, ctx.cv, ctx.M, ctx.p, ctx.site, ctx.rs = plan, cq, cv, M, float(p_attn), site, rs
         return tuple(outs)
 
     @staticmethod
@@ -889,7 +925,7 @@ class _PwaCoreFn(torch.autograd.Function):
         if nws is None:
             nws = cache[(B, M)] = H.query("vx_pwa_attn_bwd_ws_floats", pp, B, M)
         delta = torch.empty(nws, device=dev, dtype=torch.float32)
-        rs = rng_state(dev) if ctx.p > 0 else None
+        rs = ctx.rs              # the {seed, step} tensor of THIS node's forward
         dtab = grad_buf(ctx.table) if ctx.table.requires_grad else torch.zeros_like(tbl)
         H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
                H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, st)

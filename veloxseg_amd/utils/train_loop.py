@@ -124,11 +124,18 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
             model, args.checkpoint_path, optimizer, warmup_scheduler, training_scheduler, device)
         log.info("Load Checkpoint, Continue to Train!!!!")
     batch = train_config["batch_size"]
+    import torch.distributed as dist
+    ddp = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if ddp else 0
     if train_loader is None:
+        # every rank draws its OWN synthetic stream (seed + rank): data parallelism must add data, not replicate the same batch on every GPU
         source = SyntheticVolumes if getattr(args, "augment", False) else SyntheticPatches
-        train_loader = source(mcfg, batch, getattr(args, "synthetic_steps", 4), device)
-    x0, y0 = next(iter(train_loader))
-    engine = TrainEngine(model, criterion, tuple(x0.shape), label_dtype=y0.dtype, optimizer=optimizer, use_graph=getattr(args, "use_graph", False))
+        train_loader = source(mcfg, batch, getattr(args, "synthetic_steps", 4), device, seed=12345 + rank)
+    # engine buffers from the configuration, not from a pulled batch (that would consume one batch of a one-shot iterable and spin up an extra
+    # worker pool); loaders must yield (batch_size, sum(in_ch), *input_size) inputs -- labels of any integer dtype are converted by the copy
+    size = list(mcfg["input_size"])
+    x_shape = (batch, sum(mcfg["in_ch"]), *size)
+    engine = TrainEngine(model, criterion, x_shape, label_dtype=torch.int64, optimizer=optimizer, use_graph=getattr(args, "use_graph", False))
     show_deep_metrics = _metric_fns(args.dataset_name)
     not_pred = 2 + num_modal if args.model_name == "VeloxSeg" else 0
     sched_type = train_config["train_scheduler"]["scheduler_type"]
@@ -178,6 +185,10 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
                     tot += metrics[0] if args.dataset_name == "BraTS2021" else metrics[3]
                     n += 1
             val_dice = tot / max(n, 1)
+            if ddp:      # the LR plateau scheduler and the best-checkpoint decision must see the same number on every rank
+                t_ = torch.tensor([tot, float(n)], device=device, dtype=torch.float64)
+                dist.all_reduce(t_)
+                val_dice = float(t_[0] / max(float(t_[1]), 1.0))
             hist["val_dice"].append(val_dice)
             if sched_type == "reducelronplateau" and epoch >= warmup_epoch:
                 step_scheduler(training_scheduler, sched_type, val_dice)
