@@ -23,6 +23,7 @@ struct VxJlc {
     double* part;                                     // forward: [3][B*C][ntiles][2] (sum, sumsq)
     int B, C, G, D, H, W;
     int TD, TH, TWq, nTd, nTh, nTw, cic, nthr;
+    int parts, nsp;      // input-channel split: the block's nthr threads = nsp spatial slots x parts channel parts (2 on small volumes: twice the waves per SIMD)
 };
 
 // stage the K-halo of `ncc` channels starting at channel c_first of sample b into xs[cil][HD][HH][HWp] (zero outside the volume)
@@ -42,10 +43,11 @@ __device__ __forceinline__ void vx_jlc_stage(const float* __restrict__ src, floa
     const long chan = (long)p.D * p.H * p.W;
     const float* __restrict__ xb = src + ((long)b * p.C + c_first) * chan;
     const int total = ncc * HD * HH * HWp;
-    for (int e = tid; e < total; e += nthr * 4) {
-        float v[4];
+    constexpr int SU = 8;                            // loads in flight per thread (a rolled load -> store loop pays one L2 round trip per element)
+    for (int e = tid; e < total; e += nthr * SU) {
+        float v[SU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
             const int id = d0 - P + hd, ih = h0 - P + hh, iw = w0 - P + hw;
             const bool ok = (e + u * nthr < total) && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const float t_ = xb[ok ? cil * chan + ((long)id * p.H + ih) * p.W + iw : 0];
@@ -56,8 +58,20 @@ __device__ __forceinline__ void vx_jlc_stage(const float* __restrict__ src, floa
             cil += st_c;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < SU; ++u)
             if (e + u * nthr < total) xs[e + u * nthr] = v[u];
+    }
+}
+
+// weight slice staging with 8 independent loads in flight per thread; `src(e)` maps the LDS element index to the global weight element
+template <class F>
+__device__ __forceinline__ void vx_jlc_stage_w(float* __restrict__ ws, int total, int nthr, F src) {
+    for (int e0 = threadIdx.x; e0 < total; e0 += nthr * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthr; v[u] = src(e < total ? e : 0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * nthr; if (e < total) ws[e] = v[u]; }
     }
 }
 
@@ -65,14 +79,14 @@ __device__ __forceinline__ void vx_jlc_tile(const VxJlc& p, int& d0, int& h0, in
     const int tile = blockIdx.x;
     const int tw_i = tile % p.nTw, th_i = (tile / p.nTw) % p.nTh, td_i = tile / (p.nTw * p.nTh);
     d0 = td_i * p.TD; h0 = th_i * p.TH; w0 = tw_i * p.TWq * 4;
-    const int sp = threadIdx.x;
+    const int sp = threadIdx.x % p.nsp;
     tq = sp % p.TWq; th = (sp / p.TWq) % p.TH; td = sp / (p.TWq * p.TH);
     active = td < p.TD;
 }
 
 // --------------------------------------------------------------------------------------------------------------------- forward convolutions
 template <int COT>
-__global__ void __launch_bounds__(256) vx_jlc_conv_fwd_k(VxJlc p) {
+__global__ void __launch_bounds__(512) vx_jlc_conv_fwd_k(VxJlc p) {
     extern __shared__ __attribute__((aligned(16))) float vx_jlc_lds[];
     constexpr int NT = 125 + 27 + 1;                 // taps of the three kernels, in this order, per (ci, co)
     const int Cg = p.C / p.G;
@@ -85,6 +99,7 @@ __global__ void __launch_bounds__(256) vx_jlc_conv_fwd_k(VxJlc p) {
     float* __restrict__ xs = vx_jlc_lds;
     float* __restrict__ ws = vx_jlc_lds + p.cic * plane;
     const int tid = threadIdx.x;
+    const int part = tid / p.nsp;
     float a5[4][COT], a3[4][COT], a1[4][COT];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -94,14 +109,14 @@ __global__ void __launch_bounds__(256) vx_jlc_conv_fwd_k(VxJlc p) {
         const int ncc = min(p.cic, Cg - cc);
         __syncthreads();
         vx_jlc_stage<5>(p.x, xs, p, b, g * Cg + cc, ncc, d0, h0, w0, HD, HH, HWp);
-        for (int e = tid; e < ncc * NT * COT; e += p.nthr) {
+        vx_jlc_stage_w(ws, ncc * NT * COT, p.nthr, [&](int e) {
             const int j = e % COT, t = (e / COT) % NT, cil = e / (COT * NT);
             const long wr = (long)(co0 + j) * Cg + (cc + cil);
-            ws[e] = t < 125 ? p.w5[wr * 125 + t] : t < 152 ? p.w3[wr * 27 + (t - 125)] : p.w1[wr];
-        }
+            return t < 125 ? p.w5[wr * 125 + t] : t < 152 ? p.w3[wr * 27 + (t - 125)] : p.w1[wr];
+        });
         __syncthreads();
         if (active) {
-            for (int cil = 0; cil < ncc; ++cil) {
+            for (int cil = part; cil < ncc; cil += p.parts) {
 #pragma unroll
                 for (int kd = 0; kd < 5; ++kd) {
 #pragma unroll
@@ -161,12 +176,29 @@ __global__ void __launch_bounds__(256) vx_jlc_conv_fwd_k(VxJlc p) {
             }
         }
     }
+    if (p.parts > 1) {                               // sum the channel parts through LDS (the halo / weight tiles are dead)
+        __syncthreads();
+        float* __restrict__ rb = vx_jlc_lds + (long)(tid % p.nsp) * (12 * COT);
+        if (part == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) { rb[u * COT + j] = a5[u][j]; rb[(4 + u) * COT + j] = a3[u][j]; rb[(8 + u) * COT + j] = a1[u][j]; }
+        }
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) { a5[u][j] += rb[u * COT + j]; a3[u][j] += rb[(4 + u) * COT + j]; a1[u][j] += rb[(8 + u) * COT + j]; }
+        }
+    }
     // epilogue: bias, store, per-channel partial sums of this tile
     const int od = d0 + td, oh = h0 + th, ow = w0 + 4 * tq;
-    const bool inb = active && od < p.D && oh < p.H;
+    const bool inb = active && part == 0 && od < p.D && oh < p.H;
     __syncthreads();
     float* __restrict__ red = vx_jlc_lds;            // [wave][3*COT*2]
-    const int lane = tid & 63, wave = tid >> 6, nwave = (p.nthr + 63) >> 6;
+    const int lane = tid & 63, wave = tid >> 6, nwave = (p.nsp + 63) >> 6;     // waves of part 0 hold the sums
     const long ntiles = gridDim.x;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -223,14 +255,14 @@ __device__ __forceinline__ void vx_jlc_adj(const float* __restrict__ gsrc, const
         const int ncc = min(p.cic, Cg - cc);
         __syncthreads();
         vx_jlc_stage<K>(gsrc, xs, p, b, g * Cg + cc, ncc, d0, h0, w0, HD, HH, HWp);
-        for (int e = tid; e < ncc * K3 * COT; e += p.nthr) {
+        vx_jlc_stage_w(ws, ncc * K3 * COT, p.nthr, [&](int e) {
             const int j = e % COT, t = (e / COT) % K3, cil = e / (COT * K3);
             // forward weight w[co = g*Cg + cc + cil][ci_in_group = ci0 + j - g*Cg][K3 - 1 - t]
-            ws[e] = w[((long)(g * Cg + cc + cil) * Cg + (ci0 + j - g * Cg)) * K3 + (K3 - 1 - t)];
-        }
+            return w[((long)(g * Cg + cc + cil) * Cg + (ci0 + j - g * Cg)) * K3 + (K3 - 1 - t)];
+        });
         __syncthreads();
         if (active) {
-            for (int cil = 0; cil < ncc; ++cil) {
+            for (int cil = threadIdx.x / p.nsp; cil < ncc; cil += p.parts) {
 #pragma unroll
                 for (int kd = 0; kd < K; ++kd) {
 #pragma unroll
@@ -262,7 +294,7 @@ __device__ __forceinline__ void vx_jlc_adj(const float* __restrict__ gsrc, const
 }
 
 template <int COT>
-__global__ void __launch_bounds__(256) vx_jlc_conv_bwd_k(VxJlc p) {
+__global__ void __launch_bounds__(512) vx_jlc_conv_bwd_k(VxJlc p) {
     extern __shared__ __attribute__((aligned(16))) float vx_jlc_lds[];
     const int Cg = p.C / p.G;
     const int ci0 = blockIdx.y * COT, g = ci0 / Cg, b = blockIdx.z;        // ci0: first INPUT channel (of the forward conv) this block produces dx for
@@ -276,6 +308,22 @@ __global__ void __launch_bounds__(256) vx_jlc_conv_bwd_k(VxJlc p) {
         for (int j = 0; j < COT; ++j) acc[u][j] = 0.0f;
     vx_jlc_adj<5, COT>(p.g5, p.w5, p, vx_jlc_lds, b, g, ci0, d0, h0, w0, td, th, tq, active, acc);
     vx_jlc_adj<3, COT>(p.g3, p.w3, p, vx_jlc_lds, b, g, ci0, d0, h0, w0, td, th, tq, active, acc);
+    if (p.parts > 1) {
+        __syncthreads();
+        float* __restrict__ rb = vx_jlc_lds + (long)(threadIdx.x % p.nsp) * (4 * COT);
+        if (threadIdx.x >= p.nsp) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) rb[u * COT + j] = acc[u][j];
+        }
+        __syncthreads();
+        if (threadIdx.x >= p.nsp) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[u][j] += rb[u * COT + j];
+    }
     const int od = d0 + td, oh = h0 + th, ow = w0 + 4 * tq;
     if (!active || od >= p.D || oh >= p.H) return;
     // 1x1x1 branch + residual straight from global memory
@@ -493,22 +541,27 @@ static int vx_jlc_geom(VxJlc& p, int B, int C, int G, int D, int H, int W, int K
     if (td > 8) td = 8;
     if (td < 1) td = 1;
     p.TD = td;
-    COT = (Cg % 8 == 0) ? 8 : 4;
+    COT = 4;            // (8 channels per thread would need 256 VGPRs forward: one wave per SIMD)
     // the tiling must not depend on the batch size: the order in which a sample's partial sums are folded would change with B, and a sample's
     // result must be bit-identical whatever it is batched with (tests/test_hip_model_gpu.py); 4 = the nominal batch of the training step
     auto nblk = [&]() { return (long)vx_cdiv(D, p.TD) * vx_cdiv(H, p.TH) * vx_cdiv(W, p.TWq * 4) * (C / COT) * 4; };
-    if (COT == 8 && nblk() < 512) COT = 4;
     while (p.TD > 1 && nblk() < 128 && (p.TD / 2) * p.TWq * p.TH >= 64) p.TD /= 2;      // very small volumes only: thin tiles re-stage most of their halo (16^3 measured: 121 us thin vs full tiles)
     p.nTd = vx_cdiv(D, p.TD); p.nTh = vx_cdiv(H, p.TH); p.nTw = vx_cdiv(W, p.TWq * 4);
-    p.nthr = (p.TD * p.TH * p.TWq + 63) / 64 * 64;
-    if (p.nthr > 256) p.nthr = 256;
+    p.nsp = (p.TD * p.TH * p.TWq + 63) / 64 * 64;
+    if (p.nsp > 256) p.nsp = 256;
+    // few blocks (16^3 and below: 128 blocks of 4 waves = one wave per SIMD on half of the chip, and one wave alone does not saturate a SIMD's VALU):
+    // two channel parts per spatial slot = 8 waves per block, half the FMAs per thread, partial sums folded through LDS
+    p.parts = (nblk() < 256 && Cg >= 2 && Cg % 2 == 0) ? 2 : 1;
+    p.nthr = p.nsp * p.parts;
     const int plane = (p.TD + K - 1) * (p.TH + K - 1) * (p.TWq * 4 + 4);
     const int taps = K == 5 ? 153 : 125;             // forward stages all three kernels' taps; the adjoint the largest kernel's
     int cic = Cg < 4 ? Cg : 4;
     auto lds = [&](int c) { return (size_t)c * (plane + taps * COT) * sizeof(float); };
     while (cic > 1 && lds(cic) > 64 * 1024) cic >>= 1;
+    if (cic % p.parts) { p.parts = 1; p.nthr = p.nsp; }
     p.cic = cic;
     shm = lds(cic);
+    if (p.parts > 1 && shm < (size_t)p.nsp * 12 * COT * sizeof(float)) shm = (size_t)p.nsp * 12 * COT * sizeof(float);
     if (shm < 4 * 3 * 8 * 2 * sizeof(float)) shm = 4 * 3 * 8 * 2 * sizeof(float);
     return 0;
 }
@@ -529,8 +582,7 @@ extern "C" int vx_jlc_conv_fwd(const float* x, const float* w1, const float* w3,
     p.x = x; p.w1 = w1; p.w3 = w3; p.w5 = w5; p.b1 = b1; p.b3 = b3; p.b5 = b5; p.y1 = y1; p.y3 = y3; p.y5 = y5; p.part = part;
     dim3 grid(p.nTd * p.nTh * p.nTw, C / COT, B);
     hipStream_t st = (hipStream_t)stream;
-    if (COT == 8) vx_jlc_conv_fwd_k<8><<<grid, dim3(p.nthr), shm, st>>>(p);
-    else vx_jlc_conv_fwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    vx_jlc_conv_fwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_conv_fwd");
     return 0;
 }
@@ -544,8 +596,7 @@ extern "C" int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5
     p.g1 = g1; p.g3 = g3; p.g5 = g5; p.w1 = w1; p.w3 = w3; p.w5 = w5; p.res = d_o; p.dx = dx;
     dim3 grid(p.nTd * p.nTh * p.nTw, C / COT, B);
     hipStream_t st = (hipStream_t)stream;
-    if (COT == 8) vx_jlc_conv_bwd_k<8><<<grid, dim3(p.nthr), shm, st>>>(p);
-    else vx_jlc_conv_bwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    vx_jlc_conv_bwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_conv_bwd");
     return 0;
 }
