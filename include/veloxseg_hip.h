@@ -272,6 +272,18 @@ int vx_seg_loss_bwd(const float* logits, const void* labels, int lab_kind, const
 /* all nh <= 4 heads in one launch (labels read once); head h reads its coefficients at coef + h * coef_stride floats */
 int vx_seg_loss_bwd4(const float* lg0, const float* lg1, const float* lg2, const float* lg3, int nh, const void* labels, int lab_kind, const float* coef,
                      int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, int B, int C, long V, void* stream);
+/* Deep-supervision loss with the trilinear up-sampling of VeloxSeg.py:177-184,202 fused in (csrc/loss_ds.hip): head 0 (l0) is full resolution
+ * (B, C, D, H, W); heads 1..nh-1 (l1..l3) stay on their own grids, low_dims = host array of 3*(nh-1) ints (d, h, w per head), and are interpolated
+ * on the fly (align_corners=True, the arithmetic of vx_upsample_trilinear_fwd).  Same acc / coef layouts as vx_seg_loss_fwd / vx_loss_finalize /
+ * vx_seg_loss_bwd4.  Backward: dl0 full resolution, dl1..dl3 on the heads' grids (the adjoint of the interpolation runs inside the kernels);
+ * ws = vx_seg_loss_ds_ws_floats(...) floats of workspace.  vx_seg_loss_ds_ok: 1 when the shape is covered (C in 2..4, W % 4 == 0, W/4 divides 64). */
+int vx_seg_loss_ds_ok(int C, int D, int H, int W);
+int vx_seg_loss_ds_ws_floats(const int* low_dims, int nh, int B, int C, int D);
+int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                       double* acc, int B, int C, int D, int H, int W, void* stream);
+int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                       const float* coef, int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, float* ws,
+                       int B, int C, int D, int H, int W, void* stream);
 int vx_mse_bwd(const float* a, const float* b, const float* coef, const float* gout, float* da, long n, void* stream);
 int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const float* g2, const float* g3, int M, const float* coef,
                     const float* gout, float* dgs, float* d0, float* d1, float* d2, float* d3, long n, void* stream);

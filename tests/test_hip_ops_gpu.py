@@ -635,3 +635,33 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
         H.call("vx_pwa_attn_set_mfma", 1)
     for i, (a, b) in enumerate(zip(res[3], res[0])):
         close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma vs valu tensor {i}")
+
+
+@pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32)], ids=["c2", "c4_aniso", "c3"])
+def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype):
+    """veloxseg_loss on heads that stay on their own grids (csrc/loss_ds.hip interpolates inside the kernels) == up-sample (vx_upsample_trilinear) then
+    veloxseg_loss == the oracle (F.interpolate + CE + Dice): loss 1e-5 relative, gradients of every head 1e-4 of their scale."""
+    VF = _vf()
+    d = dev()
+    heads = [rnd(B, ncls, *S, seed=1)] + [rnd(B, ncls, *[max(s // f, 2) for s in S], seed=2 + k) for k, f in enumerate((2, 4, 8))]
+    lab = torch.randint(0, ncls, (B, 1, *S), generator=torch.Generator().manual_seed(3)).to(labdtype)
+    w = (0.25, 0.25, 0.25, 0.25)
+    res = []
+    for fused in (True, False):
+        hs = [h.clone().to(d).requires_grad_(True) for h in heads]
+        outs = hs if fused else [hs[0]] + [VF.upsample_trilinear(h, S) for h in hs[1:]]
+        loss = VF.seg_only_loss(outs, lab.to(d), w)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), [h.grad.clone() for h in hs]))
+    hc = [h.clone().requires_grad_(True) for h in heads]
+    up = [hc[0]] + [F.interpolate(h, size=S, mode="trilinear", align_corners=True) for h in hc[1:]]
+    ref = sum(wi * O.seg_loss(u, lab.long()) for wi, u in zip(w, up))
+    ref.backward()
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]), (res[0][0], res[1][0])
+    assert abs(res[0][0] - float(ref)) <= 1e-5 * abs(float(ref)), (res[0][0], float(ref))
+    for k in range(4):
+        g = hc[k].grad
+        tol = 1e-4 * float(g.abs().max())
+        close(res[0][1][k], g, tol, 1e-4, f"fused: d head {k} vs oracle")
+        close(res[0][1][k], res[1][1][k], tol, 1e-4, f"fused vs unfused: d head {k}")

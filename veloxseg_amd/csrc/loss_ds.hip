@@ -1,0 +1,383 @@
+// Deep-supervision loss with the trilinear up-sampling of the low-resolution heads FUSED IN (gfx950, fp32 data, fp64 accumulators).
+// Reference: model/VeloxSeg.py:177-184,202 (scale_prediction: F.interpolate(mode="trilinear", align_corners=True) of every head to the input size)
+// followed by utils/loss.py:30-48 (CE + Dice per head).  The three up-sampled (B, ncls, S^3) tensors -- 35 % of the compulsory activation traffic of a
+// training step -- are never materialised:
+//   forward  : vx_seg_loss_ds_fwd   one sweep over the full-resolution voxels; head 0 is read, heads 1.. are interpolated on the fly from their
+//                                   (B, C, d, h, w) grids (same arithmetic as vx_upsample_trilinear_fwd, so the values are identical), labels read once
+//   backward : vx_seg_loss_ds_bwd   d(logit) of head 0 is stored; for heads 1.. the gradient at the up-sampled logits is formed in registers and pushed
+//                                   through the ADJOINT of the interpolation inside the kernel: along W in LDS per row (owner lanes sum the fine voxels
+//                                   of their coarse column), along H into per-wave LDS accumulators of the block's Z slice; a small second kernel
+//                                   (vx_seg_loss_ds_adj_z) finishes the adjoint along D for all heads.  2 launches instead of 10.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+__device__ __forceinline__ int vx_lab(const void* lab, int kind, long i) {
+    if (kind == 0) return (int)((const long long*)lab)[i];
+    if (kind == 1) return ((const int*)lab)[i];
+    return (int)((const unsigned char*)lab)[i];
+}
+__device__ __forceinline__ void vx_lab4(const void* lab, int kind, long i4, int (&y)[4]) {      // labels of 4 consecutive voxels, i4 % 4 == 0
+    if (kind == 0) {
+        const longlong2 a = ((const longlong2*)lab)[i4 >> 1], c2 = ((const longlong2*)lab)[(i4 >> 1) + 1];
+        y[0] = (int)a.x; y[1] = (int)a.y; y[2] = (int)c2.x; y[3] = (int)c2.y;
+    } else if (kind == 1) {
+        const int4 a = ((const int4*)lab)[i4 >> 2];
+        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+    } else {
+        const uchar4 a = ((const uchar4*)lab)[i4 >> 2];
+        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+    }
+}
+// source index pair + weight of output index j (align_corners=True): identical to vx_up_coord of loss.hip
+__device__ __forceinline__ void vx_ds_coord(int j, int nin, int nout, int& i0, int& i1, float& lam) {
+    if (nout == nin) { i0 = j; i1 = j; lam = 0.0f; return; }
+    const float ratio = nout > 1 ? (float)(nin - 1) / (float)(nout - 1) : 0.0f;
+    const float s = ratio * (float)j;
+    i0 = (int)s;
+    lam = s - (float)i0;
+    i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+}
+
+struct VxDs {
+    const float* l0;            // head 0, full resolution (B, C, D, H, W)
+    const float* low[3];        // heads 1..nh-1 on their own grids
+    int ld[3][3];               // (d, h, w) of those grids
+    float* dl0;                 // backward: gradient of head 0
+    float* t2[3];               // backward: (B, C, D, h, w) partially reduced gradients of heads 1..
+    int nh, B, D, H, W;
+};
+
+// logits of head hh (>= 1) at the 4 voxels (Z, Y, X0..X0+3): z[c][j]
+template <int C>
+__device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, int b, int Z, int Y, int X0, float (&z)[C][4]) {
+    const int d = P.ld[hh][0], h = P.ld[hh][1], w = P.ld[hh][2];
+    int a0, b0, a1, b1;
+    float l0, l1;
+    vx_ds_coord(Z, d, P.D, a0, b0, l0);
+    vx_ds_coord(Y, h, P.H, a1, b1, l1);
+    const float k0 = 1.0f - l0, k1 = 1.0f - l1;
+    int a2[4], b2[4];
+    float l2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, w, P.W, a2[j], b2[j], l2[j]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float* __restrict__ xb = P.low[hh] + ((long)b * C + c) * d * h * w;
+        const float* __restrict__ r00 = xb + ((long)a0 * h + a1) * w;
+        const float* __restrict__ r01 = xb + ((long)a0 * h + b1) * w;
+        const float* __restrict__ r10 = xb + ((long)b0 * h + a1) * w;
+        const float* __restrict__ r11 = xb + ((long)b0 * h + b1) * w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float k2 = 1.0f - l2[j];
+            z[c][j] = k0 * (k1 * (k2 * r00[a2[j]] + l2[j] * r00[b2[j]]) + l1 * (k2 * r01[a2[j]] + l2[j] * r01[b2[j]])) +
+                      l0 * (k1 * (k2 * r10[a2[j]] + l2[j] * r10[b2[j]]) + l1 * (k2 * r11[a2[j]] + l2[j] * r11[b2[j]]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------ forward
+// acc layout (double) as vx_seg_loss_fwd: head h at h*(1 + B*C*3): [ce_sum, (I, P, T) x (b, c)].  grid (chunks, B)
+template <int C>
+__global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* __restrict__ lab, int lab_kind, double* __restrict__ acc) {
+    constexpr int NS = 1 + 2 * C;
+    const int b = blockIdx.y;
+    const int W4 = P.W >> 2;
+    const long V = (long)P.D * P.H * P.W, V4 = V >> 2;
+    float S[4][NS], T[C];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) S[h][k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) T[c] = 0.0f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < V4; q += (long)gridDim.x * 256) {
+        const int X0 = (int)(q % W4) * 4, Y = (int)((q / W4) % P.H), Z = (int)(q / ((long)W4 * P.H));
+        int y[4];
+        vx_lab4(lab, lab_kind, (long)b * V + 4 * q, y);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[c] += (y[j] == c) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (h < P.nh) {
+                float z[C][4];
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + 4 * q);
+                        z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
+                    }
+                } else vx_ds_interp<C>(P, h - 1, b, Z, Y, X0, z);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mx = z[0][j];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                    float e[C], se = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { e[c] = expf(z[c][j] - mx); se += e[c]; }
+                    const float inv = 1.0f / se;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float pc = e[c] * inv;
+                        S[h][1 + C + c] += pc;
+                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + logf(se)) - z[c][j]; }
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float red[4][4 * NS + C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { const float v = vx_wave_sum(S[h][k]); if (lane == 0) red[wid][h * NS + k] = v; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = vx_wave_sum(T[c]); if (lane == 0) red[wid][4 * NS + c] = v; }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 4 * NS + C) {
+        const double v = (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k];
+        if (k < 4 * NS) {
+            const int h = k / NS, r = k % NS;
+            if (h < P.nh) {
+                double* __restrict__ ah = acc + (long)h * (1 + (long)P.B * C * 3);
+                if (r == 0) atomicAdd(ah, v);
+                else if (r <= C) atomicAdd(ah + 1 + ((long)b * C + (r - 1)) * 3, v);
+                else atomicAdd(ah + 1 + ((long)b * C + (r - 1 - C)) * 3 + 1, v);
+            }
+        } else {
+            const int c = k - 4 * NS;
+            for (int h = 0; h < P.nh; ++h) atomicAdd(acc + (long)h * (1 + (long)P.B * C * 3) + 1 + ((long)b * C + c) * 3 + 2, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------ backward
+// block = (b, Z slice); wave = RPW rows of the slice per step (RPW = 64 / (W/4) row segments of W/4 lanes, 4 voxels per lane).
+// LDS: gbuf[wave][row][head][c][W] (gradients at the up-sampled logits of one step) and accw[wave][sum_h C*h_h*w_h] (this wave's H/W-reduced sums).
+template <int C>
+__global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* __restrict__ lab, int lab_kind, const float* __restrict__ coef, int coef_stride,
+                                                            const float* __restrict__ gout, int nacc) {
+    extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
+    const int b = blockIdx.y, Z = blockIdx.x;
+    const int W4 = P.W >> 2, RPW = 64 / W4, nlow = P.nh - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long V = (long)P.D * P.H * P.W;
+    float* __restrict__ accw = vx_ds_lds + (long)wave * nacc;                                   // [head][c][y][x]
+    float* __restrict__ gbuf = vx_ds_lds + 4L * nacc + (long)wave * (RPW * 3 * C * P.W);        // [row][head][c][X]
+    for (int k = lane; k < nacc; k += 64) accw[k] = 0.0f;
+    const float go = gout ? gout[0] : 1.0f;
+    int aoff[3];                                                                                // offsets of the heads inside accw
+    { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += C * P.ld[hh][1] * P.ld[hh][2]; } }
+    const int rsl = lane / W4, X0 = (lane % W4) * 4;                                            // row slot of this lane, first voxel
+    for (int Y0 = wave * RPW; Y0 < P.H; Y0 += 4 * RPW) {
+        const int Y = Y0 + rsl;
+        const bool rowok = rsl < RPW && Y < P.H;
+        if (rowok) {
+            int y[4];
+            vx_lab4(lab, lab_kind, (long)b * V + ((long)Z * P.H + Y) * P.W + X0, y);
+            for (int h = 0; h < P.nh; ++h) {
+                float z[C][4];
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0);
+                        z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
+                    }
+                } else vx_ds_interp<C>(P, h - 1, b, Z, Y, X0, z);
+                const float* __restrict__ coef_h = coef + (long)h * coef_stride;
+                const float wce = coef_h[0];
+                float al[C], be[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) { al[c] = coef_h[1 + ((long)b * C + c) * 2]; be[c] = coef_h[2 + ((long)b * C + c) * 2]; }
+                float g[C][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mx = z[0][j];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                    float se = 0.0f, dot = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { z[c][j] = expf(z[c][j] - mx); se += z[c][j]; }
+                    const float inv = 1.0f / se;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { z[c][j] *= inv; dot = fmaf(z[c][j], (c == y[j] ? al[c] : 0.0f) + be[c], dot); }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float gg = (c == y[j] ? al[c] : 0.0f) + be[c];
+                        g[c][j] = go * (wce * (z[c][j] - (c == y[j] ? 1.0f : 0.0f)) + z[c][j] * (gg - dot));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (h == 0) *reinterpret_cast<float4*>(P.dl0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
+                    else *reinterpret_cast<float4*>(gbuf + (((long)rsl * 3 + (h - 1)) * C + c) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // adjoint along W (owner lane = (head, c, coarse x)), then along H into this wave's accumulators.  Owners walk the step's rows one
+        // after the other, so two rows never add into one accumulator at the same time.
+        int base = 0;
+        for (int hh = 0; hh < nlow; ++hh) {
+            const int hl = P.ld[hh][1], wl = P.ld[hh][2];
+            const int nown = C * wl;
+            for (int o = lane; o < nown; o += 64) {
+                const int c = o / wl, xl = o - c * wl;
+                // fine columns X with a tap on coarse column xl: src = ratio * X in (xl - 1, xl + 1)
+                const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
+                int lo = 0, hi = P.W - 1;
+                if (wl != P.W && ratio > 0.0f) {
+                    lo = (int)ceilf(((float)xl - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
+                    hi = (int)floorf(((float)xl + 1.0f) / ratio) + 1; if (hi > P.W - 1) hi = P.W - 1;
+                }
+                for (int r = 0; r < RPW; ++r) {
+                    const int Yr = Y0 + r;
+                    if (Yr >= P.H) break;
+                    const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * C + c) * P.W;
+                    float s = 0.0f;
+                    for (int X = lo; X <= hi; ++X) {
+                        int i0, i1; float lam;
+                        vx_ds_coord(X, wl, P.W, i0, i1, lam);
+                        const float wgt = (i0 == xl ? 1.0f - lam : 0.0f) + (i1 == xl ? lam : 0.0f);      // (i0 == i1 at the last column: weights add up to 1)
+                        s = fmaf(wgt, gr[X], s);
+                    }
+                    int a1, b1; float l1;
+                    vx_ds_coord(Yr, hl, P.H, a1, b1, l1);
+                    float* __restrict__ dst = accw + aoff[hh] + (long)c * hl * wl + xl;
+                    dst[(long)a1 * wl] += (1.0f - l1) * s;
+                    if (b1 != a1) dst[(long)b1 * wl] += l1 * s;
+                    else dst[(long)a1 * wl] += l1 * s;
+                }
+            }
+            base += nown;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // sum the 4 waves' accumulators and store this Z slice of the (B, C, D, h, w) partial gradients
+    for (int hh = 0; hh < nlow; ++hh) {
+        const int hl = P.ld[hh][1], wl = P.ld[hh][2], n = C * hl * wl;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int c = e / (hl * wl), r = e - c * hl * wl;
+            const float s = (vx_ds_lds[aoff[hh] + e] + vx_ds_lds[nacc + aoff[hh] + e]) + (vx_ds_lds[2 * nacc + aoff[hh] + e] + vx_ds_lds[3 * nacc + aoff[hh] + e]);
+            P.t2[hh][(((long)b * C + c) * P.D + Z) * hl * wl + r] = s;
+        }
+    }
+}
+
+// adjoint along D for all heads: dlow_h[b, c, z, y, x] = sum_Z A[Z][z] t2_h[b, c, Z, y, x].  One thread per output element.
+struct VxDsZ { const float* t2[3]; float* out[3]; int ld[3][3]; int nlow, BC, D; long n[3]; };
+__global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    int hh = 0;
+    while (hh < P.nlow && e >= P.n[hh]) { e -= P.n[hh]; ++hh; }
+    if (hh >= P.nlow) return;
+    const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
+    const int r = (int)(e % hw), z = (int)((e / hw) % d);
+    const long bc = e / ((long)hw * d);
+    const float ratio = P.D > 1 ? (float)(d - 1) / (float)(P.D - 1) : 0.0f;
+    int lo = 0, hi = P.D - 1;
+    if (d != P.D && ratio > 0.0f) {
+        lo = (int)ceilf(((float)z - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
+        hi = (int)floorf(((float)z + 1.0f) / ratio) + 1; if (hi > P.D - 1) hi = P.D - 1;
+    }
+    const float* __restrict__ src = P.t2[hh] + bc * P.D * hw + r;
+    float s = 0.0f;
+    for (int Z = lo; Z <= hi; ++Z) {
+        int i0, i1; float lam;
+        vx_ds_coord(Z, d, P.D, i0, i1, lam);
+        const float wgt = (i0 == z ? 1.0f - lam : 0.0f) + (i1 == z ? lam : 0.0f);
+        s = fmaf(wgt, src[(long)Z * hw], s);
+    }
+    P.out[hh][e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------ host
+static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2, const float* l3, const int* dims, int nh, int B, int C, int D, int H, int W, const char* who) {
+    VX_REQUIRE(nh >= 1 && nh <= 4 && l0 && B > 0 && (C == 2 || C == 3 || C == 4) && D > 0 && H > 0 && W > 0, "%s: bad args (C must be 2..4)", who);
+    VX_REQUIRE((W & 3) == 0 && (W >> 2) <= 64 && 64 % (W >> 2) == 0, "%s: W must be a multiple of 4 with W/4 dividing 64 (got %d)", who, W);
+    P.l0 = l0; P.low[0] = l1; P.low[1] = l2; P.low[2] = l3; P.nh = nh; P.B = B; P.D = D; P.H = H; P.W = W;
+    for (int hh = 0; hh < 3; ++hh) {
+        for (int k = 0; k < 3; ++k) P.ld[hh][k] = hh < nh - 1 ? dims[3 * hh + k] : 1;
+        if (hh < nh - 1) VX_REQUIRE(P.low[hh] && P.ld[hh][0] > 0 && P.ld[hh][0] <= D && P.ld[hh][1] > 0 && P.ld[hh][1] <= H && P.ld[hh][2] > 0 && P.ld[hh][2] <= W,
+                                    "%s: head %d: bad grid", who, hh + 1);
+    }
+    return 0;
+}
+
+// 1 when the fused kernels cover this shape (else: up-sample + vx_seg_loss_fwd / _bwd4)
+extern "C" int vx_seg_loss_ds_ok(int C, int D, int H, int W) {
+    (void)D; (void)H;
+    return (C == 2 || C == 3 || C == 4) && (W & 3) == 0 && (W >> 2) <= 64 && 64 % (W >> 2) == 0;
+}
+
+extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                                  double* acc, int B, int C, int D, int H, int W, void* stream) {
+    VxDs P = {};
+    if (int e = vx_ds_fill(P, l0, l1, l2, l3, low_dims, nh, B, C, D, H, W, "vx_seg_loss_ds_fwd")) return e;
+    VX_REQUIRE(labels && acc && lab_kind >= 0 && lab_kind <= 2, "vx_seg_loss_ds_fwd: bad labels / accumulator");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_ds_fwd: memset failed");
+    const long V4 = ((long)D * H * W) >> 2;
+    int chunks = vx_cdiv(V4, 256 * 2);
+    if (chunks > 1024) chunks = 1024;
+    const dim3 grid(chunks, B), blk(256);
+    if (C == 2) vx_seg_loss_ds_fwd_k<2><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
+    else if (C == 3) vx_seg_loss_ds_fwd_k<3><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
+    else vx_seg_loss_ds_fwd_k<4><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
+    VX_LAUNCH_CHECK("vx_seg_loss_ds_fwd");
+    return 0;
+}
+
+// workspace (floats) of vx_seg_loss_ds_bwd: the (B, C, D, h, w) partial gradients of heads 1..
+extern "C" int vx_seg_loss_ds_ws_floats(const int* low_dims, int nh, int B, int C, int D) {
+    long n = 0;
+    for (int hh = 0; hh < nh - 1; ++hh) n += (long)B * C * D * low_dims[3 * hh + 1] * low_dims[3 * hh + 2];
+    VX_REQUIRE(n < 0x7fffffffL, "vx_seg_loss_ds_ws_floats: workspace too large");
+    return (int)n;
+}
+
+extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                                  const float* coef, int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, float* ws,
+                                  int B, int C, int D, int H, int W, void* stream) {
+    VxDs P = {};
+    if (int e = vx_ds_fill(P, l0, l1, l2, l3, low_dims, nh, B, C, D, H, W, "vx_seg_loss_ds_bwd")) return e;
+    VX_REQUIRE(labels && coef && dl0 && (nh < 2 || (dl1 && ws)) && (nh < 3 || dl2) && (nh < 4 || dl3), "vx_seg_loss_ds_bwd: null pointer");
+    P.dl0 = dl0;
+    float* outs[3] = {dl1, dl2, dl3};
+    VxDsZ Zp = {};
+    int nacc = 0;
+    long off = 0, total = 0;
+    for (int hh = 0; hh < nh - 1; ++hh) {
+        P.t2[hh] = ws + off;
+        Zp.t2[hh] = ws + off;
+        Zp.out[hh] = outs[hh];
+        for (int k = 0; k < 3; ++k) Zp.ld[hh][k] = P.ld[hh][k];
+        Zp.n[hh] = (long)B * C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2];
+        total += Zp.n[hh];
+        off += (long)B * C * D * P.ld[hh][1] * P.ld[hh][2];
+        nacc += C * P.ld[hh][1] * P.ld[hh][2];
+    }
+    Zp.nlow = nh - 1; Zp.BC = B * C; Zp.D = D;
+    const int RPW = 64 / (W >> 2);
+    const size_t shm = ((size_t)4 * nacc + (size_t)4 * RPW * 3 * C * W) * sizeof(float);
+    VX_REQUIRE(shm <= 150 * 1024, "vx_seg_loss_ds_bwd: the low-resolution grids do not fit LDS (%zu bytes)", shm);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(D, B), blk(256);
+#define VX_DS_BWD(CC)                                                                                                                 \
+    {                                                                                                                                 \
+        static bool once = false;                                                                                                     \
+        if (!once) { (void)hipFuncSetAttribute((const void*)vx_seg_loss_ds_bwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
+        vx_seg_loss_ds_bwd_k<CC><<<grid, blk, shm, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);                         \
+    }
+    if (C == 2) VX_DS_BWD(2) else if (C == 3) VX_DS_BWD(3) else VX_DS_BWD(4)
+#undef VX_DS_BWD
+    if (nh > 1) vx_seg_loss_ds_adj_z_k<<<dim3(vx_cdiv(total, 256)), blk, 0, st>>>(Zp);
+    VX_LAUNCH_CHECK("vx_seg_loss_ds_bwd");
+    return 0;
+}

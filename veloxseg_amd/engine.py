@@ -73,8 +73,10 @@ class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
-                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None):
+                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True):
         self.model, self.criterion = model, criterion
+        if hasattr(model, "ds_fused"):
+            model.ds_fused = bool(fuse_ds)      # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip)
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
         self.m = torch.zeros_like(self.flat.param)

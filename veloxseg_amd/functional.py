@@ -1033,7 +1033,17 @@ class _VeloxLossFn(torch.autograd.Function):
         hw = _head_weights(head_w, dev)
         seg_acc = torch.empty((nh * (1 + B * C * 3),), device=dev, dtype=torch.float64)
         lp = [H.P(t) for t in logits] + [None] * (4 - nh)
-        H.call("vx_seg_loss_fwd", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(seg_acc, torch.float64), B, C, V, st)
+        # heads on their own (coarser) grids: the trilinear up-sampling of VeloxSeg.scale_prediction runs INSIDE the loss kernels (csrc/loss_ds.hip)
+        ctx.ds = None
+        if any(tuple(t.shape[2:]) != tuple(logits[0].shape[2:]) for t in logits[1:]):
+            D_, H_, W_ = (int(s_) for s_ in logits[0].shape[2:])
+            if not H.query("vx_seg_loss_ds_ok", C, D_, H_, W_):
+                raise RuntimeError("veloxseg_loss: deep-supervision heads on coarser grids need C in 2..4 and W % 4 == 0 with W/4 dividing 64; up-sample them first")
+            dims = (H.ctypes.c_int * (3 * max(nh - 1, 1)))(*[int(v) for t in logits[1:] for v in t.shape[2:]])
+            ctx.ds = (dims, D_, H_, W_)
+            H.call("vx_seg_loss_ds_fwd", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(seg_acc, torch.float64), B, C, D_, H_, W_, st)
+        else:
+            H.call("vx_seg_loss_fwd", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(seg_acc, torch.float64), B, C, V, st)
         has_tail = M > 0
         rcs = grams = None
         rc_acc = None
@@ -1064,7 +1074,14 @@ class _VeloxLossFn(torch.autograd.Function):
         go = _c(gout.reshape(1).to(torch.float32))
         grads = []
         stride = (1 + B * C * 2) * 4
-        if USE_LOSS_BWD4 and nh <= 4:             # every head in one launch: the labels are read once
+        if ctx.ds is not None:                    # fused: gradients of the coarse heads through the adjoint of the interpolation, 2 launches
+            dims, D_, H_, W_ = ctx.ds
+            grads = [torch.empty_like(logits[h]) for h in range(nh)]
+            nws = H.query("vx_seg_loss_ds_ws_floats", H.ctypes.addressof(dims), nh, B, C, D_)
+            ws = torch.empty((max(nws, 1),), device=go.device, dtype=torch.float32)
+            H.call("vx_seg_loss_ds_bwd", *([H.P(t) for t in logits] + [None] * (4 - nh)), H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype],
+                   coef.data_ptr(), stride // 4, H.P(go), *([H.P(d) for d in grads] + [None] * (4 - nh)), H.P(ws), B, C, D_, H_, W_, st)
+        elif USE_LOSS_BWD4 and nh <= 4:             # every head in one launch: the labels are read once
             grads = [torch.empty_like(logits[h]) for h in range(nh)]
             H.call("vx_seg_loss_bwd4", *([H.P(t) for t in logits] + [None] * (4 - nh)), nh, H.P(labels, None), _LAB_KIND[labels.dtype], coef.data_ptr(), stride // 4,
                    H.P(go), *([H.P(d) for d in grads] + [None] * (4 - nh)), B, C, V, st)

@@ -26,6 +26,10 @@ class VeloxSeg(nn.Module):
             raise NotImplementedError("veloxseg_amd implements the 3-D network (all shipped configs)")
         VF.reset_dropout_sites()
         self._on_encoder_outputs = None
+        # True (set by engine.TrainEngine): the training forward returns the deep-supervision heads 1.. on THEIR OWN grids and veloxseg_amd.utils.loss.Loss
+        # interpolates them inside the loss kernels (csrc/loss_ds.hip) -- same loss and gradients, the three (B, ncls, S^3) tensors are never written.
+        # False (default) = the reference's output list: every head up-sampled to the input size (VeloxSeg.py:202).
+        self.ds_fused = False
         self.size = list(input_size)
         self.spatial_dim = spatial_dim
         self.patch_size = patch_size
@@ -66,6 +70,8 @@ class VeloxSeg(nn.Module):
         """branch 0 -> (pred_0..pred_3, dec_pram); branch m+1 -> (rc_m, rc_pram_m).  attn[L][m] / encs[L] as returned by the encoder."""
         if k == 0:
             pred, dec_pram = self.decoder(*encs)
+            if self.ds_fused:
+                return (self.scale_prediction(pred[0]),) + tuple(pred[1:]) + (dec_pram,)
             return tuple(self.scale_prediction(p) for p in pred) + (dec_pram,)
         m = k - 1
         return tuple(self.rc_decoders[m]([attn[L][m] for L in range(4)], encs))
