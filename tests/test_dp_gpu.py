@@ -39,27 +39,47 @@ def _setup():
     return cfg_d, crit, x, lab, model, TrainEngine
 
 
-def _worker(rank, world, port, out_dir, use_graph):
+def _worker(rank, world, port, out_dir, use_graph, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                 # production: one rank per GPU, RCCL over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:                                 # the test box has one MI355X: both ranks share it over gloo
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
     eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True)
     assert eng.world == 2 and eng.overlap
     loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
     torch.cuda.synchronize()
+    if not use_graph:      # the bucketed all-reduces of one step tile the flat gradient buffer exactly once (tail first)
+        cover = sorted(eng._reduced)
+        assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
+        assert [r[1] for r in eng._reduced] == sorted((r[1] for r in eng._reduced), reverse=True), ("buckets must be reduced tail first", eng._reduced)
     if rank == 0:      # flat.grad now holds the SUM over ranks (AdamW applies the 1/world scale)
-        torch.save({"grad": (eng.flat.grad / world).cpu(), "param": eng.flat.param.cpu(), "loss": float(loss)}, os.path.join(out_dir, "dp.pt"))
+        torch.save({"grad": (eng.flat.grad / world).cpu(), "param": eng.flat.param.cpu(), "loss": float(loss), "plan": eng.flat.plan()}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (RCCL); the one-GPU box runs the gloo variant below")
+def test_two_rank_engine_over_rccl_equals_single_process(tmp_path):
+    """the same check on the production backend: torch.distributed "nccl" = RCCL, one rank per GPU"""
+    _check_two_ranks(tmp_path, False, "nccl")
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graphs"])
 def test_two_rank_engine_equals_single_process(tmp_path, use_graph):
+    _check_two_ranks(tmp_path, use_graph, "gloo")
+
+
+def _check_two_ranks(tmp_path, use_graph, backend):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph, backend), nprocs=world, join=True)
     dp = torch.load(os.path.join(str(tmp_path), "dp.pt"))
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
     eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=False, overlap=True)    # world 1: overlap off automatically

@@ -45,11 +45,14 @@ struct VxDs {
     float* dl0;                 // backward: gradient of head 0
     float* t2[3];               // backward: (B, C, D, h, w) partially reduced gradients of heads 1..
     int nh, B, D, H, W;
+    int stage;                  // 1: the grids of a sample are staged in LDS (they fit); 0: gathered from global memory
 };
 
 // logits of head hh (>= 1) at the 4 voxels (Z, Y, X0..X0+3): z[c][j]
+// `lowb` = the (C, d, h, w) grid of THIS sample (staged in LDS by vx_ds_stage: the 8 taps of a voxel are gathers, and gathers from global memory were
+// what the first version of these kernels spent their time on)
 template <int C>
-__device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, int b, int Z, int Y, int X0, float (&z)[C][4]) {
+__device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, const float* __restrict__ lowb, int Z, int Y, int X0, float (&z)[C][4]) {
     const int d = P.ld[hh][0], h = P.ld[hh][1], w = P.ld[hh][2];
     int a0, b0, a1, b1;
     float l0, l1;
@@ -62,7 +65,7 @@ __device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, int b, int Z
     for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, w, P.W, a2[j], b2[j], l2[j]);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const float* __restrict__ xb = P.low[hh] + ((long)b * C + c) * d * h * w;
+        const float* __restrict__ xb = lowb + (long)c * d * h * w;
         const float* __restrict__ r00 = xb + ((long)a0 * h + a1) * w;
         const float* __restrict__ r01 = xb + ((long)a0 * h + b1) * w;
         const float* __restrict__ r10 = xb + ((long)b0 * h + a1) * w;
@@ -76,14 +79,40 @@ __device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, int b, int Z
     }
 }
 
+// stage the grids of sample b (heads 1..nh-1) into LDS; lows[hh] receives the LDS base of head hh.  Returns the floats used.
+template <int C>
+__device__ __forceinline__ int vx_ds_stage(const VxDs& P, int b, float* __restrict__ lds, const float* (&lows)[3]) {
+    int off = 0;
+    for (int hh = 0; hh < 3; ++hh) {
+        lows[hh] = lds + off;
+        if (hh >= P.nh - 1) continue;
+        const int n = C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2];
+        const float* __restrict__ src = P.low[hh] + (long)b * n;
+        if (!P.stage) { lows[hh] = src; continue; }
+        for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; v[u] = src[e < n ? e : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; if (e < n) lds[off + e] = v[u]; }
+        }
+        off += (n + 3) & ~3;
+    }
+    return off;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------ forward
 // acc layout (double) as vx_seg_loss_fwd: head h at h*(1 + B*C*3): [ce_sum, (I, P, T) x (b, c)].  grid (chunks, B)
 template <int C>
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* __restrict__ lab, int lab_kind, double* __restrict__ acc) {
     constexpr int NS = 1 + 2 * C;
+    extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
     const int b = blockIdx.y;
     const int W4 = P.W >> 2;
     const long V = (long)P.D * P.H * P.W, V4 = V >> 2;
+    const float* lows[3];
+    vx_ds_stage<C>(P, b, vx_ds_lds, lows);
+    __syncthreads();
     float S[4][NS], T[C];
 #pragma unroll
     for (int h = 0; h < 4; ++h)
@@ -109,7 +138,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* 
                         const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + 4 * q);
                         z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
                     }
-                } else vx_ds_interp<C>(P, h - 1, b, Z, Y, X0, z);
+                } else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float mx = z[0][j];
@@ -169,7 +198,39 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     const long V = (long)P.D * P.H * P.W;
     float* __restrict__ accw = vx_ds_lds + (long)wave * nacc;                                   // [head][c][y][x]
     float* __restrict__ gbuf = vx_ds_lds + 4L * nacc + (long)wave * (RPW * 3 * C * P.W);        // [row][head][c][X]
+    // banded adjoint tables of the W axis: coarse column xl of head hh collects the fine columns lo .. lo + BW - 1 with weights wtab (zero past the band)
+    float* __restrict__ wtab = vx_ds_lds + 4L * nacc + 4L * (RPW * 3 * C * P.W);                // [head][xl][BW]
+    int bw[3], toff[3], ntab = 0;
+    for (int hh = 0; hh < 3; ++hh) {
+        const int wl = P.ld[hh][2];
+        const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
+        bw[hh] = (hh < nlow) ? ((wl == P.W || ratio <= 0.0f) ? P.W : min(P.W, (int)(2.0f / ratio) + 4)) : 0;
+        toff[hh] = ntab;
+        if (hh < nlow) ntab += wl * bw[hh];
+    }
+    int* __restrict__ lotab = reinterpret_cast<int*>(wtab + ((ntab + 3) & ~3));                  // [head][xl]: first fine column of the band
+    const float* lows[3];
+    vx_ds_stage<C>(P, b, reinterpret_cast<float*>(lotab + 3 * P.W), lows);
+    for (int hh = 0; hh < nlow; ++hh) {
+        const int wl = P.ld[hh][2];
+        const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
+        for (int e = threadIdx.x; e < wl * bw[hh]; e += 256) {
+            const int xl = e / bw[hh], k = e - xl * bw[hh];
+            int lo = 0;
+            if (wl != P.W && ratio > 0.0f) { lo = (int)ceilf(((float)xl - 1.0f) / ratio) - 1; if (lo < 0) lo = 0; }
+            const int X = lo + k;
+            float wgt = 0.0f;
+            if (X < P.W) {
+                int i0, i1; float lam;
+                vx_ds_coord(X, wl, P.W, i0, i1, lam);
+                wgt = (i0 == xl ? 1.0f - lam : 0.0f) + (i1 == xl ? lam : 0.0f);
+            }
+            wtab[toff[hh] + e] = wgt;
+            if (k == 0) lotab[hh * P.W + xl] = lo;
+        }
+    }
     for (int k = lane; k < nacc; k += 64) accw[k] = 0.0f;
+    __syncthreads();
     const float go = gout ? gout[0] : 1.0f;
     int aoff[3];                                                                                // offsets of the heads inside accw
     { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += C * P.ld[hh][1] * P.ld[hh][2]; } }
@@ -188,7 +249,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                         const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0);
                         z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
                     }
-                } else vx_ds_interp<C>(P, h - 1, b, Z, Y, X0, z);
+                } else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
                 const float* __restrict__ coef_h = coef + (long)h * coef_stride;
                 const float wce = coef_h[0];
                 float al[C], be[C];
@@ -228,24 +289,15 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
             const int nown = C * wl;
             for (int o = lane; o < nown; o += 64) {
                 const int c = o / wl, xl = o - c * wl;
-                // fine columns X with a tap on coarse column xl: src = ratio * X in (xl - 1, xl + 1)
-                const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
-                int lo = 0, hi = P.W - 1;
-                if (wl != P.W && ratio > 0.0f) {
-                    lo = (int)ceilf(((float)xl - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
-                    hi = (int)floorf(((float)xl + 1.0f) / ratio) + 1; if (hi > P.W - 1) hi = P.W - 1;
-                }
+                const int lo = lotab[hh * P.W + xl], nb = bw[hh];
+                const float* __restrict__ wt = wtab + toff[hh] + xl * nb;
                 for (int r = 0; r < RPW; ++r) {
                     const int Yr = Y0 + r;
                     if (Yr >= P.H) break;
                     const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * C + c) * P.W;
                     float s = 0.0f;
-                    for (int X = lo; X <= hi; ++X) {
-                        int i0, i1; float lam;
-                        vx_ds_coord(X, wl, P.W, i0, i1, lam);
-                        const float wgt = (i0 == xl ? 1.0f - lam : 0.0f) + (i1 == xl ? lam : 0.0f);      // (i0 == i1 at the last column: weights add up to 1)
-                        s = fmaf(wgt, gr[X], s);
-                    }
+#pragma unroll 8
+                    for (int k = 0; k < nb; ++k) s = fmaf(wt[k], gr[min(lo + k, P.W - 1)], s);      // independent LDS reads: the band's weights are zero past its end
                     int a1, b1; float l1;
                     vx_ds_coord(Yr, hl, P.H, a1, b1, l1);
                     float* __restrict__ dst = accw + aoff[hh] + (long)c * hl * wl + xl;
@@ -310,6 +362,12 @@ static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2
     return 0;
 }
 
+static size_t vx_ds_low_floats(const VxDs& P, int C) {
+    size_t n = 0;
+    for (int hh = 0; hh < P.nh - 1; ++hh) n += ((size_t)C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2] + 3) & ~(size_t)3;
+    return n;
+}
+
 // 1 when the fused kernels cover this shape (else: up-sample + vx_seg_loss_fwd / _bwd4)
 extern "C" int vx_seg_loss_ds_ok(int C, int D, int H, int W) {
     (void)D; (void)H;
@@ -324,12 +382,20 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_ds_fwd: memset failed");
     const long V4 = ((long)D * H * W) >> 2;
-    int chunks = vx_cdiv(V4, 256 * 2);
-    if (chunks > 1024) chunks = 1024;
+    int chunks = vx_cdiv(V4, 256 * 4);
+    if (chunks > 512) chunks = 512;
     const dim3 grid(chunks, B), blk(256);
-    if (C == 2) vx_seg_loss_ds_fwd_k<2><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
-    else if (C == 3) vx_seg_loss_ds_fwd_k<3><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
-    else vx_seg_loss_ds_fwd_k<4><<<grid, blk, 0, st>>>(P, labels, lab_kind, acc);
+    size_t shm = vx_ds_low_floats(P, C) * sizeof(float);
+    P.stage = shm <= 120 * 1024;
+    if (!P.stage) shm = 0;
+#define VX_DS_FWD(CC)                                                                                                                 \
+    {                                                                                                                                 \
+        static size_t cap = 64 * 1024;          /* the kernel also has static LDS: raise the dynamic limit only as far as needed */            \
+        if (shm > cap) { if (hipFuncSetAttribute((const void*)vx_seg_loss_ds_fwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) { (void)hipGetLastError(); VX_FAIL(-2, "vx_seg_loss_ds_fwd: cannot reserve %zu bytes of LDS", shm); } cap = shm; } \
+        vx_seg_loss_ds_fwd_k<CC><<<grid, blk, shm, st>>>(P, labels, lab_kind, acc);                                                   \
+    }
+    if (C == 2) VX_DS_FWD(2) else if (C == 3) VX_DS_FWD(3) else VX_DS_FWD(4)
+#undef VX_DS_FWD
     VX_LAUNCH_CHECK("vx_seg_loss_ds_fwd");
     return 0;
 }
@@ -365,14 +431,23 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
     }
     Zp.nlow = nh - 1; Zp.BC = B * C; Zp.D = D;
     const int RPW = 64 / (W >> 2);
-    const size_t shm = ((size_t)4 * nacc + (size_t)4 * RPW * 3 * C * W) * sizeof(float);
+    size_t ntab = 0;
+    for (int hh = 0; hh < nh - 1; ++hh) {
+        const int wl = P.ld[hh][2];
+        const float ratio = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.0f;
+        const int bwd_ = (wl == W || ratio <= 0.0f) ? W : ((int)(2.0f / ratio) + 4 < W ? (int)(2.0f / ratio) + 4 : W);
+        ntab += (size_t)wl * bwd_;
+    }
+    const size_t shm_base = ((size_t)4 * nacc + (size_t)4 * RPW * 3 * C * W + ((ntab + 3) & ~(size_t)3) + (size_t)3 * W) * sizeof(float);
+    P.stage = shm_base + vx_ds_low_floats(P, C) * sizeof(float) <= 150 * 1024;
+    const size_t shm = shm_base + (P.stage ? vx_ds_low_floats(P, C) * sizeof(float) : 0);
     VX_REQUIRE(shm <= 150 * 1024, "vx_seg_loss_ds_bwd: the low-resolution grids do not fit LDS (%zu bytes)", shm);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(D, B), blk(256);
 #define VX_DS_BWD(CC)                                                                                                                 \
     {                                                                                                                                 \
-        static bool once = false;                                                                                                     \
-        if (!once) { (void)hipFuncSetAttribute((const void*)vx_seg_loss_ds_bwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
+        static size_t cap = 64 * 1024;                                                                                                \
+        if (shm > cap) { if (hipFuncSetAttribute((const void*)vx_seg_loss_ds_bwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) { (void)hipGetLastError(); VX_FAIL(-2, "vx_seg_loss_ds_bwd: cannot reserve %zu bytes of LDS", shm); } cap = shm; } \
         vx_seg_loss_ds_bwd_k<CC><<<grid, blk, shm, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);                         \
     }
     if (C == 2) VX_DS_BWD(2) else if (C == 3) VX_DS_BWD(3) else VX_DS_BWD(4)

@@ -29,34 +29,75 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
-class FlatParams:
-    """Re-homes every parameter (and its .grad) of `model` as a view into one flat fp32 buffer."""
+def param_bucket(name: str) -> int:
+    """Bucket of a parameter = the order in which backward completes its gradient, LAST first: 0..3 = encoder levels 1..4 (PatchEmbed with level 1;
+    `encoder_attn.layers.k` incl. its PatchMerging, `encoder_conv.down{k+1} / layer{k+1}`, `attn2conv_{k+1}` with level k+1), 4 = the decoders.
+    Backward runs decoders -> level 4 -> ... -> level 1, so the flat buffer [L1 | L2 | L3 | L4 | decoders] is reduced from its tail to its head."""
+    import re as _re
+    if not name.startswith("encoder."):
+        return 4
+    for pat, off in ((r"encoder\.encoder_attn\.layers\.(\d+)\.", 0), (r"encoder\.encoder_conv\.(?:down|layer)(\d+)", -1), (r"encoder\.attn2conv_(\d+)", -1)):
+        m = _re.match(pat, name)
+        if m:
+            return min(max(int(m.group(1)) + off, 0), 3)
+    return 0
 
-    def __init__(self, model: torch.nn.Module, first: Sequence[str] = ("encoder.",)):
+
+class FlatParams:
+    """Re-homes every parameter (and its .grad) of `model` as a view into one flat fp32 buffer, grouped by bucket (param_bucket)."""
+
+    def __init__(self, model: torch.nn.Module, bucket_of=param_bucket):
         params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
         dev = params[0][1].device
-        head = [(n, p) for n, p in params if any(n.startswith(f) for f in first)]
-        tail = [(n, p) for n, p in params if not any(n.startswith(f) for f in first)]
+        order = sorted(range(len(params)), key=lambda i: (bucket_of(params[i][0]), i))      # stable: registration order inside a bucket
         self.names: List[str] = []
         self.slices = {}
+        self.bounds = {}                     # bucket -> (lo, hi) element range of the flat buffers
         off = 0
-        for n, p in head + tail:
+        for i in order:
+            n, p = params[i]
+            b = bucket_of(n)
+            if b not in self.bounds:
+                self.bounds[b] = [off, off]
             self.slices[n] = (off, p.numel())
             self.names.append(n)
             off = _align(off + p.numel())
-        self.split = self.slices[tail[0][0]][0] if tail else off
+            self.bounds[b][1] = off
+        self.bounds = {b: tuple(v) for b, v in self.bounds.items()}
+        self.split = self.bounds[4][0] if 4 in self.bounds else off          # start of the decoder bucket
         self.numel = off
         self.param = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for n, p in head + tail:
+            for i in order:
+                n, p = params[i]
                 o, k = self.slices[n]
                 self.param[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.param[o:o + k].view(p.shape)
                 p.grad = self.grad[o:o + k].view(p.shape)
-        self.params = [p for _, p in head + tail]
+        self.params = [params[i][1] for i in order]
+
+    def plan(self, min_bytes: int = 1 << 20):
+        """All-reduce plan for the overlapped backward: [(trigger, lo, hi)], tail first.  trigger 4 = "decoders done", 3 / 2 / 1 = "encoder level
+        4 / 3 / 2 done" (multi-grad hooks), 0 = after backward.  Buckets smaller than min_bytes are merged into the NEXT (later-finishing) one, since
+        at this payload a collective is latency-bound."""
+        out, lo_pending = [], None
+        for b in (4, 3, 2, 1, 0):
+            if b not in self.bounds:
+                continue
+            lo, hi = self.bounds[b]
+            if lo_pending is not None:
+                hi = lo_pending[1]
+            if b != 0 and (hi - lo) * 4 < min_bytes:
+                lo_pending = (lo, hi)          # too small: reduce together with the next bucket down
+                continue
+            out.append((b, lo, hi))
+            lo_pending = None
+        if lo_pending is not None:
+            out.append((0, lo_pending[0], lo_pending[1]))
+        return out
 
     def zero_grad(self):
         self.grad.zero_()
@@ -140,44 +181,58 @@ class TrainEngine:
             waiter.wait_stream(s_)
 
     def _fwd_bwd_overlapped(self):
-        """plain eager step + the decoder-bucket all-reduce started from INSIDE the backward pass: every decoder consumes the deepest
-        encoder output enc4 in its first layer, so the gradient of enc4 is complete exactly when the three decoders have finished
-        their backward (all their weight-gradient kernels are queued); a multi-grad hook on enc4 then launches the all-reduce of the
-        decoder bucket on the communication stream, where it overlaps the whole encoder backward.  No staging, no detached leaves."""
+        """plain eager step + bucketed all-reduces started from INSIDE the backward pass (FlatParams.plan): the decoder bucket when the gradient of
+        enc4 is complete (every decoder consumes enc4 in its first layer, so its gradient is final exactly when the three decoders have queued their
+        whole backward), then one bucket per encoder level when the gradients of that level's INPUTS (the tensors level L-1 hands to level L) are
+        complete; each runs on the communication stream while the earlier levels' backward executes.  Only the last, smallest bucket (levels 1-2,
+        0.65 MB of the 9.2 MB payload) is reduced after backward().  No staging, no detached leaves."""
         self.flat.zero_grad()
         handles = []
-        split, n = self.flat.split, self.flat.numel
+        plan = self.flat.plan()
+        self._reduced = []
+        by_trigger = {t: (lo, hi) for t, lo, hi in plan}
+        fired = set()
 
-        fired = []
-
-        def decoders_done(_grads):
-            fired.append(True)
+        def reduce_now(trigger):
+            fired.add(trigger)
+            lo, hi = by_trigger[trigger]
             cur = torch.cuda.current_stream(self.dev)
             self.comm_stream.wait_stream(cur)
             m = VF.cpp_module() if WGRAD_STREAM else None
             if m is not None:
-                m.wgrad_join(self.comm_stream.cuda_stream, self.dev.index or 0, False)      # the decoders' weight gradients run on the side stream
-            for s_ in VF.branch_stream_list(self.dev, self.model.num_branches, "branches"):
+                m.wgrad_join(self.comm_stream.cuda_stream, self.dev.index or 0, False)      # weight gradients deferred to the side stream
+            for s_ in VF.all_side_streams(self.dev):      # the weight-gradient kernels ran on the streams of their nodes
                 self.comm_stream.wait_stream(s_)
             with torch.cuda.stream(self.comm_stream):
-                self._allreduce(split, n)
+                self._allreduce(lo, hi)
 
         def on_enc(attn, encs):
-            handles.append(torch.autograd.graph.register_multi_grad_hook([encs[-1]], decoders_done, mode="all"))
+            if 4 in by_trigger:
+                handles.append(torch.autograd.graph.register_multi_grad_hook([encs[-1]], lambda _g: reduce_now(4), mode="all"))
+
+        def on_level(level, tensors):               # level = 2..4 (1-based): `tensors` are that level's inputs
+            trig = level - 1                         # level 4 done -> trigger 3, ...
+            ts = [t for t in tensors if t.requires_grad]
+            if trig in by_trigger and ts:
+                handles.append(torch.autograd.graph.register_multi_grad_hook(ts, lambda _g, trig=trig: reduce_now(trig), mode="all"))
 
         self.model._on_encoder_outputs = on_enc
+        self.model.encoder._on_level_inputs = on_level
         try:
             outs, loss = self._forward_loss()
             self._backward(loss)
         finally:
             self.model._on_encoder_outputs = None
+            self.model.encoder._on_level_inputs = None
             for h in handles:
                 h.remove()
-        if not fired:             # the hook did not run (e.g. enc4 needed no gradient): reduce the decoder bucket now rather than silently skipping it
-            cur = torch.cuda.current_stream(self.dev)
-            self.comm_stream.wait_stream(cur)
-            with torch.cuda.stream(self.comm_stream):
-                self._allreduce(split, n)
+        cur = torch.cuda.current_stream(self.dev)
+        for t, lo, hi in plan:                       # whatever did not fire from a hook (always trigger 0), in plan order
+            if t not in fired:
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self._allreduce(lo, hi)
+        cur.wait_stream(self.comm_stream)
         self.loss.copy_(loss.detach())
         self.last_outputs = [o.detach() for o in outs]
 
@@ -242,6 +297,8 @@ class TrainEngine:
         self._eager_stages()
 
     def _allreduce(self, lo, hi):
+        if getattr(self, "_reduced", None) is not None:
+            self._reduced.append((lo, hi))            # (tests: the slices of one step must tile the flat buffer exactly once)
         dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
 
     # ---- torch.optim.AdamW as the state carrier (reference checkpoints, LR schedulers) ---------------
@@ -253,7 +310,7 @@ class TrainEngine:
         optimizer.load_state_dict()."""
         if not isinstance(optimizer, torch.optim.AdamW):
             raise TypeError("TrainEngine drives torch.optim.AdamW only (the optimizer of every shipped train_config)")
-        if len(optimizer.param_groups) != 1 or [id(p) for p in optimizer.param_groups[0]["params"]] != [id(p) for p in self.flat.params]:
+        if len(optimizer.param_groups) != 1 or sorted(id(p) for p in optimizer.param_groups[0]["params"]) != sorted(id(p) for p in self.flat.params):
             raise ValueError("optimizer must hold exactly model.parameters() in one param group")
         if optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
             raise NotImplementedError("amsgrad / maximize are not supported by the fused AdamW")
@@ -412,11 +469,7 @@ class TrainEngine:
                 self._fwd_bwd_single()
                 self._allreduce(0, n)
             else:
-                self._fwd_bwd_overlapped()                      # decoder bucket is reduced while the encoder backward runs
-                self.comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self.comm_stream):
-                    self._allreduce(0, split)
-                cur.wait_stream(self.comm_stream)
+                self._fwd_bwd_overlapped()                      # every bucket but the last is reduced while the backward pass still runs
         self._adamw()
         return self.loss
 

@@ -122,6 +122,7 @@ class Encoder(nn.Module):
         self.encoder_conv = Conv_Encoder(patch_size=patch_size, in_ch=sum(in_ch), base_ch=base_ch, depths=conv_depths, kernel_sizes=kernel_sizes,
                                          min_dim_group=min_dim_group, expansion_factor=conv_expansion_factor, dropout=conv_drop, spatial_dim=spatial_dim)
         M = self.num_modalities
+        self._on_level_inputs = None        # engine hook: called with (level 2..4, the tensors level L-1 hands to level L) during a training forward
         for i in range(4):
             setattr(self, f"attn2conv_{i + 1}", nn.Sequential(ParamConv3d(attn_base_ch * 2 ** i * M, base_ch * 2 ** i, 1, 1), InstanceNormMarker(base_ch * 2 ** i)))
 
@@ -148,6 +149,8 @@ class Encoder(nn.Module):
         attn, encs = [], []
         prev = x
         for i in range(4):
+            if i > 0 and self._on_level_inputs is not None and self.training:
+                self._on_level_inputs(i + 1, list(cur_feats) + [prev])       # level i+1 consumes the merged tokens and the conv feature of level i
             a_i, cur_feats = ta.layers[i](cur_feats)
             attn.append(a_i)
             if side is not None:
