@@ -177,6 +177,11 @@ def _self_launch(n):
     return rc
 
 
+def _tapes(eng):
+    G = eng.graphs
+    return [G["enc_fwd"], G["loss"], G["enc_bwd"]] + list(G["dec_fwd"]) + list(G["dec_bwd"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +189,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="autopet128", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: workload default)")
-    ap.add_argument("--graph", action="store_true", help="replay per-stage hipGraphs instead of launching eagerly (slower on ROCm 7.2: DESIGN.md section 7)")
+    ap.add_argument("--eager", action="store_true", help="launch every step through autograd (host-bound: ~10 ms of enqueue per step) instead of replaying the captured launch tapes")
+    ap.add_argument("--hipgraph", action="store_true", help="replay the captured stages with hipGraphLaunch instead of the launch tape (slower on ROCm 7.2: DESIGN.md section 3)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches on forked HIP streams")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -226,7 +232,7 @@ def main():
     model = VeloxSeg(**cfg).to(dev)
     VF.manual_seed(12345 + rank, dev)
     crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, dev, num_modal=len(cfg["in_ch"]))
-    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=args.graph, overlap=not args.no_overlap)
+    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.eager, replay="graph" if args.hipgraph else "tape", overlap=not args.no_overlap)
     x, lab = synth(cfg, B, dev, 12345 + rank)
     eng.step(x, lab)                                           # capture (+ first step)
     for _ in range(max(args.warmup - 1, 0)):
@@ -262,7 +268,7 @@ def main():
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "hip_graph": bool(eng.use_graph), "launch": "hipGraph per stage" if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
+                          "hip_graph": bool(eng.use_graph), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream events" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
         from veloxseg_amd import functional as VF

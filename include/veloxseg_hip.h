@@ -325,6 +325,24 @@ int vx_label_kth_in_chunk(const void* labels, int lab_bytes, long n, long chunk_
 /* rotation about the last spatial axis (the (D,H) plane turns), centre (n-1)/2, border padding; mode 0 bilinear, 1 nearest */
 int vx_rotate_z(const float* x, float* out, int C, int D, int H, int W, float cos_a, float sin_a, int mode, void* stream);
 
+/* ---- launch tape: a captured training stage replayed as plain launches on several HIP streams -----------------------------------------
+ * The reference trains through eager PyTorch (utils/train_autopet.py:233-262: model(), loss, backward(), optimizer.step()); here one captured
+ * pass of a stage (hipStreamBeginCapture ... EndCapture -> hipGraph_t, addresses from a private pool) is read back ONCE -- kernel and memset
+ * nodes with their launch parameters (memcpy nodes are refused: ROCm 7.2 cannot read them back), and the dependency edges -- and replayed every step with hipLaunchKernel on `max_lanes`
+ * streams with events only where an edge crosses streams (~3 us of host time per node; hipGraphLaunch on ROCm 7.2 needs ~17 us and
+ * serialises the branches).  The caller keeps the hipGraph_t alive as long as the tape: kernel arguments are read from its nodes.
+ * vx_tape_replay enqueues behind `stream` and joins every lane back into it before returning (it never blocks the host). */
+typedef struct VxTape VxTape;
+int vx_tape_build(void* hip_graph, int max_lanes, VxTape** out);
+int vx_tape_info(const VxTape* tape, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events);
+int vx_tape_replay(VxTape* tape, void* stream);
+int vx_tape_free(VxTape* tape);
+/* the process-wide stream of lane `lane` (lane % 4).  The four lane streams are chosen at first use so that they sit on different hardware
+ * queues (measured with a spinning kernel: streams that share one of ROCm's 4 hardware queues never overlap, and neither does the NULL stream
+ * with anything).  A tape with one lane replays on the caller's stream; a tape with more replays on the lane streams, gated by and joined
+ * back into the caller's stream. */
+int vx_tape_lane_stream(void* any_stream, int lane, void** out);
+
 #ifdef __cplusplus
 }
 #endif

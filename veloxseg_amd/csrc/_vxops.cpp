@@ -613,6 +613,169 @@ struct AxpyFn : public torch::autograd::Function<AxpyFn> {
     }
 };
 
+// Paired-Window Attention core (gather -> attention -> scatter for all modalities, PWA.py:106-200,308-327) as ONE C++ autograd node: no interpreter
+// between its ~6 forward / ~9 backward launches.  qkv = (q0, k0, v0, q1, k1, v1, ...), (B, nb*heads*c, g0, g1, g2) each.
+struct PwaState {
+    VxPwaPlan plan;
+    Tensor tq, tk, tv, O, lse, tbl, iq, ik, iv, table;
+    std::vector<std::vector<int64_t>> shapes;
+    int cq = 0, cv = 0, M = 0, B = 0;
+    double p = 0; int64_t site = 0; const void* rs = nullptr;
+};
+struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& table, int64_t plan_ptr, int64_t cq, int64_t cv, double p_attn, int64_t site, int64_t rs,
+                                 at::TensorList qkv) {
+        auto h = put_state<PwaState>(ctx);
+        PwaState& st = h->s;
+        st.plan = *reinterpret_cast<const VxPwaPlan*>(plan_ptr);
+        const VxPwaPlan* pp = &st.plan;
+        const int M = (int)qkv.size() / 3;
+        TORCH_CHECK(M >= 1 && (int)qkv.size() == 3 * M && M <= 4, "pwa_core: expected 3*M tensors, M <= 4");
+        check_in(qkv[0], "pwa_attention");
+        void* s_ = cur_stream(qkv[0]);
+        const int B = qkv[0].size(0), hd = pp->heads, Nt = pp->Ntot, ML = M * pp->l;
+        st.cq = (int)cq; st.cv = (int)cv; st.M = M; st.B = B; st.p = p_attn; st.site = site; st.rs = p_attn > 0 ? sp(rs) : nullptr; st.table = table;
+        auto opt = qkv[0].options();
+        st.tq = at::empty({B, hd, Nt, ML, cq}, opt); st.tk = at::empty({B, hd, Nt, ML, cq}, opt); st.tv = at::empty({B, hd, Nt, ML, cv}, opt);
+        auto iopt = opt.dtype(at::kInt);
+        st.iq = at::empty({B, hd, Nt, ML, cq}, iopt); st.ik = at::empty({B, hd, Nt, ML, cq}, iopt); st.iv = at::empty({B, hd, Nt, ML, cv}, iopt);
+        std::vector<Tensor> keep;
+        const float* srcs[12];
+        for (int i = 0; i < 3 * M; ++i) { keep.push_back(contig(qkv[i])); srcs[i] = fp(keep.back()); st.shapes.push_back(keep.back().sizes().vec()); }
+        VX(vx_pwa_gather_all_fwd, srcs, mp(st.tq), mp(st.tk), mp(st.tv), st.iq.data_ptr<int>(), st.ik.data_ptr<int>(), st.iv.data_ptr<int>(), pp, (int)cq, (int)cv, M, B, s_);
+        st.O = at::empty_like(st.tv);
+        st.lse = at::empty({B, hd, Nt, ML}, opt);
+        st.tbl = contig(table);
+        VX(vx_pwa_attn_fwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), mp(st.O), mp(st.lse), pp, B, M, (int)cq, (int)cv, st.rs, (unsigned long long)site, (float)p_attn, s_);
+        variable_list outs;
+        for (int m = 0; m < M; ++m) {
+            Tensor o = at::empty({B, (long)pp->nb * hd * cv, pp->grid[0], pp->grid[1], pp->grid[2]}, opt);
+            VX(vx_pwa_scatter_fwd, fp(st.O), mp(o), pp, (int)cv, m, M, B, s_);
+            outs.push_back(o);
+        }
+        return outs;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        PwaState& st = get_state<PwaState>(ctx);
+        const VxPwaPlan* pp = &st.plan;
+        const int M = st.M, B = st.B;
+        Tensor ref;
+        for (auto& t : g) if (t.defined()) { ref = t; break; }
+        variable_list out(7 + 3 * M);
+        if (!ref.defined()) { ctx->saved_data.clear(); return out; }
+        void* s_ = cur_stream(ref);
+        Tensor dO = at::zeros_like(st.O);
+        for (int m = 0; m < M; ++m) {
+            if (!g[m].defined()) continue;
+            Tensor gm = contig(g[m]);
+            VX(vx_pwa_scatter_bwd, fp(gm), mp(dO), pp, st.cv, m, M, B, s_);
+        }
+        Tensor dq = at::empty_like(st.tq), dk = at::empty_like(st.tk), dv = at::empty_like(st.tv);
+        const int nws = vx_pwa_attn_bwd_ws_floats(pp, B, M);
+        TORCH_CHECK(nws >= 0, "vx_pwa_attn_bwd_ws_floats failed");
+        Tensor delta = at::empty({(long)nws}, st.tq.options());
+        Tensor dtab_tmp;
+        float* dtab = grad_ptr(st.table);
+        if (!dtab) { dtab_tmp = at::zeros_like(st.tbl); dtab = dtab_tmp.data_ptr<float>(); }
+        VX(vx_pwa_attn_bwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), dtab, mp(delta), pp, B, M, st.cq, st.cv,
+           st.rs, (unsigned long long)st.site, (float)st.p, s_);
+        float* dsts[12];
+        for (int i = 0; i < 3 * M; ++i) { Tensor t = at::empty(st.shapes[i], st.tq.options()); out[7 + i] = t; dsts[i] = t.data_ptr<float>(); }
+        VX(vx_pwa_gather_all_bwd, fp(dq), fp(dk), fp(dv), st.iq.data_ptr<int>(), st.ik.data_ptr<int>(), st.iv.data_ptr<int>(), dsts, pp, st.cq, st.cv, M, B, s_);
+        ctx->saved_data.clear();
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------- small single-kernel nodes
+// ConvTranspose3d(k=2, s=2) (conv_blocks.py:29-35), PatchMerging's space-to-depth (attention_utils.py:144-159), F.interpolate(trilinear, align_corners)
+// (VeloxSeg.py:183) and the SDKT Gram matrix (loss.py:39-60) as C++ nodes: the same C-ABI calls as the python nodes of functional.py.
+struct UpconvFn : public torch::autograd::Function<UpconvFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w, const OptT& b_) {
+        check_in(x_in, "conv_transpose3d");
+        Tensor x = contig(x_in), b = b_.value_or(Tensor());
+        const int B = x.size(0), Ci = x.size(1), d = x.size(2), h = x.size(3), wd = x.size(4), Co = w.size(1);
+        TORCH_CHECK(w.size(0) == Ci && w.size(2) == 2 && w.size(3) == 2 && w.size(4) == 2, "conv_transpose_k2s2: weight must be (Ci, Co, 2, 2, 2)");
+        Tensor y = at::empty({B, Co, 2 * d, 2 * h, 2 * wd}, x.options());
+        VX(vx_upconv_k2s2_fwd, fp(x), fp(w), fp(b), mp(y), B, Ci, Co, d, h, wd, cur_stream(x));
+        ctx->saved_data["x"] = x; ctx->saved_data["w"] = w; ctx->saved_data["b"] = b;
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        Tensor x = ctx->saved_data["x"].toTensor(), w = ctx->saved_data["w"].toTensor();
+        Tensor b = ctx->saved_data["b"].isTensor() ? ctx->saved_data["b"].toTensor() : Tensor();
+        Tensor dy = contig(g[0]), dx;
+        const int B = x.size(0), Ci = x.size(1), d = x.size(2), h = x.size(3), wd = x.size(4), Co = w.size(1);
+        void* s_ = cur_stream(dy);
+        if (ctx->needs_input_grad(0)) { dx = at::empty_like(x); VX(vx_upconv_k2s2_bwd_data, fp(dy), fp(w), mp(dx), B, Ci, Co, d, h, wd, s_); }
+        float* dw = grad_ptr(w);
+        float* db = grad_ptr(b);
+        if (dw || db)
+            wgrad_submit(s_, x.device().index(), [=](void* s) {     // the transposed conv's weight gradient = the stride-2 conv's with x and dy swapped
+                if (dw) VX(vx_conv3d_bwd_weight_tiled, fp(dy), nullptr, 0, fp(x), dw, nullptr, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, s);
+                if (db) VX(vx_channel_sum, fp(dy), db, B, Co, 8L * d * h * wd, s);
+            });
+        if (!WG.enabled) WG.done.clear();
+        ctx->saved_data.clear();
+        return {dx, Tensor(), Tensor()};
+    }
+};
+struct S2DFn : public torch::autograd::Function<S2DFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in) {
+        check_in(x_in, "space_to_depth");
+        Tensor x = contig(x_in);
+        const int B = x.size(0), C = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4);
+        TORCH_CHECK(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "space_to_depth2: even extents only");
+        Tensor out = at::empty({B, 8 * C, D / 2, H / 2, W / 2}, x.options());
+        VX(vx_space_to_depth2, fp(x), mp(out), B, C, D / 2, H / 2, W / 2, 0, cur_stream(x));
+        ctx->saved_data["shape"] = x.sizes().vec();
+        return out;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto shp = ctx->saved_data["shape"].toIntVector();
+        Tensor dy = contig(g[0]), dx = at::empty(shp, dy.options());
+        VX(vx_space_to_depth2, fp(dy), mp(dx), (int)shp[0], (int)shp[1], (int)shp[2] / 2, (int)shp[3] / 2, (int)shp[4] / 2, 1, cur_stream(dy));
+        return {dx};
+    }
+};
+struct UpsampleFn : public torch::autograd::Function<UpsampleFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in, int64_t D, int64_t H, int64_t W) {
+        check_in(x_in, "upsample_trilinear");
+        Tensor x = contig(x_in);
+        Tensor out = at::empty({x.size(0), x.size(1), D, H, W}, x.options());
+        VX(vx_upsample_trilinear_fwd, fp(x), mp(out), (long)x.size(0) * x.size(1), (int)x.size(2), (int)x.size(3), (int)x.size(4), (int)D, (int)H, (int)W, cur_stream(x));
+        ctx->saved_data["shape"] = x.sizes().vec();
+        return out;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto shp = ctx->saved_data["shape"].toIntVector();
+        Tensor dy = contig(g[0]), dx = at::empty(shp, dy.options());
+        const long BC = shp[0] * shp[1];
+        const int d = shp[2], h = shp[3], w = shp[4], H = dy.size(3), W = dy.size(4);
+        Tensor ws = at::empty({BC * d * ((long)H * W + (long)h * W)}, dy.options());
+        VX(vx_upsample_trilinear_bwd, fp(dy), mp(dx), mp(ws), BC, d, h, w, (int)dy.size(2), H, W, cur_stream(dy));
+        return {dx, Tensor(), Tensor(), Tensor()};
+    }
+};
+struct GramFn : public torch::autograd::Function<GramFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in) {
+        check_in(x_in, "gram");
+        Tensor x = contig(x_in);
+        const int B = x.size(0), C = x.size(1);
+        Tensor G = at::empty({B, C, C}, x.options());
+        VX(vx_gram_fwd, fp(x), mp(G), B, C, (long)(x.numel() / ((long)B * C)), cur_stream(x));
+        ctx->saved_data["x"] = x;
+        return G;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        Tensor x = ctx->saved_data["x"].toTensor(), dG = contig(g[0]), dx = at::empty_like(x);
+        const int B = x.size(0), C = x.size(1);
+        VX(vx_gram_bwd, fp(x), fp(dG), mp(dx), B, C, (long)(x.numel() / ((long)B * C)), cur_stream(dG));
+        ctx->saved_data.clear();
+        return {dx};
+    }
+};
+
 static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, const std::vector<Tensor>& ws, const std::vector<Tensor>& bs, int G, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w,
                         const Tensor& l2b, double p, int64_t site, int64_t rs, int64_t stream) {
         auto st = std::make_shared<JLCState>();
@@ -877,6 +1040,13 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("ffn", [](const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p, int64_t site1,
                     int64_t site2, int64_t rs) { return FFNFn::apply(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs); });
     m.def("layernorm", [](const Tensor& x, const Tensor& g, const Tensor& bt) { return LayerNormFn::apply(x, g, bt); });
+    m.def("upconv_k2s2", [](const Tensor& x, const Tensor& w, const OptT& b) { return UpconvFn::apply(x, w, b); });
+    m.def("space_to_depth2", [](const Tensor& x) { return S2DFn::apply(x); });
+    m.def("upsample_trilinear", [](const Tensor& x, int64_t D, int64_t H, int64_t W) { return UpsampleFn::apply(x, D, H, W); });
+    m.def("gram", [](const Tensor& x) { return GramFn::apply(x); });
+    m.def("pwa_core", [](const Tensor& table, int64_t plan_ptr, int64_t cq, int64_t cv, double p_attn, int64_t site, int64_t rs, std::vector<Tensor> qkv) {
+        return PwaCoreFn::apply(table, plan_ptr, cq, cv, p_attn, site, rs, at::TensorList(qkv));
+    });
     m.def("gelu", [](const Tensor& a, double p, int64_t site, int64_t rs) { return GeluFn::apply(a, p, site, rs); });
     m.def("axpy", [](const OptT& x, const Tensor& z, double alpha, double p, int64_t site, int64_t rs) { return AxpyFn::apply(x, z, alpha, p, site, rs); });
 

@@ -1,0 +1,319 @@
+// Launch tape: a captured training stage replayed as plain kernel launches on several HIP streams.
+//
+// Why: the training step is ~640 short kernels (median ~15 us).  Launched eagerly through autograd the host needs ~10 ms to enqueue them, which
+// is also what the GPU needs to run them one after the other -- the forked streams never overlap because the host is not ahead.  hipGraphLaunch
+// on ROCm 7.2 costs ~17 us of host time per kernel node and does not overlap branches either.  The capture itself is
+// fine, though: it holds every launch with its final arguments, addresses from a private memory pool, and the exact dependency DAG.  This file
+// walks a captured hipGraph_t once (nodes, edges, launch parameters), lays the nodes out on a few stream "lanes" (a node continues the lane
+// of a predecessor whenever it can; an event is needed only for edges that cross lanes), and replays the list with hipLaunchKernel /
+// hipMemsetAsync: ~3 us of host time per node, no interpreter, no allocator, no autograd, and the lanes run concurrently.
+//
+// Any schedule that respects the DAG is as valid as hipGraphLaunch's (the capture-mode allocator hands a block to a second tensor only
+// along graph edges), so memory safety is the captured graph's.  The caller keeps the captured graph (and its pool) alive: the kernel
+// argument arrays returned by hipGraphKernelNodeGetParams point into the graph's nodes.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+#include <vector>
+#include <algorithm>
+#include <unordered_map>
+
+namespace {
+enum { T_KERNEL = 0, T_MEMSET = 1 };
+struct TapeNode {
+    int type = T_KERNEL;
+    int lane = 0;
+    int mode = 0;                       // kernels: 0 = undecided, 1 = hipLaunchKernel (host stub), 2 = hipModuleLaunchKernel (hipFunction_t)
+    hipKernelNodeParams k{};
+    hipMemsetParams ms{};
+    std::vector<int> waits;             // events (indices of earlier nodes on other lanes) to wait for before the launch
+    bool record = false;                // some later node on another lane waits for this one
+    hipEvent_t ev = nullptr;
+};
+}  // namespace
+
+struct VxTape {
+    std::vector<TapeNode> nodes;        // in launch order (a topological order of the captured DAG)
+    std::vector<hipStream_t> lanes;     // set at replay: the caller's stream for a one-lane tape, else the process-wide lane streams
+    std::vector<int> lane_last;         // last node of each lane (-1: unused)
+    hipEvent_t start = nullptr;
+    std::vector<hipEvent_t> lane_end;
+    int n_kernels = 0, n_events = 0, n_cross = 0;
+};
+
+#define HIPQ(call, what)                                                                      \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) VX_FAIL(-2, "vx_tape: %s: %s", what, hipGetErrorString(e__)); \
+    } while (0)
+
+
+// ---------------------------------------------------------------------------------------------------------------- lane streams
+// ROCm multiplexes every hipStream of the process onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams that share a hardware queue run
+// one after the other.  Which queue a stream lands on cannot be queried, but it can be measured: a 1-block kernel that spins for ~60 us is put
+// on two streams at once; 60 us means two queues, 120 us means one.  The first use picks, out of a few freshly created streams, four that
+// overlap pairwise; every multi-lane tape of the process runs its lanes on those and only gates / joins them with the caller's stream.  (The
+// caller's stream is not used as a lane: work on the NULL stream -- PyTorch's default -- was measured not to overlap with any other stream.)
+__global__ void vx_spin_k(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+namespace {
+constexpr int kPool = 4;
+struct LanePool {
+    bool ready = false;
+    int distinct = 0;                   // how many of the lane streams were measured to overlap pairwise
+    hipStream_t lane[kPool] = {nullptr, nullptr, nullptr, nullptr};
+} g_pool;
+
+// elapsed microseconds of one spin on each of the two streams, launched together behind `gate`
+int pair_us(hipStream_t gate, hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t ea, hipEvent_t eb, hipEvent_t e1, float* out) {
+    const long long ticks = 6000;                 // wall_clock64 counts at 100 MHz
+    HIPQ(hipEventRecord(e0, gate), "hipEventRecord");
+    HIPQ(hipStreamWaitEvent(a, e0, 0), "hipStreamWaitEvent");
+    HIPQ(hipStreamWaitEvent(b, e0, 0), "hipStreamWaitEvent");
+    hipLaunchKernelGGL(vx_spin_k, dim3(1), dim3(64), 0, a, ticks);
+    hipLaunchKernelGGL(vx_spin_k, dim3(1), dim3(64), 0, b, ticks);
+    HIPQ(hipEventRecord(ea, a), "hipEventRecord");
+    HIPQ(hipEventRecord(eb, b), "hipEventRecord");
+    HIPQ(hipStreamWaitEvent(gate, ea, 0), "hipStreamWaitEvent");
+    HIPQ(hipStreamWaitEvent(gate, eb, 0), "hipStreamWaitEvent");
+    HIPQ(hipEventRecord(e1, gate), "hipEventRecord");
+    HIPQ(hipEventSynchronize(e1), "hipEventSynchronize");
+    HIPQ(hipEventElapsedTime(out, e0, e1), "hipEventElapsedTime");
+    *out *= 1e3f;
+    return 0;
+}
+
+int pool_init(hipStream_t main) {
+    if (g_pool.ready) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) VX_FAIL(-1, "vx_tape: the lane streams cannot be chosen during a stream capture");
+    hipEvent_t ev[4];
+    for (auto& e : ev) HIPQ(hipEventCreate(&e), "hipEventCreate");
+    constexpr int NC = 12;
+    hipStream_t cand[NC], gate;
+    for (auto& c : cand) HIPQ(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    HIPQ(hipStreamCreateWithFlags(&gate, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    hipStream_t chosen[kPool] = {};
+    bool used[NC] = {};
+    int n = 0;
+    float us = 0.f;
+    int rc = pair_us(gate, cand[0], cand[1], ev[0], ev[1], ev[2], ev[3], &us);        // warm-up (code object load)
+    for (int c = 0; c < NC && n < kPool && rc == 0; ++c) {
+        bool ok = true;
+        for (int k = 0; k < n && ok && rc == 0; ++k) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 2 && rc == 0; ++rep) { rc = pair_us(gate, chosen[k], cand[c], ev[0], ev[1], ev[2], ev[3], &us); best = us < best ? us : best; }
+            ok = best < 95.f;                     // one spin = 60 us; two in a row = 120 us
+        }
+        if (ok && rc == 0) { chosen[n++] = cand[c]; used[c] = true; }
+    }
+    g_pool.distinct = n;
+    for (int c = 0; c < NC; ++c) if (!used[c] && n < kPool && rc == 0) { chosen[n++] = cand[c]; used[c] = true; }      // fewer hardware queues than lanes: share
+    for (int c = 0; c < NC; ++c) if (!used[c]) (void)hipStreamDestroy(cand[c]);
+    (void)hipStreamDestroy(gate);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc != 0) return rc;
+    for (int k = 0; k < kPool; ++k) g_pool.lane[k] = chosen[k];
+    g_pool.ready = true;
+    return 0;
+}
+}  // namespace
+
+extern "C" int vx_tape_lane_stream(void* any_stream, int lane, void** out) {
+    VX_REQUIRE(out && lane >= 0, "vx_tape_lane_stream: bad arguments");
+    int rc = pool_init((hipStream_t)any_stream);
+    if (rc) return rc;
+    *out = (void*)g_pool.lane[lane % kPool];
+    return 0;
+}
+
+extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
+    VX_REQUIRE(graph_ && out && max_lanes >= 1 && max_lanes <= 16, "vx_tape_build: bad arguments");
+    hipGraph_t graph = (hipGraph_t)graph_;
+    size_t nn = 0, ne = 0;
+    HIPQ(hipGraphGetNodes(graph, nullptr, &nn), "hipGraphGetNodes");
+    std::vector<hipGraphNode_t> gn(nn);
+    if (nn) HIPQ(hipGraphGetNodes(graph, gn.data(), &nn), "hipGraphGetNodes");
+    HIPQ(hipGraphGetEdges(graph, nullptr, nullptr, &ne), "hipGraphGetEdges");
+    std::vector<hipGraphNode_t> ef(ne), et(ne);
+    if (ne) HIPQ(hipGraphGetEdges(graph, ef.data(), et.data(), &ne), "hipGraphGetEdges");
+    std::unordered_map<hipGraphNode_t, int> idx;
+    for (size_t i = 0; i < nn; ++i) idx[gn[i]] = (int)i;
+    const int N = (int)nn;
+    std::vector<std::vector<int>> pred(N), succ(N);
+    for (size_t e = 0; e < ne; ++e) {
+        auto a = idx.find(ef[e]), b = idx.find(et[e]);
+        VX_REQUIRE(a != idx.end() && b != idx.end(), "vx_tape_build: edge to an unknown node");
+        pred[b->second].push_back(a->second);
+        succ[a->second].push_back(b->second);
+    }
+    // node kinds; event-record / event-wait / empty nodes carry dependencies only
+    std::vector<int> kind(N, -1);
+    std::vector<TapeNode> raw(N);
+    for (int i = 0; i < N; ++i) {
+        hipGraphNodeType t;
+        HIPQ(hipGraphNodeGetType(gn[i], &t), "hipGraphNodeGetType");
+        if (t == hipGraphNodeTypeKernel) {
+            kind[i] = T_KERNEL;
+            HIPQ(hipGraphKernelNodeGetParams(gn[i], &raw[i].k), "hipGraphKernelNodeGetParams");
+            VX_REQUIRE(raw[i].k.func != nullptr, "vx_tape_build: kernel node without a function");
+        } else if (t == hipGraphNodeTypeMemset) {
+            kind[i] = T_MEMSET;
+            HIPQ(hipGraphMemsetNodeGetParams(gn[i], &raw[i].ms), "hipGraphMemsetNodeGetParams");
+            VX_REQUIRE(raw[i].ms.height <= 1, "vx_tape_build: 2-D memset nodes are not supported");
+            VX_REQUIRE(raw[i].ms.elementSize == 1 || raw[i].ms.elementSize == 2 || raw[i].ms.elementSize == 4, "vx_tape_build: memset element size %u", raw[i].ms.elementSize);
+        } else if (t == hipGraphNodeTypeMemcpy) {
+            // hipGraphMemcpyNodeGetParams returns uninitialised memory for the 1-D nodes hipMemcpyAsync is captured as (ROCm 7.2), so a copy cannot
+            // be read back: the captured code must copy with a kernel (TrainEngine does; aten's clone()/copy_() of contiguous tensors do not)
+            VX_FAIL(-1, "vx_tape_build: the graph holds a memcpy node (node %d of %d); copies inside a taped stage must be kernels", i, N);
+        } else if (t == hipGraphNodeTypeEmpty || t == hipGraphNodeTypeEventRecord || t == hipGraphNodeTypeWaitEvent) {
+            kind[i] = -1;
+        } else
+            VX_FAIL(-1, "vx_tape_build: graph node type %d is not supported", (int)t);
+        raw[i].type = kind[i];
+    }
+    // topological order, capture order as the tie-break (Kahn with a min-heap on the node index)
+    std::vector<int> indeg(N), order;
+    std::vector<int> heap;
+    for (int i = 0; i < N; ++i) { indeg[i] = (int)pred[i].size(); if (!indeg[i]) heap.push_back(i); }
+    auto cmp = [](int a, int b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        int u = heap.back(); heap.pop_back();
+        order.push_back(u);
+        for (int v : succ[u]) if (--indeg[v] == 0) { heap.push_back(v); std::push_heap(heap.begin(), heap.end(), cmp); }
+    }
+    VX_REQUIRE((int)order.size() == N, "vx_tape_build: the graph has a cycle");
+    // contract the dependency-only nodes: real predecessors of every node, in topological order
+    std::vector<std::vector<int>> rp(N);
+    for (int u : order) {
+        std::vector<int>& r = rp[u];
+        for (int p : pred[u]) {
+            if (kind[p] >= 0) r.push_back(p);
+            else r.insert(r.end(), rp[p].begin(), rp[p].end());
+        }
+        std::sort(r.begin(), r.end());
+        r.erase(std::unique(r.begin(), r.end()), r.end());
+    }
+    std::vector<int> pos(N, -1);
+    std::vector<int> real;
+    for (int u : order) if (kind[u] >= 0) { pos[u] = (int)real.size(); real.push_back(u); }
+    const int R = (int)real.size();
+    std::vector<int> nsucc(R, 0);                       // successors not yet placed
+    for (int u : real) for (int p : rp[u]) nsucc[pos[p]]++;
+
+    VxTape* T = new VxTape();
+    T->nodes.resize(R);
+    std::vector<int> tail;                              // tail[lane] = last node placed on the lane
+    // ancestors reached through the lane order make some edges redundant; track for each node, per lane, the latest node known to precede it
+    std::vector<std::vector<int>> known(R);
+    for (int i = 0; i < R; ++i) {
+        const int u = real[i];
+        TapeNode& nd = T->nodes[i];
+        nd = raw[u];
+        std::vector<int> ps;
+        for (int p : rp[u]) ps.push_back(pos[p]);
+        int lane = -1;
+        for (int p : ps) if (tail[T->nodes[p].lane] == p) { lane = T->nodes[p].lane; break; }      // continue a predecessor's lane
+        if (lane < 0) {
+            for (size_t l = 0; l < tail.size() && lane < 0; ++l)                                    // a lane whose tail has nothing left to feed
+                if (tail[l] >= 0 && nsucc[tail[l]] == 0) lane = (int)l;
+            if (lane < 0 && (int)tail.size() < max_lanes) { tail.push_back(-1); lane = (int)tail.size() - 1; }
+            if (lane < 0) lane = ps.empty() ? 0 : T->nodes[ps[0]].lane;
+        }
+        nd.lane = lane;
+        std::vector<int>& kn = known[i];
+        kn.assign(max_lanes, -1);
+        if (tail[lane] >= 0) { kn = known[tail[lane]]; kn[lane] = tail[lane]; }
+        // waits: latest predecessor per foreign lane that the lane order does not already cover
+        std::vector<int> need(max_lanes, -1);
+        for (int p : ps) { const int lp = T->nodes[p].lane; if (lp != lane && p > kn[lp]) need[lp] = std::max(need[lp], p); }
+        for (int l = 0; l < max_lanes; ++l)
+            if (need[l] >= 0) {
+                nd.waits.push_back(need[l]);
+                T->nodes[need[l]].record = true;
+                T->n_cross++;
+                for (int l2 = 0; l2 < max_lanes; ++l2) kn[l2] = std::max(kn[l2], known[need[l]][l2]);
+                kn[l] = std::max(kn[l], need[l]);
+            }
+        for (int p : ps) nsucc[p]--;
+        tail[lane] = i;
+        if (nd.type == T_KERNEL) T->n_kernels++;
+    }
+    T->lane_last = tail;
+    T->lanes.assign(tail.size(), nullptr);
+    T->lane_end.assign(tail.size(), nullptr);
+    for (size_t l = 0; l < tail.size(); ++l) HIPQ(hipEventCreateWithFlags(&T->lane_end[l], hipEventDisableTiming), "hipEventCreateWithFlags");
+    HIPQ(hipEventCreateWithFlags(&T->start, hipEventDisableTiming), "hipEventCreateWithFlags");
+    for (auto& nd : T->nodes)
+        if (nd.record) { HIPQ(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming), "hipEventCreateWithFlags"); T->n_events++; }
+    *out = T;
+    return 0;
+}
+
+extern "C" int vx_tape_info(const VxTape* T, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events) {
+    VX_REQUIRE(T, "vx_tape_info: null tape");
+    if (n_nodes) *n_nodes = (int)T->nodes.size();
+    if (n_kernels) *n_kernels = T->n_kernels;
+    if (n_lanes) *n_lanes = (int)T->lanes.size();
+    if (n_events) *n_events = T->n_events;
+    return 0;
+}
+
+extern "C" int vx_tape_replay(VxTape* T, void* stream) {
+    VX_REQUIRE(T, "vx_tape_replay: null tape");
+    if (T->nodes.empty()) return 0;
+    hipStream_t s0 = (hipStream_t)stream;
+    const size_t L = T->lanes.size();
+    if (L == 1) T->lanes[0] = s0;                 // a single chain runs on the caller's stream
+    else {
+        int rc = pool_init(s0);
+        if (rc) return rc;
+        for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[l % kPool];
+        HIPQ(hipEventRecord(T->start, s0), "hipEventRecord");
+        for (size_t l = 0; l < L && l < (size_t)kPool; ++l) HIPQ(hipStreamWaitEvent(T->lanes[l], T->start, 0), "hipStreamWaitEvent");
+    }
+    for (TapeNode& nd : T->nodes) {
+        hipStream_t s = T->lanes[nd.lane];
+        for (int w : nd.waits) HIPQ(hipStreamWaitEvent(s, T->nodes[w].ev, 0), "hipStreamWaitEvent");
+        if (nd.type == T_KERNEL) {
+            const hipKernelNodeParams& k = nd.k;
+            if (nd.mode == 0) {          // captured from a host stub (<<<>>>, hipLaunchKernel) or from a module function (hipModuleLaunchKernel)?
+                hipError_t e = k.kernelParams ? hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s) : hipErrorInvalidDeviceFunction;
+                if (e == hipSuccess) nd.mode = 1;
+                else {
+                    (void)hipGetLastError();
+                    HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
+                                               k.kernelParams, k.extra), "hipModuleLaunchKernel");
+                    nd.mode = 2;
+                }
+            } else if (nd.mode == 1) HIPQ(hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s), "hipLaunchKernel");
+            else HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
+                                            k.kernelParams, k.extra), "hipModuleLaunchKernel");
+        } else if (nd.type == T_MEMSET) {
+            const hipMemsetParams& m = nd.ms;
+            if (m.elementSize == 1) HIPQ(hipMemsetAsync(m.dst, (int)m.value, m.width, s), "hipMemsetAsync");
+            else if (m.elementSize == 2) HIPQ(hipMemsetD16Async((hipDeviceptr_t)m.dst, (unsigned short)m.value, m.width, s), "hipMemsetD16Async");
+            else HIPQ(hipMemsetD32Async((hipDeviceptr_t)m.dst, (int)m.value, m.width, s), "hipMemsetD32Async");
+        }
+        if (nd.record) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
+    }
+    if (L > 1)
+        for (size_t l = 0; l < L; ++l)
+            if (T->lane_last[l] >= 0) {
+                HIPQ(hipEventRecord(T->lane_end[l], T->lanes[l]), "hipEventRecord");
+                HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");
+            }
+    return 0;
+}
+
+extern "C" int vx_tape_free(VxTape* T) {
+    if (!T) return 0;
+    for (auto& nd : T->nodes) if (nd.ev) (void)hipEventDestroy(nd.ev);
+    for (size_t l = 0; l < T->lane_end.size(); ++l) if (T->lane_end[l]) (void)hipEventDestroy(T->lane_end[l]);
+    if (T->start) (void)hipEventDestroy(T->start);
+    delete T;
+    return 0;
+}

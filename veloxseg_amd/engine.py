@@ -12,6 +12,7 @@ the encoder outputs: the decoder bucket's all-reduce runs on a side stream while
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import warnings
 from typing import List, Optional, Sequence
@@ -22,6 +23,7 @@ import torch.distributed as dist
 from . import _hip as H
 from . import functional as VF
 
+TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
 WGRAD_STREAM = os.environ.get("VELOXSEG_WGRAD_STREAM", "0") != "0"      # experiment (off): weight-gradient kernels deferred to a side stream -- measured 13.5 vs 12.0 ms/step, they steal CUs from the critical path
 
 
@@ -110,11 +112,39 @@ class FlatParams:
                 p.grad = self.grad[o:o + k].view(p.shape)
 
 
+class LaunchTape:
+    """A captured stage (torch.cuda.CUDAGraph kept as a raw hipGraph_t, never instantiated) read back once and replayed as plain launches on
+    several HIP streams by csrc/tape.hip.  Holds the graph: its nodes own the kernel arguments and its pool owns the memory."""
+
+    def __init__(self, graph: "torch.cuda.CUDAGraph", max_lanes: int = 6):
+        import ctypes
+        self.graph = graph
+        h = ctypes.c_void_p()
+        H.call("vx_tape_build", graph.raw_cuda_graph(), int(max_lanes), ctypes.addressof(h))
+        self.handle = h.value
+        info = (ctypes.c_int * 4)()
+        base = ctypes.addressof(info)
+        H.call("vx_tape_info", self.handle, base, base + 4, base + 8, base + 12)
+        self.n_nodes, self.n_kernels, self.n_lanes, self.n_events = (int(v) for v in info)
+
+    def replay(self):
+        H.call("vx_tape_replay", self.handle, H.stream_ptr())
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                H.call("vx_tape_free", h)
+            except Exception:
+                pass
+
+
 class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
-                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True):
+                 eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
+                 replay="tape", tape_lanes=6):
         self.model, self.criterion = model, criterion
         if hasattr(model, "ds_fused"):
             model.ds_fused = bool(fuse_ds)      # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip)
@@ -131,6 +161,9 @@ class TrainEngine:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.overlap = overlap and self.world > 1
         self.use_graph = use_graph
+        if replay not in ("tape", "graph"):
+            raise ValueError("replay must be 'tape' (csrc/tape.hip launches) or 'graph' (hipGraphLaunch)")
+        self.replay_mode, self.tape_lanes = replay, int(tape_lanes)
         B = batch_shape[0]
         self.x = torch.zeros(batch_shape, device=self.dev, dtype=torch.float32)
         self.labels = torch.zeros((B, 1, *batch_shape[2:]), device=self.dev, dtype=label_dtype)
@@ -256,17 +289,35 @@ class TrainEngine:
         self._leaves[k] = leaves
         self._outs[k] = list(self.model.decode_branch(k, attn, encs))
 
+    @contextlib.contextmanager
+    def _wgrad_side(self):
+        """Inside a taped stage the weight-gradient kernels go to a side stream (csrc/_vxops.cpp WgradSide): in the captured DAG they become a
+        branch of their own instead of links of the input-gradient chain, and the tape runs them on a lane beside it.  (Launched eagerly
+        the same deferral costs more host time than it saves: WGRAD_STREAM above.)"""
+        m = VF.cpp_module() if (self.use_graph and self.replay_mode == "tape" and TAPE_WGRAD_SIDE) else None
+        if m is None:
+            yield
+            return
+        m.set_wgrad_stream(True)
+        try:
+            yield
+        finally:
+            m.set_wgrad_stream(False)
+            m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
+
     def _s_loss(self):
         outs_d = [[o.detach().requires_grad_(True) for o in outs] for outs in self._outs]
         self.last_outputs = self.model.assemble_train(outs_d)      # detached leaves: what the per-step metrics read
         loss = self.criterion(self.last_outputs, self.labels, sr_labels=self.x)
-        loss.backward()
+        with self._wgrad_side():
+            loss.backward()
         self._douts = [[o.grad for o in od] for od in outs_d]
-        self.loss.copy_(loss.detach())
+        torch.add(loss.detach(), 0.0, out=self.loss)      # a kernel, not hipMemcpyAsync: memcpy nodes cannot be read back into a launch tape
 
     def _s_dec_bwd(self, k):
         pairs = [(o, g) for o, g in zip(self._outs[k], self._douts[k]) if g is not None]
-        torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        with self._wgrad_side():
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
     def _s_enc_bwd(self):
         bt, bg = [], []
@@ -278,7 +329,8 @@ class TrainEngine:
                     g = g + h
                 bt.append(t)
                 bg.append(g)
-        torch.autograd.backward(bt, bg)
+        with self._wgrad_side():
+            torch.autograd.backward(bt, bg)
 
     def _eager_stages(self, between=None):
         """the staged pass launched eagerly: decoder stages on forked HIP streams (functional.run_branches; autograd replays each branch's
@@ -362,10 +414,14 @@ class TrainEngine:
         cur.wait_stream(self._fork_stream)
 
     def _graph(self, pool, fn, *args):
-        g = torch.cuda.CUDAGraph()
+        tape = self.replay_mode == "tape"
+        g = torch.cuda.CUDAGraph(keep_graph=True) if tape else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool):
-            self._forked(fn, *args)
-        return g
+            if tape:
+                fn(*args)                      # the tape launches node by node: no need for the second branch that keeps hipGraphLaunch correct
+            else:
+                self._forked(fn, *args)
+        return LaunchTape(g, self.tape_lanes) if tape else g
 
     def _capture(self):
         """One hipGraph per stage.  Branch graphs allocate from their own memory pool (a shared pool hands the blocks one capture freed
@@ -414,13 +470,28 @@ class TrainEngine:
                 break
         rng.copy_(rng0)
 
+    def _lane_streams(self, n):
+        """streams for n concurrent tapes: the tape's process-wide lane streams, which sit on different hardware queues (csrc/tape.hip: ROCm
+        multiplexes all streams onto 4 hardware queues, streams that share one never overlap, and nothing overlaps with the NULL stream)"""
+        import ctypes
+        cache = self.__dict__.setdefault("_lane_cache", {})
+        if n not in cache:
+            out = []
+            for k in range(n):
+                h = ctypes.c_void_p()
+                H.call("vx_tape_lane_stream", H.stream_ptr(), k, ctypes.addressof(h))
+                out.append(torch.cuda.ExternalStream(h.value, device=self.dev))
+            cache[n] = out
+        return cache[n]
+
     def _fan(self, graphs):
         cur = torch.cuda.current_stream(self.dev)
-        for s_, g in zip(self.branch_streams, graphs):
+        streams = self._lane_streams(len(graphs)) if self.replay_mode == "tape" else self.branch_streams
+        for s_, g in zip(streams, graphs):
             s_.wait_stream(cur)
             with torch.cuda.stream(s_):
                 g.replay()
-        for s_ in self.branch_streams:
+        for s_ in streams:
             cur.wait_stream(s_)
 
     def _replay(self, comm: bool):

@@ -227,7 +227,7 @@ def _flag_tuple():
     return (WGRAD_ENTRY, USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX)
 
 
-_CPP_OPS = set(os.environ.get("VELOXSEG_CPP_OPS", "conv,in,ln,gelu,axpy,jlc,ffn").split(","))      # debugging: which operators may take the C++ path
+_CPP_OPS = set(os.environ.get("VELOXSEG_CPP_OPS", "conv,in,ln,gelu,axpy,jlc,ffn,pwa,small").split(","))      # debugging: which operators may take the C++ path
 
 
 def _cpp_op(name):
@@ -455,6 +455,9 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
 
 
 def conv_transpose_k2s2(x, w, b):
+    m = _cpp_node("small") if x.is_cuda else None
+    if m is not None:
+        return m.upconv_k2s2(x, w, b)
     return _ConvTransposeK2S2Fn.apply(x, w, b)
 
 
@@ -863,6 +866,9 @@ class _SpaceToDepth2Fn(torch.autograd.Function):
 
 
 def space_to_depth2(x):
+    m = _cpp_node("small") if x.is_cuda else None
+    if m is not None:
+        return m.space_to_depth2(x)
     return _SpaceToDepth2Fn.apply(x)
 
 
@@ -939,6 +945,9 @@ class _PwaCoreFn(torch.autograd.Function):
 
 def pwa_core(table, plan, cq, cv, qkv: Sequence[torch.Tensor], p_attn: float = 0.0, site: int = 0) -> List[torch.Tensor]:
     M = len(qkv) // 3
+    m = _cpp_node("pwa") if qkv[0].is_cuda else None
+    if m is not None and M <= 4:             # the whole core as one C++ autograd node (same C-ABI calls as the python node below)
+        return list(m.pwa_core(table, H.ctypes.addressof(plan), int(cq), int(cv), float(p_attn), int(site), _rs_ptr(qkv[0].device, p_attn), list(qkv)))
     return list(_PwaCoreFn.apply(table, plan, int(cq), int(cv), M, float(p_attn), int(site), *qkv))
 
 
@@ -971,6 +980,9 @@ def upsample_trilinear(x, size):
     size = tuple(int(s) for s in size)
     if tuple(x.shape[2:]) == size:
         return x        # F.interpolate to the same size with align_corners=True is the identity (VeloxSeg.py:183)
+    m = _cpp_node("small") if x.is_cuda else None
+    if m is not None:
+        return m.upsample_trilinear(x, *size)
     return _UpsampleFn.apply(x, size)
 
 
@@ -998,6 +1010,9 @@ class _GramFn(torch.autograd.Function):
 
 
 def gram(x):
+    m = _cpp_node("small") if x.is_cuda else None
+    if m is not None:
+        return m.gram(x)
     return _GramFn.apply(x)
 
 
