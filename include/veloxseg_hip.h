@@ -328,7 +328,7 @@ int vx_rotate_z(const float* x, float* out, int C, int D, int H, int W, float co
 /* ---- launch tape: a captured training stage replayed as plain launches on several HIP streams -----------------------------------------
  * The reference trains through eager PyTorch (utils/train_autopet.py:233-262: model(), loss, backward(), optimizer.step()); here one captured
  * pass of a stage (hipStreamBeginCapture ... EndCapture -> hipGraph_t, addresses from a private pool) is read back ONCE -- kernel and memset
- * nodes with their launch parameters (memcpy nodes are refused: ROCm 7.2 cannot read them back), and the dependency edges -- and replayed every step with hipLaunchKernel on `max_lanes`
+ * nodes with their launch parameters (memcpy nodes, which ROCm 7.2 cannot read back, are kept as one-node graphs), and the dependency edges -- and replayed every step with hipLaunchKernel on `max_lanes`
  * streams with events only where an edge crosses streams (~3 us of host time per node; hipGraphLaunch on ROCm 7.2 needs ~17 us and
  * serialises the branches).  The caller keeps the hipGraph_t alive as long as the tape: kernel arguments are read from its nodes.
  * vx_tape_replay enqueues behind `stream` and joins every lane back into it before returning (it never blocks the host). */

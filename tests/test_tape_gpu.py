@@ -1,5 +1,5 @@
 """Launch tape (csrc/tape.hip): a captured hipGraph read back and replayed as plain launches on several streams must compute what the
-eager launches compute -- kernels from host stubs (aten, this library), module kernels (rocBLAS), memset nodes, forked
+eager launches compute -- kernels from host stubs (aten, this library), module kernels (rocBLAS), memset and memcpy nodes, forked
 streams -- and TrainEngine(use_graph=True, replay="tape") must track the eager engine step for step (dropout streams included)."""
 import pytest
 import torch
@@ -59,11 +59,19 @@ def test_tape_replays_kernels_memsets_and_forked_streams():
             assert torch.allclose(tot, ref_y2.sum() + ref_m.sum(), rtol=1e-4, atol=1e-1)
 
 
-def test_tape_refuses_memcpy_nodes():
+def test_tape_replays_memcpy_nodes():
+    """aten copies contiguous tensors with hipMemcpyAsync (clone(), torch.cat over dim 1 at batch 1): those nodes cannot be read back on ROCm 7.2
+    and are replayed as one-node graphs"""
     dev = torch.device("cuda:0")
-    a = torch.randn(1000, device=dev)
-    with pytest.raises(RuntimeError, match="memcpy node"):
-        _capture(lambda: a.clone())
+    a = torch.randn(1, 3, 1000, device=dev)
+    b = torch.randn(1, 2, 1000, device=dev)
+    tape, out = _capture(lambda: torch.cat([a, b], dim=1).clone() * 2.0)
+    for _ in range(2):
+        a.normal_()
+        b.normal_()
+        tape.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.cat([a, b], dim=1) * 2.0)
 
 
 def test_engine_tape_replay_tracks_the_eager_engine():

@@ -18,13 +18,15 @@
 #include <unordered_map>
 
 namespace {
-enum { T_KERNEL = 0, T_MEMSET = 1 };
+enum { T_KERNEL = 0, T_MEMSET = 1, T_COPY = 2 };
 struct TapeNode {
     int type = T_KERNEL;
     int lane = 0;
     int mode = 0;                       // kernels: 0 = undecided, 1 = hipLaunchKernel (host stub), 2 = hipModuleLaunchKernel (hipFunction_t)
     hipKernelNodeParams k{};
     hipMemsetParams ms{};
+    hipGraph_t copy_graph = nullptr;    // T_COPY: a one-node graph (the captured memcpy) and its executable
+    hipGraphExec_t copy_exec = nullptr;
     std::vector<int> waits;             // events (indices of earlier nodes on other lanes) to wait for before the launch
     bool record = false;                // some later node on another lane waits for this one
     hipEvent_t ev = nullptr;
@@ -164,9 +166,21 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
             VX_REQUIRE(raw[i].ms.height <= 1, "vx_tape_build: 2-D memset nodes are not supported");
             VX_REQUIRE(raw[i].ms.elementSize == 1 || raw[i].ms.elementSize == 2 || raw[i].ms.elementSize == 4, "vx_tape_build: memset element size %u", raw[i].ms.elementSize);
         } else if (t == hipGraphNodeTypeMemcpy) {
-            // hipGraphMemcpyNodeGetParams returns uninitialised memory for the 1-D nodes hipMemcpyAsync is captured as (ROCm 7.2), so a copy cannot
-            // be read back: the captured code must copy with a kernel (TrainEngine does; aten's clone()/copy_() of contiguous tensors do not)
-            VX_FAIL(-1, "vx_tape_build: the graph holds a memcpy node (node %d of %d); copies inside a taped stage must be kernels", i, N);
+            // hipGraphMemcpyNodeGetParams returns uninitialised memory for the 1-D nodes hipMemcpyAsync is captured as (ROCm 7.2), so the copy cannot be
+            // read back.  It is replayed as what it is instead: a clone of the captured graph with every other node removed, instantiated once and
+            // launched on the node's lane (~20 us of host time; aten copies contiguous tensors this way, e.g. torch.cat over dim 1 at batch 1).
+            kind[i] = T_COPY;
+            hipGraph_t one = nullptr;
+            HIPQ(hipGraphClone(&one, graph), "hipGraphClone");
+            hipGraphNode_t keep = nullptr;
+            HIPQ(hipGraphNodeFindInClone(&keep, gn[i], one), "hipGraphNodeFindInClone");
+            size_t cn = 0;
+            HIPQ(hipGraphGetNodes(one, nullptr, &cn), "hipGraphGetNodes");
+            std::vector<hipGraphNode_t> cns(cn);
+            HIPQ(hipGraphGetNodes(one, cns.data(), &cn), "hipGraphGetNodes");
+            for (hipGraphNode_t c : cns) if (c != keep) HIPQ(hipGraphDestroyNode(c), "hipGraphDestroyNode");
+            HIPQ(hipGraphInstantiate(&raw[i].copy_exec, one, nullptr, nullptr, 0), "hipGraphInstantiate");
+            raw[i].copy_graph = one;
         } else if (t == hipGraphNodeTypeEmpty || t == hipGraphNodeTypeEventRecord || t == hipGraphNodeTypeWaitEvent) {
             kind[i] = -1;
         } else
@@ -298,6 +312,7 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
             else if (m.elementSize == 2) HIPQ(hipMemsetD16Async((hipDeviceptr_t)m.dst, (unsigned short)m.value, m.width, s), "hipMemsetD16Async");
             else HIPQ(hipMemsetD32Async((hipDeviceptr_t)m.dst, (int)m.value, m.width, s), "hipMemsetD32Async");
         }
+        else if (nd.type == T_COPY) HIPQ(hipGraphLaunch(nd.copy_exec, s), "hipGraphLaunch");
         if (nd.record) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
     }
     if (L > 1)
@@ -311,7 +326,11 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
 
 extern "C" int vx_tape_free(VxTape* T) {
     if (!T) return 0;
-    for (auto& nd : T->nodes) if (nd.ev) (void)hipEventDestroy(nd.ev);
+    for (auto& nd : T->nodes) {
+        if (nd.ev) (void)hipEventDestroy(nd.ev);
+        if (nd.copy_exec) (void)hipGraphExecDestroy(nd.copy_exec);
+        if (nd.copy_graph) (void)hipGraphDestroy(nd.copy_graph);
+    }
     for (size_t l = 0; l < T->lane_end.size(); ++l) if (T->lane_end[l]) (void)hipEventDestroy(T->lane_end[l]);
     if (T->start) (void)hipEventDestroy(T->start);
     delete T;
