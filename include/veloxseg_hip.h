@@ -240,6 +240,7 @@ int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float*
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
                     const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
 int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M);   /* answer, not a status; negative = error */
+int vx_pwa_gather_set_vec(int on);   /* A/B knob for tests: 0 = the one-lane-per-(cell, channel) gather kernels instead of the channel-vectorised ones */
 int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                     const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
@@ -337,6 +338,10 @@ int vx_tape_build(void* hip_graph, int max_lanes, VxTape** out);
 int vx_tape_info(const VxTape* tape, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events);
 int vx_tape_replay(VxTape* tape, void* stream);
 int vx_tape_free(VxTape* tape);
+/* introspection: stand-alone time of every node (launch order, microseconds, minimum over reps; the nodes run one at a time, so the values
+ * computed are those of a replay), and the layout of the tape: lane, workgroups, up to 4 cross-lane waits (-1 padded) and the kernel name per node */
+int vx_tape_profile(VxTape* tape, void* stream, int reps, float* us);
+int vx_tape_describe(const VxTape* tape, int* lane, int* grid, int* waits4, char* names, int name_stride);
 /* the process-wide stream of lane `lane` (lane % 4).  The four lane streams are chosen at first use so that they sit on different hardware
  * queues (measured with a spinning kernel: streams that share one of ROCm's 4 hardware queues never overlap, and neither does the NULL stream
  * with anything).  A tape with one lane replays on the caller's stream; a tape with more replays on the lane streams, gated by and joined

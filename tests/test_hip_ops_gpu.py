@@ -637,6 +637,43 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
         close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma vs valu tensor {i}")
 
 
+@pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),
+                                                    ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 3)],
+                         ids=["c8v8", "c8v16", "c16v32", "c4v8", "c4v4_M3"])
+def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big, heads, mdh, C, M):
+    """vx_pwa_gather_all_fwd / _bwd: the kernels that move 4 or 8 channels per lane (csrc/pwa.hip *_v_k) against the one-lane-per-channel kernels:
+    the pooled tokens (hence the outputs) are bit-identical and the gradients are routed to the same voxels (both take the first maximum of a cell)."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    n = pl["n"]
+    base = []
+    for m in range(M):
+        base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
+    base[0][:, :, :2, :2, :2] = 0.25            # ties inside pooling cells: the first maximum must win in both forms
+    res = {}
+    try:
+        for on in (1, 0):
+            H.call("vx_pwa_gather_set_vec", on)
+            table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=0.0, site=9)
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gouts)
+            torch.cuda.synchronize()
+            res[on] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
+    finally:
+        H.call("vx_pwa_gather_set_vec", 1)
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        if i < M:
+            assert torch.equal(a, b), f"output {i} differs between the gather forms"
+        else:                    # the attention backward in between accumulates with float atomics: equal routing, summation-order noise
+            assert torch.equal(a == 0, b == 0), f"gradient {i}: different arg-max routing"
+            close(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, f"gradient {i}")
+
+
 @pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32)], ids=["c2", "c4_aniso", "c3"])
 def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype):
     """veloxseg_loss on heads that stay on their own grids (csrc/loss_ds.hip interpolates inside the kernels) == up-sample (vx_upsample_trilinear) then

@@ -166,6 +166,115 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_k(VxGatherPtrs ptrs
     dsrc[((long)b * (P.nb * P.heads * c) + ch) * V + v] = (tix[ti] == (int)v) ? dtok[ti] : 0.0f;
 }
 
+
+// Channel-vectorised forms (c % 4 == 0, every shipped config): one lane owns CH = 4 or 8 consecutive channels of its cell / voxel, so the
+// token side is read and written as 16-32 contiguous bytes per lane (neighbouring tokens follow each other in memory) instead of one float
+// every c floats, while the volume side stays one coalesced access per channel.  blockIdx.y = ((m * 3 + kind) * nb + i) * heads * (c / CH) ...
+template <int CH>
+__global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_v_k(VxGatherPtrs ptrs, float* __restrict__ tq, float* __restrict__ tk, float* __restrict__ tv,
+                                                                 int* __restrict__ iq, int* __restrict__ ik, int* __restrict__ iv,
+                                                                 VxPwaPlan P, int cq, int cv, int M) {
+    // blockIdx.y enumerates (m, kind, branch i, head a, channel chunk) with the chunk count of the widest kind; narrower kinds leave early
+    const int nchq = cq / CH, nchv = cv / CH, nchm = nchq > nchv ? nchq : nchv;
+    int y = blockIdx.y;
+    const int chunk = y % nchm; y /= nchm;
+    const int a = y % P.heads; y /= P.heads;
+    const int i = y % P.nb; y /= P.nb;
+    const int kind = y % 3, m = y / 3;
+    const int c = kind == 2 ? cv : cq;
+    if (chunk * CH >= c) return;
+    const int b = blockIdx.z;
+    const float* __restrict__ src = ptrs.src[3 * m + kind];
+    float* __restrict__ tok = kind == 0 ? tq : (kind == 1 ? tk : tv);
+    int* __restrict__ tix = kind == 0 ? iq : (kind == 1 ? ik : iv);
+    const int s0 = P.small[i][0], s1 = P.small[i][1], s2 = P.small[i][2];
+    const int csz = s0 * s1 * s2;
+    int T = 1;
+    while (T < 64 && T < csz) T <<= 1;
+    const int p0n = P.grid[0] / s0, p1n = P.grid[1] / s1, p2n = P.grid[2] / s2;
+    const int ncell = p0n * p1n * p2n;
+    const int cells_per_block = 256 / T;
+    if ((long)blockIdx.x * cells_per_block >= ncell) return;
+    const int sub = threadIdx.x % T;
+    const int cell = blockIdx.x * cells_per_block + threadIdx.x / T;
+    const bool cok = cell < ncell;
+    const int cl = cok ? cell : 0;
+    const int p2 = cl % p2n, p1 = (cl / p2n) % p1n, p0 = cl / (p2n * p1n);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const int ch0 = (i * P.heads + a) * c + chunk * CH;
+    const float* __restrict__ sc = src + ((long)b * (P.nb * P.heads * c) + ch0) * V;
+    float best[CH];
+    int bidx[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { best[k] = -INFINITY; bidx[k] = 0x7fffffff; }
+    for (int e = sub; e < csz; e += T) {
+        const int w = e % s2, h = (e / s2) % s1, d = e / (s2 * s1);
+        const int idx = ((p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const float val = sc[(long)k * V + idx];
+            if (val > best[k] || bidx[k] == 0x7fffffff) { best[k] = val; bidx[k] = idx; }     // increasing idx per lane: strict > keeps the first
+        }
+    }
+    for (int o = T >> 1; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const float ov = __shfl_xor(best[k], o, 64);
+            const int oi = __shfl_xor(bidx[k], o, 64);
+            if (ov > best[k] || (ov == best[k] && oi < bidx[k])) { best[k] = ov; bidx[k] = oi; }
+        }
+    }
+    if (cok && sub == 0) {
+        const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+        const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+        const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+        const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + chunk * CH;
+#pragma unroll
+        for (int k = 0; k < CH; k += 4) {
+            *reinterpret_cast<float4*>(tok + ti + k) = make_float4(best[k], best[k + 1], best[k + 2], best[k + 3]);
+            *reinterpret_cast<int4*>(tix + ti + k) = make_int4(bidx[k], bidx[k + 1], bidx[k + 2], bidx[k + 3]);
+        }
+    }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs ptrs, const float* __restrict__ dtq, const float* __restrict__ dtk, const float* __restrict__ dtv,
+                                                                 const int* __restrict__ iq, const int* __restrict__ ik, const int* __restrict__ iv,
+                                                                 VxPwaPlan P, int cq, int cv, int M) {
+    const int nchq = cq / CH, nchv = cv / CH, nchm = nchq > nchv ? nchq : nchv;
+    int y = blockIdx.y;
+    const int chunk = y % nchm; y /= nchm;
+    const int a = y % P.heads; y /= P.heads;
+    const int i = y % P.nb; y /= P.nb;
+    const int kind = y % 3, m = y / 3;
+    const int c = kind == 2 ? cv : cq;
+    if (chunk * CH >= c) return;
+    const int b = blockIdx.z;
+    float* __restrict__ dsrc = ptrs.dsrc[3 * m + kind];
+    const float* __restrict__ dtok = kind == 0 ? dtq : (kind == 1 ? dtk : dtv);
+    const int* __restrict__ tix = kind == 0 ? iq : (kind == 1 ? ik : iv);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
+    const int p0 = x0 / P.small[i][0], p1 = x1 / P.small[i][1], p2 = x2 / P.small[i][2];
+    const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
+    const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + chunk * CH;
+    const int ch0 = (i * P.heads + a) * c + chunk * CH;
+    float* __restrict__ dc = dsrc + ((long)b * (P.nb * P.heads * c) + ch0) * V + v;
+#pragma unroll
+    for (int k = 0; k < CH; k += 4) {
+        const float4 g = *reinterpret_cast<const float4*>(dtok + ti + k);
+        const int4 ix = *reinterpret_cast<const int4*>(tix + ti + k);
+        dc[(long)(k + 0) * V] = ix.x == (int)v ? g.x : 0.0f;
+        dc[(long)(k + 1) * V] = ix.y == (int)v ? g.y : 0.0f;
+        dc[(long)(k + 2) * V] = ix.z == (int)v ? g.z : 0.0f;
+        dc[(long)(k + 3) * V] = ix.w == (int)v ? g.w : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // scatter: per-window trilinear up-sampling (align_corners=True) of the n^3 window outputs
 // ---------------------------------------------------------------------------------------------
@@ -791,6 +900,8 @@ extern "C" int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsr
     return 0;
 }
 
+static int vx_gather_vec_enabled = 1;
+extern "C" int vx_pwa_gather_set_vec(int on) { vx_gather_vec_enabled = on ? 1 : 0; return 0; }      // A/B knob (tests): 0 = one lane per (cell, channel)
 extern "C" int vx_pwa_gather_all_fwd(const float* const* srcs, float* tq, float* tk, float* tv, int* iq, int* ik, int* iv,
                                      const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_gather_all_fwd")) return e;
@@ -799,6 +910,15 @@ extern "C" int vx_pwa_gather_all_fwd(const float* const* srcs, float* tq, float*
     for (int k = 0; k < 3 * M; ++k) { VX_REQUIRE(srcs[k], "vx_pwa_gather_all_fwd: null source %d", k); ptrs.src[k] = srcs[k]; ptrs.dsrc[k] = nullptr; }
     const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
     const int per_m = plan->nb * plan->heads * (2 * cq + cv);
+    if (cq % 4 == 0 && cv % 4 == 0 && vx_gather_vec_enabled) {
+        const int CH = (cq % 8 == 0 && cv % 8 == 0) ? 8 : 4;
+        const int nchm = (cq > cv ? cq : cv) / CH;
+        const dim3 g(vx_cdiv(V, 256), M * 3 * plan->nb * plan->heads * nchm, B);
+        if (CH == 8) hipLaunchKernelGGL(vx_pwa_gather_all_fwd_v_k<8>, g, dim3(256), 0, (hipStream_t)stream, ptrs, tq, tk, tv, iq, ik, iv, *plan, cq, cv, M);
+        else hipLaunchKernelGGL(vx_pwa_gather_all_fwd_v_k<4>, g, dim3(256), 0, (hipStream_t)stream, ptrs, tq, tk, tv, iq, ik, iv, *plan, cq, cv, M);
+        VX_LAUNCH_CHECK("vx_pwa_gather_all_fwd");
+        return 0;
+    }
     // grid.x covers the finest scale (one lane per cell, 256 cells per block); coarser scales use fewer cells but T lanes each
     hipLaunchKernelGGL(vx_pwa_gather_all_fwd_k, dim3(vx_cdiv(V, 256), per_m * M, B), dim3(256), 0, (hipStream_t)stream, ptrs, tq, tk, tv, iq, ik, iv, *plan, cq, cv, M);
     VX_LAUNCH_CHECK("vx_pwa_gather_all_fwd");
@@ -813,6 +933,15 @@ extern "C" int vx_pwa_gather_all_bwd(const float* dtq, const float* dtk, const f
     for (int k = 0; k < 3 * M; ++k) { VX_REQUIRE(dsrcs[k], "vx_pwa_gather_all_bwd: null destination %d", k); ptrs.dsrc[k] = dsrcs[k]; ptrs.src[k] = nullptr; }
     const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
     const int per_m = plan->nb * plan->heads * (2 * cq + cv);
+    if (cq % 4 == 0 && cv % 4 == 0 && vx_gather_vec_enabled) {
+        const int CH = (cq % 8 == 0 && cv % 8 == 0) ? 8 : 4;
+        const int nchm = (cq > cv ? cq : cv) / CH;
+        const dim3 g(vx_cdiv(V, 256), M * 3 * plan->nb * plan->heads * nchm, B);
+        if (CH == 8) hipLaunchKernelGGL(vx_pwa_gather_all_bwd_v_k<8>, g, dim3(256), 0, (hipStream_t)stream, ptrs, dtq, dtk, dtv, iq, ik, iv, *plan, cq, cv, M);
+        else hipLaunchKernelGGL(vx_pwa_gather_all_bwd_v_k<4>, g, dim3(256), 0, (hipStream_t)stream, ptrs, dtq, dtk, dtv, iq, ik, iv, *plan, cq, cv, M);
+        VX_LAUNCH_CHECK("vx_pwa_gather_all_bwd");
+        return 0;
+    }
     hipLaunchKernelGGL(vx_pwa_gather_all_bwd_k, dim3(vx_cdiv(V, 256), per_m * M, B), dim3(256), 0, (hipStream_t)stream, ptrs, dtq, dtk, dtv, iq, ik, iv, *plan, cq, cv, M);
     VX_LAUNCH_CHECK("vx_pwa_gather_all_bwd");
     return 0;

@@ -276,6 +276,31 @@ extern "C" int vx_tape_info(const VxTape* T, int* n_nodes, int* n_kernels, int* 
     return 0;
 }
 
+static int tape_launch(TapeNode& nd, hipStream_t s) {
+    if (nd.type == T_KERNEL) {
+        const hipKernelNodeParams& k = nd.k;
+        if (nd.mode == 0) {          // captured from a host stub (<<<>>>, hipLaunchKernel) or from a module function (hipModuleLaunchKernel)?
+            hipError_t e = k.kernelParams ? hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s) : hipErrorInvalidDeviceFunction;
+            if (e == hipSuccess) nd.mode = 1;
+            else {
+                (void)hipGetLastError();
+                HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
+                                           k.kernelParams, k.extra), "hipModuleLaunchKernel");
+                nd.mode = 2;
+            }
+        } else if (nd.mode == 1) HIPQ(hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s), "hipLaunchKernel");
+        else HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
+                                        k.kernelParams, k.extra), "hipModuleLaunchKernel");
+    } else if (nd.type == T_MEMSET) {
+        const hipMemsetParams& m = nd.ms;
+        if (m.elementSize == 1) HIPQ(hipMemsetAsync(m.dst, (int)m.value, m.width, s), "hipMemsetAsync");
+        else if (m.elementSize == 2) HIPQ(hipMemsetD16Async((hipDeviceptr_t)m.dst, (unsigned short)m.value, m.width, s), "hipMemsetD16Async");
+        else HIPQ(hipMemsetD32Async((hipDeviceptr_t)m.dst, (int)m.value, m.width, s), "hipMemsetD32Async");
+    }
+    else if (nd.type == T_COPY) HIPQ(hipGraphLaunch(nd.copy_exec, s), "hipGraphLaunch");
+    return 0;
+}
+
 extern "C" int vx_tape_replay(VxTape* T, void* stream) {
     VX_REQUIRE(T, "vx_tape_replay: null tape");
     if (T->nodes.empty()) return 0;
@@ -292,27 +317,7 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
     for (TapeNode& nd : T->nodes) {
         hipStream_t s = T->lanes[nd.lane];
         for (int w : nd.waits) HIPQ(hipStreamWaitEvent(s, T->nodes[w].ev, 0), "hipStreamWaitEvent");
-        if (nd.type == T_KERNEL) {
-            const hipKernelNodeParams& k = nd.k;
-            if (nd.mode == 0) {          // captured from a host stub (<<<>>>, hipLaunchKernel) or from a module function (hipModuleLaunchKernel)?
-                hipError_t e = k.kernelParams ? hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s) : hipErrorInvalidDeviceFunction;
-                if (e == hipSuccess) nd.mode = 1;
-                else {
-                    (void)hipGetLastError();
-                    HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
-                                               k.kernelParams, k.extra), "hipModuleLaunchKernel");
-                    nd.mode = 2;
-                }
-            } else if (nd.mode == 1) HIPQ(hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, s), "hipLaunchKernel");
-            else HIPQ(hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y, k.blockDim.z, k.sharedMemBytes, s,
-                                            k.kernelParams, k.extra), "hipModuleLaunchKernel");
-        } else if (nd.type == T_MEMSET) {
-            const hipMemsetParams& m = nd.ms;
-            if (m.elementSize == 1) HIPQ(hipMemsetAsync(m.dst, (int)m.value, m.width, s), "hipMemsetAsync");
-            else if (m.elementSize == 2) HIPQ(hipMemsetD16Async((hipDeviceptr_t)m.dst, (unsigned short)m.value, m.width, s), "hipMemsetD16Async");
-            else HIPQ(hipMemsetD32Async((hipDeviceptr_t)m.dst, (int)m.value, m.width, s), "hipMemsetD32Async");
-        }
-        else if (nd.type == T_COPY) HIPQ(hipGraphLaunch(nd.copy_exec, s), "hipGraphLaunch");
+        { int rc = tape_launch(nd, s); if (rc) return rc; }
         if (nd.record) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
     }
     if (L > 1)
@@ -334,5 +339,44 @@ extern "C" int vx_tape_free(VxTape* T) {
     for (size_t l = 0; l < T->lane_end.size(); ++l) if (T->lane_end[l]) (void)hipEventDestroy(T->lane_end[l]);
     if (T->start) (void)hipEventDestroy(T->start);
     delete T;
+    return 0;
+}
+
+// ---- introspection (tools/tape_critical_path.py): where does a stage spend its time, and which kernels are on its critical path?
+extern "C" int vx_tape_profile(VxTape* T, void* stream, int reps, float* us) {
+    VX_REQUIRE(T && us && reps >= 1, "vx_tape_profile: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPQ(hipEventCreate(&e0), "hipEventCreate");
+    HIPQ(hipEventCreate(&e1), "hipEventCreate");
+    for (size_t i = 0; i < T->nodes.size(); ++i) us[i] = 1e30f;
+    for (int r = 0; r < reps; ++r)
+        for (size_t i = 0; i < T->nodes.size(); ++i) {          // launch order, one node at a time: the values computed are those of a replay
+            HIPQ(hipEventRecord(e0, s), "hipEventRecord");
+            int rc = tape_launch(T->nodes[i], s);
+            if (rc) return rc;
+            HIPQ(hipEventRecord(e1, s), "hipEventRecord");
+            HIPQ(hipEventSynchronize(e1), "hipEventSynchronize");
+            float ms = 0.f;
+            HIPQ(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+            us[i] = ms * 1e3f < us[i] ? ms * 1e3f : us[i];
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
+/* lane[i], grid[i] (workgroups, 0 for non-kernels), waits: up to 4 per node (-1 padded), names: name_stride bytes per node */
+extern "C" int vx_tape_describe(const VxTape* T, int* lane, int* grid, int* waits4, char* names, int name_stride) {
+    VX_REQUIRE(T && lane && grid && waits4 && names && name_stride >= 8, "vx_tape_describe: bad arguments");
+    for (size_t i = 0; i < T->nodes.size(); ++i) {
+        const TapeNode& nd = T->nodes[i];
+        lane[i] = nd.lane;
+        grid[i] = nd.type == T_KERNEL ? (int)(nd.k.gridDim.x * nd.k.gridDim.y * nd.k.gridDim.z) : 0;
+        for (int w = 0; w < 4; ++w) waits4[4 * i + w] = w < (int)nd.waits.size() ? nd.waits[w] : -1;
+        const char* nm = nd.type == T_MEMSET ? "memset" : nd.type == T_COPY ? "memcpy" : nullptr;
+        if (!nm) { nm = nd.mode == 2 ? hipKernelNameRef((hipFunction_t)nd.k.func) : hipKernelNameRefByPtr(nd.k.func, nullptr); if (!nm) nm = "?"; }
+        snprintf(names + (size_t)i * name_stride, name_stride, "%s", nm);
+    }
     return 0;
 }

@@ -428,6 +428,8 @@ class TrainEngine:
         to the next capture, which is only safe when the graphs replay in capture order, not concurrently); tensors that cross
         stages stay referenced by the engine for the lifetime of the graphs."""
         self.model.train()
+        if self.replay_mode == "tape":
+            VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # forks cost the tape nothing on the host: every per-modality piece gets its own branch
         VF.RNG_INPLACE = True       # replays must bump the tensor the captured kernels point at
         rng = VF.rng_state(self.dev)
         rng0 = rng.clone()
