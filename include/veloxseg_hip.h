@@ -326,6 +326,17 @@ int vx_label_kth_in_chunk(const void* labels, int lab_bytes, long n, long chunk_
 /* rotation about the last spatial axis (the (D,H) plane turns), centre (n-1)/2, border padding; mode 0 bilinear, 1 nearest */
 int vx_rotate_z(const float* x, float* out, int C, int D, int H, int W, float cos_a, float sin_a, int mode, void* stream);
 
+/* ---- dense strided convolution on MFMA (groups = 1; k odd <= 7, stride 2..4, pad = k / 2): the DownConv layers between the encoder levels and the
+ * stem (Encoder.py:29-58, conv_blocks.py:8-27 of the reference).  Implicit GEMM on v_mfma_f32_16x16x4_f32, fp32 in / fp32 accumulate.  ws =
+ * vx_conv_mfma_ws_floats(Cin, Cout, K, backward) floats for the operand-order weight image (written by every call).  bwd_data: accumulate = 1 adds
+ * into dx.  vx_conv_mfma_ok: 1 when the shape is covered (D, H, W multiples of the stride, Cout % 4 == 0). */
+int vx_conv_mfma_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P, int G, int ps);
+int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward);
+int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P,
+                     void* stream);
+int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P, int accumulate,
+                          void* stream);
+
 /* ---- launch tape: a captured training stage replayed as plain launches on several HIP streams -----------------------------------------
  * The reference trains through eager PyTorch (utils/train_autopet.py:233-262: model(), loss, backward(), optimizer.step()); here one captured
  * pass of a stage (hipStreamBeginCapture ... EndCapture -> hipGraph_t, addresses from a private pool) is read back ONCE -- kernel and memset

@@ -76,6 +76,11 @@ CONV_CASES = [
     ("jlc_k5_g8", 1, 64, (4, 4, 4), 64, 5, 1, 2, 8, 1),
     ("down_k7s4", 2, 2, (16, 16, 16), 16, 7, 4, 3, 1, 1),
     ("down_k3s2", 2, 16, (8, 8, 6), 32, 3, 2, 1, 1, 1),
+    ("down_k3s2_c32", 3, 32, (8, 8, 8), 64, 3, 2, 1, 1, 1),          # the MFMA implicit-GEMM path (csrc/conv_mfma.hip): several column tiles, ragged row tiles
+    ("down_k3s2_c64", 2, 64, (4, 4, 4), 128, 3, 2, 1, 1, 1),
+    ("down_k3s2_odd_c", 1, 12, (6, 4, 10), 20, 3, 2, 1, 1, 1),
+    ("stem_k7s4_c4", 1, 4, (16, 16, 12), 16, 7, 4, 3, 1, 1),
+    ("down_k5s2", 1, 8, (8, 8, 8), 16, 5, 2, 2, 1, 1),
     ("embed_k4s4", 1, 1, (16, 12, 8), 16, 4, 4, 0, 1, 1),
     ("embed_k2s2", 1, 4, (8, 8, 8), 16, 2, 2, 0, 1, 1),
     ("expand_ps4", 1, 16, (4, 5, 6), 128, 3, 1, 1, 1, 4),

@@ -26,7 +26,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool fuse_blocks = true, use_s1 = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
+    bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -126,7 +126,7 @@ inline void wgrad_submit(void* cur, int dev, std::function<void(void*)> launch) 
 struct ConvState {
     Tensor x, x2, w, b;
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
-    bool pw = false, s1 = false, patch = false;
+    bool pw = false, s1 = false, patch = false, cm = false;      // cm: strided dense conv on MFMA (csrc/conv_mfma.hip)
 };
 
 Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
@@ -143,6 +143,7 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     st.s1 = (!x2.defined() && S == 1 && (K == 3 || K == 5) && P == K / 2 && (Cout / G) % 4 == 0 && (Cin / G) % 4 == 0 && F.use_s1);
     st.patch = (F.use_patchify && K == S && (K == 2 || K == 4) && P == 0 && G == 1 && ps == 1 && !x2.defined() && !x_requires_grad &&
                 D % K == 0 && H % K == 0 && W % K == 0 && (Cin * K * K * K) % 4 == 0);
+    st.cm = (F.use_conv_mfma && !x2.defined() && !st.patch && S >= 2 && vx_conv_mfma_ok(Cin, Cout, D, H, W, K, S, P, G, ps) == 1);
     st.w = w; st.b = b;
     st.B = B; st.C1 = C1; st.Cin = Cin; st.D = D; st.H = H; st.W = W; st.Cout = Cout; st.K = K; st.S = S; st.P = P; st.G = G; st.ps = ps;
     if (st.patch) {
@@ -166,6 +167,10 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
         }
         if (rc == 1) VX(vx_conv_s1, fp(x), fp(w), fp(b), mp(y), B, Cin, Cout, D, H, W, K, G, 0, 1, ps, 0, stream);
+    }
+    else if (st.cm) {
+        Tensor ws = at::empty({(long)vx_conv_mfma_ws_floats(Cin, Cout, K, 0)}, x.options());
+        VX(vx_conv_mfma_fwd, fp(x), fp(w), fp(b), mp(y), mp(ws), B, Cin, D, H, W, Cout, K, S, P, stream);
     }
     else VX(vx_conv3d_fwd, fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, D, H, W, Cout, K, S, P, G, ps, stream);
     st.x = x; st.x2 = x2;
@@ -213,6 +218,10 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
             Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
             VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
         } else if (st.s1) VX(vx_conv_s1, fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream);
+        else if (st.cm) {
+            Tensor ws = at::empty({(long)vx_conv_mfma_ws_floats(Cin, Cout, K, 1)}, x.options());
+            VX(vx_conv_mfma_bwd_data, fp(dy), fp(w), mp(dx), mp(ws), B, Cin, D, H, W, Cout, K, S, P, acc, stream);
+        }
         else VX(vx_conv3d_bwd_data, fp(dy), fp(w), nullptr, mp(dx), mp(dx2), C1, B, Cin, D, H, W, Cout, K, S, P, G, ps, acc, stream);
     }
     if (w.requires_grad()) {
@@ -1076,6 +1085,7 @@ PYBIND11_MODULE(_vxops, m) {
         PROF.recs.clear();
         return out;
     });
+    m.def("set_conv_mfma", [](bool on) { F.use_conv_mfma = on; });
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
     m.def("set_fuse_bwd_add", [](bool on) { F.fuse_bwd_add = on; });   // A/B: residual-gradient sums in the stores of the InstanceNorm / LayerNorm backward kernels
