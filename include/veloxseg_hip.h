@@ -199,12 +199,16 @@ int vx_gelu_drop_bwd(const float* dh, const float* a, float* da, long n, const v
 int vx_axpy_drop_fwd(const float* x, const float* z, float* out, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
 int vx_axpy_drop_bwd(const float* dout, float* dx, float* dz, float alpha, long n, const void* seed_ptr, unsigned long long dstream, float p, void* stream);
 int vx_add(const float* a, const float* b, const float* c, float* out, long n, void* stream);          /* out = a + b (+ c) */
+/* out[k] = a[k] + b[k] (+ c[k]; c or c[k] may be NULL), k < count <= 16 tensors of n[k] floats, one launch (host arrays of device pointers) */
+int vx_add_many(const float* const* a, const float* const* b, const float* const* c, float* const* out, const long* n, int count, void* stream);
 int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream);                  /* db[c] += sum_{b,v} dy */
 /* PatchMerging.faeture_sample (attention_utils.py:144-159); Dc,Hc,Wc = coarse dims; inverse=1 is the adjoint */
 int vx_space_to_depth2(const float* x, float* out, int B, int C, int Dc, int Hc, int Wc, int inverse, void* stream);
 /* out[b, c*K^3 + (kd*K+kh)*K + kw, z,y,x] = x[b, c, z*K+kd, y*K+kh, x*K+kw] (K = 2, 3, 4; d,h,w = OUTPUT grid): turns a kernel == stride conv
  * (PatchEmbed, Encoder.py:150-156) into a 1x1 conv over C*K^3 channels with the conv weight viewed as (Cout, C*K^3) */
 int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, int K, void* stream);
+/* the same for a channel slice of a wider tensor: batch_stride = floats between consecutive samples of x (the slice itself contiguous within a sample) */
+int vx_patchify_bs(const float* x, long batch_stride, float* out, int B, int C, int d, int h, int w, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Paired-Window Attention (model/components/PWA.py).  Geometry of one layer:

@@ -132,7 +132,12 @@ struct ConvState {
 Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
                      bool x_requires_grad, void* stream) {
     check_in(x_in, "conv3d");
-    Tensor x = contig(x_in), x2 = x2_in.defined() ? contig(x2_in) : Tensor();
+    // a channel slice of a wider contiguous tensor (the per-modality chunks of the network input): the patch-embedding path reads it in place
+    const bool slice = x_in.dim() == 5 && !x_in.is_contiguous() && !x2_in.defined() && x_in.stride(4) == 1 && x_in.stride(3) == x_in.size(4) &&
+                       x_in.stride(2) == x_in.size(3) * x_in.size(4) && (x_in.size(1) == 1 || x_in.stride(1) == x_in.size(2) * x_in.size(3) * x_in.size(4)) &&
+                       F.use_patchify && K == S && (K == 2 || K == 4) && P == 0 && G == 1 && ps == 1 && !x_requires_grad && x_in.stride(0) % 4 == 0 &&
+                       x_in.size(2) % K == 0 && x_in.size(3) % K == 0 && x_in.size(4) % K == 0 && (x_in.size(1) * K * K * K) % 4 == 0 && (x_in.storage_offset() % 4) == 0;
+    Tensor x = slice ? x_in : contig(x_in), x2 = x2_in.defined() ? contig(x2_in) : Tensor();
     const int B = x.size(0), C1 = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4);
     const int Cin = C1 + (x2.defined() ? (int)x2.size(1) : 0), Cout = w.size(0);
     TORCH_CHECK(w.size(1) * G == Cin && w.size(2) == K, "conv3d: weight shape does not match the input");
@@ -150,7 +155,7 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
         const int Ck = Cin * K * K * K;
         const long Vo = (long)Do * Ho * Wo;
         Tensor xs = at::empty({B, Ck, Do, Ho, Wo}, x.options());
-        VX(vx_patchify, fp(x), mp(xs), B, Cin, Do, Ho, Wo, K, stream);
+        VX(vx_patchify_bs, fp(x), (long)x.stride(0), mp(xs), B, Cin, Do, Ho, Wo, K, stream);
         if (Vo <= F.pw_mfma_max_v) VX(vx_pw_conv_mfma, fp(xs), nullptr, Ck, fp(w), 0, fp(b), mp(y), nullptr, 0, B, Cout, Ck, Ck, Vo, 0, stream);
         else VX(vx_pw_conv_fwd, fp(xs), nullptr, Ck, fp(w), fp(b), mp(y), B, Ck, Cout, Vo, stream);
         st.x = xs;

@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(256) vx_conv_mfma_bwd_data_k(VxCm P) {
     }
 }
 
+
 // ------------------------------------------------------------------------------------------------------------------------------- host
 extern "C" int vx_conv_mfma_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P, int G, int ps) {
     if (G != 1 || ps != 1 || K > 7 || S < 2 || S > 4 || P != K / 2 || (K & 1) == 0) return 0;
@@ -275,9 +276,12 @@ extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bia
     vx_conv_mfma_wprep_k<<<dim3(vx_cdiv(nw, 256) > 1024 ? 1024 : vx_cdiv(nw, 256)), dim3(256), 0, st>>>(w, ws, Cout, Cin, K * K * K, A.ksteps, A.NTtot, 0);
     const long Mtot = (long)B * A.Do * A.Ho * A.Wo;
     // few row tiles (deep levels): one column tile per block, and below ~256 blocks the four waves of a block split K instead of the rows
+    // K is split on the geometry of a NOMINAL batch of 4, so that a sample's sums are folded in the same order whatever it is batched with
+    const long Mnom = 4L * A.Do * A.Ho * A.Wo;
     int NT = A.NTtot >= 4 ? 4 : (A.NTtot >= 2 ? 2 : 1);
-    while (NT > 1 && (long)vx_cdiv(Mtot, 64) * vx_cdiv(A.NTtot, NT) < 256) NT >>= 1;
-    const bool ksplit = (long)vx_cdiv(Mtot, 64) * vx_cdiv(A.NTtot, NT) < 256;
+    while (NT > 1 && (long)vx_cdiv(Mnom, 64) * vx_cdiv(A.NTtot, NT) < 256) NT >>= 1;
+    const bool ksplit = (long)vx_cdiv(Mnom, 64) * vx_cdiv(A.NTtot, NT) < 256;
+    if (ksplit) NT = 1;
     const int gx = ksplit ? vx_cdiv(Mtot, 16) : vx_cdiv(Mtot, 64);
     const size_t shm = sizeof(int) * 8 * (size_t)A.ksteps + (ksplit ? sizeof(float) * 4 * NT * 4 * 64 : 0);
     VX_REQUIRE(shm <= 64 * 1024, "vx_conv_mfma_fwd: k table does not fit LDS");
@@ -305,9 +309,11 @@ extern "C" int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx,
     vx_conv_mfma_wprep_k<<<dim3(vx_cdiv(nw, 256) > 1024 ? 1024 : vx_cdiv(nw, 256)), dim3(256), 0, st>>>(w, ws, Cout, Cin, K * K * K, A.ksteps, A.NTtot, 1);
     const long Mtot = (long)B * (D / S) * (H / S) * (W / S);
     const int ncls = S * S * S;
+    const long Mnom = 4L * (D / S) * (H / S) * (W / S);       // (nominal batch of 4: see vx_conv_mfma_fwd)
     int NT = A.NTtot >= 4 ? 4 : (A.NTtot >= 2 ? 2 : 1);
-    while (NT > 1 && (long)vx_cdiv(Mtot, 64) * ncls * vx_cdiv(A.NTtot, NT) < 256) NT >>= 1;
-    const bool ksplit = (long)vx_cdiv(Mtot, 64) * ncls * vx_cdiv(A.NTtot, NT) < 256;
+    while (NT > 1 && (long)vx_cdiv(Mnom, 64) * ncls * vx_cdiv(A.NTtot, NT) < 256) NT >>= 1;
+    const bool ksplit = (long)vx_cdiv(Mnom, 64) * ncls * vx_cdiv(A.NTtot, NT) < 256;
+    if (ksplit) NT = 1;
     const int gx = ksplit ? vx_cdiv(Mtot, 16) : vx_cdiv(Mtot, 64);
     const size_t shm = ksplit ? sizeof(float) * 4 * NT * 4 * 64 : 0;
     const dim3 grid(gx, ncls, vx_cdiv(A.NTtot, NT));

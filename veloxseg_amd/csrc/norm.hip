@@ -593,6 +593,42 @@ extern "C" int vx_add(const float* a, const float* b, const float* c, float* out
     VX_LAUNCH_CHECK("vx_add");
     return 0;
 }
+// out[k] = a[k] + b[k] (+ c[k]) for up to 16 tensors in ONE launch: the per-branch gradients of the tensors the encoder hands to the M + 1 decoders
+// (12 of them, two adds each as separate aten launches before) are summed at the start of the encoder backward.  blockIdx.y = tensor.
+struct VxAddMany { const float* a[16]; const float* b[16]; const float* c[16]; float* out[16]; long n[16]; };
+__global__ void __launch_bounds__(256) vx_add_many_k(VxAddMany P) {
+    const int k = blockIdx.y;
+    const long n = P.n[k];
+    const float* __restrict__ a = P.a[k]; const float* __restrict__ b = P.b[k]; const float* __restrict__ c = P.c[k];
+    float* __restrict__ o = P.out[k];
+    const bool v4 = (n & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)o) & 15) == 0);
+    if (v4) {
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 x = reinterpret_cast<const float4*>(a)[i];
+            const float4 y = reinterpret_cast<const float4*>(b)[i];
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+            if (c) { const float4 z = reinterpret_cast<const float4*>(c)[i]; x.x += z.x; x.y += z.y; x.z += z.z; x.w += z.w; }
+            reinterpret_cast<float4*>(o)[i] = x;
+        }
+    } else
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) o[i] = a[i] + b[i] + (c ? c[i] : 0.0f);
+}
+extern "C" int vx_add_many(const float* const* a, const float* const* b, const float* const* c, float* const* out, const long* n, int count, void* stream) {
+    VX_REQUIRE(a && b && out && n && count >= 1 && count <= 16, "vx_add_many: 1..16 tensors");
+    VxAddMany P;
+    long nmax = 0;
+    for (int k = 0; k < 16; ++k) {
+        const bool in = k < count;
+        P.a[k] = in ? a[k] : nullptr; P.b[k] = in ? b[k] : nullptr; P.c[k] = (in && c) ? c[k] : nullptr; P.out[k] = in ? out[k] : nullptr; P.n[k] = in ? n[k] : 0;
+        if (in) { VX_REQUIRE(a[k] && b[k] && out[k] && n[k] > 0, "vx_add_many: null tensor %d", k); if (n[k] > nmax) nmax = n[k]; }
+    }
+    int gx = vx_cdiv(nmax, 1024);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(vx_add_many_k, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, P);
+    VX_LAUNCH_CHECK("vx_add_many");
+    return 0;
+}
 extern "C" int vx_channel_sum(const float* dy, float* db, int B, int C, long V, void* stream) {
     VX_REQUIRE(dy && db && B > 0 && C > 0 && V > 0, "vx_channel_sum: bad args");
     int chunks = vx_cdiv((long)B * V, 256 * 16);
@@ -618,7 +654,7 @@ extern "C" int vx_space_to_depth2(const float* x, float* out, int B, int C, int 
 // thread = one (input row, x): reads K contiguous floats, writes one float to each of K channel planes (coalesced across lanes).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ in, float* __restrict__ out, int C, int d, int h, int w) {
+__global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ in, float* __restrict__ out, int C, int d, int h, int w, long bstride) {
     const long rows = (long)C * d * K * h * K;                  // input rows of one sample, each w*K floats long
     const long n = rows * w;
     const long b = blockIdx.y;
@@ -631,7 +667,7 @@ __global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ i
         const int kd = (int)(r % K); r /= K;
         const int z = (int)(r % d);
         const int c = (int)(r / d);
-        const float* __restrict__ src = in + (((b * C + c) * (long)(d * K) + (z * K + kd)) * (long)(h * K) + (y * K + kh)) * (long)(w * K) + (long)x * K;
+        const float* __restrict__ src = in + b * bstride + (((long)c * (d * K) + (z * K + kd)) * (long)(h * K) + (y * K + kh)) * (long)(w * K) + (long)x * K;
         float v[K];
         if (K == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[K - 1] = t.w; }
         else if (K == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[0] = t.x; v[K - 1] = t.y; }
@@ -645,19 +681,25 @@ __global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ i
     }
 }
 
-extern "C" int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, int K, void* stream) {
+// batch_stride (floats) = distance between the samples of x: C * (d K)(h K)(w K) for a contiguous tensor, larger for a channel slice of a wider one
+// (the per-modality chunks of the network input, Encoder.py:192 of the reference) -- no .contiguous() copy in front of the patch embedding
+extern "C" int vx_patchify_bs(const float* x, long batch_stride, float* out, int B, int C, int d, int h, int w, int K, void* stream) {
     VX_REQUIRE(x && out && B > 0 && C > 0 && d > 0 && h > 0 && w > 0, "vx_patchify: bad args");
     VX_REQUIRE(K == 2 || K == 3 || K == 4, "vx_patchify: patch size 2, 3 or 4 (got %d)", K);
+    VX_REQUIRE(batch_stride >= (long)C * d * K * h * K * w * K && (K == 3 || batch_stride % K == 0), "vx_patchify: bad batch stride %ld", batch_stride);
     const long n = (long)C * d * K * h * K * w;
     int g = vx_cdiv(n, 256 * 4);
     if (g > 16384) g = 16384;
     const dim3 grid(g, B), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 4) vx_patchify_k<4><<<grid, blk, 0, st>>>(x, out, C, d, h, w);
-    else if (K == 3) vx_patchify_k<3><<<grid, blk, 0, st>>>(x, out, C, d, h, w);
-    else vx_patchify_k<2><<<grid, blk, 0, st>>>(x, out, C, d, h, w);
+    if (K == 4) vx_patchify_k<4><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);
+    else if (K == 3) vx_patchify_k<3><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);
+    else vx_patchify_k<2><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);
     VX_LAUNCH_CHECK("vx_patchify");
     return 0;
+}
+extern "C" int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, int K, void* stream) {
+    return vx_patchify_bs(x, (long)C * d * K * h * K * w * K, out, B, C, d, h, w, K, stream);
 }
 
 

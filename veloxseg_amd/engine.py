@@ -320,17 +320,40 @@ class TrainEngine:
             torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
     def _s_enc_bwd(self):
-        bt, bg = [], []
+        bt, groups = [], []
         for j, t in enumerate(self._boundary):
             gs = [lv[j].grad for lv in self._leaves if lv[j].grad is not None]
             if gs:
-                g = gs[0]
-                for h in gs[1:]:
-                    g = g + h
                 bt.append(t)
-                bg.append(g)
+                groups.append(gs)
+        bg = self._sum_groups(groups)
         with self._wgrad_side():
             torch.autograd.backward(bt, bg)
+
+    def _sum_groups(self, groups):
+        """[g0 (+ g1 (+ g2))] per boundary tensor: the per-branch gradients of one tensor summed; all the 2- and 3-term sums in ONE launch (vx_add_many)"""
+        import ctypes
+        out = [g[0] if len(g) == 1 else None for g in groups]
+        todo = [i for i, g in enumerate(groups) if 2 <= len(g) <= 3 and all(t.is_contiguous() and t.dtype == torch.float32 for t in g)]
+        for i, g in enumerate(groups):
+            if out[i] is None and i not in todo:
+                acc = g[0]
+                for h in g[1:]:
+                    acc = acc + h
+                out[i] = acc
+        for lo in range(0, len(todo), 16):
+            idx = todo[lo:lo + 16]
+            k = len(idx)
+            res = [torch.empty_like(groups[i][0]) for i in idx]
+            arr = lambda vals: (ctypes.c_void_p * k)(*vals)
+            a, b = arr([H.P(groups[i][0]) for i in idx]), arr([H.P(groups[i][1]) for i in idx])
+            c = arr([H.P(groups[i][2]) if len(groups[i]) == 3 else None for i in idx])
+            o = arr([H.P(r) for r in res])
+            n = (ctypes.c_long * k)(*[groups[i][0].numel() for i in idx])
+            H.call("vx_add_many", ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), ctypes.addressof(o), ctypes.addressof(n), k, H.stream_ptr())
+            for i, r in zip(idx, res):
+                out[i] = r
+        return out
 
     def _eager_stages(self, between=None):
         """the staged pass launched eagerly: decoder stages on forked HIP streams (functional.run_branches; autograd replays each branch's

@@ -86,7 +86,7 @@ class Transformer_Encoder(nn.Module):
         xs = torch.chunk(xs, self.num_modalities, dim=1)            # Encoder.py:192
         p = self.p_pos if self.training else 0.0
         def one(m):
-            e = self.patch_embeds[m](xs[m].contiguous())
+            e = self.patch_embeds[m](xs[m])          # a channel slice: the patch-embedding kernels read it in place (vx_patchify_bs)
             return VF.residual_dropout(None, e, 0.0, p, self.sites_pos[m]) if p > 0 else e
 
         M = self.num_modalities
