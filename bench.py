@@ -297,6 +297,13 @@ def main():
                         rf["traffic_source"] = src
                 out["roofline"] = rf
                 break
+        # the JLC spatial stage (the reference's Johnson-Lindenstrauss block, conv_blocks.py:51-58) at level 1: its own roofline object with PMC traffic
+        jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == "vx_jlc_conv_fwd"]
+        if jl:
+            ms1, n1, key1 = max(jl, key=lambda t: t[2][3] * t[2][4] * t[2][5])
+            rj = roofline_for("vx_jlc_conv_fwd", key1, ms1, model)
+            rj["launches_per_step"] = n1
+            out["roofline_jlc"] = rj
     if rank == 0:
         gf, mb, opt_mb = STEP_WORK[args.workload]
         flops = gf * 1e9 * B * world
@@ -321,7 +328,28 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01z_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_NAME = "profiles/r02_pmc_traffic.json"
+
+
+def _pmc_traffic_by_grid(kernel, B, grid_threads):
+    """HBM bytes per launch of `kernel` at the launch geometry `grid_threads` (total work-items), from the committed PMC passes"""
+    try:
+        d = json.load(open(PMC_FILE))["kernels"][kernel]
+        if B != 4 or _pmc_traffic.workload != "autopet128":
+            return None, None
+        bg = d.get("by_grid", {})
+        if grid_threads in ("max", "min") and bg:            # the kernel runs with two launch geometries per step (level 1 / level 2): largest / smallest grid
+            key = (max if grid_threads == "max" else min)(bg, key=int)
+            return float(bg[key]["hbm_bytes_per_launch_corrected"]), PMC_NAME + f" (grid of {key} work-items)"
+        g = bg.get(str(grid_threads))
+        if g is not None:
+            return float(g["hbm_bytes_per_launch_corrected"]), PMC_NAME + " (by grid size)"
+        if "by_grid" not in d:
+            return float(d["hbm_bytes_per_launch_corrected"]), PMC_NAME
+    except Exception:
+        pass
+    return None, None
 
 
 def _pmc_traffic_by_launches(kernel, B, launches_per_step, trace_steps=5):
@@ -332,24 +360,24 @@ def _pmc_traffic_by_launches(kernel, B, launches_per_step, trace_steps=5):
             return None, None
         hits = [g for g in d.get("by_grid", {}).values() if g["launches_in_trace"] == launches_per_step * trace_steps]
         if len(hits) == 1:
-            return float(hits[0]["hbm_bytes_per_launch_corrected"]), "profiles/r01z_pmc_traffic.json (by grid size)"
+            return float(hits[0]["hbm_bytes_per_launch_corrected"]), PMC_NAME + " (by grid size)"
         if "by_grid" in d:
             return None, None
         note = "" if d["launches_in_trace"] == launches_per_step * trace_steps else f" (mean over all {d['launches_in_trace'] // trace_steps} launches of this kernel per step, more than one shape)"
-        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r01z_pmc_traffic.json" + note
+        return float(d["hbm_bytes_per_launch_corrected"]), PMC_NAME + note
     except Exception:
         return None, None
 
 
 def _pmc_traffic(kernels, B):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
-    correction applied: profiles/r01z_pmc_traffic.json).  Counters cannot be read from inside bench.py; the figure is valid for the workload
+    correction applied: profiles/r02_pmc_traffic.json).  Counters cannot be read from inside bench.py; the figure is valid for the workload
     and batch it was collected on (autopet128, B = 4) and null otherwise."""
     try:
         d = json.load(open(PMC_FILE))["kernels"]
         if B != 4 or _pmc_traffic.workload != "autopet128":
             return None, None
-        return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), "profiles/r01z_pmc_traffic.json"
+        return float(sum(d[k]["hbm_bytes_per_launch_corrected"] for k in kernels)), PMC_NAME
     except Exception:
         return None, None
 
@@ -396,6 +424,37 @@ def roofline_for(name, key, ms_per_launch, model=None):
                 r["pairs"], r["kernels"] = pairs, 1 if name == "vx_pwa_attn_fwd" else 2
                 r["traffic"], r["traffic_source"] = _pmc_traffic([f"vx_pwa_attn_fwd_k<{cq}, {cv}>"] if name == "vx_pwa_attn_fwd" else
                                                                  [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"], B)
+        elif name in ("vx_jlc_conv_fwd", "vx_jlc_conv_bwd"):
+            B, C, G, D, H, W = k[:6]                  # grouped k = 1, 3, 5 convolutions of one JLC block from one K = 5 halo (csrc/jlc.hip)
+            v = B * D * H * W
+            flops = 2.0 * v * C * (C // G) * (1 + 27 + 125)
+            # forward: x read, y1 / y3 / y5 written; backward: g1 / g3 / g5 and d_o read, dx written (+ the three weight tensors)
+            bytes_ = 4.0 * (v * C * (4 if name == "vx_jlc_conv_fwd" else 5) + C * (C // G) * 153)
+            r["traffic"], src = _pmc_traffic_by_grid("vx_jlc_conv_fwd_k<4>" if name == "vx_jlc_conv_fwd" else "vx_jlc_conv_bwd_k<4>", B, "max" if D * H * W >= 16384 else "min")
+            if src:
+                r["traffic_source"] = src
+        elif name in ("vx_mlp_fwd", "vx_mlp_bwd"):
+            ints = [int(a) for a in k]
+            B, C, R, V = ints[2:6] if name == "vx_mlp_fwd" else ints[1:5]      # (norm, nparts, B, C, R, V, ...) / (norm, B, C, R, V, ...)
+            flops = (4.0 if name == "vx_mlp_fwd" else 10.0) * B * V * C * R      # fwd: two GEMMs; bwd: GEMM1 recomputed + four gradient GEMMs
+            bytes_ = 4.0 * (B * V * C * (2 if name == "vx_mlp_fwd" else 3) + 2 * C * R)
+        elif name in ("vx_seg_loss_ds_fwd", "vx_seg_loss_ds_bwd"):
+            ints = [int(a) for a in k]
+            B, C, D, H, W = ints[-5:]
+            lab_bytes = {0: 8, 1: 4, 2: 1}.get(ints[1], 8)
+            v = B * D * H * W
+            low = sum(v // f ** 3 for f in (2, 4, 8)) * C                      # the deep-supervision heads on their own grids
+            flops = 40.0 * v * C
+            bytes_ = 4.0 * (v * C + low) * (1 if name == "vx_seg_loss_ds_fwd" else 2) + lab_bytes * v
+        elif name == "vx_expand_fwd_mfma":
+            B, Cc, D, H, W = k[:5]
+            v = B * D * H * W
+            flops, bytes_ = 2.0 * v * 64 * Cc * 16 * 27, 4.0 * (v * (16 + 64 * Cc) + 64 * Cc * 16 * 27)
+        elif name in ("vx_conv_mfma_fwd", "vx_conv_mfma_bwd_data"):
+            B, Cin, Di, Hi, Wi, Cout, K, S, P = k[:9]
+            Do, Ho, Wo = (_conv_out(d, K, S, P) for d in (Di, Hi, Wi))
+            vin, vout, nw = B * Cin * Di * Hi * Wi, B * Cout * Do * Ho * Wo, Cout * Cin * K ** 3
+            flops, bytes_ = 2.0 * vout * Cin * K ** 3, 4.0 * (vin + vout + 2 * nw)
         elif name in ("vx_pw_conv_fwd", "vx_pw_conv_bwd_data", "vx_pw_conv_bwd_weight"):
             B, Cin, Cout, V = k[-4:] if name != "vx_pw_conv_bwd_data" else k[-5:-1]
             flops, bytes_ = 2.0 * B * V * Cin * Cout, 4.0 * (B * V * (Cin + Cout) + Cin * Cout)
