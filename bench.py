@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="autopet128", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: workload default)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = the opt-in mode of BASELINE configs[1]: bf16 MFMA operands (fp32 accumulate, fp32 storage) in the patch-expand layers; a separate line, never the headline")
     ap.add_argument("--eager", action="store_true", help="launch every step through autograd (host-bound: ~10 ms of enqueue per step) instead of replaying the captured launch tapes")
     ap.add_argument("--hipgraph", action="store_true", help="replay the captured stages with hipGraphLaunch instead of the launch tape (slower on ROCm 7.2: DESIGN.md section 3)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches on forked HIP streams")
@@ -232,7 +233,7 @@ def main():
     model = VeloxSeg(**cfg).to(dev)
     VF.manual_seed(12345 + rank, dev)
     crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, dev, num_modal=len(cfg["in_ch"]))
-    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.eager, replay="graph" if args.hipgraph else "tape", overlap=not args.no_overlap)
+    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.eager, replay="graph" if args.hipgraph else "tape", overlap=not args.no_overlap, precision="bf16" if args.dtype == "bf16" else "fp32")
     x, lab = synth(cfg, B, dev, 12345 + rank)
     eng.step(x, lab)                                           # capture (+ first step)
     for _ in range(max(args.warmup - 1, 0)):
@@ -263,7 +264,8 @@ def main():
         out = {"metric": "training patches/s on 128^3 2-mod volumes (fwd+loss+bwd+allreduce+AdamW)" if args.workload == "autopet128"
                else f"training patches/s ({args.workload})",
                "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers (fp32 accumulate, fp32 storage, fp32 everywhere else)",
                "data": "synthetic (randn volumes, rand>0.97 labels, random-init weights, seed 12345)",
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",

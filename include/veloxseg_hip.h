@@ -78,6 +78,11 @@ int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float*
 /* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
  * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
 int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);
+/* bf16 opt-in mode (BASELINE configs[1]: the BraTS bf16 line): the same two layers with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16), fp32
+ * accumulation and fp32 tensors in HBM; weights and activations are rounded to bf16 (nearest-even) on their way into the MFMA.  Same arguments and
+ * workspaces as the fp32 entries above; return 1 = shape not covered (D, H % 4, W % 16), the caller then uses the fp32 entry. */
+int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream);
+int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, void* stream);
 /* 1x1x1 convolutions: thread-per-voxel with scalar-path weights (fwd / bwd_data; Cin % 4 == 0), fp32-MFMA GEMM over the voxel
  * axis for the weight gradient.  w: (Cout, Cin).  Same concat / accumulate conventions as vx_conv3d_*. */
 int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,

@@ -26,7 +26,7 @@ typedef c10::optional<Tensor> OptT;
 namespace {
 
 struct Flags {
-    bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
+    bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -168,7 +168,11 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
         int rc = 1;
         if (ps == 4 && K == 3 && Cin == 16 && G == 1 && Cout % 64 == 0 && F.use_expand_mfma) {       // patch-expand layer: MFMA tiles over an LDS halo
             Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
-            rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
+            if (F.bf16_expand) {
+                rc = vx_expand_fwd_mfma_bf16(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
+                if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma_bf16");
+            }
+            if (rc == 1) rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
         }
         if (rc == 1) VX(vx_conv_s1, fp(x), fp(w), fp(b), mp(y), B, Cin, Cout, D, H, W, K, G, 0, 1, ps, 0, stream);
@@ -221,7 +225,12 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         else if (st.pw) VX(vx_pw_conv_bwd_data, fp(dy), fp(w), mp(dx), mp(dx2), C1, B, Cin, Cout, V, acc, stream);
         else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
             Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
-            VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
+            int rcb = 1;
+            if (F.bf16_expand) {
+                rcb = vx_expand_bwd_data_mfma_bf16(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
+                if (rcb != 0 && rcb != 1) chk(rcb, "vx_expand_bwd_data_mfma_bf16");
+            }
+            if (rcb == 1) VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
         } else if (st.s1) VX(vx_conv_s1, fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream);
         else if (st.cm) {
             Tensor ws = at::empty({(long)vx_conv_mfma_ws_floats(Cin, Cout, K, 1)}, x.options());
@@ -1091,6 +1100,8 @@ PYBIND11_MODULE(_vxops, m) {
         return out;
     });
     m.def("set_conv_mfma", [](bool on) { F.use_conv_mfma = on; });
+    m.def("set_bf16_expand", [](bool on) { F.bf16_expand = on; });      // bf16 opt-in mode: bf16 MFMA operands in the patch-expand forward / input gradient
+    m.def("get_bf16_expand", []() { return F.bf16_expand; });
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
     m.def("set_fuse_bwd_add", [](bool on) { F.fuse_bwd_add = on; });   // A/B: residual-gradient sums in the stores of the InstanceNorm / LayerNorm backward kernels

@@ -450,3 +450,206 @@ extern "C" int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* 
     VX_LAUNCH_CHECK("vx_expand_wgrad_mfma");
     return 0;
 }
+
+// ======================================================================================================================================
+// bf16 opt-in mode (BASELINE configs[1]; veloxseg_amd.set_precision("bf16")): the patch-expand forward and input gradient with bf16 MFMA
+// OPERANDS (v_mfma_f32_16x16x32_bf16: 16 SIMD-clk for 8192 MACs, fp32 accumulate), storage fp32 as everywhere else.  K of one MFMA = TWO taps x 16
+// channels (forward) / two taps x 16 (s2, s3) sub-positions (input gradient): lane (r, q) holds k = 8 q + j, i.e. tap 2 p + (q >> 1) and the
+// channels / sub-positions 8 (q & 1) + j.  27 taps = 14 pairs (the last one half empty): 56 MFMAs per (c, s1) group instead of 432 fp32 ones.
+// Weights are converted once per launch into an operand-order bf16 image (one 16-byte load per lane and pair); activations are rounded to
+// bf16 (nearest-even) when they enter LDS (forward) or when they leave it (input gradient).  Error: 2^-9 relative per product, fp32 sums.
+// ======================================================================================================================================
+typedef __bf16 vx_bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t vx_pack_bf16(float a, float b) {            // (a -> low half, b -> high half), round to nearest even
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+__device__ __forceinline__ vx_bf8 vx_as_bf8(uint4 v) { return __builtin_bit_cast(vx_bf8, v); }
+
+// img[((g * 14 + p) * 64 + lane) * 8 + j], g = (c, s1) group of 16 output channels
+//   forward : row r = lane & 15 -> co = 16 g + r;  tap = 2 p + (q >> 1), ci = 8 (q & 1) + j
+//   backward: col r -> ci = r;                     tap = 2 p + (q >> 1), co = 16 g + 4 s2 + s3 with s2 = 2 (q & 1) + (j >> 2), s3 = j & 3
+__global__ void __launch_bounds__(256) vx_expand_wimg_bf16_k(const float* __restrict__ w, uint32_t* __restrict__ img, int groups, int backward) {
+    const long n = (long)groups * 14 * 64 * 4;               // packed pairs
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int jp = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long t = e >> 8;
+    const int p = (int)(t % 14), g = (int)(t / 14);
+    const int r = lane & 15, q = lane >> 4;
+    const int tap = 2 * p + (q >> 1);
+    float v[2] = {0.f, 0.f};
+    if (tap < 27)
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * jp + u;
+            int co, ci;
+            if (backward) { co = 16 * g + 4 * (2 * (q & 1) + (j >> 2)) + (j & 3); ci = r; }
+            else { co = 16 * g + r; ci = 8 * (q & 1) + j; }
+            v[u] = w[((long)co * 16 + ci) * 27 + tap];
+        }
+    img[e] = vx_pack_bf16(v[0], v[1]);
+}
+
+__global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+    __shared__ uint4 xh[2 * 648];                       // [channel half][6 x 6 x 18 halo voxel] x 8 bf16
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const float* __restrict__ xb = x + (long)b * 16 * V;
+    for (int e = threadIdx.x; e < 2 * 648; e += 256) {
+        const int hv = e % 648, half = e / 648;
+        const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+        const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+        const float* __restrict__ src = xb + (long)(8 * half) * V + (ok ? ((long)qd * H + qh) * W + qw : 0);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(long)j * V];
+        uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) pk = make_uint4(vx_pack_bf16(v[0], v[1]), vx_pack_bf16(v[2], v[3]), vx_pack_bf16(v[4], v[5]), vx_pack_bf16(v[6], v[7]));
+        xh[e] = pk;
+    }
+    __syncthreads();
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    // this lane's B-operand base per tap pair: tap = 2 p + (q >> 1), channel half q & 1, voxel column r
+    for (int g = 0; g < Cc * 4; ++g) {                                     // (c, s1) groups
+        const int c = g >> 2, s1 = g & 3;
+        const int co_base = g * 16;
+        vx_f4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+        const uint4* __restrict__ wg = wimg + (long)g * 14 * 64 + lane;
+#pragma unroll 2
+        for (int p = 0; p < 14; ++p) {
+            const int t = 2 * p + (q >> 1);
+            const int tt = t < 27 ? t : 26;                                // (the empty half pair has zero weights)
+            const int tw = tt % 3, th = (tt / 3) % 3, td = tt / 9;
+            const uint4 av = wg[p * 64];
+            const uint4* __restrict__ xt = xh + (q & 1) * 648 + ((wave + td) * 6 + th) * 18 + r + tw;
+            uint4 bv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bv[m] = xt[m * 18];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av), vx_as_bf8(bv[m]), acc[m], 0, 0, 0);
+        }
+        // D: row 4q+reg = (s2 = q, s3 = reg), col r = voxel w0 + r
+        const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+    }
+}
+
+extern "C" int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma_bf16: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = Cc * 4;
+    vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
+    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    vx_expand_fwd_bf16_k<<<dim3((unsigned)nblk), 256, 0, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
+    VX_LAUNCH_CHECK("vx_expand_fwd_mfma_bf16");
+    return 0;
+}
+
+// input gradient, bf16 operands: the block / wave / halo layout of vx_expand_bwd_data_lds_k (fp32 halo of one (c, s1) group in LDS), rows = 16 coarse
+// voxels, cols = 16 ci; A = 2 x 4 contiguous fine-gradient floats of this lane's tap (rounded to bf16 here), B = the operand-order weight image
+__global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
+                                                                 int B, int Cc, int D, int H, int W, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float vx_halo_t[];          // [6][6][4][72]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
+    vx_f4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cc; ++c) {
+        for (int s1 = 0; s1 < 4; ++s1) {
+            __syncthreads();
+            {
+                float4 v[11];
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+                    const int f4 = e % 18, row = e / 18;
+                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = (int)threadIdx.x + u * 256;
+                    if (e < 144 * 18) *reinterpret_cast<float4*>(vx_halo_t + (e / 18) * 72 + (e % 18) * 4) = v[u];
+                }
+            }
+            __syncthreads();
+            const uint4* __restrict__ wg = wimg + (long)(c * 4 + s1) * 14 * 64 + lane;
+#pragma unroll 2
+            for (int p = 0; p < 14; ++p) {
+                const int t = 2 * p + (q >> 1);
+                const int tt = t < 27 ? t : 26;
+                const int tw = tt % 3, th = (tt / 3) % 3, td = tt / 9;
+                const uint4 bv = wg[p * 64];
+                const int hd = wave - td + 2;
+                const int s2 = 2 * (q & 1);
+                const float* __restrict__ ht = vx_halo_t + ((hd * 6 + (2 - th)) * 4 + s2) * 72 + (r - tw + 2) * 4;
+                uint4 av[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 lo = *reinterpret_cast<const float4*>(ht + m * 4 * 72);
+                    const float4 hi = *reinterpret_cast<const float4*>(ht + m * 4 * 72 + 72);
+                    av[m] = make_uint4(vx_pack_bf16(lo.x, lo.y), vx_pack_bf16(lo.z, lo.w), vx_pack_bf16(hi.x, hi.y), vx_pack_bf16(hi.z, hi.w));
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[m]), vx_as_bf8(bv), acc[m], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
+        float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst) = o;
+    }
+}
+
+extern "C" int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
+                                            int accumulate, void* stream) {
+    VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma_bf16: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = Cc * 4;
+    vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
+    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    vx_expand_bwd_data_bf16_k<<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_bf16");
+    return 0;
+}

@@ -144,8 +144,10 @@ class TrainEngine:
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
-                 replay="tape", tape_lanes=6):
+                 replay="tape", tape_lanes=6, precision="fp32"):
         self.model, self.criterion = model, criterion
+        VF.set_precision(precision)            # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision); process-wide
+        self.precision = precision
         if hasattr(model, "ds_fused"):
             model.ds_fused = bool(fuse_ds)      # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip)
         self.dev = next(model.parameters()).device

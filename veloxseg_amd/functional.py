@@ -223,6 +223,29 @@ def cpp_module(reload: bool = False):
     return _CPP[1]
 
 
+_PRECISION = "fp32"
+
+
+def set_precision(mode: str):
+    """"fp32" (default: every product in fp32, the parity mode) or "bf16": the opt-in mode of BASELINE configs[1] -- bf16 MFMA operands with fp32
+    accumulation in the patch-expand layers (forward and input gradient; 49 % of the training FLOPs), fp32 tensors in HBM, fp32 norms / soft-max /
+    loss.  Judged by Dice, not by the fp32 logit tolerance (tests/test_bf16_gpu.py).  Process-wide; TrainEngine(precision=...) sets it."""
+    global _PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    m = cpp_module()
+    if m is None:
+        if mode == "bf16":
+            raise RuntimeError("veloxseg_amd: the bf16 mode lives in the C++ operator path (veloxseg_amd._vxops), which is not built / enabled")
+        return
+    m.set_bf16_expand(mode == "bf16")
+    _PRECISION = mode
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
 def _flag_tuple():
     return (WGRAD_ENTRY, USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX)
 
