@@ -13,6 +13,8 @@ from veloxseg_amd.utils.loss import Loss
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "autopet128"
 cfg, B = WORKLOADS[wl]
+if os.environ.get("VX_ATTN_DROP"):
+    cfg = dict(cfg, attn_drop=float(os.environ["VX_ATTN_DROP"]))      # what-if: cost of the attention dropout (Philox) in the attention kernels
 torch.manual_seed(12345)
 model = VeloxSeg(**cfg).cuda()
 crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))

@@ -13,6 +13,7 @@
 // argument arrays returned by hipGraphKernelNodeGetParams point into the graph's nodes.
 #include "vx_common.h"
 #include "../../include/veloxseg_hip.h"
+#include <stdlib.h>
 #include <vector>
 #include <algorithm>
 #include <unordered_map>
@@ -94,6 +95,7 @@ int pool_init(hipStream_t main) {
     for (auto& e : ev) HIPQ(hipEventCreate(&e), "hipEventCreate");
     constexpr int NC = 12;
     hipStream_t cand[NC], gate;
+    // (default priority: lanes created with hipStreamCreateWithPriority -- highest or lowest, all or some -- made the step 1.7x slower)
     for (auto& c : cand) HIPQ(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreateWithFlags");
     HIPQ(hipStreamCreateWithFlags(&gate, hipStreamNonBlocking), "hipStreamCreateWithFlags");
     hipStream_t chosen[kPool] = {};
