@@ -88,8 +88,11 @@ struct VxPhilox {
 };
 __device__ __forceinline__ void vx_philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    // one 32 x 32 -> 64 multiply per word pair (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32: all three are quarter-rate, so this halves the
+    // multiplier time of a round; same bits
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c[0], p1 = (uint64_t)M1 * (uint64_t)c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
