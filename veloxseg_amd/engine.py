@@ -441,7 +441,10 @@ class TrainEngine:
     def _graph(self, pool, fn, *args):
         tape = self.replay_mode == "tape"
         g = torch.cuda.CUDAGraph(keep_graph=True) if tape else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool):
+        # with RCCL running (world > 1) its watchdog thread polls events while we capture: in the default "global" error mode that invalidates the
+        # capture; "thread_local" checks only the capturing thread (kernels queued by autograd's device thread are captured either way)
+        mode = "thread_local" if (self.world > 1 or os.environ.get("VELOXSEG_CAPTURE_MODE") == "thread_local") else "global"
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
             if tape:
                 fn(*args)                      # the tape launches node by node: no need for the second branch that keeps hipGraphLaunch correct
             else:
@@ -554,7 +557,13 @@ class TrainEngine:
         if not self.model.training:
             self.model.train()
         if self.use_graph and self.graphs is None:
-            self._capture()                                    # may clear use_graph (self-check)
+            try:
+                self._capture()                                # may clear use_graph (self-check)
+            except Exception as e:                             # a capture that cannot be taken (or read back) must not take the training run down
+                warnings.warn(f"TrainEngine: capturing the step failed ({type(e).__name__}: {str(e)[:300]}); falling back to eager launches")
+                self.graphs, self.use_graph = None, False
+                VF.RNG_INPLACE = False
+                torch.cuda.synchronize()
         if self.use_graph:
             self._replay(comm=True)
         else:
