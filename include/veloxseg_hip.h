@@ -367,6 +367,7 @@ int vx_tape_describe(const VxTape* tape, int* lane, int* grid, int* waits4, char
  * with anything).  A tape with one lane replays on the caller's stream; a tape with more replays on the lane streams, gated by and joined
  * back into the caller's stream. */
 int vx_tape_lane_stream(void* any_stream, int lane, void** out);
+int vx_tape_lanes_distinct(void);      /* answer, not a status: how many of the 4 lane streams were measured to overlap pairwise (-1 before the first use) */
 
 #ifdef __cplusplus
 }

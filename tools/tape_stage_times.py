@@ -5,6 +5,7 @@ import os, sys, time, types
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from bench import LOSS_CFG, WORKLOADS, synth
+from veloxseg_amd import _hip as H
 from veloxseg_amd import functional as VF
 from veloxseg_amd.engine import TrainEngine
 from veloxseg_amd.model.VeloxSeg import VeloxSeg
@@ -69,6 +70,7 @@ for k in range(len(G["dec_fwd"])):
 for name, fn in rows:
     gpu, host = timed(fn)
     print(f"{name:22s} gpu {gpu:7.3f} ms   host {host:6.3f} ms")
+print("lanes measured distinct:", H.query("vx_tape_lanes_distinct"))
 for name in ("enc_fwd", "loss", "enc_bwd"):
     t = G[name]
     print(name, "nodes", t.n_nodes, "kernels", t.n_kernels, "lanes", t.n_lanes, "events", t.n_events)

@@ -87,42 +87,67 @@ int pair_us(hipStream_t gate, hipStream_t a, hipStream_t b, hipEvent_t e0, hipEv
     return 0;
 }
 
-int pool_init(hipStream_t main) {
-    if (g_pool.ready) return 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) VX_FAIL(-1, "vx_tape: the lane streams cannot be chosen during a stream capture");
+// one attempt: pick kPool pairwise-overlapping streams out of NC fresh ones; *nd = how many were found (the rest are filled with sharing streams)
+int pool_attempt(hipStream_t (&chosen)[kPool], int* nd) {
     hipEvent_t ev[4];
     for (auto& e : ev) HIPQ(hipEventCreate(&e), "hipEventCreate");
-    constexpr int NC = 12;
+    constexpr int NC = 16;
     hipStream_t cand[NC], gate;
     // (default priority: lanes created with hipStreamCreateWithPriority -- highest or lowest, all or some -- made the step 1.7x slower)
     for (auto& c : cand) HIPQ(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreateWithFlags");
     HIPQ(hipStreamCreateWithFlags(&gate, hipStreamNonBlocking), "hipStreamCreateWithFlags");
-    hipStream_t chosen[kPool] = {};
     bool used[NC] = {};
     int n = 0;
     float us = 0.f;
     int rc = pair_us(gate, cand[0], cand[1], ev[0], ev[1], ev[2], ev[3], &us);        // warm-up (code object load)
+    auto overlap = [&](hipStream_t a, hipStream_t b, bool* ok) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3 && rc == 0; ++rep) { rc = pair_us(gate, a, b, ev[0], ev[1], ev[2], ev[3], &us); best = us < best ? us : best; }
+        *ok = best < 95.f;                        // one spin = 60 us; two in a row = 120 us
+    };
     for (int c = 0; c < NC && n < kPool && rc == 0; ++c) {
         bool ok = true;
-        for (int k = 0; k < n && ok && rc == 0; ++k) {
-            float best = 1e9f;
-            for (int rep = 0; rep < 2 && rc == 0; ++rep) { rc = pair_us(gate, chosen[k], cand[c], ev[0], ev[1], ev[2], ev[3], &us); best = us < best ? us : best; }
-            ok = best < 95.f;                     // one spin = 60 us; two in a row = 120 us
-        }
+        for (int k = 0; k < n && ok && rc == 0; ++k) overlap(chosen[k], cand[c], &ok);
         if (ok && rc == 0) { chosen[n++] = cand[c]; used[c] = true; }
     }
-    g_pool.distinct = n;
+    // second look at every pair of the selection (a disturbed measurement must not freeze a bad choice for the life of the process)
+    bool all_ok = (n == kPool);
+    for (int i = 0; i < n && all_ok && rc == 0; ++i)
+        for (int j = i + 1; j < n && all_ok && rc == 0; ++j) overlap(chosen[i], chosen[j], &all_ok);
+    *nd = all_ok ? n : (n < kPool ? n : kPool - 1);
     for (int c = 0; c < NC; ++c) if (!used[c] && n < kPool && rc == 0) { chosen[n++] = cand[c]; used[c] = true; }      // fewer hardware queues than lanes: share
     for (int c = 0; c < NC; ++c) if (!used[c]) (void)hipStreamDestroy(cand[c]);
     (void)hipStreamDestroy(gate);
     for (auto& e : ev) (void)hipEventDestroy(e);
-    if (rc != 0) return rc;
-    for (int k = 0; k < kPool; ++k) g_pool.lane[k] = chosen[k];
+    return rc;
+}
+
+int pool_init(hipStream_t main) {
+    if (g_pool.ready) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) VX_FAIL(-1, "vx_tape: the lane streams cannot be chosen during a stream capture");
+    HIPQ(hipDeviceSynchronize(), "hipDeviceSynchronize");        // the spin measurements need a quiet device
+    hipStream_t best[kPool] = {};
+    int best_n = -1;
+    for (int attempt = 0; attempt < 3 && best_n < kPool; ++attempt) {
+        hipStream_t chosen[kPool] = {};
+        int nd = 0;
+        int rc = pool_attempt(chosen, &nd);
+        if (rc != 0) return rc;
+        if (nd > best_n) {
+            for (int k = 0; k < kPool; ++k) { if (best[k]) (void)hipStreamDestroy(best[k]); best[k] = chosen[k]; }
+            best_n = nd;
+        } else
+            for (int k = 0; k < kPool; ++k) if (chosen[k]) (void)hipStreamDestroy(chosen[k]);
+    }
+    g_pool.distinct = best_n;
+    for (int k = 0; k < kPool; ++k) g_pool.lane[k] = best[k];
     g_pool.ready = true;
     return 0;
 }
 }  // namespace
+
+extern "C" int vx_tape_lanes_distinct(void) { return g_pool.ready ? g_pool.distinct : -1; }      // how many lane streams were measured to overlap pairwise (-1: not chosen yet)
 
 extern "C" int vx_tape_lane_stream(void* any_stream, int lane, void** out) {
     VX_REQUIRE(out && lane >= 0, "vx_tape_lane_stream: bad arguments");
