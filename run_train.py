@@ -33,7 +33,8 @@ if __name__ == "__main__":
     parser.add_argument("--augment", action="store_true", help="synthetic whole cases through the GPU transform chain (crop foreground, pos/neg crop, z-rotation) instead of ready-made patches")
     parser.add_argument("--data_module", type=str, default=None, help="python module with build_loaders(args, train_config, model_config)")
     parser.add_argument("--save_path", type=str, default=None, help="checkpoint directory (default ./checkpoints/<date>_<dataset>)")
-    parser.add_argument("--graph", action="store_true", dest="use_graph", help="per-stage hipGraph replay instead of eager launches")
+    parser.add_argument("--graph", action="store_true", dest="use_graph", help="capture the training step once and replay it as a launch tape (csrc/tape.hip: ~2 ms of host time per step instead of ~10 ms; falls back to eager launches if the capture cannot be verified)")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16 = opt-in mode: bf16 MFMA operands (fp32 accumulate, fp32 storage) in the patch-expand layers")
     args = parser.parse_args()
     with open(args.train_config, "r", encoding="utf-8") as f:
         train_config = json.load(f)

@@ -47,6 +47,24 @@ def test_run_train_synthetic_checkpoints_and_resume(tmp_path):
     assert len(h3["dice"]) == 1 and 0.0 <= h3["dice"][0] <= 1.0
 
 
+def test_run_train_with_launch_tapes_tracks_the_eager_harness(tmp_path):
+    """run_train --graph: the step replayed as launch tapes (static buffers, LR from the scheduler through the state carrier, per-step metrics read
+    from the engine's static outputs) gives the loss / Dice history of the eager harness"""
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.utils.train_loop import run_train
+    cfg, _ = CASES["g2_32_m2"]
+    tc = dict(TRAIN_CFG, epochs=2)
+    hist = {}
+    for tape in (False, True):
+        VF.reset_dropout_sites()
+        torch.manual_seed(12345)
+        hist[tape] = run_train(_args(use_graph=tape), tc, {"VeloxSeg": cfg})
+    for k in ("loss", "dice"):
+        for a, b in zip(hist[True][k], hist[False][k]):
+            assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), (k, hist[True][k], hist[False][k])
+    assert hist[True]["lr"] == hist[False]["lr"]
+
+
 def test_fused_adamw_through_the_carrier_equals_torch_adamw():
     from veloxseg_amd.engine import TrainEngine
     from veloxseg_amd.model.VeloxSeg import VeloxSeg
