@@ -151,6 +151,17 @@ class Encoder(nn.Module):
         for i in range(4):
             if i > 0 and self._on_level_inputs is not None and self.training:
                 self._on_level_inputs(i + 1, list(cur_feats) + [prev])       # level i+1 consumes the merged tokens and the conv feature of level i
+            # the strided DownConv of this level only needs the previous conv feature: it is queued on the conv-chain stream BEFORE that stream waits for
+            # the transformer level, so it overlaps PWA level i; and because the mixer is then the LAST node of the pair in the forward order, autograd
+            # runs its backward FIRST -- the attention gradients leave the conv chain before the DownConv's input / weight gradients are computed
+            if side is not None:
+                ctx = torch.cuda.stream(side)
+                ctx.__enter__()
+            try:
+                d_raw = getattr(self.encoder_conv, f"down{i + 1}").raw(prev)
+            finally:
+                if side is not None:
+                    ctx.__exit__(None, None, None)
             a_i, cur_feats = ta.layers[i](cur_feats)
             attn.append(a_i)
             if side is not None:
@@ -161,7 +172,6 @@ class Encoder(nn.Module):
                 ctx.__enter__()
             try:
                 a_raw = self._mix(i, a_i)
-                d_raw = getattr(self.encoder_conv, f"down{i + 1}").raw(prev)
                 fused = VF.instnorm_sum([d_raw, a_raw])                  # IN(down) + IN(mix)  (Encoder.py:351-360)
                 prev = getattr(self.encoder_conv, f"layer{i + 1}")(fused)
             finally:
