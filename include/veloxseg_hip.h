@@ -358,6 +358,11 @@ int vx_tape_build(void* hip_graph, int max_lanes, VxTape** out);
 int vx_tape_info(const VxTape* tape, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events);
 int vx_tape_replay(VxTape* tape, void* stream);
 int vx_tape_free(VxTape* tape);
+/* markers: vx_tape_mark(id, stream) inside the captured code; the tape records an event at that point of its schedule instead of launching anything,
+ * vx_tape_wait_marker makes `stream` wait for it (after vx_tape_replay has been called for this step).  vx_tape_has_marker: 1 / 0. */
+int vx_tape_mark(int id, void* stream);
+int vx_tape_wait_marker(VxTape* tape, int id, void* stream);
+int vx_tape_has_marker(const VxTape* tape, int id);
 /* introspection: stand-alone time of every node (launch order, microseconds, minimum over reps; the nodes run one at a time, so the values
  * computed are those of a replay), and the layout of the tape: lane, workgroups, up to 4 cross-lane waits (-1 padded) and the kernel name per node */
 int vx_tape_profile(VxTape* tape, void* stream, int reps, float* us);

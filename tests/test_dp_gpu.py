@@ -50,14 +50,18 @@ def _worker(rank, world, port, out_dir, use_graph, backend="gloo"):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
-    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True)
+    # (a bucket floor of 16 KB so that this small model gets one bucket per encoder level, as the 128^3 models do at the default 1 MB)
+    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True, bucket_min_bytes=1 << 14)
     assert eng.world == 2 and eng.overlap
     loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
     torch.cuda.synchronize()
-    if not use_graph:      # the bucketed all-reduces of one step tile the flat gradient buffer exactly once (tail first)
-        cover = sorted(eng._reduced)
-        assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
-        assert [r[1] for r in eng._reduced] == sorted((r[1] for r in eng._reduced), reverse=True), ("buckets must be reduced tail first", eng._reduced)
+    # the bucketed all-reduces of one step tile the flat gradient buffer exactly once (tail first): eager = multi-grad hooks inside backward(),
+    # tape = markers recorded by the encoder-backward tape (engine._mark) that the communication stream waits for
+    assert eng.use_graph == use_graph
+    cover = sorted(eng._reduced)
+    assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
+    assert [r[1] for r in eng._reduced] == sorted((r[1] for r in eng._reduced), reverse=True), ("buckets must be reduced tail first", eng._reduced)
+    assert len(eng._reduced) >= 3, ("expected the decoder bucket and at least two encoder buckets", eng._reduced, eng.flat.plan(1 << 14))
     if rank == 0:      # flat.grad now holds the SUM over ranks (AdamW applies the 1/world scale)
         torch.save({"grad": (eng.flat.grad / world).cpu(), "param": eng.flat.param.cpu(), "loss": float(loss), "plan": eng.flat.plan()}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()

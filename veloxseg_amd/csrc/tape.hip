@@ -23,6 +23,7 @@ enum { T_KERNEL = 0, T_MEMSET = 1, T_COPY = 2 };
 struct TapeNode {
     int type = T_KERNEL;
     int lane = 0;
+    int marker = -1;                    // >= 0: a vx_tape_mark(id) node -- not launched, an event is recorded in its place
     int mode = 0;                       // kernels: 0 = undecided, 1 = hipLaunchKernel (host stub), 2 = hipModuleLaunchKernel (hipFunction_t)
     hipKernelNodeParams k{};
     hipMemsetParams ms{};
@@ -147,6 +148,17 @@ int pool_init(hipStream_t main) {
 }
 }  // namespace
 
+// A marker is a captured no-op kernel that carries an id.  The tape does not launch it: at its place in the schedule (after every node it depends on)
+// it records an event on its lane, which another stream (the communication stream of a data-parallel step) can wait for while the rest of
+// the tape is still running: "bucket `id` of the flat gradient is complete from here on".
+__global__ void vx_tape_marker_k(int id) { (void)id; }
+extern "C" int vx_tape_mark(int id, void* stream) {
+    VX_REQUIRE(id >= 0, "vx_tape_mark: id must be >= 0");
+    hipLaunchKernelGGL(vx_tape_marker_k, dim3(1), dim3(1), 0, (hipStream_t)stream, id);
+    VX_LAUNCH_CHECK("vx_tape_mark");
+    return 0;
+}
+
 extern "C" int vx_tape_lanes_distinct(void) { return g_pool.ready ? g_pool.distinct : -1; }      // how many lane streams were measured to overlap pairwise (-1: not chosen yet)
 
 extern "C" int vx_tape_lane_stream(void* any_stream, int lane, void** out) {
@@ -187,6 +199,8 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
             kind[i] = T_KERNEL;
             HIPQ(hipGraphKernelNodeGetParams(gn[i], &raw[i].k), "hipGraphKernelNodeGetParams");
             VX_REQUIRE(raw[i].k.func != nullptr, "vx_tape_build: kernel node without a function");
+            if (raw[i].k.func == reinterpret_cast<void*>(&vx_tape_marker_k) && raw[i].k.kernelParams && raw[i].k.kernelParams[0])
+                raw[i].marker = *reinterpret_cast<const int*>(raw[i].k.kernelParams[0]);
         } else if (t == hipGraphNodeTypeMemset) {
             kind[i] = T_MEMSET;
             HIPQ(hipGraphMemsetNodeGetParams(gn[i], &raw[i].ms), "hipGraphMemsetNodeGetParams");
@@ -289,7 +303,7 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
     for (size_t l = 0; l < tail.size(); ++l) HIPQ(hipEventCreateWithFlags(&T->lane_end[l], hipEventDisableTiming), "hipEventCreateWithFlags");
     HIPQ(hipEventCreateWithFlags(&T->start, hipEventDisableTiming), "hipEventCreateWithFlags");
     for (auto& nd : T->nodes)
-        if (nd.record) { HIPQ(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming), "hipEventCreateWithFlags"); T->n_events++; }
+        if (nd.record || nd.marker >= 0) { HIPQ(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming), "hipEventCreateWithFlags"); T->n_events++; }
     *out = T;
     return 0;
 }
@@ -344,8 +358,8 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
     for (TapeNode& nd : T->nodes) {
         hipStream_t s = T->lanes[nd.lane];
         for (int w : nd.waits) HIPQ(hipStreamWaitEvent(s, T->nodes[w].ev, 0), "hipStreamWaitEvent");
-        { int rc = tape_launch(nd, s); if (rc) return rc; }
-        if (nd.record) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
+        if (nd.marker < 0) { int rc = tape_launch(nd, s); if (rc) return rc; }
+        if (nd.record || nd.marker >= 0) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
     }
     if (L > 1)
         for (size_t l = 0; l < L; ++l)
@@ -353,6 +367,19 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
                 HIPQ(hipEventRecord(T->lane_end[l], T->lanes[l]), "hipEventRecord");
                 HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");
             }
+    return 0;
+}
+
+extern "C" int vx_tape_wait_marker(VxTape* T, int id, void* stream) {
+    VX_REQUIRE(T && id >= 0, "vx_tape_wait_marker: bad arguments");
+    for (TapeNode& nd : T->nodes)
+        if (nd.marker == id) { HIPQ(hipStreamWaitEvent((hipStream_t)stream, nd.ev, 0), "hipStreamWaitEvent"); return 0; }
+    VX_FAIL(-1, "vx_tape_wait_marker: the tape holds no marker %d", id);
+}
+
+extern "C" int vx_tape_has_marker(const VxTape* T, int id) {      // answer, not a status
+    if (!T) return 0;
+    for (const TapeNode& nd : T->nodes) if (nd.marker == id) return 1;
     return 0;
 }
 

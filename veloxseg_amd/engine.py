@@ -144,10 +144,11 @@ class TrainEngine:
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
-                 replay="tape", tape_lanes=6, precision="fp32"):
+                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20):
         self.model, self.criterion = model, criterion
         VF.set_precision(precision)            # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision); process-wide
         self.precision = precision
+        self.bucket_min_bytes = int(bucket_min_bytes)      # all-reduce buckets below this size are merged into the next one (latency-bound collectives)
         if hasattr(model, "ds_fused"):
             model.ds_fused = bool(fuse_ds)      # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip)
         self.dev = next(model.parameters()).device
@@ -223,7 +224,7 @@ class TrainEngine:
         0.65 MB of the 9.2 MB payload) is reduced after backward().  No staging, no detached leaves."""
         self.flat.zero_grad()
         handles = []
-        plan = self.flat.plan()
+        plan = self.flat.plan(self.bucket_min_bytes)
         self._reduced = []
         by_trigger = {t: (lo, hi) for t, lo, hi in plan}
         fired = set()
@@ -279,8 +280,47 @@ class TrainEngine:
     def _s_enc_fwd(self):
         self.flat.zero_grad()
         VF.advance_rng(self.dev)
-        attn, encs = self.model.encoder(self.x)
+        self._drop_level_hooks()
+        if self._mark_levels():
+            # data-parallel tape: a marker where the gradients of a level's inputs are complete (multi-grad hooks, as in the eager overlapped step);
+            # the encoder-backward tape records an event there and the bucket of that level is all-reduced while the lower levels still run
+            by_trigger = {t: (lo, hi) for t, lo, hi in self.flat.plan(self.bucket_min_bytes)}
+
+            def on_level(level, tensors):
+                trig = level - 1
+                ts = [t for t in tensors if t.requires_grad]
+                if trig in by_trigger and trig != 4 and ts:
+                    self._level_hooks.append(torch.autograd.graph.register_multi_grad_hook(ts, lambda _g, trig=trig: self._mark(trig), mode="all"))
+            self.model.encoder._on_level_inputs = on_level
+        try:
+            attn, encs = self.model.encoder(self.x)
+        finally:
+            self.model.encoder._on_level_inputs = None
         self._boundary = list(encs) + [t for lvl in attn for t in lvl]
+
+    def _mark_levels(self):
+        return self.use_graph and self.replay_mode == "tape" and ((self.world > 1 and self.overlap) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
+
+    def _drop_level_hooks(self):
+        for h in getattr(self, "_level_hooks", []):
+            h.remove()
+        self._level_hooks = []
+
+    def _mark(self, trig):
+        """(inside the encoder backward, on autograd's device thread) everything queued so far on the forked streams joins the STAGE's stream, then
+        the marker goes there.  Not the thread's current stream: in the hook that is the NULL stream, and touching it during a capture kills the capture."""
+        st = self._stage_stream
+        with torch.cuda.stream(st):
+            capturing = torch.cuda.is_current_stream_capturing()
+        for s_ in VF.all_side_streams(self.dev):
+            if s_.cuda_stream == st.cuda_stream:
+                continue
+            if capturing:
+                with torch.cuda.stream(s_):
+                    if not torch.cuda.is_current_stream_capturing():
+                        continue                    # not part of this capture: nothing of this stage runs there
+            st.wait_stream(s_)
+        H.call("vx_tape_mark", int(trig), st.cuda_stream)
 
     def _s_dec_fwd(self, k):
         # every branch gets its own leaves (same storage, separate .grad), so concurrent branches never accumulate into one tensor
@@ -329,8 +369,12 @@ class TrainEngine:
                 bt.append(t)
                 groups.append(gs)
         bg = self._sum_groups(groups)
-        with self._wgrad_side():
-            torch.autograd.backward(bt, bg)
+        self._stage_stream = torch.cuda.current_stream(self.dev)
+        try:
+            with self._wgrad_side():
+                torch.autograd.backward(bt, bg)
+        finally:
+            self._drop_level_hooks()
 
     def _sum_groups(self, groups):
         """[g0 (+ g1 (+ g2))] per boundary tensor: the per-branch gradients of one tensor summed; all the 2- and 3-term sums in ONE launch (vx_add_many)"""
@@ -533,6 +577,8 @@ class TrainEngine:
         G["loss"].replay()
         self._fan(G["dec_bwd"])
         split, n = self.flat.split, self.flat.numel
+        if comm:
+            self._reduced = []
         if comm and self.overlap:
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
@@ -540,9 +586,21 @@ class TrainEngine:
         G["enc_bwd"].replay()
         if comm and self.world > 1:
             if self.overlap:
-                self.comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self.comm_stream):
-                    self._allreduce(0, split)               # encoder bucket
+                tape = G["enc_bwd"] if self.replay_mode == "tape" else None
+                done = split
+                for trig, lo, hi in self.flat.plan(self.bucket_min_bytes):       # tail first: (decoders), level 4, level 3, ...
+                    if trig == 4 or hi > done:
+                        continue
+                    if tape is not None and H.query("vx_tape_has_marker", tape.handle, int(trig)):
+                        # the tape recorded an event where this level's gradients were complete: reduce the bucket while the lower levels still run
+                        H.call("vx_tape_wait_marker", tape.handle, int(trig), self.comm_stream.cuda_stream)
+                        with torch.cuda.stream(self.comm_stream):
+                            self._allreduce(lo, hi)
+                        done = lo
+                if done > 0:
+                    self.comm_stream.wait_stream(cur)
+                    with torch.cuda.stream(self.comm_stream):
+                        self._allreduce(0, done)            # what has no marker (always levels 1-2)
                 cur.wait_stream(self.comm_stream)
             else:
                 self._allreduce(0, n)

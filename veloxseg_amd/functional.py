@@ -204,7 +204,8 @@ _CPP_DEFAULTS = None
 
 
 def cpp_module(reload: bool = False):
-    """veloxseg_amd._vxops (csrc/_vxops.cpp, built by __graft_entry__.build) or None: then the python bodies below run (same kernels)."""
+    """veloxseg_amd._vxops (csrc/_vxops.cpp, built by __graft_entry__.build); None only when VELOXSEG_NO_CPP=1 selects the python operator bodies
+    (same kernels) on purpose; a module that is missing or does not import raises"""
     if reload:
         _CPP[0] = False
     if not _CPP[0]:
@@ -218,8 +219,12 @@ def cpp_module(reload: bool = False):
                 _vxops.set_fuse_pw_bwd(os.environ.get("VELOXSEG_FUSE_PW_BWD", "1") != "0")
                 _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
                 _CPP[1] = _vxops
-            except ImportError:
-                _CPP[1] = None
+            except ImportError as e:
+                # the C++ operator path IS the product path; the python bodies below are its A/B twin and are only taken when asked for
+                # (VELOXSEG_NO_CPP=1).  A build that lost _vxops must not silently change which host code runs.
+                raise RuntimeError("veloxseg_amd: the C++ operator module veloxseg_amd._vxops cannot be imported (" + str(e)[:200] + "); build it with "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`, or set VELOXSEG_NO_CPP=1 to run the python operator bodies "
+                                   "(same HIP kernels) on purpose") from e
     return _CPP[1]
 
 
