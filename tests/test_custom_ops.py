@@ -1,0 +1,67 @@
+"""torch.ops.veloxseg.* (veloxseg_amd/ops.py): the operators are registered dispatcher ops; on CPU they fail loudly (no fallback); on the GPU they
+are the operators of veloxseg_amd.functional (same values, same gradients)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_ops_are_registered_and_have_no_cpu_kernel():
+    import veloxseg_amd.ops as O
+    for name in O.OPS:
+        op = getattr(torch.ops.veloxseg, name)
+        assert op.default._schema.name == f"veloxseg::{name}"
+    with pytest.raises(RuntimeError, match="MI355X"):
+        torch.ops.veloxseg.gram(torch.randn(1, 4, 4, 4, 4))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        torch.ops.veloxseg.conv3d(torch.randn(1, 4, 4, 4, 4), torch.randn(4, 4, 1, 1, 1), None, 1, 0, 1, 1)
+
+
+@pytest.mark.gpu
+def test_ops_equal_the_functional_operators():
+    import veloxseg_amd.ops  # noqa: F401
+    from veloxseg_amd import functional as VF
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from oracle import veloxseg_oracle as Or
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(0)
+    x = torch.randn(2, 16, 8, 8, 8, device=d, generator=g)
+    w = torch.randn(16, 4, 3, 3, 3, device=d, generator=g) * 0.1
+    b = torch.randn(16, device=d, generator=g) * 0.1
+
+    def both(f_op, f_vf, tensors):
+        outs = []
+        for f in (f_op, f_vf):
+            ts = [t.clone().requires_grad_(True) for t in tensors]
+            y = f(*ts)
+            ys = list(y) if isinstance(y, (list, tuple)) else [y]
+            sum((o * o).sum() for o in ys).backward()
+            outs.append(([o.detach() for o in ys], [t.grad for t in ts]))
+        for a, r in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+            assert torch.allclose(a, r, rtol=1e-5, atol=1e-5 * float(r.abs().max()))
+
+    both(lambda x, w, b: torch.ops.veloxseg.conv3d(x, w, b, 1, 1, 4, 1), lambda x, w, b: VF.conv3d(x, w, b, stride=1, padding=1, groups=4), [x, w, b])
+    both(lambda a, c: torch.ops.veloxseg.instance_norm_sum([a, c], True, None), lambda a, c: VF.instnorm_sum([a, c], act=True), [x, x * 0.5 + 1.0])
+    gam, bet = torch.randn(16, device=d, generator=g), torch.randn(16, device=d, generator=g)
+    both(lambda x, ga, be: torch.ops.veloxseg.layer_norm_cf(x, ga, be), lambda x, ga, be: VF.layernorm_cf(x, ga, be), [x, gam, bet])
+    both(lambda x: torch.ops.veloxseg.gram(x), lambda x: VF.gram(x), [x])
+    both(lambda x: torch.ops.veloxseg.upsample_trilinear(x, [16, 16, 16]), lambda x: VF.upsample_trilinear(x, (16, 16, 16)), [x])
+    both(lambda x: torch.ops.veloxseg.space_to_depth2(x), lambda x: VF.space_to_depth2(x), [x])
+    # paired-window attention through the op (plan built from the integer lists) against the functional core
+    from veloxseg_amd import _hip as H
+    grid, heads = [8, 8, 8], 2
+    pl = Or.plan_pwa(grid, [4, 4, 4], [1, 1, 1], 2, heads, 8, 32)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    n = pl["n"]
+    table = torch.randn((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, device=d, generator=g) * 0.5
+    qkv = [torch.randn(2, pl["ch_qk"] if k < 2 else pl["ch_v"], *grid, device=d, generator=g) for k in range(3)]
+    flat = lambda ll: [int(v) for row in ll for v in row]
+    both(lambda t, q, k, v: torch.ops.veloxseg.pwa_attention(t, [q, k, v], grid, list(n), heads, flat(pl["small"]), flat(pl["nwin"]), pl["c_qk"], pl["c_v"], 0.0, 3),
+         lambda t, q, k, v: VF.pwa_core(t, plan, pl["c_qk"], pl["c_v"], [q, k, v], p_attn=0.0, site=3), [table] + qkv)
+    # loss
+    heads4 = [torch.randn(2, 2, 16, 16, 16, device=d, generator=g) for _ in range(2)]
+    lab = (torch.rand(2, 1, 16, 16, 16, device=d, generator=g) > 0.8).long()
+    both(lambda a, c: torch.ops.veloxseg.seg_loss([a, c], lab, None, [0.6, 0.4], 0.0, 0.0, 0), lambda a, c: VF.seg_only_loss([a, c], lab, [0.6, 0.4]), heads4)
