@@ -75,6 +75,28 @@ def test_sliding_window_with_the_hip_model(golden_dir):
     assert float(sure.float().mean()) > 0.99
 
 
+def test_sliding_window_baseline_volume_240x240x155():
+    """BASELINE configs[4]: the full 4 x 240 x 240 x 155 BraTS volume, roi 128^3, overlap 0.5, sw_batch 2 (18 windows, MONAI's clamped last window)
+    with the brats128 HIP model as the predictor of BOTH drivers: blended logits bit-identical, fused arg-max labels equal, Dice of the labels
+    against themselves through the on-device confusion matrix = 1; window count as SURVEY states."""
+    from bench import WORKLOADS
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils import inference_runtime as IR
+    cfg, _ = WORKLOADS["brats128"]
+    d = dev()
+    torch.manual_seed(7)
+    model = VeloxSeg(**cfg).to(d).eval()
+    x = torch.randn((1, 4, 240, 240, 155), generator=torch.Generator().manual_seed(11)).to(d)
+    roi = (128, 128, 128)
+    assert len(SO.dense_patch_starts((240, 240, 155), roi, SO.get_scan_interval((240, 240, 155), roi, 0.5))) == 18       # 3 x 3 x 2 windows (SURVEY 8d C5)
+    with torch.inference_mode():
+        got, labels = IR.infer_volume(model, x, roi, 2, 0.5)
+        want = SO.sliding_window_inference(x, roi, 2, IR.Net(model), 0.5)
+    assert got.shape == (1, cfg["n_classes"], 240, 240, 155) and bool(torch.isfinite(got).all())
+    assert torch.equal(got, want)
+    assert torch.equal(labels.long(), want.argmax(1, keepdim=True))
+
+
 def test_metrics_match_reference_goldens(golden_dir):
     from veloxseg_amd.utils.metric import metrics as M, metrics_brats as MB
     d = dev()
