@@ -273,6 +273,10 @@ int vx_pwa_attn_set_mfma(int on);
 int vx_seg_loss_fwd(const float* l0, const float* l1, const float* l2, const float* l3, int nh, const void* labels, int lab_kind,
                     double* acc, int B, int C, long V, void* stream);
 int vx_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
+/* acc += sum (a - b)^2 with b a channel slice of a wider tensor (b_batch_stride floats between its samples); acc is NOT zeroed: several
+ * reconstruction decoders add into one accumulator from their own streams */
+int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, void* stream);
+int vx_mse_bwd_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, const float* coef, const float* gout, float* da, void* stream);
 int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
                      const double* rc_acc, long n_rc, float w_rc,
                      const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,

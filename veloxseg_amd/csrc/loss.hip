@@ -529,6 +529,40 @@ extern "C" int vx_sqdiff_sum(const float* a, const float* b, long n, double* acc
     return 0;
 }
 
+// batch-strided forms for the staged loss (engine.TrainEngine, tape mode): every reconstruction decoder adds ITS sum of squares against its own
+// channels of the network input (a channel slice: b_batch_stride floats between samples) into the shared accumulator, inside its own branch
+__global__ void __launch_bounds__(256) vx_sqdiff_sum_bs_k(const float* __restrict__ a, const float* __restrict__ b, long n, long bstride, double* __restrict__ acc) {
+    const float* __restrict__ as = a + (long)blockIdx.y * n;
+    const float* __restrict__ bs = b + (long)blockIdx.y * bstride;
+    float s = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float d = as[i] - bs[i]; s = fmaf(d, d, s); }
+    __shared__ float red[4];
+    s = vx_block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)s);
+}
+extern "C" int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, void* stream) {
+    VX_REQUIRE(a && b && acc && n_per_sample > 0 && B > 0 && b_batch_stride >= n_per_sample, "vx_sqdiff_sum_bs: bad args");
+    int blocks = vx_cdiv(n_per_sample, 256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(vx_sqdiff_sum_bs_k, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, a, b, n_per_sample, b_batch_stride, acc);
+    VX_LAUNCH_CHECK("vx_sqdiff_sum_bs");
+    return 0;
+}
+__global__ void __launch_bounds__(256) vx_mse_bwd_bs_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ coef,
+                                                       const float* __restrict__ gout, float* __restrict__ da, long n, long bstride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const long o = (long)blockIdx.y * n + i;
+        da[o] = (gout ? gout[0] : 1.0f) * coef[0] * (a[o] - b[(long)blockIdx.y * bstride + i]);
+    }
+}
+extern "C" int vx_mse_bwd_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, const float* coef, const float* gout, float* da, void* stream) {
+    VX_REQUIRE(a && b && coef && da && n_per_sample > 0 && B > 0 && b_batch_stride >= n_per_sample, "vx_mse_bwd_bs: bad args");
+    hipLaunchKernelGGL(vx_mse_bwd_bs_k, dim3(vx_cdiv(n_per_sample, 256), B), dim3(256), 0, (hipStream_t)stream, a, b, coef, gout, da, n_per_sample, b_batch_stride);
+    VX_LAUNCH_CHECK("vx_mse_bwd_bs");
+    return 0;
+}
+
 extern "C" int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
                                 const double* rc_acc, long n_rc, float w_rc,
                                 const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,

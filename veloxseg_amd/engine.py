@@ -142,6 +142,19 @@ class LaunchTape:
 class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 
+    @property
+    def last_outputs(self):
+        """the training outputs of the last step in the reference's list layout (what per-step metrics read); with the staged loss the
+        reconstruction channels are concatenated only when somebody asks"""
+        if self._last_outputs is None and getattr(self, "_last_parts", None) is not None:
+            self._last_outputs = self.model.assemble_train(self._last_parts)
+        return self._last_outputs
+
+    @last_outputs.setter
+    def last_outputs(self, v):
+        self._last_outputs = v
+        self._last_parts = None
+
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
                  replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20):
@@ -167,6 +180,7 @@ class TrainEngine:
         if replay not in ("tape", "graph"):
             raise ValueError("replay must be 'tape' (csrc/tape.hip launches) or 'graph' (hipGraphLaunch)")
         self.replay_mode, self.tape_lanes = replay, int(tape_lanes)
+        self._setup_branch_loss()
         B = batch_shape[0]
         self.x = torch.zeros(batch_shape, device=self.dev, dtype=torch.float32)
         self.labels = torch.zeros((B, 1, *batch_shape[2:]), device=self.dev, dtype=label_dtype)
@@ -297,6 +311,17 @@ class TrainEngine:
         finally:
             self.model.encoder._on_level_inputs = None
         self._boundary = list(encs) + [t for lvl in attn for t in lvl]
+        if getattr(self, "_bl", None) is not None:
+            if self._bl == "pending":
+                self._bl = self.criterion.staged(self._n_ds_heads())
+            self._bl.begin(self.dev, self.x.shape[0], self._n_classes())
+            self._rc_c = [None] * self.model.num_branches
+
+    def _n_ds_heads(self):
+        return 4           # VeloxSeg.decode_branch(0) returns pred_0 .. pred_3 + the Gram matrix (VeloxSeg.py:199-221); checked in _s_dec_fwd
+
+    def _n_classes(self):
+        return int(getattr(self.model, "n_classes", 0) or self.model.decoder.n_classes)
 
     def _mark_levels(self):
         return self.use_graph and self.replay_mode == "tape" and ((self.world > 1 and self.overlap) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
@@ -330,12 +355,35 @@ class TrainEngine:
         attn = [flat_attn[L * M:(L + 1) * M] for L in range(4)]
         self._leaves[k] = leaves
         self._outs[k] = list(self.model.decode_branch(k, attn, encs))
+        bl = self._branch_loss()
+        if bl is not None:        # this branch's share of the loss forward, on this branch's stream (functional.StagedLoss)
+            if k == 0:
+                if bl.nh != len(self._outs[0]) - 1:
+                    raise RuntimeError("staged loss: unexpected number of deep-supervision heads")
+                bl.seg_forward([t.detach() for t in self._outs[0][:-1]], self.labels)
+            else:
+                self._rc_c[k] = bl.rc_forward(self._outs[k][0].detach(), self.x, self._ch_off[k - 1])
+
+    def _branch_loss(self):
+        """the loss taken apart into per-branch pieces (taped steps with the library's own Loss only; any other criterion runs as one call in _s_loss)"""
+        return getattr(self, "_bl", None)
+
+    def _setup_branch_loss(self):
+        from .utils.loss import Loss
+        self._bl = None
+        ok = (self.use_graph and self.replay_mode == "tape" and isinstance(self.criterion, Loss) and hasattr(self.model, "decode_branch")
+              and self.model.num_modalities >= 1 and os.environ.get("VELOXSEG_STAGED_LOSS", "1") != "0")
+        if ok:
+            in_ch = list(self.model.encoder.in_channels)
+            self._ch_off = [sum(in_ch[:m]) for m in range(len(in_ch))]
+            self._n_heads = None
+            self._bl = "pending"            # built at the first enc_fwd, when the number of heads is known from the decoder outputs
 
     @contextlib.contextmanager
     def _wgrad_side(self):
-        """Inside a taped stage the weight-gradient kernels go to a side stream (csrc/_vxops.cpp WgradSide): in the captured DAG they become a
-        branch of their own instead of links of the input-gradient chain, and the tape runs them on a lane beside it.  (Launched eagerly
-        the same deferral costs more host time than it saves: WGRAD_STREAM above.)"""
+        """Inside a taped stage the weight-gradient kernels can go to a side stream (csrc/_vxops.cpp WgradSide): in the captured DAG they become a
+        branch of their own instead of links of the input-gradient chain.  Off by default (VELOXSEG_TAPE_WGRAD_SIDE): the critical path gets
+        0.3 ms shorter and the step slower -- the big weight-gradient grids then take CUs from the chain."""
         m = VF.cpp_module() if (self.use_graph and self.replay_mode == "tape" and TAPE_WGRAD_SIDE) else None
         if m is None:
             yield
@@ -348,6 +396,14 @@ class TrainEngine:
             m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
 
     def _s_loss(self):
+        bl = self._branch_loss()
+        if bl is not None:
+            n_rc = sum(int(r.numel()) for r in self._rc_c[1:])
+            loss = bl.finalize(self._outs[0][-1].detach(), [self._outs[k][1].detach() for k in range(1, len(self._outs))], n_rc)
+            self._last_parts = [[o.detach() for o in outs] for outs in self._outs]
+            self._last_outputs = None
+            torch.add(loss, 0.0, out=self.loss)
+            return
         outs_d = [[o.detach().requires_grad_(True) for o in outs] for outs in self._outs]
         self.last_outputs = self.model.assemble_train(outs_d)      # detached leaves: what the per-step metrics read
         loss = self.criterion(self.last_outputs, self.labels, sr_labels=self.x)
@@ -357,6 +413,13 @@ class TrainEngine:
         torch.add(loss.detach(), 0.0, out=self.loss)      # a kernel, not hipMemcpyAsync: memcpy nodes cannot be read back into a launch tape
 
     def _s_dec_bwd(self, k):
+        bl = self._branch_loss()
+        if bl is not None:        # this branch's share of the loss backward, then its decoder
+            outs = self._outs[k]
+            grads = (bl.seg_backward() + [bl.dgs]) if k == 0 else [bl.rc_backward(self._rc_c[k], self.x, self._ch_off[k - 1]), bl.dgm[k - 1]]
+            with self._wgrad_side():
+                torch.autograd.backward(list(outs), grads)
+            return
         pairs = [(o, g) for o, g in zip(self._outs[k], self._douts[k]) if g is not None]
         with self._wgrad_side():
             torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
@@ -409,7 +472,7 @@ class TrainEngine:
         self._s_enc_fwd()
         VF.run_branches([(lambda k=k: self._s_dec_fwd(k)) for k in range(nb)], self.dev, uses=[self._boundary] * nb)
         self._s_loss()
-        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev, uses=[self._douts[k] for k in range(nb)])
+        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev, uses=[([] if self._branch_loss() is not None else self._douts[k]) for k in range(nb)])
         if between is not None:
             between()
         self._s_enc_bwd()

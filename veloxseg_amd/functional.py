@@ -1150,6 +1150,106 @@ class _VeloxLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
+class StagedLoss:
+    """The VeloxSeg loss (utils/loss.py:52-66) taken apart for the staged training step (engine.TrainEngine): the kernels of _VeloxLossFn, but
+    every decoder branch runs ITS part on its own stream -- the Seg branch the deep-supervision CE + Dice sums and, later, their gradients; each
+    reconstruction branch its sum of squares against its channels of the input and, later, its MSE gradient -- and only the one-wave `finalize`
+    (scalar loss, Dice coefficients, Gram term) sits between the forward and the backward fans.  Same arithmetic, same accumulators, same
+    coefficients as the fused autograd function; nothing here is differentiated by autograd (the gradients are handed to autograd.backward)."""
+
+    def __init__(self, head_weights, w_rc, w_f, num_modal):
+        self.head_weights, self.w_rc, self.w_f, self.M = tuple(float(w) for w in head_weights), float(w_rc), float(w_f), int(num_modal)
+        self.nh = len(self.head_weights)
+
+    def begin(self, dev, B, C):
+        """fresh accumulators (zero-filled here, i.e. before the forward fan: the branches only add)"""
+        self.B, self.C = B, C
+        self.seg_acc = torch.empty((self.nh * (1 + B * C * 3),), device=dev, dtype=torch.float64)      # (zeroed by the Seg branch's forward entry)
+        self.rc_acc = torch.zeros((1,), device=dev, dtype=torch.float64)
+        self.n_rc = 0
+        self.ds = None
+
+    def seg_forward(self, logits, labels):
+        logits = [_c(t) for t in logits]
+        _check(logits[0], "loss")
+        nh, B, C = self.nh, self.B, self.C
+        assert len(logits) == nh and logits[0].shape[0] == B and logits[0].shape[1] == C
+        if labels.dtype not in _LAB_KIND:
+            raise RuntimeError(f"labels must be int64/int32/uint8, got {labels.dtype}")
+        labels = _c(labels)
+        V = logits[0][0, 0].numel()
+        st = H.stream_ptr()
+        lp = [H.P(t) for t in logits] + [None] * (4 - nh)
+        if any(tuple(t.shape[2:]) != tuple(logits[0].shape[2:]) for t in logits[1:]):
+            D_, H_, W_ = (int(v) for v in logits[0].shape[2:])
+            if not H.query("vx_seg_loss_ds_ok", C, D_, H_, W_):
+                raise RuntimeError("veloxseg_loss: deep-supervision heads on coarser grids need C in 2..4 and W % 4 == 0 with W/4 dividing 64; up-sample them first")
+            dims = (H.ctypes.c_int * (3 * max(nh - 1, 1)))(*[int(v) for t in logits[1:] for v in t.shape[2:]])
+            self.ds = (dims, D_, H_, W_)
+            H.call("vx_seg_loss_ds_fwd", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(self.seg_acc, torch.float64), B, C, D_, H_, W_, st)
+        else:
+            H.call("vx_seg_loss_fwd", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(self.seg_acc, torch.float64), B, C, V, st)
+        self.logits, self.labels, self.V = logits, labels, V
+
+    @staticmethod
+    def _slice(x, ch_off, ch_n):
+        """(pointer, floats between samples) of channels [ch_off, ch_off + ch_n) of the contiguous (B, Cx, ...) input"""
+        Vx = x[0, 0].numel()
+        return x.data_ptr() + 4 * ch_off * Vx, x.shape[1] * Vx, ch_n * Vx
+
+    def rc_forward(self, rc, x, ch_off):
+        rc = _c(rc)
+        ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
+        assert rc[0].numel() == n and x.is_contiguous()
+        H.call("vx_sqdiff_sum_bs", H.P(rc), ptr, n, bstride, rc.shape[0], H.P(self.rc_acc, torch.float64), H.stream_ptr())
+        return rc
+
+    def finalize(self, gram_seg, grams_rc, n_rc):
+        """-> scalar loss (device tensor); keeps the coefficients and the Gram gradients for the backward fans"""
+        dev = self.seg_acc.device
+        nh, B, C, M = self.nh, self.B, self.C, self.M
+        st = H.stream_ptr()
+        hw = _head_weights(self.head_weights, dev)
+        self.coef = torch.empty((nh * (1 + B * C * 2) + 2,), device=dev, dtype=torch.float32)
+        loss = torch.empty((1,), device=dev, dtype=torch.float32)
+        gs = _c(gram_seg)
+        gm = [_c(g) for g in grams_rc]
+        gp = [H.P(g) for g in gm] + [None] * (4 - M)
+        H.call("vx_loss_finalize", H.P(self.seg_acc, torch.float64), nh, B, C, self.V, H.P(hw), H.P(self.rc_acc, torch.float64), int(n_rc), self.w_rc,
+               H.P(gs), *gp, M, gs.shape[1], self.w_f, H.P(loss), H.P(self.coef), st)
+        stride = (1 + B * C * 2) * 4
+        self.misc = self.coef.data_ptr() + nh * stride
+        self.dgs = torch.empty_like(gs)
+        self.dgm = [torch.empty_like(g) for g in gm]
+        dp = [H.P(g) for g in self.dgm] + [None] * (4 - M)
+        H.call("vx_gram_mse_bwd", H.P(gs), *gp, M, self.misc + 4, None, H.P(self.dgs), *dp, gs.numel(), st)
+        return loss.view(())
+
+    def seg_backward(self):
+        nh, B, C = self.nh, self.B, self.C
+        logits, labels = self.logits, self.labels
+        st = H.stream_ptr()
+        stride = (1 + B * C * 2) * 4
+        grads = [torch.empty_like(t) for t in logits]
+        lp = [H.P(t) for t in logits] + [None] * (4 - nh)
+        gp = [H.P(d) for d in grads] + [None] * (4 - nh)
+        if self.ds is not None:
+            dims, D_, H_, W_ = self.ds
+            nws = H.query("vx_seg_loss_ds_ws_floats", H.ctypes.addressof(dims), nh, B, C, D_)
+            ws = torch.empty((max(nws, 1),), device=grads[0].device, dtype=torch.float32)
+            H.call("vx_seg_loss_ds_bwd", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], self.coef.data_ptr(), stride // 4, None, *gp,
+                   H.P(ws), B, C, D_, H_, W_, st)
+        else:
+            H.call("vx_seg_loss_bwd4", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], self.coef.data_ptr(), stride // 4, None, *gp, B, C, self.V, st)
+        return grads
+
+    def rc_backward(self, rc, x, ch_off):
+        ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
+        drc = torch.empty_like(rc)
+        H.call("vx_mse_bwd_bs", H.P(rc), ptr, n, bstride, rc.shape[0], self.misc, None, H.P(drc), H.stream_ptr())
+        return drc
+
+
 def veloxseg_loss(outputs: Sequence[torch.Tensor], labels: torch.Tensor, sr_labels: Optional[torch.Tensor], head_weights: Sequence[float],
                   w_rc: float, w_f: float, num_modal: int) -> torch.Tensor:
     """outputs = nh logits [+ rcs, G_seg, G_rc x M]."""

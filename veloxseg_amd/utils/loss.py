@@ -28,5 +28,9 @@ class Loss(nn.Module):
         w = normalized_deep_loss_weights(self._deep_w, b - a)
         return VF.veloxseg_loss(list(output), labels, sr_labels, w, self.rc_loss_weight, self.feature_loss_weight, self.num_modal)
 
+    def staged(self, n_heads):
+        """the same loss as separable pieces for the staged training step (functional.StagedLoss): head weights, w_rc, w_f, M"""
+        return VF.StagedLoss(normalized_deep_loss_weights(self._deep_w, n_heads), self.rc_loss_weight, self.feature_loss_weight, self.num_modal)
+
     def forward(self, output, labels, sr_labels=None):
         return self.cal_loss(output, labels, sr_labels)
