@@ -676,7 +676,7 @@ def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big,
             assert torch.equal(a, b), f"output {i} differs between the gather forms"
         else:                    # the attention backward in between accumulates with float atomics: equal routing, summation-order noise
             assert torch.equal(a == 0, b == 0), f"gradient {i}: different arg-max routing"
-            close(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, f"gradient {i}")
+            close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 1e-4, f"gradient {i}")      # (2e-5 of the maximum is seen run to run with EITHER form)
 
 
 @pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32)], ids=["c2", "c4_aniso", "c3"])
