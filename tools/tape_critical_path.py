@@ -19,7 +19,7 @@ torch.manual_seed(12345)
 model = VeloxSeg(**cfg).cuda()
 crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
 x, lab = synth(cfg, B, "cuda", 12345)
-eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=True, overlap=False)
+eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=True, overlap=False, precision=os.environ.get("VX_PRECISION", "fp32"))
 for _ in range(3):
     eng.step(x, lab)
 torch.cuda.synchronize()

@@ -461,10 +461,10 @@ extern "C" int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* 
 // ======================================================================================================================================
 typedef __bf16 vx_bf8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t vx_pack_bf16(float a, float b) {            // (a -> low half, b -> high half), round to nearest even
-    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32, which keeps a NaN a NaN (the integer rounding trick turns some NaNs into 0 or infinity)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ vx_bf8 vx_as_bf8(uint4 v) { return __builtin_bit_cast(vx_bf8, v); }
 
