@@ -119,6 +119,12 @@ def test_entrypoints_run_with_the_reference_command_line(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["epochs"] == 2 and os.path.exists(tmp_path / "ck" / "train_best.pth")
+    # the same command with the step replayed as launch tapes and the bf16 opt-in mode (flags of this library, not of the reference)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "run_train.py"), "--dataset_name", "AutoPETII", "--model_name", "VeloxSeg", "--train_config", str(tc),
+                         "--model_config", str(mc), "--synthetic", "2", "--save_path", str(tmp_path / "ck2"), "--graph", "--precision", "bf16"],
+                        capture_output=True, text=True, env=env, timeout=500)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert json.loads(r2.stdout.strip().splitlines()[-1])["epochs"] == 2 and "falling back" not in r2.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "run_test.py"), "--dataset_name", "AutoPETII", "--model_name", "VeloxSeg", "--train_config", str(tc),
                         "--model_config", str(mc), "--test_config", str(te), "--checkpoint_dir", str(tmp_path / "ck"), "--checkpoint_index", "train_best",
                         "--synthetic", "1", "--volume_shape", "48", "40", "36", "--out_csv", str(tmp_path / "res.csv")], capture_output=True, text=True, env=env, timeout=500)
