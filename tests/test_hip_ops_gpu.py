@@ -471,9 +471,11 @@ def test_pw_conv_bwd_fused_equals_two_launches(B, Cin, Cout, V, C1):
             assert float(got_db.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("grid,big,heads,c", [([16, 16, 16], [8, 8, 8], 2, 8), ([16, 16, 16], [4, 4, 4], 1, 16), ([8, 8, 8], [4, 4, 4], 4, 32)])
+@pytest.mark.parametrize("grid,big,heads,c", [([16, 16, 16], [8, 8, 8], 2, 8), ([16, 16, 16], [4, 4, 4], 1, 16), ([8, 8, 8], [4, 4, 4], 4, 32),
+                                              ([32, 32, 32], [4, 4, 4], 1, 4), ([32, 32, 32], [4, 4, 4], 2, 8)])
 def test_scatter_adjoint_transpose_kernel_equals_general_adjoint(grid, big, heads, c):
-    """1x1x1 small windows: the LDS-transpose adjoint of window_scattering_3d writes exactly what the general (LDS-atomic) adjoint accumulates"""
+    """the specialised adjoints of window_scattering_3d -- LDS transpose (1x1x1 small windows), parallel gather (cells up to 4^3), separable
+    reductions (wider cells: the coarse scale of the 32^3 level) -- write exactly what the general (LDS-atomic) adjoint accumulates"""
     from veloxseg_amd import _hip as H
     d = dev()
     pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, c, heads * c * 2)

@@ -437,6 +437,79 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(const float* 
     }
 }
 
+
+// Large small-windows (cells wider than 4: the coarse scale of the 32^3 level has 8^3-voxel cells, one window = the whole volume): the adjoint as three
+// separable 1-D reductions.  One block = (window, b * head, channel, chunk of ZC planes of the window's voxel box).  Per plane: stage it in LDS
+// (coalesced), reduce along W with the axis' tap weights (thread = (row, coarse column)), then along H (thread = (coarse row, coarse column)) and
+// add the plane's n1 x n2 result into the block's n0 x n1 x n2 accumulator with the two D weights of that plane; one float atomic per token
+// element and block at the end.  Replaces 8 scattered ds_add_f32 per voxel of vx_pwa_scatter_bwd_k (58 us per launch there) by plain LDS reads.
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale, int ZC) {
+    extern __shared__ __attribute__((aligned(16))) float vx_sacc[];
+    const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
+    const int i = scale;
+    const int cc = blockIdx.z % c, zc = blockIdx.z / c;
+    const int Nl = blockIdx.x, N = P.woff[i] + Nl;
+    const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
+    const int bw0 = n0 * P.small[i][0], bw1 = n1 * P.small[i][1], bw2 = n2 * P.small[i][2];
+    float* __restrict__ plane = vx_sacc;                        // [bw1][bw2]
+    float* __restrict__ tmp = plane + bw1 * bw2;                // [bw1][n2]
+    float* __restrict__ acc = tmp + bw1 * n2;                   // [n0][n1][n2]
+    float* __restrict__ A2 = acc + n0 * n1 * n2;                // [n2][bw2]  weight of fine column j2 for coarse column t2
+    float* __restrict__ A1 = A2 + n2 * bw2;                     // [n1][bw1]
+    for (int e = threadIdx.x; e < n2 * bw2; e += 256) {
+        const int t = e / bw2, j = e - t * bw2;
+        int i0, i1; float lam;
+        vx_src_coord(j, n2, bw2, i0, i1, lam);
+        A2[e] = (i0 == t ? 1.0f - lam : 0.0f) + (i1 == t ? lam : 0.0f);
+    }
+    for (int e = threadIdx.x; e < n1 * bw1; e += 256) {
+        const int t = e / bw1, j = e - t * bw1;
+        int i0, i1; float lam;
+        vx_src_coord(j, n1, bw1, i0, i1, lam);
+        A1[e] = (i0 == t ? 1.0f - lam : 0.0f) + (i1 == t ? lam : 0.0f);
+    }
+    for (int e = threadIdx.x; e < n0 * n1 * n2; e += 256) acc[e] = 0.0f;
+    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c + cc) * V;
+    const int jz0 = zc * ZC, jz1 = min(bw0, jz0 + ZC);
+    for (int j0 = jz0; j0 < jz1; ++j0) {
+        __syncthreads();
+        const float* __restrict__ src = db + ((long)(W0 * bw0 + j0) * P.grid[1] + W1 * bw1) * P.grid[2] + W2 * bw2;
+        for (int e = threadIdx.x; e < bw1 * bw2; e += 256) {
+            const int j1 = e / bw2, j2 = e - j1 * bw2;
+            plane[e] = src[(long)j1 * P.grid[2] + j2];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < bw1 * n2; e += 256) {      // along W
+            const int j1 = e / n2, t2 = e - j1 * n2;
+            const float* __restrict__ row = plane + j1 * bw2;
+            const float* __restrict__ w2 = A2 + t2 * bw2;
+            float s_ = 0.0f;
+            for (int j2 = 0; j2 < bw2; ++j2) s_ = fmaf(w2[j2], row[j2], s_);
+            tmp[e] = s_;
+        }
+        __syncthreads();
+        int t0a, t0b; float l0;
+        vx_src_coord(j0, n0, bw0, t0a, t0b, l0);
+        for (int e = threadIdx.x; e < n1 * n2; e += 256) {       // along H, then into the two coarse planes this fine plane touches
+            const int t1 = e / n2, t2 = e - t1 * n2;
+            const float* __restrict__ w1 = A1 + t1 * bw1;
+            float s_ = 0.0f;
+            for (int j1 = 0; j1 < bw1; ++j1) s_ = fmaf(w1[j1], tmp[j1 * n2 + t2], s_);
+            acc[(t0a * n1 + t1) * n2 + t2] += (1.0f - l0) * s_;      // each (t1, t2) is owned by one thread; planes are walked one after the other
+            if (t0b != t0a) acc[(t0b * n1 + t1) * n2 + t2] += l0 * s_;
+            else acc[(t0a * n1 + t1) * n2 + t2] += l0 * s_;
+        }
+    }
+    __syncthreads();
+    float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l) * c + cc;
+    for (int t = threadIdx.x; t < n0 * n1 * n2; t += 256) {
+        const float v = acc[t];
+        if (v != 0.0f) atomicAdd(dt + (long)t * c, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // attention
 // ---------------------------------------------------------------------------------------------
@@ -983,6 +1056,17 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
                 int PT = 256 / plan->l;                       // threads per token: power of two in 1..4
                 PT = PT >= 4 ? 4 : (PT >= 2 ? 2 : 1);
                 hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i, PT);
+                continue;
+            }
+        }
+        {
+            // cells wider than 4: separable adjoint (plane in LDS, W then H then D), ZC planes per block so that ~256+ blocks exist
+            const int bw0 = plan->n[0] * plan->small[i][0], bw1 = plan->n[1] * plan->small[i][1], bw2 = plan->n[2] * plan->small[i][2];
+            const size_t shm3 = sizeof(float) * ((size_t)bw1 * bw2 + (size_t)bw1 * plan->n[2] + (size_t)plane_l(plan) + (size_t)plan->n[2] * bw2 + (size_t)plan->n[1] * bw1);
+            if (vx_scatter_ident_enabled && shm3 <= 60 * 1024 && (long)B * plan->heads * c <= 65535) {
+                int ZC = bw0;
+                while (ZC > 1 && (long)nwin * B * plan->heads * c * vx_cdiv(bw0, ZC) < 256) ZC = (ZC + 1) / 2;
+                hipLaunchKernelGGL(vx_pwa_scatter_bwd_sep_k, dim3(nwin, B * plan->heads, c * vx_cdiv(bw0, ZC)), dim3(256), shm3, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i, ZC);
                 continue;
             }
         }
