@@ -1030,6 +1030,7 @@ extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan*
 }
 
 static int vx_scatter_ident_enabled = 1;
+static const int vx_scatter_gather_max = 2;      // cells up to 2^3: the per-token gather; wider cells: the separable kernel (4^3 cells measured 36 -> 17 us per launch)
 extern "C" int vx_pwa_scatter_set_ident(int on) { vx_scatter_ident_enabled = on ? 1 : 0; return 0; }      // A/B knob: 0 = always the general (LDS-atomic) adjoint
 extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
@@ -1052,7 +1053,7 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
                                                                     : (plan->small[i][1] > plan->small[i][2] ? plan->small[i][1] : plan->small[i][2]);
             const int nmax = plan->n[0] > plan->n[1] ? (plan->n[0] > plan->n[2] ? plan->n[0] : plan->n[2]) : (plan->n[1] > plan->n[2] ? plan->n[1] : plan->n[2]);
             const size_t shm2 = sizeof(float) * (((size_t)nv + 3) / 4 * 4 + (size_t)3 * nmax * VX_SC_TAPS * 2 + 3 * nmax);
-            if (smax <= 4 && shm2 <= 64 * 1024 && c <= 65535 && vx_scatter_ident_enabled) {      // <= 4x4x4: at most 5 + 4 taps per token and axis (VX_SC_TAPS = 12)
+            if (smax <= vx_scatter_gather_max && shm2 <= 64 * 1024 && c <= 65535 && vx_scatter_ident_enabled) {      // <= 4x4x4: at most 5 + 4 taps per token and axis (VX_SC_TAPS = 12)
                 int PT = 256 / plan->l;                       // threads per token: power of two in 1..4
                 PT = PT >= 4 ? 4 : (PT >= 2 ? 2 : 1);
                 hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i, PT);
