@@ -648,8 +648,8 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
                                                     ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 3)],
                          ids=["c8v8", "c8v16", "c16v32", "c4v8", "c4v4_M3"])
 def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big, heads, mdh, C, M):
-    """vx_pwa_gather_all_fwd / _bwd: the kernels that move 4 or 8 channels per lane (csrc/pwa.hip *_v_k) against the one-lane-per-channel kernels:
-    the pooled tokens (hence the outputs) are bit-identical and the gradients are routed to the same voxels (both take the first maximum of a cell)."""
+    """vx_pwa_gather_all_fwd / _bwd and vx_pwa_scatter_fwd: the kernels that move 4 or 8 channels per lane (csrc/pwa.hip *_v_k) against the one-lane-per-channel kernels:
+    the pooled tokens are the same (outputs equal to an ulp of the scatter's interpolation) and the gradients are routed to the same voxels (both take the first maximum of a cell)."""
     VF = _vf()
     from veloxseg_amd import _hip as H
     d = dev()
@@ -674,8 +674,8 @@ def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big,
     finally:
         H.call("vx_pwa_gather_set_vec", 1)
     for i, (a, b) in enumerate(zip(res[1], res[0])):
-        if i < M:
-            assert torch.equal(a, b), f"output {i} differs between the gather forms"
+        if i < M:        # same pooled tokens; the scatter forward's lerps are contracted differently by the two kernels (1 ulp)
+            close(a, b, 2e-6 * max(1.0, float(b.abs().max())), 2e-6, f"output {i}")
         else:                    # the attention backward in between accumulates with float atomics: equal routing, summation-order noise
             assert torch.equal(a == 0, b == 0), f"gradient {i}: different arg-max routing"
             close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 1e-4, f"gradient {i}")      # (2e-5 of the maximum is seen run to run with EITHER form)

@@ -310,6 +310,38 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restr
     out[((long)b * (P.nb * P.heads * c) + ch) * V + v] = val;
 }
 
+// the same with 4 channels per lane (c % 4 == 0): the 8 taps of a voxel are 8 float4 reads of whole token rows instead of 32 scalar reads at stride c
+__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __restrict__ tok, float* __restrict__ out, VxPwaPlan P, int c, int m, int M) {
+    const int c4 = c >> 2;
+    const int chq = blockIdx.y, b = blockIdx.z;                 // chq enumerates (scale i, head a, channel quad)
+    const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int i = chq / (P.heads * c4), a = (chq / c4) % P.heads, q4 = chq % c4;
+    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
+    const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
+    const int W0 = x0 / bw0, W1 = x1 / bw1, W2 = x2 / bw2;
+    int a0, b0, a1, b1, a2, b2;
+    float l0, l1, l2;
+    vx_src_coord(x0 % bw0, P.n[0], bw0, a0, b0, l0);
+    vx_src_coord(x1 % bw1, P.n[1], bw1, a1, b1, l1);
+    vx_src_coord(x2 % bw2, P.n[2], bw2, a2, b2, l2);
+    const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
+    const float* __restrict__ tw = tok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l) * c + 4 * q4;
+    auto T = [&](int t0, int t1, int t2) { return *reinterpret_cast<const float4*>(tw + (long)((t0 * P.n[1] + t1) * P.n[2] + t2) * c); };
+    const float k0 = 1.0f - l0, k1 = 1.0f - l1, k2 = 1.0f - l2;
+    const float4 t000 = T(a0, a1, a2), t001 = T(a0, a1, b2), t010 = T(a0, b1, a2), t011 = T(a0, b1, b2);
+    const float4 t100 = T(b0, a1, a2), t101 = T(b0, a1, b2), t110 = T(b0, b1, a2), t111 = T(b0, b1, b2);
+    // (the scalar kernel's nesting of the lerps, so that the values are bit-identical)
+#define VX_SCF(f) (k0 * (k1 * (k2 * t000.f + l2 * t001.f) + l1 * (k2 * t010.f + l2 * t011.f)) + l0 * (k1 * (k2 * t100.f + l2 * t101.f) + l1 * (k2 * t110.f + l2 * t111.f)))
+    float* __restrict__ ob = out + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c + 4 * q4) * V + v;
+    ob[0] = VX_SCF(x);
+    ob[V] = VX_SCF(y);
+    ob[2 * V] = VX_SCF(z);
+    ob[3 * V] = VX_SCF(w);
+#undef VX_SCF
+}
+
 // adjoint of the scatter: one block = (b, head, window, voxel chunk); the window's l x c token gradients are accumulated in LDS
 // (ds_add_f32) from the block's output voxels (8 corners each), then flushed with one float atomic per token element.
 __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale) {
@@ -955,6 +987,8 @@ static int vx_plan_check(const VxPwaPlan* P, const char* who) {
     return 0;
 }
 
+static int vx_gather_vec_enabled = 1;
+extern "C" int vx_pwa_gather_set_vec(int on) { vx_gather_vec_enabled = on ? 1 : 0; return 0; }      // A/B knob (tests): 0 = one lane per (cell / voxel, channel) in the gather and the scatter forward
 extern "C" int vx_pwa_gather_fwd(const float* src, float* tok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_gather_fwd")) return e;
     VX_REQUIRE(src && tok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_gather_fwd: bad args");
@@ -973,8 +1007,6 @@ extern "C" int vx_pwa_gather_bwd(const float* src, const float* dtok, float* dsr
     return 0;
 }
 
-static int vx_gather_vec_enabled = 1;
-extern "C" int vx_pwa_gather_set_vec(int on) { vx_gather_vec_enabled = on ? 1 : 0; return 0; }      // A/B knob (tests): 0 = one lane per (cell, channel)
 extern "C" int vx_pwa_gather_all_fwd(const float* const* srcs, float* tq, float* tk, float* tv, int* iq, int* ik, int* iv,
                                      const VxPwaPlan* plan, int cq, int cv, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_gather_all_fwd")) return e;
@@ -1024,7 +1056,10 @@ extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan*
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_fwd")) return e;
     VX_REQUIRE(tok && out && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_fwd: bad args");
     const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
-    hipLaunchKernelGGL(vx_pwa_scatter_fwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
+    if ((c & 3) == 0 && vx_gather_vec_enabled)
+        hipLaunchKernelGGL(vx_pwa_scatter_fwd_v_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * (c >> 2), B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
+    else
+        hipLaunchKernelGGL(vx_pwa_scatter_fwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
     VX_LAUNCH_CHECK("vx_pwa_scatter_fwd");
     return 0;
 }
