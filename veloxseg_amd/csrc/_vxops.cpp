@@ -671,11 +671,12 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         st.tbl = contig(table);
         VX(vx_pwa_attn_fwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), mp(st.O), mp(st.lse), pp, B, M, (int)cq, (int)cv, st.rs, (unsigned long long)site, (float)p_attn, s_);
         variable_list outs;
+        float* optr[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int m = 0; m < M; ++m) {
-            Tensor o = at::empty({B, (long)pp->nb * hd * cv, pp->grid[0], pp->grid[1], pp->grid[2]}, opt);
-            VX(vx_pwa_scatter_fwd, fp(st.O), mp(o), pp, (int)cv, m, M, B, s_);
-            outs.push_back(o);
+            outs.push_back(at::empty({B, (long)pp->nb * hd * cv, pp->grid[0], pp->grid[1], pp->grid[2]}, opt));
+            optr[m] = outs.back().data_ptr<float>();
         }
+        VX(vx_pwa_scatter_fwd_all, fp(st.O), optr, pp, (int)cv, M, B, s_);      // every modality in one launch
         return outs;
     }
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -688,10 +689,15 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         if (!ref.defined()) { ctx->saved_data.clear(); return out; }
         void* s_ = cur_stream(ref);
         Tensor dO = at::zeros_like(st.O);
-        for (int m = 0; m < M; ++m) {
-            if (!g[m].defined()) continue;
-            Tensor gm = contig(g[m]);
-            VX(vx_pwa_scatter_bwd, fp(gm), mp(dO), pp, st.cv, m, M, B, s_);
+        {
+            std::vector<Tensor> gm(M);
+            const float* gptr[4] = {nullptr, nullptr, nullptr, nullptr};
+            bool all = true;
+            for (int m = 0; m < M; ++m) { all = all && g[m].defined(); if (g[m].defined()) { gm[m] = contig(g[m]); gptr[m] = gm[m].data_ptr<float>(); } }
+            if (all) VX(vx_pwa_scatter_bwd_all, gptr, mp(dO), pp, st.cv, M, B, s_);       // every modality in one launch per scale
+            else
+                for (int m = 0; m < M; ++m)
+                    if (gptr[m]) VX(vx_pwa_scatter_bwd, gptr[m], mp(dO), pp, st.cv, m, M, B, s_);
         }
         Tensor dq = at::empty_like(st.tq), dk = at::empty_like(st.tk), dv = at::empty_like(st.tv);
         const int nws = vx_pwa_attn_bwd_ws_floats(pp, B, M);

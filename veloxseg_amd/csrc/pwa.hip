@@ -278,6 +278,9 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
 // ---------------------------------------------------------------------------------------------
 // scatter: per-window trilinear up-sampling (align_corners=True) of the n^3 window outputs
 // ---------------------------------------------------------------------------------------------
+// all M modalities of one direction in ONE launch: grid.x = (blocks of one modality) * M; block (mm, bx) works on modality m0 + mm with its own tensor
+struct VxScPtrs { const float* in[4]; float* out[4]; };
+
 __device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int& i1, float& lam) {
     if (bw == n) { i0 = j; i1 = j; lam = 0.0f; return; }
     const float ratio = (float)(n - 1) / (float)(bw - 1);
@@ -287,10 +290,13 @@ __device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int&
     i1 = i0 + (i0 < n - 1 ? 1 : 0);
 }
 
-__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restrict__ tok, float* __restrict__ out, VxPwaPlan P, int c, int m, int M) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restrict__ tok, VxScPtrs ptrs, VxPwaPlan P, int c, int m0, int M, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    float* __restrict__ out = ptrs.out[mm];
     const int ch = blockIdx.y, b = blockIdx.z;
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const long v = (long)bx * 256 + threadIdx.x;
     if (v >= V) return;
     const int i = ch / (P.heads * c), a = (ch / c) % P.heads, cc = ch % c;
     const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
@@ -311,11 +317,14 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restr
 }
 
 // the same with 4 channels per lane (c % 4 == 0): the 8 taps of a voxel are 8 float4 reads of whole token rows instead of 32 scalar reads at stride c
-__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __restrict__ tok, float* __restrict__ out, VxPwaPlan P, int c, int m, int M) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __restrict__ tok, VxScPtrs ptrs, VxPwaPlan P, int c, int m0, int M, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    float* __restrict__ out = ptrs.out[mm];
     const int c4 = c >> 2;
     const int chq = blockIdx.y, b = blockIdx.z;                 // chq enumerates (scale i, head a, channel quad)
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const long v = (long)bx * 256 + threadIdx.x;
     if (v >= V) return;
     const int i = chq / (P.heads * c4), a = (chq / c4) % P.heads, q4 = chq % c4;
     const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
@@ -344,7 +353,10 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __res
 
 // adjoint of the scatter: one block = (b, head, window, voxel chunk); the window's l x c token gradients are accumulated in LDS
 // (ds_add_f32) from the block's output voxels (8 corners each), then flushed with one float atomic per token element.
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c]
     const int b = blockIdx.z / P.heads, a = blockIdx.z % P.heads;
     const int i = scale;
@@ -352,7 +364,7 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restr
     const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
     const int nv = bw0 * bw1 * bw2;
     const int items = nv * c;
-    const int chunks = gridDim.x;
+    const int chunks = nx;                            // (per modality)
     for (int k = threadIdx.x; k < P.l * c; k += 256) vx_sacc[k] = 0.0f;
     __syncthreads();
     const int Nl = N - P.woff[i];
@@ -360,7 +372,7 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restr
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const int chbase = (i * P.heads + a) * c;
     const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + chbase) * V;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < items; e += chunks * 256) {
+    for (int e = bx * 256 + threadIdx.x; e < items; e += chunks * 256) {
         const int vox = e % nv, cc = e / nv;
         const int j2 = vox % bw2, j1 = (vox / bw2) % bw1, j0 = vox / (bw2 * bw1);
         int a0, b0, a1, b1, a2, b2;
@@ -385,11 +397,14 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(const float* __restr
 // small window 1x1x1 (every shipped config: min_small_window_sizes = [[1,1,1]] * 4): the per-window resampling is the identity, so the adjoint
 // is a transpose of the window's (c, voxels) slab into its (tokens, c) rows -- staged through LDS (pitch c + 1), coalesced on both sides, no atomics.
 // One block = one (b, head, window); every element of the destination rows is written exactly once, which equals "+=" on the zeroed buffer.
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c + 1]
     const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
     const int i = scale;
-    const int Nl = blockIdx.x, N = P.woff[i] + Nl;
+    const int Nl = bx, N = P.woff[i] + Nl;
     const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
     const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
@@ -410,12 +425,15 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(const float* _
 // staged in LDS; PT = 256 / l threads share a token (they split the outermost tap axis) and are summed with shuffles.  Replaces 8 scattered
 // ds_add_f32 per voxel of the atomic kernel below (45 us per launch at the second scale) by 8 LDS reads per voxel.
 #define VX_SC_TAPS 12
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale, int PT) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int PT, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [nv] slab | taps
     const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
     const int cc = blockIdx.z;
     const int i = scale;
-    const int Nl = blockIdx.x, N = P.woff[i] + Nl;
+    const int Nl = bx, N = P.woff[i] + Nl;
     const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
     const int bw0 = n0 * P.small[i][0], bw1 = n1 * P.small[i][1], bw2 = n2 * P.small[i][2];
     const int nv = bw0 * bw1 * bw2, l = P.l;
@@ -475,12 +493,15 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(const float* 
 // (coalesced), reduce along W with the axis' tap weights (thread = (row, coarse column)), then along H (thread = (coarse row, coarse column)) and
 // add the plane's n1 x n2 result into the block's n0 x n1 x n2 accumulator with the two D weights of that plane; one float atomic per token
 // element and block at the end.  Replaces 8 scattered ds_add_f32 per voxel of vx_pwa_scatter_bwd_k (58 us per launch there) by plain LDS reads.
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(const float* __restrict__ dout, float* __restrict__ dtok, VxPwaPlan P, int c, int m, int M, int scale, int ZC) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int ZC, int nx) {
+    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    const int m = m0 + mm;
+    const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];
     const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
     const int i = scale;
     const int cc = blockIdx.z % c, zc = blockIdx.z / c;
-    const int Nl = blockIdx.x, N = P.woff[i] + Nl;
+    const int Nl = bx, N = P.woff[i] + Nl;
     const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
     const int bw0 = n0 * P.small[i][0], bw1 = n1 * P.small[i][1], bw2 = n2 * P.small[i][2];
     float* __restrict__ plane = vx_sacc;                        // [bw1][bw2]
@@ -1052,24 +1073,36 @@ extern "C" int vx_pwa_gather_all_bwd(const float* dtq, const float* dtk, const f
     return 0;
 }
 
+static int vx_scatter_fwd_launch(const float* tok, const VxScPtrs& ptrs, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream) {
+    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
+    const int nx = vx_cdiv(V, 256);
+    if ((c & 3) == 0 && vx_gather_vec_enabled)
+        hipLaunchKernelGGL(vx_pwa_scatter_fwd_v_k, dim3(nx * mcount, plan->nb * plan->heads * (c >> 2), B), dim3(256), 0, (hipStream_t)stream, tok, ptrs, *plan, c, m0, M, nx);
+    else
+        hipLaunchKernelGGL(vx_pwa_scatter_fwd_k, dim3(nx * mcount, plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, tok, ptrs, *plan, c, m0, M, nx);
+    VX_LAUNCH_CHECK("vx_pwa_scatter_fwd");
+    return 0;
+}
 extern "C" int vx_pwa_scatter_fwd(const float* tok, float* out, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_fwd")) return e;
     VX_REQUIRE(tok && out && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_fwd: bad args");
-    const long V = (long)plan->grid[0] * plan->grid[1] * plan->grid[2];
-    if ((c & 3) == 0 && vx_gather_vec_enabled)
-        hipLaunchKernelGGL(vx_pwa_scatter_fwd_v_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * (c >> 2), B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
-    else
-        hipLaunchKernelGGL(vx_pwa_scatter_fwd_k, dim3(vx_cdiv(V, 256), plan->nb * plan->heads * c, B), dim3(256), 0, (hipStream_t)stream, tok, out, *plan, c, m, M);
-    VX_LAUNCH_CHECK("vx_pwa_scatter_fwd");
-    return 0;
+    VxScPtrs ptrs = {};
+    ptrs.out[0] = out;
+    return vx_scatter_fwd_launch(tok, ptrs, plan, c, m, 1, M, B, stream);
+}
+// every modality in one launch per kernel kind (outs[m], m < M <= 4)
+extern "C" int vx_pwa_scatter_fwd_all(const float* tok, float* const* outs, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_fwd_all")) return e;
+    VX_REQUIRE(tok && outs && c > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_scatter_fwd_all: bad args");
+    VxScPtrs ptrs = {};
+    for (int m = 0; m < M; ++m) { VX_REQUIRE(outs[m], "vx_pwa_scatter_fwd_all: null output %d", m); ptrs.out[m] = outs[m]; }
+    return vx_scatter_fwd_launch(tok, ptrs, plan, c, 0, M, M, B, stream);
 }
 
 static int vx_scatter_ident_enabled = 1;
 static const int vx_scatter_gather_max = 2;      // cells up to 2^3: the per-token gather; wider cells: the separable kernel (4^3 cells measured 36 -> 17 us per launch)
 extern "C" int vx_pwa_scatter_set_ident(int on) { vx_scatter_ident_enabled = on ? 1 : 0; return 0; }      // A/B knob: 0 = always the general (LDS-atomic) adjoint
-extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
-    if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
-    VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
+static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream) {
     const size_t shm = sizeof(float) * (size_t)plane_l(plan) * c;
     VX_REQUIRE(shm <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
     for (int i = 0; i < plan->nb; ++i) {
@@ -1080,7 +1113,7 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
         if (plan->small[i][0] == 1 && plan->small[i][1] == 1 && plan->small[i][2] == 1 && vx_scatter_ident_enabled) {
             const size_t shm1 = sizeof(float) * (size_t)plane_l(plan) * (c + 1);
             VX_REQUIRE(shm1 <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
-            hipLaunchKernelGGL(vx_pwa_scatter_bwd_ident_k, dim3(nwin, B * plan->heads), dim3(256), shm1, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i);
+            hipLaunchKernelGGL(vx_pwa_scatter_bwd_ident_k, dim3(nwin * mcount, B * plan->heads), dim3(256), shm1, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, nwin);
             continue;
         }
         {
@@ -1091,7 +1124,7 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
             if (smax <= vx_scatter_gather_max && shm2 <= 64 * 1024 && c <= 65535 && vx_scatter_ident_enabled) {      // <= 4x4x4: at most 5 + 4 taps per token and axis (VX_SC_TAPS = 12)
                 int PT = 256 / plan->l;                       // threads per token: power of two in 1..4
                 PT = PT >= 4 ? 4 : (PT >= 2 ? 2 : 1);
-                hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i, PT);
+                hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin * mcount, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, PT, nwin);
                 continue;
             }
         }
@@ -1102,14 +1135,30 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
             if (vx_scatter_ident_enabled && shm3 <= 60 * 1024 && (long)B * plan->heads * c <= 65535) {
                 int ZC = bw0;
                 while (ZC > 1 && (long)nwin * B * plan->heads * c * vx_cdiv(bw0, ZC) < 256) ZC = (ZC + 1) / 2;
-                hipLaunchKernelGGL(vx_pwa_scatter_bwd_sep_k, dim3(nwin, B * plan->heads, c * vx_cdiv(bw0, ZC)), dim3(256), shm3, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i, ZC);
+                hipLaunchKernelGGL(vx_pwa_scatter_bwd_sep_k, dim3(nwin * mcount, B * plan->heads, c * vx_cdiv(bw0, ZC)), dim3(256), shm3, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, ZC, nwin);
                 continue;
             }
         }
-        hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(chunks, nwin, B * plan->heads), dim3(256), shm, (hipStream_t)stream, dout, dtok, *plan, c, m, M, i);
+        hipLaunchKernelGGL(vx_pwa_scatter_bwd_k, dim3(chunks * mcount, nwin, B * plan->heads), dim3(256), shm, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, chunks);
     }
     VX_LAUNCH_CHECK("vx_pwa_scatter_bwd");
     return 0;
+}
+
+extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, int c, int m, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd")) return e;
+    VX_REQUIRE(dout && dtok && c > 0 && m >= 0 && m < M && B > 0, "vx_pwa_scatter_bwd: bad args");
+    VxScPtrs ptrs = {};
+    ptrs.in[0] = dout;
+    return vx_scatter_bwd_launch(ptrs, dtok, plan, c, m, 1, M, B, stream);
+}
+// every modality in one launch per scale (douts[m] may not be NULL; dtok zeroed by the caller)
+extern "C" int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd_all")) return e;
+    VX_REQUIRE(douts && dtok && c > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_scatter_bwd_all: bad args");
+    VxScPtrs ptrs = {};
+    for (int m = 0; m < M; ++m) { VX_REQUIRE(douts[m], "vx_pwa_scatter_bwd_all: null gradient %d", m); ptrs.in[m] = douts[m]; }
+    return vx_scatter_bwd_launch(ptrs, dtok, plan, c, 0, M, M, B, stream);
 }
 
 static int vx_attn_fill(VxAttn& A, const VxPwaPlan* P, int B, int M, int cq, int cv, const char* who) {
