@@ -85,8 +85,9 @@ inline float* grad_ptr(const Tensor& p) {          // running gradient buffer of
 #define VX_WG_FLUSH 8
 struct WgradSide {
     bool enabled = false;
+    bool same = false;                 // deferral WITHOUT a side stream: the closures are launched at the join, each on the stream it was submitted from
     c10::optional<c10::hip::HIPStreamMasqueradingAsCUDA> stream;      // torch on ROCm presents HIP streams with the CUDA device type
-    hipEvent_t ev[64];
+    hipEvent_t ev[64] = {};
     unsigned next = 0;
     std::vector<std::pair<void*, std::function<void(void*)>>> pending;      // (stream the operands were produced on, launch closure)
     std::vector<std::function<void(void*)>> done;                            // launched, kept alive until the final join
@@ -119,7 +120,7 @@ inline void wg_flush(int dev) {
 inline void wgrad_submit(void* cur, int dev, std::function<void(void*)> launch) {
     if (!WG.enabled) { launch(cur); return; }
     WG.pending.emplace_back(cur, std::move(launch));
-    if (WG.pending.size() >= VX_WG_FLUSH) wg_flush(dev);
+    if (!WG.same && WG.pending.size() >= VX_WG_FLUSH) wg_flush(dev);
 }
 
 // ------------------------------------------------------------------------------------------------------------------- convolution
@@ -203,14 +204,14 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         }
         return;
     }
-    if (need_x && st.pw && V <= F.pw_mfma_max_v && w.requires_grad() && !WG.enabled && F.fuse_pw_bwd) {      // both gradients of a small 1x1 conv in one launch
+    if (need_x && st.pw && V <= F.pw_mfma_max_v && w.requires_grad() && (!WG.enabled || WG.same) && F.fuse_pw_bwd) {      // both gradients of a small 1x1 conv in one launch
         const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
         dx = acc ? acc_into : at::empty_like(x);
         if (x2.defined()) dx2 = at::empty_like(x2);
         VX(vx_pw_conv_bwd_fused, fp(dy), fp(w), fp(x), fp(x2), C1, mp(dx), mp(dx2), grad_ptr(w), skip_bias ? nullptr : grad_ptr(b), B, Cin, Cout, V, acc, stream);
         return;
     }
-    if (need_x && st.pw && V > F.pw_mfma_max_v && w.requires_grad() && !WG.enabled && F.fuse_pw_bwd) {     // the same at the large levels
+    if (need_x && st.pw && V > F.pw_mfma_max_v && w.requires_grad() && (!WG.enabled || WG.same) && F.fuse_pw_bwd) {     // the same at the large levels
         const int acc = (acc_into.defined() && !x2.defined()) ? 1 : 0;
         dx = acc ? acc_into : at::empty_like(x);
         if (x2.defined()) dx2 = at::empty_like(x2);
@@ -890,12 +891,24 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             // weight gradients (the bias gradients behind an InstanceNorm are zero by construction: see below)
             grad_ptr(f.b1); grad_ptr(f.b3); grad_ptr(f.b5);
             const int Cg = C / G;
-            if (f.w1.requires_grad()) {
-                if (F.use_gconv1 && (Cg == 4 || Cg == 8 || Cg == 16) && V % 4 == 0) VX(vx_gconv1_bwd_weight, fp(f.x), gp, grad_ptr(f.w1), nullptr, B, C, G, V, s_);
-                else VX(vx_conv3d_bwd_weight_tiled, fp(f.x), nullptr, 0, gp, grad_ptr(f.w1), nullptr, B, C, D, H, W, C, 1, 1, 0, G, 1, s_);
+            {
+                // (through wgrad_submit: immediate by default; deferred to the end of this stream in the taped encoder backward -- the closure owns x and g)
+                Tensor xk = f.x, gk = g;
+                float* dw1 = f.w1.requires_grad() ? grad_ptr(f.w1) : nullptr;
+                float* dw3 = f.w3.requires_grad() ? grad_ptr(f.w3) : nullptr;
+                float* dw5 = f.w5.requires_grad() ? grad_ptr(f.w5) : nullptr;
+                const bool g1fast = F.use_gconv1 && (Cg == 4 || Cg == 8 || Cg == 16) && V % 4 == 0;
+                wgrad_submit(s_, f.x.device().index(), [=](void* s) {
+                    const float* gq = gk.data_ptr<float>();
+                    if (dw1) {
+                        if (g1fast) VX(vx_gconv1_bwd_weight, fp(xk), gq, dw1, nullptr, B, C, G, V, s);
+                        else VX(vx_conv3d_bwd_weight_tiled, fp(xk), nullptr, 0, gq, dw1, nullptr, B, C, D, H, W, C, 1, 1, 0, G, 1, s);
+                    }
+                    if (dw3) VX(vx_conv3d_bwd_weight_tiled, fp(xk), nullptr, 0, gq + n1, dw3, nullptr, B, C, D, H, W, C, 3, 1, 1, G, 1, s);
+                    if (dw5) VX(vx_conv3d_bwd_weight_tiled, fp(xk), nullptr, 0, gq + 2 * n1, dw5, nullptr, B, C, D, H, W, C, 5, 1, 2, G, 1, s);
+                });
+                if (!WG.enabled) WG.done.clear();
             }
-            if (f.w3.requires_grad()) VX(vx_conv3d_bwd_weight_tiled, fp(f.x), nullptr, 0, gp + n1, grad_ptr(f.w3), nullptr, B, C, D, H, W, C, 3, 1, 1, G, 1, s_);
-            if (f.w5.requires_grad()) VX(vx_conv3d_bwd_weight_tiled, fp(f.x), nullptr, 0, gp + 2 * n1, grad_ptr(f.w5), nullptr, B, C, D, H, W, C, 5, 1, 2, G, 1, s_);
             st.reset();
             return dx;
         }
@@ -1081,7 +1094,25 @@ PYBIND11_MODULE(_vxops, m) {
 
     // weight-gradient side stream: enable around the backward pass, join (make `stream` wait for it) before anything reads the parameter gradients
     m.def("set_wgrad_stream", [](bool on) { WG.enabled = on; });
+    // deferral on the submitting streams (taped encoder backward): the weight-gradient kernels of a stream run after everything else queued on it, so
+    // the input gradients that OTHER streams wait for leave it earlier; no extra stream competes for CUs.  The closures keep their operands alive.
+    m.def("set_wgrad_defer", [](bool on) { WG.enabled = on; WG.same = on; });
     m.def("wgrad_join", [](int64_t stream, int64_t device, bool final) {
+        if (WG.same) {
+            hipStream_t js = (hipStream_t)sp(stream);
+            if (WG.ev[0] == nullptr) for (auto& e : WG.ev) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+            void* seen[8]; int ns = 0;
+            for (auto& p : WG.pending) {
+                p.second(p.first);
+                bool dup = p.first == (void*)js;
+                for (int i = 0; i < ns; ++i) dup = dup || seen[i] == p.first;
+                if (!dup && ns < 8) seen[ns++] = p.first;
+            }
+            for (int i = 0; i < ns; ++i) wg_order((hipStream_t)seen[i], js);      // the joining stream waits for the streams that got late work
+            WG.pending.clear();
+            WG.done.clear();
+            return;
+        }
         wg_flush((int)device);
         if (WG.stream.has_value() && !WG.done.empty()) wg_order(WG.stream->stream(), (hipStream_t)sp(stream));
         if (final) WG.done.clear();          // after the wait above: the memory may be reused by the joining stream

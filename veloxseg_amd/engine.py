@@ -24,6 +24,7 @@ from . import _hip as H
 from . import functional as VF
 
 TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
+TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
 WGRAD_STREAM = os.environ.get("VELOXSEG_WGRAD_STREAM", "0") != "0"      # experiment (off): weight-gradient kernels deferred to a side stream -- measured 13.5 vs 12.0 ms/step, they steal CUs from the critical path
 
 
@@ -433,10 +434,18 @@ class TrainEngine:
                 groups.append(gs)
         bg = self._sum_groups(groups)
         self._stage_stream = torch.cuda.current_stream(self.dev)
+        # taped encoder backward: the weight-gradient kernels are deferred to the end of the stream they were queued on (csrc/_vxops.cpp WgradSide,
+        # `same`): the mixer / level-input gradients that the OTHER lanes wait for leave the conv chain before its weight gradients run
+        m = VF.cpp_module() if (self.use_graph and self.replay_mode == "tape" and TAPE_WGRAD_DEFER) else None
+        if m is not None:
+            m.set_wgrad_defer(True)
         try:
             with self._wgrad_side():
                 torch.autograd.backward(bt, bg)
         finally:
+            if m is not None:
+                m.wgrad_join(self._stage_stream.cuda_stream, self.dev.index or 0, True)
+                m.set_wgrad_defer(False)
             self._drop_level_hooks()
 
     def _sum_groups(self, groups):
