@@ -1097,6 +1097,7 @@ PYBIND11_MODULE(_vxops, m) {
     // deferral on the submitting streams (taped encoder backward): the weight-gradient kernels of a stream run after everything else queued on it, so
     // the input gradients that OTHER streams wait for leave it earlier; no extra stream competes for CUs.  The closures keep their operands alive.
     m.def("set_wgrad_defer", [](bool on) { WG.enabled = on; WG.same = on; });
+    m.def("set_wgrad_hold", []() { WG.enabled = false; WG.same = false; });      // stop deferring but KEEP what is queued (a later wgrad_join under set_wgrad_defer launches it)
     m.def("wgrad_join", [](int64_t stream, int64_t device, bool final) {
         if (WG.same) {
             hipStream_t js = (hipStream_t)sp(stream);

@@ -413,7 +413,31 @@ class TrainEngine:
         self._douts = [[o.grad for o in od] for od in outs_d]
         torch.add(loss.detach(), 0.0, out=self.loss)      # a kernel, not hipMemcpyAsync: memcpy nodes cannot be read back into a launch tape
 
+    def _split_dec_wgrad(self):
+        """taped steps: the weight-gradient kernels of a decoder's backward become a tape of their own (dec_wg[k]) that is replayed on the lane the
+        encoder backward leaves idle, concurrently with it -- the decoder fans then only carry the input-gradient chains"""
+        return self.use_graph and self.replay_mode == "tape" and TAPE_WGRAD_DEFER and VF.cpp_module() is not None
+
     def _s_dec_bwd(self, k):
+        m = VF.cpp_module() if self._split_dec_wgrad() else None
+        if m is not None:
+            m.set_wgrad_defer(True)              # weight-gradient launches are queued as closures (they own their operands) ...
+        try:
+            self._s_dec_bwd_body(k)
+        finally:
+            if m is not None:
+                m.set_wgrad_hold()               # ... and stay queued when the stage ends: _s_dec_wg(k) launches them
+
+    def _s_dec_wg(self, k):
+        """the queued weight-gradient kernels of decoder k, on the current stream"""
+        m = VF.cpp_module()
+        m.set_wgrad_defer(True)
+        try:
+            m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
+        finally:
+            m.set_wgrad_defer(False)
+
+    def _s_dec_bwd_body(self, k):
         bl = self._branch_loss()
         if bl is not None:        # this branch's share of the loss backward, then its decoder
             outs = self._outs[k]
@@ -481,7 +505,11 @@ class TrainEngine:
         self._s_enc_fwd()
         VF.run_branches([(lambda k=k: self._s_dec_fwd(k)) for k in range(nb)], self.dev, uses=[self._boundary] * nb)
         self._s_loss()
-        VF.run_branches([(lambda k=k: self._s_dec_bwd(k)) for k in range(nb)], self.dev, uses=[([] if self._branch_loss() is not None else self._douts[k]) for k in range(nb)])
+        def dec_bwd(k):
+            self._s_dec_bwd(k)
+            if self._split_dec_wgrad():
+                self._s_dec_wg(k)
+        VF.run_branches([(lambda k=k: dec_bwd(k)) for k in range(nb)], self.dev, uses=[([] if self._branch_loss() is not None else self._douts[k]) for k in range(nb)])
         if between is not None:
             between()
         self._s_enc_bwd()
@@ -598,7 +626,13 @@ class TrainEngine:
         G = {"enc_fwd": self._graph(main_pool, self._s_enc_fwd)}
         G["dec_fwd"] = [self._graph(pools[k], self._s_dec_fwd, k) for k in range(nb)]
         G["loss"] = self._graph(main_pool, self._s_loss)
-        G["dec_bwd"] = [self._graph(pools[k], self._s_dec_bwd, k) for k in range(nb)]
+        if self._split_dec_wgrad():
+            G["dec_bwd"], G["dec_wg"] = [], []
+            for k in range(nb):                   # (pairwise: the closures queued by dec_bwd[k] are launched by dec_wg[k])
+                G["dec_bwd"].append(self._graph(pools[k], self._s_dec_bwd, k))
+                G["dec_wg"].append(self._graph(pools[k], self._s_dec_wg, k))
+        else:
+            G["dec_bwd"] = [self._graph(pools[k], self._s_dec_bwd, k) for k in range(nb)]
         G["enc_bwd"] = self._graph(main_pool, self._s_enc_bwd)
         self.graphs = G
         # self-check: replays separated by device synchronisation must reproduce the eager pass (same dropout streams)
@@ -649,10 +683,18 @@ class TrainEngine:
         G["loss"].replay()
         self._fan(G["dec_bwd"])
         split, n = self.flat.split, self.flat.numel
+        wg_lane = None
+        if "dec_wg" in G:
+            # the decoders' weight gradients: one after the other on the lane the encoder backward does not use, while it runs on the other three
+            wg_lane = self._lane_streams(4)[3]
+            wg_lane.wait_stream(cur)
+            with torch.cuda.stream(wg_lane):
+                for t in G["dec_wg"]:
+                    t.replay()
         if comm:
             self._reduced = []
         if comm and self.overlap:
-            self.comm_stream.wait_stream(cur)
+            self.comm_stream.wait_stream(wg_lane if wg_lane is not None else cur)
             with torch.cuda.stream(self.comm_stream):
                 self._allreduce(split, n)                   # decoder bucket, overlapped with the encoder backward
         G["enc_bwd"].replay()
@@ -675,7 +717,11 @@ class TrainEngine:
                         self._allreduce(0, done)            # what has no marker (always levels 1-2)
                 cur.wait_stream(self.comm_stream)
             else:
+                if wg_lane is not None:
+                    cur.wait_stream(wg_lane)
                 self._allreduce(0, n)
+        if wg_lane is not None:
+            cur.wait_stream(wg_lane)
 
     # ---- public ---------------------------------------------------------------------------------
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
