@@ -107,3 +107,42 @@ def test_engine_tape_replay_tracks_the_eager_engine():
         for a, b in zip(res[mode][0], res["eager"][0]):
             assert abs(a - b) <= 2e-3 * abs(b), (mode, res[mode][0], res["eager"][0])
         assert float((res[mode][1] - res["eager"][1]).abs().max()) < 2e-3, mode
+
+
+def test_eager_stages_are_reproducible_at_full_size_brats128_b4():
+    """Regression (round 2): the deferred weight-gradient closures allocate their temporaries when they are launched.  Taken from the CALLING stream's
+    pool and used on the launch stream, a recycled block was still being read by the level-1 attention backward queued on the calling stream:
+    from the third pass on (allocator cache warm) the eager passes of TrainEngine(use_graph=True) disagreed with each other by 5e-2 and the
+    capture's self-check fell back to eager launches.  Same weights, same dropout streams => every pass and the tape replay agree."""
+    import types
+    from bench import LOSS_CFG, WORKLOADS, synth
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg, _ = WORKLOADS["brats128"]
+    B = 4
+    torch.manual_seed(12345)
+    model = VeloxSeg(**cfg).cuda()
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
+    x, lab = synth(cfg, B, "cuda", 12345)
+    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=True, overlap=False)
+    eng.step(x, lab)
+    torch.cuda.synchronize()
+    assert eng.use_graph and eng.graphs is not None, "the capture's self-check (replay == eager pass) failed"
+    rng = VF.rng_state(eng.dev)
+    rng0 = rng.clone()
+    ref = None
+    for i in range(6):                       # on the default stream, as a training loop would
+        rng.copy_(rng0)
+        torch.cuda.synchronize()
+        eng._eager_pass()
+        torch.cuda.synchronize()
+        g = eng.flat.grad.clone()
+        ref = g if ref is None else ref
+        assert float((g - ref).abs().max()) < 1e-5, (i, float((g - ref).abs().max()))
+    rng.copy_(rng0)
+    torch.cuda.synchronize()
+    eng._replay(comm=False)
+    torch.cuda.synchronize()
+    assert float((eng.flat.grad - ref).abs().max()) < 1e-5

@@ -13,6 +13,7 @@
 #include <torch/custom_class.h>
 #include <c10/hip/HIPStream.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 #include <functional>
 #include <type_traits>
@@ -90,6 +91,7 @@ struct WgradSide {
     hipEvent_t ev[64] = {};
     unsigned next = 0;
     std::vector<std::pair<void*, std::function<void(void*)>>> pending;      // (stream the operands were produced on, launch closure)
+    std::vector<int> pending_dev;                                            // device of each pending closure
     std::vector<std::function<void(void*)>> done;                            // launched, kept alive until the final join
 } WG;
 
@@ -113,13 +115,19 @@ inline void wg_flush(int dev) {
         for (int i = 0; i < ns; ++i) dup = dup || seen[i] == p.first;
         if (!dup) { wg_order((hipStream_t)p.first, side); if (ns < 8) seen[ns++] = p.first; }
     }
-    for (auto& p : WG.pending) { p.second((void*)side); WG.done.push_back(std::move(p.second)); }
-    WG.pending.clear();
+    {
+        // the closures allocate their temporaries when they are launched: make the side stream current, so that the caching allocator hands out
+        // blocks whose earlier users are ordered before the side stream's kernels (a block of another stream's pool may still be in use there)
+        c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(*WG.stream);
+        for (auto& p : WG.pending) { p.second((void*)side); WG.done.push_back(std::move(p.second)); }
+    }
+    WG.pending.clear(); WG.pending_dev.clear();
 }
 // run `launch(stream)` now on `cur`, or queue it for the side stream
 inline void wgrad_submit(void* cur, int dev, std::function<void(void*)> launch) {
     if (!WG.enabled) { launch(cur); return; }
     WG.pending.emplace_back(cur, std::move(launch));
+    WG.pending_dev.push_back(dev);
     if (!WG.same && WG.pending.size() >= VX_WG_FLUSH) wg_flush(dev);
 }
 
@@ -1103,14 +1111,23 @@ PYBIND11_MODULE(_vxops, m) {
             hipStream_t js = (hipStream_t)sp(stream);
             if (WG.ev[0] == nullptr) for (auto& e : WG.ev) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
             void* seen[8]; int ns = 0;
-            for (auto& p : WG.pending) {
-                p.second(p.first);
+            for (size_t i = 0; i < WG.pending.size(); ++i) {
+                auto& p = WG.pending[i];
+                {
+                    // the closure allocates its temporaries (partial-sum slices, a channels-last copy) when it is launched.  They must come from
+                    // the pool of the stream the kernels run on: a cached block of the CALLER's stream may still be in use by kernels queued on
+                    // it, which the launch stream does not wait for (seen as a corrupted level-1 attention backward, brats128 B=4, eager stages)
+                    const c10::DeviceIndex dev = (c10::DeviceIndex)(i < WG.pending_dev.size() ? WG.pending_dev[i] : device);
+                    auto ls = p.first ? c10::hip::getStreamFromExternalMasqueradingAsCUDA((hipStream_t)p.first, dev) : c10::hip::getDefaultHIPStreamMasqueradingAsCUDA(dev);
+                    c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(ls);
+                    p.second(p.first);
+                }
                 bool dup = p.first == (void*)js;
                 for (int i = 0; i < ns; ++i) dup = dup || seen[i] == p.first;
                 if (!dup && ns < 8) seen[ns++] = p.first;
             }
             for (int i = 0; i < ns; ++i) wg_order((hipStream_t)seen[i], js);      // the joining stream waits for the streams that got late work
-            WG.pending.clear();
+            WG.pending.clear(); WG.pending_dev.clear();
             WG.done.clear();
             return;
         }
