@@ -146,3 +146,31 @@ def test_eager_stages_are_reproducible_at_full_size_brats128_b4():
     eng._replay(comm=False)
     torch.cuda.synchronize()
     assert float((eng.flat.grad - ref).abs().max()) < 1e-5
+
+
+def test_taped_engine_on_96_cube_patches_keeps_the_reference_output_list():
+    """96^3 patches (BASELINE configs with 3^3 windows): rows of 96 are not tiled by the fused deep-supervision loss kernels, so the engine keeps the
+    reference's up-sampled heads -- the capture must still succeed (no silent fall-back to eager launches) and track the eager engine."""
+    import types
+    from bench import LOSS_CFG, WORKLOADS, synth
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg, _ = WORKLOADS["autopet96"]
+    B = 1
+    losses = {}
+    import veloxseg_amd.functional as VF
+    for mode in ("eager", "tape"):
+        VF.reset_dropout_sites()
+        torch.manual_seed(7)
+        model = VeloxSeg(**cfg).cuda()
+        VF.manual_seed(77, "cuda")
+        crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
+        x, lab = synth(cfg, B, "cuda", 7)
+        eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=(mode == "tape"), overlap=False)
+        assert model.ds_fused is False
+        losses[mode] = [float(eng.step(x, lab)) for _ in range(3)]
+        if mode == "tape":
+            assert eng.use_graph and eng.graphs is not None
+    for a, b in zip(losses["eager"], losses["tape"]):
+        assert abs(a - b) <= 2e-3 * abs(a), losses

@@ -164,7 +164,10 @@ class TrainEngine:
         self.precision = precision
         self.bucket_min_bytes = int(bucket_min_bytes)      # all-reduce buckets below this size are merged into the next one (latency-bound collectives)
         if hasattr(model, "ds_fused"):
-            model.ds_fused = bool(fuse_ds)      # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip)
+            # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip).  Row widths the kernels do not tile
+            # (W/4 must divide 64: 96^3 patches) keep the reference's up-sampled output list
+            ok = bool(fuse_ds) and bool(H.query("vx_seg_loss_ds_ok", int(model.n_classes), *[int(v) for v in batch_shape[2:]]))
+            model.ds_fused = ok
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
         self.m = torch.zeros_like(self.flat.param)
