@@ -58,6 +58,9 @@ int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, fl
 int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps);
 int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);
+/* A/B knob of the two entries above: 1 (default) = the JLC grouped convs (k 3 / 5, stride 1, Cin/G == Cout/G in {4, 8}, W % 4 == 0; conv_blocks.py:51-58)
+ * take the row-sliding kernel (a thread owns a kw row of taps and slides the input row through registers), 0 = always the (ci, tap)-pair kernel */
+int vx_wgrad_set_rows(int on);
 /* weight + bias gradient of a 1x1x1 GROUPED conv with Cin == Cout == C (JLC k = 1 branch, conv_blocks.py:51-58): dw (C, C/G) +=, db (C) += (may be NULL).
  * Needs V % 4 == 0 and a group width of 4, 8 or 16; other shapes go through vx_conv3d_bwd_weight_tiled. */
 int vx_gconv1_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int G, long V, void* stream);

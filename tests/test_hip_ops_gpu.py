@@ -709,3 +709,43 @@ def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype):
         tol = 1e-4 * float(g.abs().max())
         close(res[0][1][k], g, tol, 1e-4, f"fused: d head {k} vs oracle")
         close(res[0][1][k], res[1][1][k], tol, 1e-4, f"fused vs unfused: d head {k}")
+
+
+@pytest.mark.parametrize("C,G,K,sp,B", [(16, 4, 5, (32, 32, 32), 2), (16, 4, 3, (32, 32, 32), 2), (32, 4, 5, (16, 16, 16), 2), (32, 4, 3, (16, 16, 16), 3),
+                                        (64, 8, 5, (8, 8, 8), 2), (64, 16, 3, (8, 8, 8), 2), (128, 16, 5, (4, 4, 4), 2), (32, 8, 5, (6, 5, 12), 2),
+                                        (16, 4, 5, (5, 7, 20), 1)])
+def test_row_sliding_weight_gradient_of_the_jlc_convs(C, G, K, sp, B):
+    """vx_wgrad_rows_k (a thread owns a kw row of taps, csrc/conv_wgrad.hip) vs the (ci, tap)-pair kernel vs aten in fp64: the JLC grouped convs
+    (conv_blocks.py:51-58) at every level of the 128^3 configurations, widths that only take the 4-voxel chunks (W = 12, 20), ragged D / H tiles, and
+    the partial-sum (deterministic) variant"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    x = rnd(B, C, *sp, seed=1).to(d)
+    dy = rnd(B, C, *sp, seed=2).to(d)
+    Cg = C // G
+    ref_w = torch.nn.grad.conv3d_weight(x.double().cpu(), (C, Cg, K, K, K), dy.double().cpu(), padding=K // 2, groups=G)
+    ref_b = dy.double().cpu().sum(dim=(0, 2, 3, 4))
+    st = H.stream_ptr()
+    outs = {}
+    for rows in (1, 0):
+        H.call("vx_wgrad_set_rows", rows)
+        try:
+            dw = torch.zeros(C, Cg, K, K, K, device=d)
+            db = torch.zeros(C, device=d)
+            H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, C, H.P(dy), H.P(dw), H.P(db), B, C, *sp, C, K, 1, K // 2, G, 1, st)
+            nws = H.query("vx_conv3d_bwd_weight_ws_floats", B, C, *sp, C, K, 1, K // 2, G, 1)
+            dw2 = torch.zeros_like(dw)
+            if nws > 0:
+                ws = torch.empty(nws, device=d)
+                H.call("vx_conv3d_bwd_weight_tiled_ws", H.P(x), None, C, H.P(dy), H.P(dw2), None, H.P(ws), nws, B, C, *sp, C, K, 1, K // 2, G, 1, st)
+            else:
+                dw2 = dw.clone()
+            torch.cuda.synchronize()
+        finally:
+            H.call("vx_wgrad_set_rows", 1)
+        tol = 2e-5 * max(1.0, float(ref_w.abs().max()))
+        close(dw, ref_w, tol, 1e-4, f"rows={rows} dw")
+        close(dw2, ref_w, tol, 1e-4, f"rows={rows} dw (partial-sum workspace)")
+        close(db, ref_b, 2e-5 * max(1.0, float(ref_b.abs().max())), 1e-4, f"rows={rows} db")
+        outs[rows] = dw
+    close(outs[1], outs[0], 2e-5 * max(1.0, float(ref_w.abs().max())), 1e-4, "rows vs pairs")

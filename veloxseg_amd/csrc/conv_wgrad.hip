@@ -211,6 +211,144 @@ __global__ void __launch_bounds__(256) vx_wgrad_tiled_k(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-sliding weight gradient for the JLC grouped convolutions (conv_blocks.py:51-58: k = 3 / 5, stride 1, padding k/2, Cin/G == Cout/G == CG).
+// vx_wgrad_tiled_k gives a thread (ci, tap) pairs: every LDS read feeds Cout/G = 4 or 8 FMAs, and the LDS pipe -- not the VALU -- sets its
+// 12-15 % of the fp32 peak.  Here a thread owns (ci, kd, kh) and ALL K taps of the kw row for all CG output channels (K * CG accumulators): for U
+// consecutive output voxels of a row it reads the U + K - 1 input values once (ds_read_b128) and slides them across the kw taps in registers --
+// U * K * CG FMAs per U + K - 1 LDS dwords (160 per 12 at k = 5, CG = 4) -- with dy entering as scalar (SGPR) operands as before.
+// A block = (b, group, run of output tiles); its CG * K * K owner threads fill WPS waves, and the block's 4 / WPS sub-blocks take alternate output
+// rows of the same LDS halo tile; their sums meet in LDS before one float atomic per (weight, block) (or one store into the partial-sum slice).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float vx_wf2 __attribute__((ext_vector_type(2)));
+template <int K, int CG, int U>
+__global__ void __launch_bounds__(256) vx_wgrad_rows_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, VxWg p) {
+    constexpr int T = CG * K * K;
+    constexpr int WPS = (T + 63) / 64;                 // waves per sub-block
+    constexpr int NS = 4 / WPS;                        // sub-blocks per block (alternate output rows)
+    constexpr int NX = (U + K - 1 + 3) & ~3;           // input values per chunk, whole float4s
+    static_assert(WPS == 1 || WPS == 2 || WPS == 4, "owner threads must tile the block's waves");
+    extern __shared__ __attribute__((aligned(16))) float vx_halo[];      // [CG][HD][HH][HW], HW a multiple of 4
+    constexpr int K3 = K * K * K;
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int co0 = g * CG;
+    const int plane = p.HD * p.HH * p.HW;
+    const long Vi = (long)p.Di * p.Hi * p.Wi;
+    const int ntiles = p.nTd * p.nTh * p.nTw;
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, ntiles);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = wave / WPS;
+    const int r = threadIdx.x - sub * (WPS * 64);
+    const bool owner = r < T;
+    const int rc = owner ? r : 0;
+    const int ci = rc / (K * K), kd = (rc / K) % K, kh = rc % K;
+    const int toff = ci * plane + (kd * p.HH + kh) * p.HW;
+    // accumulators as float2 (x: even voxels of a chunk, y: odd voxels): the FMAs are v_pk_fma_f32 with an SGPR pair (two consecutive dy values) as one
+    // operand and an aligned register pair of the input row as the other -- no per-FMA register shuffling
+    vx_wf2 acc2[K][CG];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) acc2[k][j] = (vx_wf2){0.0f, 0.0f};
+    const int st_hw0 = threadIdx.x % p.HW, st_t1 = threadIdx.x / p.HW;
+    const int st_hh0 = st_t1 % p.HH, st_t2 = st_t1 / p.HH;
+    const int st_hd0 = st_t2 % p.HD, st_c0 = st_t2 / p.HD;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tw = t % p.nTw, th = (t / p.nTw) % p.nTh, td = t / (p.nTw * p.nTh);
+        const int od0 = td * p.TD, oh0 = th * p.TH, ow0 = tw * p.TW;
+        const int id0 = od0 - p.P, ih0 = oh0 - p.P, iw0 = ow0 - p.P;
+        __syncthreads();
+        {   // halo staging as in vx_wgrad_tiled_k: (hw, hh, hd, ci) advance by the host-decomposed stride of 256, unconditional (clamped) loads, 4 in flight
+            int hw = st_hw0, hh = st_hh0, hd = st_hd0, cc = st_c0;
+            const int total = CG * plane;
+            for (int e = threadIdx.x; e < total; e += 256 * 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+                    const bool ok = (e + u * 256 < total) && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                    const float* src = x + ((long)b * p.Cin + co0 + (ok ? cc : 0)) * Vi;
+                    const float t_ = src[ok ? ((long)id * p.Hi + ih) * p.Wi + iw : 0];
+                    v[u] = ok ? t_ : 0.0f;
+                    hw += p.st_hw; if (hw >= p.HW) { hw -= p.HW; ++hh; }
+                    hh += p.st_hh; if (hh >= p.HH) { hh -= p.HH; ++hd; }
+                    hd += p.st_hd; if (hd >= p.HD) { hd -= p.HD; ++cc; }
+                    cc += p.st_c;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e + u * 256 < total) vx_halo[e + u * 256] = v[u];
+            }
+        }
+        __syncthreads();
+        const int nd = min(p.TD, p.Do - od0), nh = min(p.TH, p.Ho - oh0), nw = min(p.TW, p.Wo - ow0);      // nw % U == 0 (launcher)
+        for (int rr = sub; rr < nd * nh; rr += NS) {
+            const int qd = rr / nh, qh = rr - qd * nh;
+            const float* __restrict__ xrow = vx_halo + toff + (qd * p.HH + qh) * p.HW;
+            const float* __restrict__ dyr = dy + ((((long)b * p.Cout + co0) * p.Do + od0 + qd) * p.Ho + oh0 + qh) * (long)p.Wo + ow0;      // wave-uniform
+            const long cstride = (long)p.Do * p.Ho * p.Wo;
+            for (int qw = 0; qw < nw; qw += U) {
+                float xr[NX];
+#pragma unroll
+                for (int i = 0; i < NX; i += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(xrow + qw + i);
+                    xr[i] = v4.x; xr[i + 1] = v4.y; xr[i + 2] = v4.z; xr[i + 3] = v4.w;
+                }
+                vx_wf2 xe[NX / 2], xo[NX / 2];         // (x[2i], x[2i+1]) and (x[2i+1], x[2i+2])
+#pragma unroll
+                for (int i = 0; i < NX / 2; ++i) {
+                    xe[i] = (vx_wf2){xr[2 * i], xr[2 * i + 1]};
+                    xo[i] = (vx_wf2){xr[2 * i + 1], xr[2 * i + 2 < NX ? 2 * i + 2 : 2 * i + 1]};
+                }
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    vx_wf2 d2[U / 2];
+#pragma unroll
+                    for (int u = 0; u < U; u += 4) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(dyr + j * cstride + qw + u);      // s_load_dwordx4
+                        d2[u / 2] = (vx_wf2){d4.x, d4.y};
+                        d2[u / 2 + 1] = (vx_wf2){d4.z, d4.w};
+                    }
+#pragma unroll
+                    for (int u2 = 0; u2 < U / 2; ++u2)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int idx = 2 * u2 + k;
+                            acc2[k][j] = __builtin_elementwise_fma(d2[u2], (idx & 1) ? xo[idx / 2] : xe[idx / 2], acc2[k][j]);
+                        }
+                }
+            }
+        }
+    }
+    // Flush: the sub-blocks' sums meet in an LDS image of the group's weights ([CG co][CG * K^3]), then ALL threads add consecutive addresses to dw
+    // (a lane's own K * CG sums are K floats apart per lane: flushed from registers, a wave's atomic touched 10-20 cache lines instead of 2, and
+    // the flush was 2/3 of the kernel)
+    constexpr int NPAIRS = CG * K3;
+    const int pi0 = ci * K3 + (kd * K + kh) * K;
+    float* __restrict__ img = vx_halo;                 // [CG][NPAIRS]
+    for (int s2 = 0; s2 < NS; ++s2) {
+        __syncthreads();
+        if (sub == s2 && owner) {
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float v = acc2[k][j].x + acc2[k][j].y;
+                    img[j * NPAIRS + pi0 + k] = s2 == 0 ? v : img[j * NPAIRS + pi0 + k] + v;
+                }
+        }
+    }
+    __syncthreads();
+    if (p.part) {
+        float* __restrict__ pd = p.part + ((long)blockIdx.z * gridDim.x + blockIdx.x) * ((long)p.Cout * NPAIRS) + (long)co0 * NPAIRS;
+        for (int i = threadIdx.x; i < CG * NPAIRS; i += 256) pd[i] = img[i];
+    } else {
+        float* __restrict__ dst = dw + (long)co0 * NPAIRS;
+        for (int i = threadIdx.x; i < CG * NPAIRS; i += 256) atomicAdd(dst + i, img[i]);
+    }
+}
+
 // db[co] += sum_{b,q} dy[b,co,q]  (dy possibly pixel-shuffled); grid (Cout, chunks)
 __global__ void __launch_bounds__(256) vx_bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, VxWg p) {
     const int co = blockIdx.x;
@@ -242,6 +380,8 @@ __global__ void __launch_bounds__(256) vx_wg_reduce_k(const float* __restrict__ 
 }
 
 template <int N> using vx_ic2 = std::integral_constant<int, N>;
+static int vx_wg_rows_enabled = 1;
+extern "C" int vx_wgrad_set_rows(int on) { vx_wg_rows_enabled = on ? 1 : 0; return 0; }      // A/B switch for tests and tools (vx_wgrad_rows_k vs vx_wgrad_tiled_k)
 #ifndef VX_WG_MIN_BLOCKS_SMALL
 #define VX_WG_MIN_BLOCKS_SMALL 384
 #endif
@@ -278,6 +418,20 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
     }
     if (p.TH > p.Ho) p.TH = p.Ho;
     if (p.TD > p.Do) p.TD = p.Do;
+    // JLC grouped convs (k 3 / 5, stride 1, Cin/G == Cout/G in {4, 8}) on rows of >= 16 voxels: the row-sliding kernel (vx_wgrad_rows_k)
+    const bool rows_ok = vx_wg_rows_enabled && S == 1 && ps == 1 && (K == 3 || K == 5) && P == K / 2 && Cin_g == Cout_g && (Cin_g == 4 || Cin_g == 8) && p.C1 == Cin &&
+                         G > 1 && p.Wo >= 16 && p.Wo % 4 == 0;
+    if (rows_ok) {
+        // its halo staging and its FMA phase cost about the same, so the tiles stay compact (halo / tile volume): halve the taller of H and 2*D until
+        // ~1024 blocks exist (measured at 32^3: 4 x 4 x 32 tiles 44 us, 1 x 8 x 32 63 us; at 16^3: 2 x 4 x 16 34 us)
+        auto nblk = [&]() { return (long)vx_cdiv(p.Do, p.TD) * vx_cdiv(p.Ho, p.TH) * vx_cdiv(p.Wo, p.TW) * G * B; };
+        const long want = ((long)p.Do * p.Ho * p.Wo <= 4096) ? VX_WG_MIN_BLOCKS_SMALL : 1024;
+        while (nblk() < want && (p.TD > 1 || p.TH > 1)) {
+            if (p.TH >= 2 * p.TD && p.TH > 1) p.TH = (p.TH + 1) / 2;
+            else if (p.TD > 1) p.TD = (p.TD + 1) / 2;
+            else p.TH = (p.TH + 1) / 2;
+        }
+    } else
     {   // small volumes: prefer more, smaller tiles (>= ~512 blocks) over LDS-filling ones; the atomic flush stays cheap
         const int COT0 = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
         auto nblk = [&]() { return (long)vx_cdiv(p.Do, p.TD) * vx_cdiv(p.Ho, p.TH) * vx_cdiv(p.Wo, p.TW) * G * (Cout_g / COT0) * B; };
@@ -288,6 +442,9 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
         while (nblk() < want && p.TW > 8) p.TW = (p.TW + 1) / 2;
     }
     p.HD = (p.TD - 1) * S + K; p.HH = (p.TH - 1) * S + K; p.HW = (p.TW - 1) * S + K;
+    // voxels per chunk of the row-sliding kernel (0 = the pair kernel); its halo rows are whole float4s
+    const int rows_u = rows_ok ? ((p.Wo % 8 == 0 && p.TW % 8 == 0) ? 8 : (p.TW % 4 == 0) ? 4 : 0) : 0;
+    if (rows_u) p.HW = (p.HW + 3) & ~3;
     {
         int r_ = 256;
         p.st_hw = r_ % p.HW; r_ /= p.HW;
@@ -297,7 +454,7 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
     }
     p.nTd = vx_cdiv(p.Do, p.TD); p.nTh = vx_cdiv(p.Ho, p.TH); p.nTw = vx_cdiv(p.Wo, p.TW);
     const int ntiles = p.nTd * p.nTh * p.nTw;
-    const int COT = (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
+    const int COT = rows_u ? Cout_g : (Cout_g % 8 == 0) ? 8 : (Cout_g % 4 == 0) ? 4 : (Cout_g % 2 == 0) ? 2 : 1;
     const int gy = G * (Cout_g / COT);
     // enough blocks to fill 256 CUs a few times over, but several tiles per block to amortise the atomic flush
     int tpb = (int)(((long)ntiles * gy * B + 2047) / 2048);
@@ -306,7 +463,12 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
     p.tiles_per_block = tpb;
     const int npairs = Cin_g * K * K * K;
     const int NP = npairs > 512 ? 4 : (npairs > 256 ? 2 : 1);
-    const size_t shm = halo_bytes(p.TD, p.TH, p.TW);
+    size_t shm = halo_bytes(p.TD, p.TH, p.TW);
+    if (rows_u) {
+        shm = (size_t)Cin_g * p.HD * p.HH * p.HW * sizeof(float);
+        const size_t red = (size_t)Cin_g * Cin_g * K * K * K * sizeof(float);      // the flush image of the group's weights reuses the halo region
+        if (shm < red) shm = red;
+    }
     dim3 grid(vx_cdiv(ntiles, tpb), gy, B);
     hipStream_t st = (hipStream_t)stream;
     const long nw = (long)Cout * npairs;
@@ -337,6 +499,14 @@ static int vx_wg_run(const float* x, const float* x2, int C1, const float* dy, f
             default: with_np(kt, vx_ic2<1>{}); break;
         }
     };
+    if (rows_u) {
+#define VX_ROWS(K_, CG_, U_) vx_wgrad_rows_k<K_, CG_, U_><<<grid, dim3(256), shm, st>>>(x, dy, dw, p)
+        if (K == 5 && Cin_g == 4) { if (rows_u == 8) VX_ROWS(5, 4, 8); else VX_ROWS(5, 4, 4); }
+        else if (K == 5) { if (rows_u == 8) VX_ROWS(5, 8, 8); else VX_ROWS(5, 8, 4); }
+        else if (Cin_g == 4) { if (rows_u == 8) VX_ROWS(3, 4, 8); else VX_ROWS(3, 4, 4); }
+        else { if (rows_u == 8) VX_ROWS(3, 8, 8); else VX_ROWS(3, 8, 4); }
+#undef VX_ROWS
+    } else
     switch (K) {
         case 3: with_cot(vx_ic2<3>{}); break;
         case 5: with_cot(vx_ic2<5>{}); break;

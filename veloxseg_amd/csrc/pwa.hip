@@ -585,10 +585,16 @@ __device__ __forceinline__ int vx_lin_of_token(const VxAttn& A, int T) {
 
 // Per-block LDS tables shared by the attention kernels: lin[t] (t < l) and the bias table of every head (Tsz x heads floats).
 // LDS layout (dynamic): [lin: l ints][bias: heads*Tsz floats][per-wave slabs ...]
-__device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __restrict__ table, int Tsz, int* lin, float* bias) {
+// head >= 0: only that head's column is staged (bias[k]); a block whose units all belong to one head needs no more, and the 8^3-window level's
+// 15^3-entry table then takes 13.5 KB of LDS instead of 54 KB (the difference between one and three resident blocks per CU in the backward)
+__device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __restrict__ table, int Tsz, int* lin, float* bias, int head = -1) {
     for (int t = threadIdx.x; t < A.l; t += 256) {
         const int t2 = t % A.n[2], t1 = (t / A.n[2]) % A.n[1], t0 = t / (A.n[2] * A.n[1]);
         lin[t] = (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+    }
+    if (head >= 0) {
+        for (int k = threadIdx.x; k < Tsz; k += 256) bias[k] = table[(long)k * A.heads + head];
+        return;
     }
     for (int e = threadIdx.x; e < Tsz * A.heads; e += 256) {       // transpose (Tsz, heads) -> [head][Tsz]
         const int a = e / Tsz, k = e % Tsz;
@@ -604,20 +610,20 @@ __device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __r
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                          const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
-                                                         int Tsz, VxAttn A, VxDrop drop, int S) {
+                                                         int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
     constexpr int RS = CQ + CV;
     static_assert(RS >= CV + 2, "the merge reuses the slab rows");
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
     float* __restrict__ bias_all = vx_sm + lin_pad;
-    float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
-    vx_attn_tables(A, table, Tsz, lin, bias_all);
+    float* __restrict__ slabs = bias_all + (((long)Tsz * (one_head ? 1 : A.heads) + 3) & ~3);
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)blockIdx.x * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
     __syncthreads();
     const VxDropCtx dc = vx_drop_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
-    const int chunks = (A.ML + 63) / 64;
-    const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = wave % S;
     const long u_raw = (long)blockIdx.x * (4 / S) + wave / S;
@@ -628,7 +634,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;                       // (bh*Nt + N)
     const int a = (int)((win / A.Nt) % A.heads);
-    const float* __restrict__ bias = bias_all + (long)a * Tsz;
+    const float* __restrict__ bias = bias_all + (one_head ? 0L : (long)a * Tsz);
     const int i = chunk * 64 + lane;
     const bool ok = active && i < A.ML;
     const int iq = (i < A.ML) ? i : A.ML - 1;
@@ -715,34 +721,38 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S) {
+                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
     constexpr int RS = CQ + CV;
-    extern __shared__ __attribute__((aligned(16))) float vx_sm[];   // lin | bias tables | [4/S][Tsz] bias-gradient tables | [4] K/V slabs
+    // lin | bias tables | bias-gradient tables | [4] K/V slabs.  one_head (every unit of a block belongs to one head: launcher): ONE bias column and ONE
+    // bias-gradient table shared by the block's waves (they reach it through ds_add_f32 only); else all heads and a table per unit.
+    extern __shared__ __attribute__((aligned(16))) float vx_sm[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
     float* __restrict__ bias_all = vx_sm + lin_pad;
-    float* __restrict__ gtabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
+    float* __restrict__ gtabs = bias_all + (((long)Tsz * (one_head ? 1 : A.heads) + 3) & ~3);
     const int upb = 4 / S;
-    float* __restrict__ slabs = gtabs + (((long)upb * Tsz + 3) & ~3);
+    const int ntab = one_head ? 1 : upb;
+    float* __restrict__ slabs = gtabs + (((long)ntab * Tsz + 3) & ~3);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int split = wave % S;
-    float* __restrict__ stab = gtabs + (long)(wave / S) * Tsz;
+    float* __restrict__ stab = gtabs + (one_head ? 0L : (long)(wave / S) * Tsz);
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
-    vx_attn_tables(A, table, Tsz, lin, bias_all);
-    for (int k = threadIdx.x; k < upb * Tsz; k += 256) gtabs[k] = 0.0f;
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    const int a_blk = (int)((((long)blockIdx.x * upb / chunks) / A.Nt) % A.heads);      // head of the block's first unit
+    vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? a_blk : -1);
+    for (int k = threadIdx.x; k < ntab * Tsz; k += 256) gtabs[k] = 0.0f;
     __syncthreads();
     const VxDropCtx dc = vx_drop_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
-    const int chunks = (A.ML + 63) / 64;
-    const long units = (long)A.BH * A.Nt * chunks;
     const long u_raw = (long)blockIdx.x * upb + wave / S;
     const bool active = u_raw < units;
     const long u = active ? u_raw : units - 1;
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;
     const int a = (int)((win / A.Nt) % A.heads);
-    const float* __restrict__ bias = bias_all + (long)a * Tsz;
+    const float* __restrict__ bias = bias_all + (one_head ? 0L : (long)a * Tsz);
     const int i = chunk * 64 + lane;
     const bool ok = active && i < A.ML;
     const int iq = (i < A.ML) ? i : A.ML - 1;
@@ -856,8 +866,14 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
             Delta[row] = delta;
         }
     }
-    if (active) {      // one of VX_DTABLE_REPLICAS copies per block: thousands of blocks adding into the same few hundred addresses serialise in L2
-        float* __restrict__ dst = dtable_rep + (long)(blockIdx.x % VX_DTABLE_REPLICAS) * Tsz * A.heads;
+    // one of VX_DTABLE_REPLICAS copies per block: thousands of blocks adding into the same few hundred addresses serialise in L2
+    float* __restrict__ dst = dtable_rep + (long)(blockIdx.x % VX_DTABLE_REPLICAS) * Tsz * A.heads;
+    if (one_head) {    // the block's shared table (complete after the barrier above), all threads
+        for (int k = threadIdx.x; k < Tsz; k += 256) {
+            const float g = gtabs[k];
+            if (g != 0.0f) atomicAdd(dst + (long)k * A.heads + a_blk, g);
+        }
+    } else if (active) {
         for (int k = split * 64 + lane; k < Tsz; k += 64 * S) {
             const float g = stab[k];
             if (g != 0.0f) atomicAdd(dst + (long)k * A.heads + a, g);
@@ -873,7 +889,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
                                                             const float* __restrict__ dtable_rep, float* __restrict__ dtable,
-                                                            int Tsz, VxAttn A, VxDrop drop, int S) {
+                                                            int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
     {   // fold the dQ kernel's replicated bias-gradient tables into dtable (it ran before this kernel on the same stream): one owner thread per entry
         for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < (long)Tsz * A.heads; k += (long)gridDim.x * 256) {
@@ -887,13 +903,13 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     int* __restrict__ lin = reinterpret_cast<int*>(vx_sm);
     const int lin_pad = (A.l + 3) & ~3;
     float* __restrict__ bias_all = vx_sm + lin_pad;
-    float* __restrict__ slabs = bias_all + (((long)Tsz * A.heads + 3) & ~3);
-    vx_attn_tables(A, table, Tsz, lin, bias_all);
+    float* __restrict__ slabs = bias_all + (((long)Tsz * (one_head ? 1 : A.heads) + 3) & ~3);
+    const int chunks = (A.ML + 63) / 64;
+    const long units = (long)A.BH * A.Nt * chunks;
+    vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)blockIdx.x * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
     __syncthreads();
     const VxDropCtx dc = vx_drop_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
-    const int chunks = (A.ML + 63) / 64;
-    const long units = (long)A.BH * A.Nt * chunks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = wave % S;
     const long u_raw = (long)blockIdx.x * (4 / S) + wave / S;
@@ -904,7 +920,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     const int chunk = (int)(u % chunks);
     const long win = u / chunks;
     const int a = (int)((win / A.Nt) % A.heads);
-    const float* __restrict__ bias = bias_all + (long)a * Tsz;
+    const float* __restrict__ bias = bias_all + (one_head ? 0L : (long)a * Tsz);
     const int j = chunk * 64 + lane;
     const bool ok = active && j < A.ML;
     const int jk = (j < A.ML) ? j : A.ML - 1;
@@ -1224,11 +1240,12 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     }
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
-    const size_t shm = (tab_f + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     const int S = vx_attn_split(units, A.ML, A.M);
+    const int one_head = (((long)A.Nt * ((A.ML + 63) / 64)) % (4 / S) == 0) ? 1 : 0;      // every unit of a block in one head: only that bias column is staged
+    const size_t shm = ((one_head ? (size_t)((A.l + 3) & ~3) + (((size_t)Tsz + 3) & ~(size_t)3) : tab_f) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_fwd: tables do not fit LDS (%d entries x %d heads)", Tsz, A.heads);
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
-        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S);
+        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S, one_head);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_fwd");
@@ -1261,8 +1278,11 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     const int Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
     const size_t tab_f = (size_t)((A.l + 3) & ~3) + (((size_t)Tsz * A.heads + 3) & ~(size_t)3);
     const int S = vx_attn_split(units, A.ML, A.M);
-    const size_t shm = (tab_f + (((size_t)(4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv) + (size_t)4 * VX_PRIV_BINS) * sizeof(float);
-    const size_t shm_kv = (tab_f + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
+    // every unit of a block in one head (the head changes every Nt * chunks units): one bias column, one shared bias-gradient table per block
+    const int one_head = (((long)A.Nt * ((A.ML + 63) / 64)) % (4 / S) == 0) ? 1 : 0;
+    const size_t tab_b = one_head ? (size_t)((A.l + 3) & ~3) + (((size_t)Tsz + 3) & ~(size_t)3) : tab_f;
+    const size_t shm = (tab_b + (((size_t)(one_head ? 1 : 4 / S) * Tsz + 3) & ~(size_t)3) + (size_t)4 * 64 * (cq + cv) + (size_t)4 * VX_PRIV_BINS) * sizeof(float);
+    const size_t shm_kv = (tab_b + (size_t)4 * 64 * (cq + cv + 4)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_bwd: bias table too large for LDS (%d entries)", Tsz);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
     // workspace: [rows] delta | [VX_DTABLE_REPLICAS][Tsz*heads] bias-gradient replicas (zeroed here, folded into dtable by the dK/dV kernel)
@@ -1279,8 +1299,8 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     }
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
-        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S);
-        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S);
+        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S, one_head);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S, one_head);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd");
