@@ -45,7 +45,8 @@ struct VxDs {
     float* dl0;                 // backward: gradient of head 0
     float* t2[3];               // backward: (B, C, D, h, w) partially reduced gradients of heads 1..
     int nh, B, D, H, W;
-    int stage;                  // 1: the grids of a sample are staged in LDS (they fit); 0: gathered from global memory
+    int stage;                  // 1: the Z-interpolated slices of a sample's grids are staged in LDS (they fit); 0: 8 taps gathered from global memory
+    int nsplit;                 // forward: blocks per Z slice
 };
 
 // logits of head hh (>= 1) at the 4 voxels (Z, Y, X0..X0+3): z[c][j]
@@ -101,18 +102,65 @@ __device__ __forceinline__ int vx_ds_stage(const VxDs& P, int b, float* __restri
     return off;
 }
 
+// A block works on ONE Z slice, so the Z step of the interpolation is the same for all of its voxels: the grids of sample b are interpolated along Z once,
+// while they are staged ([c][h][w] per head, C * h * w floats instead of C * d * h * w), and a voxel then gathers 4 taps per head and class instead of 8.
+template <int C>
+__device__ __forceinline__ void vx_ds_stage_slice(const VxDs& P, int b, int Z, float* __restrict__ lds, const float* (&lows)[3]) {
+    int off = 0;
+    for (int hh = 0; hh < 3; ++hh) {
+        lows[hh] = lds + off;
+        if (hh >= P.nh - 1) continue;
+        const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
+        const int n = C * hw;
+        const float* __restrict__ src = P.low[hh] + (long)b * C * d * hw;
+        int a0, b0; float l0;
+        vx_ds_coord(Z, d, P.D, a0, b0, l0);
+        const float k0 = 1.0f - l0;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int c = e / hw, r = e - c * hw;
+            lds[off + e] = k0 * src[((long)c * d + a0) * hw + r] + l0 * src[((long)c * d + b0) * hw + r];
+        }
+        off += (n + 3) & ~3;
+    }
+}
+// logits of head hh (>= 1) at the 4 voxels (Y, X0..X0+3) of the block's slice: z[c][j]
+template <int C>
+__device__ __forceinline__ void vx_ds_interp2(const VxDs& P, int hh, const float* __restrict__ sl, int Y, int X0, float (&z)[C][4]) {
+    const int h = P.ld[hh][1], w = P.ld[hh][2];
+    int a1, b1;
+    float l1;
+    vx_ds_coord(Y, h, P.H, a1, b1, l1);
+    const float k1 = 1.0f - l1;
+    int a2[4], b2[4];
+    float l2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, w, P.W, a2[j], b2[j], l2[j]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float* __restrict__ r0 = sl + ((long)c * h + a1) * w;
+        const float* __restrict__ r1 = sl + ((long)c * h + b1) * w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float k2 = 1.0f - l2[j];
+            z[c][j] = k1 * (k2 * r0[a2[j]] + l2[j] * r0[b2[j]]) + l1 * (k2 * r1[a2[j]] + l2[j] * r1[b2[j]]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------ forward
-// acc layout (double) as vx_seg_loss_fwd: head h at h*(1 + B*C*3): [ce_sum, (I, P, T) x (b, c)].  grid (chunks, B)
+// acc layout (double) as vx_seg_loss_fwd: head h at h*(1 + B*C*3): [ce_sum, (I, P, T) x (b, c)].  grid (D, B): a block = one Z slice
 template <int C>
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* __restrict__ lab, int lab_kind, double* __restrict__ acc) {
     constexpr int NS = 1 + 2 * C;
     extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
     const int W4 = P.W >> 2;
-    const long V = (long)P.D * P.H * P.W, V4 = V >> 2;
+    const long V = (long)P.D * P.H * P.W;
     const float* lows[3];
-    vx_ds_stage<C>(P, b, vx_ds_lds, lows);
+    if (P.stage) vx_ds_stage_slice<C>(P, b, Z, vx_ds_lds, lows);
+    else vx_ds_stage<C>(P, b, vx_ds_lds, lows);
     __syncthreads();
+    const int nq = P.H * W4, q_lo = (int)((long)nq * part / P.nsplit), q_hi = (int)((long)nq * (part + 1) / P.nsplit);
     float S[4][NS], T[C];
 #pragma unroll
     for (int h = 0; h < 4; ++h)
@@ -120,8 +168,9 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* 
         for (int k = 0; k < NS; ++k) S[h][k] = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; ++c) T[c] = 0.0f;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < V4; q += (long)gridDim.x * 256) {
-        const int X0 = (int)(q % W4) * 4, Y = (int)((q / W4) % P.H), Z = (int)(q / ((long)W4 * P.H));
+    for (int qs = q_lo + threadIdx.x; qs < q_hi; qs += 256) {
+        const int X0 = (qs % W4) * 4, Y = qs / W4;
+        const long q = ((long)Z * P.H * P.W >> 2) + qs;          // quad index inside the sample
         int y[4];
         vx_lab4(lab, lab_kind, (long)b * V + 4 * q, y);
 #pragma unroll
@@ -138,7 +187,8 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* 
                         const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + 4 * q);
                         z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
                     }
-                } else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
+                } else if (P.stage) vx_ds_interp2<C>(P, h - 1, lows[h - 1], Y, X0, z);
+                else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float mx = z[0][j];
@@ -210,7 +260,8 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     }
     int* __restrict__ lotab = reinterpret_cast<int*>(wtab + ((ntab + 3) & ~3));                  // [head][xl]: first fine column of the band
     const float* lows[3];
-    vx_ds_stage<C>(P, b, reinterpret_cast<float*>(lotab + 3 * P.W), lows);
+    if (P.stage) vx_ds_stage_slice<C>(P, b, Z, reinterpret_cast<float*>(lotab + 3 * P.W), lows);
+    else vx_ds_stage<C>(P, b, reinterpret_cast<float*>(lotab + 3 * P.W), lows);
     for (int hh = 0; hh < nlow; ++hh) {
         const int wl = P.ld[hh][2];
         const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
@@ -249,7 +300,8 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                         const float4 t = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0);
                         z[c][0] = t.x; z[c][1] = t.y; z[c][2] = t.z; z[c][3] = t.w;
                     }
-                } else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
+                } else if (P.stage) vx_ds_interp2<C>(P, h - 1, lows[h - 1], Y, X0, z);
+                else vx_ds_interp<C>(P, h - 1, lows[h - 1], Z, Y, X0, z);
                 const float* __restrict__ coef_h = coef + (long)h * coef_stride;
                 const float wce = coef_h[0];
                 float al[C], be[C];
@@ -281,14 +333,21 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // adjoint along W (owner lane = (head, c, coarse x)), then along H into this wave's accumulators.  Owners walk the step's rows one
-        // after the other, so two rows never add into one accumulator at the same time.
-        int base = 0;
+        // adjoint along W (owner = (head, c, coarse x)), then along H into this wave's accumulators.  An owner's band is split over SP lanes (64 / owners,
+        // a power of two: 2 / 4 / 8 for the 16 / 8 / 4-wide heads of a 2-class 128^3 patch) whose partial sums meet through shuffles: on the owner lanes
+        // alone the three heads were ~300 dependent LDS iterations per step on at most half of the lanes.
+        // Owners walk the step's rows one after the other, so two rows never add into one accumulator at the same time.
         for (int hh = 0; hh < nlow; ++hh) {
             const int hl = P.ld[hh][1], wl = P.ld[hh][2];
             const int nown = C * wl;
-            for (int o = lane; o < nown; o += 64) {
-                const int c = o / wl, xl = o - c * wl;
+            int sp = 1;
+            while (sp < 64 && nown * (sp * 2) <= 64) sp *= 2;
+            const int part = lane & (sp - 1);
+            for (int o0 = 0; o0 < nown; o0 += 64 / sp) {
+                const int o = o0 + lane / sp;
+                const bool own = o < nown;
+                const int oc = own ? o : 0;
+                const int c = oc / wl, xl = oc - c * wl;
                 const int lo = lotab[hh * P.W + xl], nb = bw[hh];
                 const float* __restrict__ wt = wtab + toff[hh] + xl * nb;
                 for (int r = 0; r < RPW; ++r) {
@@ -296,17 +355,19 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                     if (Yr >= P.H) break;
                     const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * C + c) * P.W;
                     float s = 0.0f;
-#pragma unroll 8
-                    for (int k = 0; k < nb; ++k) s = fmaf(wt[k], gr[min(lo + k, P.W - 1)], s);      // independent LDS reads: the band's weights are zero past its end
-                    int a1, b1; float l1;
-                    vx_ds_coord(Yr, hl, P.H, a1, b1, l1);
-                    float* __restrict__ dst = accw + aoff[hh] + (long)c * hl * wl + xl;
-                    dst[(long)a1 * wl] += (1.0f - l1) * s;
-                    if (b1 != a1) dst[(long)b1 * wl] += l1 * s;
-                    else dst[(long)a1 * wl] += l1 * s;
+#pragma unroll 4
+                    for (int k = part; k < nb; k += sp) s = fmaf(wt[k], gr[min(lo + k, P.W - 1)], s);      // independent LDS reads: the band's weights are zero past its end
+                    for (int m = sp >> 1; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+                    if (own && part == 0) {
+                        int a1, b1; float l1;
+                        vx_ds_coord(Yr, hl, P.H, a1, b1, l1);
+                        float* __restrict__ dst = accw + aoff[hh] + (long)c * hl * wl + xl;
+                        dst[(long)a1 * wl] += (1.0f - l1) * s;
+                        if (b1 != a1) dst[(long)b1 * wl] += l1 * s;
+                        else dst[(long)a1 * wl] += l1 * s;
+                    }
                 }
             }
-            base += nown;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -362,9 +423,10 @@ static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2
     return 0;
 }
 
-static size_t vx_ds_low_floats(const VxDs& P, int C) {
+// LDS floats of the Z-interpolated slices of heads 1.. (vx_ds_stage_slice)
+static size_t vx_ds_slice_floats(const VxDs& P, int C) {
     size_t n = 0;
-    for (int hh = 0; hh < P.nh - 1; ++hh) n += ((size_t)C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2] + 3) & ~(size_t)3;
+    for (int hh = 0; hh < P.nh - 1; ++hh) n += ((size_t)C * P.ld[hh][1] * P.ld[hh][2] + 3) & ~(size_t)3;
     return n;
 }
 
@@ -381,12 +443,11 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     VX_REQUIRE(labels && acc && lab_kind >= 0 && lab_kind <= 2, "vx_seg_loss_ds_fwd: bad labels / accumulator");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_ds_fwd: memset failed");
-    const long V4 = ((long)D * H * W) >> 2;
-    int chunks = vx_cdiv(V4, 256 * 4);
-    if (chunks > 512) chunks = 512;
-    const dim3 grid(chunks, B), blk(256);
-    size_t shm = vx_ds_low_floats(P, C) * sizeof(float);
-    P.stage = shm <= 120 * 1024;
+    P.nsplit = 1;                                                      // >= ~2048 blocks: the kernel waits on its logit / label loads, occupancy hides them
+    while ((long)D * B * P.nsplit < 2048 && (long)H * (W >> 2) / (P.nsplit * 2) >= 256) P.nsplit *= 2;
+    const dim3 grid(D * P.nsplit, B), blk(256);
+    size_t shm = vx_ds_slice_floats(P, C) * sizeof(float);
+    P.stage = shm <= 120 * 1024;          // else: 8-tap gathers from global memory
     if (!P.stage) shm = 0;
 #define VX_DS_FWD(CC)                                                                                                                 \
     {                                                                                                                                 \
@@ -439,8 +500,8 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
         ntab += (size_t)wl * bwd_;
     }
     const size_t shm_base = ((size_t)4 * nacc + (size_t)4 * RPW * 3 * C * W + ((ntab + 3) & ~(size_t)3) + (size_t)3 * W) * sizeof(float);
-    P.stage = shm_base + vx_ds_low_floats(P, C) * sizeof(float) <= 150 * 1024;
-    const size_t shm = shm_base + (P.stage ? vx_ds_low_floats(P, C) * sizeof(float) : 0);
+    P.stage = shm_base + vx_ds_slice_floats(P, C) * sizeof(float) <= 150 * 1024;
+    const size_t shm = shm_base + (P.stage ? vx_ds_slice_floats(P, C) * sizeof(float) : 0);
     VX_REQUIRE(shm <= 150 * 1024, "vx_seg_loss_ds_bwd: the low-resolution grids do not fit LDS (%zu bytes)", shm);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(D, B), blk(256);
