@@ -247,6 +247,7 @@ int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, in
 /* all M <= 4 modalities in one launch per kernel kind (host arrays of M device pointers) */
 int vx_pwa_scatter_fwd_all(const float* tok, float* const* outs, const VxPwaPlan* plan, int c, int M, int B, void* stream);
 int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream);
+int vx_pwa_attn_set_fused_bwd(int on); /* A/B knob: 1 (default) = the dQ and dK/dV passes of vx_pwa_attn_bwd share one launch (interleaved blocks), 0 = two launches */
 int vx_pwa_scatter_set_ident(int on);   /* A/B knob: 1 (default) = 1x1x1 small windows take the transpose kernel, 0 = always the general adjoint */
 /* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).
  * O: (B,heads,Ntot,M*l,cv); LSE: (B,heads,Ntot,M*l).  bwd: dtable += ; delta_ws = vx_pwa_attn_bwd_ws_floats(plan, B, M) floats

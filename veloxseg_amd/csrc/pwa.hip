@@ -718,10 +718,10 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
 #define VX_PRIV_BINS 256
 #define VX_DTABLE_REPLICAS 16
 template <int CQ, int CV>
-__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
-                                                           const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
-                                                           const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+__device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                   const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                   const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
+                                                   float* __restrict__ dtable_rep, int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head) {
     constexpr int RS = CQ + CV;
     // lin | bias tables | bias-gradient tables | [4] K/V slabs.  one_head (every unit of a block belongs to one head: launcher): ONE bias column and ONE
     // bias-gradient table shared by the block's waves (they reach it through ds_add_f32 only); else all heads and a table per unit.
@@ -740,13 +740,13 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    const int a_blk = (int)((((long)blockIdx.x * upb / chunks) / A.Nt) % A.heads);      // head of the block's first unit
+    const int a_blk = (int)((((long)bid * upb / chunks) / A.Nt) % A.heads);      // head of the block's first unit
     vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? a_blk : -1);
     for (int k = threadIdx.x; k < ntab * Tsz; k += 256) gtabs[k] = 0.0f;
     __syncthreads();
     const VxDropCtx dc = vx_drop_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
-    const long u_raw = (long)blockIdx.x * upb + wave / S;
+    const long u_raw = (long)bid * upb + wave / S;
     const bool active = u_raw < units;
     const long u = active ? u_raw : units - 1;
     const int chunk = (int)(u % chunks);
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
         }
     }
     // one of VX_DTABLE_REPLICAS copies per block: thousands of blocks adding into the same few hundred addresses serialise in L2
-    float* __restrict__ dst = dtable_rep + (long)(blockIdx.x % VX_DTABLE_REPLICAS) * Tsz * A.heads;
+    float* __restrict__ dst = dtable_rep + (long)(bid % VX_DTABLE_REPLICAS) * Tsz * A.heads;
     if (one_head) {    // the block's shared table (complete after the barrier above), all threads
         for (int k = threadIdx.x; k < Tsz; k += 256) {
             const float g = gtabs[k];
@@ -881,18 +881,28 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restri
     }
 }
 
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                           const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                           const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
+                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+    vx_attn_bwd_q_body<CQ, CV>((int)blockIdx.x, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head);
+}
+
 // backward B: lane = key row.  dK, dV.  Query-side rows (q, dO, lse, delta) are staged per wave in LDS; the S splits of a unit walk
 // interleaved query slabs and are summed through LDS.  Dropout: lane (quad position t) draws the Philox counter of query row i+t
 // for its quad's 4 keys; a quad transpose (DPP) hands every lane its own key's word for the 4 rows -> one Philox call per 4 pairs.
+// Delta == nullptr: delta = rowsum(dO * O) is recomputed from O while the query slab is staged, and the replicas are NOT folded here (the kernel then
+// has no input from the dQ pass and runs in the same launch: vx_pwa_attn_bwd_both_k)
 template <int CQ, int CV>
-__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
-                                                            const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
-                                                            const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
-                                                            const float* __restrict__ dtable_rep, float* __restrict__ dtable,
-                                                            int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+__device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbid, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                    const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                    const float* __restrict__ O, const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
+                                                    const float* __restrict__ dtable_rep, float* __restrict__ dtable,
+                                                    int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
-    {   // fold the dQ kernel's replicated bias-gradient tables into dtable (it ran before this kernel on the same stream): one owner thread per entry
-        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < (long)Tsz * A.heads; k += (long)gridDim.x * 256) {
+    if (Delta) {   // fold the dQ kernel's replicated bias-gradient tables into dtable (it ran before this kernel on the same stream): one owner thread per entry
+        for (long k = (long)bid * 256 + threadIdx.x; k < (long)Tsz * A.heads; k += (long)nbid * 256) {
             float g = 0.0f;
 #pragma unroll
             for (int r = 0; r < VX_DTABLE_REPLICAS; ++r) g += dtable_rep[(long)r * Tsz * A.heads + k];
@@ -906,13 +916,13 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
     float* __restrict__ slabs = bias_all + (((long)Tsz * (one_head ? 1 : A.heads) + 3) & ~3);
     const int chunks = (A.ML + 63) / 64;
     const long units = (long)A.BH * A.Nt * chunks;
-    vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)blockIdx.x * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
+    vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)bid * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
     __syncthreads();
     const VxDropCtx dc = vx_drop_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = wave % S;
-    const long u_raw = (long)blockIdx.x * (4 / S) + wave / S;
+    const long u_raw = (long)bid * (4 / S) + wave / S;
     const bool active = u_raw < units;
     const long u = active ? u_raw : units - 1;
     float* __restrict__ slab = slabs + (long)wave * VX_KV_ROWS * RS;
@@ -944,7 +954,15 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
 #pragma unroll
             for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = dop[(long)(i0 + lane) * CV + c];
             slab[lane * RS + CQ + CV] = LSE[win * A.ML + i0 + lane];
-            slab[lane * RS + CQ + CV + 1] = Delta[win * A.ML + i0 + lane];
+            float dl;
+            if (Delta) dl = Delta[win * A.ML + i0 + lane];
+            else {
+                const float* __restrict__ orow = O + (win * A.ML + i0 + lane) * CV;
+                dl = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CV; ++c) dl = fmaf(dop[(long)(i0 + lane) * CV + c], orow[c], dl);      // same order as the dQ pass: identical bits
+            }
+            slab[lane * RS + CQ + CV + 1] = dl;
         }
         __builtin_amdgcn_wave_barrier();
         for (int ii = 0; ii < nq; ii += 4) {
@@ -1008,6 +1026,35 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
 #pragma unroll
         for (int c = 0; c < CV; ++c) dV[krow * CV + c] = dv[c];
     }
+}
+
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                            const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                            const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
+                                                            const float* __restrict__ dtable_rep, float* __restrict__ dtable,
+                                                            int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+    vx_attn_bwd_kv_body<CQ, CV>((int)blockIdx.x, (int)gridDim.x, Q, K, Vt, table, LSE, Delta, nullptr, dO, dK, dV, dtable_rep, dtable, Tsz, A, drop, S, one_head);
+}
+// Both passes in ONE launch: even blocks run the dQ pass, odd blocks the dK / dV pass of the same block index.  Each pass alone leaves the SIMDs waiting
+// (dQ: 53 % of its wave cycles in s_waitcnt, dK/dV: 31 % + 20 % stalled; profiles/r02_sq_wave_breakdown.txt); interleaved on the same CUs they fill each
+// other's gaps, and the stream loses one launch boundary.  The dK/dV blocks recompute delta, and the replica fold moves to vx_attn_fold_k.
+template <int CQ, int CV>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd_both_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                              const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                              const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                              float* __restrict__ Delta, float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+    const int bid = (int)(blockIdx.x >> 1);
+    if (blockIdx.x & 1) vx_attn_bwd_kv_body<CQ, CV>(bid, (int)(gridDim.x >> 1), Q, K, Vt, table, LSE, nullptr, O, dO, dK, dV, nullptr, nullptr, Tsz, A, drop, S, one_head);
+    else vx_attn_bwd_q_body<CQ, CV>(bid, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head);
+}
+// dtable[k] += sum over the replicas (vx_pwa_attn_bwd_both_k's dQ blocks filled them)
+__global__ void __launch_bounds__(256) vx_attn_fold_k(const float* __restrict__ rep, float* __restrict__ dtable, long n, int nrep) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float g = 0.0f;
+    for (int r = 0; r < nrep; ++r) g += rep[(long)r * n + k];
+    dtable[k] += g;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1188,6 +1235,8 @@ static int vx_attn_fill(VxAttn& A, const VxPwaPlan* P, int B, int M, int cq, int
 }
 
 // key/query split S of the attention kernels: enough waves to fill 256 CUs x 4 SIMDs several times over, never more splits than slabs
+static int vx_attn_bwd_fused = 1;
+extern "C" int vx_pwa_attn_set_fused_bwd(int on) { vx_attn_bwd_fused = on ? 1 : 0; return 0; }      // A/B: dQ and dK/dV passes in one launch (default) or two
 static int vx_attn_split_override = 0;
 extern "C" int vx_pwa_attn_set_split(int S) {
     if (S != 0 && S != 1 && S != 2 && S != 4) VX_FAIL(-1, "vx_pwa_attn_set_split: S must be 0 (auto), 1, 2 or 4");
@@ -1299,6 +1348,13 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
     }
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
+        if (vx_attn_bwd_fused) {
+            const size_t shm2 = shm > shm_kv ? shm : shm_kv;
+            vx_pwa_attn_bwd_both_k<CQ, CV><<<dim3(2 * nblk), dim3(256), shm2, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws, rep, Tsz, A, d, S, one_head);
+            const long nt = (long)Tsz * A.heads;
+            vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
+            return;
+        }
         vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S, one_head);
         vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S, one_head);
     });
