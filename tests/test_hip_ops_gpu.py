@@ -749,3 +749,38 @@ def test_row_sliding_weight_gradient_of_the_jlc_convs(C, G, K, sp, B):
         close(db, ref_b, 2e-5 * max(1.0, float(ref_b.abs().max())), 1e-4, f"rows={rows} db")
         outs[rows] = dw
     close(outs[1], outs[0], 2e-5 * max(1.0, float(ref_w.abs().max())), 1e-4, "rows vs pairs")
+
+
+@pytest.mark.parametrize("grid,big,heads,mdh,C,M,B", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2, 3), ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2, 2),
+                                                      ([6, 6, 6], [3, 3, 3], 2, 8, 32, 2, 1), ([12, 12, 12], [6, 6, 6], 1, 4, 16, 1, 2)],
+                         ids=["c8v8_ML1024", "c8v16", "c4v8", "w3_ragged_units", "w6_M1"])
+def test_pwa_attention_backward_in_one_launch_equals_the_two_pass_backward(grid, big, heads, mdh, C, M, B):
+    """vx_pwa_attn_bwd with the dQ and dK/dV passes interleaved in ONE launch (the dK/dV blocks recompute delta = rowsum(dO * O), the bias-gradient
+    replicas are folded by their own kernel) against the two-launch form, dropout ON: dq / dk / dv to fp32 round-off (same arithmetic in the same order), the
+    bias-table gradient to float-atomic noise.  The 3^3 / 6^3 windows are the 96^3 configurations (blocks whose units straddle heads keep all bias columns)."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    n = pl["n"]
+    base = []
+    for m in range(M):
+        base += [rnd(B, pl["ch_qk"], *grid, seed=10 + m), rnd(B, pl["ch_qk"], *grid, seed=20 + m), rnd(B, pl["ch_v"], *grid, seed=30 + m)]
+    res = {}
+    try:
+        for on in (1, 0):
+            H.call("vx_pwa_attn_set_fused_bwd", on)
+            VF.manual_seed(77, d)
+            table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=0.2, site=9)
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gouts)
+            torch.cuda.synchronize()
+            res[on] = [x.grad for x in t] + [table.grad.clone()]
+    finally:
+        H.call("vx_pwa_attn_set_fused_bwd", 1)
+    for i, (a, b) in enumerate(zip(res[1][:-1], res[0][:-1])):      # (the two instantiations of a pass may contract a * b + c differently: not bit-equal)
+        close(a, b, 4e-6 * max(1.0, float(b.abs().max())), 1e-5, f"input gradient {i}: one launch vs two")
+    close(res[1][-1], res[0][-1], 3e-5 * max(1.0, float(res[0][-1].abs().max())), 2e-4, "bias-table gradient")
