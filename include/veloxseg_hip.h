@@ -199,6 +199,10 @@ int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* d
                  int B, int C, long V, float eps, void* stream);
 int vx_ln_cf_bwd_add(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* dgamma, float* dbeta, float* ws,
                      int B, int C, long V, float eps, void* stream);   /* dx = add + LayerNorm backward (add != dx) */   /* dgamma/dbeta: += ; ws = 2*B*V floats of workspace */
+/* the two halves of vx_ln_cf_bwd(_add) as entries of their own (attention_utils.py:29-43 backward): _data = input gradient (add may be NULL) and the
+ * per-voxel statistics in ws (2*B*V floats); _param = dgamma / dbeta (+=) from x, dout and ws.  Only the first is on the backward's dependent chain. */
+int vx_ln_cf_bwd_data(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* ws, int B, int C, long V, float eps, void* stream);
+int vx_ln_cf_bwd_param(const float* x, const float* dout, const float* ws, float* dgamma, float* dbeta, int B, int C, long V, void* stream);
 
 /* element-wise pieces: h = drop(gelu(a)) (attention_utils.py:64-66, conv_blocks.py:66); out = alpha*x + drop(z)
  * (PWA.py:377 + :436 double residual, attention_utils.py:68-70, conv_blocks.py:69,74, Encoder.py:196) */
@@ -261,6 +265,13 @@ int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float*
                     const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
                     const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+/* vx_pwa_attn_bwd without its last step: the bias-table gradient (attention_utils.py:120-125) stays in the replicas inside delta_ws until
+ * vx_pwa_attn_bwd_fold adds them to dtable.  _nofold returns 1 (nothing launched) when this geometry / mode folds inside its kernels: use vx_pwa_attn_bwd. */
+int vx_pwa_attn_bwd_nofold(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                           const float* dO, float* dQ, float* dK, float* dV, float* delta_ws,
+                           const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                           const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
+int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const VxPwaPlan* plan, int B, int M, void* stream);
 /* tuning knob of the two entries above: key/query split per 64-row unit (0 = automatic from the unit count, else 1, 2 or 4; clamped to the
  * number of 64-row slabs).  Results are identical up to fp32 summation order; the dropout mask does not depend on it. */
 int vx_pwa_attn_set_split(int S);

@@ -784,3 +784,29 @@ def test_pwa_attention_backward_in_one_launch_equals_the_two_pass_backward(grid,
     for i, (a, b) in enumerate(zip(res[1][:-1], res[0][:-1])):      # (the two instantiations of a pass may contract a * b + c differently: not bit-equal)
         close(a, b, 4e-6 * max(1.0, float(b.abs().max())), 1e-5, f"input gradient {i}: one launch vs two")
     close(res[1][-1], res[0][-1], 3e-5 * max(1.0, float(res[0][-1].abs().max())), 2e-4, "bias-table gradient")
+
+
+@pytest.mark.parametrize("B,C,sp", [(2, 16, (8, 8, 8)), (3, 32, (4, 6, 5)), (2, 128, (4, 4, 4)), (1, 64, (16, 16, 16))])
+def test_layernorm_backward_halves_equal_the_whole(B, C, sp):
+    """vx_ln_cf_bwd_data + vx_ln_cf_bwd_param (the input gradient now, the parameter gradients whenever the caller likes: csrc/norm.hip) == vx_ln_cf_bwd
+    and == vx_ln_cf_bwd_add, bit for bit (the same two kernels, launched by two entries)"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    V = sp[0] * sp[1] * sp[2]
+    x, dout, add = rnd(B, C, *sp, seed=1).to(d), rnd(B, C, *sp, seed=2).to(d), rnd(B, C, *sp, seed=3).to(d)
+    gamma = rnd(C, seed=4).to(d)
+    st = H.stream_ptr()
+    for with_add in (False, True):
+        dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+        dg0, db0, dg1, db1 = (torch.zeros(C, device=d) for _ in range(4))
+        ws0, ws1 = torch.empty(2 * B * V, device=d), torch.empty(2 * B * V, device=d)
+        if with_add:
+            H.call("vx_ln_cf_bwd_add", H.P(x), H.P(gamma), H.P(dout), H.P(add), H.P(dx0), H.P(dg0), H.P(db0), H.P(ws0), B, C, V, 1e-6, st)
+        else:
+            H.call("vx_ln_cf_bwd", H.P(x), H.P(gamma), H.P(dout), H.P(dx0), H.P(dg0), H.P(db0), H.P(ws0), B, C, V, 1e-6, st)
+        H.call("vx_ln_cf_bwd_data", H.P(x), H.P(gamma), H.P(dout), H.P(add) if with_add else None, H.P(dx1), H.P(ws1), B, C, V, 1e-6, st)
+        H.call("vx_ln_cf_bwd_param", H.P(x), H.P(dout), H.P(ws1), H.P(dg1), H.P(db1), B, C, V, st)
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1)
+        close(dg1, dg0, 1e-5 * max(1.0, float(dg0.abs().max())), 1e-5, "dgamma")      # float atomics across chunks
+        close(db1, db0, 1e-5 * max(1.0, float(db0.abs().max())), 1e-5, "dbeta")

@@ -374,6 +374,14 @@ Tensor ln_bwd_impl(LNState& st, const Tensor& dout_in, void* stream, const Tenso
     const long V = st.x.numel() / ((long)B * C);
     Tensor dx = at::empty_like(st.x);
     Tensor ws = at::empty({2 * (long)B * V}, st.x.options());
+    if (WG.enabled && (st.g.requires_grad() || st.bt.requires_grad())) {      // deferral on: the parameter gradients leave the chain (a closure that owns x, dout, ws)
+        Tensor addc = add.defined() ? contig(add) : Tensor();
+        VX(vx_ln_cf_bwd_data, fp(st.x), fp(st.g), fp(dout), fp(addc), mp(dx), mp(ws), B, C, V, (float)F.ln_eps, stream);
+        Tensor x = st.x;
+        float* dg = grad_ptr(st.g); float* db = grad_ptr(st.bt);
+        wgrad_submit(stream, dx.device().index(), [=](void* s) { VX(vx_ln_cf_bwd_param, fp(x), fp(dout), fp(ws), dg, db, B, C, V, s); });
+        return dx;
+    }
     if (add.defined()) {
         Tensor addc = contig(add);
         VX(vx_ln_cf_bwd_add, fp(st.x), fp(st.g), fp(dout), fp(addc), mp(dx), grad_ptr(st.g), grad_ptr(st.bt), mp(ws), B, C, V, (float)F.ln_eps, stream);
@@ -715,6 +723,18 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         Tensor dtab_tmp;
         float* dtab = grad_ptr(st.table);
         if (!dtab) { dtab_tmp = at::zeros_like(st.tbl); dtab = dtab_tmp.data_ptr<float>(); }
+        int rc_nf = 1;
+        if (WG.enabled) {                  // deferral on: the fold of the bias-table gradient (a parameter gradient) leaves the chain
+            rc_nf = vx_pwa_attn_bwd_nofold(fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), mp(delta), pp, B, M, st.cq, st.cv,
+                                           st.rs, (unsigned long long)st.site, (float)st.p, s_);
+            if (rc_nf != 0 && rc_nf != 1) chk(rc_nf, "vx_pwa_attn_bwd_nofold");
+            if (rc_nf == 0) {
+                const VxPwaPlan plan_copy = st.plan;
+                Tensor keep_tmp = dtab_tmp;
+                wgrad_submit(s_, dq.device().index(), [=](void* s) { VX(vx_pwa_attn_bwd_fold, fp(delta), dtab, &plan_copy, B, M, s); (void)keep_tmp; });
+            }
+        }
+        if (rc_nf == 1)
         VX(vx_pwa_attn_bwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), dtab, mp(delta), pp, B, M, st.cq, st.cv,
            st.rs, (unsigned long long)st.site, (float)st.p, s_);
         float* dsts[12];

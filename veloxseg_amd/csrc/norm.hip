@@ -539,18 +539,34 @@ extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* bet
     return 0;
 }
 
+// parts: 1 = input gradient (+ the per-voxel statistics in ws), 2 = parameter gradients from ws, 3 = both
 static int vx_ln_cf_bwd_run(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* dgamma, float* dbeta, float* ws,
-                            int B, int C, long V, float eps, void* stream) {
-    VX_REQUIRE(x && gamma && dout && dx && dgamma && dbeta && ws && add != dx, "vx_ln_cf_bwd: bad pointers");
-    if (vx_ln_use_lanes(B, C, V))
-        vx_ln_cf_lanes_k<true><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, add, dout, dx, ws, C, V, (long)B * V, eps);
-    else
-        hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps, add);
-    int chunks = vx_cdiv((long)B * V, 256 * 8);
-    if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL(vx_ln_cf_bwd_param_k, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, x, dout, ws, dgamma, dbeta, B, C, V);
+                            int B, int C, long V, float eps, void* stream, int parts = 3) {
+    VX_REQUIRE(x && dout && ws && B > 0 && C > 0 && V > 0, "vx_ln_cf_bwd: bad pointers");
+    if (parts & 1) {
+        VX_REQUIRE(gamma && dx && add != dx, "vx_ln_cf_bwd: bad pointers");
+        if (vx_ln_use_lanes(B, C, V))
+            vx_ln_cf_lanes_k<true><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, add, dout, dx, ws, C, V, (long)B * V, eps);
+        else
+            hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps, add);
+    }
+    if (parts & 2) {
+        VX_REQUIRE(dgamma && dbeta, "vx_ln_cf_bwd: bad pointers");
+        int chunks = vx_cdiv((long)B * V, 256 * 8);
+        if (chunks > 64) chunks = 64;
+        hipLaunchKernelGGL(vx_ln_cf_bwd_param_k, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, x, dout, ws, dgamma, dbeta, B, C, V);
+    }
     VX_LAUNCH_CHECK("vx_ln_cf_bwd");
     return 0;
+}
+// The two halves of vx_ln_cf_bwd / vx_ln_cf_bwd_add as entries of their own: only the input gradient is on the backward's dependent chain, the
+// parameter gradients (from x, dout and the per-voxel statistics the first half left in ws) are a sink that the caller may launch later.
+extern "C" int vx_ln_cf_bwd_data(const float* x, const float* gamma, const float* dout, const float* add, float* dx, float* ws, int B, int C, long V, float eps,
+                                 void* stream) {
+    return vx_ln_cf_bwd_run(x, gamma, dout, add, dx, nullptr, nullptr, ws, B, C, V, eps, stream, 1);
+}
+extern "C" int vx_ln_cf_bwd_param(const float* x, const float* dout, const float* ws, float* dgamma, float* dbeta, int B, int C, long V, void* stream) {
+    return vx_ln_cf_bwd_run(x, nullptr, dout, nullptr, nullptr, dgamma, dbeta, const_cast<float*>(ws), B, C, V, 0.0f, stream, 2);
 }
 extern "C" int vx_ln_cf_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta, float* ws,
                             int B, int C, long V, float eps, void* stream) {

@@ -1316,10 +1316,41 @@ extern "C" int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M) {
     return (int)n;
 }
 
+static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                               const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
+                               const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold);
 extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
                                const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
+    return vx_pwa_attn_bwd_run(Q, K, V, table, O, LSE, dO, dQ, dK, dV, dtable, delta_ws, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, stream, true);
+}
+// vx_pwa_attn_bwd without its last step: the bias-table gradient stays in the replicas of delta_ws until vx_pwa_attn_bwd_fold adds them to dtable (a
+// parameter gradient: nothing on the backward's dependent chain waits for it, the caller may launch the fold later).  Returns 1 and launches nothing
+// when this geometry / mode folds inside its kernels (MFMA backward, two-launch backward): the caller then uses vx_pwa_attn_bwd.
+extern "C" int vx_pwa_attn_bwd_nofold(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                                      const float* dO, float* dQ, float* dK, float* dV, float* delta_ws,
+                                      const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                                      const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
+    if (!vx_attn_bwd_fused || (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2)) return 1;
+    return vx_pwa_attn_bwd_run(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws /* unused, non-null */, delta_ws, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, stream, false);
+}
+extern "C" int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const VxPwaPlan* plan, int B, int M, void* stream) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, 4, 4, "vx_pwa_attn_bwd_fold")) return e;
+    VX_REQUIRE(delta_ws && dtable, "vx_pwa_attn_bwd_fold: null pointer");
+    const long Tsz = (long)(2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+    const long rows = (long)A.BH * A.Nt * A.ML;
+    const long nt = Tsz * A.heads;
+    vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(delta_ws + ((rows + 3) & ~3L), dtable, nt, VX_DTABLE_REPLICAS);
+    VX_LAUNCH_CHECK("vx_pwa_attn_bwd_fold");
+    return 0;
+}
+static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                               const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
+                               const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold) {
     VxAttn A;
     if (int e = vx_attn_fill(A, plan, B, M, cq, cv, "vx_pwa_attn_bwd")) return e;
     VX_REQUIRE(Q && K && V && table && O && LSE && dO && dQ && dK && dV && dtable && delta_ws, "vx_pwa_attn_bwd: null pointer");
@@ -1352,7 +1383,7 @@ extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, c
             const size_t shm2 = shm > shm_kv ? shm : shm_kv;
             vx_pwa_attn_bwd_both_k<CQ, CV><<<dim3(2 * nblk), dim3(256), shm2, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws, rep, Tsz, A, d, S, one_head);
             const long nt = (long)Tsz * A.heads;
-            vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
+            if (fold) vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
             return;
         }
         vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S, one_head);
