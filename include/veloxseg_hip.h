@@ -382,6 +382,14 @@ int vx_tape_replay(VxTape* tape, void* stream);
 int vx_tape_free(VxTape* tape);
 /* markers: vx_tape_mark(id, stream) inside the captured code; the tape records an event at that point of its schedule instead of launching anything,
  * vx_tape_wait_marker makes `stream` wait for it (after vx_tape_replay has been called for this step).  vx_tape_has_marker: 1 / 0. */
+/* cross-lane dependency without an event (csrc/tape.hip): _set stores `value` to the device word `flag` once the stream reaches it, _wait holds the
+ * stream until the word has reached `value` (wrap-around compare).  ONLY between streams on different hardware queues (vx_tape_lanes_distinct). */
+int vx_tape_flag_set(void* flag, int value, void* stream);
+int vx_tape_flag_wait(const void* flag, int value, void* stream);
+int vx_tape_set_flags(int on);   /* A/B: cross-lane dependencies inside a tape through flag kernels (1, default; VELOXSEG_TAPE_FLAGS=0 in the environment turns it off) or events (0) */
+/* `dst` waits for everything enqueued on `src` so far (event record + wait, or -- flags on -- a set kernel on src and a poll kernel on dst);
+ * slot 0..255 names the call site, which must always pass the same src stream */
+int vx_tape_hop(int slot, void* src, void* dst);
 int vx_tape_mark(int id, void* stream);
 int vx_tape_wait_marker(VxTape* tape, int id, void* stream);
 int vx_tape_has_marker(const VxTape* tape, int id);

@@ -32,6 +32,7 @@ struct TapeNode {
     std::vector<int> waits;             // events (indices of earlier nodes on other lanes) to wait for before the launch
     bool record = false;                // some later node on another lane waits for this one
     hipEvent_t ev = nullptr;
+    int flag = -1;                      // record nodes: slot in the tape's device flag words (cross-lane dependencies through flag kernels)
 };
 }  // namespace
 
@@ -42,6 +43,10 @@ struct VxTape {
     hipEvent_t start = nullptr;
     std::vector<hipEvent_t> lane_end;
     int n_kernels = 0, n_events = 0, n_cross = 0;
+    unsigned* flags = nullptr;          // one device word per recording node; replay r stores r, waiters poll for >= r (no reset between replays)
+    unsigned seq = 0;
+    int flag_start = 0;
+    hipStream_t last_s0 = nullptr;
 };
 
 #define HIPQ(call, what)                                                                      \
@@ -60,6 +65,61 @@ struct VxTape {
 __global__ void vx_spin_k(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) {}
+}
+// Cross-lane dependencies without events: the producing lane runs a one-thread kernel that stores a sequence number to a device flag; the waiting
+// lane runs a one-wave kernel that polls the flag until it reaches that number.  On this runtime an event record + stream wait costs ~14 us of
+// queue time per hop (tools/event_hop_probe.py: every flag combination of hipEventCreateWithFlags); two back-to-back tiny kernels cost ~1.6 us each.
+// Safe only when the two lanes sit on different hardware queues (the poll would otherwise block the kernel it waits for): tape.hip uses it only
+// between lanes of the calibrated pool, and only when the calibration found them pairwise overlapping.
+__global__ void vx_flag_set_k(unsigned* flag, unsigned value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void vx_flag_wait_k(const unsigned* flag, unsigned value) {
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 500000000LL) __builtin_trap();      // 5 s at 100 MHz: a dependency that never arrives must fail, not hang the GPU
+        }
+    }
+}
+static int g_use_flags = -1;            // -1: from the environment (VELOXSEG_TAPE_FLAGS, default on)
+static bool use_flags() {
+    if (g_use_flags < 0) { const char* e = getenv("VELOXSEG_TAPE_FLAGS"); g_use_flags = (e && e[0] == '0') ? 0 : 1; }
+    return g_use_flags == 1;
+}
+extern "C" int vx_tape_set_flags(int on) { g_use_flags = on ? 1 : 0; return 0; }
+// `dst` waits for everything enqueued on `src` so far -- hipEventRecord + hipStreamWaitEvent, or (flags on) a set kernel on src and a poll kernel on dst.
+// `slot` (0..255) names the call site: a site must always use the same src stream (its sequence numbers rely on that stream's order).
+static unsigned* g_hop_flags = nullptr;
+static unsigned g_hop_seq[256] = {};
+static hipEvent_t g_hop_ev[256] = {};
+static void* g_hop_src[256] = {};
+extern "C" int vx_tape_hop(int slot, void* src, void* dst) {
+    if (slot < 0 || slot >= 256) return -1;
+    if (src == dst) return 0;
+    if (use_flags()) {
+        if (!g_hop_flags) {
+            if (hipMalloc((void**)&g_hop_flags, sizeof(unsigned) * 256) != hipSuccess || hipMemset(g_hop_flags, 0, sizeof(unsigned) * 256) != hipSuccess) return -2;
+        }
+        if (g_hop_src[slot] && g_hop_src[slot] != src) (void)hipStreamSynchronize((hipStream_t)g_hop_src[slot]);      // the site changed its source stream (rare): keep the order
+        g_hop_src[slot] = src;
+        const unsigned seq = ++g_hop_seq[slot];
+        hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, (hipStream_t)src, g_hop_flags + slot, seq);
+        hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, (hipStream_t)dst, (const unsigned*)(g_hop_flags + slot), seq);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (!g_hop_ev[slot] && hipEventCreateWithFlags(&g_hop_ev[slot], hipEventDisableTiming) != hipSuccess) return -2;
+    if (hipEventRecord(g_hop_ev[slot], (hipStream_t)src) != hipSuccess || hipStreamWaitEvent((hipStream_t)dst, g_hop_ev[slot], 0) != hipSuccess) return -2;
+    return 0;
+}      // A/B: cross-lane dependencies through flag kernels (1) or events (0)
+extern "C" int vx_tape_flag_set(void* flag, int value, void* stream) {
+    hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)flag, (unsigned)value);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int vx_tape_flag_wait(const void* flag, int value, void* stream) {
+    hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned)value);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 namespace {
 constexpr int kPool = 4;
@@ -302,8 +362,16 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
     T->lane_end.assign(tail.size(), nullptr);
     for (size_t l = 0; l < tail.size(); ++l) HIPQ(hipEventCreateWithFlags(&T->lane_end[l], hipEventDisableTiming), "hipEventCreateWithFlags");
     HIPQ(hipEventCreateWithFlags(&T->start, hipEventDisableTiming), "hipEventCreateWithFlags");
+    int nflags = 0;
     for (auto& nd : T->nodes)
-        if (nd.record || nd.marker >= 0) { HIPQ(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming), "hipEventCreateWithFlags"); T->n_events++; }
+        if (nd.record || nd.marker >= 0) {
+            HIPQ(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming), "hipEventCreateWithFlags"); T->n_events++;
+            if (nd.marker < 0) nd.flag = nflags++;
+        }
+    T->flag_start = nflags;                       // + 1 word for the start gate, + 1 per lane for the joins
+    nflags += 1 + (int)tail.size();
+    HIPQ(hipMalloc((void**)&T->flags, sizeof(unsigned) * (size_t)nflags), "hipMalloc");
+    HIPQ(hipMemset(T->flags, 0, sizeof(unsigned) * (size_t)nflags), "hipMemset");
     *out = T;
     return 0;
 }
@@ -352,20 +420,46 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
         int rc = pool_init(s0);
         if (rc) return rc;
         for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[l % kPool];
-        HIPQ(hipEventRecord(T->start, s0), "hipEventRecord");
-        for (size_t l = 0; l < L && l < (size_t)kPool; ++l) HIPQ(hipStreamWaitEvent(T->lanes[l], T->start, 0), "hipStreamWaitEvent");
     }
+    const bool fl = use_flags() && T->flags != nullptr;
+    const unsigned seq = ++T->seq;
+    if (L > 1) {
+        if (fl) {
+            if (T->last_s0 && T->last_s0 != s0) (void)hipStreamSynchronize(T->last_s0);      // another caller stream than last time (rare): its set kernel must not be overtaken
+            T->last_s0 = s0;
+            hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s0, T->flags + T->flag_start, seq);
+            for (size_t l = 0; l < L && l < (size_t)kPool; ++l)
+                if (T->lanes[l] != s0) hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, T->lanes[l], (const unsigned*)(T->flags + T->flag_start), seq);
+        } else {
+            HIPQ(hipEventRecord(T->start, s0), "hipEventRecord");
+            for (size_t l = 0; l < L && l < (size_t)kPool; ++l) HIPQ(hipStreamWaitEvent(T->lanes[l], T->start, 0), "hipStreamWaitEvent");
+        }
+    }
+    // cross-lane dependencies: flag kernels (~2 us of queue time per hop) instead of event record + stream wait (~14 us: tools/event_hop_probe.py).
+    // Deadlock-free for any stream -> hardware-queue mapping as long as a hardware queue runs its packets in submission order: the set kernel of a
+    // dependency is always submitted before its poll kernel (the nodes are in topological order), so the earliest unfinished packet can always run.
     for (TapeNode& nd : T->nodes) {
         hipStream_t s = T->lanes[nd.lane];
-        for (int w : nd.waits) HIPQ(hipStreamWaitEvent(s, T->nodes[w].ev, 0), "hipStreamWaitEvent");
+        for (int w : nd.waits) {
+            const TapeNode& src = T->nodes[w];
+            if (fl && src.flag >= 0) hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s, (const unsigned*)(T->flags + src.flag), seq);
+            else HIPQ(hipStreamWaitEvent(s, src.ev, 0), "hipStreamWaitEvent");
+        }
         if (nd.marker < 0) { int rc = tape_launch(nd, s); if (rc) return rc; }
-        if (nd.record || nd.marker >= 0) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
+        if (nd.marker >= 0 || (nd.record && !(fl && nd.flag >= 0))) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
+        else if (nd.record) hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s, T->flags + nd.flag, seq);
     }
+    if (fl && hipGetLastError() != hipSuccess) VX_FAIL(-2, "vx_tape_replay: a flag kernel could not be launched");
     if (L > 1)
         for (size_t l = 0; l < L; ++l)
-            if (T->lane_last[l] >= 0) {
-                HIPQ(hipEventRecord(T->lane_end[l], T->lanes[l]), "hipEventRecord");
-                HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");
+            if (T->lane_last[l] >= 0 && T->lanes[l] != s0) {
+                if (fl && l < (size_t)kPool) {
+                    hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, T->lanes[l], T->flags + T->flag_start + 1 + l, seq);
+                    hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s0, (const unsigned*)(T->flags + T->flag_start + 1 + l), seq);
+                } else {
+                    HIPQ(hipEventRecord(T->lane_end[l], T->lanes[l]), "hipEventRecord");
+                    HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");
+                }
             }
     return 0;
 }
@@ -392,6 +486,7 @@ extern "C" int vx_tape_free(VxTape* T) {
     }
     for (size_t l = 0; l < T->lane_end.size(); ++l) if (T->lane_end[l]) (void)hipEventDestroy(T->lane_end[l]);
     if (T->start) (void)hipEventDestroy(T->start);
+    if (T->flags) (void)hipFree(T->flags);
     delete T;
     return 0;
 }

@@ -667,30 +667,38 @@ class TrainEngine:
             cache[n] = out
         return cache[n]
 
-    def _fan(self, graphs):
+    def _hop(self, slot, src, dst):
+        """dst waits for what is enqueued on src: in tape mode through the tape's flag kernels (csrc/tape.hip vx_tape_hop: ~2 us of queue time per hop
+        against ~14 us for an event record + wait on this runtime), else an event"""
+        if self.replay_mode == "tape":
+            H.call("vx_tape_hop", int(slot), src.cuda_stream, dst.cuda_stream)
+        else:
+            dst.wait_stream(src)
+
+    def _fan(self, graphs, slot0=0):
         cur = torch.cuda.current_stream(self.dev)
         streams = self._lane_streams(len(graphs)) if self.replay_mode == "tape" else self.branch_streams
-        for s_, g in zip(streams, graphs):
-            s_.wait_stream(cur)
+        for k, (s_, g) in enumerate(zip(streams, graphs)):
+            self._hop(slot0 + k, cur, s_)
             with torch.cuda.stream(s_):
                 g.replay()
-        for s_ in streams:
-            cur.wait_stream(s_)
+        for k, s_ in enumerate(streams[:len(graphs)]):
+            self._hop(slot0 + 8 + k, s_, cur)
 
     def _replay(self, comm: bool):
         """enc_fwd, {dec_fwd}, loss, {dec_bwd}, [decoder bucket all-reduce on the comm stream ||] enc_bwd, [encoder bucket all-reduce]"""
         G = self.graphs
         cur = torch.cuda.current_stream(self.dev)
         G["enc_fwd"].replay()
-        self._fan(G["dec_fwd"])
+        self._fan(G["dec_fwd"], 0)
         G["loss"].replay()
-        self._fan(G["dec_bwd"])
+        self._fan(G["dec_bwd"], 16)
         split, n = self.flat.split, self.flat.numel
         wg_lane = None
         if "dec_wg" in G:
             # the decoders' weight gradients: one after the other on the lane the encoder backward does not use, while it runs on the other three
             wg_lane = self._lane_streams(4)[3]
-            wg_lane.wait_stream(cur)
+            self._hop(40, cur, wg_lane)
             with torch.cuda.stream(wg_lane):
                 for t in G["dec_wg"]:
                     t.replay()
@@ -724,7 +732,7 @@ class TrainEngine:
                     cur.wait_stream(wg_lane)
                 self._allreduce(0, n)
         if wg_lane is not None:
-            cur.wait_stream(wg_lane)
+            self._hop(41, wg_lane, cur)
 
     # ---- public ---------------------------------------------------------------------------------
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
