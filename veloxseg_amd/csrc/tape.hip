@@ -85,7 +85,14 @@ __global__ void vx_flag_wait_k(const unsigned* flag, unsigned value) {
 }
 static int g_use_flags = -1;            // -1: from the environment (VELOXSEG_TAPE_FLAGS, default on)
 static bool use_flags() {
-    if (g_use_flags < 0) { const char* e = getenv("VELOXSEG_TAPE_FLAGS"); g_use_flags = (e && e[0] == '0') ? 0 : 1; }
+    if (g_use_flags < 0) {
+        const char* e = getenv("VELOXSEG_TAPE_FLAGS");
+        // rocprofv3 --pmc runs ONE kernel at a time, across all queues: a polling kernel would never see its flag set (found the safe way: the 5 s trap)
+        const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+        const char* ctr = getenv("ROCPROF_COUNTERS");
+        const bool serialised = (pmc && pmc[0] == '1') || (ctr && ctr[0]);
+        g_use_flags = ((e && e[0] == '0') || serialised) ? 0 : 1;
+    }
     return g_use_flags == 1;
 }
 extern "C" int vx_tape_set_flags(int on) { g_use_flags = on ? 1 : 0; return 0; }
