@@ -174,3 +174,54 @@ def test_taped_engine_on_96_cube_patches_keeps_the_reference_output_list():
             assert eng.use_graph and eng.graphs is not None
     for a, b in zip(losses["eager"], losses["tape"]):
         assert abs(a - b) <= 2e-3 * abs(a), losses
+
+
+def test_tape_cross_lane_dependencies_through_flag_kernels_and_through_events_agree():
+    """The lanes of a tape are ordered by flag kernels (a store on the producing lane, a poll on the waiting lane: csrc/tape.hip) or -- vx_tape_set_flags(0)
+    -- by events.  A diamond of forked branches whose kernels are long enough to expose a missing dependency must give the eager result in both modes,
+    also when the host replays many times without synchronising in between (sequence numbers instead of resets)."""
+    from veloxseg_amd import _hip as H
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    a = torch.randn(1024, 1024, device=dev)
+    x0 = torch.randn(1024, 1024, device=dev)
+    x = x0.clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def fn():
+        cur = torch.cuda.current_stream()
+        y = x @ a                                   # producer
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            p = (y @ a) * 0.01                      # branch 1
+            p.record_stream(cur)
+        with torch.cuda.stream(s2):
+            q = torch.tanh(y) @ a                   # branch 2
+            q.record_stream(cur)
+        cur.wait_stream(s1); cur.wait_stream(s2)
+        r = p + q                                   # join
+        x.copy_(torch.tanh(r * 0.01))               # the next replay reads what this one wrote
+        return r
+
+    tape, r = _capture(fn)
+    assert tape.n_lanes >= 2
+    def eager(n):
+        xe = x0.clone()
+        for _ in range(n):
+            y = xe @ a
+            re = (y @ a) * 0.01 + torch.tanh(y) @ a
+            xe = torch.tanh(re * 0.01)
+        return re
+    try:
+        for flags in (1, 0):
+            H.call("vx_tape_set_flags", flags)
+            for n in (1, 25):
+                x.copy_(x0)
+                torch.cuda.synchronize()
+                for _ in range(n):
+                    tape.replay()                   # no synchronisation between replays
+                torch.cuda.synchronize()
+                ref = eager(n)
+                assert torch.allclose(r, ref, rtol=2e-3, atol=2e-2 * float(ref.abs().max())), (flags, n, float((r - ref).abs().max()), float(ref.abs().max()))
+    finally:
+        H.call("vx_tape_set_flags", 1)
