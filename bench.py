@@ -270,7 +270,7 @@ def main():
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream events" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
+                          "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
         from veloxseg_amd import functional as VF
