@@ -298,3 +298,17 @@ def test_two_forwards_before_their_backwards_keep_their_dropout_masks():
         for n, g in ref[k].items():
             d_ = float((got[k][n] - g).abs().max())
             assert d_ <= 2e-4 * max(0.1, float(g.abs().max())), (k, n, d_)
+
+
+@pytest.mark.gpu
+def test_python_operator_bodies_still_match_the_oracle():
+    """VELOXSEG_NO_CPP=1 selects the python operator bodies of functional.py (same C-ABI launches, issued from python autograd.Functions instead of the
+    C++ nodes of csrc/_vxops.cpp).  It is a debugging path, never the default -- but it must not rot: the eval and train-step parity of a golden case
+    is re-run under it in a child process (the switch is read at import time)."""
+    import os, subprocess, sys
+    env = dict(os.environ, VELOXSEG_NO_CPP="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_model_gpu.py"), "-q", "-m", "gpu", "-x", "-k", "g2_32_m2 and not python_operator"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
