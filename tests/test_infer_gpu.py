@@ -61,7 +61,11 @@ def test_sliding_window_with_the_hip_model(golden_dir):
     with torch.inference_mode():
         got, labels = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5)
         want = SO.sliding_window_inference(x.to(d), (32, 32, 32), 2, IR.Net(model), 0.5)
-    assert torch.equal(got, want)
+        got_eager, _ = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5, taped=False)
+    assert torch.equal(got, want)                       # infer_volume replays the captured forward of a window batch (engine.TapedPredictor) ...
+    assert torch.equal(got, got_eager)                  # ... which is bit for bit the eager forward
+    tp = IR._taped[id(model)][1]
+    assert any(e is not None and e[2].n_kernels > 0 for e in tp._tapes.values()), "the window batches were expected to replay a launch tape"
     ocfg = O.OracleConfig(**cfg)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     with torch.no_grad():

@@ -140,6 +140,66 @@ class LaunchTape:
                 pass
 
 
+class TapedPredictor:
+    """An eval-mode forward of a fixed input shape captured once and replayed as a launch tape: the `predictor` of
+    utils.inference_runtime.sliding_window_inference (the reference runs `model(window_batch)` through autograd-free eager launches,
+    utils/inference_brats.py:41-53,209-216; here the ~250 launches of a window batch cost the host ~0.6 ms instead of ~2 ms and the modality /
+    conv-chain branches run on their own hardware queues).  Inputs of another shape (the ragged last batch) take the eager forward.
+    The first call of a shape captures and checks the replay against the eager forward; a mismatch disables the tape for that shape."""
+
+    def __init__(self, model: torch.nn.Module, max_lanes: int = 6, check: bool = True):
+        self.model, self.max_lanes, self.check = model, int(max_lanes), bool(check)
+        self._tapes = {}
+
+    def _first(self, out):
+        return out[0] if isinstance(out, (list, tuple)) else out
+
+    def _capture(self, x):
+        dev = x.device
+        xs = torch.empty_like(x)
+        xs.copy_(x)
+        VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            ref = None
+            for _ in range(2):                      # lazy initialisation and allocator warm-up outside the capture
+                ref = self._first(self.model(xs)).float().clone()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            out = self._first(self.model(xs))
+        tape = LaunchTape(g, self.max_lanes)
+        if self.check:
+            tape.replay()
+            torch.cuda.synchronize(dev)
+            if not torch.allclose(out.float(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max()))):
+                warnings.warn("TapedPredictor: the replay does not reproduce the eager forward; this shape keeps eager launches")
+                return None
+        return (xs, out, tape)
+
+    @torch.inference_mode()
+    def __call__(self, x: torch.Tensor):
+        if self.model.training or not x.is_cuda:
+            return self.model(x)
+        key = (tuple(x.shape), x.dtype, str(x.device))
+        if key not in self._tapes:
+            try:
+                self._tapes[key] = self._capture(x.contiguous())
+            except Exception as e:                 # a capture that cannot be taken must not take the inference run down
+                warnings.warn(f"TapedPredictor: capture failed ({type(e).__name__}: {str(e)[:200]}); eager launches for shape {tuple(x.shape)}")
+                self._tapes[key] = None
+                torch.cuda.synchronize(x.device)
+        ent = self._tapes[key]
+        if ent is None:
+            return self.model(x)
+        xs, out, tape = ent
+        xs.copy_(x, non_blocking=True)
+        tape.replay()
+        return out
+
+
 class TrainEngine:
     """step(x, labels) = zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW, on static buffers."""
 

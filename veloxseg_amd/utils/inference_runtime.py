@@ -138,13 +138,27 @@ class Net(torch.nn.Module):
         return out[0] if isinstance(out, (list, tuple)) else out
 
 
+_taped = {}
+
+
 @torch.inference_mode()
-def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int, overlap: float):
-    """eval-mode sliding-window segmentation of one (B, C, D, H, W) volume -> (blended logits, uint8 label map)"""
+def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int, overlap: float, taped: bool = True):
+    """eval-mode sliding-window segmentation of one (B, C, D, H, W) volume -> (blended logits, uint8 label map).
+    taped (default): the forward of a full window batch is captured once per model and replayed as a launch tape (engine.TapedPredictor); the result
+    is the eager forward's (checked at capture).  The accumulator of the blending reads the predictor's static output before the next replay
+    overwrites it (same stream)."""
     was_training = model.training
     model.eval()
     try:
-        return sliding_window_inference(volume, roi_size, sw_batch_size, Net(model) if not isinstance(model, Net) else model, overlap=overlap,
-                                        return_labels=True)
+        net = Net(model) if not isinstance(model, Net) else model
+        pred = net
+        if taped and volume.is_cuda:
+            from ..engine import TapedPredictor
+            key = id(model)
+            if key not in _taped or _taped[key][0]() is not model:
+                import weakref
+                _taped[key] = (weakref.ref(model), TapedPredictor(net))
+            pred = _taped[key][1]
+        return sliding_window_inference(volume, roi_size, sw_batch_size, pred, overlap=overlap, return_labels=True)
     finally:
         model.train(was_training)
