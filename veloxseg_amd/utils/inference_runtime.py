@@ -151,6 +151,7 @@ def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequenc
     model.eval()
     try:
         net = Net(model) if not isinstance(model, Net) else model
+        net.eval()
         pred = net
         if taped and volume.is_cuda:
             from ..engine import TapedPredictor
