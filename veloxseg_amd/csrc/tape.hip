@@ -83,6 +83,8 @@ __global__ void vx_flag_wait_k(const unsigned* flag, unsigned value) {
         }
     }
 }
+static inline void flag_set(hipStream_t s, unsigned* f, unsigned v) { hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s, f, v); }
+static inline void flag_wait(hipStream_t s, const unsigned* f, unsigned v) { hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s, f, v); }
 static int g_use_flags = -1;            // -1: from the environment (VELOXSEG_TAPE_FLAGS, default on)
 static bool use_flags() {
     if (g_use_flags < 0) {
@@ -107,13 +109,17 @@ extern "C" int vx_tape_hop(int slot, void* src, void* dst) {
     if (src == dst) return 0;
     if (use_flags()) {
         if (!g_hop_flags) {
-            if (hipMalloc((void**)&g_hop_flags, sizeof(unsigned) * 256) != hipSuccess || hipMemset(g_hop_flags, 0, sizeof(unsigned) * 256) != hipSuccess) return -2;
+            // hipMemset of device memory may return before the fill has run (it is queued on the NULL stream): a poll on another stream would then read
+            // whatever the allocation held and pass at once.  That was the first replay of a process going wrong when the GPU was shared with
+            // another process (tools/two_procs.sh) -- the words must be zero before anything is launched
+            if (hipMalloc((void**)&g_hop_flags, sizeof(unsigned) * 256) != hipSuccess || hipMemset(g_hop_flags, 0, sizeof(unsigned) * 256) != hipSuccess ||
+                hipDeviceSynchronize() != hipSuccess) return -2;
         }
         if (g_hop_src[slot] && g_hop_src[slot] != src) (void)hipStreamSynchronize((hipStream_t)g_hop_src[slot]);      // the site changed its source stream (rare): keep the order
         g_hop_src[slot] = src;
         const unsigned seq = ++g_hop_seq[slot];
-        hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, (hipStream_t)src, g_hop_flags + slot, seq);
-        hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, (hipStream_t)dst, (const unsigned*)(g_hop_flags + slot), seq);
+        flag_set((hipStream_t)src, g_hop_flags + slot, seq);
+        flag_wait((hipStream_t)dst, (const unsigned*)(g_hop_flags + slot), seq);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (!g_hop_ev[slot] && hipEventCreateWithFlags(&g_hop_ev[slot], hipEventDisableTiming) != hipSuccess) return -2;
@@ -379,6 +385,7 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
     nflags += 1 + (int)tail.size();
     HIPQ(hipMalloc((void**)&T->flags, sizeof(unsigned) * (size_t)nflags), "hipMalloc");
     HIPQ(hipMemset(T->flags, 0, sizeof(unsigned) * (size_t)nflags), "hipMemset");
+    HIPQ(hipDeviceSynchronize(), "hipDeviceSynchronize");      // (the fill is queued on the NULL stream: it must have run before the first poll)
     *out = T;
     return 0;
 }
@@ -434,9 +441,9 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
         if (fl) {
             if (T->last_s0 && T->last_s0 != s0) (void)hipStreamSynchronize(T->last_s0);      // another caller stream than last time (rare): its set kernel must not be overtaken
             T->last_s0 = s0;
-            hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s0, T->flags + T->flag_start, seq);
+            flag_set(s0, T->flags + T->flag_start, seq);
             for (size_t l = 0; l < L && l < (size_t)kPool; ++l)
-                if (T->lanes[l] != s0) hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, T->lanes[l], (const unsigned*)(T->flags + T->flag_start), seq);
+                if (T->lanes[l] != s0) flag_wait(T->lanes[l], (const unsigned*)(T->flags + T->flag_start), seq);
         } else {
             HIPQ(hipEventRecord(T->start, s0), "hipEventRecord");
             for (size_t l = 0; l < L && l < (size_t)kPool; ++l) HIPQ(hipStreamWaitEvent(T->lanes[l], T->start, 0), "hipStreamWaitEvent");
@@ -449,20 +456,20 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
         hipStream_t s = T->lanes[nd.lane];
         for (int w : nd.waits) {
             const TapeNode& src = T->nodes[w];
-            if (fl && src.flag >= 0) hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s, (const unsigned*)(T->flags + src.flag), seq);
+            if (fl && src.flag >= 0) flag_wait(s, (const unsigned*)(T->flags + src.flag), seq);
             else HIPQ(hipStreamWaitEvent(s, src.ev, 0), "hipStreamWaitEvent");
         }
         if (nd.marker < 0) { int rc = tape_launch(nd, s); if (rc) return rc; }
         if (nd.marker >= 0 || (nd.record && !(fl && nd.flag >= 0))) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
-        else if (nd.record) hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s, T->flags + nd.flag, seq);
+        else if (nd.record) flag_set(s, T->flags + nd.flag, seq);
     }
     if (fl && hipGetLastError() != hipSuccess) VX_FAIL(-2, "vx_tape_replay: a flag kernel could not be launched");
     if (L > 1)
         for (size_t l = 0; l < L; ++l)
             if (T->lane_last[l] >= 0 && T->lanes[l] != s0) {
                 if (fl && l < (size_t)kPool) {
-                    hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, T->lanes[l], T->flags + T->flag_start + 1 + l, seq);
-                    hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s0, (const unsigned*)(T->flags + T->flag_start + 1 + l), seq);
+                    flag_set(T->lanes[l], T->flags + T->flag_start + 1 + l, seq);
+                    flag_wait(s0, (const unsigned*)(T->flags + T->flag_start + 1 + l), seq);
                 } else {
                     HIPQ(hipEventRecord(T->lane_end[l], T->lanes[l]), "hipEventRecord");
                     HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");

@@ -155,8 +155,14 @@ class TapedPredictor:
         return out[0] if isinstance(out, (list, tuple)) else out
 
     def _capture(self, x):
+        # outside inference mode (no_grad instead): torch.cuda.graph registers the default generator's state tensors at capture_begin, and tensors
+        # born in inference mode there make every later capture of the process fail ("inplace update to inference tensor")
+        with torch.inference_mode(False), torch.no_grad():
+            return self._capture_body(x)
+
+    def _capture_body(self, x):
         dev = x.device
-        xs = torch.empty_like(x)
+        xs = torch.empty(x.shape, dtype=x.dtype, device=dev)
         xs.copy_(x)
         VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)
         s = torch.cuda.Stream(device=dev)

@@ -8,6 +8,7 @@ HIP kernels (csrc/infer.hip), the predictor being the HIP VeloxSeg forward.  Sem
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -153,7 +154,7 @@ def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequenc
         net = Net(model) if not isinstance(model, Net) else model
         net.eval()
         pred = net
-        if taped and volume.is_cuda:
+        if taped and volume.is_cuda and os.environ.get("VELOXSEG_INFER_TAPE", "1") != "0":
             from ..engine import TapedPredictor
             key = id(model)
             if key not in _taped or _taped[key][0]() is not model:
