@@ -39,7 +39,7 @@ def _setup():
     return cfg_d, crit, x, lab, model, TrainEngine
 
 
-def _worker(rank, world, port, out_dir, use_graph, backend="gloo"):
+def _worker(rank, world, port, out_dir, use_graph, backend="gloo", level_buckets=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -51,7 +51,7 @@ def _worker(rank, world, port, out_dir, use_graph, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
     # (a bucket floor of 16 KB so that this small model gets one bucket per encoder level, as the 128^3 models do at the default 1 MB)
-    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True, bucket_min_bytes=1 << 14)
+    eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True, bucket_min_bytes=1 << 14, level_buckets=level_buckets)
     assert eng.world == 2 and eng.overlap
     loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
     torch.cuda.synchronize()
@@ -61,7 +61,10 @@ def _worker(rank, world, port, out_dir, use_graph, backend="gloo"):
     cover = sorted(eng._reduced)
     assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
     assert [r[1] for r in eng._reduced] == sorted((r[1] for r in eng._reduced), reverse=True), ("buckets must be reduced tail first", eng._reduced)
-    assert len(eng._reduced) >= 3, ("expected the decoder bucket and at least two encoder buckets", eng._reduced, eng.flat.plan(1 << 14))
+    if level_buckets or not use_graph:
+        assert len(eng._reduced) >= 3, ("expected the decoder bucket and at least two encoder buckets", eng._reduced, eng.flat.plan(1 << 14))
+    else:              # the taped default: the decoder bucket during the encoder backward, the encoder's gradients in one bucket after it
+        assert len(eng._reduced) == 2, eng._reduced
     if rank == 0:      # flat.grad now holds the SUM over ranks (AdamW applies the 1/world scale)
         torch.save({"grad": (eng.flat.grad / world).cpu(), "param": eng.flat.param.cpu(), "loss": float(loss), "plan": eng.flat.plan()}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()
@@ -76,14 +79,14 @@ def test_two_rank_engine_over_rccl_equals_single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graphs"])
-def test_two_rank_engine_equals_single_process(tmp_path, use_graph):
-    _check_two_ranks(tmp_path, use_graph, "gloo")
+@pytest.mark.parametrize("use_graph,level_buckets", [(False, True), (True, True), (True, False)], ids=["eager", "tape_level_buckets", "tape_default"])
+def test_two_rank_engine_equals_single_process(tmp_path, use_graph, level_buckets):
+    _check_two_ranks(tmp_path, use_graph, "gloo", level_buckets)
 
 
-def _check_two_ranks(tmp_path, use_graph, backend):
+def _check_two_ranks(tmp_path, use_graph, backend, level_buckets=True):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph, backend), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph, backend, level_buckets), nprocs=world, join=True)
     dp = torch.load(os.path.join(str(tmp_path), "dp.pt"))
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
     eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=False, overlap=True)    # world 1: overlap off automatically

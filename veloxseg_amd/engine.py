@@ -224,8 +224,13 @@ class TrainEngine:
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
-                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20):
+                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False):
         self.model, self.criterion = model, criterion
+        # taped data-parallel steps: True = one all-reduce bucket per encoder level, released by markers inside the encoder-backward tape; False
+        # (default) = the decoder bucket during the encoder backward, the encoder's gradients in one bucket after it.  A marker joins every forked
+        # stream of the stage: measured on one GPU the markers cost 0.85 ms per step (7.50 vs 6.65 ms), more than the ~0.2 ms of all-reduce
+        # (5.5 MB over xGMI) they can hide
+        self.level_buckets = bool(level_buckets) or os.environ.get("VELOXSEG_LEVEL_BUCKETS") == "1"
         VF.set_precision(precision)            # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision); process-wide
         self.precision = precision
         self.bucket_min_bytes = int(bucket_min_bytes)      # all-reduce buckets below this size are merged into the next one (latency-bound collectives)
@@ -394,7 +399,7 @@ class TrainEngine:
         return int(getattr(self.model, "n_classes", 0) or self.model.decoder.n_classes)
 
     def _mark_levels(self):
-        return self.use_graph and self.replay_mode == "tape" and ((self.world > 1 and self.overlap) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
+        return self.use_graph and self.replay_mode == "tape" and ((self.world > 1 and self.overlap and self.level_buckets) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
 
     def _drop_level_hooks(self):
         for h in getattr(self, "_level_hooks", []):
