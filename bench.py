@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, production) or gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--lane-probe", action="store_true", help="diagnostic: after the timed region, time dispatch-heavy kernels on every pair of tape lanes (lanes that share a dispatch pipe overlap worse)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -266,6 +267,36 @@ def main():
     loss = float(eng.loss)
     assert loss == loss, "loss is NaN"
 
+    lane_probe = None
+    if args.lane_probe and rank == 0 and not args.eager:
+        import ctypes
+        lanes = []
+        for k in range(4):
+            h = ctypes.c_void_p()
+            H.call("vx_tape_lane_stream", H.stream_ptr(), k, ctypes.addressof(h))
+            lanes.append(torch.cuda.ExternalStream(h.value, device=dev))
+        bufs = [torch.zeros(1 << 22, device=dev) for _ in range(4)]
+
+        def burst(idx):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cur = torch.cuda.current_stream()
+            e0.record()
+            for i in idx:
+                lanes[i].wait_stream(cur)
+                with torch.cuda.stream(lanes[i]):
+                    for _ in range(100):
+                        bufs[i].add_(1.0)                 # 4096 small workgroups per launch: dispatch-heavy
+            for i in idx:
+                cur.wait_stream(lanes[i])
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3
+        for _ in range(2):
+            single = [round(burst([i]), 1) for i in range(4)]
+            pairs = {f"{i}{j}": round(burst([i, j]), 1) for i in range(4) for j in range(i + 1, 4)}
+        lane_probe = {"single_us": single, "pair_us": pairs, "all4_us": round(burst([0, 1, 2, 3]), 1)}
+
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -280,6 +311,8 @@ def main():
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
+    if rank == 0 and lane_probe is not None:
+        out["lane_probe"] = lane_probe
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
         from veloxseg_amd import functional as VF
@@ -433,8 +466,13 @@ def roofline_for(name, key, ms_per_launch, model=None):
                 flops = pairs * (2.0 * cq + 2.0 * cv) if name == "vx_pwa_attn_fwd" else pairs * (8.0 * cq + 6.0 * cv)
                 bytes_ = 4.0 * rows * ((2 * cq + 2 * cv + 1) if name == "vx_pwa_attn_fwd" else (4 * cq + 4 * cv + 3))
                 r["pairs"], r["kernels"] = pairs, 1 if name == "vx_pwa_attn_fwd" else 2
-                r["traffic"], r["traffic_source"] = _pmc_traffic([f"vx_pwa_attn_fwd_k<{cq}, {cv}>"] if name == "vx_pwa_attn_fwd" else
-                                                                 [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"], B)
+                # (the kernels behind the entry: MFMA forward where the geometry allows it; the one-launch backward, else its two passes)
+                cands = ([[f"vx_pwa_attn_mfma_fwd_k<{cq}, {cv}>"], [f"vx_pwa_attn_fwd_k<{cq}, {cv}>"]] if name == "vx_pwa_attn_fwd" else
+                         [[f"vx_pwa_attn_bwd_both_k<{cq}, {cv}>"], [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"]])
+                for kn in cands:
+                    r["traffic"], r["traffic_source"] = _pmc_traffic(kn, B)
+                    if r["traffic"] is not None:
+                        break
         elif name in ("vx_jlc_conv_fwd", "vx_jlc_conv_bwd"):
             B, C, G, D, H, W = k[:6]                  # grouped k = 1, 3, 5 convolutions of one JLC block from one K = 5 halo (csrc/jlc.hip)
             v = B * D * H * W
