@@ -535,6 +535,25 @@ __global__ void __launch_bounds__(256) vx_sqdiff_sum_bs_k(const float* __restric
     const float* __restrict__ as = a + (long)blockIdx.y * n;
     const float* __restrict__ bs = b + (long)blockIdx.y * bstride;
     float s = 0.0f;
+    if (((n | bstride) & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0)) {      // 16-byte loads, two independent quads in flight per thread (scalar loads: 1.2 TB/s)
+        const long n4 = n >> 2, step = (long)gridDim.x * 256;
+        const float4* __restrict__ a4 = reinterpret_cast<const float4*>(as);
+        const float4* __restrict__ b4 = reinterpret_cast<const float4*>(bs);
+        float s0 = 0.0f, s1 = 0.0f;
+        long i = (long)blockIdx.x * 256 + threadIdx.x;
+        for (; i + step < n4; i += 2 * step) {
+            const float4 x0 = a4[i], y0 = b4[i], x1 = a4[i + step], y1 = b4[i + step];
+            float d;
+            d = x0.x - y0.x; s0 = fmaf(d, d, s0); d = x0.y - y0.y; s0 = fmaf(d, d, s0); d = x0.z - y0.z; s0 = fmaf(d, d, s0); d = x0.w - y0.w; s0 = fmaf(d, d, s0);
+            d = x1.x - y1.x; s1 = fmaf(d, d, s1); d = x1.y - y1.y; s1 = fmaf(d, d, s1); d = x1.z - y1.z; s1 = fmaf(d, d, s1); d = x1.w - y1.w; s1 = fmaf(d, d, s1);
+        }
+        if (i < n4) {
+            const float4 x0 = a4[i], y0 = b4[i];
+            float d;
+            d = x0.x - y0.x; s0 = fmaf(d, d, s0); d = x0.y - y0.y; s0 = fmaf(d, d, s0); d = x0.z - y0.z; s0 = fmaf(d, d, s0); d = x0.w - y0.w; s0 = fmaf(d, d, s0);
+        }
+        s = s0 + s1;
+    } else
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float d = as[i] - bs[i]; s = fmaf(d, d, s); }
     __shared__ float red[4];
     s = vx_block_sum_256(s, red);
@@ -542,7 +561,7 @@ __global__ void __launch_bounds__(256) vx_sqdiff_sum_bs_k(const float* __restric
 }
 extern "C" int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, void* stream) {
     VX_REQUIRE(a && b && acc && n_per_sample > 0 && B > 0 && b_batch_stride >= n_per_sample, "vx_sqdiff_sum_bs: bad args");
-    int blocks = vx_cdiv(n_per_sample, 256 * 8);
+    int blocks = vx_cdiv(n_per_sample, 256 * 16);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(vx_sqdiff_sum_bs_k, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, a, b, n_per_sample, b_batch_stride, acc);
     VX_LAUNCH_CHECK("vx_sqdiff_sum_bs");
