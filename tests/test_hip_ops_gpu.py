@@ -163,7 +163,7 @@ def test_layernorm_and_s2d():
     run_pair(lambda x, w, b: VF.layernorm_cf(x, w, b), lambda x, w, b: O.layernorm_cf(x, w, b), [x], [1 + 0.2 * rnd(16, seed=1), 0.2 * rnd(16, seed=2)], what="ln")
     run_pair(lambda x: VF.space_to_depth2(x), lambda x: O.space_to_depth2(x), [x], atol=0, rtol=0, what="s2d")
     # few voxels, many channels (PatchMerging LN over 8C at the coarse levels): the lane-parallel kernels
-    for shape in [(2, 128, 4, 4, 4), (1, 64, 3, 5, 2), (4, 512, 4, 4, 4), (2, 100, 2, 3, 3)]:
+    for shape in [(2, 128, 4, 4, 4), (1, 64, 3, 5, 2), (4, 512, 4, 4, 4), (2, 100, 2, 3, 3), (3, 256, 5, 7, 9), (2, 1024, 2, 2, 2), (4, 128, 16, 16, 16)]:     # (4, 512, 4^3), (3, 256, ..), (2, 1024, ..): 64 lanes per voxel
         C = shape[1]
         run_pair(lambda x, w, b: VF.layernorm_cf(x, w, b), lambda x, w, b: O.layernorm_cf(x, w, b), [rnd(*shape, seed=C) * 2 + 0.5],
                  [1 + 0.2 * rnd(C, seed=1), 0.2 * rnd(C, seed=2)], gtol=(2e-5, 2e-3), what=f"ln{shape}")

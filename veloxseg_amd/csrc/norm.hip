@@ -473,25 +473,30 @@ extern "C" int vx_in_bwd_split(const float* dout, const float* y0, const float* 
 // (4 voxels per wave, 16 per block), each lane takes every 16th channel, sums meet in a 16-lane shuffle tree.  Same pivot-shifted
 // single-sweep statistics as vx_ln_stats.
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float vx_sum16(float v) {
+template <int LPV>
+__device__ __forceinline__ float vx_sum_lpv(float v) {
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = LPV / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+#define vx_sum16 vx_sum_lpv<LPV>
 
-template <bool BWD>
+// LPV lanes per voxel: 16 (16 voxels per block), or 64 where even that leaves the chip empty (B*V <= 1024 voxels of >= 256 channels: the PatchMerging
+// LayerNorm in front of level 4 ran 16 blocks for 38 us)
+template <bool BWD, int LPV = 16>
 __global__ void __launch_bounds__(256) vx_ln_cf_lanes_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ dout, float* __restrict__ out, float* __restrict__ ws, int C, long V,
                                                         long BV, float eps) {
-    const long vox = (long)blockIdx.x * 16 + (threadIdx.x >> 4);       // over (b, v)
-    const int sub = threadIdx.x & 15;
+    constexpr int VPB = 256 / LPV;                                       // voxels per block
+    const long vox = (long)blockIdx.x * VPB + (threadIdx.x / LPV);       // over (b, v)
+    const int sub = threadIdx.x & (LPV - 1);
     const bool live = vox < BV;
     const long vv = live ? vox : 0;
     const long b = vv / V, v = vv % V;
     const float* __restrict__ xb = x + b * C * V + v;
     const float pivot = xb[0];
     float s_ = 0.0f, q_ = 0.0f;
-    for (int c = sub; c < C; c += 16) { const float d = xb[(long)c * V] - pivot; s_ += d; q_ = fmaf(d, d, q_); }
+    for (int c = sub; c < C; c += LPV) { const float d = xb[(long)c * V] - pivot; s_ += d; q_ = fmaf(d, d, q_); }
     s_ = vx_sum16(s_);
     q_ = vx_sum16(q_);
     const float md = s_ / (float)C;
@@ -501,11 +506,11 @@ __global__ void __launch_bounds__(256) vx_ln_cf_lanes_k(const float* __restrict_
     if (!BWD) {
         float* __restrict__ ob = out + b * C * V + v;
         if (live)
-            for (int c = sub; c < C; c += 16) ob[(long)c * V] = fmaf(gamma[c], (xb[(long)c * V] - u) * r, beta[c]);
+            for (int c = sub; c < C; c += LPV) ob[(long)c * V] = fmaf(gamma[c], (xb[(long)c * V] - u) * r, beta[c]);
     } else {
         const float* __restrict__ db = dout + b * C * V + v;
         float s1 = 0.0f, s2 = 0.0f;
-        for (int c = sub; c < C; c += 16) {
+        for (int c = sub; c < C; c += LPV) {
             const float xh = (xb[(long)c * V] - u) * r;
             const float g = db[(long)c * V] * gamma[c];
             s1 += g;
@@ -516,7 +521,7 @@ __global__ void __launch_bounds__(256) vx_ln_cf_lanes_k(const float* __restrict_
         if (live) {
             float* __restrict__ ob = out + b * C * V + v;
             const float* __restrict__ ab = beta ? beta + b * C * V + v : nullptr;      // backward: `beta` carries the optional gradient to add (same layout as out)
-            for (int c = sub; c < C; c += 16) {
+            for (int c = sub; c < C; c += LPV) {
                 const float xh = (xb[(long)c * V] - u) * r;
                 const float o = r * (db[(long)c * V] * gamma[c] - s1 - xh * s2);
                 ob[(long)c * V] = ab ? ab[(long)c * V] + o : o;
@@ -525,11 +530,15 @@ __global__ void __launch_bounds__(256) vx_ln_cf_lanes_k(const float* __restrict_
         }
     }
 }
-static inline bool vx_ln_use_lanes(int B, int C, long V) { return (long)B * V <= 8192 && C >= 64; }
+#undef vx_sum16
+static inline bool vx_ln_use_lanes(int B, int C, long V) { return (long)B * V <= 16384 && C >= 64; }
+static inline bool vx_ln_wide_lanes(int B, int C, long V) { return (long)B * V <= 1024 && C >= 256; }
 
 extern "C" int vx_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int C, long V, float eps, void* stream) {
     VX_REQUIRE(x && gamma && beta && out && B > 0 && C > 0 && V > 0, "vx_ln_cf_fwd: bad args");
     if (vx_ln_use_lanes(B, C, V)) {
+        if (vx_ln_wide_lanes(B, C, V)) vx_ln_cf_lanes_k<false, 64><<<dim3(vx_cdiv((long)B * V, 4)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, nullptr, out, nullptr, C, V, (long)B * V, eps);
+        else
         vx_ln_cf_lanes_k<false><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, nullptr, out, nullptr, C, V, (long)B * V, eps);
         VX_LAUNCH_CHECK("vx_ln_cf_fwd");
         return 0;
@@ -545,7 +554,9 @@ static int vx_ln_cf_bwd_run(const float* x, const float* gamma, const float* dou
     VX_REQUIRE(x && dout && ws && B > 0 && C > 0 && V > 0, "vx_ln_cf_bwd: bad pointers");
     if (parts & 1) {
         VX_REQUIRE(gamma && dx && add != dx, "vx_ln_cf_bwd: bad pointers");
-        if (vx_ln_use_lanes(B, C, V))
+        if (vx_ln_use_lanes(B, C, V) && vx_ln_wide_lanes(B, C, V))
+            vx_ln_cf_lanes_k<true, 64><<<dim3(vx_cdiv((long)B * V, 4)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, add, dout, dx, ws, C, V, (long)B * V, eps);
+        else if (vx_ln_use_lanes(B, C, V))
             vx_ln_cf_lanes_k<true><<<dim3(vx_cdiv((long)B * V, 16)), dim3(256), 0, (hipStream_t)stream>>>(x, gamma, add, dout, dx, ws, C, V, (long)B * V, eps);
         else
             hipLaunchKernelGGL(vx_ln_cf_bwd_k, dim3(vx_cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, dout, dx, ws, C, V, eps, add);
