@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Soak test of the taped step: N replays from the same weights and dropout streams must all give the same loss and gradient (float-atomic noise aside).
+A cross-lane dependency that is missed even once shows up as an outlier.  argv: [workload] [batch] [replays]"""
+import os, sys, types
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from bench import LOSS_CFG, WORKLOADS, synth
+from veloxseg_amd import functional as VF
+from veloxseg_amd.engine import TrainEngine
+from veloxseg_amd.model.VeloxSeg import VeloxSeg
+from veloxseg_amd.utils.loss import Loss
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "autopet128"
+cfg, B = WORKLOADS[wl]
+if len(sys.argv) > 2:
+    B = int(sys.argv[2])
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+torch.manual_seed(12345)
+model = VeloxSeg(**cfg).cuda()
+crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
+x, lab = synth(cfg, B, "cuda", 12345)
+eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=True, overlap=False)
+eng.step(x, lab)
+torch.cuda.synchronize()
+assert eng.use_graph and eng.graphs is not None, "capture failed"
+rng = VF.rng_state(eng.dev)
+rng0 = rng.clone()
+ref = None
+worst = 0.0
+bad = 0
+sync_every = int(os.environ.get("VX_SYNC_EVERY", "1"))
+for i in range(n):
+    rng.copy_(rng0)
+    eng._replay(comm=False)
+    if (i + 1) % sync_every == 0 or i == n - 1:
+        torch.cuda.synchronize()
+        g = eng.flat.grad
+        if ref is None:
+            ref = (float(eng.loss), g.clone(), float(g.abs().max()))
+        else:
+            d = float((g - ref[1]).abs().max()) / ref[2]
+            worst = max(worst, d)
+            if d > 1e-4 or float(eng.loss) != ref[0]:
+                bad += 1
+                print(f"replay {i}: loss {float(eng.loss)} vs {ref[0]}, max |dgrad| / max|grad| = {d:.3e}")
+print(f"{wl} B={B}: {n} replays, {bad} outliers, worst relative gradient deviation {worst:.3e}")
+sys.exit(1 if bad else 0)
