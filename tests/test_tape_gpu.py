@@ -225,3 +225,14 @@ def test_tape_cross_lane_dependencies_through_flag_kernels_and_through_events_ag
                 assert torch.allclose(r, ref, rtol=2e-3, atol=2e-2 * float(ref.abs().max())), (flags, n, float((r - ref).abs().max()), float(ref.abs().max()))
     finally:
         H.call("vx_tape_set_flags", 1)
+
+
+def test_taped_step_soak_full_size():
+    """60 replays of the full-size taped step from the same weights and dropout streams, the host running ahead of the GPU (a synchronisation every 15
+    replays): every checked replay reproduces loss and gradient of the first (float-atomic noise only).  A cross-lane dependency missed once would be an
+    outlier (tools/tape_soak.py is the long form)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tape_soak.py"), "autopet128", "2", "60"], env=dict(os.environ, VX_SYNC_EVERY="15"),
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 outliers" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
