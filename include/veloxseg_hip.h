@@ -75,6 +75,7 @@ int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, 
                             int accumulate, void* stream);
 /* A/B knob of the entry above: 1 (default) = LDS-tiled kernel when D%4 == H%4 == W%16 == 0, 0 = every operand straight from global */
 int vx_expand_set_lds(int on);
+int vx_expand_set_fwd_wlds(int on);   /* A/B knob of vx_expand_fwd_mfma: 1 (default) = the weights of a (c, s1) group staged in LDS once per block, 0 = loaded from global memory per tap */
 /* forward of the same layer (conv 16 -> 64*Cc, k3 p1, PixelShuffle(4) store) as MFMA tiles over an LDS halo; wt_ws: Cout*16*27 floats.
  * Needs D % 4 == 0, H % 4 == 0, W % 16 == 0: returns 1 (and launches nothing) otherwise -- the caller then uses vx_conv_s1. */
 int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream);

@@ -400,7 +400,7 @@ def test_kernel_variants_agree():
             for i, (a, b_) in enumerate(zip(got, ref)):
                 close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")
         from veloxseg_amd import _hip as H
-        for knob in ("vx_pw_mfma_set_wide", "vx_expand_set_lds"):          # library-side A/B knobs: narrow MFMA tiles / un-tiled expand gradient
+        for knob in ("vx_pw_mfma_set_wide", "vx_expand_set_lds", "vx_expand_set_fwd_wlds"):          # library-side A/B knobs: narrow MFMA tiles / un-tiled expand gradient
             H.call(knob, 0)
             try:
                 got = run(base)

@@ -300,6 +300,92 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_k(const float* __restr
     }
 }
 
+// The same forward with the A operand (the tap-major weights of one (c, s1) group: 27 taps x 16 outputs x 16 inputs = 27 KB) staged in LDS once per
+// group and block, in operand order (element (t, j, lane) at (t*4 + j)*64 + lane: conflict-free ds_read_b32), instead of four dependent global loads
+// per tap in each of the four waves: the SQ counters showed the kernel above waiting 65 % of its wave cycles (profiles/r02_sq_wave_breakdown.txt),
+// 7.6 % active.  LDS 42 + 27 KB: still two blocks per CU.
+__global__ void __launch_bounds__(256) vx_expand_fwd_mfma_w_k(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float vx_xh[];          // [16][VX_EF_PITCH] halo | [27][4][64] weights of the current group
+    float* __restrict__ wl = vx_xh + 16 * VX_EF_PITCH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const int Cout = Cc * 64;
+    const float* __restrict__ xb = x + (long)b * 16 * V;
+    for (int e0 = threadIdx.x; e0 < 16 * 648; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * 256, 16 * 648 - 1);
+            const int hv = e % 648, ci = e / 648;
+            const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+            const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+            const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+            const float t_ = xb[ok ? (long)ci * V + ((long)qd * H + qh) * W + qw : 0];
+            v[u] = ok ? t_ : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            if (e < 16 * 648) vx_xh[(e / 648) * VX_EF_PITCH + (e % 648)] = v[u];
+        }
+    }
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    // staging slot of this thread: source element tid of a tap's 16 x 16 block = (output row tid >> 4, input channel tid & 15) -> operand slot
+    const int st_dst = ((threadIdx.x & 15) >> 2) * 64 + (threadIdx.x & 3) * 16 + (threadIdx.x >> 4);
+    for (int g = 0; g < Cc * 4; ++g) {                                     // (c, s1) groups
+        const int c = g >> 2, s1 = g & 3;
+        const int co_base = g * 16;
+        {
+            float wv[27];
+            const float* __restrict__ src = wt + (long)co_base * 16 + threadIdx.x;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) wv[t] = src[(long)t * Cout * 16];       // 27 independent 1 KB-coalesced loads in flight
+            __syncthreads();                                               // (the previous group's MFMAs have read wl; first pass: the halo stores are done)
+#pragma unroll
+            for (int t = 0; t < 27; ++t) wl[t * 256 + st_dst] = wv[t];
+            __syncthreads();
+        }
+        vx_f4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+        for (int t = 0; t < 27; ++t) {
+            const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+            const float* __restrict__ wa = wl + t * 256 + lane;
+            const float* __restrict__ xt = vx_xh + q * VX_EF_PITCH + ((wave + td) * 6 + th) * 18 + r + tw;
+            float av[4], bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[j] = wa[j * 64];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bv[j][m] = xt[4 * j * VX_EF_PITCH + m * 18];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j][m], acc[m], 0, 0, 0);
+        }
+        const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+    }
+}
+static int vx_expand_fwd_wlds = 1;
+extern "C" int vx_expand_set_fwd_wlds(int on) { vx_expand_fwd_wlds = on ? 1 : 0; return 0; }      // A/B: weights of a group staged in LDS (default) or loaded per tap
+
 // returns 1 when the shape is not covered (caller uses the direct convolution), 0 on success
 extern "C" int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
     VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma: bad args");
@@ -309,6 +395,12 @@ extern "C" int vx_expand_fwd_mfma(const float* x, const float* w, const float* b
     const long nW = (long)Cout * 16 * 27;
     vx_weight_tap_major_k<<<vx_cdiv(nW, 256), 256, 0, st>>>(w, wt_ws, Cout, 16, 27);
     const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    if (vx_expand_fwd_wlds) {
+        const size_t shm = (16 * VX_EF_PITCH + 27 * 256) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)vx_expand_fwd_mfma_w_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+        vx_expand_fwd_mfma_w_k<<<dim3((unsigned)nblk), 256, shm, st>>>(x, wt_ws, bias, y, B, Cc, D, H, W);
+    } else
     vx_expand_fwd_mfma_k<<<dim3((unsigned)nblk), 256, 16 * VX_EF_PITCH * sizeof(float), st>>>(x, wt_ws, bias, y, B, Cc, D, H, W);
     VX_LAUNCH_CHECK("vx_expand_fwd_mfma");
     return 0;
