@@ -73,7 +73,8 @@ int vx_conv_s1(const float* x, const float* w, const float* bias, float* y, int 
  * tap-major weights in 256-byte runs.  dy_fine: (B, Cc, 4D,4H,4W); w: (64*Cc, 16, 3,3,3); wt_ws: 64*Cc*16*27 floats; dx: (B,16,D,H,W) */
 int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
                             int accumulate, void* stream);
-/* A/B knob of the entry above: 1 (default) = LDS-tiled kernel when D%4 == H%4 == W%16 == 0, 0 = every operand straight from global */
+/* A/B knob of the entry above: 1 (default) = LDS-tiled kernel (fine-gradient halo AND the group's weights in LDS) when D%4 == H%4 == W%16 == 0,
+ * 2 = halo only (weights per tap from global memory), 0 = every operand straight from global */
 int vx_expand_set_lds(int on);
 int vx_expand_set_fwd_wlds(int on);   /* A/B knob of vx_expand_fwd_mfma: 1 (default) = the weights of a (c, s1) group staged in LDS once per block, 0 = loaded from global memory per tap */
 /* forward of the same layer (conv 16 -> 64*Cc, k3 p1, PixelShuffle(4) store) as MFMA tiles over an LDS halo; wt_ws: Cout*16*27 floats.

@@ -401,13 +401,14 @@ def test_kernel_variants_agree():
                 close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"variant {variant} tensor {i}")
         from veloxseg_amd import _hip as H
         for knob in ("vx_pw_mfma_set_wide", "vx_expand_set_lds", "vx_expand_set_fwd_wlds"):          # library-side A/B knobs: narrow MFMA tiles / un-tiled expand gradient
-            H.call(knob, 0)
-            try:
-                got = run(base)
-            finally:
-                H.call(knob, 1)
-            for i, (a, b_) in enumerate(zip(got, ref)):
-                close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"{knob}=0 tensor {i}")
+            for val in ((0, 2) if knob == "vx_expand_set_lds" else (0,)):
+                H.call(knob, val)
+                try:
+                    got = run(base)
+                finally:
+                    H.call(knob, 1)
+                for i, (a, b_) in enumerate(zip(got, ref)):
+                    close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"{knob}={val} tensor {i}")
     finally:
         run(base)
 

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_mfma_k(const float* __
 
 
 static int vx_expand_lds_enabled = 1;
-extern "C" int vx_expand_set_lds(int on) { vx_expand_lds_enabled = on ? 1 : 0; return 0; }
+extern "C" int vx_expand_set_lds(int on) { vx_expand_lds_enabled = on; return 0; }      // 1 (default): halo AND weights in LDS; 2: halo only; 0: every operand from global
 
 // LDS-tiled variant (D % 4 == 0, H % 4 == 0, W % 16 == 0).  The kernel above reads every A operand (64 contiguous floats of the fine gradient)
 // from L2/HBM once per tap: 693 MB of memory-side traffic per launch for ~50 MB of data (profiles/r01q_pmc_traffic.json).  Here a block owns a
@@ -199,6 +199,94 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_k(const float* __r
     }
 }
 
+// the same with the B operand (the weights of the group) staged in LDS beside the halo: 41.5 + 27 KB, two blocks per CU
+__global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_w_k(const float* __restrict__ dyf, const float* __restrict__ wt, float* __restrict__ dx,
+                                                                int B, int Cc, int D, int H, int W, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float vx_halo_t[];          // [6][6][4][72] | [27][256] weights of the current (c, s1) group
+    float* __restrict__ wl = vx_halo_t + 6 * 6 * 4 * 72;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const int Cout = Cc * 64;
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
+    vx_f4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cc; ++c) {
+        for (int s1 = 0; s1 < 4; ++s1) {
+            __syncthreads();
+            // stage: 144 rows (hd, hh, s2) x 18 float4
+            // 144 * 18 = 2592 float4 = 10.1 per thread: up to 11 unconditional loads in flight per thread (clamped address, value selected afterwards)
+            {
+                // the group's weights: tap t, 16 outputs x 16 inputs = 256 contiguous floats of the tap-major copy, already in operand order
+                // ((s2 * 4 + q) * 16 + r): a straight copy, 27 independent loads in flight, instead of 4 dependent global loads per tap and wave
+                float wv[27];
+                const float* __restrict__ wsrc = wt + (long)(((c * 4 + s1) * 4) * 4) * 16 + threadIdx.x;
+#pragma unroll
+                for (int t = 0; t < 27; ++t) wv[t] = wsrc[(long)t * Cout * 16];
+#pragma unroll
+                for (int t = 0; t < 27; ++t) wl[t * 256 + threadIdx.x] = wv[t];
+            }
+            {
+                float4 v[11];
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+                    const int f4 = e % 18, row = e / 18;
+                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = (int)threadIdx.x + u * 256;
+                    if (e < 144 * 18) *reinterpret_cast<float4*>(vx_halo_t + (e / 18) * 72 + (e % 18) * 4) = v[u];
+                }
+            }
+            __syncthreads();
+#pragma unroll 3
+            for (int t = 0; t < 27; ++t) {
+                const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+                const float* __restrict__ wtt = wl + t * 256 + lane;
+                const int hd = wave - td + 2;
+                const int lbase = (r - tw + 2) * 4 + q;
+                float bv[4], av[4][4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    bv[s2] = wtt[s2 * 64];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) av[m][s2] = vx_halo_t[((hd * 6 + (m - th + 2)) * 4 + s2) * 72 + lbase];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][s2], bv[s2], acc[m], 0, 0, 0);
+            }
+        }
+    }
+    // D: row = voxel 4q+reg of the M-tile (w = w0 + 4q + reg), col = ci r
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
+        float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst) = o;
+    }
+}
+
 extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
                                        int accumulate, void* stream) {
     VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma: bad args");
@@ -209,6 +297,12 @@ extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, flo
     const long V = (long)D * H * W;
     if (vx_expand_lds_enabled && D % 4 == 0 && H % 4 == 0 && W % 16 == 0) {
         const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+        if (vx_expand_lds_enabled == 1) {
+            const size_t shm = (6 * 6 * 4 * 72 + 27 * 256) * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)vx_expand_bwd_data_lds_w_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+            vx_expand_bwd_data_lds_w_k<<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, wt_ws, dx, B, Cc, D, H, W, accumulate);
+        } else
         vx_expand_bwd_data_lds_k<<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>(dy_fine, wt_ws, dx, B, Cc, D, H, W, accumulate);
         VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma");
         return 0;
