@@ -336,7 +336,7 @@ def main():
             if rf.get("achieved") is not None:
                 rf["launches_per_step"], rf["share_of_step"] = n, round(tot_ms / total, 4)
                 if rf.get("traffic") is None and name in ("vx_expand_wgrad_mfma", "vx_expand_bwd_data_mfma"):
-                    kern = "vx_expand_wgrad_mfma_k" if name == "vx_expand_wgrad_mfma" else "vx_expand_bwd_data_lds_k"
+                    kern = "vx_expand_wgrad_mfma_k" if name == "vx_expand_wgrad_mfma" else "vx_expand_bwd_data_lds_w_k"
                     rf["traffic"], src = _pmc_traffic_by_launches(kern, B, n)
                     if src:
                         rf["traffic_source"] = src
