@@ -39,7 +39,7 @@ def _setup():
     return cfg_d, crit, x, lab, model, TrainEngine
 
 
-def _worker(rank, world, port, out_dir, use_graph, backend="gloo", level_buckets=True):
+def _worker(rank, world, port, out_dir, use_graph, backend="gloo", level_buckets=True, break_rank1=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -53,15 +53,27 @@ def _worker(rank, world, port, out_dir, use_graph, backend="gloo", level_buckets
     # (a bucket floor of 16 KB so that this small model gets one bucket per encoder level, as the 128^3 models do at the default 1 MB)
     eng = TrainEngine(model, crit, (1, 2, 32, 32, 32), use_graph=use_graph, overlap=True, bucket_min_bytes=1 << 14, level_buckets=level_buckets)
     assert eng.world == 2 and eng.overlap
-    loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
+    if break_rank1 and rank == 1:         # this rank's capture "fails": it falls back to eager launches and must still issue the collectives of the taped rank
+        def _boom():
+            raise RuntimeError("forced capture failure (test)")
+        eng._capture = _boom
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = eng.step(x[rank:rank + 1].cuda(), lab[rank:rank + 1].cuda())
     torch.cuda.synchronize()
+    if break_rank1:
+        assert eng.use_graph == (rank == 0)
+        use_graph = eng.use_graph
     # the bucketed all-reduces of one step tile the flat gradient buffer exactly once (tail first): eager = multi-grad hooks inside backward(),
     # tape = markers recorded by the encoder-backward tape (engine._mark) that the communication stream waits for
     assert eng.use_graph == use_graph
     cover = sorted(eng._reduced)
     assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
     assert [r[1] for r in eng._reduced] == sorted((r[1] for r in eng._reduced), reverse=True), ("buckets must be reduced tail first", eng._reduced)
-    if level_buckets or not use_graph:
+    if break_rank1:
+        assert len(eng._reduced) == 2, eng._reduced
+    elif level_buckets or not use_graph:
         assert len(eng._reduced) >= 3, ("expected the decoder bucket and at least two encoder buckets", eng._reduced, eng.flat.plan(1 << 14))
     else:              # the taped default: the decoder bucket during the encoder backward, the encoder's gradients in one bucket after it
         assert len(eng._reduced) == 2, eng._reduced
@@ -79,14 +91,15 @@ def test_two_rank_engine_over_rccl_equals_single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("use_graph,level_buckets", [(False, True), (True, True), (True, False)], ids=["eager", "tape_level_buckets", "tape_default"])
-def test_two_rank_engine_equals_single_process(tmp_path, use_graph, level_buckets):
-    _check_two_ranks(tmp_path, use_graph, "gloo", level_buckets)
+@pytest.mark.parametrize("use_graph,level_buckets,break_rank1", [(False, True, False), (True, True, False), (True, False, False), (True, False, True)],
+                         ids=["eager", "tape_level_buckets", "tape_default", "tape_default_rank1_falls_back_to_eager"])
+def test_two_rank_engine_equals_single_process(tmp_path, use_graph, level_buckets, break_rank1):
+    _check_two_ranks(tmp_path, use_graph, "gloo", level_buckets, break_rank1)
 
 
-def _check_two_ranks(tmp_path, use_graph, backend, level_buckets=True):
+def _check_two_ranks(tmp_path, use_graph, backend, level_buckets=True, break_rank1=False):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph, backend, level_buckets), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_graph, backend, level_buckets, break_rank1), nprocs=world, join=True)
     dp = torch.load(os.path.join(str(tmp_path), "dp.pt"))
     cfg_d, crit, x, lab, model, TrainEngine = _setup()
     eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=False, overlap=True)    # world 1: overlap off automatically

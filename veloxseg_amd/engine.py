@@ -231,6 +231,7 @@ class TrainEngine:
         # stream of the stage: measured on one GPU the markers cost 0.85 ms per step (7.50 vs 6.65 ms), more than the ~0.2 ms of all-reduce
         # (5.5 MB over xGMI) they can hide
         self.level_buckets = bool(level_buckets) or os.environ.get("VELOXSEG_LEVEL_BUCKETS") == "1"
+        self._two_buckets = bool(use_graph) and replay == "tape" and not self.level_buckets
         VF.set_precision(precision)            # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision); process-wide
         self.precision = precision
         self.bucket_min_bytes = int(bucket_min_bytes)      # all-reduce buckets below this size are merged into the next one (latency-bound collectives)
@@ -314,6 +315,10 @@ class TrainEngine:
         self.flat.zero_grad()
         handles = []
         plan = self.flat.plan(self.bucket_min_bytes)
+        if self._two_buckets:
+            # an engine that was asked for tapes reduces [decoders | encoder] (see level_buckets); a rank whose capture failed and fell back to these eager
+            # launches must issue the SAME collectives as the ranks that replay tapes
+            plan = [(4, self.flat.split, self.flat.numel), (0, 0, self.flat.split)] if self.flat.split > 0 else [(0, 0, self.flat.numel)]
         self._reduced = []
         by_trigger = {t: (lo, hi) for t, lo, hi in plan}
         fired = set()
