@@ -385,10 +385,16 @@ int vx_tape_free(VxTape* tape);
 /* markers: vx_tape_mark(id, stream) inside the captured code; the tape records an event at that point of its schedule instead of launching anything,
  * vx_tape_wait_marker makes `stream` wait for it (after vx_tape_replay has been called for this step).  vx_tape_has_marker: 1 / 0. */
 /* cross-lane dependency without an event (csrc/tape.hip): _set stores `value` to the device word `flag` once the stream reaches it, _wait holds the
- * stream until the word has reached `value` (wrap-around compare).  ONLY between streams on different hardware queues (vx_tape_lanes_distinct). */
+ * stream until the word has reached `value` (wrap-around compare).  The tapes use them only when the four lane streams were measured to sit on
+ * different hardware queues (vx_tape_lanes_distinct() == 4); otherwise, and with VELOXSEG_TAPE_FLAGS=0, the same dependencies are events. */
 int vx_tape_flag_set(void* flag, int value, void* stream);
 int vx_tape_flag_wait(const void* flag, int value, void* stream);
 int vx_tape_set_flags(int on);   /* A/B: cross-lane dependencies inside a tape through flag kernels (1, default; VELOXSEG_TAPE_FLAGS=0 in the environment turns it off) or events (0) */
+/* a poll that waited longer than this gives up WITHOUT trapping: it bumps a host-visible counter and lets its stream continue.  Default 5000 ms
+ * (VELOXSEG_TAPE_FLAG_TIMEOUT_MS); 0 = wait for ever.  vx_tape_flag_timeouts(): answer, not a status -- polls that gave up since the last call
+ * (clears the count); vx_tape_replay / vx_tape_hop return -3 with a message in vx_last_error() when the count is non-zero at their entry. */
+int vx_tape_set_flag_timeout_ms(int ms);
+int vx_tape_flag_timeouts(void);
 /* `dst` waits for everything enqueued on `src` so far (event record + wait, or -- flags on -- a set kernel on src and a poll kernel on dst);
  * slot 0..255 names the call site, which must always pass the same src stream */
 int vx_tape_hop(int slot, void* src, void* dst);

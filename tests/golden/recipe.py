@@ -136,6 +136,9 @@ CASES = {
                        min_big_window_sizes=[[4] * 3, [8] * 3, [4] * 3, [4] * 3]), 1),
     "g6_128_brats": (dict(BASE, input_size=[128, 128, 128], patch_size=4, in_ch=[4], n_classes=4,
                           min_big_window_sizes=[[4] * 3, [8] * 3, [4] * 3, [4] * 3]), 1),
+    # G7: the SHIPPED AutoPET-II configuration exactly (config/models_config_autopetii.json "VeloxSeg": 96^3, patch 4, windows [3,6,3,3]), batch 1
+    "g7_96_m2": (dict(BASE, input_size=[96, 96, 96], patch_size=4, in_ch=[1, 1],
+                      min_big_window_sizes=[[3] * 3, [6] * 3, [3] * 3, [3] * 3]), 1),
 }
-BIG_CASES = ("g5_128_m2", "g6_128_brats")      # fixtures store the arg-max mask bit-packed and coarser subsamples
+BIG_CASES = ("g5_128_m2", "g6_128_brats", "g7_96_m2")      # fixtures store the arg-max mask bit-packed and coarser subsamples
 LOSS_CFG = {"deep_Loss_weight": [1, 1, 1, 1], "RC_Loss_weight": 0.5, "Feature_Loss_weight": 2.0}

@@ -53,7 +53,7 @@ def test_eval_logits_vs_oracle_and_golden(golden_dir, name):
     assert abs(d_ours - d_ref) < 1e-3, (d_ours, d_ref)
 
 
-@pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2", "g6_128_brats"])
+@pytest.mark.parametrize("name", ["g2_32_m2", "g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2", "g6_128_brats", "g7_96_m2"])
 def test_train_step_vs_oracle(golden_dir, name):
     from veloxseg_amd.utils.loss import Loss
     import types

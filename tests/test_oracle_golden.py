@@ -44,7 +44,7 @@ def test_eval_logits_and_argmax(golden_dir, name):
     assert mism == 0.0, f"argmax differs on {mism:.2e} of voxels"
 
 
-@pytest.mark.parametrize("name", ["g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2"])
+@pytest.mark.parametrize("name", ["g1_48_m2", "g3_64_brats", "g4_aniso_m2", "g5_128_m2", "g7_96_m2"])
 def test_train_outputs_loss_grads(golden_dir, name):
     fix, cfg, sd, x, labels = _case(golden_dir, name)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}

@@ -45,7 +45,7 @@ struct VxTape {
     int n_kernels = 0, n_events = 0, n_cross = 0;
     unsigned* flags = nullptr;          // one device word per recording node; replay r stores r, waiters poll for >= r (no reset between replays)
     unsigned seq = 0;
-    int flag_start = 0;
+    int flag_start = 0, n_flags = 0;
     hipStream_t last_s0 = nullptr;
 };
 
@@ -69,35 +69,77 @@ __global__ void vx_spin_k(long long ticks) {
 // Cross-lane dependencies without events: the producing lane runs a one-thread kernel that stores a sequence number to a device flag; the waiting
 // lane runs a one-wave kernel that polls the flag until it reaches that number.  On this runtime an event record + stream wait costs ~14 us of
 // queue time per hop (tools/event_hop_probe.py: every flag combination of hipEventCreateWithFlags); two back-to-back tiny kernels cost ~1.6 us each.
-// Safe only when the two lanes sit on different hardware queues (the poll would otherwise block the kernel it waits for): tape.hip uses it only
-// between lanes of the calibrated pool, and only when the calibration found them pairwise overlapping.
+// Progress: the set kernel of a dependency is always SUBMITTED before its poll kernel (tape order is topological, a hop submits set then wait), and a
+// hardware queue runs its packets in submission order, so the earliest unfinished packet of the process can always run -- whatever the stream ->
+// hardware-queue mapping.  The code nevertheless uses the flags ONLY when the lane calibration found the kPool lanes on pairwise different hardware
+// queues (flags_ok(): g_pool.distinct == kPool); with aliased lanes, under a kernel-serialising profiler, or with VELOXSEG_TAPE_FLAGS=0 the same
+// dependencies are events.
+// A poll gives up after g_flag_timeout_ticks (default 5 s, VELOXSEG_TAPE_FLAG_TIMEOUT_MS / vx_tape_set_flag_timeout_ms; 0 = never): it then bumps a
+// host-visible error word and RETURNS (the kernels behind it run with an unmet dependency -- wrong numbers, but no trap, no dead GPU context); the
+// next vx_tape_replay / vx_tape_hop / vx_tape_flag_timeouts call reports it through its status and vx_last_error().
 __global__ void vx_flag_set_k(unsigned* flag, unsigned value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void vx_flag_wait_k(const unsigned* flag, unsigned value) {
+__global__ void vx_flag_fill_k(unsigned* flags, int n, unsigned value) {       // error path of a replay: release every waiter of the tape
+    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(flags + i, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void vx_flag_wait_k(const unsigned* flag, unsigned value, long long timeout_ticks, unsigned* err) {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 500000000LL) __builtin_trap();      // 5 s at 100 MHz: a dependency that never arrives must fail, not hang the GPU
+            if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) {      // wall_clock64 counts at 100 MHz
+                if (err) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
 }
+static long long g_flag_timeout_ticks = -1;          // -1: from the environment
+static unsigned* g_flag_err_host = nullptr;          // pinned, device-visible word: number of polls that gave up
+static unsigned* g_flag_err_dev = nullptr;
+static long long flag_timeout_ticks() {
+    if (g_flag_timeout_ticks < 0) {
+        const char* e = getenv("VELOXSEG_TAPE_FLAG_TIMEOUT_MS");
+        const long long ms = (e && e[0]) ? atoll(e) : 5000;
+        g_flag_timeout_ticks = ms < 0 ? 0 : ms * 100000LL;
+    }
+    return g_flag_timeout_ticks;
+}
+static unsigned* flag_err_word() {
+    if (!g_flag_err_dev) {
+        if (hipHostMalloc((void**)&g_flag_err_host, sizeof(unsigned) * 4, hipHostMallocMapped) != hipSuccess) { g_flag_err_host = nullptr; return nullptr; }
+        g_flag_err_host[0] = 0;
+        if (hipHostGetDevicePointer((void**)&g_flag_err_dev, g_flag_err_host, 0) != hipSuccess) g_flag_err_dev = nullptr;
+    }
+    return g_flag_err_dev;
+}
+extern "C" int vx_tape_set_flag_timeout_ms(int ms) { g_flag_timeout_ticks = ms <= 0 ? 0 : (long long)ms * 100000LL; return 0; }
+// number of polls that gave up since the last call (answer, not a status); clears the count
+extern "C" int vx_tape_flag_timeouts(void) {
+    if (!g_flag_err_host) return 0;
+    const unsigned n = __atomic_exchange_n(g_flag_err_host, 0u, __ATOMIC_RELAXED);
+    return (int)n;
+}
 static inline void flag_set(hipStream_t s, unsigned* f, unsigned v) { hipLaunchKernelGGL(vx_flag_set_k, dim3(1), dim3(1), 0, s, f, v); }
-static inline void flag_wait(hipStream_t s, const unsigned* f, unsigned v) { hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s, f, v); }
+static inline void flag_wait(hipStream_t s, const unsigned* f, unsigned v) {
+    hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, s, f, v, flag_timeout_ticks(), flag_err_word());
+}
 static int g_use_flags = -1;            // -1: from the environment (VELOXSEG_TAPE_FLAGS, default on)
 static bool use_flags() {
     if (g_use_flags < 0) {
         const char* e = getenv("VELOXSEG_TAPE_FLAGS");
-        // rocprofv3 --pmc runs ONE kernel at a time, across all queues: a polling kernel would never see its flag set (found the safe way: the 5 s trap)
+        // rocprofv3 --pmc runs ONE kernel at a time, across all queues: a polling kernel would never see its flag set
         const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
         const char* ctr = getenv("ROCPROF_COUNTERS");
-        const bool serialised = (pmc && pmc[0] == '1') || (ctr && ctr[0]);
+        const char* ser = getenv("AMD_SERIALIZE_KERNEL");
+        const bool serialised = (pmc && pmc[0] == '1') || (ctr && ctr[0]) || (ser && ser[0] && ser[0] != '0');
         g_use_flags = ((e && e[0] == '0') || serialised) ? 0 : 1;
     }
     return g_use_flags == 1;
 }
 extern "C" int vx_tape_set_flags(int on) { g_use_flags = on ? 1 : 0; return 0; }
+static bool flags_ok();                 // use_flags() AND the calibrated lanes sit on pairwise different hardware queues (defined below the lane pool)
 // `dst` waits for everything enqueued on `src` so far -- hipEventRecord + hipStreamWaitEvent, or (flags on) a set kernel on src and a poll kernel on dst.
 // `slot` (0..255) names the call site: a site must always use the same src stream (its sequence numbers rely on that stream's order).
 static unsigned* g_hop_flags = nullptr;
@@ -107,7 +149,8 @@ static void* g_hop_src[256] = {};
 extern "C" int vx_tape_hop(int slot, void* src, void* dst) {
     if (slot < 0 || slot >= 256) return -1;
     if (src == dst) return 0;
-    if (use_flags()) {
+    if (int nto = vx_tape_flag_timeouts()) VX_FAIL(-3, "vx_tape_hop: %d cross-lane poll(s) of an earlier replay gave up after the flag timeout (results of that step are not trustworthy)", nto);
+    if (flags_ok()) {
         if (!g_hop_flags) {
             // hipMemset of device memory may return before the fill has run (it is queued on the NULL stream): a poll on another stream would then read
             // whatever the allocation held and pass at once.  That was the first replay of a process going wrong when the GPU was shared with
@@ -131,7 +174,7 @@ extern "C" int vx_tape_flag_set(void* flag, int value, void* stream) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vx_tape_flag_wait(const void* flag, int value, void* stream) {
-    hipLaunchKernelGGL(vx_flag_wait_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned)value);
+    flag_wait((hipStream_t)stream, (const unsigned*)flag, (unsigned)value);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 namespace {
@@ -232,6 +275,7 @@ extern "C" int vx_tape_mark(int id, void* stream) {
     return 0;
 }
 
+static bool flags_ok() { return use_flags() && (!g_pool.ready || g_pool.distinct >= kPool); }
 extern "C" int vx_tape_lanes_distinct(void) { return g_pool.ready ? g_pool.distinct : -1; }      // how many lane streams were measured to overlap pairwise (-1: not chosen yet)
 
 extern "C" int vx_tape_lane_stream(void* any_stream, int lane, void** out) {
@@ -383,6 +427,7 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
         }
     T->flag_start = nflags;                       // + 1 word for the start gate, + 1 per lane for the joins
     nflags += 1 + (int)tail.size();
+    T->n_flags = nflags;
     HIPQ(hipMalloc((void**)&T->flags, sizeof(unsigned) * (size_t)nflags), "hipMalloc");
     HIPQ(hipMemset(T->flags, 0, sizeof(unsigned) * (size_t)nflags), "hipMemset");
     HIPQ(hipDeviceSynchronize(), "hipDeviceSynchronize");      // (the fill is queued on the NULL stream: it must have run before the first poll)
@@ -424,19 +469,8 @@ static int tape_launch(TapeNode& nd, hipStream_t s) {
     return 0;
 }
 
-extern "C" int vx_tape_replay(VxTape* T, void* stream) {
-    VX_REQUIRE(T, "vx_tape_replay: null tape");
-    if (T->nodes.empty()) return 0;
-    hipStream_t s0 = (hipStream_t)stream;
+static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq) {
     const size_t L = T->lanes.size();
-    if (L == 1) T->lanes[0] = s0;                 // a single chain runs on the caller's stream
-    else {
-        int rc = pool_init(s0);
-        if (rc) return rc;
-        for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[l % kPool];
-    }
-    const bool fl = use_flags() && T->flags != nullptr;
-    const unsigned seq = ++T->seq;
     if (L > 1) {
         if (fl) {
             if (T->last_s0 && T->last_s0 != s0) (void)hipStreamSynchronize(T->last_s0);      // another caller stream than last time (rare): its set kernel must not be overtaken
@@ -449,9 +483,8 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
             for (size_t l = 0; l < L && l < (size_t)kPool; ++l) HIPQ(hipStreamWaitEvent(T->lanes[l], T->start, 0), "hipStreamWaitEvent");
         }
     }
-    // cross-lane dependencies: flag kernels (~2 us of queue time per hop) instead of event record + stream wait (~14 us: tools/event_hop_probe.py).
-    // Deadlock-free for any stream -> hardware-queue mapping as long as a hardware queue runs its packets in submission order: the set kernel of a
-    // dependency is always submitted before its poll kernel (the nodes are in topological order), so the earliest unfinished packet can always run.
+    // cross-lane dependencies: flag kernels (~2 us of queue time per hop) instead of event record + stream wait (~14 us: tools/event_hop_probe.py);
+    // see the comment at vx_flag_set_k for why this cannot deadlock and when it is used
     for (TapeNode& nd : T->nodes) {
         hipStream_t s = T->lanes[nd.lane];
         for (int w : nd.waits) {
@@ -476,6 +509,35 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
                 }
             }
     return 0;
+}
+
+extern "C" int vx_tape_replay(VxTape* T, void* stream) {
+    VX_REQUIRE(T, "vx_tape_replay: null tape");
+    if (T->nodes.empty()) return 0;
+    if (int nto = vx_tape_flag_timeouts()) VX_FAIL(-3, "vx_tape_replay: %d cross-lane poll(s) of an earlier replay gave up after the flag timeout (results of that step are not trustworthy)", nto);
+    hipStream_t s0 = (hipStream_t)stream;
+    const size_t L = T->lanes.size();
+    if (L == 1) T->lanes[0] = s0;                 // a single chain runs on the caller's stream
+    else {
+        int rc = pool_init(s0);
+        if (rc) return rc;
+        for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[l % kPool];
+    }
+    const bool fl = flags_ok() && T->flags != nullptr;
+    const unsigned seq = ++T->seq;
+    const int rc = tape_replay_body(T, s0, fl, seq);
+    if (rc != 0 && fl) {
+        // a launch failed half-way: polls may already be queued whose set kernels never will be.  Release them (every word of this tape >= seq) from a
+        // stream of its own, so that the queues drain instead of spinning into the timeout.
+        hipStream_t rs = nullptr;
+        if (hipStreamCreateWithFlags(&rs, hipStreamNonBlocking) == hipSuccess) {
+            hipLaunchKernelGGL(vx_flag_fill_k, dim3(1), dim3(256), 0, rs, T->flags, T->n_flags, seq);
+            (void)hipStreamSynchronize(rs);
+            (void)hipStreamDestroy(rs);
+        }
+        (void)hipGetLastError();
+    }
+    return rc;
 }
 
 extern "C" int vx_tape_wait_marker(VxTape* T, int id, void* stream) {

@@ -93,8 +93,10 @@ class FlatParams:
             lo, hi = self.bounds[b]
             if lo_pending is not None:
                 hi = lo_pending[1]
-            if b != 0 and (hi - lo) * 4 < min_bytes:
-                lo_pending = (lo, hi)          # too small: reduce together with the next bucket down
+            if b != 0 and b != 4 and (hi - lo) * 4 < min_bytes:
+                # too small: reduce together with the next bucket down.  (Never the decoder bucket: the taped step always reduces [split, n) on its
+                # own between the decoder and the encoder backward, and a rank that fell back to eager launches must issue the same collectives.)
+                lo_pending = (lo, hi)
                 continue
             out.append((b, lo, hi))
             lo_pending = None
@@ -138,6 +140,15 @@ class LaunchTape:
                 H.call("vx_tape_free", h)
             except Exception:
                 pass
+
+
+class _EmptyTape:
+    """a captured stage without a single launch: nothing to build, nothing to replay"""
+    n_nodes = n_kernels = n_lanes = n_events = 0
+    handle = None
+
+    def replay(self):
+        pass
 
 
 class TapedPredictor:
@@ -185,10 +196,18 @@ class TapedPredictor:
                 return None
         return (xs, out, tape)
 
+    def _signature(self):
+        """where the parameters and buffers live: a tape holds raw device pointers, so it is only valid while nothing was re-homed (TrainEngine's
+        flat buffer sets p.data, model.to() / .float(), a swapped parameter)"""
+        return tuple((t.data_ptr(), t.dtype, t.device.index) for t in list(self.model.parameters()) + list(self.model.buffers()))
+
     @torch.inference_mode()
     def __call__(self, x: torch.Tensor):
         if self.model.training or not x.is_cuda:
             return self.model(x)
+        sig = self._signature()
+        if sig != getattr(self, "_sig", None):
+            self._tapes, self._sig = {}, sig          # the storage moved since the capture: drop every tape of the old addresses
         key = (tuple(x.shape), x.dtype, str(x.device))
         if key not in self._tapes:
             try:
@@ -238,7 +257,11 @@ class TrainEngine:
         if hasattr(model, "ds_fused"):
             # deep-supervision heads stay on their grids; the loss kernels interpolate (csrc/loss_ds.hip).  Row widths the kernels do not tile
             # (W/4 must divide 64: 96^3 patches) keep the reference's up-sampled output list
-            ok = bool(fuse_ds) and bool(H.query("vx_seg_loss_ds_ok", int(model.n_classes), *[int(v) for v in batch_shape[2:]]))
+            # Only with the library's own Loss: any other criterion gets the reference's output list (every head at the input size).
+            from .utils.loss import Loss as _Loss
+            ok = (bool(fuse_ds) and isinstance(criterion, _Loss)
+                  and bool(H.query("vx_seg_loss_ds_ok", int(model.n_classes), *[int(v) for v in batch_shape[2:]])))
+            self._ds_fused_before = bool(model.ds_fused)
             model.ds_fused = ok
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
@@ -363,6 +386,7 @@ class TrainEngine:
                 with torch.cuda.stream(self.comm_stream):
                     self._allreduce(lo, hi)
         cur.wait_stream(self.comm_stream)
+        self._check_tiling()
         self.loss.copy_(loss.detach())
         self.last_outputs = [o.detach() for o in outs]
 
@@ -415,6 +439,12 @@ class TrainEngine:
         """(inside the encoder backward, on autograd's device thread) everything queued so far on the forked streams joins the STAGE's stream, then
         the marker goes there.  Not the thread's current stream: in the hook that is the NULL stream, and touching it during a capture kills the capture."""
         st = self._stage_stream
+        m = VF.cpp_module() if getattr(self, "_enc_bwd_defer", False) else None
+        if m is not None:
+            # the weight-gradient launches of this level are deferred closures (set_wgrad_defer in _s_enc_bwd): launch them NOW, each on the stream it
+            # was queued from, so that the marker -- and with it the all-reduce of this level's bucket -- is ordered after them.  Without this the
+            # bucket was reduced before its deferred weight gradients ran and they landed on top of the reduced values (ranks diverge).
+            m.wgrad_join(st.cuda_stream, self.dev.index or 0, True)
         with torch.cuda.stream(st):
             capturing = torch.cuda.is_current_stream_capturing()
         for s_ in VF.all_side_streams(self.dev):
@@ -542,10 +572,12 @@ class TrainEngine:
         m = VF.cpp_module() if (self.use_graph and self.replay_mode == "tape" and TAPE_WGRAD_DEFER) else None
         if m is not None:
             m.set_wgrad_defer(True)
+        self._enc_bwd_defer = m is not None
         try:
             with self._wgrad_side():
                 torch.autograd.backward(bt, bg)
         finally:
+            self._enc_bwd_defer = False
             if m is not None:
                 m.wgrad_join(self._stage_stream.cuda_stream, self.dev.index or 0, True)
                 m.set_wgrad_defer(False)
@@ -595,6 +627,17 @@ class TrainEngine:
 
     def _eager_pass(self):
         self._eager_stages()
+
+    def _check_tiling(self):
+        """the slices reduced in one step must tile [0, numel) exactly once (ranks that disagree on this hang or diverge)"""
+        got = sorted(self._reduced or [])
+        pos = 0
+        for lo, hi in got:
+            if lo != pos:
+                break
+            pos = hi
+        if pos != self.flat.numel or not got:
+            raise RuntimeError(f"TrainEngine: the all-reduce slices of this step {got} do not tile the flat gradient buffer [0, {self.flat.numel})")
 
     def _allreduce(self, lo, hi):
         if getattr(self, "_reduced", None) is not None:
@@ -667,12 +710,20 @@ class TrainEngine:
         # with RCCL running (world > 1) its watchdog thread polls events while we capture: in the default "global" error mode that invalidates the
         # capture; "thread_local" checks only the capturing thread (kernels queued by autograd's device thread are captured either way)
         mode = "thread_local" if (self.world > 1 or os.environ.get("VELOXSEG_CAPTURE_MODE") == "thread_local") else "global"
-        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-            if tape:
-                fn(*args)                      # the tape launches node by node: no need for the second branch that keeps hipGraphLaunch correct
-            else:
-                self._forked(fn, *args)
-        return LaunchTape(g, self.tape_lanes) if tape else g
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                if tape:
+                    fn(*args)                      # the tape launches node by node: no need for the second branch that keeps hipGraphLaunch correct
+                else:
+                    self._forked(fn, *args)
+        for w_ in caught:                          # a stage may hold no launches in some configurations (e.g. dec_wg[k] of a decoder without deferred
+            if "Graph is empty" not in str(w_.message):      # weight gradients): that is an _EmptyTape below, not a warning for the user
+                warnings.warn_explicit(w_.message, w_.category, w_.filename, w_.lineno)
+        if not tape:
+            return g
+        t = LaunchTape(g, self.tape_lanes)
+        return t if t.n_nodes > 0 else _EmptyTape()
 
     def _capture(self):
         """One hipGraph per stage.  Branch graphs allocate from their own memory pool (a shared pool hands the blocks one capture freed
@@ -790,7 +841,10 @@ class TrainEngine:
                 tape = G["enc_bwd"] if self.replay_mode == "tape" else None
                 done = split
                 for trig, lo, hi in self.flat.plan(self.bucket_min_bytes):       # tail first: (decoders), level 4, level 3, ...
-                    if trig == 4 or hi > done:
+                    if trig == 4:
+                        continue
+                    hi = min(hi, done)        # a small decoder bucket is merged into the next plan entry: its tail [split, n) is already reduced
+                    if hi <= lo:
                         continue
                     if tape is not None and H.query("vx_tape_has_marker", tape.handle, int(trig)):
                         # the tape recorded an event where this level's gradients were complete: reduce the bucket while the lower levels still run
@@ -803,6 +857,7 @@ class TrainEngine:
                     with torch.cuda.stream(self.comm_stream):
                         self._allreduce(0, done)            # what has no marker (always levels 1-2)
                 cur.wait_stream(self.comm_stream)
+                self._check_tiling()
             else:
                 if wg_lane is not None:
                     cur.wait_stream(wg_lane)

@@ -139,15 +139,14 @@ class Net(torch.nn.Module):
         return out[0] if isinstance(out, (list, tuple)) else out
 
 
-_taped = {}
-
-
 @torch.inference_mode()
 def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int, overlap: float, taped: bool = True):
     """eval-mode sliding-window segmentation of one (B, C, D, H, W) volume -> (blended logits, uint8 label map).
     taped (default): the forward of a full window batch is captured once per model and replayed as a launch tape (engine.TapedPredictor); the result
     is the eager forward's (checked at capture).  The accumulator of the blending reads the predictor's static output before the next replay
-    overwrites it (same stream)."""
+    overwrites it (same stream).  The predictor hangs on the model object (no process-wide cache, nothing outlives the model) and re-captures
+    when the parameters / buffers were re-homed since the capture (TrainEngine's flat buffer, .to(), a parameter swap): a tape bakes in raw
+    device pointers."""
     was_training = model.training
     model.eval()
     try:
@@ -156,11 +155,10 @@ def infer_volume(model: torch.nn.Module, volume: torch.Tensor, roi_size: Sequenc
         pred = net
         if taped and volume.is_cuda and os.environ.get("VELOXSEG_INFER_TAPE", "1") != "0":
             from ..engine import TapedPredictor
-            key = id(model)
-            if key not in _taped or _taped[key][0]() is not model:
-                import weakref
-                _taped[key] = (weakref.ref(model), TapedPredictor(net))
-            pred = _taped[key][1]
+            pred = model.__dict__.get("_vx_taped_predictor")
+            if pred is None:
+                pred = TapedPredictor(net)
+                model.__dict__["_vx_taped_predictor"] = pred       # plain attribute (not a sub-module): dies with the model
         return sliding_window_inference(volume, roi_size, sw_batch_size, pred, overlap=overlap, return_labels=True)
     finally:
         model.train(was_training)
