@@ -370,6 +370,33 @@ int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y
 int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P, int accumulate,
                           void* stream);
 
+/* ---- fused per-voxel chains of a PWA transformer block, every modality of the block in one launch (csrc/pwa_fused.hip) ------------------------------
+ * "pre": xn = LN_channels(x) (attention_utils.py:29-43, eps as given) followed by NS <= 3 1x1 projections out_s = W_s xn + b_s (PWA.py:291-298: q, k, v).
+ * With s2d = 1 the input is gathered 8-way strided from a (B, C/8, 2gd, 2gh, 2gw) tensor first, i.e. PatchMerging (attention_utils.py:127-168): LN(8C) and the
+ * 8C -> 2C reduction.  Every pointer array is a HOST array (read at the call): M modalities x a fixed number of entries, listed at each entry.  Shapes:
+ * x (B, C, V), W_s (J_s, C), out_s (B, J_s, V), xn (B, C, V) or NULL.  C and J_s multiples of 16.  vx_ln_pw_ok: 1 when the shape is covered.
+ * Backward: dx = dres + LN'(sum_s W_s^T dout_s); the LayerNorm-parameter sums leave as per-block partial rows part[vx_ln_pw_tiles(B, V)][2C] (dgamma | dbeta)
+ * that vx_pw_wgrad_group folds; the weight gradients dW_s = dout_s xn^T are jobs of the same grouped launch. */
+int vx_ln_pw_ok(int C, int NS, const int* J, long V, int s2d);
+int vx_ln_pw_tiles(int B, long V);
+/* per modality 13 entries: x, gamma, beta, w0, b0, w1, b1, w2, b2, xn, out0, out1, out2 */
+int vx_ln_pw_fwd(const void* const* ptrs, int M, int NS, const int* J, int B, int C, long V, float eps, int s2d, int gd, int gh, int gw, void* stream);
+/* per modality 11 entries: x, gamma, w0, w1, w2, dout0, dout1, dout2, dres (NULL ok; not with s2d), dx, part */
+int vx_ln_pw_bwd(const void* const* ptrs, int M, int NS, const int* J, int B, int C, long V, float eps, int s2d, int gd, int gh, int gw, void* stream);
+/* "post": y = alpha x + Drop_mix(Wm s + bm) (PWA.py:377,436); out = y + Drop_2(W2 Drop_1(GELU(W1 LN(y) + b1)) + b2) (PWA.py:437, attention_utils.py:45-71).
+ * s (B, Cv, V), x / y / out (B, C, V), Wm (C, Cv), W1 (R, C), W2 (C, R).  Dropout masks = those of vx_axpy_drop_* / vx_gelu_drop_* for the same sites.
+ * per modality 24 entries: s, x, wm, bm, gamma, beta, w1, b1, w2, b2, y, out, dout, ds, dxres, part, sc_n, sc_h, sc_da, sc_dz, sc_dmix, site_mix, site1, site2
+ * (sites: integers cast to pointers).  Backward writes ds = Wm^T dmix, dxres = alpha dy, the partial rows part[vx_pwa_post_tiles(B, V)][2C] and the operands
+ * of the weight-gradient jobs: sc_n = LN(y) (C), sc_h (R), sc_da (R), sc_dz (C), sc_dmix (C) -- dW1 = da n^T, dW2 = dz h^T, dWm = dmix s^T. */
+int vx_pwa_post_ok(int C, int Cv, int R, long V);
+int vx_pwa_post_tiles(int B, long V);
+int vx_pwa_post_fwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
+int vx_pwa_post_bwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
+/* up to 12 weight gradients of 1x1 convs (dW += dy x^T, db += sum dy) and up to 8 folds of partial rows in one launch.
+ * jobs: ptrs 4 per job (x (B,Cin,V), dy (B,Cout,V), dw, db or NULL), dims 4 per job (Cin, Cout, V, B); folds: fptrs 3 per fold (part (rows, 2C), dgamma, dbeta),
+ * fdims 2 per fold (C, rows) */
+int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int nj, const void* const* fptrs, const int* fdims, int nf, void* stream);
+
 /* ---- launch tape: a captured training stage replayed as plain launches on several HIP streams -----------------------------------------
  * The reference trains through eager PyTorch (utils/train_autopet.py:233-262: model(), loss, backward(), optimizer.step()); here one captured
  * pass of a stage (hipStreamBeginCapture ... EndCapture -> hipGraph_t, addresses from a private pool) is read back ONCE -- kernel and memset

@@ -64,8 +64,19 @@ def test_sliding_window_with_the_hip_model(golden_dir):
         got_eager, _ = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5, taped=False)
     assert torch.equal(got, want)                       # infer_volume replays the captured forward of a window batch (engine.TapedPredictor) ...
     assert torch.equal(got, got_eager)                  # ... which is bit for bit the eager forward
-    tp = IR._taped[id(model)][1]
+    tp = model.__dict__["_vx_taped_predictor"]          # the predictor hangs on the model (no process-wide cache)
     assert any(e is not None and e[2].n_kernels > 0 for e in tp._tapes.values()), "the window batches were expected to replay a launch tape"
+    # re-homed parameters (what engine.FlatParams does, or model.to()): the tape holds the OLD addresses and must be re-captured, not replayed
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.data = (p_.data * 1.5).clone()
+    with torch.inference_mode():
+        got2, _ = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5)
+        want2, _ = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5, taped=False)
+    assert torch.equal(got2, want2) and not torch.equal(got2, got), "the taped predictor kept reading the parameters' old storage"
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.data = (p_.data / 1.5).clone()
     ocfg = O.OracleConfig(**cfg)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     with torch.no_grad():

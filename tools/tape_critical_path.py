@@ -44,6 +44,8 @@ def demangle(names):
 
 def analyse(tag, tape):
     n = tape.n_nodes
+    if n == 0 or tape.handle is None:
+        return dict(tag=tag, n=0, total=0.0, cp=0.0, lanes={}, path=[], all=[])
     us = (ctypes.c_float * n)()
     H.call("vx_tape_profile", tape.handle, H.stream_ptr(), 3, ctypes.addressof(us))
     lane, grid, waits = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * (4 * n))()

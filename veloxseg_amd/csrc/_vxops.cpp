@@ -1126,27 +1126,51 @@ PYBIND11_MODULE(_vxops, m) {
     // the input gradients that OTHER streams wait for leave it earlier; no extra stream competes for CUs.  The closures keep their operands alive.
     m.def("set_wgrad_defer", [](bool on) { WG.enabled = on; WG.same = on; });
     m.def("set_wgrad_hold", []() { WG.enabled = false; WG.same = false; });      // stop deferring but KEEP what is queued (a later wgrad_join under set_wgrad_defer launches it)
-    m.def("wgrad_join", [](int64_t stream, int64_t device, bool final) {
+    // a weight-gradient launch written in python (functional._submit_wgrad: the grouped launch of the fused PWA chains): same queue, same rules.  The
+    // callable receives the stream to launch on; it is released under the GIL wherever the queue drops it.
+    m.def("wgrad_submit_py", [](int64_t stream, int64_t device, py::function f) {
+        std::shared_ptr<py::function> sf(new py::function(std::move(f)), [](py::function* p) { py::gil_scoped_acquire g; delete p; });
+        wgrad_submit(sp(stream), (int)device, [sf](void* s) { py::gil_scoped_acquire g; (*sf)((int64_t)(uintptr_t)s); });
+    });
+    // spread > 1 (deferral on the submitting streams only): the queued launches are independent sinks, so instead of running one after the other at the
+    // end of the stream they were queued from they are dealt round-robin onto `spread` streams (the submitting stream and spread - 1 forked ones, which
+    // first wait for it); the joining stream waits for all of them.  In a captured stage these become parallel branches, i.e. different tape lanes.
+    m.def("wgrad_join", [](int64_t stream, int64_t device, bool final, int64_t spread) {
         if (WG.same) {
             hipStream_t js = (hipStream_t)sp(stream);
             if (WG.ev[0] == nullptr) for (auto& e : WG.ev) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+            static std::vector<c10::hip::HIPStreamMasqueradingAsCUDA> sides;
+            const int nsp = (int)std::max<int64_t>(1, std::min<int64_t>(spread, 4));
+            while ((int)sides.size() < nsp - 1) sides.push_back(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, (c10::DeviceIndex)device));
             void* seen[8]; int ns = 0;
+            std::vector<std::pair<void*, int>> forked;                    // (submitting stream, side index) pairs already ordered
+            bool side_used[4] = {false, false, false, false};
             for (size_t i = 0; i < WG.pending.size(); ++i) {
                 auto& p = WG.pending[i];
-                {
+                const int k = nsp > 1 ? (int)(i % (size_t)nsp) : 0;
+                const c10::DeviceIndex dev = (c10::DeviceIndex)(i < WG.pending_dev.size() ? WG.pending_dev[i] : device);
+                if (k == 0) {
                     // the closure allocates its temporaries (partial-sum slices, a channels-last copy) when it is launched.  They must come from
                     // the pool of the stream the kernels run on: a cached block of the CALLER's stream may still be in use by kernels queued on
                     // it, which the launch stream does not wait for (seen as a corrupted level-1 attention backward, brats128 B=4, eager stages)
-                    const c10::DeviceIndex dev = (c10::DeviceIndex)(i < WG.pending_dev.size() ? WG.pending_dev[i] : device);
                     auto ls = p.first ? c10::hip::getStreamFromExternalMasqueradingAsCUDA((hipStream_t)p.first, dev) : c10::hip::getDefaultHIPStreamMasqueradingAsCUDA(dev);
                     c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(ls);
                     p.second(p.first);
+                    bool dup = p.first == (void*)js;
+                    for (int j = 0; j < ns; ++j) dup = dup || seen[j] == p.first;
+                    if (!dup && ns < 8) seen[ns++] = p.first;
+                } else {
+                    auto& side = sides[k - 1];
+                    bool ordered = false;
+                    for (auto& f : forked) ordered = ordered || (f.first == p.first && f.second == k);
+                    if (!ordered) { wg_order((hipStream_t)p.first, side.stream()); forked.emplace_back(p.first, k); }
+                    c10::hip::HIPStreamGuardMasqueradingAsCUDA guard(side);
+                    p.second((void*)side.stream());
+                    side_used[k] = true;
                 }
-                bool dup = p.first == (void*)js;
-                for (int i = 0; i < ns; ++i) dup = dup || seen[i] == p.first;
-                if (!dup && ns < 8) seen[ns++] = p.first;
             }
-            for (int i = 0; i < ns; ++i) wg_order((hipStream_t)seen[i], js);      // the joining stream waits for the streams that got late work
+            for (int j = 0; j < ns; ++j) wg_order((hipStream_t)seen[j], js);      // the joining stream waits for the streams that got late work
+            for (int k = 1; k < nsp; ++k) if (side_used[k]) wg_order(sides[k - 1].stream(), js);
             WG.pending.clear(); WG.pending_dev.clear();
             WG.done.clear();
             return;
@@ -1154,7 +1178,7 @@ PYBIND11_MODULE(_vxops, m) {
         wg_flush((int)device);
         if (WG.stream.has_value() && !WG.done.empty()) wg_order(WG.stream->stream(), (hipStream_t)sp(stream));
         if (final) WG.done.clear();          // after the wait above: the memory may be reused by the joining stream
-    });
+    }, py::arg("stream"), py::arg("device"), py::arg("final"), py::arg("spread") = 0);
 
     // kernel pass of bench.py: every C-ABI call made from this module between profile_begin() and profile_end() is timed with HIP events on its
     // launch stream; profile_end() -> [(entry, (small integer arguments...), ms)]

@@ -635,6 +635,75 @@ extern "C" int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float
     return 0;
 }
 
+// Several weight gradients (and the folds of LayerNorm-parameter partial sums) in ONE launch: the sink of a fused PWA chain's backward
+// (csrc/pwa_fused.hip).  Job j owns blocks [blk0, blk0 + nblk); a weight-gradient job is vx_pw_wgrad_body over its own (x, dy), a fold job adds
+// `rows` partial rows of width 2C (dgamma | dbeta, one row per block of the chain kernel) into the two parameter gradients, 64 rows per block.
+struct VxWgJob { const float* x; const float* dy; float* dw; float* db; int Cin, Cout; long V; int B, vpw, chunks_per_b, nt, gx, blk0, nblk; };
+struct VxFoldJob { const float* part; float* dg; float* dbeta; int C, rows, blk0, nblk; };
+struct VxWgGroup { VxWgJob j[12]; VxFoldJob f[8]; int nj, nf; };
+__global__ void __launch_bounds__(256) vx_pw_wgrad_group_k(VxWgGroup g) {
+    const int id = blockIdx.x;
+    for (int k = 0; k < g.nj; ++k) {
+        const VxWgJob& J = g.j[k];
+        if (id >= J.blk0 && id < J.blk0 + J.nblk) {
+            const int l = id - J.blk0;
+            vx_pw_wgrad_body(l % J.gx, l / J.gx, J.x, nullptr, J.Cin, J.Cin, J.dy, J.Cout, J.V, J.B, J.dw, J.db, J.vpw, J.chunks_per_b, J.nt);
+            return;
+        }
+    }
+    for (int k = 0; k < g.nf; ++k) {
+        const VxFoldJob& F = g.f[k];
+        if (id >= F.blk0 && id < F.blk0 + F.nblk) {
+            const int r0 = (id - F.blk0) * 64, r1 = min(F.rows, r0 + 64), n = 2 * F.C;
+            for (int i = threadIdx.x; i < n; i += 256) {
+                float s0 = 0.0f, s1 = 0.0f;
+                int rr = r0;
+                for (; rr + 1 < r1; rr += 2) { s0 += F.part[(long)rr * n + i]; s1 += F.part[(long)(rr + 1) * n + i]; }
+                if (rr < r1) s0 += F.part[(long)rr * n + i];
+                atomicAdd(i < F.C ? F.dg + i : F.dbeta + (i - F.C), s0 + s1);
+            }
+            return;
+        }
+    }
+}
+
+/* jobs: ptrs 4 per job (x (B,Cin,V), dy (B,Cout,V), dw (Cout,Cin) +=, db (Cout) += or NULL), dims 4 per job (Cin, Cout, V, B);
+ * folds: fptrs 3 per fold (part (rows, 2C), dgamma +=, dbeta +=), fdims 2 per fold (C, rows) */
+extern "C" int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int nj, const void* const* fptrs, const int* fdims, int nf, void* stream) {
+    VX_REQUIRE(nj >= 0 && nj <= 12 && nf >= 0 && nf <= 8 && (nj + nf) > 0 && (nj == 0 || (ptrs && dims)) && (nf == 0 || (fptrs && fdims)), "vx_pw_wgrad_group: bad args");
+    VxWgGroup g = {};
+    g.nj = nj; g.nf = nf;
+    long blk = 0;
+    for (int k = 0; k < nj; ++k) {
+        VxWgJob& J = g.j[k];
+        J.x = (const float*)ptrs[4 * k]; J.dy = (const float*)ptrs[4 * k + 1]; J.dw = (float*)ptrs[4 * k + 2]; J.db = (float*)ptrs[4 * k + 3];
+        J.Cin = (int)dims[4 * k]; J.Cout = (int)dims[4 * k + 1]; J.V = dims[4 * k + 2]; J.B = (int)dims[4 * k + 3];
+        VX_REQUIRE(J.x && J.dy && J.dw && J.Cin > 0 && J.Cout > 0 && J.V > 0 && J.B > 0, "vx_pw_wgrad_group: bad job %d", k);
+        const int mt = vx_cdiv(J.Cout, 16), nt = vx_cdiv(J.Cin, 16);
+        long waves_per_tile = 1024 / ((long)mt * nt);
+        if (waves_per_tile < 4) waves_per_tile = 4;
+        long vpw = ((long)J.B * J.V + waves_per_tile - 1) / waves_per_tile;
+        vpw = (vpw + 63) / 64 * 64;
+        if (vpw < 256) vpw = 256;
+        J.vpw = (int)vpw; J.chunks_per_b = vx_cdiv(J.V, vpw); J.nt = nt;
+        J.gx = vx_cdiv((long)J.B * J.chunks_per_b, 4);
+        J.blk0 = (int)blk; J.nblk = J.gx * mt * nt;
+        blk += J.nblk;
+    }
+    for (int k = 0; k < nf; ++k) {
+        VxFoldJob& F = g.f[k];
+        F.part = (const float*)fptrs[3 * k]; F.dg = (float*)fptrs[3 * k + 1]; F.dbeta = (float*)fptrs[3 * k + 2];
+        F.C = fdims[2 * k]; F.rows = fdims[2 * k + 1];
+        VX_REQUIRE(F.part && F.dg && F.dbeta && F.C > 0 && F.rows > 0, "vx_pw_wgrad_group: bad fold %d", k);
+        F.blk0 = (int)blk; F.nblk = vx_cdiv(F.rows, 64);
+        blk += F.nblk;
+    }
+    VX_REQUIRE(blk < 0x7fffffffL, "vx_pw_wgrad_group: grid too large");
+    vx_pw_wgrad_group_k<<<dim3((unsigned)blk), 256, 0, (hipStream_t)stream>>>(g);
+    VX_LAUNCH_CHECK("vx_pw_wgrad_group");
+    return 0;
+}
+
 // The same one-launch backward for LARGE volumes (one voxel per thread for the input gradient): blocks [0, n1) run vx_pw_bwd_data_body, the rest the
 // MFMA weight-gradient body.
 template <int CIT>

@@ -579,7 +579,9 @@ class TrainEngine:
         finally:
             self._enc_bwd_defer = False
             if m is not None:
-                m.wgrad_join(self._stage_stream.cuda_stream, self.dev.index or 0, True)
+                # (VELOXSEG_WGRAD_SPREAD=3 deals these sinks onto the stage's three lanes instead of the stream they were queued from: measured 7.21 vs
+                # 6.28 ms per step on one MI355X -- the big weight-gradient grids then land beside the tail of the chain; off)
+                m.wgrad_join(self._stage_stream.cuda_stream, self.dev.index or 0, True, int(os.environ.get("VELOXSEG_WGRAD_SPREAD", "0")))
                 m.set_wgrad_defer(False)
             self._drop_level_hooks()
 
@@ -704,7 +706,7 @@ class TrainEngine:
         fn(*args)
         cur.wait_stream(self._fork_stream)
 
-    def _graph(self, pool, fn, *args):
+    def _graph(self, pool, fn, *args, lanes=None):
         tape = self.replay_mode == "tape"
         g = torch.cuda.CUDAGraph(keep_graph=True) if tape else torch.cuda.CUDAGraph()
         # with RCCL running (world > 1) its watchdog thread polls events while we capture: in the default "global" error mode that invalidates the
@@ -722,7 +724,7 @@ class TrainEngine:
                 warnings.warn_explicit(w_.message, w_.category, w_.filename, w_.lineno)
         if not tape:
             return g
-        t = LaunchTape(g, self.tape_lanes)
+        t = LaunchTape(g, int(lanes or self.tape_lanes))
         return t if t.n_nodes > 0 else _EmptyTape()
 
     def _capture(self):
@@ -763,7 +765,9 @@ class TrainEngine:
                 G["dec_wg"].append(self._graph(pools[k], self._s_dec_wg, k))
         else:
             G["dec_bwd"] = [self._graph(pools[k], self._s_dec_bwd, k) for k in range(nb)]
-        G["enc_bwd"] = self._graph(main_pool, self._s_enc_bwd)
+        # the encoder backward shares the GPU with the dec_wg tapes, which are replayed on the 4th lane stream: keep it on the other three (a tape laid
+        # out on four lanes would put one of its chains behind ~2 ms of decoder weight gradients)
+        G["enc_bwd"] = self._graph(main_pool, self._s_enc_bwd, lanes=3 if "dec_wg" in G else None)
         self.graphs = G
         # self-check: replays separated by device synchronisation must reproduce the eager pass (same dropout streams)
         for k in range(self.verify_replays):

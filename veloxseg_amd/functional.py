@@ -872,6 +872,222 @@ def ffn_tail(y, norm, ffn, p: float):
     return _FFNTailFn.apply(y, norm, ffn, float(p))
 
 
+# ------------------------------------------------------------------------------------------------
+# fused per-voxel chains of a PWA transformer block, all modalities in one launch (csrc/pwa_fused.hip)
+# ------------------------------------------------------------------------------------------------
+USE_PWA_FUSED = os.environ.get("VELOXSEG_PWA_FUSED", "1") != "0"      # A/B: 0 = LN, q / k / v, mix, FFN as separate launches per modality
+
+
+def _ptrs(vals):
+    """host array of device pointers (None -> NULL); the caller keeps it alive across the call"""
+    return (H.ctypes.c_void_p * len(vals))(*[(v if v else None) for v in vals])
+
+
+def _submit_wgrad(fn):
+    """run fn(stream_ptr) now on the current stream, or -- while the engine defers weight gradients (csrc/_vxops.cpp WgradSide) -- queue it with the
+    other weight-gradient launches of the pass; fn owns its operands"""
+    m = _cpp_mod()
+    st = H.stream_ptr()
+    if m is not None and hasattr(m, "wgrad_submit_py"):
+        m.wgrad_submit_py(int(st or 0), int(torch.cuda.current_device()), fn)
+    else:
+        fn(st)
+
+
+def _wgrad_group(jobs, folds, st):
+    """jobs: [(x, dy, dw, db or None, Cin, Cout, V, B)], folds: [(part, dgamma, dbeta, C, rows)] -> one launch"""
+    jp = _ptrs([v for j in jobs for v in (H.P(j[0]), H.P(j[1]), H.P(j[2]), H.P(j[3]))])
+    jd = (H.ctypes.c_long * (4 * len(jobs)))(*[int(v) for j in jobs for v in j[4:8]])
+    fp = _ptrs([v for f in folds for v in (H.P(f[0]), H.P(f[1]), H.P(f[2]))])
+    fd = (H.ctypes.c_int * max(1, 2 * len(folds)))(*[int(v) for f in folds for v in f[3:5]])
+    H.call("vx_pw_wgrad_group", H.ctypes.addressof(jp) if jobs else None, H.ctypes.addressof(jd) if jobs else None, len(jobs),
+           H.ctypes.addressof(fp) if folds else None, H.ctypes.addressof(fd) if folds else None, len(folds), st)
+
+
+def _gb(p):
+    return grad_buf(p) if (p is not None and p.requires_grad) else None
+
+
+class _LnPwFn(torch.autograd.Function):
+    """For every modality m: xn = LN(x_m), out_{m,s} = W_{m,s} xn + b_{m,s} (s < NS), all in ONE launch; s2d = PatchMerging's 8-way gather first.
+    Returns the M * NS projections followed (not s2d) by the M inputs passed through: whoever adds x_m as a residual later takes the pass-through,
+    so that its gradient arrives HERE and is added inside the backward kernel instead of by an autograd add launch."""
+
+    @staticmethod
+    def forward(ctx, M, NS, s2d, eps, *args):
+        xs = [_c(t) for t in args[:M]]
+        _check(xs[0], "pwa_pre")
+        per = 2 + 2 * NS
+        prm = [list(args[M + m * per: M + (m + 1) * per]) for m in range(M)]
+        B = xs[0].shape[0]
+        dev = xs[0].device
+        if s2d:
+            C0 = xs[0].shape[1]
+            g = [int(v) // 2 for v in xs[0].shape[2:]]
+            C = 8 * C0
+        else:
+            C = xs[0].shape[1]
+            g = [int(v) for v in xs[0].shape[2:]]
+        V = g[0] * g[1] * g[2]
+        J = [int(prm[0][2 + 2 * s_].shape[0]) for s_ in range(NS)]
+        Jc = (H.ctypes.c_int * 3)(*(J + [0] * (3 - NS)))
+        xn = [torch.empty((B, C, *g), device=dev, dtype=torch.float32) for _ in range(M)]
+        outs = [[torch.empty((B, J[s_], *g), device=dev, dtype=torch.float32) for s_ in range(NS)] for _ in range(M)]
+        vals = []
+        for m in range(M):
+            gam, bet = prm[m][0], prm[m][1]
+            ws = [prm[m][2 + 2 * s_] for s_ in range(NS)] + [None] * (3 - NS)
+            bs = [prm[m][3 + 2 * s_] for s_ in range(NS)] + [None] * (3 - NS)
+            os_ = outs[m] + [None] * (3 - NS)
+            vals += [H.P(xs[m]), H.P(gam), H.P(bet), H.P(ws[0]), H.P(bs[0]), H.P(ws[1]), H.P(bs[1]), H.P(ws[2]), H.P(bs[2]), H.P(xn[m]), H.P(os_[0]), H.P(os_[1]), H.P(os_[2])]
+        arr = _ptrs(vals)
+        H.call("vx_ln_pw_fwd", H.ctypes.addressof(arr), M, NS, H.ctypes.addressof(Jc), B, C, V, float(eps), int(s2d), g[0], g[1], g[2], H.stream_ptr())
+        ctx.save_for_backward(*xs, *xn)
+        ctx.prm, ctx.geo = prm, (M, NS, int(s2d), float(eps), B, C, V, g, J)
+        flat = [t for o in outs for t in o]
+        if s2d:
+            return tuple(flat)
+        return tuple(flat) + tuple(args[:M])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        M, NS, s2d, eps, B, C, V, g, J = ctx.geo
+        xs, xn = ctx.saved_tensors[:M], ctx.saved_tensors[M:]
+        prm = ctx.prm
+        dev = xs[0].device
+        douts = [[grads[m * NS + s_] for s_ in range(NS)] for m in range(M)]
+        dres = [None] * M if s2d else list(grads[M * NS:])
+        for m in range(M):
+            for s_ in range(NS):
+                douts[m][s_] = _c(douts[m][s_]) if douts[m][s_] is not None else torch.zeros((B, J[s_], *g), device=dev, dtype=torch.float32)
+        rows = H.query("vx_ln_pw_tiles", B, V) if not s2d else B * ((V + 15) // 16)
+        parts = [torch.empty((rows, 2 * C), device=dev, dtype=torch.float32) for _ in range(M)]
+        dxs = [torch.empty_like(x) for x in xs]
+        Jc = (H.ctypes.c_int * 3)(*(J + [0] * (3 - NS)))
+        vals = []
+        for m in range(M):
+            ws = [prm[m][2 + 2 * s_] for s_ in range(NS)] + [None] * (3 - NS)
+            ds_ = douts[m] + [None] * (3 - NS)
+            dr = _c(dres[m]) if dres[m] is not None else None
+            vals += [H.P(xs[m]), H.P(prm[m][0]), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(ds_[0]), H.P(ds_[1]), H.P(ds_[2]), H.P(dr), H.P(dxs[m]), H.P(parts[m])]
+        arr = _ptrs(vals)
+        H.call("vx_ln_pw_bwd", H.ctypes.addressof(arr), M, NS, H.ctypes.addressof(Jc), B, C, V, eps, s2d, g[0], g[1], g[2], H.stream_ptr())
+        jobs, folds = [], []
+        for m in range(M):
+            for s_ in range(NS):
+                w_, b_ = prm[m][2 + 2 * s_], prm[m][3 + 2 * s_]
+                if w_.requires_grad:
+                    jobs.append((xn[m], douts[m][s_], grad_buf(w_), _gb(b_), C, J[s_], V, B))
+            if prm[m][0].requires_grad:
+                folds.append((parts[m], grad_buf(prm[m][0]), grad_buf(prm[m][1]), C, rows))
+        if jobs or folds:
+            _submit_wgrad(lambda st, jobs=jobs, folds=folds: _wgrad_group(jobs, folds, st))
+        return (None, None, None, None) + tuple(dxs) + (None,) * (len(prm) * len(prm[0]))
+
+
+def ln_pw_ok(C, J, V, s2d=False):
+    Jc = (H.ctypes.c_int * 3)(*(list(J) + [0] * (3 - len(J))))
+    return bool(H.query("vx_ln_pw_ok", int(C), len(J), H.ctypes.addressof(Jc), int(V), int(bool(s2d))))
+
+
+def pwa_pre(xs, norms, projs):
+    """xs[m] -> ([q_m, k_m, v_m] per modality, x pass-throughs); norms[m] = LayerNorm module, projs[m] = the three ParamConv3d of modality m"""
+    M = len(xs)
+    args = list(xs)
+    for m in range(M):
+        args += [norms[m].weight, norms[m].bias]
+        for c in projs[m]:
+            args += [c.weight, c.bias]
+    out = _LnPwFn.apply(M, 3, False, LN_EPS, *args)
+    return [list(out[3 * m: 3 * m + 3]) for m in range(M)], list(out[3 * M:])
+
+
+def patch_merge_all(xs, downs):
+    """PatchMerging of every modality in one launch (attention_utils.py:127-168): 8-way gather -> LN(8C) -> 1x1 (8C -> 2C, no bias)"""
+    M = len(xs)
+    args = list(xs)
+    for m in range(M):
+        args += [downs[m].norm.weight, downs[m].norm.bias, downs[m].reduction.weight, None]
+    return list(_LnPwFn.apply(M, 1, True, LN_EPS, *args))
+
+
+class _PwaPostFn(torch.autograd.Function):
+    """For every modality: y = alpha x + Drop(Wm s + bm); out = y + Drop(W2 Drop(GELU(W1 LN(y) + b1)) + b2)  -- one launch (PWA.py:377,433-439)"""
+
+    @staticmethod
+    def forward(ctx, M, alpha, p_mix, p_ffn, sites, *args):
+        ss = [_c(t) for t in args[:M]]
+        xs = [_c(t) for t in args[M:2 * M]]
+        _check(ss[0], "pwa_post")
+        prm = [list(args[2 * M + 8 * m: 2 * M + 8 * (m + 1)]) for m in range(M)]      # wm, bm, gamma, beta, w1, b1, w2, b2
+        B, Cv = ss[0].shape[:2]
+        C = xs[0].shape[1]
+        R = prm[0][4].shape[0]
+        V = ss[0][0, 0].numel()
+        dev = ss[0].device
+        ys = [torch.empty_like(x) for x in xs]
+        outs = [torch.empty_like(x) for x in xs]
+        rs = rng_state(dev) if (p_mix > 0 or p_ffn > 0) else None
+        vals = []
+        for m in range(M):
+            vals += [H.P(ss[m]), H.P(xs[m])] + [H.P(t) for t in prm[m]] + [H.P(ys[m]), H.P(outs[m])] + [None] * 9 + [int(sites[3 * m]), int(sites[3 * m + 1]), int(sites[3 * m + 2])]
+        arr = _ptrs(vals)
+        H.call("vx_pwa_post_fwd", H.ctypes.addressof(arr), M, B, C, Cv, R, V, LN_EPS, float(alpha), H.P(rs, torch.int64), float(p_mix), float(p_ffn), H.stream_ptr())
+        ctx.save_for_backward(*ss, *ys)
+        ctx.prm, ctx.geo, ctx.rs, ctx.sites = prm, (M, float(alpha), float(p_mix), float(p_ffn), B, C, Cv, R, V), rs, tuple(sites)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        M, alpha, p_mix, p_ffn, B, C, Cv, R, V = ctx.geo
+        ss, ys = ctx.saved_tensors[:M], ctx.saved_tensors[M:]
+        prm, sites = ctx.prm, ctx.sites
+        dev = ss[0].device
+        rows = H.query("vx_pwa_post_tiles", B, V)
+        dsl, dxl, parts, scr = [], [], [], []
+        vals = []
+        for m in range(M):
+            do = _c(douts[m]) if douts[m] is not None else torch.zeros_like(ys[m])
+            ds_, dx_ = torch.empty_like(ss[m]), torch.empty_like(ys[m])
+            part = torch.empty((rows, 2 * C), device=dev, dtype=torch.float32)
+            sc = [torch.empty_like(ys[m]), torch.empty((B, R, V), device=dev, dtype=torch.float32), torch.empty((B, R, V), device=dev, dtype=torch.float32),
+                  torch.empty_like(ys[m]), torch.empty_like(ys[m])]          # n, h, da, dz, dmix
+            dsl.append(ds_); dxl.append(dx_); parts.append(part); scr.append(sc)
+            vals += [H.P(ss[m]), None] + [H.P(t) for t in prm[m]] + [H.P(ys[m]), None, H.P(do), H.P(ds_), H.P(dx_), H.P(part)] + [H.P(t) for t in sc] + \
+                    [int(sites[3 * m]), int(sites[3 * m + 1]), int(sites[3 * m + 2])]
+        arr = _ptrs(vals)
+        H.call("vx_pwa_post_bwd", H.ctypes.addressof(arr), M, B, C, Cv, R, V, LN_EPS, alpha, H.P(ctx.rs, torch.int64), p_mix, p_ffn, H.stream_ptr())
+        jobs, folds = [], []
+        for m in range(M):
+            wm, bm, gam, bet, w1, b1, w2, b2 = prm[m]
+            n_, h_, da_, dz_, dmix_ = scr[m]
+            if w1.requires_grad:
+                jobs.append((n_, da_, grad_buf(w1), _gb(b1), C, R, V, B))
+            if w2.requires_grad:
+                jobs.append((h_, dz_, grad_buf(w2), _gb(b2), R, C, V, B))
+            if wm.requires_grad:
+                jobs.append((ss[m], dmix_, grad_buf(wm), _gb(bm), Cv, C, V, B))
+            if gam.requires_grad:
+                folds.append((parts[m], grad_buf(gam), grad_buf(bet), C, rows))
+        if jobs or folds:
+            _submit_wgrad(lambda st, jobs=jobs, folds=folds: _wgrad_group(jobs, folds, st))
+        return (None, None, None, None, None) + tuple(dsl) + tuple(dxl) + (None,) * (8 * M)
+
+
+def pwa_post_ok(C, Cv, R, V):
+    return bool(H.query("vx_pwa_post_ok", int(C), int(Cv), int(R), int(V)))
+
+
+def pwa_post(ss, xs, mixes, norms, ffns, alpha, p_mix, p_ffn, sites_mix):
+    M = len(ss)
+    args = list(ss) + list(xs)
+    sites = []
+    for m in range(M):
+        args += [mixes[m].weight, mixes[m].bias, norms[m].weight, norms[m].bias, ffns[m].linear1.weight, ffns[m].linear1.bias, ffns[m].linear2.weight, ffns[m].linear2.bias]
+        sites += [int(sites_mix[m]), int(ffns[m].site1), int(ffns[m].site2)]
+    return list(_PwaPostFn.apply(M, float(alpha), float(p_mix), float(p_ffn), tuple(sites), *args))
+
+
 class _SpaceToDepth2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

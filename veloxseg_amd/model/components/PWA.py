@@ -80,6 +80,7 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
         self.dropout_attns = nn.ModuleList(dropout_attns)
         self.site_attn = VF.new_dropout_site()
         self.sites_proj = [VF.new_dropout_site() for _ in range(self.num_modalities)]
+        self._fused_ok = {}
 
     def _qkv(self, m: int, x):
         xn = self.input_norms[m](x)                      # LN once (the reference evaluates the same LN three times)
@@ -100,12 +101,53 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
             y = VF.residual_dropout(x, mix, residual_scale, p, self.sites_proj[m])
         return tail(m, y) if tail is not None else y
 
-    def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0, tail=None) -> List[torch.Tensor]:
+    def _fused_pre_ok(self, x):
+        if not (VF.USE_PWA_FUSED and x.is_cuda and x.dtype == torch.float32 and 1 <= self.num_modalities <= 4 and len(set(self.in_channels)) == 1):
+            return False
+        if any((c.bias is None) != (self.qkv_proj[0][0].bias is None) for pr in self.qkv_proj for c in pr):
+            return False
+        key = ("pre", int(x[0, 0].numel()))
+        ok = self._fused_ok.get(key)
+        if ok is None:
+            ok = self._fused_ok[key] = VF.ln_pw_ok(self.in_channels[0], [self.channels_qk, self.channels_qk, self.channels_v], key[1])
+        return ok
+
+    def _fused_post_ok(self, x, ffn):
+        """the whole tail of the block (mix conv + residual, LN, FFN) as one launch: where csrc/mlp.hip does not cover the FFN (the 8^3 / 4^3 levels)"""
+        if ffn is None or not (VF.USE_PWA_FUSED and x.is_cuda and len(set(self.in_channels)) == 1) or any(mc.bias is None for mc in self.mix_channels):
+            return False
+        norms, ffns = ffn
+        C, V = self.in_channels[0], int(x[0, 0].numel())
+        R = int(ffns[0].linear1.weight.shape[0])
+        key = ("post", V, R)
+        ok = self._fused_ok.get(key)
+        if ok is None:
+            ok = self._fused_ok[key] = (VF.pwa_post_ok(C, self.channels_v, R, V) and not bool(H.query("vx_mlp_supported", C, R, V))
+                                        and all(f.p == ffns[0].p for f in ffns))
+        return ok
+
+    def forward(self, inputs: List[torch.Tensor], residual_scale: float = 1.0, tail=None, ffn=None) -> List[torch.Tensor]:
         """returns residual_scale * x_m + Drop(mix(attention)) ; the transformer block passes 2.0 (double residual).
-        Everything except the joint attention is per modality and independent: with functional.MODALITY_STREAMS the M modalities run on
-        forked HIP streams before and after the attention (`tail(m, y)`, e.g. the block's FFN, rides on the same branch)."""
+        Everything except the joint attention is per modality and independent.  Default (functional.USE_PWA_FUSED): LN + q / k / v of ALL modalities
+        are one launch (csrc/pwa_fused.hip), and so is -- given `ffn` = (norms, ffns) of the enclosing block, at the levels csrc/mlp.hip does not
+        cover -- the whole tail mix conv + residual + LN + FFN.  Otherwise, with functional.MODALITY_STREAMS, the M modalities run on forked HIP
+        streams before and after the attention (`tail(m, y)`, e.g. the block's FFN, rides on the same branch)."""
         M = self.num_modalities
         assert len(inputs) == M, f"The number of modalities should be {M}, but got {len(inputs)}"
+        if self._fused_pre_ok(inputs[0]):
+            parts, res = VF.pwa_pre(inputs, self.input_norms, self.qkv_proj)      # res[m]: x_m passed through (its gradient is added inside the pre-backward kernel)
+            qkv = [t for p_ in parts for t in p_]
+            scat = VF.pwa_core(self.position_embedding.relative_position_bias_table, self.plan, self.c_qk, self.c_v, qkv,
+                               self.attn_drop if self.training else 0.0, self.site_attn)
+            if self._fused_post_ok(inputs[0], ffn):
+                norms, ffns = ffn
+                return VF.pwa_post(scat, res, self.mix_channels, norms, ffns, residual_scale, self.proj_drop if self.training else 0.0,
+                                   ffns[0].p if self.training else 0.0, self.sites_proj)
+            par = VF.MODALITY_STREAMS and VF.BRANCH_STREAMS and M > 1
+            if par:
+                return VF.run_branches([(lambda m=m: self._post(m, res[m], scat[m], residual_scale, tail)) for m in range(M)], inputs[0].device,
+                                       tag="modalities", uses=[[res[m], scat[m]] for m in range(M)])
+            return [self._post(m, res[m], scat[m], residual_scale, tail) for m in range(M)]
         par = VF.MODALITY_STREAMS and VF.BRANCH_STREAMS and M > 1 and inputs[0].is_cuda
         if par:
             parts = VF.run_branches([(lambda m=m: self._qkv(m, inputs[m])) for m in range(M)], inputs[0].device, tag="modalities",
@@ -148,7 +190,7 @@ class Paired_Windows_TransformerBlock(nn.Module):
             tail = lambda m, y: VF.ffn_tail(y, self.norms[m], self.ffns[m], self.ffns[m].p if self.training else 0.0)      # noqa: E731
         else:
             tail = lambda m, y: self.ffns[m](self.norms[m](y), residual=y)      # noqa: E731
-        return self.attn(xs, residual_scale=2.0, tail=tail)
+        return self.attn(xs, residual_scale=2.0, tail=tail, ffn=(self.norms, self.ffns))
 
 
 class Transformer_BasicLayer(nn.Module):
@@ -177,6 +219,9 @@ class Transformer_BasicLayer(nn.Module):
         if self.downs is None:
             return xs, None
         M = self.num_modalities
+        if (VF.USE_PWA_FUSED and xs[0].is_cuda and 1 <= M <= 4 and len({d.in_ch for d in self.downs}) == 1
+                and all(v % 2 == 0 for v in xs[0].shape[2:]) and VF.ln_pw_ok(8 * self.downs[0].in_ch, [2 * self.downs[0].in_ch], xs[0][0, 0].numel() // 8, True)):
+            return xs, VF.patch_merge_all(xs, self.downs)          # gather + LN(8C) + reduction of every modality: one launch
         if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:       # PatchMerging is per modality too
             down = VF.run_branches([(lambda m=m: self.downs[m](xs[m])) for m in range(M)], xs[0].device, tag="modalities", uses=[[xs[m]] for m in range(M)])
         else:
