@@ -85,6 +85,7 @@ CONV_CASES = [
     ("embed_k2s2", 1, 4, (8, 8, 8), 16, 2, 2, 0, 1, 1),
     ("expand_ps4", 1, 16, (4, 5, 6), 128, 3, 1, 1, 1, 4),
     ("expand_ps2", 2, 16, (4, 4, 4), 16, 3, 1, 1, 1, 2),
+    ("expand_ps4_w24", 1, 16, (4, 8, 24), 128, 3, 1, 1, 1, 4),      # 24-wide rows (shipped 96^3 patches): LDS-tiled MFMA kernels with a partly idle last tile
 ]
 
 
@@ -382,7 +383,8 @@ def test_kernel_variants_agree():
         res = []
         for (Cin, Cout, K, G, ps, sp) in [(16, 128, 3, 1, 4, (6, 5, 8)), (16, 16, 5, 4, 1, (8, 8, 8)), (32, 32, 3, 4, 1, (4, 6, 8)), (64, 32, 1, 1, 1, (4, 4, 4)),
                                           (16, 16, 1, 4, 1, (8, 8, 8)), (32, 32, 1, 4, 1, (6, 5, 8)), (128, 128, 1, 8, 1, (4, 4, 4)),
-                                          (16, 64, 3, 1, 4, (4, 8, 16)), (16, 128, 3, 1, 4, (8, 4, 32))]:     # the last two hit the LDS-tiled expand kernel
+                                          (16, 64, 3, 1, 4, (4, 8, 16)), (16, 128, 3, 1, 4, (8, 4, 32)),      # these two hit the LDS-tiled expand kernel ...
+                                          (16, 128, 3, 1, 4, (4, 4, 24)), (16, 64, 3, 1, 4, (4, 8, 8))]:       # ... and these with a partly idle last tile (24-wide rows = the shipped 96^3 patches)
             x = rnd(2, Cin, *sp, seed=Cin).to(d).requires_grad_(True)
             w = (rnd(Cout, Cin // G, K, K, K, seed=K) * 0.1).to(d).requires_grad_(True)
             b = rnd(Cout, seed=3).to(d).requires_grad_(True)
@@ -499,7 +501,8 @@ def test_scatter_adjoint_transpose_kernel_equals_general_adjoint(grid, big, head
     close(res[0], res[1], 2e-6 * max(1.0, float(res[1].abs().max())), 1e-5, "scatter adjoint")       # the general adjoint sums with float atomics
 
 
-@pytest.mark.parametrize("B,Cin,sp", [(2, 2, (64, 64, 64)), (1, 1, (32, 64, 128)), (2, 4, (16, 32, 64)), (4, 2, (128, 128, 128))], ids=["m2_64", "m1_aniso", "m4", "bench_shape"])
+@pytest.mark.parametrize("B,Cin,sp", [(2, 2, (64, 64, 64)), (1, 1, (32, 64, 128)), (2, 4, (16, 32, 64)), (4, 2, (128, 128, 128)), (2, 2, (32, 48, 96)), (1, 2, (96, 96, 96))],
+                         ids=["m2_64", "m1_aniso", "m4", "bench_shape", "w96_rows_of_24", "shipped_96"])
 def test_stem_weight_gradient_mfma_equals_tiled_kernel(B, Cin, sp):
     """Conv3d(k7, s4, p3) weight + bias gradient: MFMA tiles + partial-sum slices vs the tiled VALU kernel (float atomics) vs aten on a small case"""
     from veloxseg_amd import _hip as H
@@ -523,9 +526,9 @@ def test_stem_weight_gradient_mfma_equals_tiled_kernel(B, Cin, sp):
         xc, wc = x.cpu().double(), torch.zeros(Cout, Cin, 7, 7, 7, dtype=torch.float64, requires_grad=True)
         torch.nn.functional.conv3d(xc, wc, stride=4, padding=3).backward(dy.cpu().double())
         close(dw.cpu(), wc.grad.float(), 2e-5 * max(1.0, float(wc.grad.abs().max())), 1e-4, "dw vs aten")
-    # shapes the tile geometry does not cover: the query says 0 and the entry declines without launching
-    assert H.query("vx_down_wgrad_ws_floats", 1, 2, 96, 96, 96, 16) == 0
-    assert H.query("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, 1, 2, 96, 96, 96, 16, st) == 1
+    # shapes the tile geometry does not cover (output rows not a multiple of 4 in H): the query says 0 and the entry declines without launching
+    assert H.query("vx_down_wgrad_ws_floats", 1, 2, 96, 88, 96, 16) == 0
+    assert H.query("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, 1, 2, 96, 88, 96, 16, st) == 1
 
 
 @pytest.mark.parametrize("nk,act,V,BC", [(3, 1, 32768, 8), (1, 0, 8192, 6), (2, 1, 5000, 3)])
@@ -682,7 +685,8 @@ def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big,
             close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 1e-4, f"gradient {i}")      # (2e-5 of the maximum is seen run to run with EITHER form)
 
 
-@pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32)], ids=["c2", "c4_aniso", "c3"])
+@pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32),
+                                               (2, 2, (24, 24, 96), torch.int64), (4, 1, (16, 24, 48), torch.uint8)], ids=["c2", "c4_aniso", "c3", "c2_w96", "c4_w48"])
 def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype):
     """veloxseg_loss on heads that stay on their own grids (csrc/loss_ds.hip interpolates inside the kernels) == up-sample (vx_upsample_trilinear) then
     veloxseg_loss == the oracle (F.interpolate + CE + Dice): loss 1e-5 relative, gradients of every head 1e-4 of their scale."""

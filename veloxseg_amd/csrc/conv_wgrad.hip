@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256, 2) vx_down_wgrad_mfma_k(const float* __re
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (vx_wf4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
-    const int nTw = Wo / 16, nTh = Ho / 4;
+    const int nTw = (Wo + 15) / 16, nTh = Ho / 4;
     const long Vi = (long)Di * Hi * Wi, Vo = (long)Do * Ho * Wo;
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
     for (int t = t_begin; t < t_end; ++t) {
@@ -618,10 +618,14 @@ __global__ void __launch_bounds__(256, 2) vx_down_wgrad_mfma_k(const float* __re
             }
         }
         __syncthreads();
-        const float* __restrict__ dyr = dy + ((long)b * Cout + co0 + r) * Vo + ((long)d * Ho + h0 + wave) * Wo + w0 + q;
+        const float* __restrict__ dyr = dy + ((long)b * Cout + co0 + r) * Vo + ((long)d * Ho + h0 + wave) * Wo;
         float av[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) av[s4] = dyr[4 * s4];
+        for (int s4 = 0; s4 < 4; ++s4) {                       // (columns beyond Wo -- a partly idle last tile -- contribute zeros)
+            const int wq = w0 + q + 4 * s4;
+            const float t_ = dyr[min(wq, Wo - 1)];
+            av[s4] = wq < Wo ? t_ : 0.0f;
+        }
 #pragma unroll 1
         for (int s4 = 0; s4 < 4; ++s4) {          // not unrolled: 4 x 43 operand prefetches would not fit 256 registers
             bsum += av[s4];
@@ -664,10 +668,10 @@ __global__ void __launch_bounds__(256, 2) vx_down_wgrad_mfma_k(const float* __re
 
 static int vx_down_cfg(int B, int Cin, int Di, int Hi, int Wi, int Cout, int& CB, int& Do, int& Ho, int& Wo, int& ntiles, int& tpb, int& nblk) {
     Do = (Di + 6 - 7) / 4 + 1; Ho = (Hi + 6 - 7) / 4 + 1; Wo = (Wi + 6 - 7) / 4 + 1;
-    if (Cout % 16 != 0 || Wo % 16 != 0 || Ho % 4 != 0 || Do < 1) return 1;
+    if (Cout % 16 != 0 || Wo < 1 || Ho % 4 != 0 || Do < 1) return 1;      // rows that are not a multiple of 16 (24: the 96^3 patches) leave part of their last tile idle
     CB = (Cin % 2 == 0) ? 2 : 1;
     if (Cin % CB != 0) return 1;
-    ntiles = B * Do * (Ho / 4) * (Wo / 16);
+    ntiles = B * Do * (Ho / 4) * ((Wo + 15) / 16);
     const int per_slice = (Cout / 16) * (Cin / CB);
     int want = 512 / per_slice;                       // 2 blocks per CU = 2 waves per SIMD (<= 256 registers, 2 x 72 KB of LDS): one stages while the other runs MFMAs
     if (want < 1) want = 1;

@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_mfma_k(const float* __
 static int vx_expand_lds_enabled = 1;
 extern "C" int vx_expand_set_lds(int on) { vx_expand_lds_enabled = on; return 0; }      // 1 (default): halo AND weights in LDS; 2: halo only; 0: every operand from global
 
-// LDS-tiled variant (D % 4 == 0, H % 4 == 0, W % 16 == 0).  The kernel above reads every A operand (64 contiguous floats of the fine gradient)
+// LDS-tiled variant (D % 4 == 0, H % 4 == 0, W % 4 == 0; rows that are not a multiple of 16 -- the 24-wide rows of the shipped 96^3 patches -- leave part of
+// their last tile idle).  The kernel above reads every A operand (64 contiguous floats of the fine gradient)
 // from L2/HBM once per tap: 693 MB of memory-side traffic per launch for ~50 MB of data (profiles/r01q_pmc_traffic.json).  Here a block owns a
 // 4 x 4 x 16 coarse tile (wave = one d-slice = 4 M-tiles of 16 voxels along W); for each (c, s1) group the 6 x 6 x 18 halo of that group's
 // fine rows ([hd][hh][s2][72 floats] = 41.5 KB) is staged once with 16-byte loads and all 27 taps x 4 s2 read their A operands from LDS
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_k(const float* __r
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_k(const float* __r
     for (int m = 0; m < 4; ++m) {
         const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
         float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        if (w0 + 4 * q >= W) continue;                          // (W % 4 == 0: a lane's four voxels are inside or outside together)
         float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         *reinterpret_cast<float4*>(dst) = o;
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_w_k(const float* _
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -281,6 +283,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_lds_w_k(const float* _
     for (int m = 0; m < 4; ++m) {
         const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
         float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        if (w0 + 4 * q >= W) continue;                          // (W % 4 == 0: a lane's four voxels are inside or outside together)
         float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         *reinterpret_cast<float4*>(dst) = o;
@@ -295,8 +298,8 @@ extern "C" int vx_expand_bwd_data_mfma(const float* dy_fine, const float* w, flo
     const long nW = (long)Cout * 16 * 27;
     vx_weight_tap_major_k<<<vx_cdiv(nW, 256), 256, 0, st>>>(w, wt_ws, Cout, 16, 27);
     const long V = (long)D * H * W;
-    if (vx_expand_lds_enabled && D % 4 == 0 && H % 4 == 0 && W % 16 == 0) {
-        const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    if (vx_expand_lds_enabled && D % 4 == 0 && H % 4 == 0 && W % 4 == 0) {
+        const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
         if (vx_expand_lds_enabled == 1) {
             const size_t shm = (6 * 6 * 4 * 72 + 27 * 256) * sizeof(float);
             static bool attr_set = false;
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_k(const float* __restr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_k(const float* __restr
         float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+            if (w0 + r < W) *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
     }
 }
 
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_w_k(const float* __res
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_mfma_w_k(const float* __res
         float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+            if (w0 + r < W) *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
     }
 }
 static int vx_expand_fwd_wlds = 1;
@@ -483,12 +486,12 @@ extern "C" int vx_expand_set_fwd_wlds(int on) { vx_expand_fwd_wlds = on ? 1 : 0;
 // returns 1 when the shape is not covered (caller uses the direct convolution), 0 on success
 extern "C" int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
     VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma: bad args");
-    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int Cout = Cc * 64;
     const long nW = (long)Cout * 16 * 27;
     vx_weight_tap_major_k<<<vx_cdiv(nW, 256), 256, 0, st>>>(w, wt_ws, Cout, 16, 27);
-    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
     if (vx_expand_fwd_wlds) {
         const size_t shm = (16 * VX_EF_PITCH + 27 * 256) * sizeof(float);
         static bool attr_set = false;
@@ -684,7 +687,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -735,17 +738,17 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restr
         float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+            if (w0 + r < W) *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
     }
 }
 
 extern "C" int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
     VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma_bf16: bad args");
-    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
-    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
     vx_expand_fwd_bf16_k<<<dim3((unsigned)nblk), 256, 0, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
     VX_LAUNCH_CHECK("vx_expand_fwd_mfma_bf16");
     return 0;
@@ -759,7 +762,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
-    const int nTw = W / 16, nTh = H / 4, nTd = D / 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
     int tile = blockIdx.x;
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
@@ -821,6 +824,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
     for (int m = 0; m < 4; ++m) {
         const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
         float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        if (w0 + 4 * q >= W) continue;                          // (W % 4 == 0: a lane's four voxels are inside or outside together)
         float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         *reinterpret_cast<float4*>(dst) = o;
@@ -830,11 +834,11 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
 extern "C" int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
                                             int accumulate, void* stream) {
     VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma_bf16: bad args");
-    if (D % 4 != 0 || H % 4 != 0 || W % 16 != 0) return 1;
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
-    const long nblk = (long)B * (D / 4) * (H / 4) * (W / 16);
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
     vx_expand_bwd_data_bf16_k<<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
     VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_bf16");
     return 0;

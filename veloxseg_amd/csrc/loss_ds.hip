@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
 // ------------------------------------------------------------------------------------------------------------------------------ host
 static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2, const float* l3, const int* dims, int nh, int B, int C, int D, int H, int W, const char* who) {
     VX_REQUIRE(nh >= 1 && nh <= 4 && l0 && B > 0 && (C == 2 || C == 3 || C == 4) && D > 0 && H > 0 && W > 0, "%s: bad args (C must be 2..4)", who);
-    VX_REQUIRE((W & 3) == 0 && (W >> 2) <= 64 && 64 % (W >> 2) == 0, "%s: W must be a multiple of 4 with W/4 dividing 64 (got %d)", who, W);
+    VX_REQUIRE((W & 3) == 0 && (W >> 2) <= 64, "%s: W must be a multiple of 4, at most 256 (got %d)", who, W);
     P.l0 = l0; P.low[0] = l1; P.low[1] = l2; P.low[2] = l3; P.nh = nh; P.B = B; P.D = D; P.H = H; P.W = W;
     for (int hh = 0; hh < 3; ++hh) {
         for (int k = 0; k < 3; ++k) P.ld[hh][k] = hh < nh - 1 ? dims[3 * hh + k] : 1;
@@ -433,7 +433,7 @@ static size_t vx_ds_slice_floats(const VxDs& P, int C) {
 // 1 when the fused kernels cover this shape (else: up-sample + vx_seg_loss_fwd / _bwd4)
 extern "C" int vx_seg_loss_ds_ok(int C, int D, int H, int W) {
     (void)D; (void)H;
-    return (C == 2 || C == 3 || C == 4) && (W & 3) == 0 && (W >> 2) <= 64 && 64 % (W >> 2) == 0;
+    return (C == 2 || C == 3 || C == 4) && (W & 3) == 0 && (W >> 2) <= 64;      // (a wave takes floor(64 / (W/4)) rows per step: 24-quad rows -- 96^3 patches -- leave 16 lanes idle)
 }
 
 extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
