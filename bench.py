@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, production) or gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--no-eager-baseline", action="store_true")
+    ap.add_argument("--dispersion-steps", type=int, default=300, help="extra steps after the timed region whose per-step times give p10 / p50 / p90 (0 = skip)")
     ap.add_argument("--lane-probe", action="store_true", help="diagnostic: after the timed region, time dispatch-heavy kernels on every pair of tape lanes (lanes that share a dispatch pipe overlap worse)")
     args = ap.parse_args()
 
@@ -268,6 +269,22 @@ def main():
     loss = float(eng.loss)
     assert loss == loss, "loss is NaN"
 
+    # ---- dispersion (outside the timed region): >= 300 more steps, each bracketed by HIP events on the step's stream; p10 / p50 / p90 of the per-step time
+    disp = None
+    if world == 1 and args.dispersion_steps > 0:
+        nd = int(args.dispersion_steps)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
+        evs[0].record()
+        for i in range(nd):
+            eng.step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nd))
+        chunks = [sum(evs[i].elapsed_time(evs[i + 1]) for i in range(c0, c0 + 50)) / 50 for c0 in range(0, nd - 49, 50)]
+        disp = {"steps": nd, "step_ms_p10": round(ts[nd // 10], 3), "step_ms_p50": round(ts[nd // 2], 3), "step_ms_p90": round(ts[(nd * 9) // 10], 3),
+                "step_ms_min": round(ts[0], 3), "step_ms_max": round(ts[-1], 3), "mean_ms_per_50_steps": [round(c, 3) for c in chunks],
+                "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None)}
+
     lane_probe = None
     if args.lane_probe and rank == 0 and not args.eager:
         import ctypes
@@ -314,6 +331,8 @@ def main():
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     if rank == 0 and lane_probe is not None:
         out["lane_probe"] = lane_probe
+    if rank == 0 and disp is not None:
+        out["dispersion"] = disp
     # ---- per-kernel pass (eager, HIP events on the launch stream) + roofline of the dominant kernel -----------------------
     if rank == 0 and not args.no_kernel_pass:
         from veloxseg_amd import functional as VF
@@ -332,7 +351,8 @@ def main():
         # dominant kernel = largest total time among the launches whose algorithmic work we can state
         out["roofline"] = None
         for tot_ms, n, (name, key) in rows:
-            rf = roofline_for(name, key, tot_ms / n, model)
+            rf = roofline_for({"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd",
+                               "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd"}.get(name, name), key, tot_ms / n, model)
             if rf.get("achieved") is not None:
                 rf["launches_per_step"], rf["share_of_step"] = n, round(tot_ms / total, 4)
                 if rf.get("traffic") is None and name in ("vx_expand_wgrad_mfma", "vx_expand_bwd_data_mfma"):
@@ -342,6 +362,17 @@ def main():
                         rf["traffic_source"] = src
                 out["roofline"] = rf
                 break
+        # PWA attention (north_star: "MFMA utilisation for PWA against gfx950 peak"): every attention launch of the step, forward and backward
+        att = []
+        for tot_ms, n, (name, key) in rows:
+            if name in ("vx_pwa_attn_fwd", "vx_pwa_attn_bwd", "vx_pwa_attn_fwd_mb", "vx_pwa_attn_bwd_mb", "vx_pwa_attn_bwd_nofold_mb", "vx_pwa_attn_bwd_nofold"):
+                base = "vx_pwa_attn_fwd" if "fwd" in name else "vx_pwa_attn_bwd"
+                ra = roofline_for(base, key, tot_ms / n, model)
+                if ra.get("achieved") is not None:
+                    att.append({"pass": "forward" if "fwd" in name else "backward", "c_qk": key[2], "c_v": key[3], "pairs": ra.get("pairs"), "avg_launch_ms": ra["avg_launch_ms"],
+                                "achieved_tflops": ra["achieved"], "frac_fp32_peak": ra["frac"], **(ra.get("mfma") or {})})
+        if att:
+            out["roofline_pwa"] = att
         # the JLC spatial stage (the reference's Johnson-Lindenstrauss block, conv_blocks.py:51-58) at level 1: its own roofline object with PMC traffic
         jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == "vx_jlc_conv_fwd"]
         if jl:
@@ -358,6 +389,12 @@ def main():
                                 "achieved_tflops": round(flops / sec / 1e12, 2), "frac_fp32": round(flops / sec / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
                                 "achieved_gbs": round(byts / sec / 1e9, 1), "frac_hbm": round(byts / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
                                 "note": "whole step against the fp32 vector/MFMA peak and the HBM peak of the GPUs used (SURVEY.md 8d work model)"}
+    if rank == 0:
+        st_ = _step_traffic(args.workload, B)
+        if st_ is not None:
+            st_["algorithmic_bytes"] = byts / world
+            st_["ratio"] = round(st_["counter_bytes_per_step"] / (byts / world), 2)
+            out["step_traffic"] = st_
     if rank == 0 and world == 1 and not args.no_eager_baseline:
         try:
             torch.cuda.empty_cache()
@@ -373,8 +410,28 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-PMC_NAME = "profiles/r02_pmc_traffic.json"
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json")
+PMC_NAME = "profiles/" + os.path.basename(PMC_FILE)
+
+
+def _step_traffic(workload, B, trace_steps=None):
+    """HBM bytes of ONE training step summed over every kernel of the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, gfx950 correction:
+    tools/pmc_traffic.py) -- valid for the workload / batch they were collected on (autopet128, B = 4), null otherwise"""
+    try:
+        d = json.load(open(PMC_FILE))
+        if B != 4 or workload != "autopet128":
+            return None
+        steps = trace_steps or d.get("steps_in_trace") or next((v["launches_in_trace"] for k, v in d["kernels"].items() if k.startswith("vx_adamw_k")), None)
+        if not steps:
+            return None
+        tot = sum(float(k["hbm_bytes_per_launch_corrected"]) * k["launches_in_trace"] for k in d["kernels"].values() if "hbm_bytes_per_launch_corrected" in k)
+        for k in d["kernels"].values():
+            for g in k.get("by_grid", {}).values():
+                if "hbm_bytes_per_launch_corrected" not in k:
+                    tot += float(g["hbm_bytes_per_launch_corrected"]) * g["launches_in_trace"]
+        return {"counter_bytes_per_step": round(tot / steps), "source": PMC_NAME, "steps_in_trace": steps}
+    except Exception:
+        return None
 
 
 def _pmc_traffic_by_grid(kernel, B, grid_threads):
@@ -434,6 +491,28 @@ def _conv_out(d, K, S, P):
     return (d + 2 * P - K) // S + 1
 
 
+def _attn_mfma_util(name, plan, B, M, cq, cv, pairs, ms):
+    """MFMA utilisation of an attention launch against the fp32 MFMA peak: `raw` = the algorithmic GEMM flops of the pass, `padded` = the flops the matrix
+    cores actually issue (v_mfma_f32_16x16x4_f32 = 2048 flop; head widths below 16 leave rows of the 16 x 16 tiles idle, and windows are padded to 16 tokens).
+    `on_mfma`: whether this pass of this geometry runs its GEMMs on MFMA in the default selection (csrc/pwa_mfma.hip): forward when l % 64 == 0; backward = the
+    one-pass kernel where selected, else the fp32-VALU kernels (then both figures are 0 by definition and the VALU rate is the launch's achieved TFLOP/s)."""
+    try:
+        pp = H.ctypes.addressof(plan)
+        fwd = name == "vx_pwa_attn_fwd"
+        on = bool(H.query("vx_pwa_attn_mfma_ok", pp, B, M, cq, cv) & 1) if fwd else bool(H.query("vx_pwa_attn_bwd1_ok", pp, B, M, cq, cv))
+        lpad = (plan.l + 15) // 16 * 16
+        tiles = B * plan.heads * plan.Ntot * (M * lpad // 16) ** 2
+        cvb = (cv + 15) // 16
+        per_tile = (cq // 4 + 4 * cvb) if fwd else (cq // 4 + cv // 4 + 4 * cvb + 4 + 4)      # S (+ dP) k-steps, then 4 k-steps per 16-row output block of PV / dV, dK, dQ
+        raw = pairs * ((2.0 * cq + 2.0 * cv) if fwd else (6.0 * cq + 4.0 * cv))
+        padded = tiles * per_tile * 2048.0
+        sec = ms * 1e-3
+        return {"on_mfma": on, "mfma_util_raw": round(raw / sec / 1e12 / FP32_PEAK_TFLOPS, 4) if on else 0.0,
+                "mfma_util_padded": round(padded / sec / 1e12 / FP32_PEAK_TFLOPS, 4) if on else 0.0, "mfma_per_tile": per_tile, "tiles": tiles}
+    except Exception as e:
+        return {"error": str(e)[:120]}
+
+
 def roofline_for(name, key, ms_per_launch, model=None):
     """Algorithmic flops / bytes of ONE launch of C-ABI entry `name` with integer arguments `key` (argument order: include/veloxseg_hip.h).
     Convolutions and attention sit above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B) -> priced against the fp32 vector = f32-MFMA peak;
@@ -463,10 +542,12 @@ def roofline_for(name, key, ms_per_launch, model=None):
             if plan is not None:
                 rows = B * plan.heads * plan.Ntot * M * plan.l
                 pairs = rows * M * plan.l
-                # forward: QK^T + PV.  backward (two kernels, P recomputed from the saved LSE): dQ pass QK^T, dP, dQ; dK/dV pass QK^T, dP, dV, dK
-                flops = pairs * (2.0 * cq + 2.0 * cv) if name == "vx_pwa_attn_fwd" else pairs * (8.0 * cq + 6.0 * cv)
+                # forward: QK^T + PV.  backward: S (recomputed from the saved LSE), dP, dV, dQ, dK, each counted ONCE = 6 c_qk + 4 c_v flop per pair (80 at
+                # head widths 8 / 8); the VALU kernels compute S and dP twice (once per pass) -- that redundancy is not algorithmic work
+                flops = pairs * (2.0 * cq + 2.0 * cv) if name == "vx_pwa_attn_fwd" else pairs * (6.0 * cq + 4.0 * cv)
                 bytes_ = 4.0 * rows * ((2 * cq + 2 * cv + 1) if name == "vx_pwa_attn_fwd" else (4 * cq + 4 * cv + 3))
                 r["pairs"], r["kernels"] = pairs, 1 if name == "vx_pwa_attn_fwd" else 2
+                r["mfma"] = _attn_mfma_util(name, plan, B, M, cq, cv, pairs, ms_per_launch)
                 # (the kernels behind the entry: MFMA forward where the geometry allows it; the one-launch backward, else its two passes)
                 cands = ([[f"vx_pwa_attn_mfma_fwd_k<{cq}, {cv}>"], [f"vx_pwa_attn_fwd_k<{cq}, {cv}>"]] if name == "vx_pwa_attn_fwd" else
                          [[f"vx_pwa_attn_bwd_both_k<{cq}, {cv}>"], [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"]])

@@ -277,11 +277,27 @@ int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const VxPwaPlan* 
 /* tuning knob of the two entries above: key/query split per 64-row unit (0 = automatic from the unit count, else 1, 2 or 4; clamped to the
  * number of 64-row slabs).  Results are identical up to fp32 summation order; the dropout mask does not depend on it. */
 int vx_pwa_attn_set_split(int S);
-/* The two entries above run on the matrix cores (csrc/pwa_mfma.hip: QK^T, PV, dP, dQ, dK, dV as v_mfma_f32_16x16x4_f32 tiles, K/V of a window staged
- * once per 128-query block) when a window's tokens tile into 16-token blocks (l % 64 == 0) and the head widths are one of (4,4) (8,8) (8,16) (16,32)
- * (16,16) (4,8); same masks, same results up to fp32 summation order.  vx_pwa_attn_set_mfma(mask) selects the passes: bit 0 forward, bit 1 backward
- * (default 1: the forward; the backward's d(bias) sum is faster in the VALU kernels, see pwa_mfma.hip); vx_pwa_attn_mfma_ok answers that mask for a
- * geometry the MFMA kernels cover and 0 otherwise. */
+/* The two entries above run on the matrix cores (csrc/pwa_mfma.hip; head widths (4,4) (8,8) (8,16) (16,32) (16,16) (4,8); same masks, same results up
+ * to fp32 summation order).  Forward: QK^T and PV as v_mfma_f32_16x16x4_f32 tiles, K/V of a window staged once per 128-query block, when a window's tokens
+ * tile into 16-token blocks (l % 64 == 0).  Backward: ONE pass per (query, key) pair -- S, dP, dS once, then dV, dK, dQ (through a wave-private LDS
+ * transpose) and d(bias) -- for any l and M <= 2; selected (vx_pwa_attn_bwd1_ok) where it was measured faster than the VALU kernels: windows whose token count
+ * is not a multiple of 16 (the 27- / 216-token windows of the shipped 96^3 configurations).  vx_pwa_attn_set_mfma(mask): bit 0 forward, bit 1 backward (that
+ * rule), bit 3 the one-pass backward for every geometry it covers, bit 2 (A/B only) the older two-kernel MFMA backward; default 3.  vx_pwa_attn_mfma_ok answers bit 0 (forward) | bit 1 (two-kernel backward selected)
+ * for a geometry those kernels cover and 0 otherwise. */
+int vx_pwa_attn_bwd1_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+/* Dropout mask words: with p_drop > 0 the forward can keep ONE BIT per (query row, key) -- uint16 W[B*heads*Ntot][ceil(ML/16)][ML], word w of row r = keys
+ * 16w .. 16w+15, bit k & 15, 1 = kept; vx_pwa_attn_mbits_words = number of uint16 -- and the one-pass backward reads it instead of drawing the Philox words
+ * again (the draw is ~1/3 of the backward's per-pair instruction count).  `mbits` NULL or p_drop == 0: exactly vx_pwa_attn_fwd / _bwd / _bwd_nofold. */
+int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M);
+int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv);   /* 1: the one-pass backward is selected for this geometry and reading the bits beats re-drawing (l % 4 != 0) */
+int vx_pwa_attn_fwd_mb(const float* q, const float* k, const float* v, const float* table, float* out, float* lse, const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                       const void* seed_ptr, unsigned long long dstream, float p_drop, void* mbits, void* stream);
+int vx_pwa_attn_bwd_mb(const float* q, const float* k, const float* v, const float* table, const float* out, const float* lse, const float* dout,
+                       float* dq, float* dk, float* dv, float* dtable, float* delta_ws, const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                       const void* seed_ptr, unsigned long long dstream, float p_drop, const void* mbits, void* stream);
+int vx_pwa_attn_bwd_nofold_mb(const float* q, const float* k, const float* v, const float* table, const float* out, const float* lse, const float* dout,
+                              float* dq, float* dk, float* dv, float* delta_ws, const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                              const void* seed_ptr, unsigned long long dstream, float p_drop, const void* mbits, void* stream);
 int vx_pwa_attn_mfma_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
 int vx_pwa_attn_set_mfma(int on);
 
@@ -392,7 +408,7 @@ int vx_pwa_post_ok(int C, int Cv, int R, long V);
 int vx_pwa_post_tiles(int B, long V);
 int vx_pwa_post_fwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
 int vx_pwa_post_bwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
-/* up to 12 weight gradients of 1x1 convs (dW += dy x^T, db += sum dy) and up to 8 folds of partial rows in one launch.
+/* up to 24 weight gradients of 1x1 convs (dW += dy x^T, db += sum dy) and up to 16 folds of partial rows in one launch.
  * jobs: ptrs 4 per job (x (B,Cin,V), dy (B,Cout,V), dw, db or NULL), dims 4 per job (Cin, Cout, V, B); folds: fptrs 3 per fold (part (rows, 2C), dgamma, dbeta),
  * fdims 2 per fold (C, rows) */
 int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int nj, const void* const* fptrs, const int* fdims, int nf, void* stream);
@@ -437,6 +453,7 @@ int vx_tape_describe(const VxTape* tape, int* lane, int* grid, int* waits4, char
  * with anything).  A tape with one lane replays on the caller's stream; a tape with more replays on the lane streams, gated by and joined
  * back into the caller's stream. */
 int vx_tape_lane_stream(void* any_stream, int lane, void** out);
+int vx_spin_us(float us, void* stream);   /* diagnostic: one wave spins for `us` microseconds on `stream` (stand-in for a collective: tools/comm_standin_probe.py) */
 int vx_tape_lanes_distinct(void);      /* answer, not a status: how many of the 4 lane streams were measured to overlap pairwise (-1 before the first use) */
 
 #ifdef __cplusplus

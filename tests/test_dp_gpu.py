@@ -112,3 +112,21 @@ def _check_two_ranks(tmp_path, use_graph, backend, level_buckets=True, break_ran
     mask = g_ref.abs() > 1e-6
     err = float((dp["param"] - eng.flat.param.cpu())[mask].abs().max())
     assert err < 1e-6, f"parameters after one data-parallel AdamW step differ by {err:.3e}"
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_end_to_end_over_gloo():
+    """`python bench.py --gpus 2 --backend gloo`: the driver's command line for N > 1 (self-launched ranks, rendezvous on 127.0.0.1, barrier + max-over-ranks timing,
+    rank 0 prints ONE parsable JSON line) end to end -- both ranks share the test box's one MI355X over gloo; production is --backend nccl (RCCL), one rank per GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--workload", "autopet96", "--batch", "1",
+                        "--no-cpu-baseline", "--no-eager-baseline", "--no-kernel-pass", "--dispersion-steps", "0"], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, ("exactly one JSON line from rank 0", r.stdout[-1000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"

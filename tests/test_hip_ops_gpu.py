@@ -614,25 +614,33 @@ def test_loss_backward_one_launch_for_all_heads_equals_per_head_launches():
 
 
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),
-                                                    ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 1), ([16, 16, 16], [8, 8, 8], 2, 8, 32, 1)],
-                         ids=["c8v8_ML1024", "c8v16", "c16v32", "c4v8", "c4v4_M1", "c8v8_M1"])
+                                                    ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 1), ([16, 16, 16], [8, 8, 8], 2, 8, 32, 1),
+                                                    ([12, 12, 12], [6, 6, 6], 2, 8, 32, 2), ([6, 6, 6], [3, 3, 3], 2, 8, 64, 2), ([3, 3, 3], [3, 3, 3], 4, 16, 128, 2),
+                                                    ([24, 24, 24], [3, 3, 3], 1, 4, 16, 2), ([8, 8, 4], [4, 4, 2], 2, 8, 64, 2)],
+                         ids=["c8v8_ML1024", "c8v16", "c16v32", "c4v8", "c4v4_M1", "c8v8_M1", "96_L2_l216", "96_L3_l27", "96_L4_l27", "96_L1_l27", "aniso_l32"])
 def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh, C, M):
     """The MFMA attention kernels (csrc/pwa_mfma.hip) against the fp32-VALU kernels of the same library on the same inputs, dropout ON (p = 0.2: both
-    draw the same Philox words for the same (query, key) element): outputs, dq / dk / dv and the bias-table gradient agree to fp32 summation noise."""
+    draw the same Philox words for the same (query, key) element): outputs, dq / dk / dv and the bias-table gradient agree to fp32 summation noise.
+    Mask 11 = MFMA forward (where l % 64 == 0) + the ONE-pass MFMA backward for every geometry (any l: padded 16-token tiles, incl. the 27- / 216- / 32-token
+    windows of the shipped 96^3 and anisotropic configurations; the default mask 3 selects it only where it is the faster kernel: l % 16 != 0); mask 5 = the
+    older two-kernel MFMA backward; mask 0 = the VALU kernels.  With l % 4 != 0 the one-pass backward reads the forward's keep bits instead of Philox words."""
     VF = _vf()
     from veloxseg_amd import _hip as H
     d = dev()
     pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
     plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
-    H.call("vx_pwa_attn_set_mfma", 3)
-    assert H.query("vx_pwa_attn_mfma_ok", H.ctypes.addressof(plan), 2, M, pl["c_qk"], pl["c_v"]) == 3, "geometry is expected to take the MFMA path"
+    H.call("vx_pwa_attn_set_mfma", 11)
+    l = pl["n"][0] * pl["n"][1] * pl["n"][2]
+    assert H.query("vx_pwa_attn_bwd1_ok", H.ctypes.addressof(plan), 2, M, pl["c_qk"], pl["c_v"]) == 1, "geometry is expected to take the one-pass MFMA backward"
+    assert H.query("vx_pwa_attn_mfma_ok", H.ctypes.addressof(plan), 2, M, pl["c_qk"], pl["c_v"]) == (1 if l % 64 == 0 else 0)
+    masks = (11, 5, 0) if l % 64 == 0 else (11, 0)
     n = pl["n"]
     base = []
     for m in range(M):
         base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
     res = {}
     try:
-        for on in (3, 0):            # 3 = forward AND backward on the MFMA kernels, 0 = the VALU kernels
+        for on in masks:
             H.call("vx_pwa_attn_set_mfma", on)
             VF.manual_seed(77, d)
             table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
@@ -643,9 +651,10 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
             torch.cuda.synchronize()
             res[on] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
     finally:
-        H.call("vx_pwa_attn_set_mfma", 1)
-    for i, (a, b) in enumerate(zip(res[3], res[0])):
-        close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma vs valu tensor {i}")
+        H.call("vx_pwa_attn_set_mfma", 3)
+    for on in masks[:-1]:
+        for i, (a, b) in enumerate(zip(res[on], res[0])):
+            close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma (mask {on}) vs valu tensor {i}")
 
 
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),

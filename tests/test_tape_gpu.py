@@ -148,9 +148,10 @@ def test_eager_stages_are_reproducible_at_full_size_brats128_b4():
     assert float((eng.flat.grad - ref).abs().max()) < 1e-5
 
 
-def test_taped_engine_on_96_cube_patches_keeps_the_reference_output_list():
-    """96^3 patches (BASELINE configs with 3^3 windows): rows of 96 are not tiled by the fused deep-supervision loss kernels, so the engine keeps the
-    reference's up-sampled heads -- the capture must still succeed (no silent fall-back to eager launches) and track the eager engine."""
+def test_taped_engine_on_96_cube_patches_takes_the_fused_loss_and_tracks_eager():
+    """96^3 patches (the reference's SHIPPED configurations: 3^3 / 6^3 windows, 24-wide coarse rows): since round 3 the fused deep-supervision loss, the
+    patch-expand MFMA kernels and the stem weight-gradient MFMA kernel accept these rows (a partly idle last tile), and the 27- / 216-token windows take the
+    one-pass MFMA attention backward.  The capture must succeed (no silent fall-back to eager launches) and track the eager engine."""
     import types
     from bench import LOSS_CFG, WORKLOADS, synth
     from veloxseg_amd.engine import TrainEngine
@@ -168,7 +169,7 @@ def test_taped_engine_on_96_cube_patches_keeps_the_reference_output_list():
         crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
         x, lab = synth(cfg, B, "cuda", 7)
         eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=(mode == "tape"), overlap=False)
-        assert model.ds_fused is False
+        assert model.ds_fused is True          # (the library's own Loss + a width the loss kernels tile: W % 4 == 0, W <= 256)
         losses[mode] = [float(eng.step(x, lab)) for _ in range(3)]
         if mode == "tape":
             assert eng.use_graph and eng.graphs is not None

@@ -56,7 +56,9 @@ def main():
         if len(grids) > 1:
             kernels[k]["by_grid"] = {str(g): {"launches_in_trace": fg[(k, g)][0],
                                               "hbm_bytes_per_launch_corrected": int((2 * fg[(k, g)][1] / fg[(k, g)][0] + wg[(k, g)][1] / wg[(k, g)][0]) * 1024)} for g in grids}
-    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2`, B=4 autopet128; traffic = "
+    # steps covered by the trace = launches of the once-per-step optimiser kernel
+    steps = next((v["launches_in_trace"] for k, v in kernels.items() if k.startswith("vx_adamw_k")), None)
+    doc = {"steps_in_trace": steps, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2`, B=4 autopet128; traffic = "
                      "2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), KB -> bytes",
            "kernels": kernels}
     with open(out, "w") as fh:

@@ -657,7 +657,7 @@ struct AxpyFn : public torch::autograd::Function<AxpyFn> {
 // between its ~6 forward / ~9 backward launches.  qkv = (q0, k0, v0, q1, k1, v1, ...), (B, nb*heads*c, g0, g1, g2) each.
 struct PwaState {
     VxPwaPlan plan;
-    Tensor tq, tk, tv, O, lse, tbl, iq, ik, iv, table;
+    Tensor tq, tk, tv, O, lse, tbl, iq, ik, iv, table, mbits;      // mbits: the forward's dropout keep bits (1 per score element), read by the one-pass backward
     std::vector<std::vector<int64_t>> shapes;
     int cq = 0, cv = 0, M = 0, B = 0;
     double p = 0; int64_t site = 0; const void* rs = nullptr;
@@ -686,7 +686,14 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         st.O = at::empty_like(st.tv);
         st.lse = at::empty({B, hd, Nt, ML}, opt);
         st.tbl = contig(table);
-        VX(vx_pwa_attn_fwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), mp(st.O), mp(st.lse), pp, B, M, (int)cq, (int)cv, st.rs, (unsigned long long)site, (float)p_attn, s_);
+        void* mb = nullptr;
+        if (p_attn > 0 && vx_pwa_attn_mbits_useful(pp, B, M, (int)cq, (int)cv) == 1) {
+            const int nmb = vx_pwa_attn_mbits_words(pp, B, M);
+            TORCH_CHECK(nmb >= 0, "vx_pwa_attn_mbits_words failed");
+            st.mbits = at::empty({(long)nmb}, opt.dtype(at::kShort));
+            mb = st.mbits.data_ptr();
+        }
+        VX(vx_pwa_attn_fwd_mb, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), mp(st.O), mp(st.lse), pp, B, M, (int)cq, (int)cv, st.rs, (unsigned long long)site, (float)p_attn, mb, s_);
         variable_list outs;
         float* optr[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int m = 0; m < M; ++m) {
@@ -725,8 +732,8 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         if (!dtab) { dtab_tmp = at::zeros_like(st.tbl); dtab = dtab_tmp.data_ptr<float>(); }
         int rc_nf = 1;
         if (WG.enabled) {                  // deferral on: the fold of the bias-table gradient (a parameter gradient) leaves the chain
-            rc_nf = vx_pwa_attn_bwd_nofold(fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), mp(delta), pp, B, M, st.cq, st.cv,
-                                           st.rs, (unsigned long long)st.site, (float)st.p, s_);
+            rc_nf = vx_pwa_attn_bwd_nofold_mb(fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), mp(delta), pp, B, M, st.cq, st.cv,
+                                              st.rs, (unsigned long long)st.site, (float)st.p, st.mbits.defined() ? st.mbits.data_ptr() : nullptr, s_);
             if (rc_nf != 0 && rc_nf != 1) chk(rc_nf, "vx_pwa_attn_bwd_nofold");
             if (rc_nf == 0) {
                 const VxPwaPlan plan_copy = st.plan;
@@ -735,8 +742,8 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
             }
         }
         if (rc_nf == 1)
-        VX(vx_pwa_attn_bwd, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), dtab, mp(delta), pp, B, M, st.cq, st.cv,
-           st.rs, (unsigned long long)st.site, (float)st.p, s_);
+        VX(vx_pwa_attn_bwd_mb, fp(st.tq), fp(st.tk), fp(st.tv), fp(st.tbl), fp(st.O), fp(st.lse), fp(dO), mp(dq), mp(dk), mp(dv), dtab, mp(delta), pp, B, M, st.cq, st.cv,
+           st.rs, (unsigned long long)st.site, (float)st.p, (const void*)(st.mbits.defined() ? st.mbits.data_ptr() : nullptr), s_);
         float* dsts[12];
         for (int i = 0; i < 3 * M; ++i) { Tensor t = at::empty(st.shapes[i], st.tq.options()); out[7 + i] = t; dsts[i] = t.data_ptr<float>(); }
         VX(vx_pwa_gather_all_bwd, fp(dq), fp(dk), fp(dv), st.iq.data_ptr<int>(), st.ik.data_ptr<int>(), st.iv.data_ptr<int>(), dsts, pp, st.cq, st.cv, M, B, s_);
@@ -1135,6 +1142,7 @@ PYBIND11_MODULE(_vxops, m) {
     // spread > 1 (deferral on the submitting streams only): the queued launches are independent sinks, so instead of running one after the other at the
     // end of the stream they were queued from they are dealt round-robin onto `spread` streams (the submitting stream and spread - 1 forked ones, which
     // first wait for it); the joining stream waits for all of them.  In a captured stage these become parallel branches, i.e. different tape lanes.
+    m.def("wgrad_deferring", []() { return WG.enabled; });
     m.def("wgrad_join", [](int64_t stream, int64_t device, bool final, int64_t spread) {
         if (WG.same) {
             hipStream_t js = (hipStream_t)sp(stream);

@@ -640,7 +640,9 @@ extern "C" int vx_pw_conv_bwd_fused(const float* dy, const float* w, const float
 // `rows` partial rows of width 2C (dgamma | dbeta, one row per block of the chain kernel) into the two parameter gradients, 64 rows per block.
 struct VxWgJob { const float* x; const float* dy; float* dw; float* db; int Cin, Cout; long V; int B, vpw, chunks_per_b, nt, gx, blk0, nblk; };
 struct VxFoldJob { const float* part; float* dg; float* dbeta; int C, rows, blk0, nblk; };
-struct VxWgGroup { VxWgJob j[12]; VxFoldJob f[8]; int nj, nf; };
+#define VX_WGG_JOBS 24
+#define VX_WGG_FOLDS 16
+struct VxWgGroup { VxWgJob j[VX_WGG_JOBS]; VxFoldJob f[VX_WGG_FOLDS]; int nj, nf; };
 __global__ void __launch_bounds__(256) vx_pw_wgrad_group_k(VxWgGroup g) {
     const int id = blockIdx.x;
     for (int k = 0; k < g.nj; ++k) {
@@ -670,7 +672,7 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_group_k(VxWgGroup g) {
 /* jobs: ptrs 4 per job (x (B,Cin,V), dy (B,Cout,V), dw (Cout,Cin) +=, db (Cout) += or NULL), dims 4 per job (Cin, Cout, V, B);
  * folds: fptrs 3 per fold (part (rows, 2C), dgamma +=, dbeta +=), fdims 2 per fold (C, rows) */
 extern "C" int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int nj, const void* const* fptrs, const int* fdims, int nf, void* stream) {
-    VX_REQUIRE(nj >= 0 && nj <= 12 && nf >= 0 && nf <= 8 && (nj + nf) > 0 && (nj == 0 || (ptrs && dims)) && (nf == 0 || (fptrs && fdims)), "vx_pw_wgrad_group: bad args");
+    VX_REQUIRE(nj >= 0 && nj <= VX_WGG_JOBS && nf >= 0 && nf <= VX_WGG_FOLDS && (nj + nf) > 0 && (nj == 0 || (ptrs && dims)) && (nf == 0 || (fptrs && fdims)), "vx_pw_wgrad_group: bad args");
     VxWgGroup g = {};
     g.nj = nj; g.nf = nf;
     long blk = 0;

@@ -610,7 +610,7 @@ __device__ __forceinline__ void vx_attn_tables(const VxAttn& A, const float* __r
 template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                          const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
-                                                         int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+                                                         int Tsz, VxAttn A, VxDrop drop, int S, int one_head, unsigned short* __restrict__ mbits) {
     constexpr int RS = CQ + CV;
     static_assert(RS >= CV + 2, "the merge reuses the slab rows");
     extern __shared__ __attribute__((aligned(16))) float vx_sm[];
@@ -661,9 +661,18 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
             for (int c = 0; c < CV; ++c) slab[lane * RS + CQ + c] = vp[(long)(j0 + lane) * CV + c];
         }
         __builtin_amdgcn_wave_barrier();
+        unsigned wb = 0;                               // keep bits of the 16 keys of the current mask word (vx_pwa_attn_mbits_words)
         for (int jj = 0; jj < nk; jj += 4) {
             float m4[4];
             vx_drop4(dc, drow + j0 + jj, al4, m4);
+            if (mbits != nullptr && dc.on) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wb |= (m4[t] != 0.0f ? 1u : 0u) << ((jj + t) & 15);
+                if (((jj + 4) & 15) == 0 || jj + 4 >= nk) {
+                    if (ok) mbits[(win * ((A.ML + 15) >> 4) + ((j0 + jj) >> 4)) * A.ML + i] = (unsigned short)wb;
+                    wb = 0;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (jj + t < nk) {
@@ -1267,22 +1276,44 @@ template <class F> static bool vx_attn_dispatch(int cq, int cv, F&& f) {
 }
 
 // MFMA kernels (pwa_mfma.hip) for windows whose tokens tile into 16-token blocks
-int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE, const VxPwaPlan* plan, int B, int M,
+int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE, unsigned short* mbits, const VxPwaPlan* plan, int B, int M,
                          int cq, int cv, VxDrop d, void* stream);
+extern "C" int vx_pwa_attn_bwd1_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
+                     float* dK, float* dV, float* rep, const unsigned short* mbits, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d, void* stream);
 int vx_pwa_attn_mfma_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
                          float* dK, float* dV, float* dtable, float* delta, float* rep, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d,
                          void* stream);
 
+extern "C" int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, 4, 4, "vx_pwa_attn_mbits_words")) return e;
+    const long n = (long)A.BH * A.Nt * ((A.ML + 15) >> 4) * A.ML;
+    VX_REQUIRE(n < 0x7fffffffL, "vx_pwa_attn_mbits_words: too large");
+    return (int)n;
+}
+// 1 when keeping the forward's mask bits pays for this geometry: the one-pass backward is selected AND would otherwise draw one Philox word set per
+// ELEMENT (l % 4 != 0: the 4 queries of a lane do not share a counter); with aligned windows re-drawing costs the same as reading the bits back
+extern "C" int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv) {
+    if (plan == nullptr) return 0;
+    return (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) == 1 && (plan->l & 3) != 0) ? 1 : 0;
+}
 extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
                                const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
+    return vx_pwa_attn_fwd_mb(Q, K, V, table, O, LSE, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, nullptr, stream);
+}
+extern "C" int vx_pwa_attn_fwd_mb(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
+                                  const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                                  const void* seed_ptr, unsigned long long dstream, float p_drop, void* mbits_, void* stream) {
+    unsigned short* mbits = p_drop > 0 ? (unsigned short*)mbits_ : nullptr;
     VxAttn A;
     if (int e = vx_attn_fill(A, plan, B, M, cq, cv, "vx_pwa_attn_fwd")) return e;
     VX_REQUIRE(Q && K && V && table && O && LSE, "vx_pwa_attn_fwd: null pointer");
     const long units = (long)A.BH * A.Nt * ((A.ML + 63) / 64);
     VxDrop d; d.seed_ptr = p_drop > 0 ? (const uint64_t*)seed_ptr : nullptr; d.stream = dstream; d.p = p_drop;
     if (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 1) {
-        const int rc = vx_pwa_attn_mfma_fwd(Q, K, V, table, O, LSE, plan, B, M, cq, cv, d, stream);
+        const int rc = vx_pwa_attn_mfma_fwd(Q, K, V, table, O, LSE, mbits, plan, B, M, cq, cv, d, stream);
         if (rc) return rc;
         VX_LAUNCH_CHECK("vx_pwa_attn_fwd (mfma)");
         return 0;
@@ -1294,7 +1325,7 @@ extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, c
     const size_t shm = ((one_head ? (size_t)((A.l + 3) & ~3) + (((size_t)Tsz + 3) & ~(size_t)3) : tab_f) + (size_t)4 * 64 * (cq + cv)) * sizeof(float);
     VX_REQUIRE(shm <= 160 * 1024, "vx_pwa_attn_fwd: tables do not fit LDS (%d entries x %d heads)", Tsz, A.heads);
     const bool found = vx_attn_dispatch(cq, cv, [&](auto pr) {
-        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S, one_head);
+        vx_pwa_attn_fwd_k<decltype(pr)::a, decltype(pr)::b><<<dim3(vx_cdiv(units, 4 / S)), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, Tsz, A, d, S, one_head, mbits);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_fwd");
@@ -1319,7 +1350,7 @@ extern "C" int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M) {
 static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
-                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold);
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold, const unsigned short* mbits = nullptr);
 extern "C" int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
@@ -1333,8 +1364,25 @@ extern "C" int vx_pwa_attn_bwd_nofold(const float* Q, const float* K, const floa
                                       const float* dO, float* dQ, float* dK, float* dV, float* delta_ws,
                                       const VxPwaPlan* plan, int B, int M, int cq, int cv,
                                       const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream) {
-    if (!vx_attn_bwd_fused || (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2)) return 1;
+    if (!vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) && (!vx_attn_bwd_fused || (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2))) return 1;
     return vx_pwa_attn_bwd_run(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws /* unused, non-null */, delta_ws, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, stream, false);
+}
+/* the same two entries with the forward's dropout mask words (vx_pwa_attn_fwd_mb): the one-pass MFMA backward then reads one bit per pair instead of
+ * re-drawing the Philox words (mbits NULL or p_drop == 0: as the entries above) */
+extern "C" int vx_pwa_attn_bwd_mb(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                                  const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
+                                  const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                                  const void* seed_ptr, unsigned long long dstream, float p_drop, const void* mbits, void* stream) {
+    return vx_pwa_attn_bwd_run(Q, K, V, table, O, LSE, dO, dQ, dK, dV, dtable, delta_ws, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, stream, true,
+                               p_drop > 0 ? (const unsigned short*)mbits : nullptr);
+}
+extern "C" int vx_pwa_attn_bwd_nofold_mb(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
+                                         const float* dO, float* dQ, float* dK, float* dV, float* delta_ws,
+                                         const VxPwaPlan* plan, int B, int M, int cq, int cv,
+                                         const void* seed_ptr, unsigned long long dstream, float p_drop, const void* mbits, void* stream) {
+    if (!vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) && (!vx_attn_bwd_fused || (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2))) return 1;
+    return vx_pwa_attn_bwd_run(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws /* unused, non-null */, delta_ws, plan, B, M, cq, cv, seed_ptr, dstream, p_drop, stream, false,
+                               p_drop > 0 ? (const unsigned short*)mbits : nullptr);
 }
 extern "C" int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const VxPwaPlan* plan, int B, int M, void* stream) {
     VxAttn A;
@@ -1350,7 +1398,7 @@ extern "C" int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const 
 static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
-                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold) {
+                               const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream, bool fold, const unsigned short* mbits) {
     VxAttn A;
     if (int e = vx_attn_fill(A, plan, B, M, cq, cv, "vx_pwa_attn_bwd")) return e;
     VX_REQUIRE(Q && K && V && table && O && LSE && dO && dQ && dK && dV && dtable && delta_ws, "vx_pwa_attn_bwd: null pointer");
@@ -1371,6 +1419,14 @@ static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, c
     const long rep_floats = (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
     const unsigned nblk = (unsigned)vx_cdiv(units, 4 / S);
     vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
+    if (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv)) {             // one evaluation of the soft-max side per pair, every GEMM on MFMA (csrc/pwa_mfma.hip)
+        const int rc = vx_pwa_attn_bwd1(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, mbits, plan, B, M, cq, cv, d, stream);
+        if (rc) VX_FAIL(rc, "vx_pwa_attn_bwd: one-pass kernel could not be launched");
+        const long nt = (long)Tsz * A.heads;
+        if (fold) vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
+        VX_LAUNCH_CHECK("vx_pwa_attn_bwd (one pass)");
+        return 0;
+    }
     if (vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2) {
         const int rc = vx_pwa_attn_mfma_bwd(Q, K, V, table, O, LSE, dO, dQ, dK, dV, dtable, delta_ws, rep, plan, B, M, cq, cv, d, stream);
         if (rc) return rc;

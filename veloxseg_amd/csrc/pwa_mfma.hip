@@ -16,6 +16,7 @@
 // A block = 8 waves = 128 queries (or keys) of ONE window: K and V (resp. Q, dO, LSE, delta) of the whole window are staged in LDS once per block
 // and shared by the 8 waves, instead of being re-fetched by every 64-row unit as in the VALU kernels.
 #include "vx_common.h"
+#include <stdlib.h>
 #include "../../include/veloxseg_hip.h"
 
 typedef float vx_f32x4 __attribute__((ext_vector_type(4)));
@@ -72,7 +73,7 @@ template <int C> __device__ __forceinline__ int vx_am_op_index(int tile, int r, 
 template <int CQ, int CV>
 __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                               const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
-                                                              VxAttnM A, VxDrop drop) {
+                                                              VxAttnM A, VxDrop drop, unsigned short* __restrict__ mbits) {
     constexpr int KSQ = CQ / 4, CVB = (CV + 15) / 16, SV = CV + 2;
     extern __shared__ __attribute__((aligned(16))) float vx_am_lds[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_am_lds);
@@ -144,6 +145,12 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
         for (int u = 0; u < KU; ++u) {
             float m4[4];
             vx_masks_vox4(dc, (uint64_t)row, A.ML, 16 * (kt0 + u) + 4 * qg, m4);
+            if (mbits != nullptr && dc.on) {           // the keep bits of this query's 16 keys as one word (read back by the one-pass backward)
+                unsigned w = ((m4[0] != 0.0f ? 1u : 0u) | (m4[1] != 0.0f ? 2u : 0u) | (m4[2] != 0.0f ? 4u : 0u) | (m4[3] != 0.0f ? 8u : 0u)) << (4 * qg);
+                w |= __shfl_xor(w, 16, 64);
+                w |= __shfl_xor(w, 32, 64);
+                if (qg == 0) mbits[(win * (A.ML >> 4) + (kt0 + u)) * A.ML + q0 + m] = (unsigned short)w;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float p = __expf(s[u][i] - mn); psum += p; s[u][i] = p * m4[i]; }
         }
@@ -372,6 +379,346 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_bwd_kv_k(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------- backward, ONE pass
+// dQ, dK, dV and d(bias) from ONE evaluation of S, P, dP, dS per (query, key) pair (the two-kernel backward above evaluates the soft-max side -- exp,
+// Philox mask, bias gather -- once per kernel).  Key-owner layout: a wave owns the 16-key tile kt of EVERY modality (MF = M folded tiles: tokens t and
+// t + l share their relative-position bins); a block = 4 waves = 4 key tiles x NTq <= 4 query tiles (x M x M modality pairs), so a 1024-token window is
+// 8 x 8 short blocks (72 long windows in few long blocks left the last round of blocks alone on the chip: 578 -> 149 us from the decomposition alone).
+// "S" orientation: rows = queries 4 qg + i, columns = keys m.
+//   S = Qs K^T, dP = dO V^T                     A = the query tile (global loads, prefetched one step ahead), B = this wave's K / V (registers)
+//   dV^T += dO^T (P*M),  dK^T += Qs^T dS         the accumulators ARE the B operands (reduction over the tile's queries = its rows)
+//   dQ^T += K^T dS^T                             needs the tile transposed: one trip through a wave-private 16 x 20 LDS patch (4 ds_write_b32 + 1 ds_read_b128 per lane)
+//   dQ: each wave sums into ITS OWN LDS image of the block's query rows (plain read-add-write, no barrier in the loop); the four images are added after the
+//   loop and leave as float atomics (several key chunks per window) or stores.  dK / dV leave as float atomics when a window's queries are split over blocks.
+//   d(bias): the MF x MF tiles of a step hit the same bins, their dS are added in registers first; then, WIN = true, into a wave-private window of 256
+//   consecutive bins (the bins of 16 keys x <= 64 queries span < 256 values for every shipped geometry; host-checked) with plain read-add-write, one 16-lane
+//   group at a time (the 16 lanes of a group hold 16 different keys of one query: distinct bins) -- an LDS float atomic per lane cost ~700 clocks per wave
+//   instruction here (94 of 347 us at the 8^3-window level).  WIN = false (span too wide): LDS float atomics into a full table.
+// The keep bits of the forward's dropout mask (vx_pwa_attn_fwd_mb) replace the Philox draw when given.
+// Any l: tiles are laid out per modality in a padded token index (16 * ceil(l / 16)); rows / columns beyond l contribute zeros.
+#define VX_B1_WIN 256
+template <int CQ, int CV, int MF, bool AL, bool WIN>
+__global__ void __launch_bounds__(256) vx_pwa_attn_bwd1_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                          const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                          const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                          float* __restrict__ dtable_rep, VxAttnM A, VxDrop drop, int waves_used, int atomic_dq, int QS, int NTq,
+                                                          const unsigned short* __restrict__ mbits) {
+    constexpr int KSQ = CQ / 4, KSV = CV / 4, CVB = (CV + 15) / 16, TS = 20;
+    extern __shared__ __attribute__((aligned(16))) float vx_am_lds[];
+    const int NT = (A.l + 15) >> 4, lp = NT * 16;
+    const int nq = NTq * 16;                                                     // padded query tokens of this block (per modality)
+    const int nbias = WIN ? 2 * VX_B1_WIN : ((A.Tsz + 3) & ~3);
+    int* __restrict__ lin = reinterpret_cast<int*>(vx_am_lds);                  // [lp]
+    float* __restrict__ bias = vx_am_lds + lp;                                   // WIN: the block's window of the bias column (512 bins); else the whole column
+    float* __restrict__ gwin = bias + nbias;                                     // WIN: [4 waves][256] bias-gradient windows; else [tpad] shared table
+    float* __restrict__ lse_s = gwin + (WIN ? 4 * VX_B1_WIN : nbias);            // [MF * nq]
+    float* __restrict__ del_s = lse_s + MF * nq;                                 // [MF * nq]
+    float* __restrict__ dqw = del_s + MF * nq;                                   // [4 waves][MF * nq][CQ]
+    float* __restrict__ trb = dqw + 4 * MF * nq * CQ;                            // [4 waves][MF][16 * TS]
+    const long win = blockIdx.y;
+    const int a = (int)((win / A.Nt) % A.heads);
+    const long wrow = win * A.ML;
+    const int qsi = blockIdx.x % QS, q_lo = qsi * NTq;                           // this block's query tiles: [q_lo, q_lo + NTq)
+    const int kc = blockIdx.x / QS;                                              // its key chunk: tiles kc * waves_used ..
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
+    // ---- token -> linear coordinate, this block's lse / delta = rowsum(dO * O), zeroed accumulators
+    for (int t = threadIdx.x; t < lp; t += 256) {
+        const int tc = t < A.l ? t : A.l - 1;
+        const int t2 = tc % A.n[2], t1 = (tc / A.n[2]) % A.n[1], t0 = tc / (A.n[2] * A.n[1]);
+        lin[t] = (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+    }
+    for (int e = threadIdx.x; e < MF * nq; e += 256) {
+        const int f = e / nq, t = 16 * q_lo + (e - f * nq);
+        float lse = 0.0f, del = 0.0f;
+        if (t < A.l) {
+            const long r = wrow + (long)f * A.l + t;
+            lse = LSE[r];
+#pragma unroll
+            for (int c4 = 0; c4 < CV / 4; ++c4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(dO + r * CV + 4 * c4), o4 = *reinterpret_cast<const float4*>(O + r * CV + 4 * c4);
+                del = fmaf(g4.x, o4.x, fmaf(g4.y, o4.y, fmaf(g4.z, o4.z, fmaf(g4.w, o4.w, del))));
+            }
+        }
+        lse_s[e] = lse; del_s[e] = del;
+    }
+    for (int e = threadIdx.x; e < 4 * MF * nq * CQ; e += 256) dqw[e] = 0.0f;
+    for (int e = threadIdx.x; e < (WIN ? 4 * VX_B1_WIN : nbias); e += 256) gwin[e] = 0.0f;
+    __syncthreads();
+    // ---- bin ranges: raw bin = lin_q - lin_k; the block's queries x its 64 keys, and this wave's 16 keys
+    const int kt = kc * waves_used + wave;
+    const bool wlive = wave < waves_used && kt < NT;
+    const int ktc = wlive ? kt : 0;
+    const int kcol = 16 * ktc + m;                                               // padded token of this lane's key column
+    const bool kval = wlive && kcol < A.l;
+    const int kcl = kcol < A.l ? kcol : A.l - 1;
+    int bbase = 0, wbase = 0;
+    if (WIN) {
+        const int tq = min(16 * q_lo + min(lane, nq - 1), A.l - 1), tk = min(16 * kc * waves_used + lane, A.l - 1);      // (clamped tokens repeat a valid one: harmless for min / max)
+        int qmin = lin[tq], kmax = lin[tk], kmaxw = lin[min(16 * ktc + m, A.l - 1)];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { qmin = min(qmin, __shfl_xor(qmin, o, 64)); kmax = max(kmax, __shfl_xor(kmax, o, 64)); kmaxw = max(kmaxw, __shfl_xor(kmaxw, o, 64)); }
+        bbase = qmin - kmax;                                                     // smallest raw bin of the block
+        wbase = qmin - kmaxw;                                                    // ... of this wave
+        for (int x = threadIdx.x; x < 2 * VX_B1_WIN; x += 256) {
+            const int k = bbase + x + A.lin_cst;
+            bias[x] = table[(long)(k < 0 ? 0 : (k >= A.Tsz ? A.Tsz - 1 : k)) * A.heads + a];
+        }
+    } else {
+        for (int k0 = threadIdx.x; k0 < A.Tsz; k0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * 256; v[u] = table[(long)(k < A.Tsz ? k : 0) * A.heads + a]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * 256; if (k < A.Tsz) bias[k] = v[u]; }
+        }
+    }
+    __syncthreads();
+    const VxDropCtx dc = vx_drop_ctx(drop);
+    float* __restrict__ tr = trb + wave * (MF * 16 * TS);
+    float* __restrict__ dqm = dqw + wave * (MF * nq * CQ);
+    float* __restrict__ gw = gwin + (WIN ? wave * VX_B1_WIN : 0);
+    // ---- this wave's keys
+    float kb[MF][KSQ], vb[MF][KSV], kA[MF][4];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const long kr = wrow + (long)f * A.l + kcl;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) { const float t_ = K[kr * CQ + 4 * ks + qg]; kb[f][ks] = kval ? t_ : 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < KSV; ++ks) { const float t_ = Vt[kr * CV + 4 * ks + qg]; vb[f][ks] = kval ? t_ : 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                            // A operand of dQ^T: K[key 4 qg + i][c = m]
+            const int kk = 16 * ktc + 4 * qg + i;
+            const float t_ = K[(wrow + (long)f * A.l + (kk < A.l ? kk : A.l - 1)) * CQ + (m < CQ ? m : 0)];
+            kA[f][i] = (wlive && kk < A.l && m < CQ) ? t_ : 0.0f;
+        }
+    }
+    const int lin_k = lin[kcol];
+    vx_f32x4 dk[MF], dv[MF][CVB];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        dk[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb) dv[f][cb] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- operands of one query tile (every modality).  mk[g][f]: the forward's keep bits of the 4 query rows x 16 keys of tile (g, f)
+    struct QOps { float qa[MF][KSQ], da[MF][KSV], qT[MF][4], dT[MF][CVB][4]; unsigned mk[MF][MF][4]; };
+    const bool use_bits = mbits != nullptr && dc.on;
+    const int NW16 = (A.ML + 15) >> 4;
+    const unsigned short* __restrict__ mbw = use_bits ? mbits + win * NW16 * A.ML : nullptr;
+    // (32-bit element offsets from the window's uniform base pointers: the loads take an SGPR base + VGPR offset, no 64-bit vector arithmetic)
+    const float* __restrict__ Qw = Q + wrow * CQ;
+    const float* __restrict__ dOw = dO + wrow * CV;
+    auto load_q = [&](QOps& o, int qt) {
+        const int qm = 16 * qt + m, qmc = qm < A.l ? qm : A.l - 1;
+#pragma unroll
+        for (int g = 0; g < MF; ++g) {
+            const int r = g * A.l + qmc;
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) o.qa[g][ks] = Qw[r * CQ + 4 * ks + qg] * A.scale;
+#pragma unroll
+            for (int ks = 0; ks < KSV; ++ks) o.da[g][ks] = dOw[r * CV + 4 * ks + qg];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qq = 16 * qt + 4 * qg + i;
+                const int r2 = g * A.l + (qq < A.l ? qq : A.l - 1);
+                o.qT[g][i] = Qw[r2 * CQ + (m < CQ ? m : 0)] * A.scale;
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) o.dT[g][cb][i] = dOw[r2 * CV + (16 * cb + m < CV ? 16 * cb + m : 0)];
+            }
+        }
+        if (use_bits) {
+#pragma unroll
+            for (int g = 0; g < MF; ++g)
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const int k0 = f * A.l + 16 * ktc;                       // first key of the tile (window index); its 16 keys start at bit k0 & 15 of word k0 >> 4
+                    const int w0 = k0 >> 4, w1 = min(w0 + 1, NW16 - 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int qq = 16 * qt + 4 * qg + i;
+                        const int rr = g * A.l + (qq < A.l ? qq : A.l - 1);
+                        const unsigned lo = mbw[w0 * A.ML + rr], hi = mbw[w1 * A.ML + rr];
+                        o.mk[g][f][i] = (lo | (hi << 16)) >> (k0 & 15);
+                    }
+                }
+        }
+    };
+    QOps opa, opb;
+    auto step = [&](QOps& cur, QOps& nxt, int j) {
+        {
+            const int qt = q_lo + j;
+            if (j + 1 < NTq) load_q(nxt, qt + 1);
+            const int4 lq = *reinterpret_cast<const int4*>(&lin[16 * qt + 4 * qg]);
+            const int raw[4] = {lq.x - lin_k, lq.y - lin_k, lq.z - lin_k, lq.w - lin_k};
+            bool qv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qv[i] = kval && (16 * qt + 4 * qg + i < A.l);
+            float bs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bs[i] = bias[qv[i] ? (WIN ? raw[i] - bbase : raw[i] + A.lin_cst) : 0];
+            float dssum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < MF; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[g * nq + 16 * j + 4 * qg]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&del_s[g * nq + 16 * j + 4 * qg]);
+                const float lse[4] = {l4.x, l4.y, l4.z, l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
+                // the MF key tiles of this query tile are worked on TOGETHER, phase by phase: their MFMA chains, exponentials and LDS round trips are independent
+                vx_f32x4 sv[MF], dp[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) { sv[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; dp[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks)
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) sv[f] = VX_MFMA(cur.qa[g][ks], kb[f][ks], sv[f]);
+#pragma unroll
+                for (int ks = 0; ks < KSV; ++ks)
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) dp[f] = VX_MFMA(cur.da[g][ks], vb[f][ks], dp[f]);
+                float ds[MF][4], pm[MF][4];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    float m4[4];
+                    const uint64_t row0 = (uint64_t)(wrow + (long)g * A.l + 16 * qt + 4 * qg);
+                    const long keyc = (long)f * A.l + kcol;
+                    if (use_bits) {                          // one bit per pair, written by the forward: no Philox in the backward
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) m4[i] = ((cur.mk[g][f][i] >> m) & 1u) ? dc.inv_keep : 0.0f;
+                    } else if constexpr (AL) vx_masks_rows4(dc, row0, 1, A.ML, keyc, m4);      // l % 4 == 0: one Philox call per lane and tile (DPP quad transpose)
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) m4[i] = vx_drop1(dc, (row0 + i) * (uint64_t)A.ML + (uint64_t)keyc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float p = qv[i] ? __expf(sv[f][i] + bs[i] - lse[i]) : 0.0f;
+                        pm[f][i] = p * m4[i];
+                        ds[f][i] = p * (dp[f][i] * m4[i] - del[i]);
+                        dssum[i] += ds[f][i];
+                    }
+                }
+                // transpose dS through the wave's LDS patches (one per key tile): written [query 4 qg + i][key m], read [query m][keys 4 qg ..]
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tr[f * (16 * TS) + (4 * qg + i) * TS + m] = ds[f][i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                        for (int cb = 0; cb < CVB; ++cb) dv[f][cb] = VX_MFMA(cur.dT[g][cb][i], pm[f][i], dv[f][cb]);
+                        dk[f] = VX_MFMA(cur.qT[g][i], ds[f][i], dk[f]);
+                    }
+                // (a wave's LDS instructions execute in order: the reads below see every lane's writes; the barriers only pin the compiler's schedule --
+                // a memory fence here would also wait for the prefetched global loads of the next query tile)
+                __builtin_amdgcn_wave_barrier();
+                float4 t4[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) t4[f] = *reinterpret_cast<const float4*>(&tr[f * (16 * TS) + m * TS + 4 * qg]);
+                __builtin_amdgcn_wave_barrier();
+                vx_f32x4 dqT[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) dqT[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < MF; ++f) dqT[f] = VX_MFMA(kA[f][0], t4[f].x, dqT[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) dqT[f] = VX_MFMA(kA[f][1], t4[f].y, dqT[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) dqT[f] = VX_MFMA(kA[f][2], t4[f].z, dqT[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) dqT[f] = VX_MFMA(kA[f][3], t4[f].w, dqT[f]);
+                if constexpr (MF == 2) dqT[0] += dqT[1];
+                // dqT: lane (q = m, c = 4 qg + i) -> this wave's dQ image
+                if (4 * qg < CQ) {
+                    float4* dst = reinterpret_cast<float4*>(&dqm[(g * nq + 16 * j + m) * CQ + 4 * qg]);
+                    float4 o4 = *dst;
+                    o4.x += dqT[0][0]; o4.y += dqT[0][1]; o4.z += dqT[0][2]; o4.w += dqT[0][3];
+                    *dst = o4;
+                }
+            }
+            if constexpr (WIN) {
+                // one 16-lane group at a time: its lanes are 16 different keys of one query -> 16 different bins -> plain read-add-write
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    if (qg == ph) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (qv[i]) gw[raw[i] - wbase] += dssum[i];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (qv[i]) atomicAdd(&gw[raw[i] + A.lin_cst], dssum[i]);
+            }
+        }
+    };
+    if (wlive) {
+        load_q(opa, q_lo);
+        for (int j = 0; j < NTq; j += 2) {          // two steps per trip: the operand sets swap roles instead of being copied
+            step(opa, opb, j);
+            if (j + 1 < NTq) step(opb, opa, j + 1);
+        }
+    }
+    // ---- results
+    if (kval) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const long kr = wrow + (long)f * A.l + kcol;
+            if (QS == 1) {
+                if (4 * qg < CQ) *reinterpret_cast<float4*>(dK + kr * CQ + 4 * qg) = make_float4(dk[f][0], dk[f][1], dk[f][2], dk[f][3]);
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) {
+                    const int ch = 16 * cb + 4 * qg;
+                    if (ch < CV) *reinterpret_cast<float4*>(dV + kr * CV + ch) = make_float4(dv[f][cb][0], dv[f][cb][1], dv[f][cb][2], dv[f][cb][3]);
+                }
+            } else {
+                if (4 * qg < CQ) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) atomicAdd(dK + kr * CQ + 4 * qg + i, dk[f][i]);
+                }
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) {
+                    const int ch = 16 * cb + 4 * qg;
+                    if (ch < CV) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) atomicAdd(dV + kr * CV + ch + i, dv[f][cb][i]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int img = MF * nq * CQ;
+    for (int e = threadIdx.x; e < img; e += 256) {
+        const int c = e % CQ, rr = e / CQ, f = rr / nq, t = 16 * q_lo + (rr - f * nq);
+        if (t < A.l) {
+            float* dst = dQ + (wrow + (long)f * A.l + t) * CQ + c;
+            const float v = ((dqw[e] + dqw[img + e]) + (dqw[2 * img + e] + dqw[3 * img + e])) * A.scale;
+            if (atomic_dq) atomicAdd(dst, v); else *dst = v;
+        }
+    }
+    float* __restrict__ dst = dtable_rep + (long)((blockIdx.x + gridDim.x * blockIdx.y) % VX_DTABLE_REPLICAS) * A.Tsz * A.heads;
+    if (WIN) {
+        // raw bin x + bbase of the block window: the waves' windows start at wbase_w = qmin - kmax_w >= bbase
+        __shared__ int wb_s[4];
+        if (lane == 0) wb_s[wave] = wbase - bbase;
+        __syncthreads();
+        for (int x = threadIdx.x; x < 2 * VX_B1_WIN; x += 256) {
+            float g = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int y = x - wb_s[w]; if (y >= 0 && y < VX_B1_WIN) g += gwin[w * VX_B1_WIN + y]; }
+            const int k = bbase + x + A.lin_cst;
+            if (g != 0.0f && k >= 0 && k < A.Tsz) atomicAdd(dst + (long)k * A.heads + a, g);
+        }
+    } else {
+        for (int k = threadIdx.x; k < A.Tsz; k += 256) {
+            const float g = gwin[k];
+            if (g != 0.0f) atomicAdd(dst + (long)k * A.heads + a, g);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------- host
 static bool vx_am_fill(VxAttnM& A, const VxPwaPlan* P, int B, int M, int cq) {
     A.BH = B * P->heads; A.heads = P->heads; A.Nt = P->Ntot; A.l = P->l; A.M = M; A.ML = M * P->l;
@@ -386,23 +733,28 @@ static size_t vx_am_lds_fwd(const VxAttnM& A, int cq, int cv) { return (vx_am_ta
 static size_t vx_am_lds_q(const VxAttnM& A, int cq, int cv) { return (vx_am_tab_floats(A) + (size_t)4 * ((A.Tsz + 3) & ~3) + (size_t)A.ML * (cq + cv)) * 4; }
 static size_t vx_am_lds_kv(const VxAttnM& A, int cq, int cv) { return (vx_am_tab_floats(A) + (size_t)A.ML * (cq + cv + 2)) * 4; }
 
-// Which passes take the MFMA kernels: bit 0 forward, bit 1 backward.  Default = forward only.  Measured on MI355X at the bench shape (8^3-window level,
-// 1024 keys, c_qk = c_v = 8, p_drop 0.1; profiles/r02*): forward 153 us MFMA vs 157 us VALU; dK/dV pass 232 vs 181 us; dQ pass 640 vs 273 us.  At head
-// widths 4..16 the two GEMMs are 6 of ~180 instructions per 16 x 16 tile: the tile's time is the per-pair soft-max side (Philox draw = half of the VALU
-// issue, exp, bias gather), and d(bias) on LDS float atomics costs ~200 clocks per wave instruction in this orientation (the VALU dQ kernel's lanes
-// are 64 different queries of one key, which is what lets it use plain read-add-write windows).  So the backward stays on the VALU kernels.
-static int vx_am_enabled = 1;
-extern "C" int vx_pwa_attn_set_mfma(int mask) { vx_am_enabled = mask & 3; return 0; }
+// Which passes take the MFMA kernels: bit 0 forward; bit 1 backward = the ONE-pass kernel vx_pwa_attn_bwd1_k where it is the faster one (below); bit 3
+// (A/B, tests) the one-pass kernel for EVERY geometry it covers; bit 2 (A/B only) the older two-kernel MFMA backward where its geometry allows.  Default 3.
+// Measured on one MI355X, B = 4, M = 2, p_drop 0.1 (tools/attn_bwd_probe.py, profiles/r03_attn_bwd_probe.txt), microseconds per backward:
+//   128^3 (l = 64 / 512 / 64 / 64):   one-pass 133 / 332 / 33 / 44    VALU 122 / 304 / 32 / 43    two-kernel MFMA 313 / 778 / 43 / 51
+//    96^3 (l = 27 / 216 / 27 / 27):   one-pass  74 / 111 / 21 / 26    VALU  82 / 119 / 36 / 46
+// The one-pass kernel evaluates the soft-max side once per pair and runs all five GEMMs on MFMA, but its issue stream (~320 instructions per 16 x 16 tile:
+// accumulator moves, the d(bias) windows, the dS transpose) is no shorter than the two VALU passes when the tokens fill the VALU kernels' 64-row units
+// (l a multiple of 16); with the 27- / 216-token windows of the shipped 96^3 configurations the VALU units are ragged and it wins by 7 - 45 %.
+// So: bit 1 selects it for l % 16 != 0, bit 3 everywhere.
+static int vx_am_enabled = 3;
+extern "C" int vx_pwa_attn_set_mfma(int mask) { vx_am_enabled = mask & 15; return 0; }
 
 // bit mask of the passes this geometry can run on the MFMA kernels (0 = none), after the vx_pwa_attn_set_mfma selection
 extern "C" int vx_pwa_attn_mfma_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
-    if (!vx_am_enabled || P == nullptr || B <= 0 || M <= 0) return 0;
+    const int want = (vx_am_enabled & 1) | ((vx_am_enabled & 4) ? 2 : 0);      // bit 1 of the ANSWER = the two-kernel MFMA backward (A/B knob bit 2)
+    if (!want || P == nullptr || B <= 0 || M <= 0) return 0;
     if (P->l % 64 != 0 || cq % 4 != 0 || cq > 16 || cv % 4 != 0 || cv > 32) return 0;
     if (!((cq == 4 && cv == 4) || (cq == 8 && cv == 8) || (cq == 8 && cv == 16) || (cq == 16 && cv == 32) || (cq == 16 && cv == 16) || (cq == 4 && cv == 8))) return 0;
     VxAttnM A;
     vx_am_fill(A, P, B, M, cq);
     const size_t cap = 150 * 1024;
-    return (vx_am_lds_fwd(A, cq, cv) <= cap && vx_am_lds_q(A, cq, cv) <= cap && vx_am_lds_kv(A, cq, cv) <= cap) ? vx_am_enabled : 0;
+    return (vx_am_lds_fwd(A, cq, cv) <= cap && vx_am_lds_q(A, cq, cv) <= cap && vx_am_lds_kv(A, cq, cv) <= cap) ? want : 0;
 }
 
 template <int A_, int B_> struct vx_am_pair { static constexpr int a = A_, b = B_; };
@@ -415,7 +767,7 @@ template <class F> static bool vx_am_dispatch(int cq, int cv, F&& f) {
 template <class K> static void vx_am_attr(K kernel) { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 
 // same contracts as vx_pwa_attn_fwd / vx_pwa_attn_bwd (include/veloxseg_hip.h); the caller checked vx_pwa_attn_mfma_ok and zeroed the replicas
-int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE, const VxPwaPlan* plan, int B, int M,
+int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE, unsigned short* mbits, const VxPwaPlan* plan, int B, int M,
                          int cq, int cv, VxDrop d, void* stream) {
     VxAttnM A;
     vx_am_fill(A, plan, B, M, cq);
@@ -425,7 +777,7 @@ int vx_pwa_attn_mfma_fwd(const float* Q, const float* K, const float* V, const f
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
         static bool once = false;
         if (!once) { vx_am_attr(vx_pwa_attn_mfma_fwd_k<CQ, CV>); once = true; }
-        vx_pwa_attn_mfma_fwd_k<CQ, CV><<<grid, dim3(512), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, A, d);
+        vx_pwa_attn_mfma_fwd_k<CQ, CV><<<grid, dim3(512), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, A, d, mbits);
     });
     return 0;
 }
@@ -442,6 +794,80 @@ int vx_pwa_attn_mfma_bwd(const float* Q, const float* K, const float* V, const f
         if (!once) { vx_am_attr(vx_pwa_attn_mfma_bwd_q_k<CQ, CV>); vx_am_attr(vx_pwa_attn_mfma_bwd_kv_k<CQ, CV>); once = true; }
         vx_pwa_attn_mfma_bwd_q_k<CQ, CV><<<grid, dim3(512), shm_q, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta, rep, A, d);
         vx_pwa_attn_mfma_bwd_kv_k<CQ, CV><<<grid, dim3(512), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta, dO, dK, dV, rep, dtable, A, d);
+    });
+    return 0;
+}
+
+// ---- one-pass backward: geometry test + launch (contract of vx_pwa_attn_bwd without the fold; `rep` zeroed by the caller) -------------------------
+struct VxB1Geo { int NT, waves_used, nbx, QS, NTq, win; size_t shm; };
+// largest spread of the linear coordinate over `ntok` consecutive tokens starting at a multiple of `step` (tokens beyond l repeat the last one)
+static int vx_b1_span(const VxAttnM& A, int ntok, int step) {
+    int worst = 0;
+    for (int t0 = 0; t0 < A.l; t0 += step) {
+        int lo = 1 << 30, hi = -(1 << 30);
+        for (int t = t0; t < t0 + ntok; ++t) {
+            const int tc = t < A.l ? t : A.l - 1;
+            const int t2 = tc % A.n[2], t1 = (tc / A.n[2]) % A.n[1], tz = tc / (A.n[2] * A.n[1]);
+            const int v = (tz * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+            lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+        }
+        worst = (hi - lo) > worst ? (hi - lo) : worst;
+    }
+    return worst;
+}
+static VxB1Geo vx_b1_geo(const VxAttnM& A, int cq, int mf) {
+    VxB1Geo g;
+    g.NT = (A.l + 15) / 16;
+    g.waves_used = g.NT < 4 ? g.NT : 4;
+    g.nbx = (g.NT + g.waves_used - 1) / g.waves_used;
+    g.NTq = g.NT < 4 ? g.NT : 4;                          // query tiles per block: short blocks balance the chip (72 windows of 1024 tokens: 8 x 8 blocks each)
+    while (g.NT % g.NTq) --g.NTq;
+    g.QS = g.NT / g.NTq;
+    // bias-gradient windows: bins of (NTq * 16 queries) x (16 keys) inside 256 values, x (64 keys) inside 512
+    const int sq = vx_b1_span(A, g.NTq * 16, g.NTq * 16), sk16 = vx_b1_span(A, 16, 16), sk64 = vx_b1_span(A, 16 * g.waves_used, 16 * g.waves_used);
+    g.win = (sq + sk16 + 1 <= VX_B1_WIN && sq + sk64 + 1 <= 2 * VX_B1_WIN) ? 1 : 0;
+    const size_t lp = (size_t)g.NT * 16, nq = (size_t)g.NTq * 16, tpad = (size_t)((A.Tsz + 3) & ~3);
+    g.shm = (lp + (g.win ? 2 * VX_B1_WIN + 4 * VX_B1_WIN : 2 * tpad) + 2 * mf * nq + 4 * mf * nq * cq + (size_t)4 * mf * 16 * 20) * sizeof(float);
+    return g;
+}
+extern "C" int vx_pwa_attn_bwd1_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
+    if (!(vx_am_enabled & 10) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M < 1 || M > 2) return 0;
+    if (!(vx_am_enabled & 8) && P->l % 16 == 0) return 0;          // (measured: see vx_am_enabled)
+    if (!((cq == 4 && cv == 4) || (cq == 8 && cv == 8) || (cq == 8 && cv == 16) || (cq == 16 && cv == 32) || (cq == 16 && cv == 16) || (cq == 4 && cv == 8))) return 0;
+    VxAttnM A;
+    vx_am_fill(A, P, B, M, cq);
+    return vx_b1_geo(A, cq, M).shm <= 80 * 1024 ? 1 : 0;
+}
+int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
+                     float* dK, float* dV, float* rep, const unsigned short* mbits, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d, void* stream) {
+    VxAttnM A;
+    vx_am_fill(A, plan, B, M, cq);
+    const VxB1Geo g = vx_b1_geo(A, cq, M);
+    const long nwin = (long)A.BH * A.Nt;
+    const dim3 grid((unsigned)(g.nbx * g.QS), (unsigned)nwin);
+    const int atomic_dq = g.nbx > 1 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = nwin * A.ML;
+    if (atomic_dq && hipMemsetAsync(dQ, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess) return -2;
+    if (g.QS > 1 && (hipMemsetAsync(dK, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess || hipMemsetAsync(dV, 0, (size_t)rows * cv * sizeof(float), st) != hipSuccess)) return -2;
+    vx_am_dispatch(cq, cv, [&](auto pr) {
+        constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
+        const bool al = (A.l & 3) == 0;
+#define VX_B1(MF_, AL_, WIN_)                                                                                                         \
+        {                                                                                                                             \
+            static bool once = false;                                                                                                 \
+            if (!once) {          /* (the kernel also has 16 bytes of static LDS: 160 KB of dynamic LDS would be refused) */                      \
+                if (hipFuncSetAttribute((const void*)vx_pwa_attn_bwd1_k<CQ, CV, MF_, AL_, WIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) (void)hipGetLastError(); \
+                once = true;                                                                                                          \
+            }                                                                                                                         \
+            vx_pwa_attn_bwd1_k<CQ, CV, MF_, AL_, WIN_><<<grid, dim3(256), g.shm, st>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, A, d, g.waves_used, atomic_dq, \
+                                                                                      g.QS, g.NTq, mbits);                         \
+        }
+#define VX_B1W(MF_, AL_) { if (g.win) VX_B1(MF_, AL_, true) else VX_B1(MF_, AL_, false) }
+        if (M == 1) { if (al) VX_B1W(1, true) else VX_B1W(1, false) }
+        else { if (al) VX_B1W(2, true) else VX_B1W(2, false) }
+#undef VX_B1W
+#undef VX_B1
     });
     return 0;
 }

@@ -66,6 +66,13 @@ __global__ void vx_spin_k(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) {}
 }
+// a one-block kernel that keeps one wave busy for `us` microseconds on `stream`: the stand-in for a collective in tools/comm_standin_probe.py
+extern "C" int vx_spin_us(float us, void* stream) {
+    VX_REQUIRE(us >= 0.0f && us <= 1e6f, "vx_spin_us: 0 .. 1 s");
+    hipLaunchKernelGGL(vx_spin_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(us * 100.0f));      // wall_clock64 counts at 100 MHz
+    VX_LAUNCH_CHECK("vx_spin_us");
+    return 0;
+}
 // Cross-lane dependencies without events: the producing lane runs a one-thread kernel that stores a sequence number to a device flag; the waiting
 // lane runs a one-wave kernel that polls the flag until it reaches that number.  On this runtime an event record + stream wait costs ~14 us of
 // queue time per hop (tools/event_hop_probe.py: every flag combination of hipEventCreateWithFlags); two back-to-back tiny kernels cost ~1.6 us each.

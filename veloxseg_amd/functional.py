@@ -894,14 +894,46 @@ def _submit_wgrad(fn):
         fn(st)
 
 
+WGG_JOBS, WGG_FOLDS = 24, 16          # capacity of one vx_pw_wgrad_group launch (csrc/pointwise.hip)
+_wgg_pending = {}                     # (device, stream) -> [jobs, folds] collected while the engine defers weight gradients
+
+
 def _wgrad_group(jobs, folds, st):
-    """jobs: [(x, dy, dw, db or None, Cin, Cout, V, B)], folds: [(part, dgamma, dbeta, C, rows)] -> one launch"""
-    jp = _ptrs([v for j in jobs for v in (H.P(j[0]), H.P(j[1]), H.P(j[2]), H.P(j[3]))])
-    jd = (H.ctypes.c_long * (4 * len(jobs)))(*[int(v) for j in jobs for v in j[4:8]])
-    fp = _ptrs([v for f in folds for v in (H.P(f[0]), H.P(f[1]), H.P(f[2]))])
-    fd = (H.ctypes.c_int * max(1, 2 * len(folds)))(*[int(v) for f in folds for v in f[3:5]])
-    H.call("vx_pw_wgrad_group", H.ctypes.addressof(jp) if jobs else None, H.ctypes.addressof(jd) if jobs else None, len(jobs),
-           H.ctypes.addressof(fp) if folds else None, H.ctypes.addressof(fd) if folds else None, len(folds), st)
+    """jobs: [(x, dy, dw, db or None, Cin, Cout, V, B)], folds: [(part, dgamma, dbeta, C, rows)] -> as few launches as the capacity allows"""
+    jobs, folds = list(jobs), list(folds)
+    while jobs or folds:
+        j, jobs = jobs[:WGG_JOBS], jobs[WGG_JOBS:]
+        f, folds = folds[:WGG_FOLDS], folds[WGG_FOLDS:]
+        jp = _ptrs([v for q in j for v in (H.P(q[0]), H.P(q[1]), H.P(q[2]), H.P(q[3]))])
+        jd = (H.ctypes.c_long * max(1, 4 * len(j)))(*[int(v) for q in j for v in q[4:8]])
+        fp = _ptrs([v for q in f for v in (H.P(q[0]), H.P(q[1]), H.P(q[2]))])
+        fd = (H.ctypes.c_int * max(1, 2 * len(f)))(*[int(v) for q in f for v in q[3:5]])
+        H.call("vx_pw_wgrad_group", H.ctypes.addressof(jp) if j else None, H.ctypes.addressof(jd) if j else None, len(j),
+               H.ctypes.addressof(fp) if f else None, H.ctypes.addressof(fd) if f else None, len(f), st)
+
+
+def _submit_wgrad_jobs(jobs, folds):
+    """The weight-gradient jobs / LayerNorm-parameter folds of one fused chain.  Immediate mode: one grouped launch now.  While the engine defers weight
+    gradients, the jobs of EVERY chain of the pass submitted from this stream are pooled and leave in one or two grouped launches when the queue is joined
+    (13 launches at the end of the encoder backward -> 2)."""
+    if not jobs and not folds:
+        return
+    m = _cpp_mod()
+    if m is None or not hasattr(m, "wgrad_deferring") or not m.wgrad_deferring():
+        _wgrad_group(jobs, folds, H.stream_ptr())
+        return
+    key = (int(torch.cuda.current_device()), int(H.stream_ptr() or 0))
+    pend = _wgg_pending.get(key)
+    if pend is None:
+        pend = _wgg_pending[key] = [[], []]
+
+        def flush(st, key=key):
+            p_ = _wgg_pending.pop(key, None)
+            if p_ is not None:
+                _wgrad_group(p_[0], p_[1], st)
+        _submit_wgrad(flush)
+    pend[0].extend(jobs)
+    pend[1].extend(folds)
 
 
 def _gb(p):
@@ -980,8 +1012,7 @@ class _LnPwFn(torch.autograd.Function):
                     jobs.append((xn[m], douts[m][s_], grad_buf(w_), _gb(b_), C, J[s_], V, B))
             if prm[m][0].requires_grad:
                 folds.append((parts[m], grad_buf(prm[m][0]), grad_buf(prm[m][1]), C, rows))
-        if jobs or folds:
-            _submit_wgrad(lambda st, jobs=jobs, folds=folds: _wgrad_group(jobs, folds, st))
+        _submit_wgrad_jobs(jobs, folds)
         return (None, None, None, None) + tuple(dxs) + (None,) * (len(prm) * len(prm[0]))
 
 
@@ -1069,8 +1100,7 @@ class _PwaPostFn(torch.autograd.Function):
                 jobs.append((ss[m], dmix_, grad_buf(wm), _gb(bm), Cv, C, V, B))
             if gam.requires_grad:
                 folds.append((parts[m], grad_buf(gam), grad_buf(bet), C, rows))
-        if jobs or folds:
-            _submit_wgrad(lambda st, jobs=jobs, folds=folds: _wgrad_group(jobs, folds, st))
+        _submit_wgrad_jobs(jobs, folds)
         return (None, None, None, None, None) + tuple(dsl) + tuple(dxl) + (None,) * (8 * M)
 
 
@@ -1144,8 +1174,12 @@ class _PwaCoreFn(torch.autograd.Function):
         lse = torch.empty((B, h, Nt, ML), device=dev, dtype=torch.float32)
         rs = rng_state(dev) if p_attn > 0 else None
         tbl = _c(table)
-        H.call("vx_pwa_attn_fwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), pp, B, M, cq, cv,
-               H.P(rs, torch.int64), site, float(p_attn), st)
+        mbits = None
+        if p_attn > 0 and H.query("vx_pwa_attn_mbits_useful", pp, B, M, cq, cv) == 1:      # keep bits of the dropout mask for the one-pass backward
+            mbits = torch.empty((H.query("vx_pwa_attn_mbits_words", pp, B, M),), device=dev, dtype=torch.int16)
+        H.call("vx_pwa_attn_fwd_mb", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), pp, B, M, cq, cv,
+               H.P(rs, torch.int64), site, float(p_attn), H.P(mbits, torch.int16), st)
+        ctx.mbits = mbits
         g = (plan.grid[0], plan.grid[1], plan.grid[2])
         outs = []
         for m in range(M):
@@ -1177,8 +1211,8 @@ class _PwaCoreFn(torch.autograd.Function):
         delta = torch.empty(nws, device=dev, dtype=torch.float32)
         rs = ctx.rs              # the {seed, step} tensor of THIS node's forward
         dtab = grad_buf(ctx.table) if ctx.table.requires_grad else torch.zeros_like(tbl)
-        H.call("vx_pwa_attn_bwd", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
-               H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, st)
+        H.call("vx_pwa_attn_bwd_mb", H.P(tq), H.P(tk), H.P(tv), H.P(tbl), H.P(O), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv),
+               H.P(dtab), H.P(delta), pp, B, M, cq, cv, H.P(rs, torch.int64), ctx.site, ctx.p, H.P(ctx.mbits, torch.int16), st)
         grads = [torch.empty(shp, device=dev, dtype=torch.float32) for shp in ctx.qkv_shapes]
         dsts_arr = (H.ctypes.c_void_p * (3 * M))(*[H.P(t) for t in grads])
         dsts = H.ctypes.addressof(dsts_arr)
