@@ -497,6 +497,7 @@ def _attn_mfma_util(name, plan, B, M, cq, cv, pairs, ms):
     `on_mfma`: whether this pass of this geometry runs its GEMMs on MFMA in the default selection (csrc/pwa_mfma.hip): forward when l % 64 == 0; backward = the
     one-pass kernel where selected, else the fp32-VALU kernels (then both figures are 0 by definition and the VALU rate is the launch's achieved TFLOP/s)."""
     try:
+        from veloxseg_amd import _hip as H
         pp = H.ctypes.addressof(plan)
         fwd = name == "vx_pwa_attn_fwd"
         on = bool(H.query("vx_pwa_attn_mfma_ok", pp, B, M, cq, cv) & 1) if fwd else bool(H.query("vx_pwa_attn_bwd1_ok", pp, B, M, cq, cv))

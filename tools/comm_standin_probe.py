@@ -39,8 +39,9 @@ def spin(stream, us):
     H.call("vx_spin_us", float(us), stream.cuda_stream)
 
 
-def replay(where, comm):
-    """engine._replay with the stand-ins: where = set of {"dec", "enc"}; comm = the stream the stand-ins run on"""
+def replay(where, comm, late=False):
+    """engine._replay with the stand-ins: where = set of {"dec", "enc"}; comm = the stream the stand-ins run on; late = the decoder-bucket stand-in is ENQUEUED
+    after the encoder-backward tape (a stream that waits for a long dependency blocks the hardware queue it shares from the moment its wait is enqueued)"""
     G = eng.graphs
     cur = torch.cuda.current_stream(dev)
     G["enc_fwd"].replay()
@@ -54,12 +55,23 @@ def replay(where, comm):
         with torch.cuda.stream(wg_lane):
             for t in G["dec_wg"]:
                 t.replay()
-    if "dec" in where:
-        comm.wait_stream(cur)                    # the decoder bucket is complete once the decoder-backward fan has joined (the dec_wg lane only adds weight gradients of the SAME bucket)
+    def dec_standin():
+        comm.wait_stream(cur)                    # the decoder bucket is complete once the decoder-backward fan has joined AND the dec_wg lane has added the decoders' weight gradients
         if wg_lane is not None:
             comm.wait_stream(wg_lane)
         spin(comm, spin_us)
+    ev = None
+    if "dec" in where and not late:
+        dec_standin()
+    if "dec" in where and late:
+        ev = torch.cuda.Event()
+        ev.record(cur)
     G["enc_bwd"].replay()
+    if "dec" in where and late:
+        comm.wait_event(ev)
+        if wg_lane is not None:
+            comm.wait_stream(wg_lane)
+        spin(comm, spin_us)
     if "enc" in where:
         comm.wait_stream(cur)
         spin(comm, spin_us * 0.6)                # 5.5 MB of the 9.2 MB payload
@@ -70,13 +82,13 @@ def replay(where, comm):
     eng._adamw()
 
 
-def timed(where, comm, n=60):
+def timed(where, comm, n=60, late=False):
     for _ in range(10):
-        replay(where, comm)
+        replay(where, comm, late)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
-        replay(where, comm)
+        replay(where, comm, late)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
@@ -86,8 +98,12 @@ lanes = eng._lane_streams(4)
 res = {"none": timed(set(), comm_new)}
 for name, comm in (("fresh_stream", comm_new), ("lane0", lanes[0]), ("lane1", lanes[1]), ("lane2", lanes[2]), ("lane3_dec_wg", lanes[3])):
     res[f"dec_on_{name}"] = timed({"dec"}, comm)
+res["dec_on_fresh_stream_LATE"] = timed({"dec"}, comm_new, late=True)
 res["dec+enc_on_fresh_stream"] = timed({"dec", "enc"}, comm_new)
+res["dec+enc_on_lane3"] = timed({"dec", "enc"}, lanes[3])
+res["dec+enc_fresh_LATE"] = timed({"dec", "enc"}, comm_new, late=True)
 base = res["none"]
+print(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(default 4)')}")
 print(f"workload {wl}, B = {B}, stand-in spin {spin_us:.0f} us (decoder bucket) / {spin_us * 0.6:.0f} us (encoder bucket); lanes on distinct hw queues: {H.query('vx_tape_lanes_distinct')}")
 for k, v in res.items():
     print(f"  {k:28s} {v:7.3f} ms/step   delta {1e3 * (v - base):+7.1f} us")

@@ -817,7 +817,8 @@ class TrainEngine:
             self._hop(slot0 + 8 + k, s_, cur)
 
     def _replay(self, comm: bool):
-        """enc_fwd, {dec_fwd}, loss, {dec_bwd}, [decoder bucket all-reduce on the comm stream ||] enc_bwd, [encoder bucket all-reduce]"""
+        """enc_fwd, {dec_fwd}, loss, {dec_bwd}, {dec_wg on the fourth lane || enc_bwd}, then -- enqueued AFTER the encoder-backward tape -- the decoder bucket's
+        all-reduce on the dec_wg lane's stream (it runs behind the weight gradients, beside the rest of the encoder backward) and the encoder bucket's"""
         G = self.graphs
         cur = torch.cuda.current_stream(self.dev)
         G["enc_fwd"].replay()
@@ -835,13 +836,21 @@ class TrainEngine:
                     t.replay()
         if comm:
             self._reduced = []
-        if comm and self.overlap:
-            self.comm_stream.wait_stream(wg_lane if wg_lane is not None else cur)
-            with torch.cuda.stream(self.comm_stream):
-                self._allreduce(split, n)                   # decoder bucket, overlapped with the encoder backward
         G["enc_bwd"].replay()
         if comm and self.world > 1:
             if self.overlap:
+                # WHERE the collectives are enqueued decides whether they cost their own duration or a millisecond (tools/comm_standin_probe.py, one MI355X,
+                # a 150 us stand-in kernel for the decoder bucket): ROCm multiplexes every stream onto 4 hardware queues that run their packets in order, so a
+                # stream that WAITS for a long dependency blocks the queue it shares from the moment the wait is enqueued.  The decoder bucket is complete
+                # only when the dec_wg tapes (the decoders' weight gradients, ~1 ms on the fourth lane) are done; enqueued BEFORE the encoder-backward tape
+                # on a stream of its own, that wait stalled one of the tape's lanes: +1.07 ms per step.  Enqueued AFTER the tape, on the dec_wg lane's own
+                # stream (stream order instead of an event wait): +0.09 ms -- it runs behind the weight gradients while the encoder backward still has
+                # ~1 ms to go.  More hardware queues are no way out (GPU_MAX_HW_QUEUES 5 / 6: the step itself 6.25 -> 6.95 / 8.2 ms).
+                cs = wg_lane if wg_lane is not None else self.comm_stream
+                if wg_lane is None:
+                    cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    self._allreduce(split, n)                   # decoder bucket: behind the dec_wg tapes, beside the rest of the encoder backward
                 tape = G["enc_bwd"] if self.replay_mode == "tape" else None
                 done = split
                 for trig, lo, hi in self.flat.plan(self.bucket_min_bytes):       # tail first: (decoders), level 4, level 3, ...
@@ -851,16 +860,16 @@ class TrainEngine:
                     if hi <= lo:
                         continue
                     if tape is not None and H.query("vx_tape_has_marker", tape.handle, int(trig)):
-                        # the tape recorded an event where this level's gradients were complete: reduce the bucket while the lower levels still run
-                        H.call("vx_tape_wait_marker", tape.handle, int(trig), self.comm_stream.cuda_stream)
-                        with torch.cuda.stream(self.comm_stream):
+                        # (opt-in per-level buckets) the tape recorded an event where this level's gradients were complete
+                        H.call("vx_tape_wait_marker", tape.handle, int(trig), cs.cuda_stream)
+                        with torch.cuda.stream(cs):
                             self._allreduce(lo, hi)
                         done = lo
                 if done > 0:
-                    self.comm_stream.wait_stream(cur)
-                    with torch.cuda.stream(self.comm_stream):
-                        self._allreduce(0, done)            # what has no marker (always levels 1-2)
-                cur.wait_stream(self.comm_stream)
+                    cs.wait_stream(cur)
+                    with torch.cuda.stream(cs):
+                        self._allreduce(0, done)            # the encoder's gradients (one bucket by default)
+                cur.wait_stream(cs)
                 self._check_tiling()
             else:
                 if wg_lane is not None:
