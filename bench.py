@@ -339,10 +339,11 @@ def main():
         _pmc_traffic.workload = args.workload
         eng.flat.reattach()
         VF.BRANCH_STREAMS = False          # one stream: HIP-event intervals are then the kernels' own durations, not shared-GPU time
-        eng._fwd_bwd_single()
-        H.profile_begin()
-        eng._fwd_bwd_single()
-        prof = H.profile_end()
+        with eng._settings():                  # (the engine's precision: the eager pass reads the process-wide switches it scopes to its own passes)
+            eng._fwd_bwd_single()
+            H.profile_begin()
+            eng._fwd_bwd_single()
+            prof = H.profile_end()
         VF.BRANCH_STREAMS = True
         rows = sorted(((v[1], v[0], k) for k, v in prof.items()), reverse=True)
         total = sum(r[0] for r in rows)

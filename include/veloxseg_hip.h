@@ -386,6 +386,13 @@ int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y
 int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P, int accumulate,
                           void* stream);
 
+/* ---- patch-expand (Decoder.py:73-76,150-153) with fp32-ACCURATE products on the bf16 matrix pipe: every operand split into ns bf16 pieces (2: 3 products per pair,
+ * ~1e-5 relative; 3: 6 products, the fp32 product), fp32 accumulate, fp32 storage.  Same contracts as vx_expand_fwd_mfma / vx_expand_bwd_data_mfma; wt_ws
+ * holds vx_expand_split_ws_floats(Cc, ns) floats; returns 1 (nothing launched) when the shape is not covered. */
+int vx_expand_split_ws_floats(int Cc, int ns);
+int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream);
+int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns, void* stream);
+
 /* ---- fused per-voxel chains of a PWA transformer block, every modality of the block in one launch (csrc/pwa_fused.hip) ------------------------------
  * "pre": xn = LN_channels(x) (attention_utils.py:29-43, eps as given) followed by NS <= 3 1x1 projections out_s = W_s xn + b_s (PWA.py:291-298: q, k, v).
  * With s2d = 1 the input is gathered 8-way strided from a (B, C/8, 2gd, 2gh, 2gw) tensor first, i.e. PatchMerging (attention_utils.py:127-168): LN(8C) and the

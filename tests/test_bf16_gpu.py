@@ -94,6 +94,8 @@ def test_bf16_training_tracks_fp32_training():
         eng = TrainEngine(model, crit, (1, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=True, overlap=False, precision=mode)
         losses[mode] = [float(eng.step(x, lab)) for _ in range(4)]
         assert eng.use_graph, "tape self-check failed"
+        # the engine's precision / fork / RNG settings are its own: nothing process-wide is left behind by its capture or its steps
+        assert VF.get_precision() == "fp32" and VF.RNG_INPLACE is False, (VF.get_precision(), VF.RNG_INPLACE)
         del eng, model
     for a, r in zip(losses["bf16"], losses["fp32"]):
         assert abs(a - r) <= 1e-2 * abs(r), losses

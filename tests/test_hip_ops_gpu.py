@@ -395,6 +395,7 @@ def test_kernel_variants_agree():
         return res
 
     base = dict(WGRAD_ENTRY="vx_conv3d_bwd_weight_tiled", USE_S1=True, USE_EXPAND_MFMA=True, PW_MFMA_MAX_V=4096, USE_GCONV1=True, USE_WGRAD_WS=True)
+    saved = {k: getattr(F_, k) for k in base}            # (restored below: a flag left changed sends every later test of the session down the python operator bodies)
     ref = run(dict(WGRAD_ENTRY="vx_conv3d_bwd_weight", USE_S1=False, USE_EXPAND_MFMA=False, PW_MFMA_MAX_V=0, USE_GCONV1=False, USE_WGRAD_WS=False))
     try:
         for variant in (base, dict(base, USE_EXPAND_MFMA=False), dict(base, PW_MFMA_MAX_V=0), dict(base, USE_GCONV1=False), dict(base, USE_WGRAD_WS=False)):
@@ -412,7 +413,8 @@ def test_kernel_variants_agree():
                 for i, (a, b_) in enumerate(zip(got, ref)):
                     close(a, b_, 2e-5 * max(1.0, float(b_.abs().max())), 1e-4, f"{knob}={val} tensor {i}")
     finally:
-        run(base)
+        for k, v in saved.items():
+            setattr(F_, k, v)
 
 
 @pytest.mark.parametrize("Cin,Cout,K,sp", [(1, 16, 4, (16, 16, 8)), (2, 8, 2, (8, 12, 16)), (1, 16, 4, (32, 32, 32))])

@@ -136,7 +136,8 @@ def test_eager_stages_are_reproducible_at_full_size_brats128_b4():
     for i in range(6):                       # on the default stream, as a training loop would
         rng.copy_(rng0)
         torch.cuda.synchronize()
-        eng._eager_pass()
+        with eng._settings(capture=True):    # (the engine's switches -- in-place RNG step, per-modality forks -- are scoped to its own passes since round 3)
+            eng._eager_pass()
         torch.cuda.synchronize()
         g = eng.flat.grad.clone()
         ref = g if ref is None else ref

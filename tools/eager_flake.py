@@ -33,9 +33,11 @@ for i in range(n):
     if os.environ.get("VX_ON_SIDE", "0") == "1":
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            eng._eager_pass()
+            with eng._settings(capture=True):          # the engine's own switches (in-place RNG step, forks) for its eager pass
+                eng._eager_pass()
     else:
-        eng._eager_pass()
+        with eng._settings(capture=True):          # the engine's own switches (in-place RNG step, forks) for its eager pass
+            eng._eager_pass()
     torch.cuda.synchronize()
     g = eng.flat.grad.clone()
     if ref is None:

@@ -30,7 +30,8 @@ for mode in ("eager", "tape", "eager2", "tape2", "eager3", "eager4"):
     rng.copy_(rng0)
     torch.cuda.synchronize()
     if mode.startswith("eager"):
-        eng._eager_pass()
+        with eng._settings(capture=True):          # the engine's own switches (in-place RNG step, forks) for its eager pass
+            eng._eager_pass()
     else:
         eng._replay(comm=False)
     torch.cuda.synchronize()

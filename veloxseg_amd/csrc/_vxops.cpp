@@ -15,6 +15,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
 #include <functional>
 #include <type_traits>
 #include <memory>
@@ -29,6 +30,7 @@ namespace {
 struct Flags {
     bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
 
@@ -176,10 +178,14 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     else if (st.s1) {
         int rc = 1;
         if (ps == 4 && K == 3 && Cin == 16 && G == 1 && Cout % 64 == 0 && F.use_expand_mfma) {       // patch-expand layer: MFMA tiles over an LDS halo
-            Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
+            const long wsn = std::max<long>((long)Cout * 16 * 27, F.expand_split ? (long)vx_expand_split_ws_floats(Cout / 64, F.expand_split) : 0);
+            Tensor wt = at::empty({wsn}, x.options());
             if (F.bf16_expand) {
                 rc = vx_expand_fwd_mfma_bf16(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
                 if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma_bf16");
+            } else if (F.expand_split) {
+                rc = vx_expand_fwd_mfma_split(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
+                if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma_split");
             }
             if (rc == 1) rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
@@ -233,11 +239,15 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         if (st.pw && V <= F.pw_mfma_max_v) VX(vx_pw_conv_mfma, fp(dy), nullptr, 0, fp(w), 1, nullptr, mp(dx), mp(dx2), C1, B, Cin, Cout, Cin, V, acc, stream);
         else if (st.pw) VX(vx_pw_conv_bwd_data, fp(dy), fp(w), mp(dx), mp(dx2), C1, B, Cin, Cout, V, acc, stream);
         else if (st.s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
-            Tensor wt = at::empty({(long)Cout * 16 * 27}, x.options());
+            const long wsn = std::max<long>((long)Cout * 16 * 27, F.expand_split ? (long)vx_expand_split_ws_floats(Cout / 64, F.expand_split) : 0);
+            Tensor wt = at::empty({wsn}, x.options());
             int rcb = 1;
             if (F.bf16_expand) {
                 rcb = vx_expand_bwd_data_mfma_bf16(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
                 if (rcb != 0 && rcb != 1) chk(rcb, "vx_expand_bwd_data_mfma_bf16");
+            } else if (F.expand_split) {
+                rcb = vx_expand_bwd_data_mfma_split(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, stream);
+                if (rcb != 0 && rcb != 1) chk(rcb, "vx_expand_bwd_data_mfma_split");
             }
             if (rcb == 1) VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
         } else if (st.s1) VX(vx_conv_s1, fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream);
@@ -1209,6 +1219,8 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("set_conv_mfma", [](bool on) { F.use_conv_mfma = on; });
     m.def("set_bf16_expand", [](bool on) { F.bf16_expand = on; });      // bf16 opt-in mode: bf16 MFMA operands in the patch-expand forward / input gradient
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
+    m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
+    m.def("get_expand_split", []() { return F.expand_split; });
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
     m.def("set_fuse_bwd_add", [](bool on) { F.fuse_bwd_add = on; });   // A/B: residual-gradient sums in the stores of the InstanceNorm / LayerNorm backward kernels

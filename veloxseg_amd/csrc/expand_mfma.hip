@@ -843,3 +843,276 @@ extern "C" int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w
     VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_bf16");
     return 0;
 }
+
+
+// ======================================================================================================================================
+// fp32-ACCURATE patch-expand on the bf16 matrix pipe: every fp32 operand is split into NS bf16 pieces (x = x0 + x1 (+ x2), each piece the bf16 rounding
+// of what the previous ones left) and a product is the sum of the piece products whose weight exceeds the target accuracy:
+//   NS = 2: x0 w0 + x0 w1 + x1 w0                        (3 MFMAs, neglects 2^-18-relative terms: ~1e-5 relative per product)
+//   NS = 3: ... + x0 w2 + x2 w0 + x1 w1                   (6 MFMAs, neglects 2^-27-relative terms: the fp32 product to its last bits; fp32 accumulate)
+// v_mfma_f32_16x16x32_bf16 does 8192 MACs in 16 SIMD clocks against 1024 in 32 for v_mfma_f32_16x16x4_f32: 6 bf16 MFMAs per 32 k-steps = 96 clocks
+// against 256 (2.7 x), 3 = 48 clocks (5.3 x).  Layout, tiling and the operand-order weight image are those of the bf16 opt-in kernels above (K of one
+// MFMA = two taps x 16 channels); the halo is split once when it is staged (forward) or when it is packed (input gradient).
+// These kernels compute in fp32 ACCURACY on fp32 storage: they are the default of the fp32 mode when the unchanged fp32 parity tests pass with them
+// (functional.EXPAND_SPLIT; tests/test_hip_model_gpu.py runs the whole-network oracle comparisons through them).
+// ======================================================================================================================================
+template <int NS>
+__device__ __forceinline__ void vx_split8(const float (&v)[8], uint4 (&out)[NS]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        uint32_t pk[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            const bf2 h = {(__bf16)r[2 * j2], (__bf16)r[2 * j2 + 1]};
+            pk[j2] = __builtin_bit_cast(uint32_t, h);
+            if (s + 1 < NS) { r[2 * j2] -= (float)h[0]; r[2 * j2 + 1] -= (float)h[1]; }
+        }
+        out[s] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+// img[s][((g * 14 + p) * 64 + lane) * 8 + j]: piece s of the weights in the operand order of vx_expand_wimg_bf16_k
+template <int NS>
+__global__ void __launch_bounds__(256) vx_expand_wimg_split_k(const float* __restrict__ w, uint32_t* __restrict__ img, int groups, int backward) {
+    const long n = (long)groups * 14 * 64 * 4;               // packed pairs per piece
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int jp = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long t = e >> 8;
+    const int p = (int)(t % 14), g = (int)(t / 14);
+    const int r = lane & 15, q = lane >> 4;
+    const int tap = 2 * p + (q >> 1);
+    float v[2] = {0.f, 0.f};
+    if (tap < 27)
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * jp + u;
+            int co, ci;
+            if (backward) { co = 16 * g + 4 * (2 * (q & 1) + (j >> 2)) + (j & 3); ci = r; }
+            else { co = 16 * g + r; ci = 8 * (q & 1) + j; }
+            v[u] = w[((long)co * 16 + ci) * 27 + tap];
+        }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 h = {(__bf16)v[0], (__bf16)v[1]};
+        img[(long)s * n + e] = __builtin_bit_cast(uint32_t, h);
+        v[0] -= (float)h[0]; v[1] -= (float)h[1];
+    }
+}
+// the piece products that are kept, smallest first: (activation piece, weight piece)
+template <int NS> struct VxSplitTerms;
+template <> struct VxSplitTerms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int W[3] = {0, 1, 0}; };
+template <> struct VxSplitTerms<3> { static constexpr int N = 6; static constexpr int A[6] = {1, 2, 0, 1, 0, 0}; static constexpr int W[6] = {1, 0, 2, 0, 1, 0}; };
+
+template <int NS>
+__global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) uint4 vx_xs[];          // [NS][channel half][6 x 6 x 18 halo voxel] x 8 bf16
+    using TT = VxSplitTerms<NS>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const float* __restrict__ xb = x + (long)b * 16 * V;
+    for (int e = threadIdx.x; e < 2 * 648; e += 256) {
+        const int hv = e % 648, half = e / 648;
+        const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+        const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+        const float* __restrict__ src = xb + (long)(8 * half) * V + (ok ? ((long)qd * H + qh) * W + qw : 0);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t_ = src[(long)j * V]; v[j] = ok ? t_ : 0.0f; }
+        uint4 pk[NS];
+        vx_split8<NS>(v, pk);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) vx_xs[s * (2 * 648) + e] = pk[s];
+    }
+    __syncthreads();
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    const long wn = (long)Cc * 4 * 14 * 64;                                // uint4 per weight piece
+    for (int g = 0; g < Cc * 4; ++g) {                                     // (c, s1) groups
+        const int c = g >> 2, s1 = g & 3;
+        const int co_base = g * 16;
+        vx_f4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+        const uint4* __restrict__ wg = wimg + (long)g * 14 * 64 + lane;
+#pragma unroll 2
+        for (int p = 0; p < 14; ++p) {
+            const int t = 2 * p + (q >> 1);
+            const int tt = t < 27 ? t : 26;                                // (the empty half pair has zero weights)
+            const int tw = tt % 3, th = (tt / 3) % 3, td = tt / 9;
+            uint4 av[NS], bv[NS][4];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                av[s] = wg[s * wn + p * 64];
+                const uint4* __restrict__ xt = vx_xs + s * (2 * 648) + (q & 1) * 648 + ((wave + td) * 6 + th) * 18 + r + tw;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bv[s][m] = xt[m * 18];
+            }
+#pragma unroll
+            for (int k = 0; k < TT::N; ++k)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[TT::W[k]]), vx_as_bf8(bv[TT::A[k]][m]), acc[m], 0, 0, 0);
+        }
+        const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (w0 + r < W) *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+    }
+}
+
+// 4 floats -> NS pieces of 4 bf16 (8 bytes each)
+template <int NS>
+__device__ __forceinline__ void vx_split4(const float4 v, uint2 (&out)[NS]) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 h0 = {(__bf16)r[0], (__bf16)r[1]}, h1 = {(__bf16)r[2], (__bf16)r[3]};
+        out[s] = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+        if (s + 1 < NS) { r[0] -= (float)h0[0]; r[1] -= (float)h0[1]; r[2] -= (float)h1[0]; r[3] -= (float)h1[1]; }
+    }
+}
+// input gradient: the halo of the fine gradient is split into its NS bf16 pieces ONCE, while it is staged ([piece][(hd, hh, s2) row][18 coarse voxels] x 4 bf16);
+// the A operand of a tap pair is then two 8-byte LDS reads per piece (splitting it again for every tap cost more VALU time than the MFMAs saved)
+template <int NS>
+__global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
+                                                                  int B, int Cc, int D, int H, int W, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) uint2 vx_hs[];          // [NS][144 rows][18]
+    using TT = VxSplitTerms<NS>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;
+    int tile = blockIdx.x;
+    const int tw_i = tile % nTw; tile /= nTw;
+    const int th_i = tile % nTh; tile /= nTh;
+    const int td_i = tile % nTd;
+    const int b = tile / nTd;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const long V = (long)D * H * W;
+    const long FH = 4L * H, FW = 4L * W;
+    const long fplane = (4L * D) * FH * FW;
+    const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
+    const long wn = (long)Cc * 4 * 14 * 64;
+    vx_f4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cc; ++c) {
+        for (int s1 = 0; s1 < 4; ++s1) {
+            __syncthreads();
+            {
+                float4 v[11];
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+                    const int f4 = e % 18, row = e / 18;
+                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 11; ++u) {
+                    const int e = (int)threadIdx.x + u * 256;
+                    if (e < 144 * 18) {
+                        uint2 pc[NS];
+                        vx_split4<NS>(v[u], pc);
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) vx_hs[s * (144 * 18) + e] = pc[s];
+                    }
+                }
+            }
+            __syncthreads();
+            const uint4* __restrict__ wg = wimg + (long)(c * 4 + s1) * 14 * 64 + lane;
+#pragma unroll 2
+            for (int p = 0; p < 14; ++p) {
+                const int t = 2 * p + (q >> 1);
+                const int tt = t < 27 ? t : 26;
+                const int tw = tt % 3, th = (tt / 3) % 3, td = tt / 9;
+                uint4 bv[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) bv[s] = wg[s * wn + p * 64];
+                const int hd = wave - td + 2;
+                const int s2 = 2 * (q & 1);
+                const uint2* __restrict__ ht = vx_hs + ((hd * 6 + (2 - th)) * 4 + s2) * 18 + (r - tw + 2);
+                uint4 av[4][NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const uint2 lo = ht[s * (144 * 18) + m * 4 * 18], hi = ht[s * (144 * 18) + m * 4 * 18 + 18];
+                        av[m][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+#pragma unroll
+                for (int k = 0; k < TT::N; ++k)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[m][TT::A[k]]), vx_as_bf8(bv[TT::W[k]]), acc[m], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const long pbase = ((long)(d0 + wave) * H + (h0 + m)) * W + w0 + 4 * q;
+        float* dst = dx + ((long)b * 16 + r) * V + pbase;
+        if (w0 + 4 * q >= W) continue;
+        float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        if (accumulate) { const float4 old = *reinterpret_cast<float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst) = o;
+    }
+}
+
+// floats of wt_ws for NS pieces: NS operand-order bf16 images of (Cc * 4) groups x 14 tap pairs x 64 lanes x 16 bytes
+extern "C" int vx_expand_split_ws_floats(int Cc, int ns) { return (Cc <= 0 || ns < 2 || ns > 3) ? -1 : Cc * 4 * 14 * 64 * 4 * ns; }
+
+// returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernels), 0 on success.  ns = 2 (3 products) or 3 (6 products: fp32-exact products)
+extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream) {
+    VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_fwd_mfma_split: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = Cc * 4;
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
+    const size_t shm = (size_t)ns * 2 * 648 * sizeof(uint4);
+    if (ns == 2) {
+        vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
+        vx_expand_fwd_split_k<2><<<dim3((unsigned)nblk), 256, shm, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
+    } else {
+        vx_expand_wimg_split_k<3><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
+        vx_expand_fwd_split_k<3><<<dim3((unsigned)nblk), 256, shm, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
+    }
+    VX_LAUNCH_CHECK("vx_expand_fwd_mfma_split");
+    return 0;
+}
+extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
+                                             void* stream) {
+    VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_bwd_data_mfma_split: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = Cc * 4;
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
+    const size_t shm = (size_t)ns * 144 * 18 * sizeof(uint2);
+    if (ns == 2) {
+        vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
+        vx_expand_bwd_data_split_k<2><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    } else {
+        vx_expand_wimg_split_k<3><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
+        vx_expand_bwd_data_split_k<3><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    }
+    VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_split");
+    return 0;
+}

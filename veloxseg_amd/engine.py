@@ -175,18 +175,22 @@ class TapedPredictor:
         dev = x.device
         xs = torch.empty(x.shape, dtype=x.dtype, device=dev)
         xs.copy_(x)
-        VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            ref = None
-            for _ in range(2):                      # lazy initialisation and allocator warm-up outside the capture
-                ref = self._first(self.model(xs)).float().clone()
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            out = self._first(self.model(xs))
+        prev_ms = VF.MODALITY_STREAMS
+        VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # (for the capture only: the setting is baked into the tape, the process-wide value is restored)
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                ref = None
+                for _ in range(2):                      # lazy initialisation and allocator warm-up outside the capture
+                    ref = self._first(self.model(xs)).float().clone()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._first(self.model(xs))
+        finally:
+            VF.MODALITY_STREAMS = prev_ms
         tape = LaunchTape(g, self.max_lanes)
         if self.check:
             tape.replay()
@@ -251,7 +255,11 @@ class TrainEngine:
         # (5.5 MB over xGMI) they can hide
         self.level_buckets = bool(level_buckets) or os.environ.get("VELOXSEG_LEVEL_BUCKETS") == "1"
         self._two_buckets = bool(use_graph) and replay == "tape" and not self.level_buckets
-        VF.set_precision(precision)            # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision); process-wide
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        # "bf16": bf16 MFMA operands in the patch-expand layers (functional.set_precision).  A property of THIS engine: the process-wide switches it needs
+        # (precision, per-modality forks, in-place RNG step) are set for the duration of its own eager passes / captures only (`_settings`) -- a tape has them
+        # baked in -- so two engines with different settings in one process do not interfere
         self.precision = precision
         self.bucket_min_bytes = int(bucket_min_bytes)      # all-reduce buckets below this size are merged into the next one (latency-bound collectives)
         if hasattr(model, "ds_fused"):
@@ -291,6 +299,21 @@ class TrainEngine:
         self.verify_replays = verify_replays
         if self.world > 1:
             dist.broadcast(self.flat.param, src=0, group=self.pg)      # identical replicas at start
+
+    @contextlib.contextmanager
+    def _settings(self, capture: bool = False):
+        """this engine's values of the process-wide switches of veloxseg_amd.functional, for the duration of one of its eager passes or captures"""
+        prev = (VF.get_precision(), VF.MODALITY_STREAMS, VF.RNG_INPLACE)
+        VF.set_precision(self.precision)
+        if capture:
+            if self.replay_mode == "tape":
+                VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # forks cost the tape nothing on the host: every per-modality piece gets its own branch
+            VF.RNG_INPLACE = True       # replays must bump the tensor the captured kernels point at
+        try:
+            yield
+        finally:
+            VF.set_precision(prev[0])
+            VF.MODALITY_STREAMS, VF.RNG_INPLACE = prev[1], prev[2]
 
     # ---- pieces ---------------------------------------------------------------------------------
     def _forward_loss(self):
@@ -732,9 +755,6 @@ class TrainEngine:
         to the next capture, which is only safe when the graphs replay in capture order, not concurrently); tensors that cross
         stages stay referenced by the engine for the lifetime of the graphs."""
         self.model.train()
-        if self.replay_mode == "tape":
-            VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # forks cost the tape nothing on the host: every per-modality piece gets its own branch
-        VF.RNG_INPLACE = True       # replays must bump the tensor the captured kernels point at
         rng = VF.rng_state(self.dev)
         rng0 = rng.clone()
         self.flat.reattach()
@@ -889,15 +909,17 @@ class TrainEngine:
             self.model.train()
         if self.use_graph and self.graphs is None:
             try:
-                self._capture()                                # may clear use_graph (self-check)
+                with self._settings(capture=True):
+                    self._capture()                            # may clear use_graph (self-check)
             except Exception as e:                             # a capture that cannot be taken (or read back) must not take the training run down
                 warnings.warn(f"TrainEngine: capturing the step failed ({type(e).__name__}: {str(e)[:300]}); falling back to eager launches")
                 self.graphs, self.use_graph = None, False
-                VF.RNG_INPLACE = False
                 torch.cuda.synchronize()
         if self.use_graph:
-            self._replay(comm=True)
-        else:
+            self._replay(comm=True)                            # (everything the tapes need is baked in: no process-wide state is read)
+            self._adamw()
+            return self.loss
+        with self._settings():
             cur = torch.cuda.current_stream(self.dev)
             self.flat.reattach()
             split, n = self.flat.split, self.flat.numel

@@ -20,6 +20,9 @@ from . import _hip as H
 
 WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled reference kernel (kept for A/B tests)
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
+# fp32 mode of the patch-expand layers (forward + input gradient, 49 % of the training FLOPs): 3 = every fp32 operand as three bf16 pieces, six bf16 MFMAs per
+# pair (the fp32 product to 2^-27; 2.7 x fewer matrix-pipe clocks than v_mfma_f32_16x16x4_f32), 2 = two pieces / three MFMAs (~1e-5 relative), 0 = fp32 MFMA
+EXPAND_SPLIT = int(os.environ.get("VELOXSEG_EXPAND_SPLIT", "3"))
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 USE_IN_ROW = True                             # InstanceNorm of short rows (V <= 4096): statistics + application in one launch
 IN_ROW_MAX = 4096
@@ -216,6 +219,7 @@ def cpp_module(reload: bool = False):
                 from . import _vxops
                 _vxops.set_fuse_gelu(os.environ.get("VELOXSEG_FUSE_GELU", "1") != "0")
                 _vxops.set_down_mfma(USE_DOWN_MFMA)
+                _vxops.set_expand_split(EXPAND_SPLIT)
                 _vxops.set_fuse_pw_bwd(os.environ.get("VELOXSEG_FUSE_PW_BWD", "1") != "0")
                 _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
                 _CPP[1] = _vxops
