@@ -83,6 +83,12 @@ int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float*
 /* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
  * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
 int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);
+/* the same weight gradient with every product formed from ns bf16 pieces per fp32 operand (ns = 3: fp32-exact products, fp32 accumulation); x is read in
+   its own (B, 16, D, H, W) layout.  part_ws: vx_expand_wgrad_split_ws_floats(...) floats of partial sums, added into dw in a fixed order (reproducible).
+   Returns 1 when W % 4 != 0 (use vx_expand_wgrad_mfma). */
+int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int W);
+int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
+                               int ns, void* stream);
 /* bf16 opt-in mode (BASELINE configs[1]: the BraTS bf16 line): the same two layers with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16), fp32
  * accumulation and fp32 tensors in HBM; weights and activations are rounded to bf16 (nearest-even) on their way into the MFMA.  Same arguments and
  * workspaces as the fp32 entries above; return 1 = shape not covered (D, H % 4, W % 16), the caller then uses the fp32 entry. */

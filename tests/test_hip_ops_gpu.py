@@ -86,6 +86,8 @@ CONV_CASES = [
     ("expand_ps4", 1, 16, (4, 5, 6), 128, 3, 1, 1, 1, 4),
     ("expand_ps2", 2, 16, (4, 4, 4), 16, 3, 1, 1, 1, 2),
     ("expand_ps4_w24", 1, 16, (4, 8, 24), 128, 3, 1, 1, 1, 4),      # 24-wide rows (shipped 96^3 patches): LDS-tiled MFMA kernels with a partly idle last tile
+    ("expand_ps4_w40", 2, 16, (3, 5, 40), 64, 3, 1, 1, 1, 4),       # two 32-wide chunks per row (the second one partly empty) in the split weight-gradient kernel
+    ("expand_ps4_w32", 2, 16, (5, 9, 32), 128, 3, 1, 1, 1, 4),      # the headline row width; strips of 8 + 1 rows
 ]
 
 
@@ -105,6 +107,34 @@ def test_conv3d(case):
         return O.pixel_shuffle3d(y, ps) if ps > 1 else y
 
     run_pair(g, c, [x], [w, b], what=name)
+
+
+@pytest.mark.parametrize("ns", [2, 3])
+@pytest.mark.parametrize("B,Cc,sp", [(2, 2, (4, 20, 32)), (1, 1, (3, 4, 24)), (2, 1, (2, 9, 72)), (1, 3, (1, 1, 4))], ids=["w32_strips", "w24", "w72_3chunks", "tiny"])
+def test_expand_wgrad_split_direct(B, Cc, sp, ns):
+    """C-ABI vx_expand_wgrad_mfma_split (products from ns bf16 pieces per fp32 operand, partial-sum rows folded in a fixed order) against an fp64
+    reference: ns = 3 to fp32 round-off of the sums, ns = 2 to ~1e-5 relative; accumulates INTO dw / db; two runs give identical bits."""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    D_, H_, W_ = sp
+    x = rnd(B, 16, *sp).to(d)
+    dy = rnd(B, Cc, 4 * D_, 4 * H_, 4 * W_, seed=5).to(d)
+    dyc = dy.view(B, Cc, D_, 4, H_, 4, W_, 4).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, 64 * Cc, D_, H_, W_)
+    wref = torch.nn.grad.conv3d_weight(x.double(), (64 * Cc, 16, 3, 3, 3), dyc.double(), padding=1)
+    bref = dyc.double().sum((0, 2, 3, 4))
+    nws = H.query("vx_expand_wgrad_split_ws_floats", B, Cc, D_, H_, W_)
+    ws = torch.full((nws,), float("nan"), device=d)                      # (every row that is folded must have been written)
+    outs = []
+    for _ in range(2):
+        dw = torch.ones(64 * Cc, 16, 3, 3, 3, device=d)
+        db = torch.full((64 * Cc,), 2.0, device=d)
+        H.call("vx_expand_wgrad_mfma_split", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, B, Cc, D_, H_, W_, ns, H.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((dw.clone(), db.clone()))
+    tol = 3e-6 if ns == 3 else 4e-5
+    close(outs[0][0] - 1.0, wref.float(), tol * float(wref.abs().max()), tol, f"dW ns={ns}")
+    close(outs[0][1] - 2.0, bref.float(), 3e-6 * float(bref.abs().max()) + 1e-5, 1e-5, "db")
+    assert torch.equal(outs[0][0], outs[1][0]), "the folded weight gradient is not reproducible"
 
 
 def test_conv3d_concat_nobias():

@@ -53,3 +53,23 @@ for (B, Cc, S) in [(4, 2, 32), (4, 1, 32), (4, 2, 24)]:
         rows.append(f"  {name:16s} fwd {tf:7.1f} us ({gf / tf * 1e3:6.1f} TFLOP/s)  max err / max |y| {ef:.2e}   dX {tb:7.1f} us ({gf / tb * 1e3:6.1f} TFLOP/s)  err {eb:.2e}")
     print(f"B={B} Cc={Cc} grid {S}^3:")
     print("\n".join(rows), flush=True)
+    # ---- weight gradient: dW / db against an fp64 reference (all samples, computed on the GPU in double) ----
+    dyc = dy.view(B, Cc, S, 4, S, 4, S, 4).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, 64 * Cc, S, S, S)           # coarse view (co = (c, s1, s2, s3))
+    wref = torch.nn.grad.conv3d_weight(x.double(), w.shape, dyc.double(), padding=1).cpu()
+    bref = dyc.double().sum((0, 2, 3, 4)).cpu()
+    xcl = torch.empty(B * S ** 3 * 16, device=d)
+    nws = H.query("vx_expand_wgrad_split_ws_floats", B, Cc, S, S, S)
+    pws = torch.empty(nws, device=d)
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    rows = []
+    for name, fn in [("fp32 MFMA", lambda: H.call("vx_expand_wgrad_mfma", H.P(x), H.P(xcl), H.P(dy), H.P(dw), H.P(db), B, Cc, S, S, S, st)),
+                     ("split 3 pieces", lambda: H.call("vx_expand_wgrad_mfma_split", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(pws), nws, B, Cc, S, S, S, 3, st)),
+                     ("split 2 pieces", lambda: H.call("vx_expand_wgrad_mfma_split", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(pws), nws, B, Cc, S, S, S, 2, st))]:
+        t = timeit(fn)
+        dw.zero_(); db.zero_()
+        fn(); torch.cuda.synchronize()
+        ew = float((dw.double().cpu() - wref).abs().max()) / float(wref.abs().max())
+        eb = float((db.double().cpu() - bref).abs().max()) / float(bref.abs().max())
+        gf = 2.0 * B * S ** 3 * 64 * Cc * 16 * 27 / 1e9
+        rows.append(f"  {name:16s} dW {t:7.1f} us ({gf / t * 1e3:6.1f} TFLOP/s)  max err / max |dW| {ew:.2e}   db err {eb:.2e}")
+    print("\n".join(rows), flush=True)

@@ -107,7 +107,32 @@ for tag, tapes, fn in stages:
     if verbose:
         for nm, u, g in worst["path"]:
             print(f"      {u:7.1f} us  g{g:<6d} {nm}")
-print(f"step: measured {step_meas:.0f} us, sum of stage critical paths {step_cp:.0f} us")
+print(f"stages one after the other: measured {step_meas:.0f} us, sum of stage critical paths {step_cp:.0f} us")
+if "dec_wg" in G:
+    # the decoders' weight gradients run on the fourth lane BESIDE the encoder backward: that phase is as long as the two together need
+    res = [analyse(f"dec_wg[{k}]", t) for k, t in enumerate(G["dec_wg"])]
+    def wg_only():
+        for t in G["dec_wg"]:
+            t.replay()
+    m_wg = measure(wg_only)
+    def both():
+        lane = eng._lane_streams(4)[3]
+        cur = torch.cuda.current_stream()
+        eng._hop(40, cur, lane)
+        with torch.cuda.stream(lane):
+            wg_only()
+        G["enc_bwd"].replay()
+        eng._hop(41, lane, cur)
+    m_both = measure(both)
+    print(f"dec_wg  : measured {m_wg:7.1f} us alone | kernel-time sum {sum(r['total'] for r in res):7.1f} us over {sum(r['n'] for r in res)} nodes | dec_wg || enc_bwd together: {m_both:7.1f} us")
+    wgk = collections.Counter()
+    for r in res:
+        for nm, u, g in r["all"]:
+            wgk[nm] += u
+    for nm, u in wgk.most_common(14):
+        print(f"      {u:7.1f} us  {nm}")
+m_step = measure(lambda: eng.step(x, lab))
+print(f"step: measured {m_step:.0f} us (input copies + tapes + AdamW)")
 print("kernels on the critical paths (time on path / time in the whole step):")
 for nm, u in on_path.most_common(40):
     print(f"  {u:7.1f} us {cnt_path[nm]:3d}x / {everything[nm]:7.1f} us  {nm}")

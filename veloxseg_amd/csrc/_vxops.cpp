@@ -30,6 +30,7 @@ namespace {
 struct Flags {
     bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -267,9 +268,19 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
             else if (F.use_gconv1 && K == 1 && S == 1 && P == 0 && G > 1 && ps == 1 && !x2.defined() && Cin == Cout && (Cin / G == 4 || Cin / G == 8 || Cin / G == 16) && V % 4 == 0)
                 VX(vx_gconv1_bwd_weight, fp(x), fp(dy), dw, db, B, Cin, G, V, s);
             else if (s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
-                auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
-                WG.done.push_back([xcl](void*) {});          // keeps the temporary alive as long as the launches of this pass
-                VX(vx_expand_wgrad_mfma, fp(x), mp(*xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, s);
+                int rcw = 1;
+                if (F.expand_split >= 2 && F.expand_wgrad_split) {        // fp32-exact products on the bf16 pipe (expand_mfma.hip vx_expand_wgrad_split_k)
+                    const long nws = vx_expand_wgrad_split_ws_floats(B, Cout / 64, D, H, W);
+                    auto pws = std::make_shared<Tensor>(at::empty({nws}, x.options()));
+                    WG.done.push_back([pws](void*) {});
+                    rcw = vx_expand_wgrad_mfma_split(fp(x), fp(dy), dw, db, mp(*pws), nws, B, Cout / 64, D, H, W, F.expand_split, s);
+                    if (rcw != 0 && rcw != 1) chk(rcw, "vx_expand_wgrad_mfma_split");
+                }
+                if (rcw == 1) {
+                    auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
+                    WG.done.push_back([xcl](void*) {});          // keeps the temporary alive as long as the launches of this pass
+                    VX(vx_expand_wgrad_mfma, fp(x), mp(*xcl), fp(dy), dw, db, B, Cout / 64, D, H, W, s);
+                }
             } else if (K == 7 && S == 4 && P == 3 && G == 1 && ps == 1 && !x2.defined() && F.use_down_mfma && vx_down_wgrad_ws_floats(B, Cin, D, H, W, Cout) > 0) {
                 const int nws = vx_down_wgrad_ws_floats(B, Cin, D, H, W, Cout);          // stem DownConv: MFMA tiles + partial-sum slices
                 auto ws = std::make_shared<Tensor>(at::empty({(long)nws}, x.options()));
@@ -1221,6 +1232,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
     m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
+    m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });
     m.def("set_fuse_bwd_add", [](bool on) { F.fuse_bwd_add = on; });   // A/B: residual-gradient sums in the stores of the InstanceNorm / LayerNorm backward kernels

@@ -1116,3 +1116,221 @@ extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* 
     VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_split");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix pipe with fp32-exact products (the split of the kernels above):
+//   dW[co, ci, t] += sum_{b,p} dyf[co, p] * x[ci, p + t - 1]      (+ db[co] += sum dyf[co, p])
+//   one MFMA = a whole coarse row: rows = the 16 output channels (s2, s3) of one (c, s1) group, cols = 16 input channels, K = 32 coarse voxels along W.
+//   block = (channel block c, tap plane td) x a strip of coarse rows (b, d, h0 .. h0+HL-1, 32-wide W chunk); wave = s1: 9 accumulator tiles per wave,
+//   three blocks per CU (the staging of one hides behind the MFMAs of the others).
+//   B operand (x): the rows h-1 .. h+1 of plane d+td-1 live in LDS as bf16 pieces, [piece][row slot (4, ring)][ci][32 voxels], split ONCE when a row is
+//                  staged and read UNSHIFTED (one aligned 16-byte read per piece and row).
+//   A operand (fine gradient): lane (r = (s2, s3), q) owns fine[c][4d+s1][4h+s2][4(8q+j)+s3], j = -1..8 (10 dword loads per row, prefetched one row ahead);
+//                  the +-1 shift along W of a tap is applied HERE, once per row: dW[tw] = sum_w' dy[w' - tw + 1] x[w'], the three shifted operand vectors of a
+//                  piece are 5 funnel shifts (v_alignbit) of its packed pairs.  (Shifting x instead cost 72 funnel shifts per row and wave -- every
+//                  (row, piece) read three ways -- and left the kernel VALU-bound at twice the MFMA time.)
+//   Flush: a block's tiles go through LDS into ITS row of a partial-sum workspace (plain stores); vx_expand_wgrad_fold_k adds the rows into dW in a fixed
+//   order, so the weight gradient is reproducible run to run.  (History: a wave that owned all 27 taps flushed 55 K sums per CU -- 14 M float atomics,
+//   38 of 107 us; atomics in runs of 9 floats into the (co, ci, 27) layout were 8 x slower per element than full-line ones: hence the workspace rows.)
+// ------------------------------------------------------------------------------------------------------------------
+#define VX_WS_PITCH 20                 // dwords per (piece, slot, ci) row image: 32 bf16 + 8 bytes (bank spread)
+template <int NS>
+__global__ void __launch_bounds__(256, 3) vx_expand_wgrad_split_k(const float* __restrict__ x, const float* __restrict__ dyf, float* __restrict__ part, float* __restrict__ db,
+                                                                   int B, int Cc, int D, int H, int W, int HL, int nHs, int nWc, int nUnits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t vx_wx[];       // [NS][4][16][VX_WS_PITCH], then the flush image [4][16][16][9]
+    using TT = VxSplitTerms<NS>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, q = lane >> 4;
+    // block id -> (unit = (strip, c), plane): the three planes of a unit are neighbours in dispatch order on the same XCD (ids 8 apart), so the fine
+    // gradient rows they share are in that XCD's L2 for the second and third reader
+    const int xcd = blockIdx.x & 7, m_ = blockIdx.x >> 3;
+    const int pd = m_ % 3, unit = (m_ / 3) * 8 + xcd;
+    if (unit >= nUnits) return;
+    const int c = unit % Cc;
+    int strip = unit / Cc;
+    const int strip_id = strip;
+    const int wc = strip % nWc; strip /= nWc;
+    const int hs = strip % nHs; strip /= nHs;
+    const int d = strip % D;
+    const int b = strip / D;
+    const int dq = d - 1 + pd;
+    if ((unsigned)dq >= (unsigned)D) return;                              // this plane is the zero padding: nothing to add (the fold kernel skips the row)
+    const int h_lo = hs * HL, h_hi = (h_lo + HL < H) ? h_lo + HL : H, wc0 = wc * 32;
+    const long V = (long)D * H * W;
+    const float* __restrict__ xb = x + (long)b * 16 * V + (long)dq * H * W;
+    // ---- staging of one coarse row (16 channels x 32 voxels): threads 0..127, one float4 each ----
+    float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int st_ci = (threadIdx.x >> 3) & 15, st_seg = threadIdx.x & 7;
+    auto fetch = [&](int hq) {
+        if (threadIdx.x < 128) {
+            const int w = wc0 + 4 * st_seg;
+            pf = ((unsigned)hq < (unsigned)H && w < W) ? *reinterpret_cast<const float4*>(xb + (long)st_ci * V + (long)hq * W + w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int hq) {
+        if (threadIdx.x < 128) {
+            const int slot = hq & 3;
+            uint2 pk[NS];
+            vx_split4<NS>(pf, pk);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(vx_wx + (((s * 4 + slot) * 16 + st_ci) * VX_WS_PITCH + 2 * st_seg)) = pk[s];
+        }
+    };
+    // ---- the fine gradient of this wave's group: lane (r, q), voxels 8q-1 .. 8q+8 ----
+    const int s1 = wave, s2 = r >> 2, s3 = r & 3;
+    const long FH = 4L * H, FW = 4L * W;
+    const float* __restrict__ dyb = dyf + (((long)b * Cc + c) * (4L * D) + 4 * d + s1) * FH * FW + (long)s2 * FW + 4L * (wc0 + 8 * q) + s3;
+    float dv[10];
+    auto fetch_dy = [&](int h) {
+        const float* __restrict__ p = dyb + 4L * h * FW;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int w = wc0 + 8 * q + j - 1;
+            dv[j] = (h < h_hi && (unsigned)w < (unsigned)W) ? p[4 * (j - 1)] : 0.0f;
+        }
+    };
+    vx_f4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    for (int hq = h_lo - 1; hq <= h_lo + 1; ++hq) { fetch(hq); stash(hq); }      // prologue: rows h_lo-1, h_lo, h_lo+1
+    fetch_dy(h_lo);
+    __syncthreads();
+    for (int h = h_lo; h < h_hi; ++h) {
+        // pieces of the 10 values, packed in pairs (0,1) .. (6,7) of the 8 own voxels; the neighbours go to the half a funnel shift takes them from
+        uint4 a[NS][3];
+        {
+            float rr[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) rr[j] = dv[j];
+#pragma unroll
+            for (int j = 1; j < 9; ++j) bsum += dv[j];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                uint32_t p[4];
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const bf2 hh = {(__bf16)rr[1 + 2 * j2], (__bf16)rr[2 + 2 * j2]};
+                    p[j2] = __builtin_bit_cast(uint32_t, hh);
+                    if (s + 1 < NS) { rr[1 + 2 * j2] -= (float)hh[0]; rr[2 + 2 * j2] -= (float)hh[1]; }
+                }
+                const bf2 he = {(__bf16)rr[9], (__bf16)rr[0]};                // low half: voxel 8q+8, high half: voxel 8q-1
+                if (s + 1 < NS) { rr[9] -= (float)he[0]; rr[0] -= (float)he[1]; }
+                const uint32_t ends = __builtin_bit_cast(uint32_t, he);
+                const uint32_t s01 = __builtin_amdgcn_alignbit(p[1], p[0], 16), s12 = __builtin_amdgcn_alignbit(p[2], p[1], 16), s23 = __builtin_amdgcn_alignbit(p[3], p[2], 16);
+                a[s][1] = make_uint4(p[0], p[1], p[2], p[3]);
+                a[s][2] = make_uint4(__builtin_amdgcn_alignbit(p[0], ends, 16), s01, s12, s23);          // element j = dy[j - 1]
+                a[s][0] = make_uint4(s01, s12, s23, __builtin_amdgcn_alignbit(ends, p[3], 16));          // element j = dy[j + 1]
+            }
+        }
+        const bool more = h + 1 < h_hi;
+        if (more) { fetch(h + 2); fetch_dy(h + 1); }
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int slot = (h - 1 + ph) & 3;
+            uint4 bv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) bv[s] = *reinterpret_cast<const uint4*>(vx_wx + (((s * 4 + slot) * 16 + r) * VX_WS_PITCH + 4 * q));
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+                for (int k = 0; k < TT::N; ++k)
+                    acc[ph * 3 + tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(a[TT::W[k]][tw]), vx_as_bf8(bv[TT::A[k]]), acc[ph * 3 + tw], 0, 0, 0);
+        }
+        if (more) stash(h + 2);
+        __syncthreads();
+    }
+    // ---- flush: red[wave][co][ci][9] through LDS, then one contiguous 36 KB row of the workspace ----
+    float* __restrict__ red = reinterpret_cast<float*>(vx_wx);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wave * 2304 + ((4 * q + reg) * 16 + r) * 9 + t] = acc[t][reg];
+    __syncthreads();
+    float4* __restrict__ prow = reinterpret_cast<float4*>(part + (((long)strip_id * Cc + c) * 3 + pd) * 9216);
+    for (int e = threadIdx.x; e < 2304; e += 256) prow[e] = reinterpret_cast<const float4*>(red)[e];
+    if (db != nullptr && pd == 1) {                                       // (the centre plane exists for every d: one block per strip adds the bias sums)
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0) atomicAdd(db + (c * 4 + s1) * 16 + r, bsum);
+    }
+}
+// dw[(c, wave) group][co][ci][9 pd + t] += sum over the strips whose plane d + pd - 1 exists of part[strip][c][pd][wave][co][ci][t]
+// block = 16 float4 outputs x 16 parts of the strip list (summed through LDS in a fixed order)
+__global__ void __launch_bounds__(256) vx_expand_wgrad_fold_k(const float* __restrict__ part, float* __restrict__ dw, int Cc, int D, int nStrips, int perD) {
+    __shared__ float4 sm[16][16];
+    const int i = threadIdx.x & 15, k = threadIdx.x >> 4;
+    const int o4 = blockIdx.x * 16 + i;                                   // float4 index into (c, pd, 9216 / 4)
+    const int total4 = Cc * 3 * 2304;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0, pd = 0, e4 = 0;
+    if (o4 < total4) {
+        e4 = o4 % 2304;
+        pd = (o4 / 2304) % 3;
+        c = o4 / (3 * 2304);
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part) + ((long)c * 3 + pd) * 2304 + e4;
+        const long stride4 = (long)Cc * 3 * 2304;
+#pragma unroll 4
+        for (int st = k; st < nStrips; st += 16) {
+            const int d = (st / perD) % D;
+            if ((unsigned)(d - 1 + pd) < (unsigned)D) {
+                const float4 v = p4[(long)st * stride4];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+    }
+    sm[k][i] = s;
+    __syncthreads();
+    if (k == 0 && o4 < total4) {
+        float4 v = sm[0][i];
+#pragma unroll
+        for (int kk = 1; kk < 16; ++kk) { const float4 u = sm[kk][i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = 4 * e4 + u;
+            const int wv = e / 2304, rem = e - wv * 2304, cc = rem / 9, t = rem - cc * 9;
+            dw[((long)c * 4 + wv) * 6912 + cc * 27 + 9 * pd + t] += vv[u];
+        }
+    }
+}
+
+static void vx_wgs_plan(int B, int Cc, int D, int H, int W, int& HL, int& nHs, int& nWc) {
+    nWc = (W + 31) / 32;
+    const long base = (long)B * D * nWc * Cc * 3;
+    int want = (int)((768 + base - 1) / base);               // strips per (b, d, chunk, c, plane): three blocks per CU
+    if (want < 1) want = 1;
+    HL = (H + want - 1) / want;
+    if (HL < 8) HL = H < 8 ? H : 8;
+    nHs = (H + HL - 1) / HL;
+}
+// floats of the partial-sum workspace of vx_expand_wgrad_mfma_split
+extern "C" int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int W) {
+    if (B <= 0 || Cc <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+    int HL, nHs, nWc;
+    vx_wgs_plan(B, Cc, D, H, W, HL, nHs, nWc);
+    const long n = (long)B * D * nHs * nWc * Cc * 3 * 9216;
+    return n > 0x7fffffffL ? -1 : (int)n;
+}
+// returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernel), 0 on success.  part_ws: vx_expand_wgrad_split_ws_floats floats
+extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
+                                          int ns, void* stream) {
+    VX_REQUIRE(x && dy_fine && dw && part_ws && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_wgrad_mfma_split: bad args");
+    if (W % 4 != 0) return 1;
+    int HL, nHs, nWc;
+    vx_wgs_plan(B, Cc, D, H, W, HL, nHs, nWc);
+    const long nStrips = (long)B * D * nHs * nWc;
+    VX_REQUIRE(ws_floats >= nStrips * Cc * 3 * 9216, "vx_expand_wgrad_mfma_split: workspace too small");
+    const size_t shm = (size_t)ns * 4 * 16 * VX_WS_PITCH * sizeof(uint32_t);
+    const size_t need = 4 * 2304 * sizeof(float);
+    const size_t lds = shm > need ? shm : need;
+    const int nUnits = (int)(nStrips * Cc);
+    dim3 grid((unsigned)(((nUnits + 7) / 8) * 8 * 3));
+    if (ns == 2) vx_expand_wgrad_split_k<2><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    else vx_expand_wgrad_split_k<3><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    vx_expand_wgrad_fold_k<<<vx_cdiv((long)Cc * 3 * 2304, 16), 256, 0, (hipStream_t)stream>>>(part_ws, dw, Cc, D, (int)nStrips, nHs * nWc);
+    VX_LAUNCH_CHECK("vx_expand_wgrad_mfma_split");
+    return 0;
+}
