@@ -421,6 +421,18 @@ int vx_pwa_post_ok(int C, int Cv, int R, long V);
 int vx_pwa_post_tiles(int B, long V);
 int vx_pwa_post_fwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
 int vx_pwa_post_bwd(const void* const* ptrs, int M, int B, int C, int Cv, int R, long V, float eps, float alpha, const void* seed_ptr, float p_mix, float p_ffn, void* stream);
+
+/* Channel stage of the JLC block at C = 64 / 128 (reference conv_blocks.py:60-66,74): out = o + Drop(W2 GELU(W1 IN(o) + b1) + b2), IN statistics folded
+   from the producer's partial sums `part` ([B*C][nparts][2] doubles; NULL = read `stats` (B*C, 2) mean / rstd).  Same contract as vx_mlp_fwd / vx_mlp_bwd
+   with norm = 0; the backward leaves the weight-gradient operands in scratch (dW2 = dz h^T, dW1 = da nhat^T: vx_pw_wgrad_group) and writes
+   vx_inmlp_tiles(V) partial-sum rows (sum dn, sum dn nhat) per (b, c). */
+int vx_inmlp_ok(int C, int R, long V);
+int vx_inmlp_tiles(long V);
+int vx_inmlp_fwd(const float* o, const double* part, int nparts, float* stats, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                 int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site, float p_drop, void* stream);
+int vx_inmlp_bwd(const float* o, const float* stats, const float* w1, const float* b1, const float* w2, const float* dout, float* dn, float* part_dn,
+                 float* sc_n, float* sc_h, float* sc_da, float* sc_dz, int B, int C, int R, long V, const void* seed_ptr, unsigned long long site, float p_drop,
+                 void* stream);
 /* up to 24 weight gradients of 1x1 convs (dW += dy x^T, db += sum dy) and up to 16 folds of partial rows in one launch.
  * jobs: ptrs 4 per job (x (B,Cin,V), dy (B,Cout,V), dw, db or NULL), dims 4 per job (Cin, Cout, V, B); folds: fptrs 3 per fold (part (rows, 2C), dgamma, dbeta),
  * fdims 2 per fold (C, rows) */

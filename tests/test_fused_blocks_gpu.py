@@ -44,6 +44,11 @@ JLC_CASES = [
     ("L1_aniso", 1, 16, 4, 3, (8, 12, 20)),
     ("L2_small", 2, 32, 4, 3, (8, 8, 8)),
     ("w16", 1, 32, 2, 3, (8, 8, 16)),
+    # the coarse levels (channel stage on the tile-GEMM kernels of csrc/pwa_fused.hip: vx_inmlp_*)
+    ("L3_w8_8cube", 4, 64, 8, 2, (8, 8, 8)),
+    ("L4_w16_4cube", 4, 128, 8, 2, (4, 4, 4)),
+    ("L3_96_6cube", 2, 64, 8, 2, (6, 6, 6)),
+    ("L3_aniso", 1, 64, 8, 2, (8, 8, 4)),
 ]
 
 
@@ -75,7 +80,10 @@ def test_fused_jlc_block_vs_oracle(case):
         _close(p.grad, g_ref, 2e-3 * float(g_ref.abs().max()) + 1e-6, 2e-3, f"jlc d{k}")
 
 
-@pytest.mark.parametrize("case", JLC_CASES[:3], ids=[c[0] for c in JLC_CASES[:3]])
+_DROP_CASES = JLC_CASES[:3] + JLC_CASES[5:7]
+
+
+@pytest.mark.parametrize("case", _DROP_CASES, ids=[c[0] for c in _DROP_CASES])
 def test_fused_jlc_block_equals_per_operator_kernels_with_dropout(case):
     from veloxseg_amd import functional as VF
     _, B, C, G, r, sp = case

@@ -30,6 +30,7 @@ namespace {
 struct Flags {
     bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
     double in_eps = 1e-5, ln_eps = 1e-6;
@@ -506,6 +507,7 @@ struct JLCFusedState {
     Tensor x, y, o, stats_y, stats_o;            // y: (3, B, C, D, H, W) = the three conv outputs
     Tensor w1, w3, w5, b1, b3, b5, l1w, l1b, l2w, l2b;
     int B = 0, C = 0, G = 0, D = 0, H = 0, W = 0, R = 0, nch = 0;
+    bool tile = false;                           // channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*: C = 64 / 128) instead of mlp.hip
     double p = 0; int64_t site = 0; const void* rs = nullptr;
 };
 struct JLCState {
@@ -777,25 +779,29 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
 // ConvTranspose3d(k=2, s=2) (conv_blocks.py:29-35), PatchMerging's space-to-depth (attention_utils.py:144-159), F.interpolate(trilinear, align_corners)
 // (VeloxSeg.py:183) and the SDKT Gram matrix (loss.py:39-60) as C++ nodes: the same C-ABI calls as the python nodes of functional.py.
 struct UpconvFn : public torch::autograd::Function<UpconvFn> {
-    static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w, const OptT& b_) {
+    static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w, const OptT& b_, bool feeds_in) {
         check_in(x_in, "conv_transpose3d");
         Tensor x = contig(x_in), b = b_.value_or(Tensor());
         const int B = x.size(0), Ci = x.size(1), d = x.size(2), h = x.size(3), wd = x.size(4), Co = w.size(1);
         TORCH_CHECK(w.size(0) == Ci && w.size(2) == 2 && w.size(3) == 2 && w.size(4) == 2, "conv_transpose_k2s2: weight must be (Ci, Co, 2, 2, 2)");
         Tensor y = at::empty({B, Co, 2 * d, 2 * h, 2 * wd}, x.options());
         VX(vx_upconv_k2s2_fwd, fp(x), fp(w), fp(b), mp(y), B, Ci, Co, d, h, wd, cur_stream(x));
-        ctx->saved_data["x"] = x; ctx->saved_data["w"] = w; ctx->saved_data["b"] = b;
+        ctx->saved_data["x"] = x; ctx->saved_data["w"] = w; ctx->saved_data["b"] = b; ctx->saved_data["feeds_in"] = feeds_in;
         return y;
     }
     static variable_list backward(AutogradContext* ctx, variable_list g) {
         Tensor x = ctx->saved_data["x"].toTensor(), w = ctx->saved_data["w"].toTensor();
         Tensor b = ctx->saved_data["b"].isTensor() ? ctx->saved_data["b"].toTensor() : Tensor();
+        // the output feeds an InstanceNorm directly (UpConv, conv_blocks.py:29-35): its backward removes the per-(b, c) mean, so the bias gradient is zero
+        // up to round-off -- as for the JLC spatial convs it is not computed (the zero gradient tensor still exists)
+        const bool skip_db = ctx->saved_data["feeds_in"].toBool() && F.skip_in_bias;
         Tensor dy = contig(g[0]), dx;
         const int B = x.size(0), Ci = x.size(1), d = x.size(2), h = x.size(3), wd = x.size(4), Co = w.size(1);
         void* s_ = cur_stream(dy);
         if (ctx->needs_input_grad(0)) { dx = at::empty_like(x); VX(vx_upconv_k2s2_bwd_data, fp(dy), fp(w), mp(dx), B, Ci, Co, d, h, wd, s_); }
         float* dw = grad_ptr(w);
         float* db = grad_ptr(b);
+        if (skip_db) db = nullptr;
         if (dw || db)
             wgrad_submit(s_, x.device().index(), [=](void* s) {     // the transposed conv's weight gradient = the stride-2 conv's with x and dy swapped
                 if (dw) VX(vx_conv3d_bwd_weight_tiled, fp(dy), nullptr, 0, fp(x), dw, nullptr, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, s);
@@ -803,7 +809,7 @@ struct UpconvFn : public torch::autograd::Function<UpconvFn> {
             });
         if (!WG.enabled) WG.done.clear();
         ctx->saved_data.clear();
-        return {dx, Tensor(), Tensor()};
+        return {dx, Tensor(), Tensor(), Tensor()};
     }
 };
 struct S2DFn : public torch::autograd::Function<S2DFn> {
@@ -870,7 +876,8 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
         if (F.fuse_blocks && n == 3 && x.dim() == 5 && ws[0].size(2) == 1 && ws[1].size(2) == 3 && ws[2].size(2) == 5) {
             const int B = x.size(0), C = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4), R = l1w.size(0);
             const long V = (long)D * H * W;
-            if ((C / G) % 4 == 0 && vx_mlp_supported(C, R, V) && bs[0].defined() && bs[1].defined() && bs[2].defined()) {
+            const bool mlp_ok = vx_mlp_supported(C, R, V), tile_ok = !mlp_ok && F.jlc_tile && V % 4 == 0 && vx_inmlp_ok(C, R, V);
+            if ((C / G) % 4 == 0 && (mlp_ok || tile_ok) && bs[0].defined() && bs[1].defined() && bs[2].defined()) {
                 check_in(x, "jlc");
                 JLCFusedState& f = st->f;
                 st->blk = true;
@@ -892,6 +899,10 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 f.o = at::empty_like(f.x);
                 VX(vx_jlc_mid_fwd, fp(f.x), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), nty, mp(f.stats_y), mp(f.o), part_o.data_ptr<double>(), BC, V, (float)F.in_eps, s_);
                 Tensor out = at::empty_like(f.x);
+                f.tile = tile_ok;
+                if (tile_ok) VX(vx_inmlp_fwd, fp(f.o), part_o.data_ptr<double>(), f.nch, mp(f.stats_o), fp(l1w), fp(l1b), fp(l2w), fp(l2b), mp(out), B, C, R, V, (float)F.in_eps,
+                                f.rs, (unsigned long long)site, (float)p, s_);
+                else
                 VX(vx_mlp_fwd, fp(f.o), 0, part_o.data_ptr<double>(), f.nch, mp(f.stats_o), nullptr, nullptr, fp(l1w), fp(l1b), fp(l2w), fp(l2b), mp(out), B, C, R, V,
                                (float)F.in_eps, f.rs, 0ull, 0.0f, (unsigned long long)site, (float)p, s_);
                 return {out, st};
@@ -928,8 +939,20 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             Tensor dout = contig(dout_in);
             const int B = f.B, C = f.C, G = f.G, D = f.D, H = f.H, W = f.W, R = f.R;
             const long V = (long)D * H * W, BC = (long)B * C, n1 = BC * V;
-            const int npd = vx_mlp_bwd_nparts(B, C, V);
+            const int npd = f.tile ? vx_inmlp_tiles(V) : vx_mlp_bwd_nparts(B, C, V);
             Tensor dn = at::empty_like(f.x), part_dn = at::empty({BC, (long)npd, 2}, f.x.options());
+            if (f.tile) {
+                // scratch operands of the two weight gradients (dW2 = dz h^T, dW1 = da nhat^T): one grouped launch, a sink of the pass
+                Tensor sc_n = at::empty_like(f.x), sc_dz = at::empty_like(f.x), sc_h = at::empty({B, R, D, H, W}, f.x.options()), sc_da = at::empty({B, R, D, H, W}, f.x.options());
+                VX(vx_inmlp_bwd, fp(f.o), fp(f.stats_o), fp(f.l1w), fp(f.l1b), fp(f.l2w), fp(dout), mp(dn), mp(part_dn), mp(sc_n), mp(sc_h), mp(sc_da), mp(sc_dz), B, C, R, V,
+                                 f.rs, (unsigned long long)f.site, (float)f.p, s_);
+                float *dw1 = grad_ptr(f.l1w), *db1 = grad_ptr(f.l1b), *dw2 = grad_ptr(f.l2w), *db2 = grad_ptr(f.l2b);
+                wgrad_submit(s_, f.x.device().index(), [=](void* s) {
+                    const void* ptrs[8] = {fp(sc_h), fp(sc_dz), dw2, db2, fp(sc_n), fp(sc_da), dw1, db1};
+                    const long dims[8] = {R, C, V, B, C, R, V, B};
+                    VX(vx_pw_wgrad_group, ptrs, dims, 2, nullptr, nullptr, 0, s);
+                });
+            } else
             VX(vx_mlp_bwd, fp(f.o), 0, fp(f.stats_o), nullptr, nullptr, fp(f.l1w), fp(f.l1b), fp(f.l2w), fp(dout), mp(dn), mp(part_dn), nullptr, nullptr,
                            grad_ptr(f.l1w), grad_ptr(f.l1b), grad_ptr(f.l2w), grad_ptr(f.l2b), B, C, R, V, (float)F.in_eps, f.rs, 0ull, 0.0f,
                            (unsigned long long)f.site, (float)f.p, s_);
@@ -1138,7 +1161,8 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("ffn", [](const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p, int64_t site1,
                     int64_t site2, int64_t rs) { return FFNFn::apply(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs); });
     m.def("layernorm", [](const Tensor& x, const Tensor& g, const Tensor& bt) { return LayerNormFn::apply(x, g, bt); });
-    m.def("upconv_k2s2", [](const Tensor& x, const Tensor& w, const OptT& b) { return UpconvFn::apply(x, w, b); });
+    m.def("upconv_k2s2", [](const Tensor& x, const Tensor& w, const OptT& b, bool feeds_in) { return UpconvFn::apply(x, w, b, feeds_in); }, py::arg("x"), py::arg("w"), py::arg("b"),
+          py::arg("feeds_in") = false);
     m.def("space_to_depth2", [](const Tensor& x) { return S2DFn::apply(x); });
     m.def("upsample_trilinear", [](const Tensor& x, int64_t D, int64_t H, int64_t W) { return UpsampleFn::apply(x, D, H, W); });
     m.def("gram", [](const Tensor& x) { return GramFn::apply(x); });
@@ -1232,6 +1256,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
     m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
+    m.def("set_jlc_tile", [](bool on) { F.jlc_tile = on; });      // A/B (tests): JLC block of the coarse levels fused (default) or per operator
     m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels
     m.def("set_fuse_gelu", [](bool on) { F.fuse_gelu = on; });

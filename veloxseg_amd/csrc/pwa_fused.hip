@@ -767,3 +767,208 @@ extern "C" int vx_pwa_post_bwd(const void* const* ptrs, int M, int B, int C, int
     VX_LAUNCH_CHECK("vx_pwa_post_bwd");
     return 0;
 }
+
+// =====================================================================================================================
+// channel stage of the JLC block at the levels mlp.hip has no instance for (C = 64 / 128: the 8^3 / 4^3 grids of the headline network)
+//     out = o + Drop(W2 GELU(W1 IN(o) + b1) + b2)                                  (reference conv_blocks.py:60-66,74)
+// IN = InstanceNorm over the volume: its statistics come from the producer's per-(b, c) partial sums (jlc.hip vx_jlc_mid_fwd), folded by every block for
+// its sample as vx_mlp_in_stats does.  Same tile-GEMM chain as the PWA "post" kernels (T = 1 tiles of 16 voxels), same contract as vx_mlp_fwd / vx_mlp_bwd
+// with NORM = 0: the backward returns dn (gradient at the normalised input) and per-tile partial sums (sum dn, sum dn nhat) per (b, c), which
+// vx_jlc_mid_bwd folds into the InstanceNorm backward.  The weight gradients are two jobs of the grouped launch (pointwise.hip vx_pw_wgrad_group) over
+// the operands this kernel leaves in scratch: dW2 = dz h^T, dW1 = da nhat^T.
+// =====================================================================================================================
+struct VxInMlp {
+    const float *o, *w1, *b1, *w2, *b2, *dout;
+    const double* part;          // forward: [B*C][nparts][2] (sum, sumsq) or null (stats given)
+    float* stats;                // (B*C, 2) mean, rstd: written by the forward when part != null, read otherwise
+    float *out, *dn, *part_dn;   // part_dn: [B*C][tiles_per_b][2]
+    float *sc_n, *sc_h, *sc_da, *sc_dz;
+    int C, R, nparts, tiles_per_b;
+    long V;
+    float eps, p;
+    unsigned long long site;
+    const void* seed_ptr;
+};
+namespace {
+template <int NW>
+__device__ __forceinline__ void inmlp_stats(const VxInMlp& p, int b, float* __restrict__ mu, float* __restrict__ rs, bool writer) {
+    for (int c = threadIdx.x; c < p.C; c += 64 * NW) {
+        const long bc = (long)b * p.C + c;
+        float mean, rstd;
+        if (p.part != nullptr) {
+            double s = 0.0, q = 0.0;
+            const double* pp = p.part + bc * p.nparts * 2;
+            for (int i = 0; i < p.nparts; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
+            const double m = s / (double)p.V;
+            double var = q / (double)p.V - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            mean = (float)m;
+            rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            if (writer) { p.stats[2 * bc] = mean; p.stats[2 * bc + 1] = rstd; }
+        } else {
+            mean = p.stats[2 * bc];
+            rstd = p.stats[2 * bc + 1];
+        }
+        mu[c] = mean;
+        rs[c] = rstd;
+    }
+}
+}  // namespace
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) vx_inmlp_fwd_k(VxInMlp p) {
+    constexpr int T = 1, NT = 16, S = Geo<1>::S, NP = 64 * NW / NT;
+    extern __shared__ __attribute__((aligned(16))) float vx_pf_lds[];
+    const int C = p.C, R = p.R;
+    float* __restrict__ O = vx_pf_lds;               // [C][S]
+    float* __restrict__ N = O + C * S;               // [C][S]
+    float* __restrict__ Hh = N + C * S;              // [R][S]
+    float* __restrict__ mu = Hh + R * S, *rs = mu + C, *b2 = rs + C, *b1 = b2 + C;      // C | C | C | R
+    const int b = blockIdx.x / p.tiles_per_b, tile = blockIdx.x % p.tiles_per_b;
+    const long V = p.V, v0 = (long)tile * NT;
+    const VxDropCtx d2 = drop_ctx_dev(p.seed_ptr, p.site, p.p);
+    inmlp_stats<NW>(p, b, mu, rs, tile == 0);
+    stage_vec<NW>(b2, p.b2, C, 0.0f);
+    stage_vec<NW>(b1, p.b1, R, 0.0f);
+    load_tile<T, NW>(O, p.o + (long)b * C * V, C, V, v0);
+    __syncthreads();
+    {
+        const int col = threadIdx.x % NT, part = threadIdx.x / NT;
+        for (int c = part; c < C; c += NP) N[c * S + col] = (O[c * S + col] - mu[c]) * rs[c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long v = v0 + r;
+    const bool vlive = v < V;
+    tile_gemm1<T, NW, false>(p.w1, C, C, 1, R, N, [&](int mt, vx_f32x4 (&acc)[T]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = 16 * mt + 4 * q + reg;
+            Hh[j * S + r] = vlive ? vx_gelu_fast(acc[0][reg] + b1[j]) : 0.0f;
+        }
+    });
+    __syncthreads();
+    tile_gemm1<T, NW, false>(p.w2, R, R, 1, C, Hh, [&](int mt, vx_f32x4 (&acc)[T]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * mt + 4 * q + reg;
+            if (vlive) {
+                const long idx = ((long)b * C + m) * V + v;
+                p.out[idx] = fmaf(acc[0][reg] + b2[m], vx_drop1(d2, (uint64_t)idx), O[m * S + r]);
+            }
+        }
+    });
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) vx_inmlp_bwd_k(VxInMlp p) {
+    constexpr int T = 1, NT = 16, S = Geo<1>::S, NP = 64 * NW / NT;
+    extern __shared__ __attribute__((aligned(16))) float vx_pf_lds[];
+    const int C = p.C, R = p.R;
+    float* __restrict__ DZ = vx_pf_lds;              // [C][S]  dout * mask, later dn
+    float* __restrict__ N = DZ + C * S;              // [C][S]  nhat
+    float* __restrict__ A = N + C * S;               // [R][S]  pre-activation a, then da
+    float* __restrict__ mu = A + R * S, *rs = mu + C, *b1 = rs + C;      // C | C | R
+    const int b = blockIdx.x / p.tiles_per_b, tile = blockIdx.x % p.tiles_per_b;
+    const long V = p.V, v0 = (long)tile * NT;
+    const VxDropCtx d2 = drop_ctx_dev(p.seed_ptr, p.site, p.p);
+    const int col = threadIdx.x % NT, part = threadIdx.x / NT;
+    const bool clive = v0 + col < V;
+    inmlp_stats<NW>(p, b, mu, rs, false);
+    stage_vec<NW>(b1, p.b1, R, 0.0f);
+    load_tile<T, NW>(N, p.o + (long)b * C * V, C, V, v0);
+    load_tile<T, NW>(DZ, p.dout + (long)b * C * V, C, V, v0);
+    __syncthreads();
+    for (int c = part; c < C; c += NP) {
+        const long idx = ((long)b * C + c) * V + v0 + col;
+        const float g = clive ? DZ[c * S + col] * vx_drop1(d2, (uint64_t)idx) : 0.0f;
+        const float nh = clive ? (N[c * S + col] - mu[c]) * rs[c] : 0.0f;
+        DZ[c * S + col] = g;
+        N[c * S + col] = nh;
+        if (clive) { p.sc_dz[idx] = g; p.sc_n[idx] = nh; }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long v = v0 + r;
+    const bool vlive = v < V;
+    // a = W1 nhat + b1 ; h = gelu(a) -> global (dW2's operand)
+    tile_gemm1<T, NW, false>(p.w1, C, C, 1, R, N, [&](int mt, vx_f32x4 (&acc)[T]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = 16 * mt + 4 * q + reg;
+            const float a = acc[0][reg] + b1[j];
+            A[j * S + r] = a;
+            if (vlive) p.sc_h[((long)b * R + j) * V + v] = vx_gelu_fast(a);
+        }
+    });
+    __syncthreads();
+    // da = (W2^T dz) * gelu'(a)
+    tile_gemm1<T, NW, true>(p.w2, C, 1, R, R, DZ, [&](int mt, vx_f32x4 (&acc)[T]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = 16 * mt + 4 * q + reg;
+            const float da = vlive ? acc[0][reg] * vx_gelu_grad_fast(A[j * S + r]) : 0.0f;
+            A[j * S + r] = da;
+            if (vlive) p.sc_da[((long)b * R + j) * V + v] = da;
+        }
+    });
+    __syncthreads();
+    // dn = W1^T da -> global, and this tile's (sum dn, sum dn nhat) per channel: the 16 voxels of an accumulator register are the 16 lanes of a q group
+    tile_gemm1<T, NW, true>(p.w1, R, 1, C, C, A, [&](int mt, vx_f32x4 (&acc)[T]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * mt + 4 * q + reg;
+            const float dn = vlive ? acc[0][reg] : 0.0f;
+            if (vlive) p.dn[((long)b * C + m) * V + v] = dn;
+            float s1 = dn, s2 = dn * N[m * S + r];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) { s1 += __shfl_xor(s1, o_, 64); s2 += __shfl_xor(s2, o_, 64); }
+            if (r == 0) {
+                float* __restrict__ pp = p.part_dn + (((long)b * C + m) * p.tiles_per_b + tile) * 2;
+                pp[0] = s1; pp[1] = s2;
+            }
+        }
+    });
+}
+
+extern "C" int vx_inmlp_ok(int C, int R, long V) {
+    if (C % 16 || R % 16 || C < 16 || R < 16 || C > 256 || V < 1) return 0;
+    const size_t lds = ((size_t)(2 * C + R) * 20 + 3 * C + R) * sizeof(float);
+    return lds <= 150 * 1024 ? 1 : 0;
+}
+extern "C" int vx_inmlp_tiles(long V) { return vx_cdiv(V, 16); }      // partial-sum rows per (b, c) of vx_inmlp_bwd (batch-size independent)
+
+extern "C" int vx_inmlp_fwd(const float* o, const double* part, int nparts, float* stats, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                            int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site, float p_drop, void* stream) {
+    VX_REQUIRE(o && stats && w1 && b1 && w2 && b2 && out && B > 0 && (part == nullptr || nparts > 0), "vx_inmlp_fwd: bad args");
+    VX_REQUIRE(vx_inmlp_ok(C, R, V), "vx_inmlp_fwd: unsupported shape C=%d R=%d V=%ld", C, R, V);
+    VX_REQUIRE(o != out, "vx_inmlp_fwd: in-place is not supported");
+    VxInMlp p = {};
+    p.o = o; p.part = part; p.nparts = nparts; p.stats = stats; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out;
+    p.C = C; p.R = R; p.V = V; p.eps = eps; p.p = p_drop; p.site = site; p.seed_ptr = seed_ptr; p.tiles_per_b = vx_cdiv(V, 16);
+    const long blocks = (long)B * p.tiles_per_b;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = ((size_t)(2 * C + R) * 20 + 3 * C + R) * sizeof(float);
+    if (pf_nw(blocks) == 8) pf_launch<1, 8>(vx_inmlp_fwd_k<8>, p, dim3((unsigned)blocks), shm, st);
+    else pf_launch<1, 4>(vx_inmlp_fwd_k<4>, p, dim3((unsigned)blocks), shm, st);
+    VX_LAUNCH_CHECK("vx_inmlp_fwd");
+    return 0;
+}
+/* dn (B, C, V), part_dn (B*C, vx_inmlp_tiles(V), 2), scratch sc_n / sc_dz (B, C, V), sc_h / sc_da (B, R, V) */
+extern "C" int vx_inmlp_bwd(const float* o, const float* stats, const float* w1, const float* b1, const float* w2, const float* dout, float* dn, float* part_dn,
+                            float* sc_n, float* sc_h, float* sc_da, float* sc_dz, int B, int C, int R, long V, const void* seed_ptr, unsigned long long site, float p_drop,
+                            void* stream) {
+    VX_REQUIRE(o && stats && w1 && b1 && w2 && dout && dn && part_dn && sc_n && sc_h && sc_da && sc_dz && B > 0, "vx_inmlp_bwd: bad args");
+    VX_REQUIRE(vx_inmlp_ok(C, R, V), "vx_inmlp_bwd: unsupported shape C=%d R=%d V=%ld", C, R, V);
+    VxInMlp p = {};
+    p.o = o; p.stats = const_cast<float*>(stats); p.w1 = w1; p.b1 = b1; p.w2 = w2; p.dout = dout; p.dn = dn; p.part_dn = part_dn;
+    p.sc_n = sc_n; p.sc_h = sc_h; p.sc_da = sc_da; p.sc_dz = sc_dz;
+    p.C = C; p.R = R; p.V = V; p.p = p_drop; p.site = site; p.seed_ptr = seed_ptr; p.tiles_per_b = vx_cdiv(V, 16);
+    const long blocks = (long)B * p.tiles_per_b;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = ((size_t)(2 * C + R) * 20 + 2 * C + R) * sizeof(float);
+    if (pf_nw(blocks) == 8) pf_launch<1, 8>(vx_inmlp_bwd_k<8>, p, dim3((unsigned)blocks), shm, st);
+    else pf_launch<1, 4>(vx_inmlp_bwd_k<4>, p, dim3((unsigned)blocks), shm, st);
+    VX_LAUNCH_CHECK("vx_inmlp_bwd");
+    return 0;
+}

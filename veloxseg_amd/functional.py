@@ -486,10 +486,11 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
         return dx, None, None
 
 
-def conv_transpose_k2s2(x, w, b):
+def conv_transpose_k2s2(x, w, b, feeds_instnorm: bool = False):
+    """feeds_instnorm: the output goes straight into an InstanceNorm (UpConv): the bias gradient is zero by construction and is not computed"""
     m = _cpp_node("small") if x.is_cuda else None
     if m is not None:
-        return m.upconv_k2s2(x, w, b)
+        return m.upconv_k2s2(x, w, b, bool(feeds_instnorm))
     return _ConvTransposeK2S2Fn.apply(x, w, b)
 
 

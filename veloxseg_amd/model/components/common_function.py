@@ -21,9 +21,9 @@ class ParamConv3d(nn.Conv3d):
 
 
 class ParamConvTranspose3d(nn.ConvTranspose3d):
-    def forward(self, x):
+    def forward(self, x, feeds_instnorm: bool = False):
         assert self.kernel_size == (2, 2, 2) and self.stride == (2, 2, 2) and self.groups == 1
-        return VF.conv_transpose_k2s2(x, self.weight, self.bias)
+        return VF.conv_transpose_k2s2(x, self.weight, self.bias, feeds_instnorm)
 
 
 class InstanceNormMarker(nn.Module):

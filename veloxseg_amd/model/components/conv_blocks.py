@@ -33,7 +33,7 @@ class UpConv(nn.Module):
 
     def forward(self, x, skip=None):
         """IN(convT(x)) (+ skip)"""
-        return VF.instnorm_sum([self.up(x)], act=False, res=skip)
+        return VF.instnorm_sum([self.up(x, feeds_instnorm=True)], act=False, res=skip)
 
 
 class JLC(nn.Module):
