@@ -75,6 +75,15 @@ __device__ __forceinline__ void vx_jlc_stage_w(float* __restrict__ ws, int total
     }
 }
 
+
+// COT consecutive weights from LDS (one read)
+template <int COT>
+__device__ __forceinline__ void vx_jlc_ldw(const float* __restrict__ w, float (&wv)[COT]) {
+    if constexpr (COT == 4) { const float4 t = *reinterpret_cast<const float4*>(w); wv[0] = t.x; wv[1] = t.y; wv[2] = t.z; wv[3] = t.w; }
+    else if constexpr (COT == 2) { const float2 t = *reinterpret_cast<const float2*>(w); wv[0] = t.x; wv[1] = t.y; }
+    else wv[0] = w[0];
+}
+
 __device__ __forceinline__ void vx_jlc_tile(const VxJlc& p, int& d0, int& h0, int& w0, int& td, int& th, int& tq, bool& active) {
     const int tile = blockIdx.x;
     const int tw_i = tile % p.nTw, th_i = (tile / p.nTw) % p.nTh, td_i = tile / (p.nTw * p.nTh);
@@ -128,47 +137,38 @@ __global__ void __launch_bounds__(512) vx_jlc_conv_fwd_k(VxJlc p) {
                         const float* __restrict__ wp5 = ws + (cil * NT + (kd * 5 + kh) * 5) * COT;
 #pragma unroll
                         for (int kw = 0; kw < 5; ++kw) {
+                            {
+                                float wv[COT];
+                                vx_jlc_ldw<COT>(wp5 + kw * COT, wv);
 #pragma unroll
-                            for (int j4 = 0; j4 < COT; j4 += 4) {
-                                const float4 wv = *reinterpret_cast<const float4*>(wp5 + kw * COT + j4);
+                                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    a5[u][j4 + 0] = fmaf(wv.x, xr[u + kw], a5[u][j4 + 0]);
-                                    a5[u][j4 + 1] = fmaf(wv.y, xr[u + kw], a5[u][j4 + 1]);
-                                    a5[u][j4 + 2] = fmaf(wv.z, xr[u + kw], a5[u][j4 + 2]);
-                                    a5[u][j4 + 3] = fmaf(wv.w, xr[u + kw], a5[u][j4 + 3]);
-                                }
+                                    for (int j = 0; j < COT; ++j) a5[u][j] = fmaf(wv[j], xr[u + kw], a5[u][j]);
                             }
                         }
                         if (kd >= 1 && kd <= 3 && kh >= 1 && kh <= 3) {
                             const float* __restrict__ wp3 = ws + (cil * NT + 125 + ((kd - 1) * 3 + (kh - 1)) * 3) * COT;
 #pragma unroll
                             for (int kw = 0; kw < 3; ++kw) {
+                                {
+                                    float wv[COT];
+                                    vx_jlc_ldw<COT>(wp3 + kw * COT, wv);
 #pragma unroll
-                                for (int j4 = 0; j4 < COT; j4 += 4) {
-                                    const float4 wv = *reinterpret_cast<const float4*>(wp3 + kw * COT + j4);
+                                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        a3[u][j4 + 0] = fmaf(wv.x, xr[u + kw + 1], a3[u][j4 + 0]);
-                                        a3[u][j4 + 1] = fmaf(wv.y, xr[u + kw + 1], a3[u][j4 + 1]);
-                                        a3[u][j4 + 2] = fmaf(wv.z, xr[u + kw + 1], a3[u][j4 + 2]);
-                                        a3[u][j4 + 3] = fmaf(wv.w, xr[u + kw + 1], a3[u][j4 + 3]);
-                                    }
+                                        for (int j = 0; j < COT; ++j) a3[u][j] = fmaf(wv[j], xr[u + kw + 1], a3[u][j]);
                                 }
                             }
                         }
                         if (kd == 2 && kh == 2) {
                             const float* __restrict__ wp1 = ws + (cil * NT + 152) * COT;
+                            {
+                                float wv[COT];
+                                vx_jlc_ldw<COT>(wp1, wv);
 #pragma unroll
-                            for (int j4 = 0; j4 < COT; j4 += 4) {
-                                const float4 wv = *reinterpret_cast<const float4*>(wp1 + j4);
+                                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    a1[u][j4 + 0] = fmaf(wv.x, xr[u + 2], a1[u][j4 + 0]);
-                                    a1[u][j4 + 1] = fmaf(wv.y, xr[u + 2], a1[u][j4 + 1]);
-                                    a1[u][j4 + 2] = fmaf(wv.z, xr[u + 2], a1[u][j4 + 2]);
-                                    a1[u][j4 + 3] = fmaf(wv.w, xr[u + 2], a1[u][j4 + 3]);
-                                }
+                                    for (int j = 0; j < COT; ++j) a1[u][j] = fmaf(wv[j], xr[u + 2], a1[u][j]);
                             }
                         }
                     }
@@ -176,10 +176,10 @@ __global__ void __launch_bounds__(512) vx_jlc_conv_fwd_k(VxJlc p) {
             }
         }
     }
-    if (p.parts > 1) {                               // sum the channel parts through LDS (the halo / weight tiles are dead)
+    for (int pk = 1; pk < p.parts; ++pk) {           // sum the channel parts through LDS, one after the other (the halo / weight tiles are dead)
         __syncthreads();
         float* __restrict__ rb = vx_jlc_lds + (long)(tid % p.nsp) * (12 * COT);
-        if (part == 1) {
+        if (part == pk) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -274,16 +274,13 @@ __device__ __forceinline__ void vx_jlc_adj(const float* __restrict__ gsrc, const
                         const float* __restrict__ wp = ws + (cil * K3 + (kd * K + kh) * K) * COT;
 #pragma unroll
                         for (int kw = 0; kw < K; ++kw) {
+                            {
+                                float wv[COT];
+                                vx_jlc_ldw<COT>(wp + kw * COT, wv);
 #pragma unroll
-                            for (int j4 = 0; j4 < COT; j4 += 4) {
-                                const float4 wv = *reinterpret_cast<const float4*>(wp + kw * COT + j4);
+                                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    acc[u][j4 + 0] = fmaf(wv.x, xr[u + kw], acc[u][j4 + 0]);
-                                    acc[u][j4 + 1] = fmaf(wv.y, xr[u + kw], acc[u][j4 + 1]);
-                                    acc[u][j4 + 2] = fmaf(wv.z, xr[u + kw], acc[u][j4 + 2]);
-                                    acc[u][j4 + 3] = fmaf(wv.w, xr[u + kw], acc[u][j4 + 3]);
-                                }
+                                    for (int j = 0; j < COT; ++j) acc[u][j] = fmaf(wv[j], xr[u + kw], acc[u][j]);
                             }
                         }
                     }
@@ -309,20 +306,25 @@ __global__ void __launch_bounds__(512) vx_jlc_conv_bwd_k(VxJlc p) {
     vx_jlc_adj<5, COT>(p.g5, p.w5, p, vx_jlc_lds, b, g, ci0, d0, h0, w0, td, th, tq, active, acc);
     vx_jlc_adj<3, COT>(p.g3, p.w3, p, vx_jlc_lds, b, g, ci0, d0, h0, w0, td, th, tq, active, acc);
     if (p.parts > 1) {
-        __syncthreads();
+        const int part = threadIdx.x / p.nsp;
         float* __restrict__ rb = vx_jlc_lds + (long)(threadIdx.x % p.nsp) * (4 * COT);
-        if (threadIdx.x >= p.nsp) {
+        for (int pk = 1; pk < p.parts; ++pk) {
+            __syncthreads();
+            if (part == pk) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < COT; ++j) rb[u * COT + j] = acc[u][j];
+                    for (int j = 0; j < COT; ++j) rb[u * COT + j] = acc[u][j];
+            }
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < COT; ++j) acc[u][j] += rb[u * COT + j];
+            }
         }
-        __syncthreads();
-        if (threadIdx.x >= p.nsp) return;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < COT; ++j) acc[u][j] += rb[u * COT + j];
+        if (part != 0) return;
     }
     const int od = d0 + td, oh = h0 + th, ow = w0 + 4 * tq;
     if (!active || od >= p.D || oh >= p.H) return;
@@ -541,24 +543,30 @@ static int vx_jlc_geom(VxJlc& p, int B, int C, int G, int D, int H, int W, int K
     if (td > 8) td = 8;
     if (td < 1) td = 1;
     p.TD = td;
-    COT = 4;            // (8 channels per thread would need 256 VGPRs forward: one wave per SIMD)
     // the tiling must not depend on the batch size: the order in which a sample's partial sums are folded would change with B, and a sample's
     // result must be bit-identical whatever it is batched with (tests/test_hip_model_gpu.py); 4 = the nominal batch of the training step
     auto nblk = [&]() { return (long)vx_cdiv(D, p.TD) * vx_cdiv(H, p.TH) * vx_cdiv(W, p.TWq * 4) * (C / COT) * 4; };
+    // output channels per thread: 4 (8 would need 256 VGPRs forward: one wave per SIMD).  2 or 1 on the coarse grids are FASTER ALONE (8^3: 25 vs 30 us,
+    // 16^3: 48 vs 55 us -- more blocks) and SLOWER IN THE STEP (autopet128 704 vs 729 patches/s, autopet96 988 vs 1037): every input value is then re-read
+    // from LDS for fewer FMAs, and in the step these kernels share the CUs with the other lanes' kernels -- issue slots, not latency, are what they cost.
+    COT = 4;
     while (p.TD > 1 && nblk() < 128 && (p.TD / 2) * p.TWq * p.TH >= 64) p.TD /= 2;      // very small volumes only: thin tiles re-stage most of their halo (16^3 measured: 121 us thin vs full tiles)
     p.nTd = vx_cdiv(D, p.TD); p.nTh = vx_cdiv(H, p.TH); p.nTw = vx_cdiv(W, p.TWq * 4);
     p.nsp = (p.TD * p.TH * p.TWq + 63) / 64 * 64;
     if (p.nsp > 256) p.nsp = 256;
-    // few blocks (16^3 and below: 128 blocks of 4 waves = one wave per SIMD on half of the chip, and one wave alone does not saturate a SIMD's VALU):
-    // two channel parts per spatial slot = 8 waves per block, half the FMAs per thread, partial sums folded through LDS
-    p.parts = (nblk() < 256 && Cg >= 2 && Cg % 2 == 0) ? 2 : 1;
-    p.nthr = p.nsp * p.parts;
     const int plane = (p.TD + K - 1) * (p.TH + K - 1) * (p.TWq * 4 + 4);
     const int taps = K == 5 ? 153 : 125;             // forward stages all three kernels' taps; the adjoint the largest kernel's
     int cic = Cg < 4 ? Cg : 4;
     auto lds = [&](int c) { return (size_t)c * (plane + taps * COT) * sizeof(float); };
     while (cic > 1 && lds(cic) > 64 * 1024) cic >>= 1;
-    if (cic % p.parts) { p.parts = 1; p.nthr = p.nsp; }
+    // few blocks or few spatial slots: the staged input channels are split over 2 or 4 thread groups per spatial slot (more waves per SIMD, fewer FMAs per
+    // thread), their partial sums folded through LDS
+    p.parts = 1;
+    if (nblk() < 512) {
+        if (cic % 4 == 0 && p.nsp * 4 <= 512 && nblk() < 384) p.parts = 4;
+        else if (cic % 2 == 0 && p.nsp * 2 <= 512) p.parts = 2;
+    }
+    p.nthr = p.nsp * p.parts;
     p.cic = cic;
     shm = lds(cic);
     if (p.parts > 1 && shm < (size_t)p.nsp * 12 * COT * sizeof(float)) shm = (size_t)p.nsp * 12 * COT * sizeof(float);
@@ -582,7 +590,9 @@ extern "C" int vx_jlc_conv_fwd(const float* x, const float* w1, const float* w3,
     p.x = x; p.w1 = w1; p.w3 = w3; p.w5 = w5; p.b1 = b1; p.b3 = b3; p.b5 = b5; p.y1 = y1; p.y3 = y3; p.y5 = y5; p.part = part;
     dim3 grid(p.nTd * p.nTh * p.nTw, C / COT, B);
     hipStream_t st = (hipStream_t)stream;
-    vx_jlc_conv_fwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    if (COT == 4) vx_jlc_conv_fwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    else if (COT == 2) vx_jlc_conv_fwd_k<2><<<grid, dim3(p.nthr), shm, st>>>(p);
+    else vx_jlc_conv_fwd_k<1><<<grid, dim3(p.nthr), shm, st>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_conv_fwd");
     return 0;
 }
@@ -596,7 +606,9 @@ extern "C" int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5
     p.g1 = g1; p.g3 = g3; p.g5 = g5; p.w1 = w1; p.w3 = w3; p.w5 = w5; p.res = d_o; p.dx = dx;
     dim3 grid(p.nTd * p.nTh * p.nTw, C / COT, B);
     hipStream_t st = (hipStream_t)stream;
-    vx_jlc_conv_bwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    if (COT == 4) vx_jlc_conv_bwd_k<4><<<grid, dim3(p.nthr), shm, st>>>(p);
+    else if (COT == 2) vx_jlc_conv_bwd_k<2><<<grid, dim3(p.nthr), shm, st>>>(p);
+    else vx_jlc_conv_bwd_k<1><<<grid, dim3(p.nthr), shm, st>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_conv_bwd");
     return 0;
 }
