@@ -352,6 +352,9 @@ int vx_upsample_trilinear_bwd(const float* dout, float* dx, float* ws, long BC, 
 /* ConvTranspose3d(k=2, s=2) specialised (conv_blocks.py:29-35): w = (Ci, Co, 2,2,2); x: (B,Ci,d,h,w); y: (B,Co,2d,2h,2w) */
 int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream);
 int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream);
+/* weight gradient of the same layer as one MFMA GEMM (M = Ci, N = Co * 8 taps, K = B * d * h * wd): dw (Ci, Co, 2, 2, 2) +=.  Ci, Co multiples of 16, Ci <= 128 */
+int vx_upconv_k2s2_wgrad_ok(int Ci, int Co);
+int vx_upconv_k2s2_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int Co, int d, int h, int wd, void* stream);
 
 /* fused AdamW on flat buffers (torch.optim.AdamW maths; config/train_config_bs4.json:66-72); g is scaled by grad_scale first */
 int vx_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

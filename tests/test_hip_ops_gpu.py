@@ -144,11 +144,15 @@ def test_conv3d_concat_nobias():
     run_pair(lambda a, b, w: VF.conv3d(a, w, None, x2=b), lambda a, b, w: F.conv3d(torch.cat([a, b], 1), w), [x1, x2], [w], what="concat")
 
 
-def test_conv_transpose():
+@pytest.mark.parametrize("B,Ci,Co,sp", [(2, 32, 16, (3, 4, 5)), (4, 128, 64, (4, 4, 4)), (3, 64, 32, (8, 8, 8)), (2, 32, 16, (16, 16, 16)), (1, 24, 8, (3, 3, 3))],
+                         ids=["ragged", "L4_to_L3", "L3_to_L2", "L2_to_L1", "odd_channels"])
+def test_conv_transpose(B, Ci, Co, sp):
+    """ConvTranspose3d(k2, s2): forward, input gradient, and the weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad; channel counts that
+    are not multiples of 16 keep the generic kernel)"""
     VF = _vf()
-    x = rnd(2, 32, 3, 4, 5)
-    w = rnd(32, 16, 2, 2, 2, seed=5, scale=0.2)
-    b = rnd(16, seed=6, scale=0.1)
+    x = rnd(B, Ci, *sp)
+    w = rnd(Ci, Co, 2, 2, 2, seed=5, scale=0.2)
+    b = rnd(Co, seed=6, scale=0.1)
     run_pair(lambda x, w, b: VF.conv_transpose_k2s2(x, w, b), lambda x, w, b: F.conv_transpose3d(x, w, b, stride=2), [x], [w, b], what="convT")
 
 

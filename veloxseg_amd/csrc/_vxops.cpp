@@ -30,6 +30,7 @@ namespace {
 struct Flags {
     bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    bool upconv_wgrad_mfma = true;    // (A/B) ConvTranspose weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad) vs the generic strided-conv kernel
     bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
@@ -804,7 +805,8 @@ struct UpconvFn : public torch::autograd::Function<UpconvFn> {
         if (skip_db) db = nullptr;
         if (dw || db)
             wgrad_submit(s_, x.device().index(), [=](void* s) {     // the transposed conv's weight gradient = the stride-2 conv's with x and dy swapped
-                if (dw) VX(vx_conv3d_bwd_weight_tiled, fp(dy), nullptr, 0, fp(x), dw, nullptr, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, s);
+                if (dw && F.upconv_wgrad_mfma && vx_upconv_k2s2_wgrad_ok(Ci, Co)) VX(vx_upconv_k2s2_wgrad, fp(x), fp(dy), dw, B, Ci, Co, d, h, wd, s);
+                else if (dw) VX(vx_conv3d_bwd_weight_tiled, fp(dy), nullptr, 0, fp(x), dw, nullptr, B, Co, 2 * d, 2 * h, 2 * wd, Ci, 2, 2, 0, 1, 1, s);
                 if (db) VX(vx_channel_sum, fp(dy), db, B, Co, 8L * d * h * wd, s);
             });
         if (!WG.enabled) WG.done.clear();
@@ -1256,6 +1258,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
     m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
+    m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });
     m.def("set_jlc_tile", [](bool on) { F.jlc_tile = on; });      // A/B (tests): JLC block of the coarse levels fused (default) or per operator
     m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels

@@ -834,3 +834,86 @@ extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* d
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k = 2, s = 2) weight gradient (reference conv_blocks.py:29-35):  dW[ci][co][tap] += sum_{b, v} x[b, ci, v] * dy[b, co, 2v + tap]
+// = a GEMM with M = Ci, N = Co * 8 (channel, tap), K = B * V coarse voxels: 0.03-0.13 GFLOP per layer.  The generic strided-conv weight-gradient kernel
+// it used to borrow (x and dy swapped) took 25-70 us per layer; here a block stages a chunk of KC coarse voxels -- x[Ci][KC] and the 16 co x 8 taps fine
+// values dy[128][KC] -- in LDS and its 4 waves hold all Ci x 128 outputs of that chunk on v_mfma_f32_16x16x4_f32 (wave w: column tiles 2w, 2w+1, every
+// row tile), then add them to dW with float atomics in 64-byte runs.  grid = (K chunks, Co / 16).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MT>        // row tiles = Ci / 16
+__global__ void __launch_bounds__(256) vx_upconv_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int Ci, int Co, int d, int h, int wd,
+                                                         int KC, int chunks_per_b) {
+    typedef float vx_f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float vx_uw_lds[];
+    const int P = KC + 4;                             // row pitch: lanes (r, q) of an operand read fall on 64 different banks
+    float* __restrict__ xs = vx_uw_lds;               // [Ci][P]
+    float* __restrict__ ds = xs + Ci * P;             // [128 = (co_local, tap)][P]
+    const int b = blockIdx.x / chunks_per_b, v0 = (blockIdx.x % chunks_per_b) * KC;
+    const int co0 = blockIdx.y * 16;
+    const long V = (long)d * h * wd;
+    const int H2 = 2 * h, W2 = 2 * wd;
+    for (int e = threadIdx.x; e < Ci * KC; e += 256) {
+        const int ci = e / KC, kv = e - ci * KC;
+        xs[ci * P + kv] = v0 + kv < V ? x[((long)b * Ci + ci) * V + v0 + kv] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 128 * KC; e += 256) {
+        const int col = e / KC, kv = e - col * KC;
+        const int v = v0 + kv;
+        float val = 0.0f;
+        if (v < V) {
+            const int w_ = v % wd, t_ = v / wd, h_ = t_ % h, d_ = t_ / h;
+            const int co = co0 + (col >> 3), i = (col >> 2) & 1, j = (col >> 1) & 1, k = col & 1;
+            val = dy[(((long)b * Co + co) * (2 * d) + 2 * d_ + i) * (long)H2 * W2 + (long)(2 * h_ + j) * W2 + 2 * w_ + k];
+        }
+        ds[col * P + kv] = val;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    vx_f4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] = (vx_f4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (vx_f4){0.f, 0.f, 0.f, 0.f}; }
+    const float* __restrict__ bp0 = ds + ((2 * wave) * 16 + r) * P + q;
+    const float* __restrict__ bp1 = bp0 + 16 * P;
+    const float* __restrict__ ap = xs + r * P + q;
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+        const float b0 = bp0[k0], b1 = bp1[k0];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float a = ap[m * 16 * P + k0];
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[m][1], 0, 0, 0);
+        }
+    }
+    // acc[m][t][reg] = dW[ci = 16 m + 4 q + reg][col = 16 (2 wave + t) + r]; dw layout (Ci, Co, 8): 16 consecutive columns are 64 contiguous bytes
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = 16 * m + 4 * q + reg, col = 16 * (2 * wave + t) + r;
+                atomicAdd(dw + ((long)ci * Co + co0) * 8 + col, acc[m][t][reg]);
+            }
+}
+extern "C" int vx_upconv_k2s2_wgrad_ok(int Ci, int Co) { return (Ci % 16 == 0 && Co % 16 == 0 && Ci >= 16 && Ci <= 128) ? 1 : 0; }
+/* dw (Ci, Co, 2, 2, 2) += ; x (B, Ci, d, h, wd), dy (B, Co, 2d, 2h, 2wd) */
+extern "C" int vx_upconv_k2s2_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
+    VX_REQUIRE(x && dy && dw && B > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_wgrad: bad args");
+    VX_REQUIRE(vx_upconv_k2s2_wgrad_ok(Ci, Co), "vx_upconv_k2s2_wgrad: unsupported channels Ci=%d Co=%d", Ci, Co);
+    const long V = (long)d * h * wd;
+    int KC = Ci <= 64 ? 64 : 32;
+    while (KC > 16 && (long)B * vx_cdiv(V, (long)KC) * (Co / 16) < 256) KC >>= 1;      // enough blocks to fill the chip on the coarse grids
+    const int chunks_per_b = (int)vx_cdiv(V, (long)KC);
+    dim3 grid((unsigned)(B * chunks_per_b), (unsigned)(Co / 16));
+    const size_t shm = (size_t)(Ci + 128) * (KC + 4) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Ci / 16) {
+#define VX_UW(MT_) case MT_: vx_upconv_wgrad_k<MT_><<<grid, 256, shm, st>>>(x, dy, dw, Ci, Co, d, h, wd, KC, chunks_per_b); break;
+        VX_UW(1) VX_UW(2) VX_UW(3) VX_UW(4) VX_UW(5) VX_UW(6) VX_UW(7) VX_UW(8)
+#undef VX_UW
+    }
+    VX_LAUNCH_CHECK("vx_upconv_k2s2_wgrad");
+    return 0;
+}
