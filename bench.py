@@ -44,6 +44,7 @@ WORKLOADS = {
 STEP_WORK = {"autopet128": (58.50, 569.1, 73.0), "autopet96": (24.11, 240.1, 73.0), "brats128": (71.55, 916.5, 60.0), "brats96": (30.04, 386.6, 60.0)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector / fp32-input MFMA peak
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is NOT used)
 
 
 def synth(cfg, B, device, seed):
@@ -328,6 +329,9 @@ def main():
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "arithmetic": ("fp32 storage, fp32 accumulation everywhere; the patch-expand layers form every fp32 product from %d bf16 pieces per operand on the "
+                                         "bf16 matrix pipe (same error against fp64 as the fp32 MFMA kernels: profiles/r03_expand_split_probe.txt), every other kernel "
+                                         "computes in fp32" % _expand_split()) if args.dtype == "f32" and _expand_split() else "fp32",
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     if rank == 0 and lane_probe is not None:
         out["lane_probe"] = lane_probe
@@ -488,6 +492,15 @@ def _pmc_traffic(kernels, B):
 _pmc_traffic.workload = None
 
 
+def _expand_split():
+    try:
+        from veloxseg_amd import functional as VF
+        m = VF.cpp_module()
+        return int(m.get_expand_split()) if m is not None else 0
+    except Exception:
+        return 0
+
+
 def _conv_out(d, K, S, P):
     return (d + 2 * P - K) // S + 1
 
@@ -538,6 +551,20 @@ def roofline_for(name, key, ms_per_launch, model=None):
             B, Cc, D, H, W = k[:5]
             v = B * D * H * W
             flops, bytes_ = 2.0 * v * 64 * Cc * 16 * 27, 4.0 * (v * (16 + 64 * Cc) + 64 * Cc * 16 * 27)
+        elif name in ("vx_expand_fwd_mfma_split", "vx_expand_bwd_data_mfma_split", "vx_expand_wgrad_mfma_split"):
+            # the fp32-mode default of the patch-expand layers: every fp32 operand = ns bf16 pieces, a product = 6 (ns = 3) or 3 (ns = 2) bf16 MFMAs with fp32
+            # accumulation (csrc/expand_mfma.hip).  Algorithmic flops = the layer's fp32 flops; the ceiling of THIS algorithm on the matrix pipe is the dense
+            # bf16 peak divided by the piece products per pair
+            ns = int(k[-1])
+            B, Cc, D, H, W = k[-7:-2] if name == "vx_expand_bwd_data_mfma_split" else k[-6:-1]
+            v = B * D * H * W
+            flops, bytes_ = 2.0 * v * 64 * Cc * 16 * 27, 4.0 * (v * (16 + 64 * Cc) + 64 * Cc * 16 * 27)
+            r["split"] = {"pieces": ns, "bf16_mfma_per_pair": 6 if ns == 3 else 3, "peak_tflops": round(BF16_PEAK_TFLOPS / (6 if ns == 3 else 3), 1)}
+            kn = {"vx_expand_fwd_mfma_split": f"vx_expand_fwd_split_k<{ns}>", "vx_expand_bwd_data_mfma_split": f"vx_expand_bwd_data_split_k<{ns}>",
+                  "vx_expand_wgrad_mfma_split": f"vx_expand_wgrad_split_k<{ns}>"}[name]
+            r["traffic"], src = _pmc_traffic_by_grid(kn, B, "max" if Cc >= 2 else "min")
+            if src:
+                r["traffic_source"] = src
         elif name in ("vx_pwa_attn_fwd", "vx_pwa_attn_bwd"):
             B, M, cq, cv = k[:4]           # (B, M, cq, cv[, dropout site]); windows / tokens come from the model's PWA plan with these head widths
             plan = next((m.plan for m in model.modules() if hasattr(m, "plan") and getattr(m, "c_qk", None) == cq and getattr(m, "c_v", None) == cv), None)
@@ -597,7 +624,13 @@ def roofline_for(name, key, ms_per_launch, model=None):
         r.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
         return r
     r["algorithmic_flops"], r["algorithmic_bytes"] = flops, bytes_
-    if flops / bytes_ > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+    if r.get("split"):
+        ach = flops / (ms_per_launch * 1e-3) / 1e12
+        pk = r["split"]["peak_tflops"]
+        r.update({"bound": "mfma", "achieved": round(ach, 3), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_PEAK_TFLOPS, 4),
+                  "note": "fp32-exact products from bf16 pieces: peak = dense bf16 MFMA peak (%.0f TFLOP/s, MI355X_MICROARCH.md) / %d piece products per pair; "
+                          "achieved = the layer's fp32 flops / time" % (BF16_PEAK_TFLOPS, r["split"]["bf16_mfma_per_pair"])})
+    elif flops / bytes_ > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
         ach = flops / (ms_per_launch * 1e-3) / 1e12
         r.update({"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                   "note": "fp32 kernel above the ridge (%.0f flop/B): fp32 vector = f32-input MFMA peak, MI355X_MICROARCH.md" % (flops / bytes_)})

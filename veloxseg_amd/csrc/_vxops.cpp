@@ -65,6 +65,23 @@ template <class F, class... A> inline void vxcall(const char* name, F f, A&&... 
     PROF.recs.push_back(std::move(r));
 }
 #define VX(fn, ...) vxcall(#fn, fn, __VA_ARGS__)
+// VXR: entries that answer 1 for "shape not covered, use the other kernel" (nothing launched): 0 / 1 are returned, anything else throws; recorded like VX
+template <class F, class... A> inline int vxcall_rc(const char* name, F f, A&&... a) {
+    if (!PROF.on) { const int rc = f(a...); if (rc != 0 && rc != 1) chk(rc, name); return rc; }
+    hipStream_t st = (hipStream_t)last_arg(a...);
+    ProfRec r;
+    r.name = name;
+    (prof_key(r.key, a), ...);
+    TORCH_CHECK(hipEventCreate(&r.e0) == hipSuccess && hipEventCreate(&r.e1) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(r.e0, st) == hipSuccess, "hipEventRecord failed");
+    const int rc = f(a...);
+    if (rc != 0 && rc != 1) chk(rc, name);
+    TORCH_CHECK(hipEventRecord(r.e1, st) == hipSuccess, "hipEventRecord failed");
+    if (rc == 0) PROF.recs.push_back(std::move(r));
+    else { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    return rc;
+}
+#define VXR(fn, ...) vxcall_rc(#fn, fn, __VA_ARGS__)
 inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 inline float* mp(Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 inline Tensor contig(const Tensor& t) { return t.is_contiguous() ? t : t.contiguous(); }
@@ -184,11 +201,9 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
             const long wsn = std::max<long>((long)Cout * 16 * 27, F.expand_split ? (long)vx_expand_split_ws_floats(Cout / 64, F.expand_split) : 0);
             Tensor wt = at::empty({wsn}, x.options());
             if (F.bf16_expand) {
-                rc = vx_expand_fwd_mfma_bf16(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
-                if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma_bf16");
+                rc = VXR(vx_expand_fwd_mfma_bf16, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             } else if (F.expand_split) {
-                rc = vx_expand_fwd_mfma_split(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
-                if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma_split");
+                rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
             }
             if (rc == 1) rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
@@ -246,11 +261,9 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
             Tensor wt = at::empty({wsn}, x.options());
             int rcb = 1;
             if (F.bf16_expand) {
-                rcb = vx_expand_bwd_data_mfma_bf16(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
-                if (rcb != 0 && rcb != 1) chk(rcb, "vx_expand_bwd_data_mfma_bf16");
+                rcb = VXR(vx_expand_bwd_data_mfma_bf16, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
             } else if (F.expand_split) {
-                rcb = vx_expand_bwd_data_mfma_split(fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, stream);
-                if (rcb != 0 && rcb != 1) chk(rcb, "vx_expand_bwd_data_mfma_split");
+                rcb = VXR(vx_expand_bwd_data_mfma_split, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, stream);
             }
             if (rcb == 1) VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
         } else if (st.s1) VX(vx_conv_s1, fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream);
@@ -275,8 +288,7 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                     const long nws = vx_expand_wgrad_split_ws_floats(B, Cout / 64, D, H, W);
                     auto pws = std::make_shared<Tensor>(at::empty({nws}, x.options()));
                     WG.done.push_back([pws](void*) {});
-                    rcw = vx_expand_wgrad_mfma_split(fp(x), fp(dy), dw, db, mp(*pws), nws, B, Cout / 64, D, H, W, F.expand_split, s);
-                    if (rcw != 0 && rcw != 1) chk(rcw, "vx_expand_wgrad_mfma_split");
+                    rcw = VXR(vx_expand_wgrad_mfma_split, fp(x), fp(dy), dw, db, mp(*pws), (long)nws, B, Cout / 64, D, H, W, F.expand_split, s);
                 }
                 if (rcw == 1) {
                     auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
