@@ -238,3 +238,37 @@ def test_taped_step_soak_full_size():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "tape_soak.py"), "autopet128", "2", "60"], env=dict(os.environ, VX_SYNC_EVERY="15"),
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 outliers" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_poll_that_gives_up_is_reported_not_trapped():
+    """a cross-lane poll whose flag never arrives (a lost dependency) gives up after the timeout: it does NOT trap the queue -- its successors run, the
+    give-up is counted in a pinned host word, and the next hop / replay of the process reports it (csrc/tape.hip vx_flag_wait_k, vx_tape_flag_timeouts)"""
+    from veloxseg_amd import _hip as H
+    flag = torch.zeros(4, dtype=torch.int32, device="cuda")
+    marker = torch.zeros(1, device="cuda")
+    s, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    H.query("vx_tape_flag_timeouts")                       # clear
+    H.call("vx_tape_set_flag_timeout_ms", 20)
+    try:
+        H.call("vx_tape_flag_wait", flag.data_ptr(), 7, s.cuda_stream)          # nobody sets the flag to 7
+        with torch.cuda.stream(s):
+            marker.add_(1.0)                               # the successor of the poll
+        s.synchronize()
+        assert float(marker) == 1.0
+        assert H.query("vx_tape_flag_timeouts") == 1
+        assert H.query("vx_tape_flag_timeouts") == 0       # reading clears the count
+        H.call("vx_tape_flag_wait", flag.data_ptr(), 7, s.cuda_stream)
+        s.synchronize()
+        with pytest.raises(RuntimeError, match="gave up"):
+            H.call("vx_tape_hop", 250, s.cuda_stream, s2.cuda_stream)
+        # a flag that does arrive is not a timeout
+        H.call("vx_tape_flag_set", flag.data_ptr(), 9, s2.cuda_stream)
+        H.call("vx_tape_flag_wait", flag.data_ptr(), 9, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert H.query("vx_tape_flag_timeouts") == 0
+        H.call("vx_tape_hop", 250, s.cuda_stream, s2.cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        H.call("vx_tape_set_flag_timeout_ms", 5000)
+        H.query("vx_tape_flag_timeouts")
