@@ -30,6 +30,7 @@ namespace {
 struct Flags {
     bool fuse_blocks = true, use_s1 = true, use_conv_mfma = true, bf16_expand = false, use_expand_mfma = true, use_gconv1 = true, use_wgrad_ws = false, use_patchify = true, use_in_row = true, fuse_gelu = true, fuse_pw_bwd = true, use_down_mfma = true, skip_in_bias = true, in_split2 = true, fuse_res = true, fuse_bwd_add = true;
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
+    int tile_min_c = 32;              // JLC channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*) from this many channels up, mlp.hip below (functional.TILE_MIN_C)
     bool upconv_wgrad_mfma = true;    // (A/B) ConvTranspose weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad) vs the generic strided-conv kernel
     bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
@@ -890,7 +891,7 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
         if (F.fuse_blocks && n == 3 && x.dim() == 5 && ws[0].size(2) == 1 && ws[1].size(2) == 3 && ws[2].size(2) == 5) {
             const int B = x.size(0), C = x.size(1), D = x.size(2), H = x.size(3), W = x.size(4), R = l1w.size(0);
             const long V = (long)D * H * W;
-            const bool mlp_ok = vx_mlp_supported(C, R, V), tile_ok = !mlp_ok && F.jlc_tile && V % 4 == 0 && vx_inmlp_ok(C, R, V);
+            const bool mlp_ok = vx_mlp_supported(C, R, V) && C < F.tile_min_c, tile_ok = !mlp_ok && F.jlc_tile && V % 4 == 0 && vx_inmlp_ok(C, R, V);
             if ((C / G) % 4 == 0 && (mlp_ok || tile_ok) && bs[0].defined() && bs[1].defined() && bs[2].defined()) {
                 check_in(x, "jlc");
                 JLCFusedState& f = st->f;
@@ -1270,6 +1271,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
     m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
+    m.def("set_tile_min_c", [](int64_t c) { F.tile_min_c = (int)c; });
     m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });
     m.def("set_jlc_tile", [](bool on) { F.jlc_tile = on; });      // A/B (tests): JLC block of the coarse levels fused (default) or per operator
     m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels

@@ -443,8 +443,10 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     VX_REQUIRE(labels && acc && lab_kind >= 0 && lab_kind <= 2, "vx_seg_loss_ds_fwd: bad labels / accumulator");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nh * (1 + (size_t)B * C * 3), st) != hipSuccess) VX_FAIL(-2, "vx_seg_loss_ds_fwd: memset failed");
-    P.nsplit = 1;                                                      // >= ~2048 blocks: the kernel waits on its logit / label loads, occupancy hides them
-    while ((long)D * B * P.nsplit < 2048 && (long)H * (W >> 2) / (P.nsplit * 2) >= 256) P.nsplit *= 2;
+    // blocks per Z slice: every block stages the slice's interpolated grids, so a split repeats that work -- worth it only while a part keeps >= 4 sweeps of 256 quads
+    // (measured alone: 96^3 x 4: 1 / 2 / 4 / 8 parts = 75 / 65 / 93 / 137 us; 128^3 x 4: 135 / 136 / 142 / 175 us; in the step 128^3 is 0.25 % faster with 4 parts than with 1)
+    P.nsplit = 1;
+    while ((long)D * B * P.nsplit < 2048 && (long)H * (W >> 2) / (P.nsplit * 2) >= 1024) P.nsplit *= 2;
     const dim3 grid(D * P.nsplit, B), blk(256);
     size_t shm = vx_ds_slice_floats(P, C) * sizeof(float);
     P.stage = shm <= 120 * 1024;          // else: 8-tap gathers from global memory

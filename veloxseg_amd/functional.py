@@ -220,6 +220,7 @@ def cpp_module(reload: bool = False):
                 _vxops.set_fuse_gelu(os.environ.get("VELOXSEG_FUSE_GELU", "1") != "0")
                 _vxops.set_down_mfma(USE_DOWN_MFMA)
                 _vxops.set_expand_split(EXPAND_SPLIT)
+                _vxops.set_tile_min_c(TILE_MIN_C)
                 _vxops.set_fuse_pw_bwd(os.environ.get("VELOXSEG_FUSE_PW_BWD", "1") != "0")
                 _vxops.set_flags(USE_S1, USE_EXPAND_MFMA, USE_GCONV1, USE_WGRAD_WS, USE_PATCHIFY, USE_IN_ROW, PW_MFMA_MAX_V, IN_ROW_MAX, IN_EPS, LN_EPS)
                 _CPP[1] = _vxops
@@ -880,6 +881,10 @@ def ffn_tail(y, norm, ffn, p: float):
 # ------------------------------------------------------------------------------------------------
 # fused per-voxel chains of a PWA transformer block, all modalities in one launch (csrc/pwa_fused.hip)
 # ------------------------------------------------------------------------------------------------
+# channel stages (FFN tail of a PWA block, channel MLP of a JLC block) with >= this many channels run on the tile-GEMM chains of csrc/pwa_fused.hip (pwa_post / inmlp +
+# grouped weight gradients) even where csrc/mlp.hip has an instance: at C = 32 (16^3 grids) mlp.hip's per-block weight staging and in-kernel weight-gradient
+# flush cost 45-90 us per launch for 0.5 GFLOP; the tile kernels take 15-25 us (autopet128 747 -> 756 patches/s, autopet96 1061 -> 1079)
+TILE_MIN_C = int(os.environ.get("VELOXSEG_TILE_MIN_C", "32"))
 USE_PWA_FUSED = os.environ.get("VELOXSEG_PWA_FUSED", "1") != "0"      # A/B: 0 = LN, q / k / v, mix, FFN as separate launches per modality
 
 

@@ -122,7 +122,7 @@ class MultiModal_Paired_Windows_Attention(nn.Module):
         key = ("post", V, R)
         ok = self._fused_ok.get(key)
         if ok is None:
-            ok = self._fused_ok[key] = (VF.pwa_post_ok(C, self.channels_v, R, V) and not bool(H.query("vx_mlp_supported", C, R, V))
+            ok = self._fused_ok[key] = (VF.pwa_post_ok(C, self.channels_v, R, V) and (not bool(H.query("vx_mlp_supported", C, R, V)) or C >= VF.TILE_MIN_C)
                                         and all(f.p == ffns[0].p for f in ffns))
         return ok
 
