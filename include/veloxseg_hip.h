@@ -295,7 +295,8 @@ int vx_pwa_attn_bwd1_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
  * 16w .. 16w+15, bit k & 15, 1 = kept; vx_pwa_attn_mbits_words = number of uint16 -- and the one-pass backward reads it instead of drawing the Philox words
  * again (the draw is ~1/3 of the backward's per-pair instruction count).  `mbits` NULL or p_drop == 0: exactly vx_pwa_attn_fwd / _bwd / _bwd_nofold. */
 int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M);
-int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv);   /* 1: the one-pass backward is selected for this geometry and reading the bits beats re-drawing (l % 4 != 0) */
+int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+int vx_pwa_attn_set_valu_bits(int on);      /* A/B (tests): 1 = the fp32-VALU backward reads the forward's keep bits where windows are aligned (default 0: measured no faster) */   /* 1: the one-pass backward is selected for this geometry and reading the bits beats re-drawing (l % 4 != 0) */
 int vx_pwa_attn_fwd_mb(const float* q, const float* k, const float* v, const float* table, float* out, float* lse, const VxPwaPlan* plan, int B, int M, int cq, int cv,
                        const void* seed_ptr, unsigned long long dstream, float p_drop, void* mbits, void* stream);
 int vx_pwa_attn_bwd_mb(const float* q, const float* k, const float* v, const float* table, const float* out, const float* lse, const float* dout,

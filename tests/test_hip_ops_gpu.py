@@ -693,6 +693,47 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
             close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma (mask {on}) vs valu tensor {i}")
 
 
+@pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 1),
+                                                    ([8, 8, 16], [4, 4, 8], 2, 8, 32, 3)],
+                         ids=["L2_512tok", "L1_64tok", "M1", "M3_aniso"])
+def test_pwa_attention_valu_backward_reads_the_forwards_keep_bits(grid, big, heads, mdh, C, M):
+    """With aligned windows (l % 4 == 0: every 128^3 geometry) the fp32-VALU backward reads the dropout keep bits the forward stored (one 16-bit word per
+    query and 16-key tile) in BOTH of its passes instead of re-drawing the Philox words: the masks are the same bits, so dq / dk / dv and the bias-table
+    gradient equal those of the re-drawing kernels to float-atomic noise; the forward (MFMA or VALU) is unchanged.  (An A/B variant, off by default: the
+    backward is bound by LDS latency, not by the Philox arithmetic, and the step time did not move.)"""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    pp = H.ctypes.addressof(plan)
+    n = pl["n"]
+    base = []
+    for m in range(M):
+        base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
+    res = {}
+    try:
+        for bits in (1, 0):
+            H.call("vx_pwa_attn_set_valu_bits", bits)
+            assert H.query("vx_pwa_attn_bwd1_ok", pp, 2, M, pl["c_qk"], pl["c_v"]) == 0          # the default rule keeps these geometries on the VALU backward
+            assert H.query("vx_pwa_attn_mbits_useful", pp, 2, M, pl["c_qk"], pl["c_v"]) == bits
+            VF.manual_seed(77, d)
+            table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=0.2, site=9)
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gouts)
+            torch.cuda.synchronize()
+            res[bits] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
+    finally:
+        H.call("vx_pwa_attn_set_valu_bits", 0)
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        if i < M:
+            assert torch.equal(a, b), f"output {i}: the forward must not depend on whether it stores the keep bits"
+        else:
+            close(a, b, 2e-5 * max(1.0, float(b.abs().max())), 1e-4, f"keep bits vs re-drawn words, tensor {i}")
+
+
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),
                                                     ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 3)],
                          ids=["c8v8", "c8v16", "c16v32", "c4v8", "c4v4_M3"])

@@ -54,5 +54,23 @@ for name, levels in LEVELS.items():
             torch.cuda.synchronize()
             out.append(f"{e0.elapsed_time(e1) / 20 * 1e3:7.1f}")
         H.call("vx_pwa_attn_set_mfma", 3)
+        # the VALU kernels reading the forward's keep bits (aligned windows) vs re-drawing the Philox words
+        vb = []
+        for use in (True, False):
+            def run2():
+                H.call("vx_pwa_attn_bwd_mb", H.P(tq), H.P(tk), H.P(tv), H.P(table), H.P(Oo), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv), H.P(dt), H.P(ws), pp, B, M, cq, cv,
+                       H.P(rs, torch.int64), 5, p, H.P(mbits, torch.int16) if use else None, st)
+            H.call("vx_pwa_attn_set_mfma", 0)
+            for _ in range(3):
+                run2()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run2()
+            e1.record()
+            torch.cuda.synchronize()
+            vb.append(e0.elapsed_time(e1) / 20 * 1e3)
+        H.call("vx_pwa_attn_set_mfma", 3)
+        print(f"      VALU backward with the forward's keep bits {vb[0]:7.1f} us, re-drawing {vb[1]:7.1f} us")
         pairs = B * heads * Nt * ML * ML
         print(f"{name}^3 L{L}: l={plan.l:4d} ML={ML:5d} windows={B * heads * Nt:5d} c_qk/c_v={cq}/{cv}  pairs={pairs / 1e6:7.1f}M   one-pass {out[0]} us (Philox again: {out[1]}) | two-kernel MFMA {out[2]} us | VALU {out[3]} us", flush=True)

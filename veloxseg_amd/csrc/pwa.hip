@@ -730,7 +730,7 @@ template <int CQ, int CV>
 __device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                    const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                    const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                   float* __restrict__ dtable_rep, int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head) {
+                                                   float* __restrict__ dtable_rep, int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head, const unsigned short* __restrict__ mbits = nullptr) {
     constexpr int RS = CQ + CV;
     // lin | bias tables | bias-gradient tables | [4] K/V slabs.  one_head (every unit of a block belongs to one head: launcher): ONE bias column and ONE
     // bias-gradient table shared by the block's waves (they reach it through ds_add_f32 only); else all heads and a table per unit.
@@ -777,6 +777,10 @@ __device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* _
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     const uint64_t drow = (uint64_t)row * (uint64_t)A.ML;
+    // keep bits written by the forward (vx_pwa_attn_fwd_mb) instead of re-drawing the Philox words: one 2-byte load per 4 pairs against a quarter of a
+    // Philox4x32-7 call (~25 issue slots per pair).  Aligned windows only (l % 4 == 0): a quad of keys then sits inside one 16-key word
+    const bool use_bits = mbits != nullptr && dc.on && al4 && ((A.l & 3) == 0);
+    const unsigned short* __restrict__ mbq = use_bits ? mbits + win * ((A.ML + 15) >> 4) * A.ML + iq : nullptr;
     // Keys are walked TOKEN-major: a slab holds TS tokens x M modalities (row m*TS + tt <-> key m*l + t0 + tt).  The M keys of a token share
     // the relative-position bin, so their ds are summed in registers and ONE ds_add_f32 per token reaches the bias-gradient table instead
     // of one per key (LDS float atomics retire ~1 lane per clock: they were 70 % of this kernel).
@@ -817,6 +821,12 @@ __device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* _
             for (int mk = 0; mk < A.M; ++mk) {
                 float m4[4];
                 const uint64_t kidx = drow + (uint64_t)mk * A.l + t0 + tt;
+                if (use_bits) {        // the forward's keep bits: word (key tile, query), bit = key & 15; the 4 keys of an aligned quad share a word
+                    const int jkey = mk * A.l + t0 + tt;
+                    const unsigned w = (unsigned)mbq[(long)(jkey >> 4) * A.ML] >> (jkey & 15);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) m4[t] = ((w >> t) & 1u) ? dc.inv_keep : 0.0f;
+                } else
                 vx_drop4(dc, kidx, al4 && ((A.l & 3) == 0), m4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -894,8 +904,8 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_q_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ Delta,
-                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
-    vx_attn_bwd_q_body<CQ, CV>((int)blockIdx.x, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head);
+                                                           float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head, const unsigned short* __restrict__ mbits) {
+    vx_attn_bwd_q_body<CQ, CV>((int)blockIdx.x, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head, mbits);
 }
 
 // backward B: lane = key row.  dK, dV.  Query-side rows (q, dO, lse, delta) are staged per wave in LDS; the S splits of a unit walk
@@ -908,7 +918,7 @@ __device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbi
                                                     const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                     const float* __restrict__ O, const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
                                                     const float* __restrict__ dtable_rep, float* __restrict__ dtable,
-                                                    int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head) {
+                                                    int Tsz, const VxAttn& A, const VxDrop& drop, int S, int one_head, const unsigned short* __restrict__ mbits = nullptr) {
     constexpr int RS = CQ + CV + 4;          // q[CQ], dO[CV], lse, delta, pad
     if (Delta) {   // fold the dQ kernel's replicated bias-gradient tables into dtable (it ran before this kernel on the same stream): one owner thread per entry
         for (long k = (long)bid * 256 + threadIdx.x; k < (long)Tsz * A.heads; k += (long)nbid * 256) {
@@ -953,6 +963,8 @@ __device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbi
     const float* __restrict__ qp = Q + win * A.ML * CQ;
     const float* __restrict__ dop = dO + win * A.ML * CV;
     const int qt = lane & 3;
+    const bool use_bits = mbits != nullptr && dc.on && al4 && ((A.l & 3) == 0);
+    const unsigned short* __restrict__ mbk = use_bits ? mbits + (win * ((A.ML + 15) >> 4) + (jk >> 4)) * A.ML : nullptr;
     for (int i0 = split * VX_KV_ROWS; i0 < A.ML; i0 += S * VX_KV_ROWS) {
         const int nq = min(VX_KV_ROWS, A.ML - i0);
         int ti = i0 % A.l;
@@ -978,6 +990,13 @@ __device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbi
             float m4[4];
             if (!dc.on) {
                 m4[0] = m4[1] = m4[2] = m4[3] = 1.0f;
+            } else if (use_bits) {                     // the forward's keep bits of rows i0+ii .. +3 for this key's tile: four 16-bit words = one 8-byte load
+                const uint2 w2 = *reinterpret_cast<const uint2*>(mbk + i0 + ii);
+                const unsigned sh = (unsigned)(jk & 15);
+                m4[0] = ((w2.x >> sh) & 1u) ? dc.inv_keep : 0.0f;
+                m4[1] = ((w2.x >> (16 + sh)) & 1u) ? dc.inv_keep : 0.0f;
+                m4[2] = ((w2.y >> sh) & 1u) ? dc.inv_keep : 0.0f;
+                m4[3] = ((w2.y >> (16 + sh)) & 1u) ? dc.inv_keep : 0.0f;
             } else if (al4) {                          // ML % 4 == 0: quads are counter-aligned for every row, nq % 4 == 0
                 uint32_t r[4], w[4];
                 const uint64_t idx = ((uint64_t)(win * A.ML + i0 + ii + qt)) * (uint64_t)A.ML + (uint64_t)(jk & ~3);
@@ -1042,8 +1061,8 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_kv_k(const float* __restr
                                                             const float* __restrict__ table, const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                             const float* __restrict__ dO, float* __restrict__ dK, float* __restrict__ dV,
                                                             const float* __restrict__ dtable_rep, float* __restrict__ dtable,
-                                                            int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
-    vx_attn_bwd_kv_body<CQ, CV>((int)blockIdx.x, (int)gridDim.x, Q, K, Vt, table, LSE, Delta, nullptr, dO, dK, dV, dtable_rep, dtable, Tsz, A, drop, S, one_head);
+                                                            int Tsz, VxAttn A, VxDrop drop, int S, int one_head, const unsigned short* __restrict__ mbits) {
+    vx_attn_bwd_kv_body<CQ, CV>((int)blockIdx.x, (int)gridDim.x, Q, K, Vt, table, LSE, Delta, nullptr, dO, dK, dV, dtable_rep, dtable, Tsz, A, drop, S, one_head, mbits);
 }
 // Both passes in ONE launch: even blocks run the dQ pass, odd blocks the dK / dV pass of the same block index.  Each pass alone leaves the SIMDs waiting
 // (dQ: 53 % of its wave cycles in s_waitcnt, dK/dV: 31 % + 20 % stalled; profiles/r02_sq_wave_breakdown.txt); interleaved on the same CUs they fill each
@@ -1052,10 +1071,11 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(256) vx_pwa_attn_bwd_both_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                               const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                               const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
-                                                              float* __restrict__ Delta, float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head) {
+                                                              float* __restrict__ Delta, float* __restrict__ dtable_rep, int Tsz, VxAttn A, VxDrop drop, int S, int one_head,
+                                                              const unsigned short* __restrict__ mbits) {
     const int bid = (int)(blockIdx.x >> 1);
-    if (blockIdx.x & 1) vx_attn_bwd_kv_body<CQ, CV>(bid, (int)(gridDim.x >> 1), Q, K, Vt, table, LSE, nullptr, O, dO, dK, dV, nullptr, nullptr, Tsz, A, drop, S, one_head);
-    else vx_attn_bwd_q_body<CQ, CV>(bid, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head);
+    if (blockIdx.x & 1) vx_attn_bwd_kv_body<CQ, CV>(bid, (int)(gridDim.x >> 1), Q, K, Vt, table, LSE, nullptr, O, dO, dK, dV, nullptr, nullptr, Tsz, A, drop, S, one_head, mbits);
+    else vx_attn_bwd_q_body<CQ, CV>(bid, Q, K, Vt, table, O, LSE, dO, dQ, Delta, dtable_rep, Tsz, A, drop, S, one_head, mbits);
 }
 // dtable[k] += sum over the replicas (vx_pwa_attn_bwd_both_k's dQ blocks filled them)
 __global__ void __launch_bounds__(256) vx_attn_fold_k(const float* __restrict__ rep, float* __restrict__ dtable, long n, int nrep) {
@@ -1285,6 +1305,10 @@ int vx_pwa_attn_mfma_bwd(const float* Q, const float* K, const float* V, const f
                          float* dK, float* dV, float* dtable, float* delta, float* rep, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d,
                          void* stream);
 
+// OFF by default: the VALU backward is bound by the latency of its LDS slab reads (53 % / 31 % of the wave cycles in s_waitcnt, profiles/r02_sq_wave_breakdown.txt),
+// not by its VALU work -- with the bits read back the step is unchanged (746-749 vs 748-751 patches/s): the path stays as a tested A/B variant
+static int vx_attn_valu_bits = 0;
+extern "C" int vx_pwa_attn_set_valu_bits(int on) { vx_attn_valu_bits = on ? 1 : 0; return 0; }      // A/B (tests, probes): the VALU backward reads the forward's keep bits
 extern "C" int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M) {
     VxAttn A;
     if (int e = vx_attn_fill(A, plan, B, M, 4, 4, "vx_pwa_attn_mbits_words")) return e;
@@ -1296,7 +1320,10 @@ extern "C" int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M) {
 // ELEMENT (l % 4 != 0: the 4 queries of a lane do not share a counter); with aligned windows re-drawing costs the same as reading the bits back
 extern "C" int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv) {
     if (plan == nullptr) return 0;
-    return (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) == 1 && (plan->l & 3) != 0) ? 1 : 0;
+    if (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) == 1) return (plan->l & 3) != 0 ? 1 : 0;
+    // the fp32-VALU backward evaluates the soft-max side of a pair TWICE (dQ pass, dK/dV pass): with aligned windows both passes read the bits back
+    if (vx_attn_valu_bits && (plan->l & 3) == 0 && !(vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2)) return 1;
+    return 0;
 }
 extern "C" int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float* table, float* O, float* LSE,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
@@ -1437,13 +1464,13 @@ static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, c
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
         if (vx_attn_bwd_fused) {
             const size_t shm2 = shm > shm_kv ? shm : shm_kv;
-            vx_pwa_attn_bwd_both_k<CQ, CV><<<dim3(2 * nblk), dim3(256), shm2, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws, rep, Tsz, A, d, S, one_head);
+            vx_pwa_attn_bwd_both_k<CQ, CV><<<dim3(2 * nblk), dim3(256), shm2, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, delta_ws, rep, Tsz, A, d, S, one_head, mbits);
             const long nt = (long)Tsz * A.heads;
             if (fold) vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
             return;
         }
-        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S, one_head);
-        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S, one_head);
+        vx_pwa_attn_bwd_q_k<CQ, CV><<<dim3(nblk), dim3(256), shm, (hipStream_t)stream>>>(Q, K, V, table, O, LSE, dO, dQ, delta_ws, rep, Tsz, A, d, S, one_head, mbits);
+        vx_pwa_attn_bwd_kv_k<CQ, CV><<<dim3(nblk), dim3(256), shm_kv, (hipStream_t)stream>>>(Q, K, V, table, LSE, delta_ws, dO, dK, dV, rep, dtable, Tsz, A, d, S, one_head, mbits);
     });
     if (!found) VX_FAIL(-3, "PWA attention: unsupported head widths c_qk=%d c_v=%d", cq, cv);
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd");
