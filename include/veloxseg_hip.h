@@ -83,7 +83,8 @@ int vx_expand_fwd_mfma(const float* x, const float* w, const float* bias, float*
 /* patch-expand weight (+bias) gradient on fp32 MFMA: x (B,16,D,H,W) coarse input, xcl_ws = B*D*H*W*16 floats (channels-last copy made here),
  * dy_fine (B,Cc,4D,4H,4W); dw (64*Cc,16,3,3,3) +=, db (64*Cc) += */
 int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, float* dw, float* db, int B, int Cc, int D, int H, int W, void* stream);
-/* the same weight gradient with every product formed from ns bf16 pieces per fp32 operand (ns = 3: fp32-exact products, fp32 accumulation); x is read in
+/* the same weight gradient with every product formed from ns bf16 pieces per fp32 operand (ns = 3: fp32-exact products, fp32 accumulation; ns = 1: plain
+   bf16 operands, the bf16 opt-in mode); x is read in
    its own (B, 16, D, H, W) layout.  part_ws: vx_expand_wgrad_split_ws_floats(...) floats of partial sums, added into dw in a fixed order (reproducible).
    Returns 1 when W % 4 != 0 (use vx_expand_wgrad_mfma). */
 int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int W);

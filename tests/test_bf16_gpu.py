@@ -37,13 +37,11 @@ def test_patch_expand_bf16_operands_stay_within_bf16_rounding(Cout):
         gy = torch.randn(y.shape, device=d, generator=torch.Generator(device=d).manual_seed(1))
         y.backward(gy)
         res[mode] = (y.detach(), xx.grad.clone(), ww.grad.clone())
-    for i, what in enumerate(("output", "input gradient")):
+    for i, what in enumerate(("output", "input gradient", "weight gradient")):      # (round 3: the weight gradient runs with bf16 operands too)
         a, r = res["bf16"][i], res["fp32"][i]
         rel = float((a - r).norm() / r.norm())
         assert 1e-4 < rel < 5e-3, (what, rel)            # really bf16 operands (not the fp32 kernel), and no worse than their rounding
         assert float((a - r).abs().max()) < 1e-2 * float(r.abs().max()), what
-    a, r = res["bf16"][2], res["fp32"][2]                # the weight gradient stays on the fp32 kernel
-    assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
 
 
 @pytest.mark.parametrize("workload", ["brats128", "autopet128"])

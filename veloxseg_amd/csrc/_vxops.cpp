@@ -285,11 +285,12 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 VX(vx_gconv1_bwd_weight, fp(x), fp(dy), dw, db, B, Cin, G, V, s);
             else if (s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
                 int rcw = 1;
-                if (F.expand_split >= 2 && F.expand_wgrad_split) {        // fp32-exact products on the bf16 pipe (expand_mfma.hip vx_expand_wgrad_split_k)
+                const int wns = F.bf16_expand ? 1 : F.expand_split;       // bf16 opt-in mode: plain bf16 operands (one piece), fp32 accumulation
+                if (wns >= 1 && F.expand_wgrad_split) {                   // fp32 mode: fp32-exact products on the bf16 pipe (expand_mfma.hip vx_expand_wgrad_split_k)
                     const long nws = vx_expand_wgrad_split_ws_floats(B, Cout / 64, D, H, W);
                     auto pws = std::make_shared<Tensor>(at::empty({nws}, x.options()));
                     WG.done.push_back([pws](void*) {});
-                    rcw = VXR(vx_expand_wgrad_mfma_split, fp(x), fp(dy), dw, db, mp(*pws), (long)nws, B, Cout / 64, D, H, W, F.expand_split, s);
+                    rcw = VXR(vx_expand_wgrad_mfma_split, fp(x), fp(dy), dw, db, mp(*pws), (long)nws, B, Cout / 64, D, H, W, wns, s);
                 }
                 if (rcw == 1) {
                     auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));

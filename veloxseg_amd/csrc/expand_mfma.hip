@@ -904,6 +904,7 @@ __global__ void __launch_bounds__(256) vx_expand_wimg_split_k(const float* __res
 }
 // the piece products that are kept, smallest first: (activation piece, weight piece)
 template <int NS> struct VxSplitTerms;
+template <> struct VxSplitTerms<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int W[1] = {0}; };      // plain bf16 operands (the bf16 opt-in mode's weight gradient)
 template <> struct VxSplitTerms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int W[3] = {0, 1, 0}; };
 template <> struct VxSplitTerms<3> { static constexpr int N = 6; static constexpr int A[6] = {1, 2, 0, 1, 0, 0}; static constexpr int W[6] = {1, 0, 2, 0, 1, 0}; };
 
@@ -1317,7 +1318,7 @@ extern "C" int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int 
 // returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernel), 0 on success.  part_ws: vx_expand_wgrad_split_ws_floats floats
 extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
                                           int ns, void* stream) {
-    VX_REQUIRE(x && dy_fine && dw && part_ws && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_wgrad_mfma_split: bad args");
+    VX_REQUIRE(x && dy_fine && dw && part_ws && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && ns >= 1 && ns <= 3, "vx_expand_wgrad_mfma_split: bad args");
     if (W % 4 != 0) return 1;
     int HL, nHs, nWc;
     vx_wgs_plan(B, Cc, D, H, W, HL, nHs, nWc);
@@ -1328,7 +1329,8 @@ extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, 
     const size_t lds = shm > need ? shm : need;
     const int nUnits = (int)(nStrips * Cc);
     dim3 grid((unsigned)(((nUnits + 7) / 8) * 8 * 3));
-    if (ns == 2) vx_expand_wgrad_split_k<2><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    if (ns == 1) vx_expand_wgrad_split_k<1><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    else if (ns == 2) vx_expand_wgrad_split_k<2><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
     else vx_expand_wgrad_split_k<3><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
     vx_expand_wgrad_fold_k<<<vx_cdiv((long)Cc * 3 * 2304, 16), 256, 0, (hipStream_t)stream>>>(part_ws, dw, Cc, D, (int)nStrips, nHs * nWc);
     VX_LAUNCH_CHECK("vx_expand_wgrad_mfma_split");
