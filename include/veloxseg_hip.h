@@ -281,6 +281,8 @@ int vx_pwa_attn_bwd_nofold(const float* Q, const float* K, const float* V, const
                            const VxPwaPlan* plan, int B, int M, int cq, int cv,
                            const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
 int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const VxPwaPlan* plan, int B, int M, void* stream);
+/* the folds of up to 8 vx_pwa_attn_bwd_nofold* calls (same B, M) in one launch: host arrays of the calls' delta_ws / dtable / plan pointers */
+int vx_pwa_attn_bwd_fold_many(const float* const* delta_ws, float* const* dtables, const VxPwaPlan* const* plans, int count, int B, int M, void* stream);
 /* tuning knob of the two entries above: key/query split per 64-row unit (0 = automatic from the unit count, else 1, 2 or 4; clamped to the
  * number of 64-row slabs).  Results are identical up to fp32 summation order; the dropout mask does not depend on it. */
 int vx_pwa_attn_set_split(int S);

@@ -16,10 +16,14 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <map>
+#include <tuple>
 #include <functional>
 #include <type_traits>
 #include <memory>
 #include <vector>
+#include <map>
+#include <tuple>
 #include "../../include/veloxseg_hip.h"
 
 using at::Tensor;
@@ -118,6 +122,11 @@ struct WgradSide {
     std::vector<std::function<void(void*)>> done;                            // launched, kept alive until the final join
 } WG;
 
+struct AttnFoldPool { std::vector<Tensor> delta, keep; std::vector<float*> dtab; std::vector<VxPwaPlan> plans; };
+inline AttnFoldPool& attn_fold_pool(void* stream, int B, int M) {
+    static std::map<std::tuple<void*, int, int>, AttnFoldPool> pools;
+    return pools[std::make_tuple(stream, B, M)];
+}
 inline hipStream_t wg_stream(int dev) {
     if (!WG.stream.has_value()) {
         WG.stream = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, (c10::DeviceIndex)dev);
@@ -774,9 +783,26 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
                                               st.rs, (unsigned long long)st.site, (float)st.p, st.mbits.defined() ? st.mbits.data_ptr() : nullptr, s_);
             if (rc_nf != 0 && rc_nf != 1) chk(rc_nf, "vx_pwa_attn_bwd_nofold");
             if (rc_nf == 0) {
-                const VxPwaPlan plan_copy = st.plan;
-                Tensor keep_tmp = dtab_tmp;
-                wgrad_submit(s_, dq.device().index(), [=](void* s) { VX(vx_pwa_attn_bwd_fold, fp(delta), dtab, &plan_copy, B, M, s); (void)keep_tmp; });
+                // the folds of the pass's attention backward calls (one per transformer level) are pooled per (stream, B, M) and leave in ONE launch
+                // when the queue is joined: four launches of 2-27 blocks at the launch floor were 41 us at the very end of the encoder backward
+                AttnFoldPool& pool = attn_fold_pool(s_, B, M);
+                const bool first = pool.delta.empty();
+                pool.delta.push_back(delta); pool.keep.push_back(dtab_tmp); pool.dtab.push_back(dtab); pool.plans.push_back(st.plan);
+                if (first) {
+                    const int dev = dq.device().index();
+                    const int Bc = B, Mc = M;
+                    wgrad_submit(s_, dev, [s_, Bc, Mc](void* s) {
+                        AttnFoldPool p = std::move(attn_fold_pool(s_, Bc, Mc));
+                        attn_fold_pool(s_, Bc, Mc) = AttnFoldPool();
+                        for (size_t lo = 0; lo < p.delta.size(); lo += 8) {
+                            const int cnt = (int)std::min<size_t>(8, p.delta.size() - lo);
+                            const float* dl[8]; float* dt[8]; const VxPwaPlan* pl[8];
+                            for (int j = 0; j < cnt; ++j) { dl[j] = p.delta[lo + j].data_ptr<float>(); dt[j] = p.dtab[lo + j]; pl[j] = &p.plans[lo + j]; }
+                            VX(vx_pwa_attn_bwd_fold_many, dl, dt, pl, cnt, Bc, Mc, s);
+                        }
+                        WG.done.push_back([p](void*) {});        // delta / temporary tables stay alive until the final join
+                    });
+                }
             }
         }
         if (rc_nf == 1)

@@ -1422,6 +1422,36 @@ extern "C" int vx_pwa_attn_bwd_fold(const float* delta_ws, float* dtable, const 
     VX_LAUNCH_CHECK("vx_pwa_attn_bwd_fold");
     return 0;
 }
+// the folds of up to 8 attention backward passes (e.g. the four transformer levels of one step) in ONE launch: each was a 2-27-block launch at the launch
+// floor, one after the other at the end of the encoder backward
+struct VxFoldMany { const float* rep[8]; float* dt[8]; long n[8]; };
+__global__ void __launch_bounds__(256) vx_attn_fold_many_k(VxFoldMany P, int nrep) {
+    const int j = blockIdx.y;
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= P.n[j]) return;
+    float g = 0.0f;
+    for (int r = 0; r < nrep; ++r) g += P.rep[j][(long)r * P.n[j] + k];
+    P.dt[j][k] += g;
+}
+extern "C" int vx_pwa_attn_bwd_fold_many(const float* const* delta_ws, float* const* dtables, const VxPwaPlan* const* plans, int count, int B, int M, void* stream) {
+    VX_REQUIRE(delta_ws && dtables && plans && count >= 1 && count <= 8, "vx_pwa_attn_bwd_fold_many: bad args");
+    VxFoldMany P = {};
+    long nmax = 0;
+    for (int j = 0; j < count; ++j) {
+        VxAttn A;
+        if (int e = vx_attn_fill(A, plans[j], B, M, 4, 4, "vx_pwa_attn_bwd_fold_many")) return e;
+        VX_REQUIRE(delta_ws[j] && dtables[j], "vx_pwa_attn_bwd_fold_many: null pointer");
+        const long Tsz = (long)(2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+        const long rows = (long)A.BH * A.Nt * A.ML;
+        P.rep[j] = delta_ws[j] + ((rows + 3) & ~3L);
+        P.dt[j] = dtables[j];
+        P.n[j] = Tsz * A.heads;
+        nmax = P.n[j] > nmax ? P.n[j] : nmax;
+    }
+    vx_attn_fold_many_k<<<dim3((unsigned)vx_cdiv(nmax, 256), (unsigned)count), dim3(256), 0, (hipStream_t)stream>>>(P, VX_DTABLE_REPLICAS);
+    VX_LAUNCH_CHECK("vx_pwa_attn_bwd_fold_many");
+    return 0;
+}
 static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
