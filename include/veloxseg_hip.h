@@ -454,6 +454,9 @@ int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int nj, const v
  * vx_tape_replay enqueues behind `stream` and joins every lane back into it before returning (it never blocks the host). */
 typedef struct VxTape VxTape;
 int vx_tape_build(void* hip_graph, int max_lanes, VxTape** out);
+/* the same with a profile-guided layout: dur_us[i] = measured duration of node i of the tape vx_tape_build makes of this graph (vx_tape_profile); nodes are
+   list-scheduled (longest remaining path first, earliest-start lane) instead of laid out greedily in capture order */
+int vx_tape_build_pgo(void* graph, int max_lanes, const float* dur_us, int n, VxTape** out);
 int vx_tape_info(const VxTape* tape, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events);
 int vx_tape_replay(VxTape* tape, void* stream);
 int vx_tape_free(VxTape* tape);

@@ -87,23 +87,26 @@ def test_engine_tape_replay_tracks_the_eager_engine():
     x, lab = x.cuda(), lab.cuda()
     crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)
     res = {}
-    for mode in ("eager", "tape", "graph"):
+    import veloxseg_amd.engine as E
+    for mode in ("eager", "tape", "tape_pgo", "graph"):      # tape_pgo: the encoder tapes laid out again from measured node durations (vx_tape_build_pgo)
         VF.reset_dropout_sites()
         torch.manual_seed(11)
         model = VeloxSeg(**cfg_d).cuda()
         VF.manual_seed(77, "cuda")
+        E.TAPE_PGO = mode == "tape_pgo"                  # (read when the first step captures)
         eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=mode != "eager", replay="graph" if mode == "graph" else "tape", overlap=False)
         losses = []
         for it in range(4):
             losses.append(float(eng.step(x, lab)))
             torch.cuda.synchronize()
+        E.TAPE_PGO = False
         assert eng.use_graph == (mode != "eager"), "self-check of the captured stages failed: the engine fell back to eager launches"
-        if mode == "tape":
+        if mode in ("tape", "tape_pgo"):
             tapes = [eng.graphs["enc_fwd"], eng.graphs["enc_bwd"]] + eng.graphs["dec_fwd"] + eng.graphs["dec_bwd"]
             assert all(t.n_kernels > 0 for t in tapes) and eng.graphs["enc_fwd"].n_lanes >= 2      # modality / conv-chain branches on their own lanes
         res[mode] = (losses, eng.flat.param.detach().clone())
         del eng, model
-    for mode in ("tape", "graph"):
+    for mode in ("tape", "tape_pgo", "graph"):
         for a, b in zip(res[mode][0], res["eager"][0]):
             assert abs(a - b) <= 2e-3 * abs(b), (mode, res[mode][0], res["eager"][0])
         assert float((res[mode][1] - res["eager"][1]).abs().max()) < 2e-3, mode

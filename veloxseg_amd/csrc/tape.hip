@@ -293,7 +293,14 @@ extern "C" int vx_tape_lane_stream(void* any_stream, int lane, void** out) {
     return 0;
 }
 
-extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
+// dur != nullptr: PROFILE-GUIDED layout.  dur[i] = measured duration (us) of node i of the tape that vx_tape_build lays out for the same graph
+// (vx_tape_profile): the nodes are then list-scheduled -- longest remaining path first, each on the lane where it can start earliest (a hop between
+// lanes costs VX_TAPE_HOP_US, every node VX_TAPE_GAP_US of dispatch gap) -- and the tape replays them in that order on those lanes.  The greedy layout of
+// vx_tape_build knows no durations: it continues a predecessor's lane with whichever successor was captured first, which parks sinks (deferred weight
+// gradients) on the longest lane while another is nearly idle.
+#define VX_TAPE_HOP_US 3.0f
+#define VX_TAPE_GAP_US 2.0f
+static int tape_build_impl(void* graph_, int max_lanes, const float* dur, int ndur, VxTape** out) {
     VX_REQUIRE(graph_ && out && max_lanes >= 1 && max_lanes <= 16, "vx_tape_build: bad arguments");
     hipGraph_t graph = (hipGraph_t)graph_;
     size_t nn = 0, ne = 0;
@@ -380,6 +387,49 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
     std::vector<int> real;
     for (int u : order) if (kind[u] >= 0) { pos[u] = (int)real.size(); real.push_back(u); }
     const int R = (int)real.size();
+    std::vector<int> pre_lane;                          // profile-guided: lane of node i of the (re-ordered) list
+    if (dur != nullptr && R > 1 && max_lanes > 1) {
+        VX_REQUIRE(ndur == R, "vx_tape_build_pgo: %d durations for %d nodes", ndur, R);
+        std::vector<std::vector<int>> pr(R), sc(R);
+        for (int i = 0; i < R; ++i)
+            for (int p : rp[real[i]]) { pr[i].push_back(pos[p]); sc[pos[p]].push_back(i); }
+        std::vector<float> d(R), bl(R, 0.0f);
+        for (int i = 0; i < R; ++i) d[i] = (dur[i] > 0.5f && dur[i] < 1e6f ? dur[i] : 0.5f) + VX_TAPE_GAP_US;
+        for (int i = R - 1; i >= 0; --i) {                 // `real` is a topological order
+            float m = 0.0f;
+            for (int s2 : sc[i]) m = std::max(m, bl[s2]);
+            bl[i] = d[i] + m;
+        }
+        std::vector<int> left(R), lane_of(R, -1), sched;
+        std::vector<float> fin(R, 0.0f), lane_free(max_lanes, 0.0f);
+        std::vector<char> done(R, 0);
+        for (int i = 0; i < R; ++i) left[i] = (int)pr[i].size();
+        for (int step = 0; step < R; ++step) {
+            int best = -1;
+            for (int i = 0; i < R; ++i)                    // the ready node with the longest remaining path (capture order breaks ties)
+                if (!done[i] && left[i] == 0 && (best < 0 || bl[i] > bl[best])) best = i;
+            VX_REQUIRE(best >= 0, "vx_tape_build_pgo: no ready node (cycle?)");
+            int bl_lane = -1; float best_est = 0.0f;
+            int pl = -1; float pf = -1.0f;                 // lane of the predecessor that finishes last
+            for (int p : pr[best]) if (fin[p] > pf) { pf = fin[p]; pl = lane_of[p]; }
+            for (int l = 0; l < max_lanes; ++l) {
+                float est = lane_free[l];
+                for (int p : pr[best]) est = std::max(est, fin[p] + (lane_of[p] == l ? 0.0f : VX_TAPE_HOP_US));
+                if (bl_lane < 0 || est < best_est - 0.01f || (est < best_est + 0.01f && l == pl)) { bl_lane = l; best_est = est; }
+            }
+            lane_of[best] = bl_lane;
+            fin[best] = best_est + d[best];
+            lane_free[bl_lane] = fin[best];
+            done[best] = 1;
+            sched.push_back(best);
+            for (int s2 : sc[best]) left[s2]--;
+        }
+        std::vector<int> real2(R);
+        pre_lane.resize(R);
+        for (int k = 0; k < R; ++k) { real2[k] = real[sched[k]]; pre_lane[k] = lane_of[sched[k]]; }
+        real.swap(real2);
+        for (int k = 0; k < R; ++k) pos[real[k]] = k;
+    }
     std::vector<int> nsucc(R, 0);                       // successors not yet placed
     for (int u : real) for (int p : rp[u]) nsucc[pos[p]]++;
 
@@ -395,6 +445,11 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
         std::vector<int> ps;
         for (int p : rp[u]) ps.push_back(pos[p]);
         int lane = -1;
+        if (!pre_lane.empty()) {
+            lane = pre_lane[i];
+            while ((int)tail.size() <= lane) tail.push_back(-1);
+        }
+        if (lane < 0)
         for (int p : ps) if (tail[T->nodes[p].lane] == p) { lane = T->nodes[p].lane; break; }      // continue a predecessor's lane
         if (lane < 0) {
             for (size_t l = 0; l < tail.size() && lane < 0; ++l)                                    // a lane whose tail has nothing left to feed
@@ -440,6 +495,11 @@ extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) {
     HIPQ(hipDeviceSynchronize(), "hipDeviceSynchronize");      // (the fill is queued on the NULL stream: it must have run before the first poll)
     *out = T;
     return 0;
+}
+extern "C" int vx_tape_build(void* graph_, int max_lanes, VxTape** out) { return tape_build_impl(graph_, max_lanes, nullptr, 0, out); }
+extern "C" int vx_tape_build_pgo(void* graph_, int max_lanes, const float* dur_us, int n, VxTape** out) {
+    VX_REQUIRE(dur_us && n > 0, "vx_tape_build_pgo: no durations");
+    return tape_build_impl(graph_, max_lanes, dur_us, n, out);
 }
 
 extern "C" int vx_tape_info(const VxTape* T, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events) {

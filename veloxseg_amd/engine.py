@@ -24,6 +24,8 @@ from . import _hip as H
 from . import functional as VF
 
 TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
+TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
+TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
 WGRAD_STREAM = os.environ.get("VELOXSEG_WGRAD_STREAM", "0") != "0"      # experiment (off): weight-gradient kernels deferred to a side stream -- measured 13.5 vs 12.0 ms/step, they steal CUs from the critical path
 
@@ -132,6 +134,25 @@ class LaunchTape:
 
     def replay(self):
         H.call("vx_tape_replay", self.handle, H.stream_ptr())
+
+    def relayout(self, max_lanes: int):
+        """profile-guided layout (csrc/tape.hip vx_tape_build_pgo): every node is timed alone (its buffers must hold the values of a real replay), then
+        the graph is laid out again by list scheduling with those durations -- longest remaining path first, each node on the lane where it can start
+        earliest -- instead of greedily in capture order"""
+        import ctypes
+        n = self.n_nodes
+        if n < 4 or self.n_lanes < 2:
+            return
+        us = (ctypes.c_float * n)()
+        H.call("vx_tape_profile", self.handle, H.stream_ptr(), 2, ctypes.addressof(us))
+        h = ctypes.c_void_p()
+        H.call("vx_tape_build_pgo", self.graph.raw_cuda_graph(), int(max_lanes), ctypes.addressof(us), n, ctypes.addressof(h))
+        old, self.handle = self.handle, h.value
+        H.call("vx_tape_free", old)
+        info = (ctypes.c_int * 4)()
+        base = ctypes.addressof(info)
+        H.call("vx_tape_info", self.handle, base, base + 4, base + 8, base + 12)
+        self.n_nodes, self.n_kernels, self.n_lanes, self.n_events = (int(v) for v in info)
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -789,6 +810,17 @@ class TrainEngine:
         # out on four lanes would put one of its chains behind ~2 ms of decoder weight gradients)
         G["enc_bwd"] = self._graph(main_pool, self._s_enc_bwd, lanes=3 if "dec_wg" in G else None)
         self.graphs = G
+        if self.replay_mode == "tape" and TAPE_PGO:
+            # profile-guided layout of the multi-lane tapes: one replay fills every buffer with real values, then each node of the encoder tapes is timed
+            # alone and the tape is laid out again with those durations; the self-check below runs on the new layout
+            rng.copy_(rng0)
+            self._replay(comm=False)
+            torch.cuda.synchronize()
+            for key in TAPE_PGO_STAGES:
+                t = G.get(key)
+                if isinstance(t, LaunchTape):
+                    t.relayout(3 if (key == "enc_bwd" and "dec_wg" in G) else self.tape_lanes)
+            torch.cuda.synchronize()
         # self-check: replays separated by device synchronisation must reproduce the eager pass (same dropout streams)
         for k in range(self.verify_replays):
             rng.copy_(rng0)
