@@ -489,7 +489,9 @@ int vx_tape_describe(const VxTape* tape, int* lane, int* grid, int* waits4, char
  * back into the caller's stream. */
 int vx_tape_lane_stream(void* any_stream, int lane, void** out);
 int vx_spin_us(float us, void* stream);   /* diagnostic: one wave spins for `us` microseconds on `stream` (stand-in for a collective: tools/comm_standin_probe.py) */
-int vx_tape_lanes_distinct(void);      /* answer, not a status: how many of the 4 lane streams were measured to overlap pairwise (-1 before the first use) */
+int vx_tape_lanes_distinct(void);
+int vx_tape_lane_on_caller_queue(void);           /* answer: the lane whose stream shares the hardware queue of the stream the lanes were chosen from (placed on lane 2); 4 = none found, 5 = lanes not chosen yet */
+int vx_tape_permute_lanes(const int* perm4);      /* lane k is served by the stream that served lane perm4[k] (a permutation of 0..3); diagnostics */      /* answer, not a status: how many of the 4 lane streams were measured to overlap pairwise (-1 before the first use) */
 
 #ifdef __cplusplus
 }
