@@ -173,7 +173,8 @@ def test_taped_engine_on_96_cube_patches_takes_the_fused_loss_and_tracks_eager()
         crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
         x, lab = synth(cfg, B, "cuda", 7)
         eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=(mode == "tape"), overlap=False)
-        assert model.ds_fused is True          # (the library's own Loss + a width the loss kernels tile: W % 4 == 0, W <= 256)
+        assert eng._ds_fused is True and model.ds_fused is False     # the library's own Loss + a width the loss kernels tile (W % 4 == 0, W <= 256); the
+        # engine applies its choice inside its own passes only (TrainEngine._settings) and leaves the model's attribute as it found it
         losses[mode] = [float(eng.step(x, lab)) for _ in range(3)]
         if mode == "tape":
             assert eng.use_graph and eng.graphs is not None

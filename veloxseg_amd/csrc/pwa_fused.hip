@@ -626,6 +626,20 @@ extern "C" int vx_ln_pw_tiles(int B, long V) {          // answer, not a status:
     return B * vx_cdiv(V, 16 * T);
 }
 
+// dynamic LDS a block of these kernels may ask for on THIS device (queried once; 160 KB on gfx950, 64 KB on gfx942): the *_ok gates are bounded by it, so a shape
+// that does not fit falls back to the per-operator kernels instead of failing at launch.  Without a device (the CPU-side symbol checks) the gfx950 figure.
+static size_t pf_lds_limit() {
+    static size_t lim = 0;
+    if (!lim) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 0) lim = (size_t)v;
+        else if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) lim = (size_t)v;
+        else lim = 160 * 1024;
+    }
+    return lim;
+}
+static inline size_t pf_lds_budget() { const size_t l = pf_lds_limit(); return l >= 160 * 1024 ? 150 * 1024 : l - (l >> 4); }
+
 extern "C" int vx_ln_pw_ok(int C, int NS, const int* J, long V, int s2d) {
     if (C % 16 || C < 16 || C > 1024 || NS < 1 || NS > 3 || V < 1) return 0;
     int Jt = 0;
@@ -633,12 +647,15 @@ extern "C" int vx_ln_pw_ok(int C, int NS, const int* J, long V, int s2d) {
     const int T = s2d ? 1 : pf_tile_t(V);
     const int S = T == 1 ? 20 : 64;
     const size_t lds = ((size_t)(Jt + 2 * C) * S + 2 * 32 * 16 + 2 * C + Jt + 64) * sizeof(float);      // the backward kernel is the larger one
-    return lds <= 150 * 1024 ? 1 : 0;
+    return lds <= pf_lds_budget() ? 1 : 0;
 }
 
 template <int T, int NW, class P>
 static void pf_launch(void (*k)(P), const P& p, dim3 grid, size_t shm, hipStream_t st) {
-    if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (shm > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds_limit());
+        if (e != hipSuccess) return;       // not launched: the sticky error surfaces in the caller's VX_LAUNCH_CHECK (the *_ok gates keep such shapes off this path)
+    }
     k<<<grid, dim3(64 * NW), shm, st>>>(p);
 }
 
@@ -711,7 +728,7 @@ extern "C" int vx_ln_pw_bwd(const void* const* ptrs, int M, int NS, const int* J
 extern "C" int vx_pwa_post_ok(int C, int Cv, int R, long V) {
     if (C % 16 || Cv % 16 || R % 16 || C < 16 || Cv < 16 || R < 16 || V < 1) return 0;
     const size_t lds = ((size_t)(4 * C + R + Cv) * 20 + 2 * 32 * 16 + 4 * C + R) * sizeof(float);
-    return lds <= 150 * 1024 ? 1 : 0;
+    return lds <= pf_lds_budget() ? 1 : 0;
 }
 extern "C" int vx_pwa_post_tiles(int B, long V) { return B * vx_cdiv(V, 16); }
 
@@ -934,7 +951,7 @@ __global__ void __launch_bounds__(64 * NW) vx_inmlp_bwd_k(VxInMlp p) {
 extern "C" int vx_inmlp_ok(int C, int R, long V) {
     if (C % 16 || R % 16 || C < 16 || R < 16 || C > 256 || V < 1) return 0;
     const size_t lds = ((size_t)(2 * C + R) * 20 + 3 * C + R) * sizeof(float);
-    return lds <= 150 * 1024 ? 1 : 0;
+    return lds <= pf_lds_budget() ? 1 : 0;
 }
 extern "C" int vx_inmlp_tiles(long V) { return vx_cdiv(V, 16); }      // partial-sum rows per (b, c) of vx_inmlp_bwd (batch-size independent)
 

@@ -223,8 +223,26 @@ class TapedPredictor:
 
     def _signature(self):
         """where the parameters and buffers live: a tape holds raw device pointers, so it is only valid while nothing was re-homed (TrainEngine's
-        flat buffer sets p.data, model.to() / .float(), a swapped parameter)"""
-        return tuple((t.data_ptr(), t.dtype, t.device.index) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        flat buffer sets p.data, model.to() / .float(), a swapped parameter).  The module tree is walked ONCE into (owner dict, name) slots; each call
+        then costs two dict look-ups per tensor and still sees a swapped Parameter object."""
+        slots = getattr(self, "_sig_slots", None)
+        if slots is None:
+            slots = self._sig_slots = ([(m._parameters, n) for m in self.model.modules() for n, p in m._parameters.items() if p is not None]
+                                       + [(m._buffers, n) for m in self.model.modules() for n, b in m._buffers.items() if b is not None])
+        out = []
+        for d, n in slots:
+            t = d.get(n)
+            out.append(None if t is None else (t.data_ptr(), t.dtype, t.device.index))
+        return tuple(out)
+
+    # a tape holds a CUDAGraph and raw handles: copies / pickles of the model carry a FRESH, empty predictor (copy.deepcopy(model) for an EMA copy,
+    # torch.save(model)); a copied handle would also be freed twice
+    def __deepcopy__(self, memo):
+        import copy
+        return TapedPredictor(copy.deepcopy(self.model, memo), self.max_lanes, self.check)
+
+    def __reduce__(self):
+        return (TapedPredictor, (self.model, self.max_lanes, self.check))
 
     @torch.inference_mode()
     def __call__(self, x: torch.Tensor):
@@ -290,8 +308,7 @@ class TrainEngine:
             from .utils.loss import Loss as _Loss
             ok = (bool(fuse_ds) and isinstance(criterion, _Loss)
                   and bool(H.query("vx_seg_loss_ds_ok", int(model.n_classes), *[int(v) for v in batch_shape[2:]])))
-            self._ds_fused_before = bool(model.ds_fused)
-            model.ds_fused = ok
+            self._ds_fused = ok            # applied for the duration of this engine's own passes only (`_settings`), like the other switches
         self.dev = next(model.parameters()).device
         self.flat = FlatParams(model)
         self.m = torch.zeros_like(self.flat.param)
@@ -320,12 +337,18 @@ class TrainEngine:
         self.verify_replays = verify_replays
         if self.world > 1:
             dist.broadcast(self.flat.param, src=0, group=self.pg)      # identical replicas at start
+            # Data parallel: the start gate of step N+1's tapes is set behind AdamW(N), which waits for all-reduce(N) -- i.e. for the slowest PEER (data loader,
+            # rank-0 checkpoint, capture skew).  Collective latency must not count against the cross-lane poll timeout (a poll that gives up lets the kernels
+            # behind it run on an unmet dependency); the process group's own timeout / RCCL watchdog bounds a peer that never arrives.
+            H.call("vx_tape_set_flag_timeout_ms", 0)
 
     @contextlib.contextmanager
     def _settings(self, capture: bool = False):
         """this engine's values of the process-wide switches of veloxseg_amd.functional, for the duration of one of its eager passes or captures"""
-        prev = (VF.get_precision(), VF.MODALITY_STREAMS, VF.RNG_INPLACE)
+        prev = (VF.get_precision(), VF.MODALITY_STREAMS, VF.RNG_INPLACE, getattr(self.model, "ds_fused", None))
         VF.set_precision(self.precision)
+        if prev[3] is not None and hasattr(self, "_ds_fused"):
+            self.model.ds_fused = self._ds_fused
         if capture:
             if self.replay_mode == "tape":
                 VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # forks cost the tape nothing on the host: every per-modality piece gets its own branch
@@ -335,6 +358,8 @@ class TrainEngine:
         finally:
             VF.set_precision(prev[0])
             VF.MODALITY_STREAMS, VF.RNG_INPLACE = prev[1], prev[2]
+            if prev[3] is not None:
+                self.model.ds_fused = prev[3]
 
     # ---- pieces ---------------------------------------------------------------------------------
     def _forward_loss(self):
@@ -949,6 +974,11 @@ class TrainEngine:
                 torch.cuda.synchronize()
         if self.use_graph:
             self._replay(comm=True)                            # (everything the tapes need is baked in: no process-wide state is read)
+            if self.replay_mode == "tape":
+                nto = H.query("vx_tape_flag_timeouts")         # a poll of an EARLIER replay that gave up (pinned host word): never apply an update on top of it
+                if nto:
+                    raise RuntimeError(f"TrainEngine.step: {nto} cross-lane poll(s) gave up after the flag timeout; the gradients of that step are not trustworthy "
+                                       "and no optimizer update was applied for this one (VELOXSEG_TAPE_FLAG_TIMEOUT_MS / vx_tape_set_flag_timeout_ms)")
             self._adamw()
             return self.loss
         with self._settings():

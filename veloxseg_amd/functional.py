@@ -934,16 +934,19 @@ def _submit_wgrad_jobs(jobs, folds):
         return
     key = (int(torch.cuda.current_device()), int(H.stream_ptr() or 0))
     pend = _wgg_pending.get(key)
-    if pend is None:
+    fresh = pend is None
+    if fresh:
         pend = _wgg_pending[key] = [[], []]
-
+    # the jobs go into the pool BEFORE the flush closure is submitted: in side-stream deferral the queue auto-flushes every VX_WG_FLUSH closures, and a flush
+    # that ran at once on an empty pool would pop it and orphan the jobs appended afterwards (their weight gradients silently lost)
+    pend[0].extend(jobs)
+    pend[1].extend(folds)
+    if fresh:
         def flush(st, key=key):
             p_ = _wgg_pending.pop(key, None)
             if p_ is not None:
                 _wgrad_group(p_[0], p_[1], st)
         _submit_wgrad(flush)
-    pend[0].extend(jobs)
-    pend[1].extend(folds)
 
 
 def _gb(p):
