@@ -427,7 +427,8 @@ def _step_traffic(workload, B, trace_steps=None):
         d = json.load(open(PMC_FILE))
         if B != 4 or workload != "autopet128":
             return None
-        steps = trace_steps or d.get("steps_in_trace") or next((v["launches_in_trace"] for k, v in d["kernels"].items() if k.startswith("vx_adamw_k")), None)
+        # forward/backward passes covered by the trace: the launches of a once-per-pass kernel (the optimiser kernel undercounts: capture / self-check passes run no AdamW)
+        steps = trace_steps or d.get("passes_in_trace") or next((v["launches_in_trace"] for k, v in d["kernels"].items() if k.startswith("vx_loss_finalize_k")), None)
         if not steps:
             return None
         tot = sum(float(k["hbm_bytes_per_launch_corrected"]) * k["launches_in_trace"] for k in d["kernels"].values() if "hbm_bytes_per_launch_corrected" in k)
@@ -435,7 +436,7 @@ def _step_traffic(workload, B, trace_steps=None):
             for g in k.get("by_grid", {}).values():
                 if "hbm_bytes_per_launch_corrected" not in k:
                     tot += float(g["hbm_bytes_per_launch_corrected"]) * g["launches_in_trace"]
-        return {"counter_bytes_per_step": round(tot / steps), "source": PMC_NAME, "steps_in_trace": steps}
+        return {"counter_bytes_per_step": round(tot / steps), "source": PMC_NAME, "passes_in_trace": steps}
     except Exception:
         return None
 

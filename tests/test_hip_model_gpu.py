@@ -93,6 +93,60 @@ def test_train_step_vs_oracle(golden_dir, name):
             assert abs(gn - fix["grad_norms"][k]) <= 3e-3 * max(fix["grad_norms"][k], 1e-3), (k, gn, fix["grad_norms"][k])
 
 
+@pytest.mark.parametrize("name,mode", [("g5_128_m2", "tape"), ("g6_128_brats", "tape"), ("g5_128_m2", "module")])
+def test_benchmarked_batch_b4_vs_oracle(name, mode):
+    """The BENCHMARKED shapes at the BENCHMARKED batch: bench.py's headline is autopet128 (= g5's model kwargs) at B = 4 per GPU and BASELINE configs[3] is
+    brats128 at B = 4 per GPU; the golden cases run B = 1.  One training step at B = 4 (dropout 0, as every oracle comparison) against oracle.forward / loss /
+    autograd: loss 1e-4 relative, every parameter gradient 2e-3 of the oracle's norm.  mode "tape": through TrainEngine with launch tapes, staged loss and the fused
+    deep-supervision loss -- the path the bench line times (gradients read from the engine's flat buffer); mode "module": the plain nn.Module + Loss + backward."""
+    import types
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg_d, _ = CASES[name]
+    B = 4
+    model = VeloxSeg(**cfg_d)
+    sd = fill_state_dict(model.state_dict(), seed=7)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    x, labels = make_inputs(cfg_d, B)
+    cfg = O.OracleConfig(**cfg_d)
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, torch.device("cuda"), num_modal=cfg.M)
+    if mode == "tape":
+        eng = TrainEngine(model, crit, (B, sum(cfg_d["in_ch"]), *cfg_d["input_size"]), lr=0.0, weight_decay=0.0, use_graph=True, overlap=False)
+        loss = float(eng.step(x.cuda(), labels.cuda()))
+        torch.cuda.synchronize()
+        assert eng.use_graph and eng.graphs is not None, "the capture's self-check failed: the step did not run as launch tapes"
+        loss = float(eng.step())                 # a REPLAYED step (lr = 0: same parameters), the thing the bench times
+        torch.cuda.synchronize()
+        grads = {}
+        for n, p in zip(eng.flat.names, eng.flat.params):
+            o, k = eng.flat.slices[n]
+            grads[n] = eng.flat.grad[o:o + k].view(p.shape).detach().cpu().double()
+    else:
+        outs = model(x.cuda())
+        lt = crit(outs, labels.cuda(), sr_labels=x.cuda())
+        lt.backward()
+        torch.cuda.synchronize()
+        loss = float(lt)
+        grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(params)
+    ro = O.forward(x, full, cfg, training=True)
+    rl = O.loss(ro, labels, x, cfg.M, LOSS_CFG)
+    rl.backward()
+    assert abs(loss - float(rl)) <= 1e-4 * abs(float(rl)), (loss, float(rl))
+    bad = []
+    for k in grads:
+        r = params[k].grad.double()
+        rel = float((grads[k] - r).norm() / (r.norm() + 1e-4))
+        if rel > 2e-3:
+            bad.append((k, rel, float(r.norm())))
+    assert len(grads) == len([k for k, _ in model.named_parameters()])
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+
+
 def test_cpu_input_fails_loudly():
     from veloxseg_amd.model.VeloxSeg import VeloxSeg
     cfg_d, B = CASES["g2_32_m2"]

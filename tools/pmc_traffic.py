@@ -56,10 +56,18 @@ def main():
         if len(grids) > 1:
             kernels[k]["by_grid"] = {str(g): {"launches_in_trace": fg[(k, g)][0],
                                               "hbm_bytes_per_launch_corrected": int((2 * fg[(k, g)][1] / fg[(k, g)][0] + wg[(k, g)][1] / wg[(k, g)][0]) * 1024)} for g in grids}
-    # steps covered by the trace = launches of the once-per-step optimiser kernel
-    steps = next((v["launches_in_trace"] for k, v in kernels.items() if k.startswith("vx_adamw_k")), None)
-    doc = {"steps_in_trace": steps, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2`, B=4 autopet128; traffic = "
-                     "2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), KB -> bytes",
+    # Divisor of the per-step sums = forward/backward PASSES in the trace, not optimiser steps: the trace also holds the warm-up / capture / self-check passes, which
+    # run every kernel of the step but no AdamW (round 3 divided by the 37 vx_adamw_k launches of a trace with 44 passes: 9.6 GB "per step" was 8.07 GB).  A pass is
+    # counted by the kernels that run exactly once in it (the loss finalize / the stem convolution), and the two must agree.
+    once = [v["launches_in_trace"] for k, v in kernels.items() if k.startswith("vx_loss_finalize_k") or k.startswith("vx_conv_mfma_fwd_k<1, false>")]
+    passes = once[0] if once and all(o == once[0] for o in once) else None
+    adamw = next((v["launches_in_trace"] for k, v in kernels.items() if k.startswith("vx_adamw_k")), None)
+    total = sum(float(v["hbm_bytes_per_launch_corrected"]) * v["launches_in_trace"] for v in kernels.values())
+    doc = {"passes_in_trace": passes, "optimizer_steps_in_trace": adamw,
+           "counter_bytes_per_pass": (round(total / passes) if passes else None),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2 --dispersion-steps 0`, B=4 autopet128; traffic = "
+                     "2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), KB -> bytes; "
+                     "per-pass sum = sum over kernels of bytes per launch x launches, divided by the launches of the once-per-pass kernels",
            "kernels": kernels}
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
