@@ -172,6 +172,26 @@ int vx_jlc_gk(const float* d_o, const float* y1, const float* y3, const float* y
 int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5, const float* w1, const float* w3, const float* w5, const float* d_o,
                     float* dx, int B, int C, int G, int D, int H, int W, void* stream);
 
+/* The same three grouped convolutions (conv_blocks.py:51-58) and their input gradient as Toeplitz GEMMs on the bf16 matrix pipe with fp32-exact products
+ * (csrc/jlc_mfma.hip; group width 4 / 8 / 16, W % 4 == 0):
+ *   vx_jlc_tz_ok / _ntiles  : answers (1 = shape supported; tiles per (b, c) = rows of `part`, a function of (C/G, D, H, W) only)
+ *   vx_jlc_tz_img_floats    : floats of the operand-image workspace (forward + input-gradient images of the three weight tensors)
+ *   vx_jlc_tz_prep          : expands w1 / w3 / w5 into the images (once per step; the backward of the same step reads the second half)
+ *   vx_jlc_tz_fwd / _bwd    : drop-in for vx_jlc_conv_fwd / vx_jlc_conv_bwd (same outputs, same `part` layout)
+ *   vx_jlc_tz_set_pieces    : bf16 pieces per fp32 operand: 3 (default, six piece products = the fp32 product), 2, or 1 (bf16 opt-in mode) */
+int vx_jlc_tz_ok(int C, int G, int D, int H, int W);
+int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W);
+int vx_jlc_tz_img_floats(int C, int G);
+int vx_jlc_tz_set_pieces(int ns);
+int vx_jlc_tz_set_min_voxels(long v);   /* vx_jlc_tz_ok answers 0 below this many voxels per channel (default 4096: the 16^3 and 32^3 levels) */
+int vx_jlc_tz_pieces(void);
+int vx_jlc_tz_set_debug(int mask);      /* timing experiments only: bit 0 = skip the halo staging, bit 1 = skip the MFMA loops (results are then garbage) */
+int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream);
+int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, const float* b3, const float* b5, float* y1, float* y3, float* y5, double* part,
+                  int B, int C, int G, int D, int H, int W, void* stream);
+int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
+                  int B, int C, int G, int D, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
  * Encoder.py:334-337, Decoder.py:54-57).  stats[2*bc] = mean, stats[2*bc+1] = rstd.

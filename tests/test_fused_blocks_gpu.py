@@ -181,3 +181,80 @@ def test_fused_ffn_tail_equals_per_operator_kernels_with_dropout(case):
     for k in res[True][2]:
         g = res[False][2][k]
         _close(res[True][2][k], g, 2e-3 * float(g.abs().max()) + 1e-6, 2e-3, f"d{k}")
+
+
+TZ_CASES = [
+    # name, B, C, groups, spatial  (group widths 4 / 8 / 16; W % 4 == 0; ragged tiles; one w-block per row; anisotropic)
+    ("L1_w4_32cube", 2, 16, 4, (32, 32, 32)),
+    ("L2_w8_16cube", 2, 32, 4, (16, 16, 16)),
+    ("L3_w8_8cube", 2, 64, 8, (8, 8, 8)),
+    ("L4_w16_4cube", 2, 128, 8, (4, 4, 4)),
+    ("L1_96", 1, 16, 4, (24, 24, 24)),
+    ("L2_96", 1, 32, 4, (12, 12, 12)),
+    ("aniso_ragged", 1, 16, 4, (10, 9, 20)),
+    ("hecktor_L1", 1, 16, 4, (32, 32, 16)),
+]
+
+
+@pytest.mark.parametrize("pieces", [3, 1])
+@pytest.mark.parametrize("case", TZ_CASES, ids=[c[0] for c in TZ_CASES])
+def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
+    """csrc/jlc_mfma.hip (the three grouped convs of conv_blocks.py:51-58 and their input gradient as Toeplitz GEMMs on the bf16 matrix pipe) against an fp64 torch
+    convolution and against the fp32 VALU kernels of csrc/jlc.hip through the C ABI.  pieces = 3 (six piece products = the fp32 product): error within 3x the VALU
+    kernels' own (fp32 summation noise), per-tile statistics summing to the tensor's; pieces = 1 (bf16 opt-in operands): 2^-8-level relative error, fp32 sums."""
+    import torch.nn.functional as TF
+    from veloxseg_amd import _hip as H
+    _, B, C, G, (D, Hh, W) = case
+    H.LIB.load()
+    H.call("vx_jlc_tz_set_min_voxels", 0)
+    H.call("vx_jlc_tz_set_pieces", pieces)
+    try:
+        assert H.query("vx_jlc_tz_ok", C, G, D, Hh, W) == 1
+        torch.manual_seed(5)
+        Cg = C // G
+        x = torch.randn(B, C, D, Hh, W, device="cuda")
+        ws = [torch.randn(C, Cg, k, k, k, device="cuda") * (1.0 / (Cg * k ** 3) ** 0.5) for k in (1, 3, 5)]
+        bs = [torch.randn(C, device="cuda") * 0.1 for _ in range(3)]
+        st = torch.cuda.current_stream().cuda_stream
+        y_old, y_new = torch.empty(3, *x.shape, device="cuda"), torch.full((3, *x.shape), float("nan"), device="cuda")
+        nt_old, nt_new = H.query("vx_jlc_ntiles", B, C, G, D, Hh, W), H.query("vx_jlc_tz_ntiles", C, G, D, Hh, W)
+        p_old = torch.empty(3, B * C, nt_old, 2, device="cuda", dtype=torch.float64)
+        p_new = torch.full((3, B * C, nt_new, 2), float("nan"), device="cuda", dtype=torch.float64)
+        img = torch.empty(H.query("vx_jlc_tz_img_floats", C, G), device="cuda")
+        H.call("vx_jlc_conv_fwd", H.P(x), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_old[0].data_ptr(), y_old[1].data_ptr(), y_old[2].data_ptr(),
+               p_old.data_ptr(), B, C, G, D, Hh, W, st)
+        H.call("vx_jlc_tz_prep", H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(img), C, G, st)
+        H.call("vx_jlc_tz_fwd", H.P(x), H.P(img), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_new[0].data_ptr(), y_new[1].data_ptr(), y_new[2].data_ptr(), p_new.data_ptr(),
+               B, C, G, D, Hh, W, st)
+        g = torch.randn(3, *x.shape, device="cuda")
+        d_o = torch.randn_like(x)
+        dx_old, dx_new = torch.empty_like(x), torch.full_like(x, float("nan"))
+        H.call("vx_jlc_conv_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(d_o), H.P(dx_old), B, C, G, D, Hh, W, st)
+        H.call("vx_jlc_tz_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(img), H.P(ws[0]), H.P(d_o), H.P(dx_new), B, C, G, D, Hh, W, st)
+        torch.cuda.synchronize()
+        tol = 3.0 if pieces == 3 else None
+        for i, k in enumerate((1, 3, 5)):
+            ref = TF.conv3d(x.double(), ws[i].double(), bs[i].double(), padding=k // 2, groups=G)
+            sc = float(ref.abs().max())
+            e_old, e_new = float((y_old[i].double() - ref).abs().max()) / sc, float((y_new[i].double() - ref).abs().max()) / sc
+            if pieces == 3:
+                assert e_new <= max(tol * e_old, 2e-6), (k, e_old, e_new)
+            else:
+                assert e_new <= 2e-2, (k, e_new)
+            # per-tile (sum, sumsq) partials fold to the statistics of what the kernel STORED
+            s_new = p_new[i].sum(1).view(B, C, 2)
+            yk = y_new[i].double()
+            assert torch.allclose(s_new[..., 0], yk.sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * sc)
+            assert torch.allclose(s_new[..., 1], (yk * yk).sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * sc * sc)
+        ref = d_o.double()
+        for i, k in enumerate((1, 3, 5)):
+            ref = ref + TF.conv_transpose3d(g[i].double(), ws[i].double(), None, padding=k // 2, groups=G)
+        sc = float(ref.abs().max())
+        e_old, e_new = float((dx_old.double() - ref).abs().max()) / sc, float((dx_new.double() - ref).abs().max()) / sc
+        if pieces == 3:
+            assert e_new <= max(3.0 * e_old, 2e-6), (e_old, e_new)
+        else:
+            assert e_new <= 2e-2, e_new
+    finally:
+        H.call("vx_jlc_tz_set_pieces", 3)
+        H.call("vx_jlc_tz_set_min_voxels", 4096)

@@ -36,6 +36,7 @@ struct Flags {
     int64_t pw_mfma_max_v = 4096, in_row_max = 4096;
     int tile_min_c = 32;              // JLC channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*) from this many channels up, mlp.hip below (functional.TILE_MIN_C)
     bool upconv_wgrad_mfma = true;    // (A/B) ConvTranspose weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad) vs the generic strided-conv kernel
+    bool jlc_tz = true;               // JLC grouped convolutions (forward + input gradient) as Toeplitz GEMMs on the bf16 matrix pipe, fp32-exact products (csrc/jlc_mfma.hip); 0 = the fp32 VALU kernels of jlc.hip
     bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
@@ -529,6 +530,7 @@ inline Tensor sum3(const Tensor& a, const Tensor& b, const Tensor& c, void* stre
 // state of the fused block kernels (jlc.hip + mlp.hip): what the backward pass recomputes from
 struct JLCFusedState {
     Tensor x, y, o, stats_y, stats_o;            // y: (3, B, C, D, H, W) = the three conv outputs
+    Tensor img;                                  // operand images of the three weight tensors (vx_jlc_tz_prep) when the convolutions ran on jlc_mfma.hip
     Tensor w1, w3, w5, b1, b3, b5, l1w, l1b, l2w, l2b;
     int B = 0, C = 0, G = 0, D = 0, H = 0, W = 0, R = 0, nch = 0;
     bool tile = false;                           // channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*: C = 64 / 128) instead of mlp.hip
@@ -927,7 +929,8 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 f.w1 = ws[0]; f.w3 = ws[1]; f.w5 = ws[2]; f.b1 = bs[0]; f.b3 = bs[1]; f.b5 = bs[2]; f.l1w = l1w; f.l1b = l1b; f.l2w = l2w; f.l2b = l2b;
                 f.B = B; f.C = C; f.G = G; f.D = D; f.H = H; f.W = W; f.R = R; f.p = p; f.site = site; f.rs = p > 0 ? sp(rs) : nullptr;
                 const long BC = (long)B * C;
-                const int nty = vx_jlc_ntiles(B, C, G, D, H, W);
+                const bool tz = F.jlc_tz && vx_jlc_tz_ok(C, G, D, H, W);
+                const int nty = tz ? vx_jlc_tz_ntiles(C, G, D, H, W) : vx_jlc_ntiles(B, C, G, D, H, W);
                 TORCH_CHECK(nty > 0, "vx_jlc_ntiles failed");
                 f.nch = vx_jlc_nchunks(BC, V);
                 auto dopt = f.x.options().dtype(at::kDouble);
@@ -935,6 +938,11 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 f.y = at::empty({3, B, C, D, H, W}, f.x.options());
                 float* yp = f.y.data_ptr<float>();
                 const long n1 = BC * V;
+                if (tz) {
+                    f.img = at::empty({(long)vx_jlc_tz_img_floats(C, G)}, f.x.options());
+                    VX(vx_jlc_tz_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
+                    VX(vx_jlc_tz_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
+                } else
                 VX(vx_jlc_conv_fwd, fp(f.x), fp(f.w1), fp(f.w3), fp(f.w5), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 f.stats_y = at::empty({3, BC, 2}, f.x.options());
                 f.stats_o = at::empty({BC, 2}, f.x.options());
@@ -1007,6 +1015,8 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             Tensor dx;
             if (need_x) {
                 dx = dn;                                      // dn is dead after vx_jlc_mid_bwd: reuse its storage
+                if (f.img.defined()) VX(vx_jlc_tz_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                else
                 VX(vx_jlc_conv_bwd, gp, gp + n1, gp + 2 * n1, fp(f.w1), fp(f.w3), fp(f.w5), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
             }
             // weight gradients (the bias gradients behind an InstanceNorm are zero by construction: see below)
@@ -1300,6 +1310,8 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("get_expand_split", []() { return F.expand_split; });
     m.def("set_tile_min_c", [](int64_t c) { F.tile_min_c = (int)c; });
     m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });
+    m.def("set_jlc_tz", [](bool on) { F.jlc_tz = on; });          // A/B (tests): JLC grouped convs on the matrix pipe (default) or the fp32 VALU kernels
+    m.def("get_jlc_tz", []() { return F.jlc_tz; });
     m.def("set_jlc_tile", [](bool on) { F.jlc_tile = on; });      // A/B (tests): JLC block of the coarse levels fused (default) or per operator
     m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels

@@ -1,0 +1,606 @@
+// JLC grouped convolutions on the bf16 matrix pipe with fp32-exact products (reference model/components/conv_blocks.py:51-58: three grouped Conv3d, k = 1, 3, 5,
+// "same" padding, groups = C / min_dim_group, i.e. 4 / 8 / 8 / 16 channels per group at the four levels).
+//
+// Why a Toeplitz GEMM.  With 4..16 channels per group the implicit GEMM of one group is (4..16) x (4..16)*K^3: a 16 x 16 MFMA tile over (co, ci) is 6-25 % full.
+// The W axis supplies the missing rows: for one (kd, kh) the convolution along W of 4 consecutive outputs is a 4 x 8 banded (Toeplitz) matrix
+//     T[wo][j] = w[kd][kh][j - 2 - wo + K/2]   (0 <= . < K, else 0),     out[w0 + wo] += sum_j T[wo][j] * in[w0 - 2 + j],
+// so   A[(co, wo)][(ci, j)]  (16 x 32, rows = 4 output channels x 4 outputs along W, k = 4 input channels x 8 inputs along W)
+// and  B[(ci, j)][position]  (32 x 16, column = one of 16 (d, h, w-block) positions; a lane's 8 k-values are 8 CONSECUTIVE inputs along W of one channel:
+//                             one 16-byte read of the LDS halo row)
+// make v_mfma_f32_16x16x32_bf16 do 4 co x 4 ci x K taps x 4 outputs x 16 positions per issue: 62.5 % of its multipliers carry a product at K = 5 (37.5 % at K = 3).
+// fp32 accuracy on the bf16 pipe as in expand_mfma.hip: every operand is x = x0 + x1 + x2 (bf16 pieces, 24 mantissa bits), a product is the six piece products of
+// weight >= 2^-24, fp32 accumulate (NS = 3; NS = 1 is the bf16 opt-in mode).  Price: 6 x 16 clocks per 5120 useful MACs = 53 MAC/clk/SIMD against 32 for v_pk_fma_f32
+// at its peak (the fp32 VALU kernels of jlc.hip reach 9).
+//
+// Operands.  The banded weight matrices are expanded ONCE per step by vx_jlc_tz_prep into operand-order images (one coalesced 16-byte load per lane, piece and
+// entry; forward and input-gradient images: the adjoint of a "same" conv is a "same" conv with the weights transposed inside the group and flipped in space).
+// The input halo is split into its pieces when it is staged (once per element, it is then read by up to 25 (kd, kh) entries).
+//
+// forward : one halo (K = 5) of x feeds all three convolutions; per-(b, c) partial (sum, sumsq) of every output in the epilogue, exactly as vx_jlc_conv_fwd.
+// backward: dx = d_o + conv5^T(g5) + conv3^T(g3) + conv1^T(g1): g5 and g3 are staged one after the other (halo 2 / 1) into the same accumulators, the
+//           1x1x1 term and the residual are added from global memory in the epilogue.
+#include "vx_common.h"
+#include "../../include/veloxseg_hip.h"
+
+typedef __bf16 tz_bf8 __attribute__((ext_vector_type(8)));
+typedef float tz_f4 __attribute__((ext_vector_type(4)));
+
+struct TzGeo {          // LDS halo geometry of one source (elements = bf16)
+    int HD, HH;         // halo rows along D, H (= TD + 2 hw, TH + 2 hw)
+    int Sd, Sc, Sp;     // strides: d-plane, channel plane, piece
+    int nrows;          // CG * HD * HH
+    unsigned mHH, mHD;  // magic reciprocals (exact for the index ranges used here)
+    int qd0, nq;        // first quad / quads per row that this source stages (quad qd covers w0 - 4 + 4 qd .. + 3)
+    unsigned mNQ;
+};
+
+struct VxTz {
+    const float* src[3];            // forward: x; backward: g5, g3, g1
+    const uint4* img;               // operand images of this direction
+    const float* bias[3];           // forward (order k = 5, 3, 1); may be null
+    const float* res;               // backward: d_o
+    const float* w1;                // backward: the 1x1x1 weights (C, C/G)
+    float* out[3];                  // forward: y5, y3, y1; backward: dx
+    double* part;                   // forward: [3][B*C][ntiles][2], k = 0 -> y1, 1 -> y3, 2 -> y5 (layout of vx_jlc_conv_fwd)
+    int B, C, G, D, H, W;
+    int TD, TH, TWB;                // tile: TD x TH x 4*TWB outputs
+    int nTd, nTh, nTw;
+    int RW;                         // halo row length (elements) = 4 TWB + 4
+    int P, nNt;                     // positions per tile (TD*TH*TWB), N-tiles (16 positions each)
+    unsigned mTWB, mTD;
+    TzGeo geo[2];                   // [0]: halo 2 (forward / g5), [1]: halo 1 (g3)
+    int red_off;                    // byte offset of the statistics scratch behind the halo
+    int dbg;                        // timing experiments only (tools/jlc_tz_probe.py): bit 0 = skip the staging, bit 1 = skip the MFMA loops
+};
+
+__device__ __forceinline__ uint32_t tz_pack(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// i / d through the precomputed reciprocal m = ceil(2^32 / d) (exact for i * d < 2^32; m == 0 encodes d == 1)
+__device__ __forceinline__ unsigned tz_divm(unsigned i, unsigned m) { return m ? __umulhi(i, m) : i; }
+__device__ __forceinline__ float tz_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float tz_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// ------------------------------------------------------------------------------------------------------------------ operand images of the weights
+// entry e: K = 5 -> kd*5 + kh (0..24); K = 3 -> 25 + kd*3 + kh; K = 1 -> 34.   img[((((g*35 + e)*MT + mt)*KS + ks)*NS + s)*64 + lane] (uint4 = 8 bf16)
+template <int CG, int NS>
+__global__ void __launch_bounds__(256) vx_tz_prep_k(const float* __restrict__ w1, const float* __restrict__ w3, const float* __restrict__ w5, uint4* __restrict__ img_f,
+                                                    uint4* __restrict__ img_b, int G) {
+    constexpr int MT = CG / 4, KS = CG / 4;
+    const long total = (long)G * 35 * MT * KS * 64;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long r = t >> 6;
+    const int ks = (int)(r % KS); r /= KS;
+    const int mt = (int)(r % MT); r /= MT;
+    const int e = (int)(r % 35);
+    const int g = (int)(r / 35);
+    int K, kd, kh;
+    const float* w;
+    if (e < 25) { K = 5; kd = e / 5; kh = e % 5; w = w5; }
+    else if (e < 34) { K = 3; kd = (e - 25) / 3; kh = (e - 25) % 3; w = w3; }
+    else { K = 1; kd = 0; kh = 0; w = w1; }
+    const int hw = K / 2, K3 = K * K * K;
+    const int m = lane & 15, q = lane >> 4;
+    const int a_l = mt * 4 + (m >> 2), wo = m & 3;      // row channel (local), output along W
+    const int b_l = ks * 4 + q;                          // k channel (local)
+    float vf[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kw = j - 2 - wo + hw;
+        float f = 0.0f, bwd = 0.0f;
+        if (kw >= 0 && kw < K) {
+            // forward: row = output channel, k = input channel
+            f = w[((long)(g * CG + a_l) * CG + b_l) * K3 + (kd * K + kh) * K + kw];
+            // input gradient: row = INPUT channel of the forward conv, k = its output channel, taps flipped
+            bwd = w[((long)(g * CG + b_l) * CG + a_l) * K3 + ((K - 1 - kd) * K + (K - 1 - kh)) * K + (K - 1 - kw)];
+        }
+        vf[j] = f; vb[j] = bwd;
+    }
+    const long o = (t >> 6) * NS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        uint32_t pf[4], pb[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            pf[j2] = tz_pack(vf[2 * j2], vf[2 * j2 + 1]);
+            pb[j2] = tz_pack(vb[2 * j2], vb[2 * j2 + 1]);
+            if (s + 1 < NS) {
+                vf[2 * j2] -= tz_lo(pf[j2]); vf[2 * j2 + 1] -= tz_hi(pf[j2]);
+                vb[2 * j2] -= tz_lo(pb[j2]); vb[2 * j2 + 1] -= tz_hi(pb[j2]);
+            }
+        }
+        img_f[o + (long)s * 64] = make_uint4(pf[0], pf[1], pf[2], pf[3]);
+        img_b[o + (long)s * 64] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ halo staging
+// Halo of one source in LDS as NS bf16 planes: elem[s][ci][hd][hh][e], e = w - (w0 - 2) in [0, RW).  A thread stages quads (4 consecutive w, one 16-byte load);
+// the pieces of a quad leave as two packed pairs per piece (4-byte LDS stores: e = 4 qd - 2 is even, not a multiple of 4).
+template <int CG, int NS>
+__device__ __forceinline__ void tz_stage(const float* __restrict__ src, unsigned char* __restrict__ lds, const VxTz& p, const TzGeo& ge, int hw, int b, int g, int d0, int h0,
+                                         int w0, int nthr) {
+    const int total = ge.nrows * ge.nq;
+    const long chan = (long)p.D * p.H * p.W;
+    const float* __restrict__ sb = src + ((long)b * p.C + (long)g * CG) * chan;
+    constexpr int SU = 4;
+    for (int it0 = threadIdx.x; it0 < total; it0 += nthr * SU) {
+        float4 v[SU];
+        int eo[SU];      // element offset of the quad's first pair (e = 4 qd - 2) inside piece 0, or < 0: nothing to store
+        int qd_[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int it = it0 + u * nthr;
+            const bool live = it < total;
+            const unsigned iu = live ? (unsigned)it : 0u;
+            const unsigned r1 = tz_divm(iu, ge.mNQ);
+            const int qd = (int)(iu - r1 * ge.nq) + ge.qd0;
+            const unsigned r2 = tz_divm(r1, ge.mHH);
+            const int hh = (int)(r1 - r2 * ge.HH);
+            const unsigned ci = tz_divm(r2, ge.mHD);
+            const int hd = (int)(r2 - ci * ge.HD);
+            const int id = d0 - hw + hd, ih = h0 - hw + hh, iw = w0 - 4 + 4 * qd;
+            const bool ok = live && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const float4 t_ = *reinterpret_cast<const float4*>(sb + (ok ? (long)ci * chan + ((long)id * p.H + ih) * p.W + iw : 0));
+            v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+            eo[u] = live ? (int)ci * ge.Sc + hd * ge.Sd + hh * p.RW + 4 * qd - 2 : -(1 << 30);
+            qd_[u] = qd;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            if (eo[u] <= -(1 << 29)) continue;
+            float a0 = v[u].x, a1 = v[u].y, a2 = v[u].z, a3 = v[u].w;
+            const bool first = qd_[u] > 0, second = qd_[u] * 4 < p.RW;       // quad 0 contributes its last two values only, the last quad its first two
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t lo = tz_pack(a0, a1), hi = tz_pack(a2, a3);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(lds + 2 * ((long)s * ge.Sp + eo[u]));
+                if (first) dst[0] = lo;
+                if (second) dst[1] = hi;
+                if (s + 1 < NS) { a0 -= tz_lo(lo); a1 -= tz_hi(lo); a2 -= tz_lo(hi); a3 -= tz_hi(hi); }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ accumulate one convolution
+// acc[mt][nt] += sum over the K*K (kd, kh) entries and the KS k-steps.  `boff[nt]`: byte offset of the lane's position (and of its q-th channel) in piece 0;
+// `ebase`: byte offset of entry (0, 0) (a K = 3 / 1 convolution reading a K = 5 halo starts one / two rows and planes in).
+// Software pipeline: a step (entry, k-step) is cut into units of <= 2 N-tiles; the LDS reads of unit u + 1 are issued before the MFMAs of unit u (at most 12
+// reads in flight: lgkmcnt counts to 15), the weight operands of step t + 1 (global, L2-resident) before the MFMAs of step t.
+template <int NTB, int NS>
+__device__ __forceinline__ void tz_read_b(uint4 (&bv)[NTB][NS], const unsigned char* __restrict__ lds, const int* boff, int off, int Sp) {
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // two 8-byte reads (the address is 8-, not 16-byte aligned: a misaligned ds_read_b128 is replayed at 64 cycles); volatile keeps the compiler from
+            // fusing them into ds_read2_b64, which runs at half the rate of two ds_read_b64.  Explicit LDS address space: address-space inference skips
+            // volatile accesses, a generic pointer would make these FLAT loads.
+            typedef const volatile __attribute__((address_space(3))) unsigned long long* tz_lds_u64;
+            tz_lds_u64 bp = (tz_lds_u64)(lds + boff[nt] + off + 2 * s * Sp);
+            const unsigned long long lo = bp[0], hi = bp[1];
+            bv[nt][s] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+}
+template <int NTB, int MTW, int NS>
+__device__ __forceinline__ void tz_mfma(tz_f4 (*acc)[NTB], const uint4 (&a)[MTW][NS], const uint4 (&bv)[NTB][NS]) {
+    constexpr int NP = NS == 3 ? 6 : NS == 2 ? 3 : 1;
+    // piece pairs (weight piece, activation piece), smallest terms first
+    constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PW2[3] = {1, 0, 0}, PA2[3] = {0, 1, 0};
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+        const int sw = NS == 3 ? PW[pr] : NS == 2 ? PW2[pr] : 0, sa = NS == 3 ? PA[pr] : NS == 2 ? PA2[pr] : 0;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[mt][sw]), __builtin_bit_cast(tz_bf8, bv[nt][sa]), acc[mt][nt], 0, 0, 0);
+    }
+}
+template <int MTW, int NS, int KS>
+__device__ __forceinline__ void tz_read_a(uint4 (&a)[MTW][NS], const uint4* __restrict__ ap) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[mt][s] = ap[((long)mt * KS) * NS * 64 + s * 64];
+}
+template <int K, int CG, int NT, int MTW, int NS>
+__device__ __forceinline__ void tz_accumulate(tz_f4 (&acc)[MTW][NT], const uint4* __restrict__ aimg, const unsigned char* __restrict__ lds, const int (&boff)[NT], int ebase,
+                                              int Sd, int RW, int Sc, int Sp, int mt0) {
+    constexpr int MT = CG / 4, KS = CG / 4;
+    constexpr int NTB = NT >= 2 ? 2 : 1, NU = NT / NTB;
+    static_assert(NU == 1 || NU == 2, "units per step");
+    constexpr int SPR = K * KS;                         // steps per kd row: (kh, ks); fully unrolled, the kd loop is rolled
+    constexpr long STEP = (long)NS * 64, ENTRY = (long)MT * KS * NS * 64;      // uint4 per step / per entry of the image
+    const int lane = threadIdx.x & 63;
+    const uint4* __restrict__ ap = aimg + ((long)mt0 * KS) * NS * 64 + lane;   // (kd, kh = 0, ks = 0) of this wave's first M-tile
+    // weight operands: a FIFO two steps deep (global loads from the L2-resident image; one step of MFMAs does not cover their latency)
+    uint4 a0[MTW][NS], a1[MTW][NS], a2[MTW][NS];
+    auto a_ptr = [&](int st) { return ap + (long)(st / KS) * ENTRY + (long)(st % KS) * STEP; };      // step index relative to the current kd row (may run into the next)
+    tz_read_a<MTW, NS, KS>(a0, a_ptr(0));
+    tz_read_a<MTW, NS, KS>(a1, a_ptr(1));
+    // accumulators regrouped per unit: acc[mt][u * NTB + i]
+    tz_f4 au[NU][MTW][NTB];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int i = 0; i < NTB; ++i) au[u][mt][i] = acc[mt][u * NTB + i];
+    uint4 b0[NTB][NS], b1[NTB][NS];
+    int rowoff = ebase;                  // byte offset of (kd, kh = 0, ks = 0)
+    tz_read_b<NTB, NS>(b0, lds, boff, rowoff, Sp);
+#pragma unroll 1
+    for (int kd = 0; kd < K; ++kd) {
+#pragma unroll
+        for (int st = 0; st < SPR; ++st) {
+            const int kh = st / KS, ks = st % KS;
+            const int off = rowoff + 2 * (kh * RW + ks * 4 * Sc);
+            // next step (possibly the first of the next kd row)
+            const int stn = st + 1;
+            const int off_n = stn < SPR ? rowoff + 2 * ((stn / KS) * RW + (stn % KS) * 4 * Sc) : rowoff + 2 * Sd;
+            const bool more = stn < SPR || kd + 1 < K;
+            // (the image has spare entries behind it, so the last prefetches stay in bounds)
+            tz_read_a<MTW, NS, KS>(a2, a_ptr(st + 2));
+            if constexpr (NU == 2) {
+                tz_read_b<NTB, NS>(b1, lds, boff + NTB, off, Sp);
+                tz_mfma<NTB, MTW, NS>(au[0], a0, b0);
+                if (more) tz_read_b<NTB, NS>(b0, lds, boff, off_n, Sp);
+                tz_mfma<NTB, MTW, NS>(au[1], a0, b1);
+            } else {
+                if (more) tz_read_b<NTB, NS>(b1, lds, boff, off_n, Sp);
+                tz_mfma<NTB, MTW, NS>(au[0], a0, b0);
+#pragma unroll
+                for (int i = 0; i < NTB; ++i)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b0[i][s] = b1[i][s];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { a0[mt][s] = a1[mt][s]; a1[mt][s] = a2[mt][s]; }
+        }
+        rowoff += 2 * Sd;
+        ap += (long)K * ENTRY;
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int i = 0; i < NTB; ++i) acc[mt][u * NTB + i] = au[u][mt][i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------ the kernel
+template <int CG, int NT, int MTW, int NS, bool BWD>
+__global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tz_lds[];
+    constexpr int MT = CG / 4, KS = CG / 4, MG = MT / MTW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, q = lane >> 4;
+    const int nthr = blockDim.x;
+    // blocks of one (b, g) volume on one XCD (they share halo lines in that XCD's L2): consecutive ids go to different XCDs, so de-interleave
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    }
+    const int ntile = p.nTd * p.nTh * p.nTw;
+    const int tile = bid % ntile;
+    const int g = (bid / ntile) % p.G, b = bid / (ntile * p.G);
+    const int tw_i = tile % p.nTw, th_i = (tile / p.nTw) % p.nTh, td_i = tile / (p.nTw * p.nTh);
+    const int d0 = td_i * p.TD, h0 = th_i * p.TH, w0 = tw_i * p.TWB * 4;
+    const int mg = wave % MG, ng = wave / MG;
+    const int mt0 = mg * MTW;
+
+    // the lane's positions
+    int boff[NT], pd[NT], ph[NT], pw[NT];
+    bool live[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int pos = (ng * NT + nt) * 16 + n;
+        live[nt] = pos < p.P;
+        pos = live[nt] ? pos : p.P - 1;
+        // position order: w-block fastest, then D, then H -- the 16 / TWB rows of an N-tile are consecutive d-planes, whose (padded) stride makes the
+        // operand reads of a 32-lane group bank-conflict free (tz_geo)
+        const unsigned r1 = tz_divm((unsigned)pos, p.mTWB);
+        const int wb = pos - (int)r1 * p.TWB;
+        const unsigned r2 = tz_divm(r1, p.mTD);
+        pd[nt] = (int)(r1 - r2 * p.TD);
+        ph[nt] = (int)r2;
+        pw[nt] = 4 * wb;
+        live[nt] = live[nt] && d0 + pd[nt] < p.D && h0 + ph[nt] < p.H && w0 + pw[nt] < p.W;
+    }
+    tz_f4 acc[MTW][NT];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (tz_f4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto set_boff = [&](const TzGeo& ge) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) boff[nt] = 2 * (q * ge.Sc + pd[nt] * ge.Sd + ph[nt] * p.RW + pw[nt]);
+    };
+    const long chan = (long)p.D * p.H * p.W;
+    const uint4* __restrict__ img_g = p.img + (long)g * 35 * MT * KS * NS * 64;
+
+    if constexpr (!BWD) {
+        const TzGeo& ge = p.geo[0];
+        if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+        set_boff(ge);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tz_lds + p.red_off);            // [3][waves][MTW][4][2]
+        const int nwave = nthr >> 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {              // c = 0: K = 5, 1: K = 3, 2: K = 1
+            zero();
+            if (p.dbg & 2) {}
+            else if (c == 0) tz_accumulate<5, CG, NT, MTW, NS>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            else if (c == 1) tz_accumulate<3, CG, NT, MTW, NS>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 2 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            else tz_accumulate<1, CG, NT, MTW, NS>(acc, img_g + (long)34 * MT * KS * NS * 64, tz_lds, boff, 4 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            float* __restrict__ y = p.out[c];
+            const float* __restrict__ bias = p.bias[c];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int co = g * CG + (mt0 + mt) * 4 + q;
+                const float bv = bias ? bias[co] : 0.0f;
+                float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (live[nt]) {
+                        const float o0 = acc[mt][nt][0] + bv, o1 = acc[mt][nt][1] + bv, o2 = acc[mt][nt][2] + bv, o3 = acc[mt][nt][3] + bv;
+                        *reinterpret_cast<float4*>(y + ((long)b * p.C + co) * chan + ((long)(d0 + pd[nt]) * p.H + h0 + ph[nt]) * p.W + w0 + pw[nt]) = make_float4(o0, o1, o2, o3);
+                        s += (o0 + o1) + (o2 + o3);
+                        s2 = fmaf(o0, o0, s2); s2 = fmaf(o1, o1, s2); s2 = fmaf(o2, o2, s2); s2 = fmaf(o3, o3, s2);
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (n == 0) {
+                    float* r = red + ((((long)c * nwave + wave) * MTW + mt) * 4 + q) * 2;
+                    r[0] = s; r[1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * CG) {
+            const int c = threadIdx.x / CG, cl = threadIdx.x % CG;
+            const int mtg = cl >> 2, qq = cl & 3, mgi = mtg / MTW, mti = mtg % MTW;
+            double s = 0.0, s2 = 0.0;
+            const int nng = nwave / MG;
+            for (int w_ = 0; w_ < nng; ++w_) {
+                const float* r = red + ((((long)c * nwave + (w_ * MG + mgi)) * MTW + mti) * 4 + qq) * 2;
+                s += (double)r[0]; s2 += (double)r[1];
+            }
+            const int k = 2 - c;                                   // part order: y1, y3, y5
+            double* dst = p.part + ((((long)k * p.B + b) * p.C + g * CG + cl) * ntile + tile) * 2;
+            dst[0] = s; dst[1] = s2;
+        }
+    } else {
+        zero();
+        {
+            const TzGeo& ge = p.geo[0];
+            if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+            set_boff(ge);
+            __syncthreads();
+            if (!(p.dbg & 2)) tz_accumulate<5, CG, NT, MTW, NS>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+        }
+        __syncthreads();
+        {
+            const TzGeo& ge = p.geo[1];
+            if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr);
+            set_boff(ge);
+            __syncthreads();
+            if (!(p.dbg & 2)) tz_accumulate<3, CG, NT, MTW, NS>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+        }
+        // epilogue: + conv1^T(g1) + d_o straight from global memory
+        const float* __restrict__ g1 = p.src[2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (!live[nt]) continue;
+            const long sp_off = ((long)(d0 + pd[nt]) * p.H + h0 + ph[nt]) * p.W + w0 + pw[nt];
+            for (int cc = 0; cc < CG; ++cc) {
+                const float4 gv = *reinterpret_cast<const float4*>(g1 + ((long)b * p.C + g * CG + cc) * chan + sp_off);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float wv = p.w1[(long)(g * CG + cc) * CG + (mt0 + mt) * 4 + q];
+                    acc[mt][nt][0] = fmaf(wv, gv.x, acc[mt][nt][0]); acc[mt][nt][1] = fmaf(wv, gv.y, acc[mt][nt][1]);
+                    acc[mt][nt][2] = fmaf(wv, gv.z, acc[mt][nt][2]); acc[mt][nt][3] = fmaf(wv, gv.w, acc[mt][nt][3]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const long off = ((long)b * p.C + g * CG + (mt0 + mt) * 4 + q) * chan + sp_off;
+                const float4 r = *reinterpret_cast<const float4*>(p.res + off);
+                *reinterpret_cast<float4*>(p.out[0] + off) = make_float4(acc[mt][nt][0] + r.x, acc[mt][nt][1] + r.y, acc[mt][nt][2] + r.z, acc[mt][nt][3] + r.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host
+static unsigned tz_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / (unsigned long long)d); }      // see tz_divm
+
+static int g_tz_pieces = 3;
+static int g_tz_dbg = 0;
+extern "C" int vx_jlc_tz_set_debug(int mask) { g_tz_dbg = mask; return 0; }
+extern "C" int vx_jlc_tz_set_pieces(int ns) { if (ns < 1 || ns > 3) return -1; g_tz_pieces = ns; return 0; }
+extern "C" int vx_jlc_tz_pieces(void) { return g_tz_pieces; }
+
+struct TzPlan { int CG, NT, MTW, nwaves; size_t shm; };
+
+static void tz_geo(TzGeo& ge, const VxTz& p, int CG, int hw) {
+    ge.HD = p.TD + 2 * hw; ge.HH = p.TH + 2 * hw;
+    // Strides padded for the operand reads (ds_read_b64: two groups of 32 lanes = 16 positions x 2 channels, bank = (byte / 4) mod 64).  The 16 positions of an
+    // N-tile are TWB w-blocks (8 bytes each, contiguous) x 16 / TWB consecutive d-planes; with the d-plane stride an ODD multiple of the TWB * 8-byte interval
+    // (mod 256 bytes) the planes tile 32 banks, and with the channel stride = 128 bytes (mod 256) the second channel of the group takes the other 32.
+    ge.Sd = ge.HH * p.RW;
+    if (p.TWB >= 2) {
+        const int iv = 4 * p.TWB;                      // interval in elements
+        while (!((ge.Sd % iv) == 0 && ((ge.Sd / iv) & 1) && true)) ge.Sd += 4;
+        // (mod 128 elements the same test: iv divides 128)
+    }
+    ge.Sc = ge.HD * ge.Sd;
+    while ((ge.Sc & 127) != 64) ge.Sc += 4;
+    ge.Sp = CG * ge.Sc;
+    ge.nrows = CG * ge.HD * ge.HH;
+    ge.mHH = tz_magic(ge.HH); ge.mHD = tz_magic(ge.HD);
+    if (hw == 0) { ge.qd0 = 1; ge.nq = p.TWB; } else { ge.qd0 = 0; ge.nq = p.TWB + 2; }
+    ge.mNQ = tz_magic(ge.nq);
+}
+
+// tile / wave plan: a function of (C/G, D, H, W) only -- never of the batch (a sample's partial sums must fold in the same order whatever it is batched with)
+static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W, int NS) {
+    if (B <= 0 || C <= 0 || G <= 0 || C % G || D <= 0 || H <= 0 || W <= 0 || (W & 3)) return -1;
+    const int CG = C / G;
+    if (CG != 4 && CG != 8 && CG != 16) return -1;
+    p.B = B; p.C = C; p.G = G; p.D = D; p.H = H; p.W = W;
+    p.TWB = W / 4 < 8 ? W / 4 : 8;
+    p.TH = H < 8 ? H : 8;
+    p.TD = D < 8 ? D : 8;
+    auto lds_bytes = [&](int td, int th, int twb) {
+        VxTz q = p; TzGeo ge;
+        q.TD = td; q.TH = th; q.TWB = twb; q.RW = 4 * twb + 4;
+        tz_geo(ge, q, CG, 2);
+        return (size_t)NS * ge.Sp * 2;
+    };
+    while (lds_bytes(p.TD, p.TH, p.TWB) > 150 * 1024) {
+        if (p.TD > 1 && p.TD >= p.TH) p.TD = (p.TD + 1) / 2;
+        else if (p.TH > 1) p.TH = (p.TH + 1) / 2;
+        else return -1;
+    }
+    p.nTd = vx_cdiv(D, p.TD); p.nTh = vx_cdiv(H, p.TH); p.nTw = vx_cdiv(W / 4, p.TWB);
+    p.RW = 4 * p.TWB + 4;
+    p.P = p.TD * p.TH * p.TWB;
+    p.nNt = vx_cdiv(p.P, 16);
+    p.mTWB = tz_magic(p.TWB); p.mTD = tz_magic(p.TD);
+    tz_geo(p.geo[0], p, CG, 2);
+    tz_geo(p.geo[1], p, CG, 1);
+    const int MT = CG / 4;
+    pl.CG = CG;
+    // waves = (M-tile groups) x (N-tile groups), at most 8 (two per SIMD), at most 4 accumulator tiles per wave.  Most waves first (latency hiding), then more
+    // M-tiles per wave (an activation operand read from LDS then feeds more MFMAs: LDS, not the L2-resident weight images, is the scarcer path), then more N-tiles
+    int best = -1;
+    pl.NT = 1; pl.MTW = 1;
+    for (int mtw = 1; mtw <= MT; mtw <<= 1)
+        for (int nt = 1; nt <= 4; nt <<= 1) {
+            if (mtw * nt > 4) continue;
+            const int waves = (MT / mtw) * vx_cdiv(p.nNt, nt);
+            if (waves > 8) continue;
+            const int score = waves * 100 + mtw * 10 + nt;
+            if (score > best) { best = score; pl.NT = nt; pl.MTW = mtw; }
+        }
+    if (best < 0) return -1;
+    pl.nwaves = (MT / pl.MTW) * vx_cdiv(p.nNt, pl.NT);
+    if (pl.nwaves > 8) return -1;
+    size_t halo = lds_bytes(p.TD, p.TH, p.TWB);
+    halo = (halo + 15) & ~(size_t)15;
+    p.red_off = (int)halo;
+    pl.shm = halo + (size_t)3 * pl.nwaves * pl.MTW * 4 * 2 * sizeof(float);
+    return 0;
+}
+
+// Smallest volume (voxels per channel) the matrix-pipe kernels are SELECTED for (vx_jlc_tz_ok; the entry points themselves take any supported shape).  Measured
+// stand-alone at B = 4 (tools/jlc_tz_probe.py): 32^3 58 -> 32 us, 16^3 57 -> 42 us, 8^3 31 -> 34 us, 4^3 41 -> 52 us: below 16^3 a launch has 32 blocks and the chain
+// stage -> 35 dependent entries -> epilogue is latency-bound either way.
+static long g_tz_min_v = 4096;
+extern "C" int vx_jlc_tz_set_min_voxels(long v) { g_tz_min_v = v < 0 ? 0 : v; return 0; }
+extern "C" int vx_jlc_tz_ok(int C, int G, int D, int H, int W) {
+    VxTz p = {};
+    TzPlan pl;
+    if ((long)D * H * W < g_tz_min_v) return 0;
+    return tz_plan(p, pl, 1, C, G, D, H, W, g_tz_pieces) == 0 ? 1 : 0;
+}
+extern "C" int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W) {
+    VxTz p = {};
+    TzPlan pl;
+    if (tz_plan(p, pl, 1, C, G, D, H, W, g_tz_pieces) != 0) return -1;
+    return p.nTd * p.nTh * p.nTw;
+}
+// uint4 elements of ONE direction's image (+ one spare entry for the operand prefetch); the workspace of vx_jlc_tz_prep holds two (forward, input gradient)
+static long tz_img_elems(int C, int G, int NS) {
+    const int CG = C / G, MT = CG / 4;
+    return (long)G * 35 * MT * MT * NS * 64 + (long)2 * MT * MT * NS * 64;        // + two spare entries: the operand FIFO reads two steps ahead
+}
+extern "C" int vx_jlc_tz_img_floats(int C, int G) { return (int)(2 * tz_img_elems(C, G, g_tz_pieces) * 4); }
+
+extern "C" int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream) {
+    VX_REQUIRE(w1 && w3 && w5 && img && G > 0 && C % G == 0, "vx_jlc_tz_prep: bad args");
+    const int CG = C / G, NS = g_tz_pieces;
+    VX_REQUIRE(CG == 4 || CG == 8 || CG == 16, "vx_jlc_tz_prep: group width %d", CG);
+    const long ne = tz_img_elems(C, G, NS);
+    uint4* f = reinterpret_cast<uint4*>(img);
+    uint4* bw = f + ne;
+    const int MT = CG / 4;
+    const long total = (long)G * 35 * MT * MT * 64;
+    const dim3 grid((unsigned)vx_cdiv(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+#define TZ_PREP(cg, ns) vx_tz_prep_k<cg, ns><<<grid, dim3(256), 0, st>>>(w1, w3, w5, f, bw, G)
+    if (NS == 3) { if (CG == 4) TZ_PREP(4, 3); else if (CG == 8) TZ_PREP(8, 3); else TZ_PREP(16, 3); }
+    else if (NS == 2) { if (CG == 4) TZ_PREP(4, 2); else if (CG == 8) TZ_PREP(8, 2); else TZ_PREP(16, 2); }
+    else { if (CG == 4) TZ_PREP(4, 1); else if (CG == 8) TZ_PREP(8, 1); else TZ_PREP(16, 1); }
+#undef TZ_PREP
+    VX_LAUNCH_CHECK("vx_jlc_tz_prep");
+    return 0;
+}
+
+template <int CG, int NT, int MTW, int NS, bool BWD>
+static int tz_launch_t(const VxTz& p, const TzPlan& pl, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)vx_tz_k<CG, NT, MTW, NS, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+        attr = true;
+    }
+    const dim3 grid((unsigned)(p.nTd * p.nTh * p.nTw * p.G * p.B));
+    vx_tz_k<CG, NT, MTW, NS, BWD><<<grid, dim3(64 * pl.nwaves), pl.shm, st>>>(p);
+    return 0;
+}
+template <int NS, bool BWD>
+static int tz_launch(const VxTz& p, const TzPlan& pl, hipStream_t st) {
+#define TZ_CASE(cg, nt, mtw) if (pl.CG == cg && pl.NT == nt && pl.MTW == mtw) return tz_launch_t<cg, nt, mtw, NS, BWD>(p, pl, st)
+    TZ_CASE(4, 1, 1); TZ_CASE(4, 2, 1); TZ_CASE(4, 4, 1);
+    TZ_CASE(8, 1, 1); TZ_CASE(8, 2, 1); TZ_CASE(8, 4, 1); TZ_CASE(8, 1, 2); TZ_CASE(8, 2, 2);
+    TZ_CASE(16, 1, 1); TZ_CASE(16, 2, 1); TZ_CASE(16, 4, 1); TZ_CASE(16, 1, 2); TZ_CASE(16, 2, 2); TZ_CASE(16, 1, 4);
+#undef TZ_CASE
+    return -3;
+}
+
+extern "C" int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, const float* b3, const float* b5, float* y1, float* y3, float* y5, double* part,
+                             int B, int C, int G, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && img && y1 && y3 && y5 && part, "vx_jlc_tz_fwd: null pointer");
+    VxTz p = {};
+    TzPlan pl;
+    const int NS = g_tz_pieces;
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, NS) == 0, "vx_jlc_tz_fwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    p.src[0] = x; p.img = reinterpret_cast<const uint4*>(img);
+    p.bias[0] = b5; p.bias[1] = b3; p.bias[2] = b1;
+    p.out[0] = y5; p.out[1] = y3; p.out[2] = y1; p.part = part; p.dbg = g_tz_dbg;
+    const int rc = NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
+    VX_REQUIRE(rc == 0, "vx_jlc_tz_fwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
+    VX_LAUNCH_CHECK("vx_jlc_tz_fwd");
+    return 0;
+}
+
+extern "C" int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
+                             int B, int C, int G, int D, int H, int W, void* stream) {
+    VX_REQUIRE(g1 && g3 && g5 && img && w1 && d_o && dx, "vx_jlc_tz_bwd: null pointer");
+    VxTz p = {};
+    TzPlan pl;
+    const int NS = g_tz_pieces;
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, NS) == 0, "vx_jlc_tz_bwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    p.src[0] = g5; p.src[1] = g3; p.src[2] = g1;
+    p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, NS);
+    p.w1 = w1; p.res = d_o; p.out[0] = dx; p.dbg = g_tz_dbg;
+    const int rc = NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
+    VX_REQUIRE(rc == 0, "vx_jlc_tz_bwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
+    VX_LAUNCH_CHECK("vx_jlc_tz_bwd");
+    return 0;
+}
