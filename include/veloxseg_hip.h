@@ -191,6 +191,12 @@ int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, const float
                   int B, int C, int G, int D, int H, int W, void* stream);
 int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
                   int B, int C, int G, int D, int H, int W, void* stream);
+/* the three weight gradients of the same convolutions in ONE launch on the matrix pipe (accumulated into dw1 / dw3 / dw5 with float atomics, like every weight-gradient
+ * entry; a null dw skips that tensor's store); W <= 32, W % 4 == 0, H % 4 == 0, group width 4 / 8 / 16.  Bias gradients are not computed (zero behind an InstanceNorm). */
+int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W);
+int vx_jlc_wgrad_tz_set_min_voxels(long v);
+int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,

@@ -258,3 +258,40 @@ def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
     finally:
         H.call("vx_jlc_tz_set_pieces", 3)
         H.call("vx_jlc_tz_set_min_voxels", 4096)
+
+
+@pytest.mark.parametrize("pieces", [3, 1])
+@pytest.mark.parametrize("case", [c for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32], ids=[c[0] for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32])
+def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, pieces):
+    """vx_jlc_wgrad_tz (the three grouped-conv weight gradients of conv_blocks.py:51-58 in one matrix-pipe launch, csrc/jlc_mfma.hip) against torch's fp64 weight
+    gradient and the fp32 VALU kernels (csrc/conv_wgrad.hip); the entry ACCUMULATES into dw (float atomics), checked by a non-zero start value."""
+    from veloxseg_amd import _hip as H
+    _, B, C, G, (D, Hh, W) = case
+    H.LIB.load()
+    H.call("vx_jlc_tz_set_pieces", pieces)
+    try:
+        assert H.query("vx_jlc_wgrad_tz_ok", C, G, D, Hh, W) == 1
+        torch.manual_seed(11)
+        Cg = C // G
+        x = torch.randn(B, C, D, Hh, W, device="cuda")
+        g = torch.randn(3, B, C, D, Hh, W, device="cuda")
+        shapes = [(C, Cg, k, k, k) for k in (1, 3, 5)]
+        init = [torch.randn(s_, device="cuda") for s_ in shapes]
+        d_new = [t.clone() for t in init]
+        d_old = [torch.zeros(s_, device="cuda") for s_ in shapes]
+        st = torch.cuda.current_stream().cuda_stream
+        H.call("vx_jlc_wgrad_tz", H.P(x), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(d_new[0]), H.P(d_new[1]), H.P(d_new[2]), B, C, G, D, Hh, W, st)
+        H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, 0, g[1].data_ptr(), H.P(d_old[1]), None, B, C, D, Hh, W, C, 3, 1, 1, G, 1, st)
+        H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, 0, g[2].data_ptr(), H.P(d_old[2]), None, B, C, D, Hh, W, C, 5, 1, 2, G, 1, st)
+        torch.cuda.synchronize()
+        for i, k in enumerate((1, 3, 5)):
+            ref = torch.nn.grad.conv3d_weight(x.double(), shapes[i], g[i].double(), padding=k // 2, groups=G)
+            sc = float(ref.abs().max())
+            e_new = float(((d_new[i] - init[i]).double() - ref).abs().max()) / sc
+            if pieces == 3:
+                e_old = float((d_old[i].double() - ref).abs().max()) / sc if i else 0.0
+                assert e_new <= max(3.0 * e_old, 3e-6), (k, e_old, e_new)
+            else:
+                assert e_new <= 2e-2, (k, e_new)
+    finally:
+        H.call("vx_jlc_tz_set_pieces", 3)

@@ -106,6 +106,33 @@ def main():
         print(f"  bwd: rel-to-max err  valu {float((dx_old.double() - ref).abs().max()) / sc:.2e}  tz {float((dx_new.double() - ref).abs().max()) / sc:.2e}")
         t_old, t_new = timeit(b_old), timeit(b_new)
         print(f"  bwd time: valu {t_old:.1f} us ({flops / t_old / 1e6:.1f} TFLOP/s)  tz {t_new:.1f} us ({flops / t_new / 1e6:.1f} TFLOP/s)")
+        # ---------------- weight gradients (all three)
+        if H.query("vx_jlc_wgrad_tz_ok", C, G, D, Hh, W):
+            dws_old = [torch.zeros_like(w_) for w_ in ws]
+            dws_new = [torch.zeros_like(w_) for w_ in ws]
+
+            def w_old():
+                H.call("vx_gconv1_bwd_weight", H.P(x), g[0].data_ptr(), H.P(dws_old[0]), None, B, C, G, D * Hh * W, st)
+                H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, 0, g[1].data_ptr(), H.P(dws_old[1]), None, B, C, D, Hh, W, C, 3, 1, 1, G, 1, st)
+                H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, 0, g[2].data_ptr(), H.P(dws_old[2]), None, B, C, D, Hh, W, C, 5, 1, 2, G, 1, st)
+
+            def w_new():
+                H.call("vx_jlc_wgrad_tz", H.P(x), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(dws_new[0]), H.P(dws_new[1]), H.P(dws_new[2]), B, C, G, D, Hh, W, st)
+
+            w_old(); w_new()
+            torch.cuda.synchronize()
+            xg = x.double().requires_grad_(False)
+            for i, k in enumerate((1, 3, 5)):
+                ref = torch.nn.grad.conv3d_weight(x.double(), ws[i].shape, g[i].double(), padding=k // 2, groups=G)
+                sc = float(ref.abs().max())
+                print(f"  wgrad k={k}: rel-to-max err  valu {float((dws_old[i].double() - ref).abs().max()) / sc:.2e}  tz {float((dws_new[i].double() - ref).abs().max()) / sc:.2e}")
+            t_old, t_new = timeit(w_old), timeit(w_new)
+            print(f"  wgrad time (3 tensors): valu {t_old:.1f} us ({flops / t_old / 1e6:.1f} TFLOP/s)  tz {t_new:.1f} us ({flops / t_new / 1e6:.1f} TFLOP/s)")
+            if args.breakdown:
+                for mask, what in ((1, "no staging"), (2, "no MFMA phase"), (4, "no fold / atomics"), (3, "no staging, no MFMA"), (7, "launch + syncs only")):
+                    H.call("vx_jlc_tz_set_debug", mask << 4)
+                    print(f"    wgrad {what}: {timeit(w_new):.1f} us")
+                H.call("vx_jlc_tz_set_debug", 0)
         if args.breakdown:
             for mask, what in ((1, "no staging"), (2, "no MFMA loops"), (3, "neither (launch + epilogue)")):
                 H.call("vx_jlc_tz_set_debug", mask)

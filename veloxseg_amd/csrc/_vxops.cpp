@@ -37,6 +37,7 @@ struct Flags {
     int tile_min_c = 32;              // JLC channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*) from this many channels up, mlp.hip below (functional.TILE_MIN_C)
     bool upconv_wgrad_mfma = true;    // (A/B) ConvTranspose weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad) vs the generic strided-conv kernel
     bool jlc_tz = true;               // JLC grouped convolutions (forward + input gradient) as Toeplitz GEMMs on the bf16 matrix pipe, fp32-exact products (csrc/jlc_mfma.hip); 0 = the fp32 VALU kernels of jlc.hip
+    bool jlc_wg_tz = true;            // the three JLC weight gradients in one matrix-pipe launch (csrc/jlc_mfma.hip vx_jlc_wgrad_tz); 0 = the VALU kernels of conv_wgrad.hip
     bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
@@ -1029,8 +1030,13 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
                 float* dw3 = f.w3.requires_grad() ? grad_ptr(f.w3) : nullptr;
                 float* dw5 = f.w5.requires_grad() ? grad_ptr(f.w5) : nullptr;
                 const bool g1fast = F.use_gconv1 && (Cg == 4 || Cg == 8 || Cg == 16) && V % 4 == 0;
+                const bool wtz = F.jlc_wg_tz && dw1 && dw3 && dw5 && vx_jlc_wgrad_tz_ok(C, G, D, H, W);
                 wgrad_submit(s_, f.x.device().index(), [=](void* s) {
                     const float* gq = gk.data_ptr<float>();
+                    if (wtz) {                    // all three weight gradients in one launch on the matrix pipe (csrc/jlc_mfma.hip)
+                        VX(vx_jlc_wgrad_tz, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, s);
+                        return;
+                    }
                     if (dw1) {
                         if (g1fast) VX(vx_gconv1_bwd_weight, fp(xk), gq, dw1, nullptr, B, C, G, V, s);
                         else VX(vx_conv3d_bwd_weight_tiled, fp(xk), nullptr, 0, gq, dw1, nullptr, B, C, D, H, W, C, 1, 1, 0, G, 1, s);
@@ -1312,6 +1318,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });
     m.def("set_jlc_tz", [](bool on) { F.jlc_tz = on; });          // A/B (tests): JLC grouped convs on the matrix pipe (default) or the fp32 VALU kernels
     m.def("get_jlc_tz", []() { return F.jlc_tz; });
+    m.def("set_jlc_wg_tz", [](bool on) { F.jlc_wg_tz = on; });    // A/B (tests): JLC weight gradients on the matrix pipe (default) or the VALU kernels
     m.def("set_jlc_tile", [](bool on) { F.jlc_tile = on; });      // A/B (tests): JLC block of the coarse levels fused (default) or per operator
     m.def("set_expand_wgrad_split", [](bool on) { F.expand_wgrad_split = on; });      // A/B (tests, probes): weight gradient of the patch-expand layers on the split kernels
     m.def("set_fuse_blocks", [](bool on) { F.fuse_blocks = on; });     // A/B: JLC block / FFN tail on the fused block kernels (jlc.hip, mlp.hip) vs the per-operator kernels

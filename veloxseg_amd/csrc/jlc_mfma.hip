@@ -604,3 +604,374 @@ extern "C" int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, 
     VX_LAUNCH_CHECK("vx_jlc_tz_bwd");
     return 0;
 }
+
+// ======================================================================================================================================================================
+// Weight gradients of the three grouped convolutions on the same pipe:  dW_K[co][ci][kd][kh][kw] = sum_{b, d, h, w} g_K[b][co][d][h][w] * x[b][ci][d+kd-K/2][h+kh-K/2][w+kw-K/2].
+// GEMM of one MFMA: the reduction (k) axis is a whole W row -- 32 slots = nb samples x WS columns (WS = W rounded up to 8, nb = 32 / WS: the sum over the batch is part of
+// the weight gradient, so small levels fill the slots with more samples) -- rows = (4 output channels x 4 consecutive H rows of g), columns = (4 input channels x 4
+// consecutive H rows of x).  The 16 x 16 result holds every (g row j, x row i) pair: the pair belongs to tap kh = i - j + const, so one MFMA covers up to 5 taps along H
+// ("Toeplitz in H": 10 of 16 entries used); kd is the plane offset between the two operands and kw a shift of the x operand ALONG the reduction axis, which is formed in
+// registers from a 16-element aligned window (even shifts = register selection, odd shifts = 4 v_alignbit per piece).  fp32 products from 3 bf16 pieces per operand as above.
+// A block = 4 waves owns (sample group, conv group, 4 x 4 channel pair, H tile of TH rows, D chunk) and marches over the x planes of its chunk: the current x plane and rings
+// of 5 / 3 / 1 planes of g5 / g3 / g1 live in LDS as bf16 pieces; waves 0..2 hold the accumulators of (K = 5, kd = wave), (K = 3, kd = wave) and (wave 0) K = 1, wave 3 those
+// of K = 5, kd = 3 and 4 (69 tiles of 16 x 16 per 4 x 4 channel pair in all).  After the march the tiles are folded along their diagonals into an LDS image of the three
+// weight-gradient slices and added to global memory with float atomics (as every weight-gradient kernel of the library).
+struct VxWgT {
+    const float *x, *g5, *g3, *g1;
+    float *dw5, *dw3, *dw1;
+    int B, C, G, D, H, W, CG;
+    int WS, nb, nsg;                 // slots per sample, samples per reduction chunk, sample groups
+    int TH, nHt, DC, nDc, nXB;       // H tile (multiple of 4), D chunk, x row blocks per tile (TH / 4 + 1)
+    int XR;                          // x row length in LDS (WS + 8: e = w + 4)
+    int XP, GP, SP;                  // elements: x plane / one g plane / piece stride (XP + 9 GP)
+    int dbg;                         // timing experiments: bit 0 no staging, bit 1 no MFMA phase, bit 2 no fold / atomics
+};
+
+template <int NS>
+__device__ __forceinline__ void wg_split_store(float4 v, unsigned char* lds, long e0, long SP) {          // 4 consecutive elements at element offset e0 (a multiple of 4) of piece 0
+    float a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t lo = tz_pack(a0, a1), hi = tz_pack(a2, a3);
+        *reinterpret_cast<uint2*>(lds + 2 * (s * SP + e0)) = make_uint2(lo, hi);
+        if (s + 1 < NS) { a0 -= tz_lo(lo); a1 -= tz_hi(lo); a2 -= tz_lo(hi); a3 -= tz_hi(hi); }
+    }
+}
+
+// Staging of one step = the x plane dx (halo rows / columns) and the newly needed g planes (g5: dx + 2, g3: dx + 1, g1: dx; owned planes only), as one list of
+// quads (4 consecutive w): item -> (tensor, sample, channel, row, quad).  The loads of step dx + 1 are issued BEFORE the MFMAs of step dx and committed (split into
+// pieces, stored to LDS) after them: a step's global latency hides behind the previous step's arithmetic.
+#define WG_NPF 6
+// one descriptor per (thread, item), decoded ONCE (the divisions cost more than a step's arithmetic when repeated every step): `g` = element offset inside plane 0 of the
+// source tensor (the plane term pl * H * W is added per step), `l` = LDS element offset inside slot 0 (x: the x buffer), flags: bits 0..1 kind (0 x, 1 g5, 2 g3, 3 g1),
+// bit 2 live (the item exists), bit 3 ok (inside the volume; else zeros are stored)
+struct WgDesc { int g, l, f; };
+__device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int cob, int cib, int h0) {
+    WgDesc r;
+    r.g = 0; r.l = 0; r.f = 0;
+    const int nqx = p.XR / 4, rows = p.TH + 4;
+    const int nx = p.nb * 4 * rows * nqx;
+    const int chan = p.D * p.H * p.W;
+    if (it < nx) {
+        const int qd = it % nqx; int t = it / nqx;
+        const int row = t % rows; t /= rows;
+        const int ci = t & 3, s = t >> 2;
+        const int b = sg * p.nb + s, ih = h0 - 2 + row, iw = 4 * qd - 4;
+        const bool ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        r.f = 4 | (ok ? 8 : 0);
+        r.g = ok ? (b * p.C + cib + ci) * chan + ih * p.W + iw : 0;
+        r.l = ((s * 4 + ci) * rows + row) * p.XR + 4 * qd;
+        return r;
+    }
+    it -= nx;
+    const int nqg = p.WS / 4;
+    const int ng = p.nb * 4 * p.TH * nqg;
+    const int kind = it / ng;                  // 0: g5, 1: g3, 2: g1
+    if (kind > 2) return r;
+    it -= kind * ng;
+    const int qd = it % nqg; int t = it / nqg;
+    const int row = t % p.TH; t /= p.TH;
+    const int co = t & 3, s = t >> 2;
+    const int b = sg * p.nb + s, ih = h0 + row, iw = 4 * qd;
+    const bool ok = b < p.B && ih < p.H && iw < p.W;
+    r.f = (kind + 1) | 4 | (ok ? 8 : 0);
+    r.g = ok ? (b * p.C + cob + co) * chan + ih * p.W + iw : 0;
+    r.l = p.XP + ((s * 4 + co) * (p.TH + 1) + row) * p.WS + 4 * qd;
+    return r;
+}
+// plane / ring slot of item kind `k` at step dx; false: nothing to stage (plane outside the volume / not owned)
+__device__ __forceinline__ bool wg_plane(const VxWgT& p, int k, int dx, int dg0, int dg1, int& pl, int& slot) {
+    if (k == 0) { pl = dx; slot = 0; return (unsigned)dx < (unsigned)p.D; }
+    pl = dx + 3 - k;                                               // g5: dx + 2, g3: dx + 1, g1: dx
+    slot = k == 1 ? (pl + 10) % 5 : k == 2 ? 5 + (pl + 9) % 3 : 8;
+    return pl >= dg0 && pl < dg1;
+}
+__device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], const VxWgT& p, int dx, int dg0, int dg1) {
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int u = 0; u < WG_NPF; ++u) {
+        const int k = ds[u].f & 3;
+        int pl, slot;
+        const bool on = wg_plane(p, k, dx, dg0, dg1, pl, slot) && (ds[u].f & 8);
+        const float* src = k == 0 ? p.x : k == 1 ? p.g5 : k == 2 ? p.g3 : p.g1;
+        // explicit GLOBAL address space: through the pointer select the compiler falls back to FLAT loads, which count on lgkmcnt as well -- every LDS wait of the
+        // MFMA phase would then also wait for this step's prefetch
+        typedef const __attribute__((address_space(1))) tz_f4* wg_gptr;
+        const unsigned long long ga = (unsigned long long)src + 4ull * (unsigned long long)(on ? (long)ds[u].g + (long)pl * HW : 0);      // (dead items read a valid address)
+        const tz_f4 t = *(wg_gptr)ga;
+        pf[u] = on ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void wg_commit(const float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], unsigned char* lds, const VxWgT& p, int dx, int dg0, int dg1) {
+#pragma unroll
+    for (int u = 0; u < WG_NPF; ++u) {
+        const int k = ds[u].f & 3;
+        int pl, slot;
+        const bool on = wg_plane(p, k, dx, dg0, dg1, pl, slot) && (ds[u].f & 4);
+        if (on) wg_split_store<NS>(pf[u], lds, (long)ds[u].l + (long)slot * p.GP, p.SP);
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void wg_read_a(uint4 (&a)[NS], const unsigned char* lds, const VxWgT& p, int slot, int arow_base, int local, int th_lane) {
+    // lane (m = (co, j), q): row local + j of the g block, redirected to the zero row when it is outside the tile
+    const int j = threadIdx.x & 3;
+    const int r = local + j;
+    const int rr = (unsigned)r < (unsigned)th_lane ? r : p.TH;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        a[s] = *reinterpret_cast<const uint4*>(lds + 2 * ((long)s * p.SP + p.XP + (long)slot * p.GP + (long)arow_base + (long)rr * p.WS));
+}
+
+template <int NS>
+__device__ __forceinline__ void wg_mfma6(tz_f4& acc, const uint4 (&a)[NS], const uint4 (&b)[NS]) {
+    constexpr int NP = NS == 3 ? 6 : NS == 2 ? 3 : 1;
+    constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PW2[3] = {1, 0, 0}, PA2[3] = {0, 1, 0};
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+        const int sa = NS == 3 ? PW[pr] : NS == 2 ? PW2[pr] : 0, sb = NS == 3 ? PA[pr] : NS == 2 ? PA2[pr] : 0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[sa]), __builtin_bit_cast(tz_bf8, b[sb]), acc, 0, 0, 0);
+    }
+}
+
+// the x operand shifted by o elements (2..6) out of the 16-element window w[0..7] (dwords)
+__device__ __forceinline__ uint4 wg_shift(const uint32_t (&w)[8], int o) {
+    const int d = o >> 1;
+    if ((o & 1) == 0) return make_uint4(w[d], w[d + 1], w[d + 2], w[d + 3]);
+    return make_uint4(__builtin_amdgcn_alignbit(w[d + 1], w[d], 16), __builtin_amdgcn_alignbit(w[d + 2], w[d + 1], 16), __builtin_amdgcn_alignbit(w[d + 3], w[d + 2], 16),
+                      __builtin_amdgcn_alignbit(w[d + 4], w[d + 3], 16));
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r16 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int dc = bid % p.nDc; bid /= p.nDc;
+    const int ht = bid % p.nHt; bid /= p.nHt;
+    const int MT = p.CG >> 2;
+    const int ih = bid % MT; bid /= MT;
+    const int ch = bid % MT; bid /= MT;
+    const int g = bid % p.G;
+    const int sg = bid / p.G;
+    const int h0 = ht * p.TH;
+    const int dg0 = dc * p.DC, dg1 = min(p.D, dg0 + p.DC);          // owned g planes
+    const int cob = g * p.CG + ch * 4, cib = g * p.CG + ih * 4;
+
+    // zero rows of every g slot (never overwritten)
+    for (int it = threadIdx.x; it < 9 * p.nb * 4 * (p.WS / 2) * NS; it += blockDim.x) {
+        int r = it;
+        const int e2 = r % (p.WS / 2); r /= (p.WS / 2);
+        const int sc = r % (p.nb * 4); r /= (p.nb * 4);
+        const int slot = r % 9, s = r / 9;
+        *reinterpret_cast<uint32_t*>(wg_lds + 2 * ((long)s * p.SP + p.XP + (long)slot * p.GP + ((long)sc * (p.TH + 1) + p.TH) * p.WS + 2 * e2)) = 0u;
+    }
+    // lane constants: sample / column of the lane's 8 reduction slots
+    // (WS = 24: slots 24..31 belong to no sample -- those lanes read the zero row as their g operand, whatever x operand they pair it with)
+    const int smp_ = (8 * q) / p.WS;
+    const bool nosmp = smp_ >= p.nb;
+    const int smp = nosmp ? 0 : smp_, wq = nosmp ? 0 : 8 * q - smp_ * p.WS;
+    const int arow_base = ((smp * 4 + (r16 >> 2)) * (p.TH + 1)) * p.WS + wq;              // + row * WS
+    const int brow_base = ((smp * 4 + (r16 >> 2)) * (p.TH + 4) + (r16 & 3)) * p.XR + wq;  // + 4 xb * XR
+    const int th_lane = nosmp ? 0 : p.TH;                                                // rows >= th_lane are redirected to the zero row
+
+    // 20 accumulator tiles per wave, one register set for both roles.  waves 0..2: [t*5 + kw] = K5 (kd = wave), [10 + t*3 + kw] = K3 (kd = wave), [16] = K1 (wave 0);
+    // wave 3: [kk*10 + t*5 + kw] = K5 (kd = 3 + kk)
+    tz_f4 acc[20];
+#pragma unroll
+    for (int t = 0; t < 20; ++t) acc[t] = (tz_f4){0.f, 0.f, 0.f, 0.f};
+
+    auto slot5 = [&](int pl) { return (pl + 10) % 5; };
+    auto slot3 = [&](int pl) { return 5 + (pl + 9) % 3; };
+    auto owned = [&](int pl) { return pl >= dg0 && pl < dg1; };
+
+    // the march: x planes dg0 - 2 .. dg1 + 1 (every owned g plane arrives exactly when its first partner does: g5[dx + 2], g3[dx + 1], g1[dx]); a step whose
+    // x plane lies outside the volume only stages
+    float4 pf[WG_NPF];
+    WgDesc ds[WG_NPF];
+#pragma unroll
+    for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
+    wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+    for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
+        __syncthreads();                 // the previous step's reads of the x buffer and of the ring slots overwritten below are done
+        if (!(p.dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
+        __syncthreads();
+        if (dx + 1 <= dg1 + 1 && !(p.dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
+        if (p.dbg & 2) continue;
+        if ((unsigned)dx >= (unsigned)p.D) continue;
+        for (int xb = 0; xb < p.nXB; ++xb) {
+            // the lane's 16-element window of x row 4 xb + i, every piece
+            uint32_t w[NS][8];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                // (element offsets are multiples of 8: XR, SP, brow_base -- say so, or the reads become 4-byte ds_read2_b32)
+                const int eo = ((s * (p.SP >> 3) + (brow_base >> 3) + 4 * xb * (p.XR >> 3)) << 3);
+                const uint4* bp = reinterpret_cast<const uint4*>(wg_lds + 2 * (long)eo);
+                const uint4 lo = bp[0], hi = bp[1];
+                w[s][0] = lo.x; w[s][1] = lo.y; w[s][2] = lo.z; w[s][3] = lo.w; w[s][4] = hi.x; w[s][5] = hi.y; w[s][6] = hi.z; w[s][7] = hi.w;
+            }
+            uint4 sh[5][NS];              // kw = 0..4  <->  element offset 2..6
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) sh[k][s] = wg_shift(w[s], k + 2);
+            // Four units per wave and x block, the same code for every wave (role differences are wave-uniform DATA: ring slot, row offset, tap count, shift offset):
+            //   unit u -> accumulators acc[5 u .. 5 u + 4] (K = 3 units use 3);  u = 2 * slot + type
+            //   waves 0..2: slot 0 = K5 at kd = wave, slot 1 = K3 at kd = wave;   wave 3: slot 0 = K5 at kd = 3, slot 1 = K5 at kd = 4;   wave 0 also K1 -> acc[13]
+            uint4 a[NS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = u >> 1, typ = u & 1;
+                const bool k3 = sl == 1 && wave < 3;                         // this unit is a K = 3 unit
+                const int kd = sl == 0 ? (wave < 3 ? wave : 3) : (wave < 3 ? wave : 4);
+                const int pl = k3 ? dx - kd + 1 : dx - kd + 2;               // the g plane this x plane meets at tap kd
+                if (pl < dg0 || pl >= dg1) continue;
+                // type 0: g rows 4 xb + j (K3: 4 xb - 1 + j) -> kh = i - j; type 1: g rows 4 xb - 4 + j (K3: 4 xb - 5 + j) -> kh = i - j + 4
+                const int local = 4 * xb - (typ ? 4 : 0) - (k3 ? 1 : 0);
+                if (local + 3 < 0 || local >= p.TH) continue;                // no row of the block inside the tile
+                const int slot = k3 ? 5 + (pl + 9) % 3 : (pl + 10) % 5;
+                wg_read_a<NS>(a, wg_lds, p, slot, arow_base, local, th_lane);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    if (k >= 3 && k3) continue;
+                    uint4 b[NS];
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; ++s_) {
+                        if (sl == 1 && k < 3) {                              // K3 reads shift k + 1 (wave-uniform select)
+                            const uint4 b0 = sh[k][s_], b1 = sh[k + 1][s_];
+                            b[s_] = k3 ? b1 : b0;
+                        } else b[s_] = sh[k][s_];
+                    }
+                    wg_mfma6<NS>(acc[5 * u + k], a, b);
+                }
+            }
+            if (wave == 0 && dx >= dg0 && dx < dg1) {
+                wg_read_a<NS>(a, wg_lds, p, 8, arow_base, 4 * xb - 2, th_lane);
+                wg_mfma6<NS>(acc[13], a, sh[2]);
+            }
+        }
+    }
+    if (p.dbg & 4) return;
+    // Epilogue.  A tile holds every (g row j, x row i) pair of its two 4-row blocks; tap kh = i - j (+ 4 for the second block type) collects a diagonal, and the two
+    // types of one (conv, kd, kw) meet in kh = 1..3.  The tiles go to LDS with plain 16-byte stores (LDS float atomics retire about one lane per clock: 80 of them
+    // per lane were 13 us of this kernel), then one thread per weight sums its <= 8 entries and issues ONE global atomic.  Two rounds (wave slot 0, then slot 1):
+    // [wave 4][tile 10][column n = (ci, i) 16][row m = (co, j) 16] floats = 40 KB per round, inside the dead staging area.
+    float* tl = reinterpret_cast<float*>(wg_lds);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+            *reinterpret_cast<float4*>(tl + (((wave * 10 + t) * 16 + r16) * 16 + 4 * q)) = make_float4(acc[sl * 10 + t][0], acc[sl * 10 + t][1], acc[sl * 10 + t][2], acc[sl * 10 + t][3]);
+        __syncthreads();
+        // outputs of this round in ADDRESS order (a wave-instruction of atomics then covers whole runs of one (co, ci) row: scattered 4-byte atomics are several
+        // times slower per element): round 0 = K5 taps kd 0..3 (100 contiguous floats per pair), round 1 = K5 kd 4 (25 per pair) and all of K3 (27 per pair)
+        const int n5 = sl == 0 ? 1600 : 400, n3 = sl == 0 ? 0 : 432;
+        for (int it = threadIdx.x; it < n5 + n3; it += blockDim.x) {
+            const bool k3 = it >= n5;
+            const int o = k3 ? it - n5 : it;
+            const int K = k3 ? 3 : 5, per = k3 ? 27 : (sl == 0 ? 100 : 25);
+            const int pair = o / per, r = o - pair * per;
+            const int kdl = r / (K * K), r2 = r - kdl * K * K;
+            const int kh = r2 / K, kw = r2 - kh * K;
+            const int kd = k3 ? kdl : (sl == 0 ? kdl : 4);
+            const int wv = k3 ? kd : (kd < 3 ? kd : 3);
+            const int co = pair >> 2, ci = pair & 3;
+            float v = 0.0f;
+#pragma unroll
+            for (int typ = 0; typ < 2; ++typ) {
+                const float* T = tl + ((wv * 10 + typ * 5 + kw) * 16) * 16;
+                const int d = kh - (typ ? 4 : 0);                    // i - j
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int i = jj + d;
+                    if (i >= 0 && i < 4) v += T[(ci * 4 + i) * 16 + co * 4 + jj];
+                }
+            }
+            float* dst = k3 ? p.dw3 : p.dw5;
+            const int K3 = K * K * K;
+            if (dst) atomicAdd(dst + ((long)(cob + co) * p.CG + ih * 4 + ci) * K3 + (kd * K + kh) * K + kw, v);
+        }
+        if (sl == 1 && p.dw1) {                                     // K = 1: wave 0, tile 13 (= slot-1 tile 3), the diagonal i == j
+            for (int pair = threadIdx.x; pair < 16; pair += blockDim.x) {
+                const int co = pair >> 2, ci = pair & 3;
+                const float* T = tl + ((0 * 10 + 3) * 16) * 16;
+                float v = 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v += T[(ci * 4 + jj) * 16 + co * 4 + jj];
+                atomicAdd(p.dw1 + (long)(cob + co) * p.CG + ih * 4 + ci, v);
+            }
+        }
+    }
+}
+
+static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int W, int NS) {
+    if (B <= 0 || C <= 0 || G <= 0 || C % G || D <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3) || W > 32) return -1;
+    const int CG = C / G;
+    if (CG != 4 && CG != 8 && CG != 16) return -1;
+    p.B = B; p.C = C; p.G = G; p.D = D; p.H = H; p.W = W; p.CG = CG;
+    p.WS = (W + 7) / 8 * 8;
+    p.nb = 32 / p.WS;
+    p.nsg = vx_cdiv(B, p.nb);
+    p.TH = H % 8 == 0 ? 8 : 4;                        // (12-row tiles would need more than WG_NPF staging items per thread)
+    p.nHt = H / p.TH;
+    p.nXB = p.TH / 4 + 1;
+    p.XR = p.WS + 8;
+    p.XP = p.nb * 4 * (p.TH + 4) * p.XR;
+    p.GP = p.nb * 4 * (p.TH + 1) * p.WS;
+    p.SP = p.XP + 9 * p.GP;
+    const int MT = CG / 4;
+    const long base_blocks = (long)p.nsg * G * MT * MT * p.nHt;
+    static int target = 0;
+    if (!target) { const char* e = getenv("VELOXSEG_WG_TZ_BLOCKS"); target = (e && atoi(e) > 0) ? atoi(e) : 256; }
+    // Blocks per launch: 256 = one per CU.  Stand-alone, 512 (two resident blocks per CU, one's staging behind the other's MFMAs) is faster (67 vs 84 us at 32^3), but
+    // this kernel is a SINK that runs beside the backward chains of the other lanes: at 74 KB of LDS and 248 VGPRs per block, two blocks per CU leave those chains
+    // nothing to run on -- the step is 774 patches/s with 512 blocks, 798 with 256, 782 with the VALU weight-gradient kernels (VELOXSEG_WG_TZ_BLOCKS for the A/B)
+    int nchunks = (int)((target + base_blocks - 1) / base_blocks);
+    if (nchunks > D / 2) nchunks = D / 2;
+    if (nchunks < 1) nchunks = 1;
+    p.DC = vx_cdiv(D, nchunks);
+    p.nDc = vx_cdiv(D, p.DC);
+    if ((long)p.nb * 4 * (p.TH + 4) * (p.XR / 4) + 3L * p.nb * 4 * p.TH * (p.WS / 4) > (long)WG_NPF * 256) return -1;      // one step's staging list must fit the per-thread items
+    shm = (size_t)NS * p.SP * 2;
+    if (shm < 4 * 10 * 256 * sizeof(float)) shm = 4 * 10 * 256 * sizeof(float);      // the epilogue's tile area
+    if (shm > 150 * 1024) return -1;
+    return 0;
+}
+
+static long g_wg_min_v = -1;
+extern "C" int vx_jlc_wgrad_tz_set_min_voxels(long v) { g_wg_min_v = v < 0 ? 0 : v; return 0; }
+extern "C" int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W) {
+    VxWgT p = {};
+    size_t shm;
+    if (g_wg_min_v < 0) { const char* e = getenv("VELOXSEG_WG_TZ_MIN_V"); g_wg_min_v = e ? atol(e) : 0; }
+    if ((long)D * H * W < g_wg_min_v) return 0;
+    return wg_plan(p, shm, 1, C, G, D, H, W, g_tz_pieces) == 0 ? 1 : 0;
+}
+
+extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                               void* stream) {
+    VX_REQUIRE(x && g1 && g3 && g5, "vx_jlc_wgrad_tz: null pointer");
+    VxWgT p = {};
+    size_t shm;
+    const int NS = g_tz_pieces;
+    VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    p.x = x; p.g1 = g1; p.g3 = g3; p.g5 = g5; p.dw1 = dw1; p.dw3 = dw3; p.dw5 = dw5; p.dbg = g_tz_dbg >> 4;
+    const int MT = p.CG / 4;
+    const dim3 grid((unsigned)((long)p.nsg * G * MT * MT * p.nHt * p.nDc));
+    hipStream_t st = (hipStream_t)stream;
+#define WG_LAUNCH(ns)                                                                                                                                      \
+    do {                                                                                                                                                   \
+        static bool attr = false;                                                                                                                          \
+        if (!attr) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<ns>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attr = true; } \
+        vx_jlc_wg_k<ns><<<grid, dim3(256), shm, st>>>(p);                                                                                                  \
+    } while (0)
+    if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2); else WG_LAUNCH(1);
+#undef WG_LAUNCH
+    VX_LAUNCH_CHECK("vx_jlc_wgrad_tz");
+    return 0;
+}
