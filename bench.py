@@ -270,6 +270,37 @@ def main():
     loss = float(eng.loss)
     assert loss == loss, "loss is NaN"
 
+    # ---- communication diagnostics (world > 1, outside the timed region): the same step WITHOUT its collectives (every rank skips them alike), and the collectives
+    # of K more steps bracketed by HIP events on the stream they are issued from.  The first multi-GPU run then says by itself whether the all-reduces are hidden:
+    # exposed_ms = step - step_no_comm; per bucket: bytes, enqueue -> complete time, the stream (tape lane / comm stream) it ran on; VELOXSEG_COMM_PLACEMENT repeats
+    # the run with the collectives enqueued at the other two places profiles/r03_comm_standin_probe.txt measured on one GPU
+    comm = None
+    if world > 1:
+        k2 = max(10, min(args.steps, 100))
+        eng.skip_comm = True
+        for _ in range(5):
+            eng.step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            eng.step()
+        barrier()
+        tnc = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tnc, op=dist.ReduceOp.MAX)
+        eng.skip_comm = False
+        eng.comm_profile = []
+        for _ in range(k2):
+            eng.step()
+        barrier()
+        rep = eng.comm_report()
+        eng.comm_profile = None
+        ms_nc = float(tnc) / k2 * 1e3
+        comm = {"backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (debug: host copies, ranks may share a GPU)"), "rccl_ranks": world,
+                "placement": getattr(eng, "comm_placement", None), "overlap": bool(eng.overlap), "payload_bytes_per_step": int(eng.flat.numel) * 4,
+                "buckets": rep, "steps_sampled": k2, "step_ms_no_comm": round(ms_nc, 3), "exposed_ms": round(dt / args.steps * 1e3 - ms_nc, 3),
+                "note": "exposed_ms = timed step - the same step with every collective skipped (both max over ranks); a bucket's ms_mean = HIP events on its issuing "
+                        "stream from 'gradients complete' to 'reduced values visible'.  Budget at 8 GPUs for >= 0.9 weak scaling: exposed_ms <= 0.1 x step (DESIGN.md section 4)"}
+
     # ---- dispersion (outside the timed region): >= 300 more steps, each bracketed by HIP events on the step's stream; p10 / p50 / p90 of the per-step time
     disp = None
     if world == 1 and args.dispersion_steps > 0:
@@ -334,6 +365,8 @@ def main():
                                          "computes in fp32" % _expand_split()) if args.dtype == "f32" and _expand_split() else "fp32",
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None),
                           "lane_on_caller_queue": (H.query("vx_tape_lane_on_caller_queue") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
+    if rank == 0 and comm is not None:
+        out["comm"] = comm
     if rank == 0 and lane_probe is not None:
         out["lane_probe"] = lane_probe
     if rank == 0 and disp is not None:

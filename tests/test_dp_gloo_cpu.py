@@ -100,3 +100,57 @@ def test_flat_buffer_layout_and_buckets():
         p.grad = None
     flat.reattach()
     assert all(p.grad is not None and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.slices[n][0] for n, p in model.named_parameters())
+
+
+def _sched_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recipe import CASES
+    from veloxseg_amd.engine import FlatParams
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    cfg_d, _ = CASES["g2_32_m2"]
+    torch.manual_seed(0)
+    flat = FlatParams(VeloxSeg(**cfg_d))
+    res = {}
+    # the engine's own bucket sequences: default taped step (decoder bucket + one encoder bucket), every per-level marker present, a subset, tiny / huge merge thresholds
+    for name, (min_bytes, markers) in {"default": (1 << 20, ()), "levels": (1 << 20, (3, 2, 1)), "some": (1 << 20, (3,)), "nomerge": (0, (3, 2, 1)), "allmerge": (1 << 30, (3, 2, 1))}.items():
+        g = torch.Generator().manual_seed(100 + rank)
+        flat.grad.copy_(torch.randn(flat.numel, generator=g))
+        sched = flat.taped_schedule(min_bytes, markers)
+        for _, lo, hi in sched:                            # what TrainEngine._replay / _allreduce issue, slice by slice
+            dist.all_reduce(flat.grad[lo:hi], op=dist.ReduceOp.SUM)
+        res[name] = (sched, flat.grad.clone())
+    if rank == 0:
+        torch.save(res, os.path.join(out_dir, "sched.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_engine_bucket_schedule_tiles_the_flat_buffer_and_reduces_it_over_gloo(tmp_path):
+    """FlatParams.plan + FlatParams.taped_schedule (the list TrainEngine._replay issues, collective by collective) on two gloo ranks: for every marker set and
+    merge threshold the slices tile [0, numel) exactly once, start with the decoder bucket, and all-reducing them slice by slice gives the sum over ranks."""
+    world = 2
+    mp.spawn(_sched_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "sched.pt"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipe import CASES
+    from veloxseg_amd.engine import FlatParams
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    cfg_d, _ = CASES["g2_32_m2"]
+    torch.manual_seed(0)
+    flat = FlatParams(VeloxSeg(**cfg_d))
+    want = sum(torch.randn(flat.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    for name, (sched, got) in res.items():
+        assert sched[0] == (4, flat.split, flat.numel), (name, sched[0])
+        pos = 0
+        for _, lo, hi in sorted(sched, key=lambda t: t[1]):
+            assert lo == pos and hi > lo, (name, sched)
+            pos = hi
+        assert pos == flat.numel, (name, sched)
+        assert torch.allclose(got, want, rtol=0, atol=1e-6), name
+    assert len(res["default"][0]) == 2 and len(res["nomerge"][0]) >= len(res["levels"][0]) >= len(res["some"][0]) >= 2

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _setup():
+def _setup(case="g2_32_m2", batch=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import types
@@ -31,9 +31,9 @@ def _setup():
     from veloxseg_amd.engine import TrainEngine
     from veloxseg_amd.model.VeloxSeg import VeloxSeg
     from veloxseg_amd.utils.loss import Loss
-    cfg_d, _ = CASES["g2_32_m2"]                      # all dropout p = 0 -> deterministic
-    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=2)
-    x, lab = make_inputs(cfg_d, 2)
+    cfg_d, _ = CASES[case]                            # all dropout p = 0 -> deterministic
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg_d["in_ch"]))
+    x, lab = make_inputs(cfg_d, batch)
     torch.manual_seed(5)
     model = VeloxSeg(**cfg_d).cuda()
     return cfg_d, crit, x, lab, model, TrainEngine
@@ -130,3 +130,47 @@ def test_bench_two_ranks_end_to_end_over_gloo():
     assert len(lines) == 1, ("exactly one JSON line from rank 0", r.stdout[-1000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    # the self-diagnosing communication block: every field the first RCCL run will be read by
+    c = d["comm"]
+    assert c["rccl_ranks"] == 2 and c["placement"] == "lane" and c["step_ms_no_comm"] > 0 and isinstance(c["exposed_ms"], float)
+    assert sum(b["bytes"] for b in c["buckets"]) == c["payload_bytes_per_step"] and len(c["buckets"]) == 2, c["buckets"]
+    assert all(b["count"] == c["steps_sampled"] and b["ms_mean"] > 0 and b["stream"] for b in c["buckets"])
+    assert c["buckets"][0]["stream"].startswith("tape lane"), c["buckets"]         # the decoder bucket rides the dec_wg lane (engine.comm_placement = "lane")
+
+
+def _worker_big(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg_d, crit, x, lab, model, TrainEngine = _setup("g6_128_brats", 4 * world)
+    eng = TrainEngine(model, crit, (4, sum(cfg_d["in_ch"]), *cfg_d["input_size"]), lr=0.0, weight_decay=0.0, use_graph=True, overlap=True)
+    eng.comm_profile = []
+    eng.step(x[4 * rank:4 * rank + 4].cuda(), lab[4 * rank:4 * rank + 4].cuda())
+    torch.cuda.synchronize()
+    assert eng.use_graph and eng.graphs is not None
+    eng.step()                                   # a replayed step (lr = 0: same parameters)
+    torch.cuda.synchronize()
+    rep = eng.comm_report()
+    assert len(rep) == 2 and sum(b["bytes"] for b in rep) == eng.flat.numel * 4, rep
+    if rank == 0:
+        torch.save({"grad": (eng.flat.grad / world).cpu(), "loss": float(eng.loss)}, os.path.join(out_dir, "dp_big.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_taped_engine_at_the_per_gpu_shape_of_baseline_config_3(tmp_path):
+    """BASELINE configs[3]'s per-GPU shape -- brats128, B = 4 per rank -- on two ranks (gloo: both share the box's one MI355X), taped default (decoder bucket beside the
+    encoder backward, encoder bucket after it): the averaged gradient equals the gradient of ONE process on the global batch of 8."""
+    world = 2
+    mp.spawn(_worker_big, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dp = torch.load(os.path.join(str(tmp_path), "dp_big.pt"))
+    cfg_d, crit, x, lab, model, TrainEngine = _setup("g6_128_brats", 4 * world)
+    eng = TrainEngine(model, crit, (8, sum(cfg_d["in_ch"]), *cfg_d["input_size"]), lr=0.0, weight_decay=0.0, use_graph=False, overlap=False)
+    eng.step(x.cuda(), lab.cuda())
+    torch.cuda.synchronize()
+    g_ref = eng.flat.grad.cpu()
+    rel = float((dp["grad"] - g_ref).norm() / g_ref.norm())
+    assert rel < 2e-5, f"averaged 2-rank gradient differs from the global-batch gradient: rel {rel:.3e}"

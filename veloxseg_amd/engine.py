@@ -106,6 +106,26 @@ class FlatParams:
             out.append((0, lo_pending[0], lo_pending[1]))
         return out
 
+    def taped_schedule(self, min_bytes: int = 1 << 20, markers=()):
+        """The all-reduce slices of ONE taped data-parallel step, in issue order: [(trigger, lo, hi)].  First the decoder bucket [split, numel) (trigger 4: reduced
+        beside the encoder backward), then -- only for the levels whose marker the encoder-backward tape carries (`markers`, opt-in per-level buckets) -- one slice
+        per plan entry, tail first, and last whatever is left of the encoder [0, done) (trigger 0).  The slices tile [0, numel) exactly once for every `markers`
+        subset; TrainEngine._replay issues exactly this list, and a rank that fell back to eager launches must issue the same one (tests/test_dp_gloo_cpu.py)."""
+        out = [(4, self.split, self.numel)]
+        done = self.split
+        for trig, lo, hi in self.plan(min_bytes):            # tail first: (decoders), level 4, level 3, ...
+            if trig == 4:
+                continue
+            hi = min(hi, done)            # a small decoder bucket is merged into the next plan entry: its tail [split, numel) is already reduced
+            if hi <= lo:
+                continue
+            if trig in markers:
+                out.append((trig, lo, hi))
+                done = lo
+        if done > 0:
+            out.append((0, 0, done))
+        return out
+
     def zero_grad(self):
         self.grad.zero_()
 
@@ -319,6 +339,14 @@ class TrainEngine:
         if optimizer is not None:
             self.bind_optimizer(optimizer)
         self.pg = process_group
+        self.skip_comm = False            # diagnostics: issue no collective (all ranks alike) -- the step time without communication
+        self.comm_profile = None          # diagnostics: a list -> every all-reduce appends its HIP events (comm_report())
+        # where the decoder bucket's all-reduce is enqueued in the taped step (profiles/r03_comm_standin_probe.txt measured the three on one GPU with a stand-in
+        # kernel): "lane" (default) = on the dec_wg lane's stream after the encoder-backward tape; "fresh_after" = on the engine's comm stream after the tape;
+        # "fresh_before" = on the comm stream BEFORE the tape (its wait for the dec_wg lane then sits in a hardware queue the tape shares)
+        self.comm_placement = os.environ.get("VELOXSEG_COMM_PLACEMENT", "lane")
+        if self.comm_placement not in ("lane", "fresh_after", "fresh_before"):
+            raise ValueError("VELOXSEG_COMM_PLACEMENT must be lane, fresh_after or fresh_before")
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.overlap = overlap and self.world > 1
         self.use_graph = use_graph
@@ -713,7 +741,44 @@ class TrainEngine:
     def _allreduce(self, lo, hi):
         if getattr(self, "_reduced", None) is not None:
             self._reduced.append((lo, hi))            # (tests: the slices of one step must tile the flat buffer exactly once)
+        if self.skip_comm:                            # A/B leg of the comm diagnostics (bench.py `comm.step_ms_no_comm`): every rank skips the same collectives
+            return
+        prof = self.comm_profile
+        if prof is not None:
+            # HIP events on the stream the collective is issued from: with RCCL the work runs on the process group's own stream, which first waits for this
+            # stream and which this stream waits for afterwards (synchronous op) -- so e0 -> e1 on THIS stream brackets the bucket from "its gradients are
+            # complete" to "reduced values visible", queueing on the hardware queue it landed on included
+            st = torch.cuda.current_stream(self.dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
         dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        if prof is not None:
+            e1.record(st)
+            prof.append({"lo": int(lo), "hi": int(hi), "bytes": int(hi - lo) * 4, "stream": int(st.cuda_stream), "e0": e0, "e1": e1})
+
+    def comm_report(self):
+        """Summary of the collectives recorded since `comm_profile = []` was set: per bucket (lo, hi) the bytes, the mean / max enqueue -> complete time on
+        the issuing stream, which stream that was (the dec_wg lane, the engine's comm stream or the caller's) and how many were recorded.  Synchronises."""
+        prof = self.comm_profile or []
+        torch.cuda.synchronize(self.dev)
+        lanes = {}
+        try:
+            for i, s_ in enumerate(self._lane_streams(4)):
+                lanes[int(s_.cuda_stream)] = f"tape lane {i}"
+        except Exception:
+            pass
+        if self.comm_stream is not None:
+            lanes[int(self.comm_stream.cuda_stream)] = "engine comm stream"
+        by = {}
+        for r in prof:
+            d = by.setdefault((r["lo"], r["hi"]), {"lo": r["lo"], "hi": r["hi"], "bytes": r["bytes"], "ms": [], "stream": lanes.get(r["stream"], "caller stream")})
+            d["ms"].append(r["e0"].elapsed_time(r["e1"]))
+        out = []
+        for d in by.values():
+            ms = d.pop("ms")
+            d.update({"count": len(ms), "ms_mean": round(sum(ms) / len(ms), 4), "ms_max": round(max(ms), 4)})
+            out.append(d)
+        return sorted(out, key=lambda d: -d["lo"])
 
     # ---- torch.optim.AdamW as the state carrier (reference checkpoints, LR schedulers) ---------------
     def bind_optimizer(self, optimizer):
@@ -913,6 +978,11 @@ class TrainEngine:
                     t.replay()
         if comm:
             self._reduced = []
+        early = comm and self.world > 1 and self.overlap and self.comm_placement == "fresh_before" and wg_lane is not None
+        if early:                                               # (diagnostic placement: see comm_placement)
+            self.comm_stream.wait_stream(wg_lane)
+            with torch.cuda.stream(self.comm_stream):
+                self._allreduce(split, n)
         G["enc_bwd"].replay()
         if comm and self.world > 1:
             if self.overlap:
@@ -923,29 +993,24 @@ class TrainEngine:
                 # on a stream of its own, that wait stalled one of the tape's lanes: +1.07 ms per step.  Enqueued AFTER the tape, on the dec_wg lane's own
                 # stream (stream order instead of an event wait): +0.09 ms -- it runs behind the weight gradients while the encoder backward still has
                 # ~1 ms to go.  More hardware queues are no way out (GPU_MAX_HW_QUEUES 5 / 6: the step itself 6.25 -> 6.95 / 8.2 ms).
-                cs = wg_lane if wg_lane is not None else self.comm_stream
+                cs = wg_lane if (wg_lane is not None and self.comm_placement == "lane") else self.comm_stream
                 if wg_lane is None:
                     cs.wait_stream(cur)
-                with torch.cuda.stream(cs):
-                    self._allreduce(split, n)                   # decoder bucket: behind the dec_wg tapes, beside the rest of the encoder backward
+                elif cs is not wg_lane:
+                    cs.wait_stream(wg_lane)
+                if not early:
+                    with torch.cuda.stream(cs):
+                        self._allreduce(split, n)               # decoder bucket: behind the dec_wg tapes, beside the rest of the encoder backward
                 tape = G["enc_bwd"] if self.replay_mode == "tape" else None
-                done = split
-                for trig, lo, hi in self.flat.plan(self.bucket_min_bytes):       # tail first: (decoders), level 4, level 3, ...
-                    if trig == 4:
-                        continue
-                    hi = min(hi, done)        # a small decoder bucket is merged into the next plan entry: its tail [split, n) is already reduced
-                    if hi <= lo:
-                        continue
-                    if tape is not None and H.query("vx_tape_has_marker", tape.handle, int(trig)):
+                markers = [t for t in (3, 2, 1) if tape is not None and H.query("vx_tape_has_marker", tape.handle, int(t))]
+                for trig, lo, hi in self.flat.taped_schedule(self.bucket_min_bytes, markers)[1:]:      # ([0] = the decoder bucket, enqueued above)
+                    if trig != 0:
                         # (opt-in per-level buckets) the tape recorded an event where this level's gradients were complete
                         H.call("vx_tape_wait_marker", tape.handle, int(trig), cs.cuda_stream)
-                        with torch.cuda.stream(cs):
-                            self._allreduce(lo, hi)
-                        done = lo
-                if done > 0:
-                    cs.wait_stream(cur)
+                    else:
+                        cs.wait_stream(cur)                 # the encoder's gradients (one bucket by default): after the tape
                     with torch.cuda.stream(cs):
-                        self._allreduce(0, done)            # the encoder's gradients (one bucket by default)
+                        self._allreduce(lo, hi)
                 cur.wait_stream(cs)
                 self._check_tiling()
             else:
