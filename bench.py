@@ -186,8 +186,8 @@ def _tapes(eng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="autopet128", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: workload default)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = the opt-in mode of BASELINE configs[1]: bf16 MFMA operands (fp32 accumulate, fp32 storage) in the patch-expand layers; a separate line, never the headline")
@@ -314,7 +314,8 @@ def main():
         ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nd))
         chunks = [sum(evs[i].elapsed_time(evs[i + 1]) for i in range(c0, c0 + 50)) / 50 for c0 in range(0, nd - 49, 50)]
         disp = {"steps": nd, "step_ms_p10": round(ts[nd // 10], 3), "step_ms_p50": round(ts[nd // 2], 3), "step_ms_p90": round(ts[(nd * 9) // 10], 3),
-                "step_ms_min": round(ts[0], 3), "step_ms_max": round(ts[-1], 3), "mean_ms_per_50_steps": [round(c, 3) for c in chunks],
+                "step_ms_min": round(ts[0], 3), "step_ms_max": round(ts[-1], 3), "step_ms_mean": round(evs[0].elapsed_time(evs[nd]) / nd, 4),
+                "patches_per_s_over_these_steps": round(B * nd / (evs[0].elapsed_time(evs[nd]) * 1e-3), 2),      # the headline over >= 300 consecutive steps, whatever --steps the caller timed "mean_ms_per_50_steps": [round(c, 3) for c in chunks],
                 "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None)}
 
     lane_probe = None
@@ -387,20 +388,52 @@ def main():
         total = sum(r[0] for r in rows)
         top = rows[0]
         out["kernel_pass"] = {"total_ms": round(total, 3), "top": [{"entry": r[2][0], "key": list(r[2][1]), "launches": r[1], "ms": round(r[0], 4)} for r in rows[:8]]}
-        # dominant kernel = largest total time among the launches whose algorithmic work we can state
-        out["roofline"] = None
+        # `roofline` = the kernel with the most time per step, AGGREGATED BY ENTRY over every shape it is launched with (the top row of the rocprofv3 summary, which is
+        # by kernel name): sum of algorithmic flops / sum of launch time.  avg_launch_ms / achieved / frac are measured live (HIP events on the launch stream, above);
+        # `profile` repeats them from the committed rocprofv3 --kernel-trace --stats summary so that frac can be recomputed from profiles/ alone.
+        alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd"}
+        fam = {}
         for tot_ms, n, (name, key) in rows:
-            rf = roofline_for({"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd",
-                               "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd"}.get(name, name), key, tot_ms / n, model)
-            if rf.get("achieved") is not None:
-                rf["launches_per_step"], rf["share_of_step"] = n, round(tot_ms / total, 4)
-                if rf.get("traffic") is None and name in ("vx_expand_wgrad_mfma", "vx_expand_bwd_data_mfma"):
-                    kern = "vx_expand_wgrad_mfma_k" if name == "vx_expand_wgrad_mfma" else "vx_expand_bwd_data_lds_w_k"
-                    rf["traffic"], src = _pmc_traffic_by_launches(kern, B, n)
-                    if src:
-                        rf["traffic_source"] = src
-                out["roofline"] = rf
-                break
+            base = alias.get(name, name)
+            rf = roofline_for(base, key, tot_ms / n, model)
+            f = fam.setdefault(base, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "known": True, "shapes": [], "last": None})
+            f["ms"] += tot_ms
+            f["n"] += n
+            if rf.get("achieved") is None:
+                f["known"] = False
+            else:
+                f["flops"] += rf["algorithmic_flops"] * n
+                f["bytes"] += rf["algorithmic_bytes"] * n
+                f["shapes"].append({"args": list(key)[:8], "launches": n, "avg_launch_ms": round(tot_ms / n, 5), "frac": rf["frac"]})
+                f["last"] = rf
+        out["kernel_pass"]["families"] = [{"entry": k_, "launches": f["n"], "ms": round(f["ms"], 4)} for k_, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]]
+        out["roofline"] = None
+        for base, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+            if not f["known"] or f["last"] is None:
+                continue
+            rf = dict(f["last"])
+            for drop in ("args", "traffic_source", "pairs", "kernels", "mfma"):
+                rf.pop(drop, None)
+            sec = f["ms"] * 1e-3
+            rf.update({"kernel": base, "device_kernel": DEVICE_KERNEL.get(base, base), "launches_per_step": f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 5),
+                       "algorithmic_flops": f["flops"] / f["n"], "algorithmic_bytes": f["bytes"] / f["n"], "share_of_step": round(f["ms"] / total, 4), "shapes": f["shapes"]})
+            if rf["bound"] == "mfma":
+                ach = f["flops"] / sec / 1e12
+            else:
+                ach = f["bytes"] / sec / 1e9
+            rf["achieved"], rf["frac"] = round(ach, 3), round(ach / rf["peak"], 4)
+            if "frac_of_fp32_mfma_peak" in rf:
+                rf["frac_of_fp32_mfma_peak"] = round(ach / FP32_PEAK_TFLOPS, 4)
+            rf["traffic"], tsrc = _pmc_traffic_family(DEVICE_KERNEL.get(base, base), B)
+            if tsrc:
+                rf["traffic_source"] = tsrc
+            pr = _profile_row(DEVICE_KERNEL.get(base, base), args.workload, B)
+            if pr is not None:
+                pr["achieved"] = round((f["flops"] if rf["bound"] == "mfma" else f["bytes"]) / f["n"] / (pr["avg_launch_ms"] * 1e-3) / (1e12 if rf["bound"] == "mfma" else 1e9), 3)
+                pr["frac"] = round(pr["achieved"] / rf["peak"], 4)
+                rf["profile"] = pr
+            out["roofline"] = rf
+            break
         # PWA attention (north_star: "MFMA utilisation for PWA against gfx950 peak"): every attention launch of the step, forward and backward
         att = []
         for tot_ms, n, (name, key) in rows:
@@ -413,10 +446,11 @@ def main():
         if att:
             out["roofline_pwa"] = att
         # the JLC spatial stage (the reference's Johnson-Lindenstrauss block, conv_blocks.py:51-58) at level 1: its own roofline object with PMC traffic
-        jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == "vx_jlc_conv_fwd"]
+        jname = "vx_jlc_tz_fwd" if any(name == "vx_jlc_tz_fwd" for _, _, (name, _k) in rows) else "vx_jlc_conv_fwd"
+        jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == jname]
         if jl:
             ms1, n1, key1 = max(jl, key=lambda t: t[2][3] * t[2][4] * t[2][5])
-            rj = roofline_for("vx_jlc_conv_fwd", key1, ms1, model)
+            rj = roofline_for(jname, key1, ms1, model)
             rj["launches_per_step"] = n1
             out["roofline_jlc"] = rj
     if rank == 0:
@@ -449,7 +483,13 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json")
+def _newest_pmc():
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return fs[-1] if fs else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+PMC_FILE = _newest_pmc()
 PMC_NAME = "profiles/" + os.path.basename(PMC_FILE)
 
 
@@ -525,6 +565,68 @@ def _pmc_traffic(kernels, B):
 
 
 _pmc_traffic.workload = None
+
+
+# C-ABI entry -> regular expression of the device kernel(s) behind it in a rocprofv3 kernel summary
+DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_tz_fwd": r"vx_tz_k<.*, false>", "vx_jlc_tz_bwd": r"vx_tz_k<.*, true>", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
+                 "vx_jlc_conv_bwd": r"vx_jlc_conv_bwd_k<", "vx_pwa_attn_bwd": r"vx_pwa_attn_bwd_(both|q|kv)_k<|vx_pwa_attn_bwd1_k", "vx_pwa_attn_fwd": r"vx_pwa_attn_(mfma_)?fwd_k<",
+                 "vx_expand_fwd_mfma_split": r"vx_expand_fwd_split_k<", "vx_expand_bwd_data_mfma_split": r"vx_expand_bwd_data_split_k<", "vx_expand_wgrad_mfma_split": r"vx_expand_wgrad_split_k<",
+                 "vx_mlp_fwd": r"vx_mlp_fwd_k<", "vx_mlp_bwd": r"vx_mlp_bwd_k<", "vx_seg_loss_ds_fwd": r"vx_seg_loss_ds_fwd_k<", "vx_seg_loss_ds_bwd": r"vx_seg_loss_ds_bwd_k<",
+                 "vx_conv_mfma_fwd": r"vx_conv_mfma_fwd_k<", "vx_conv_mfma_bwd_data": r"vx_conv_mfma_bwd_data_k<"}
+
+
+def _latest_profile(pattern):
+    import glob
+    import re as _re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        m = _re.match(r"r(\d+)", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), f) > best):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def _profile_row(kernel_re, workload, B):
+    """average launch duration of the device kernel(s) matching `kernel_re` in the newest committed rocprofv3 --kernel-trace --stats summary of this bench
+    (profiles/rNN_kernel_stats*.csv; taken on the headline workload: autopet128, B = 4) -- lets `roofline.frac` be recomputed from profiles/ alone"""
+    import csv
+    import re as _re
+    try:
+        if workload != "autopet128" or B != 4:
+            return None
+        f = _latest_profile("r*_kernel_stats*.csv")
+        if f is None:
+            return None
+        calls = ns = 0
+        names = []
+        for row in csv.DictReader(open(f)):
+            if _re.search(kernel_re, row["Name"]):
+                calls += int(row["Calls"])
+                ns += float(row["TotalDurationNs"])
+                names.append(_re.sub(r"\(.*", "", row["Name"]).replace("void ", ""))
+        if not calls:
+            return None
+        return {"source": "profiles/" + os.path.basename(f), "kernels": names[:4], "calls": calls, "avg_launch_ms": round(ns / calls * 1e-6, 5),
+                "note": "kernels of concurrent lanes share the GPU in the profiled run, so this average sits above the stand-alone HIP-event time measured live"}
+    except Exception:
+        return None
+
+
+def _pmc_traffic_family(kernel_re, B):
+    """HBM bytes per launch (mean over every shape) of the device kernel(s) matching `kernel_re`, from the committed PMC passes"""
+    import re as _re
+    try:
+        if B != 4 or _pmc_traffic.workload != "autopet128":
+            return None, None
+        d = json.load(open(PMC_FILE))["kernels"]
+        tot = n = 0
+        for k_, v in d.items():
+            if _re.search(kernel_re, k_ + "("):
+                tot += float(v["hbm_bytes_per_launch_corrected"]) * v["launches_in_trace"]
+                n += v["launches_in_trace"]
+        return (tot / n, PMC_NAME + " (mean over all launches of the kernel)") if n else (None, None)
+    except Exception:
+        return None, None
 
 
 def _expand_split():
@@ -628,6 +730,23 @@ def roofline_for(name, key, ms_per_launch, model=None):
             r["traffic"], src = _pmc_traffic_by_grid("vx_jlc_conv_fwd_k<4>" if name == "vx_jlc_conv_fwd" else "vx_jlc_conv_bwd_k<4>", B, "max" if D * H * W >= 16384 else "min")
             if src:
                 r["traffic_source"] = src
+        elif name in ("vx_jlc_tz_fwd", "vx_jlc_tz_bwd", "vx_jlc_wgrad_tz"):
+            # the same three grouped convolutions (forward / input gradient / the three weight gradients in one launch) as Toeplitz GEMMs on the bf16 matrix pipe
+            # with fp32-exact products (csrc/jlc_mfma.hip): algorithmic flops = the layer's fp32 flops, ceiling = dense bf16 peak / 6 piece products
+            B, C, G, D, H, W = k[:6]
+            v = B * D * H * W
+            flops = 2.0 * v * C * (C // G) * (1 + 27 + 125)
+            # forward: x read, y1 / y3 / y5 written; input gradient: g1 / g3 / g5 and d_o read, dx written; weight gradients: x and g1 / g3 / g5 read
+            bytes_ = 4.0 * (v * C * (5 if name == "vx_jlc_tz_bwd" else 4) + C * (C // G) * 153)
+            ns = 3
+            try:
+                from veloxseg_amd import _hip as _H
+                ns = int(_H.query("vx_jlc_tz_pieces"))
+            except Exception:
+                pass
+            npair = {3: 6, 2: 3, 1: 1}[ns]
+            r["split"] = {"pieces": ns, "bf16_mfma_per_pair": npair, "peak_tflops": round(BF16_PEAK_TFLOPS / npair, 1),
+                          "mfma_fill": "62.5 % of the multipliers of a k = 5 issue carry a product (37.5 % at k = 3): Toeplitz band 5 of 8"}
         elif name in ("vx_mlp_fwd", "vx_mlp_bwd"):
             ints = [int(a) for a in k]
             B, C, R, V = ints[2:6] if name == "vx_mlp_fwd" else ints[1:5]      # (norm, nparts, B, C, R, V, ...) / (norm, B, C, R, V, ...)

@@ -183,7 +183,7 @@ int vx_jlc_tz_ok(int C, int G, int D, int H, int W);
 int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W);
 int vx_jlc_tz_img_floats(int C, int G);
 int vx_jlc_tz_set_pieces(int ns);
-int vx_jlc_tz_set_min_voxels(long v);   /* vx_jlc_tz_ok answers 0 below this many voxels per channel (default 4096: the 16^3 and 32^3 levels) */
+int vx_jlc_tz_set_min_voxels(long v);   /* vx_jlc_tz_ok answers 0 below this many voxels per channel (default 1024: the 12^3 levels and up) */
 int vx_jlc_tz_pieces(void);
 int vx_jlc_tz_set_debug(int mask);      /* timing experiments only: bit 0 = skip the halo staging, bit 1 = skip the MFMA loops (results are then garbage) */
 int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream);

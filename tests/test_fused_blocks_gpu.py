@@ -257,7 +257,7 @@ def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
             assert e_new <= 2e-2, e_new
     finally:
         H.call("vx_jlc_tz_set_pieces", 3)
-        H.call("vx_jlc_tz_set_min_voxels", 4096)
+        H.call("vx_jlc_tz_set_min_voxels", 1024)
 
 
 @pytest.mark.parametrize("pieces", [3, 1])

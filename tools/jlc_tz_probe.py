@@ -37,6 +37,7 @@ def main():
     args = ap.parse_args()
     H.LIB.load()
     H.call("vx_jlc_tz_set_pieces", args.pieces)
+    H.call("vx_jlc_tz_set_min_voxels", 0)          # (the probe measures every level; the library selects the matrix-pipe convolutions from 16^3 up)
     B = args.batch
     g1 = args.size // 4
     levels = {1: (16, 4, g1), 2: (32, 4, g1 // 2), 3: (64, 8, g1 // 4), 4: (128, 8, g1 // 8)}

@@ -463,9 +463,12 @@ static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W
     const int CG = C / G;
     if (CG != 4 && CG != 8 && CG != 16) return -1;
     p.B = B; p.C = C; p.G = G; p.D = D; p.H = H; p.W = W;
+    static int td_env = -1, th_env = -1;
+    if (td_env < 0) { const char* e = getenv("VELOXSEG_TZ_TD"); td_env = e ? atoi(e) : 0; const char* e2 = getenv("VELOXSEG_TZ_TH"); th_env = e2 ? atoi(e2) : 0; }
+    const int tdm = td_env > 0 ? td_env : 8, thm = th_env > 0 ? th_env : 8;
     p.TWB = W / 4 < 8 ? W / 4 : 8;
-    p.TH = H < 8 ? H : 8;
-    p.TD = D < 8 ? D : 8;
+    p.TH = H < thm ? H : thm;
+    p.TD = D < tdm ? D : tdm;
     auto lds_bytes = [&](int td, int th, int twb) {
         VxTz q = p; TzGeo ge;
         q.TD = td; q.TH = th; q.TWB = twb; q.RW = 4 * twb + 4;
@@ -509,9 +512,9 @@ static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W
 }
 
 // Smallest volume (voxels per channel) the matrix-pipe kernels are SELECTED for (vx_jlc_tz_ok; the entry points themselves take any supported shape).  Measured
-// stand-alone at B = 4 (tools/jlc_tz_probe.py): 32^3 58 -> 32 us, 16^3 57 -> 42 us, 8^3 31 -> 34 us, 4^3 41 -> 52 us: below 16^3 a launch has 32 blocks and the chain
+// stand-alone at B = 4 (tools/jlc_tz_probe.py): 32^3 58 -> 32 us, 16^3 57 -> 42 us, 12^3 55 -> 42 us, 8^3 31 -> 34 us, 4^3 41 -> 52 us: at 8^3 and below a launch has 32 blocks and the chain
 // stage -> 35 dependent entries -> epilogue is latency-bound either way.
-static long g_tz_min_v = 4096;
+static long g_tz_min_v = 1024;
 extern "C" int vx_jlc_tz_set_min_voxels(long v) { g_tz_min_v = v < 0 ? 0 : v; return 0; }
 extern "C" int vx_jlc_tz_ok(int C, int G, int D, int H, int W) {
     VxTz p = {};
@@ -917,7 +920,9 @@ static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int
     p.WS = (W + 7) / 8 * 8;
     p.nb = 32 / p.WS;
     p.nsg = vx_cdiv(B, p.nb);
-    p.TH = H % 8 == 0 ? 8 : 4;                        // (12-row tiles would need more than WG_NPF staging items per thread)
+    static int th_env = -1;
+    if (th_env < 0) { const char* e = getenv("VELOXSEG_WG_TZ_TH"); th_env = e ? atoi(e) : 0; }
+    p.TH = (H % 8 == 0 && th_env != 4) ? 8 : 4;       // (12-row tiles would need more than WG_NPF staging items per thread)
     p.nHt = H / p.TH;
     p.nXB = p.TH / 4 + 1;
     p.XR = p.WS + 8;
