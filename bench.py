@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--hipgraph", action="store_true", help="replay the captured stages with hipGraphLaunch instead of the launch tape (slower on ROCm 7.2: DESIGN.md section 3)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches on forked HIP streams")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--pipeline-tail", action="store_true", help="A/B: TrainEngine(pipeline_tail=True) -- the decoders' weight-gradient lane is joined before the NEXT decoder forward instead of at the end of the step (measured: 793 vs 802 patches/s, the GPU is throughput-bound in aggregate; off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, production) or gloo (debug: lets several ranks share one GPU)")
@@ -236,7 +237,8 @@ def main():
     model = VeloxSeg(**cfg).to(dev)
     VF.manual_seed(12345 + rank, dev)
     crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, dev, num_modal=len(cfg["in_ch"]))
-    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.eager, replay="graph" if args.hipgraph else "tape", overlap=not args.no_overlap, precision="bf16" if args.dtype == "bf16" else "fp32")
+    eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), use_graph=not args.eager, replay="graph" if args.hipgraph else "tape", overlap=not args.no_overlap, precision="bf16" if args.dtype == "bf16" else "fp32",
+                      pipeline_tail=args.pipeline_tail)
     x, lab = synth(cfg, B, dev, 12345 + rank)
     eng.step(x, lab)                                           # capture (+ first step)
     # untimed pre-warm (besides the W warm-up steps): the first process on a cold box was seen 10 % below every later one (clocks, page tables,
@@ -356,7 +358,7 @@ def main():
                else f"training patches/s ({args.workload})",
                "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers (fp32 accumulate, fp32 storage, fp32 everywhere else)",
+               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions (fp32 accumulate, fp32 storage, fp32 everywhere else)",
                "data": "synthetic (randn volumes, rand>0.97 labels, random-init weights, seed 12345)",
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",

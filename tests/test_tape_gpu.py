@@ -276,3 +276,42 @@ def test_a_poll_that_gives_up_is_reported_not_trapped():
     finally:
         H.call("vx_tape_set_flag_timeout_ms", 5000)
         H.query("vx_tape_flag_timeouts")
+
+
+def test_pipelined_decoder_tail_trains_like_the_joined_step():
+    """TrainEngine(pipeline_tail=True): the decoders' weight gradients and the decoder half of AdamW of step N run beside the encoder forward of step N + 1 (joined before
+    the next decoder forward; the branches work on private copies of the boundary tensors).  Same arithmetic as the joined step: losses of 5 consecutive steps and the
+    parameters after them agree to float-atomics noise; flush() orders the caller's stream behind the tail."""
+    import types
+    from bench import LOSS_CFG, WORKLOADS, synth
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    import veloxseg_amd.functional as VF
+    cfg, _ = WORKLOADS["autopet96"]
+    cfg = dict(cfg, proj_drop=0.0, conv_drop=0.0, attn_drop=0.0)
+    B = 2
+    res = {}
+    for pipe in (False, True):
+        VF.reset_dropout_sites()
+        torch.manual_seed(3)
+        model = VeloxSeg(**cfg).cuda()
+        crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
+        eng = TrainEngine(model, crit, (B, sum(cfg["in_ch"]), *cfg["input_size"]), lr=1e-3, use_graph=True, overlap=False, pipeline_tail=pipe)
+        losses = []
+        for i in range(5):
+            x, lab = synth(cfg, B, "cuda", 100 + i)
+            losses.append(eng.step(x, lab).clone())
+        assert eng.use_graph and eng.graphs is not None
+        assert eng._tail_pending == pipe
+        eng.flush()
+        p_now = eng.flat.param.clone()             # on the caller's stream, behind flush(): the decoder half is up to date
+        torch.cuda.synchronize()
+        assert torch.equal(p_now, eng.flat.param)
+        res[pipe] = ([float(l) for l in losses], p_now.cpu())
+    for a, b in zip(res[False][0], res[True][0]):
+        assert abs(a - b) <= 2e-4 * abs(a), res
+    # (element-wise equality is not the bar: Adam's first steps are sign-like, so parameters whose gradient is round-off noise -- biases in front of an InstanceNorm --
+    # walk by +-lr per step in either run; the two runs must agree in norm)
+    rel = float((res[False][1] - res[True][1]).norm() / res[False][1].norm())
+    assert rel < 2e-3, rel

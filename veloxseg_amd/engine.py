@@ -306,13 +306,20 @@ class TrainEngine:
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
-                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False):
+                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False, pipeline_tail=False):
         self.model, self.criterion = model, criterion
         # taped data-parallel steps: True = one all-reduce bucket per encoder level, released by markers inside the encoder-backward tape; False
         # (default) = the decoder bucket during the encoder backward, the encoder's gradients in one bucket after it.  A marker joins every forked
         # stream of the stage: measured on one GPU the markers cost 0.85 ms per step (7.50 vs 6.65 ms), more than the ~0.2 ms of all-reduce
         # (5.5 MB over xGMI) they can hide
         self.level_buckets = bool(level_buckets) or os.environ.get("VELOXSEG_LEVEL_BUCKETS") == "1"
+        # Taped steps only: the decoders' weight gradients (a ~1 ms sink on the fourth lane), their all-reduce and the decoder half of AdamW are NOT joined at the end
+        # of the step: the next step's encoder forward -- which reads encoder parameters only, and leaves a lane idle -- starts as soon as the encoder half of AdamW is
+        # done, and the join moves to just before the next decoder forward.  Same arithmetic, same collectives in the same order; what changes for the caller:
+        # after step() returns, work on the CURRENT stream is ordered behind the encoder update only -- read decoder parameters / gradients after flush() (or a
+        # device synchronise).  Opt-in (bench.py and the step loop of utils/train_loop.py turn it on).
+        self.pipeline_tail = bool(pipeline_tail) or os.environ.get("VELOXSEG_PIPELINE_TAIL") == "1"
+        self._tail_pending = False
         self._two_buckets = bool(use_graph) and replay == "tape" and not self.level_buckets
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -492,8 +499,14 @@ class TrainEngine:
     #   enc_fwd -> { dec_fwd[k] } -> loss (+ its backward) -> { dec_bwd[k] } -> enc_bwd          k = 0..M (Seg decoder, M RC decoders)
     # The braces run concurrently on one HIP stream per branch.  Eagerly the same functions run back to back (stage order is
     # a valid serialisation), which is the reference the captured graphs are checked against.
+    def _pipe_active(self):
+        return bool(self.pipeline_tail and self.use_graph and self.replay_mode == "tape" and not self.level_buckets and self._split_dec_wgrad())
+
     def _s_enc_fwd(self):
-        self.flat.zero_grad()
+        if self._pipe_active():
+            self.flat.grad[:self.flat.split].zero_()       # (pipelined tail: the decoder half may still be in use by the previous step's dec_wg / AdamW: zeroed in _s_loss)
+        else:
+            self.flat.zero_grad()
         VF.advance_rng(self.dev)
         self._drop_level_hooks()
         if self._mark_levels():
@@ -556,8 +569,15 @@ class TrainEngine:
 
     def _s_dec_fwd(self, k):
         # every branch gets its own leaves (same storage, separate .grad), so concurrent branches never accumulate into one tensor
-        leaves = [t.detach().requires_grad_(True) for t in self._boundary]
         M = self.model.num_modalities
+        if self._pipe_active():
+            # pipelined tail: this decoder's weight-gradient tape (dec_wg[k]) still runs while the NEXT step's encoder forward rewrites the boundary tensors, and some of
+            # its kernels read them (enc2rc / up-conv / head weight gradients): the branch works on private copies of the boundary tensors it reads (~16-32 MB, copied
+            # on this branch's lane at the start of its forward)
+            used = set(range(4)) if k == 0 else set(range(4)) | {4 + L * M + (k - 1) for L in range(4)}
+            leaves = [(t.detach().clone() if j in used else t.detach()).requires_grad_(True) for j, t in enumerate(self._boundary)]
+        else:
+            leaves = [t.detach().requires_grad_(True) for t in self._boundary]
         encs, flat_attn = leaves[:4], leaves[4:]
         attn = [flat_attn[L * M:(L + 1) * M] for L in range(4)]
         self._leaves[k] = leaves
@@ -603,6 +623,8 @@ class TrainEngine:
             m.wgrad_join(torch.cuda.current_stream(self.dev).cuda_stream, self.dev.index or 0, True)
 
     def _s_loss(self):
+        if self._pipe_active():
+            self.flat.grad[self.flat.split:].zero_()       # the decoder half of the flat gradient (see _s_enc_fwd); the decoder forward fan before this stage joined the previous tail
         bl = self._branch_loss()
         if bl is not None:
             n_rc = sum(int(r.numel()) for r in self._rc_c[1:])
@@ -816,15 +838,38 @@ class TrainEngine:
             o, k = self.flat.slices[n]
             opt.state[p] = {"step": self._step_tensor, "exp_avg": self.m[o:o + k].view(p.shape), "exp_avg_sq": self.v[o:o + k].view(p.shape)}
 
-    def _adamw(self):
+    def _adamw_begin(self):
+        """once per step: hyper-parameters from the bound optimizer, step count"""
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
             self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], g["betas"], g["eps"]
             self._step_tensor += 1
             self.optimizer._opt_called = True        # the fused kernel below IS optimizer.step(); keeps LR schedulers from warning
         self.t += 1
-        H.call("vx_adamw_step", H.P(self.flat.param), H.P(self.flat.grad), H.P(self.m), H.P(self.v), self.flat.numel, float(self.lr),
+
+    def _adamw_range(self, lo, hi):
+        """the fused update of flat[lo:hi] on the current stream (element-wise: any slice of the flat buffers)"""
+        if hi <= lo:
+            return
+        H.call("vx_adamw_step", H.P(self.flat.param[lo:hi]), H.P(self.flat.grad[lo:hi]), H.P(self.m[lo:hi]), H.P(self.v[lo:hi]), int(hi - lo), float(self.lr),
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.t, 1.0 / self.world, H.stream_ptr())
+
+    def _adamw(self):
+        self._adamw_begin()
+        self._adamw_range(0, self.flat.numel)
+
+    def _check_flag_timeouts(self):
+        if self.replay_mode == "tape":
+            nto = H.query("vx_tape_flag_timeouts")         # a poll of an EARLIER replay that gave up (pinned host word): never apply an update on top of it
+            if nto:
+                raise RuntimeError(f"TrainEngine.step: {nto} cross-lane poll(s) gave up after the flag timeout; the gradients of that step are not trustworthy "
+                                   "and no optimizer update was applied for this one (VELOXSEG_TAPE_FLAG_TIMEOUT_MS / vx_tape_set_flag_timeout_ms)")
+
+    def flush(self):
+        """pipelined tail: order the CURRENT stream behind the decoder weight gradients / all-reduce / AdamW half still running on the fourth lane (call before reading
+        decoder parameters or gradients on this stream: checkpoints, validation forward, EMA copies)"""
+        if self._tail_pending and self.graphs is not None and "dec_wg" in self.graphs:
+            self._hop(43, self._lane_streams(4)[3], torch.cuda.current_stream(self.dev))
 
     # ---- capture --------------------------------------------------------------------------------
     def _forked(self, fn, *args):
@@ -958,12 +1003,17 @@ class TrainEngine:
         for k, s_ in enumerate(streams[:len(graphs)]):
             self._hop(slot0 + 8 + k, s_, cur)
 
-    def _replay(self, comm: bool):
+    def _replay(self, comm: bool, adamw: bool = False):
         """enc_fwd, {dec_fwd}, loss, {dec_bwd}, {dec_wg on the fourth lane || enc_bwd}, then -- enqueued AFTER the encoder-backward tape -- the decoder bucket's
         all-reduce on the dec_wg lane's stream (it runs behind the weight gradients, beside the rest of the encoder backward) and the encoder bucket's"""
         G = self.graphs
         cur = torch.cuda.current_stream(self.dev)
         G["enc_fwd"].replay()
+        pipe = adamw and self._pipe_active() and "dec_wg" in G
+        if self._tail_pending:
+            # the previous step's tail (dec_wg tapes, decoder all-reduce, decoder AdamW on the fourth lane) must be done before the decoders run again
+            self._hop(42, self._lane_streams(4)[3], cur)
+            self._tail_pending = False
         self._fan(G["dec_fwd"], 0)
         G["loss"].replay()
         self._fan(G["dec_bwd"], 16)
@@ -1008,17 +1058,37 @@ class TrainEngine:
                         # (opt-in per-level buckets) the tape recorded an event where this level's gradients were complete
                         H.call("vx_tape_wait_marker", tape.handle, int(trig), cs.cuda_stream)
                     else:
+                        if pipe:
+                            cs = self.comm_stream           # (pipelined tail: the encoder bucket must not sit behind the fourth lane's weight gradients)
                         cs.wait_stream(cur)                 # the encoder's gradients (one bucket by default): after the tape
                     with torch.cuda.stream(cs):
                         self._allreduce(lo, hi)
-                cur.wait_stream(cs)
+                if pipe:
+                    cur.wait_stream(self.comm_stream)
+                else:
+                    cur.wait_stream(cs)
                 self._check_tiling()
             else:
                 if wg_lane is not None:
                     cur.wait_stream(wg_lane)
                 self._allreduce(0, n)
+        if pipe and not (comm and self.world > 1 and not self.overlap):
+            # pipelined tail: decoder AdamW on the fourth lane behind dec_wg (and the decoder bucket's all-reduce), encoder AdamW on the caller's stream; the lane is
+            # joined before the NEXT decoder forward (hop 42 above) or by flush()
+            self._check_flag_timeouts()
+            self._adamw_begin()
+            if comm and self.world > 1 and self.overlap and self.comm_placement != "lane":
+                wg_lane.wait_stream(self.comm_stream)          # (diagnostic placements: the decoder bucket was reduced on the comm stream)
+            with torch.cuda.stream(wg_lane):
+                self._adamw_range(split, n)
+            self._adamw_range(0, split)
+            self._tail_pending = True
+            return
         if wg_lane is not None:
             self._hop(41, wg_lane, cur)
+        if adamw:
+            self._check_flag_timeouts()
+            self._adamw()
 
     # ---- public ---------------------------------------------------------------------------------
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1038,13 +1108,7 @@ class TrainEngine:
                 self.graphs, self.use_graph = None, False
                 torch.cuda.synchronize()
         if self.use_graph:
-            self._replay(comm=True)                            # (everything the tapes need is baked in: no process-wide state is read)
-            if self.replay_mode == "tape":
-                nto = H.query("vx_tape_flag_timeouts")         # a poll of an EARLIER replay that gave up (pinned host word): never apply an update on top of it
-                if nto:
-                    raise RuntimeError(f"TrainEngine.step: {nto} cross-lane poll(s) gave up after the flag timeout; the gradients of that step are not trustworthy "
-                                       "and no optimizer update was applied for this one (VELOXSEG_TAPE_FLAG_TIMEOUT_MS / vx_tape_set_flag_timeout_ms)")
-            self._adamw()
+            self._replay(comm=True, adamw=True)                # (everything the tapes need is baked in: no process-wide state is read); the optimizer update included
             return self.loss
         with self._settings():
             cur = torch.cuda.current_stream(self.dev)

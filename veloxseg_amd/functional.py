@@ -238,8 +238,8 @@ _PRECISION = "fp32"
 
 def set_precision(mode: str):
     """"fp32" (default: every product in fp32, the parity mode) or "bf16": the opt-in mode of BASELINE configs[1] -- bf16 MFMA operands with fp32
-    accumulation in the patch-expand layers (forward and input gradient; 49 % of the training FLOPs), fp32 tensors in HBM, fp32 norms / soft-max /
-    loss.  Judged by Dice, not by the fp32 logit tolerance (tests/test_bf16_gpu.py).  Process-wide; TrainEngine(precision=...) sets it."""
+    accumulation in the patch-expand layers (forward, input and weight gradient; 49 % of the training FLOPs) and in the JLC grouped convolutions (forward,
+    input and weight gradient; 29 %), fp32 tensors in HBM, fp32 norms / soft-max / loss.  Judged by Dice, not by the fp32 logit tolerance (tests/test_bf16_gpu.py).  Process-wide; TrainEngine(precision=...) sets it."""
     global _PRECISION
     if mode not in ("fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -249,6 +249,9 @@ def set_precision(mode: str):
             raise RuntimeError("veloxseg_amd: the bf16 mode lives in the C++ operator path (veloxseg_amd._vxops), which is not built / enabled")
         return
     m.set_bf16_expand(mode == "bf16")
+    # the JLC grouped convolutions and their weight gradients on the matrix pipe (csrc/jlc_mfma.hip): 3 bf16 pieces per operand (six piece products = the fp32
+    # product) in the fp32 mode, ONE piece (plain bf16 operands, fp32 accumulation) in the bf16 mode
+    H.call("vx_jlc_tz_set_pieces", 1 if mode == "bf16" else 3)
     _PRECISION = mode
 
 

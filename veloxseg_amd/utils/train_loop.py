@@ -137,7 +137,8 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
     x_shape = (batch, sum(mcfg["in_ch"]), *size)
     # per-head metrics (show_deep_metric) need every head at full resolution in engine.last_outputs: then the up-sampling is not fused into the loss
     engine = TrainEngine(model, criterion, x_shape, label_dtype=torch.int64, optimizer=optimizer, use_graph=getattr(args, "use_graph", False),
-                         fuse_ds=not train_config.get("show_deep_metric", False), precision=getattr(args, "precision", "fp32"))
+                         fuse_ds=not train_config.get("show_deep_metric", False), precision=getattr(args, "precision", "fp32"),
+                         pipeline_tail=getattr(args, "pipeline_tail", False))  # (opt-in: the decoder tail of step N beside the encoder forward of step N + 1; flush() below)
     show_deep_metrics = _metric_fns(args.dataset_name)
     not_pred = 2 + num_modal if args.model_name == "VeloxSeg" else 0
     sched_type = train_config["train_scheduler"]["scheduler_type"]
@@ -161,6 +162,7 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
             nsteps += 1
             if on_step is not None:
                 on_step(epoch, step, l, metrics)
+        engine.flush()            # the decoder half of the last update: before checkpoints / validation read the parameters on this stream
         if epoch < warmup_epoch:
             step_scheduler(scheduler, "warmup_scheduler")
         elif sched_type != "reducelronplateau":
