@@ -130,7 +130,7 @@ def main():
             t_old, t_new = timeit(w_old), timeit(w_new)
             print(f"  wgrad time (3 tensors): valu {t_old:.1f} us ({flops / t_old / 1e6:.1f} TFLOP/s)  tz {t_new:.1f} us ({flops / t_new / 1e6:.1f} TFLOP/s)")
             if args.breakdown:
-                for mask, what in ((1, "no staging"), (2, "no MFMA phase"), (4, "no fold / atomics"), (3, "no staging, no MFMA"), (7, "launch + syncs only")):
+                for mask, what in ((1, "no staging"), (2, "no MFMA phase"), (4, "no fold / atomics"), (3, "no staging, no MFMA"), (7, "launch + syncs only"), (8, "MFMA phase without its MFMAs"), (16, "MFMA phase without its g-operand reads"), (24, "MFMA phase: x windows + shifts + control only")):
                     H.call("vx_jlc_tz_set_debug", mask << 4)
                     print(f"    wgrad {what}: {timeit(w_new):.1f} us")
                 H.call("vx_jlc_tz_set_debug", 0)

@@ -648,10 +648,10 @@ __device__ __forceinline__ void wg_split_store(float4 v, unsigned char* lds, lon
 // one descriptor per (thread, item), decoded ONCE (the divisions cost more than a step's arithmetic when repeated every step): `g` = element offset inside plane 0 of the
 // source tensor (the plane term pl * H * W is added per step), `l` = LDS element offset inside slot 0 (x: the x buffer), flags: bits 0..1 kind (0 x, 1 g5, 2 g3, 3 g1),
 // bit 2 live (the item exists), bit 3 ok (inside the volume; else zeros are stored)
-struct WgDesc { int g, l, f; };
+struct WgDesc { const float* b; int l, f; };      // b: the item's element in plane 0 of ITS tensor (pointer chosen once: a per-step pointer select goes through a scratch table)
 __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int cob, int cib, int h0) {
     WgDesc r;
-    r.g = 0; r.l = 0; r.f = 0;
+    r.b = p.x; r.l = 0; r.f = 0;
     const int nqx = p.XR / 4, rows = p.TH + 4;
     const int nx = p.nb * 4 * rows * nqx;
     const int chan = p.D * p.H * p.W;
@@ -662,7 +662,7 @@ __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int co
         const int b = sg * p.nb + s, ih = h0 - 2 + row, iw = 4 * qd - 4;
         const bool ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         r.f = 4 | (ok ? 8 : 0);
-        r.g = ok ? (b * p.C + cib + ci) * chan + ih * p.W + iw : 0;
+        r.b = p.x + (ok ? (long)(b * p.C + cib + ci) * chan + ih * p.W + iw : 0);
         r.l = ((s * 4 + ci) * rows + row) * p.XR + 4 * qd;
         return r;
     }
@@ -678,41 +678,38 @@ __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int co
     const int b = sg * p.nb + s, ih = h0 + row, iw = 4 * qd;
     const bool ok = b < p.B && ih < p.H && iw < p.W;
     r.f = (kind + 1) | 4 | (ok ? 8 : 0);
-    r.g = ok ? (b * p.C + cob + co) * chan + ih * p.W + iw : 0;
+    r.b = (kind == 0 ? p.g5 : kind == 1 ? p.g3 : p.g1) + (ok ? (long)(b * p.C + cob + co) * chan + ih * p.W + iw : 0);
     r.l = p.XP + ((s * 4 + co) * (p.TH + 1) + row) * p.WS + 4 * qd;
     return r;
 }
-// plane / ring slot of item kind `k` at step dx; false: nothing to stage (plane outside the volume / not owned)
-__device__ __forceinline__ bool wg_plane(const VxWgT& p, int k, int dx, int dg0, int dg1, int& pl, int& slot) {
-    if (k == 0) { pl = dx; slot = 0; return (unsigned)dx < (unsigned)p.D; }
-    pl = dx + 3 - k;                                               // g5: dx + 2, g3: dx + 1, g1: dx
-    slot = k == 1 ? (pl + 10) % 5 : k == 2 ? 5 + (pl + 9) % 3 : 8;
-    return pl >= dg0 && pl < dg1;
-}
+// plane of item kind k at step dx: x: dx; g5: dx + 2; g3: dx + 1; g1: dx  (no table: (0x18 >> 2k) & 3 = 0, 2, 1, 0)
+__device__ __forceinline__ int wg_dk(int k) { return (0x18 >> (2 * k)) & 3; }
 __device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], const VxWgT& p, int dx, int dg0, int dg1) {
-    const int HW = p.H * p.W;
+    const long HW = (long)p.H * p.W;
 #pragma unroll
     for (int u = 0; u < WG_NPF; ++u) {
         const int k = ds[u].f & 3;
-        int pl, slot;
-        const bool on = wg_plane(p, k, dx, dg0, dg1, pl, slot) && (ds[u].f & 8);
-        const float* src = k == 0 ? p.x : k == 1 ? p.g5 : k == 2 ? p.g3 : p.g1;
-        // explicit GLOBAL address space: through the pointer select the compiler falls back to FLAT loads, which count on lgkmcnt as well -- every LDS wait of the
-        // MFMA phase would then also wait for this step's prefetch
+        const int pl = dx + wg_dk(k);
+        const bool on = (ds[u].f & 8) && pl >= (k == 0 ? 0 : dg0) && pl < (k == 0 ? p.D : dg1);
+        // explicit GLOBAL address space (a generic pointer makes FLAT loads, which count on lgkmcnt as well: every LDS wait of the MFMA phase would then also wait for
+        // this step's prefetch)
         typedef const __attribute__((address_space(1))) tz_f4* wg_gptr;
-        const unsigned long long ga = (unsigned long long)src + 4ull * (unsigned long long)(on ? (long)ds[u].g + (long)pl * HW : 0);      // (dead items read a valid address)
-        const tz_f4 t = *(wg_gptr)ga;
-        pf[u] = on ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned long long ga = (unsigned long long)ds[u].b + 4ull * (unsigned long long)(on ? (long)pl * HW : 0);      // (dead items read a valid address)
+        const tz_f4 v = *(wg_gptr)ga;
+        pf[u] = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 template <int NS>
 __device__ __forceinline__ void wg_commit(const float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], unsigned char* lds, const VxWgT& p, int dx, int dg0, int dg1) {
+    // ring slots of the planes that arrive at this step (wave-uniform, once per step)
+    const int l5 = ((dx + 2 + 10) % 5) * p.GP, l3 = (5 + (dx + 1 + 9) % 3) * p.GP, l1 = 8 * p.GP;
 #pragma unroll
     for (int u = 0; u < WG_NPF; ++u) {
         const int k = ds[u].f & 3;
-        int pl, slot;
-        const bool on = wg_plane(p, k, dx, dg0, dg1, pl, slot) && (ds[u].f & 4);
-        if (on) wg_split_store<NS>(pf[u], lds, (long)ds[u].l + (long)slot * p.GP, p.SP);
+        const int pl = dx + wg_dk(k);
+        const bool on = (ds[u].f & 4) && pl >= (k == 0 ? 0 : dg0) && pl < (k == 0 ? p.D : dg1);
+        const int lo = k == 0 ? 0 : k == 1 ? l5 : k == 2 ? l3 : l1;
+        if (on) wg_split_store<NS>(pf[u], lds, (long)ds[u].l + lo, p.SP);
     }
 }
 
@@ -806,6 +803,15 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
         if (dx + 1 <= dg1 + 1 && !(p.dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
         if (p.dbg & 2) continue;
         if ((unsigned)dx >= (unsigned)p.D) continue;
+        // wave-uniform data of the step (hoisted: ring-slot arithmetic per x block was a visible share of the kernel).  A wave has two "slots" of accumulators:
+        //   waves 0..2: slot 0 = K5 at kd = wave, slot 1 = K3 at kd = wave;   wave 3: slot 0 = K5 at kd = 3, slot 1 = K5 at kd = 4;   wave 0 also K1 -> acc[13]
+        // slot-1 tiles hold tap kw = (k + 1) % 5 in acc[.. + k] (K3: kw3 = k), so that BOTH kinds of slot-1 unit read the x operand shifted by k + 1 and no
+        // per-lane select between shifted operands is needed
+        const bool k3w = wave < 3;
+        const int kd0 = k3w ? wave : 3, kd1 = k3w ? wave : 4;
+        const int pl0 = dx - kd0 + 2, pl1 = k3w ? dx - kd1 + 1 : dx - kd1 + 2;
+        const bool ok0 = pl0 >= dg0 && pl0 < dg1, ok1 = pl1 >= dg0 && pl1 < dg1, okc = wave == 0 && dx >= dg0 && dx < dg1;
+        const int so0 = ((pl0 + 10) % 5), so1 = k3w ? 5 + (pl1 + 9) % 3 : (pl1 + 10) % 5;
         for (int xb = 0; xb < p.nXB; ++xb) {
             // the lane's 16-element window of x row 4 xb + i, every piece
             uint32_t w[NS][8];
@@ -822,37 +828,23 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
             for (int k = 0; k < 5; ++k)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) sh[k][s] = wg_shift(w[s], k + 2);
-            // Four units per wave and x block, the same code for every wave (role differences are wave-uniform DATA: ring slot, row offset, tap count, shift offset):
-            //   unit u -> accumulators acc[5 u .. 5 u + 4] (K = 3 units use 3);  u = 2 * slot + type
-            //   waves 0..2: slot 0 = K5 at kd = wave, slot 1 = K3 at kd = wave;   wave 3: slot 0 = K5 at kd = 3, slot 1 = K5 at kd = 4;   wave 0 also K1 -> acc[13]
             uint4 a[NS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int sl = u >> 1, typ = u & 1;
-                const bool k3 = sl == 1 && wave < 3;                         // this unit is a K = 3 unit
-                const int kd = sl == 0 ? (wave < 3 ? wave : 3) : (wave < 3 ? wave : 4);
-                const int pl = k3 ? dx - kd + 1 : dx - kd + 2;               // the g plane this x plane meets at tap kd
-                if (pl < dg0 || pl >= dg1) continue;
+                const bool k3 = sl == 1 && k3w;                              // this unit is a K = 3 unit
+                if (!(sl ? ok1 : ok0)) continue;
                 // type 0: g rows 4 xb + j (K3: 4 xb - 1 + j) -> kh = i - j; type 1: g rows 4 xb - 4 + j (K3: 4 xb - 5 + j) -> kh = i - j + 4
                 const int local = 4 * xb - (typ ? 4 : 0) - (k3 ? 1 : 0);
                 if (local + 3 < 0 || local >= p.TH) continue;                // no row of the block inside the tile
-                const int slot = k3 ? 5 + (pl + 9) % 3 : (pl + 10) % 5;
-                wg_read_a<NS>(a, wg_lds, p, slot, arow_base, local, th_lane);
+                if (!(p.dbg & 16)) wg_read_a<NS>(a, wg_lds, p, sl ? so1 : so0, arow_base, local, th_lane);
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (k >= 3 && k3) continue;
-                    uint4 b[NS];
-#pragma unroll
-                    for (int s_ = 0; s_ < NS; ++s_) {
-                        if (sl == 1 && k < 3) {                              // K3 reads shift k + 1 (wave-uniform select)
-                            const uint4 b0 = sh[k][s_], b1 = sh[k + 1][s_];
-                            b[s_] = k3 ? b1 : b0;
-                        } else b[s_] = sh[k][s_];
-                    }
-                    wg_mfma6<NS>(acc[5 * u + k], a, b);
+                    if (!(p.dbg & 8)) wg_mfma6<NS>(acc[5 * u + k], a, sh[sl ? (k + 1) % 5 : k]);
                 }
             }
-            if (wave == 0 && dx >= dg0 && dx < dg1) {
+            if (okc) {
                 wg_read_a<NS>(a, wg_lds, p, 8, arow_base, 4 * xb - 2, th_lane);
                 wg_mfma6<NS>(acc[13], a, sh[2]);
             }
@@ -884,10 +876,12 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
             const int kd = k3 ? kdl : (sl == 0 ? kdl : 4);
             const int wv = k3 ? kd : (kd < 3 ? kd : 3);
             const int co = pair >> 2, ci = pair & 3;
+            // (slot-1 tiles of the K5 wave hold tap kw in tile (kw + 4) % 5: see the MFMA phase)
+            const int kt = (!k3 && sl == 1) ? (kw + 4) % 5 : kw;
             float v = 0.0f;
 #pragma unroll
             for (int typ = 0; typ < 2; ++typ) {
-                const float* T = tl + ((wv * 10 + typ * 5 + kw) * 16) * 16;
+                const float* T = tl + ((wv * 10 + typ * 5 + kt) * 16) * 16;
                 const int d = kh - (typ ? 4 : 0);                    // i - j
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
