@@ -65,3 +65,39 @@ def test_ops_equal_the_functional_operators():
     heads4 = [torch.randn(2, 2, 16, 16, 16, device=d, generator=g) for _ in range(2)]
     lab = (torch.rand(2, 1, 16, 16, 16, device=d, generator=g) > 0.8).long()
     both(lambda a, c: torch.ops.veloxseg.seg_loss([a, c], lab, None, [0.6, 0.4], 0.0, 0.0, 0), lambda a, c: VF.seg_only_loss([a, c], lab, [0.6, 0.4]), heads4)
+
+
+@pytest.mark.gpu
+def test_cpp_registered_ops_pass_opcheck_and_have_meta_kernels():
+    """The seven C++-registered operators (csrc/_vxops.cpp: TORCH_LIBRARY(veloxseg), keys Autograd / CUDA / Meta / CPU-raises): torch.library.opcheck (schema,
+    autograd registration, FakeTensor agreement with the real kernel), the Meta kernel's shape for every op, and the CUDA key reached directly in inference mode."""
+    import veloxseg_amd.ops as O
+    from torch.library import opcheck
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(1)
+    x = torch.randn(2, 16, 8, 8, 8, device=d, generator=g)
+    cases = {
+        "conv3d": (x, torch.randn(16, 4, 3, 3, 3, device=d, generator=g) * 0.1, torch.randn(16, device=d, generator=g) * 0.1, 1, 1, 4, 1),
+        "conv_transpose_k2s2": (x, torch.randn(16, 8, 2, 2, 2, device=d, generator=g) * 0.1, torch.randn(8, device=d, generator=g) * 0.1),
+        "instance_norm_sum": ([x, x * 0.5 + 1.0], True, None),
+        "layer_norm_cf": (x, torch.randn(16, device=d, generator=g), torch.randn(16, device=d, generator=g)),
+        "space_to_depth2": (x,),
+        "upsample_trilinear": (x, [16, 16, 16]),
+        "gram": (x,),
+    }
+    assert set(cases) == set(O.CPP_OPS)
+    for name, args in cases.items():
+        op = getattr(torch.ops.veloxseg, name).default
+        keys = torch._C._dispatch_dump(f"veloxseg::{name}")
+        for k in ("CUDA", "Meta", "Autograd"):
+            assert k in keys, (name, k, keys)
+        assert "CompositeImplicitAutograd" not in keys, (name, keys)
+        grad_args = tuple(a.clone().requires_grad_(True) if (isinstance(a, torch.Tensor) and a.is_floating_point()) else
+                          ([t.clone().requires_grad_(True) for t in a] if (isinstance(a, list) and a and isinstance(a[0], torch.Tensor)) else a) for a in args)
+        res = opcheck(op, grad_args, test_utils=("test_schema", "test_autograd_registration", "test_faketensor"), raise_exception=True)
+        assert all(v == "SUCCESS" for v in res.values()), (name, res)
+        with torch.inference_mode():
+            y = op(*args)                                        # Autograd keys excluded: the CUDA key kernel
+        meta_args = tuple(a.to("meta") if isinstance(a, torch.Tensor) else ([t.to("meta") for t in a] if (isinstance(a, list) and a and isinstance(a[0], torch.Tensor)) else a) for a in args)
+        ym = op(*meta_args)
+        assert ym.device.type == "meta" and tuple(ym.shape) == tuple(y.shape) and ym.dtype == y.dtype, (name, ym.shape, y.shape)

@@ -11,6 +11,7 @@
 #include <torch/extension.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/custom_class.h>
+#include <torch/library.h>
 #include <c10/hip/HIPStream.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -1184,6 +1185,99 @@ struct FFNFn : public torch::autograd::Function<FFNFn> {
 }  // namespace
 
 // =================================================================================================================== python surface
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Dispatcher registration (north_star: "re-registered as custom ops backed by hand-written HIP kernels").  Schemas are defined HERE (veloxseg_amd/ops.py lists them and adds
+// the operators whose bodies need Python-side state: dropout sites, the PWA plan, the loss).  Keys:
+//   Autograd  -> the operator's torch::autograd::Function (forward + backward launch the kernels of include/veloxseg_hip.h)
+//   CUDA      -> the same forward without a graph (inference mode reaches this key directly)
+//   Meta      -> shapes only (FakeTensor / torch.export / torch.compile tracing)
+//   CPU       -> raises: the hot path has no CPU kernel, and the dispatcher's own "no kernel for backend CPU" message would not say why
+namespace {
+using torch::autograd::AutogradContext;
+[[noreturn]] void op_no_cpu(const char* what) {
+    TORCH_CHECK(false, "veloxseg::", what, ": the VeloxSeg hot path runs only on an MI355X (HIP kernels); there is deliberately no CPU kernel behind this operator");
+}
+int64_t conv_out(int64_t n, int64_t K, int64_t S, int64_t P) { return (n + 2 * P - K) / S + 1; }
+Tensor op_conv3d_meta(const Tensor&, const Tensor&, const OptT&, int64_t, int64_t, int64_t, int64_t);
+Tensor op_upconv_meta(const Tensor&, const Tensor&, const Tensor&);
+Tensor op_in_sum_meta(at::TensorList, bool, const OptT&);
+Tensor op_ln_meta(const Tensor&, const Tensor&, const Tensor&);
+Tensor op_s2d_meta(const Tensor&);
+Tensor op_up_meta(const Tensor&, at::IntArrayRef);
+Tensor op_gram_meta(const Tensor&);
+
+Tensor op_conv3d(const Tensor& x, const Tensor& w, const OptT& b, int64_t stride, int64_t padding, int64_t groups, int64_t ps) {
+    if (x.is_meta()) return op_conv3d_meta(x, w, b, stride, padding, groups, ps);     // (the Autograd key also covers meta and CPU tensors)
+    if (!x.is_cuda()) op_no_cpu("conv3d");           // fail before anything touches HIP
+    return ConvFn::apply(x, OptT(), w, b, w.size(2), stride, padding, groups, ps);
+}
+Tensor op_conv3d_meta(const Tensor& x, const Tensor& w, const OptT&, int64_t S, int64_t P, int64_t, int64_t ps) {
+    const int64_t K = w.size(2), r = ps * ps * ps;
+    TORCH_CHECK(x.dim() == 5 && w.dim() == 5 && w.size(0) % r == 0, "veloxseg::conv3d: bad shapes");
+    return at::empty({x.size(0), w.size(0) / r, conv_out(x.size(2), K, S, P) * ps, conv_out(x.size(3), K, S, P) * ps, conv_out(x.size(4), K, S, P) * ps}, x.options());
+}
+Tensor op_conv3d_cpu(const Tensor&, const Tensor&, const OptT&, int64_t, int64_t, int64_t, int64_t) { op_no_cpu("conv3d"); }
+
+Tensor op_upconv(const Tensor& x, const Tensor& w, const Tensor& b) { if (x.is_meta()) return op_upconv_meta(x, w, b); if (!x.is_cuda()) op_no_cpu("conv_transpose_k2s2"); return UpconvFn::apply(x, w, OptT(b), false); }
+Tensor op_upconv_meta(const Tensor& x, const Tensor& w, const Tensor&) { return at::empty({x.size(0), w.size(1), 2 * x.size(2), 2 * x.size(3), 2 * x.size(4)}, x.options()); }
+Tensor op_upconv_cpu(const Tensor&, const Tensor&, const Tensor&) { op_no_cpu("conv_transpose_k2s2"); }
+
+Tensor op_in_sum(at::TensorList ys, bool act, const OptT& res) {
+    TORCH_CHECK(ys.size() >= 1 && ys.size() <= 3, "veloxseg::instance_norm_sum: 1..3 inputs");
+    if (ys[0].is_meta()) return op_in_sum_meta(ys, act, res);
+    if (!ys[0].is_cuda()) op_no_cpu("instance_norm_sum");
+    return InstNormFn::apply(res, act, ys[0], ys.size() > 1 ? OptT(ys[1]) : OptT(), ys.size() > 2 ? OptT(ys[2]) : OptT());
+}
+Tensor op_in_sum_meta(at::TensorList ys, bool, const OptT&) { return at::empty_like(ys[0]); }
+Tensor op_in_sum_cpu(at::TensorList, bool, const OptT&) { op_no_cpu("instance_norm_sum"); }
+
+Tensor op_ln(const Tensor& x, const Tensor& g, const Tensor& bt) { if (x.is_meta()) return op_ln_meta(x, g, bt); if (!x.is_cuda()) op_no_cpu("layer_norm_cf"); return LayerNormFn::apply(x, g, bt); }
+Tensor op_ln_meta(const Tensor& x, const Tensor&, const Tensor&) { return at::empty_like(x); }
+Tensor op_ln_cpu(const Tensor&, const Tensor&, const Tensor&) { op_no_cpu("layer_norm_cf"); }
+
+Tensor op_s2d(const Tensor& x) { if (x.is_meta()) return op_s2d_meta(x); if (!x.is_cuda()) op_no_cpu("space_to_depth2"); return S2DFn::apply(x); }
+Tensor op_s2d_meta(const Tensor& x) { return at::empty({x.size(0), 8 * x.size(1), x.size(2) / 2, x.size(3) / 2, x.size(4) / 2}, x.options()); }
+Tensor op_s2d_cpu(const Tensor&) { op_no_cpu("space_to_depth2"); }
+
+Tensor op_up(const Tensor& x, at::IntArrayRef size) {
+    TORCH_CHECK(size.size() == 3, "veloxseg::upsample_trilinear: size = (D, H, W)");
+    if (x.is_meta()) return op_up_meta(x, size);
+    if (!x.is_cuda()) op_no_cpu("upsample_trilinear");
+    return UpsampleFn::apply(x, size[0], size[1], size[2]);
+}
+Tensor op_up_meta(const Tensor& x, at::IntArrayRef size) { return at::empty({x.size(0), x.size(1), size[0], size[1], size[2]}, x.options()); }
+Tensor op_up_cpu(const Tensor&, at::IntArrayRef) { op_no_cpu("upsample_trilinear"); }
+
+Tensor op_gram(const Tensor& x) { if (x.is_meta()) return op_gram_meta(x); if (!x.is_cuda()) op_no_cpu("gram"); return GramFn::apply(x); }
+Tensor op_gram_meta(const Tensor& x) { return at::empty({x.size(0), x.size(1), x.size(1)}, x.options()); }
+Tensor op_gram_cpu(const Tensor&) { op_no_cpu("gram"); }
+}  // namespace
+
+TORCH_LIBRARY(veloxseg, m) {
+    m.def("conv3d(Tensor x, Tensor w, Tensor? b, int stride, int padding, int groups, int pixel_shuffle) -> Tensor");
+    m.def("conv_transpose_k2s2(Tensor x, Tensor w, Tensor b) -> Tensor");
+    m.def("instance_norm_sum(Tensor[] ys, bool act, Tensor? res) -> Tensor");
+    m.def("layer_norm_cf(Tensor x, Tensor gamma, Tensor beta) -> Tensor");
+    m.def("space_to_depth2(Tensor x) -> Tensor");
+    m.def("upsample_trilinear(Tensor x, int[] size) -> Tensor");
+    m.def("gram(Tensor x) -> Tensor");
+}
+#define VX_OP_IMPLS(KEY, SUF)                                 \
+    TORCH_LIBRARY_IMPL(veloxseg, KEY, m) {                    \
+        m.impl("conv3d", op_conv3d##SUF);                     \
+        m.impl("conv_transpose_k2s2", op_upconv##SUF);        \
+        m.impl("instance_norm_sum", op_in_sum##SUF);          \
+        m.impl("layer_norm_cf", op_ln##SUF);                  \
+        m.impl("space_to_depth2", op_s2d##SUF);               \
+        m.impl("upsample_trilinear", op_up##SUF);             \
+        m.impl("gram", op_gram##SUF);                         \
+    }
+VX_OP_IMPLS(Autograd, )
+VX_OP_IMPLS(CUDA, )
+VX_OP_IMPLS(Meta, _meta)
+VX_OP_IMPLS(CPU, _cpu)
+#undef VX_OP_IMPLS
+
 PYBIND11_MODULE(_vxops, m) {
     m.doc() = "C++ operator bodies of veloxseg_amd.functional (same C-ABI calls, no interpreter in between)";
     py::class_<ConvState, std::shared_ptr<ConvState>>(m, "ConvState");

@@ -64,13 +64,17 @@ __device__ __forceinline__ void vx_ds_interp(const VxDs& P, int hh, const float*
     float l2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, w, P.W, a2[j], b2[j], l2[j]);
+    // (reached only without staging -- P.stage == 0, grids too large for LDS -- where `lowb` is the head's tensor in global memory: an explicit address space keeps the
+    // 8 taps from becoming FLAT loads)
+    typedef const __attribute__((address_space(1))) float* glb_cf;
+    glb_cf lowg = (glb_cf)(unsigned long long)lowb;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const float* __restrict__ xb = lowb + (long)c * d * h * w;
-        const float* __restrict__ r00 = xb + ((long)a0 * h + a1) * w;
-        const float* __restrict__ r01 = xb + ((long)a0 * h + b1) * w;
-        const float* __restrict__ r10 = xb + ((long)b0 * h + a1) * w;
-        const float* __restrict__ r11 = xb + ((long)b0 * h + b1) * w;
+        glb_cf xb = lowg + (long)c * d * h * w;
+        glb_cf r00 = xb + ((long)a0 * h + a1) * w;
+        glb_cf r01 = xb + ((long)a0 * h + b1) * w;
+        glb_cf r10 = xb + ((long)b0 * h + a1) * w;
+        glb_cf r11 = xb + ((long)b0 * h + b1) * w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float k2 = 1.0f - l2[j];
@@ -135,10 +139,14 @@ __device__ __forceinline__ void vx_ds_interp2(const VxDs& P, int hh, const float
     float l2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, w, P.W, a2[j], b2[j], l2[j]);
+    // `sl` is the staged slice in LDS (this function is only reached with P.stage): say so -- through the generic pointer of `lows[]` (LDS or global, chosen at run
+    // time) these 16 gathers per class were FLAT loads, which are slower than ds_read and count on both wait counters
+    typedef const __attribute__((address_space(3))) float* lds_cf;
+    lds_cf sl3 = (lds_cf)sl;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const float* __restrict__ r0 = sl + ((long)c * h + a1) * w;
-        const float* __restrict__ r1 = sl + ((long)c * h + b1) * w;
+        lds_cf r0 = sl3 + (c * h + a1) * w;
+        lds_cf r1 = sl3 + (c * h + b1) * w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float k2 = 1.0f - l2[j];

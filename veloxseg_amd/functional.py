@@ -447,9 +447,21 @@ class _Conv3dFn(torch.autograd.Function):
         return dx, dx2, None, None, None, None, None, None, None
 
 
+# The model reaches the seven C++-registered operators THROUGH THE DISPATCHER (torch.ops.veloxseg.*: Autograd / CUDA / Meta keys registered by csrc/_vxops.cpp) wherever
+# the call has the schema's form; forms the schemas do not carry (two-pointer concat input, the "feeds an InstanceNorm" hint) call the node directly.  A taped step
+# replays captured launches, so the extra dispatcher hop costs the eager path only.  VELOXSEG_DISPATCH=0: always the direct call (A/B).
+USE_DISPATCH = os.environ.get("VELOXSEG_DISPATCH", "1") != "0"
+
+
+def _ops():
+    return torch.ops.veloxseg if (USE_DISPATCH and _cpp_node("conv") is not None) else None
+
+
 def conv3d(x, w, b=None, *, x2=None, stride=1, padding=0, groups=1, pixel_shuffle=1):
     """Conv3d (+ optional channel-concat input, + optional PixelShuffle store)."""
     m = _cpp_node("conv") if x.is_cuda else None
+    if m is not None and x2 is None and USE_DISPATCH:
+        return torch.ops.veloxseg.conv3d(x, w, b, int(stride), int(padding), int(groups), int(pixel_shuffle))
     if m is not None:
         return m.conv(x, x2, w, b, int(w.shape[2]), int(stride), int(padding), int(groups), int(pixel_shuffle))
     return _Conv3dFn.apply(x, x2, w, b, int(w.shape[2]), int(stride), int(padding), int(groups), int(pixel_shuffle))
@@ -493,6 +505,8 @@ class _ConvTransposeK2S2Fn(torch.autograd.Function):
 def conv_transpose_k2s2(x, w, b, feeds_instnorm: bool = False):
     """feeds_instnorm: the output goes straight into an InstanceNorm (UpConv): the bias gradient is zero by construction and is not computed"""
     m = _cpp_node("small") if x.is_cuda else None
+    if m is not None and not feeds_instnorm and b is not None and USE_DISPATCH:
+        return torch.ops.veloxseg.conv_transpose_k2s2(x, w, b)
     if m is not None:
         return m.upconv_k2s2(x, w, b, bool(feeds_instnorm))
     return _ConvTransposeK2S2Fn.apply(x, w, b)
@@ -574,6 +588,8 @@ class _InstNormSumFn(torch.autograd.Function):
 def instnorm_sum(ys: Sequence[torch.Tensor], act: bool = False, res: Optional[torch.Tensor] = None):
     """(res) + sum_k act(InstanceNorm(y_k))."""
     m = _cpp_node("in") if ys[0].is_cuda else None
+    if m is not None and 1 <= len(ys) <= 3 and USE_DISPATCH:
+        return torch.ops.veloxseg.instance_norm_sum(list(ys), bool(act), res)
     if m is not None and 1 <= len(ys) <= 3:
         return m.instnorm(res, bool(act), ys[0], ys[1] if len(ys) > 1 else None, ys[2] if len(ys) > 2 else None)
     return _InstNormSumFn.apply(res, bool(act), *ys)
@@ -618,6 +634,8 @@ class _LayerNormCFFn(torch.autograd.Function):
 
 def layernorm_cf(x, gamma, beta):
     m = _cpp_node("ln") if x.is_cuda else None
+    if m is not None and USE_DISPATCH:
+        return torch.ops.veloxseg.layer_norm_cf(x, gamma, beta)
     if m is not None:
         return m.layernorm(x, gamma, beta)
     return _LayerNormCFFn.apply(x, gamma, beta)
@@ -1158,7 +1176,7 @@ class _SpaceToDepth2Fn(torch.autograd.Function):
 def space_to_depth2(x):
     m = _cpp_node("small") if x.is_cuda else None
     if m is not None:
-        return m.space_to_depth2(x)
+        return torch.ops.veloxseg.space_to_depth2(x) if USE_DISPATCH else m.space_to_depth2(x)
     return _SpaceToDepth2Fn.apply(x)
 
 
@@ -1276,7 +1294,7 @@ def upsample_trilinear(x, size):
         return x        # F.interpolate to the same size with align_corners=True is the identity (VeloxSeg.py:183)
     m = _cpp_node("small") if x.is_cuda else None
     if m is not None:
-        return m.upsample_trilinear(x, *size)
+        return torch.ops.veloxseg.upsample_trilinear(x, list(size)) if USE_DISPATCH else m.upsample_trilinear(x, *size)
     return _UpsampleFn.apply(x, size)
 
 
@@ -1306,7 +1324,7 @@ class _GramFn(torch.autograd.Function):
 def gram(x):
     m = _cpp_node("small") if x.is_cuda else None
     if m is not None:
-        return m.gram(x)
+        return torch.ops.veloxseg.gram(x) if USE_DISPATCH else m.gram(x)
     return _GramFn.apply(x)
 
 

@@ -1,7 +1,8 @@
 """The hot-path operators as registered PyTorch custom ops: torch.ops.veloxseg.* (north_star: "re-registered as custom ops backed by hand-written
 HIP kernels").  Each op is the operator of veloxseg_amd.functional under a dispatcher schema; the implementation is registered for
-CompositeImplicitAutograd, i.e. autograd records the operator's own node (a C++ or Python autograd function whose forward and backward launch the
-kernels of include/veloxseg_hip.h), and a CPU tensor raises the library's "no CPU path" error -- there is no fallback kernel behind any key.
+the Autograd / CUDA / Meta keys from C++ for the seven pure operators (csrc/_vxops.cpp) and for CompositeImplicitAutograd for the four that need Python-side
+state; autograd records the operator's own node (a C++ or Python autograd function whose forward and backward launch the kernels of include/veloxseg_hip.h), and
+a CPU tensor raises the library's "no CPU path" error -- there is no fallback kernel behind any key.
 
     torch.ops.veloxseg.conv3d(x, w, b, stride, padding, groups, pixel_shuffle)        nn.Conv3d (+ PixelShuffle), conv_blocks.py / Decoder.py
     torch.ops.veloxseg.conv_transpose_k2s2(x, w, b)                                   nn.ConvTranspose3d(k=2, s=2), conv_blocks.py:29-35
@@ -20,11 +21,20 @@ import torch
 from . import _hip as H
 from . import functional as VF
 
-_lib = torch.library.Library("veloxseg", "DEF")
+# The seven operators whose bodies are pure C++ (conv3d, conv_transpose_k2s2, instance_norm_sum, layer_norm_cf, space_to_depth2, upsample_trilinear, gram) are
+# DEFINED AND REGISTERED IN C++ (csrc/_vxops.cpp: TORCH_LIBRARY(veloxseg) with Autograd / CUDA / Meta keys and a CPU key that raises): importing the extension
+# registers them.  The operators below need Python-side state (dropout sites and the RNG state tensor, the PWA plan cache, the staged loss) and stay Python bodies
+# under CompositeImplicitAutograd on the same library.
+CPP_OPS = ("conv3d", "conv_transpose_k2s2", "instance_norm_sum", "layer_norm_cf", "space_to_depth2", "upsample_trilinear", "gram")
+if VF.cpp_module() is None:
+    raise RuntimeError("veloxseg_amd.ops: the C++ operator module (veloxseg_amd._vxops) is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+_lib = torch.library.Library("veloxseg", "FRAGMENT")
 _plans = {}
 
 
 def _define(schema, fn):
+    if schema.split("(")[0] in CPP_OPS:
+        return                              # (kept in the list below as documentation of the schema: C++ owns it)
     _lib.define(schema)
     _lib.impl(schema.split("(")[0], fn, "CompositeImplicitAutograd")
 
