@@ -8,7 +8,7 @@ timeout 300 python bench.py --no-eager-baseline --no-cpu-baseline --workload bra
 timeout 300 python bench.py --no-eager-baseline --no-cpu-baseline --workload brats128 --batch 4 > gpurun_out/fin/bench_brats128_b4_f32.json 2>/dev/null
 timeout 300 python bench.py --no-eager-baseline --no-cpu-baseline --workload autopet96 > gpurun_out/fin/bench_autopet96.json 2>/dev/null
 timeout 300 python bench.py --no-eager-baseline --no-cpu-baseline --workload brats96 > gpurun_out/fin/bench_brats96.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/fin/stats -o st --output-format csv -- python3 bench.py --steps 5 --warmup 3 --no-eager-baseline --no-cpu-baseline > gpurun_out/fin/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/fin/stats -o st --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-eager-baseline --no-cpu-baseline --no-kernel-pass --dispersion-steps 0 > gpurun_out/fin/stats.log 2>&1
 # (flag kernels off: under --pmc kernels run one at a time, a polling kernel would never see its flag set)
 VELOXSEG_TAPE_FLAGS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/fin/fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-eager-baseline --no-cpu-baseline --dispersion-steps 0 > gpurun_out/fin/fetch.log 2>&1
 VELOXSEG_TAPE_FLAGS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/fin/write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-eager-baseline --no-cpu-baseline --dispersion-steps 0 > gpurun_out/fin/write.log 2>&1

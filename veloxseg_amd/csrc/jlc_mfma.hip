@@ -744,8 +744,11 @@ __device__ __forceinline__ uint4 wg_shift(const uint32_t (&w)[8], int o) {
                       __builtin_amdgcn_alignbit(w[d + 4], w[d + 3], 16));
 }
 
-template <int NS>
-__global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
+// DBG = true: the timing-experiment build (vx_jlc_tz_set_debug); the production instance carries none of its branches
+template <int NS, bool DBG>
+__global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
+    const VxWgT& p = p_;
+    const int dbg = DBG ? p_.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -798,10 +801,10 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
     wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
     for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
         __syncthreads();                 // the previous step's reads of the x buffer and of the ring slots overwritten below are done
-        if (!(p.dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
+        if (!(dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
         __syncthreads();
-        if (dx + 1 <= dg1 + 1 && !(p.dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
-        if (p.dbg & 2) continue;
+        if (dx + 1 <= dg1 + 1 && !(dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
+        if (dbg & 2) continue;
         if ((unsigned)dx >= (unsigned)p.D) continue;
         // wave-uniform data of the step (hoisted: ring-slot arithmetic per x block was a visible share of the kernel).  A wave has two "slots" of accumulators:
         //   waves 0..2: slot 0 = K5 at kd = wave, slot 1 = K3 at kd = wave;   wave 3: slot 0 = K5 at kd = 3, slot 1 = K5 at kd = 4;   wave 0 also K1 -> acc[13]
@@ -837,11 +840,11 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
                 // type 0: g rows 4 xb + j (K3: 4 xb - 1 + j) -> kh = i - j; type 1: g rows 4 xb - 4 + j (K3: 4 xb - 5 + j) -> kh = i - j + 4
                 const int local = 4 * xb - (typ ? 4 : 0) - (k3 ? 1 : 0);
                 if (local + 3 < 0 || local >= p.TH) continue;                // no row of the block inside the tile
-                if (!(p.dbg & 16)) wg_read_a<NS>(a, wg_lds, p, sl ? so1 : so0, arow_base, local, th_lane);
+                if (!(dbg & 16)) wg_read_a<NS>(a, wg_lds, p, sl ? so1 : so0, arow_base, local, th_lane);
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (k >= 3 && k3) continue;
-                    if (!(p.dbg & 8)) wg_mfma6<NS>(acc[5 * u + k], a, sh[sl ? (k + 1) % 5 : k]);
+                    if (!(dbg & 8)) wg_mfma6<NS>(acc[5 * u + k], a, sh[sl ? (k + 1) % 5 : k]);
                 }
             }
             if (okc) {
@@ -850,7 +853,7 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p) {
             }
         }
     }
-    if (p.dbg & 4) return;
+    if (dbg & 4) return;
     // Epilogue.  A tile holds every (g row j, x row i) pair of its two 4-row blocks; tap kh = i - j (+ 4 for the second block type) collects a diagonal, and the two
     // types of one (conv, kd, kw) meet in kh = 1..3.  The tiles go to LDS with plain 16-byte stores (LDS float atomics retire about one lane per clock: 80 of them
     // per lane were 13 us of this kernel), then one thread per weight sums its <= 8 entries and issues ONE global atomic.  Two rounds (wave slot 0, then slot 1):
@@ -966,8 +969,13 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
 #define WG_LAUNCH(ns)                                                                                                                                      \
     do {                                                                                                                                                   \
         static bool attr = false;                                                                                                                          \
-        if (!attr) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<ns>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attr = true; } \
-        vx_jlc_wg_k<ns><<<grid, dim3(256), shm, st>>>(p);                                                                                                  \
+        if (!attr) {                                                                                                                                       \
+            VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<ns, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&           \
+                       hipFuncSetAttribute((const void*)vx_jlc_wg_k<ns, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); \
+            attr = true;                                                                                                                                   \
+        }                                                                                                                                                  \
+        if (p.dbg) vx_jlc_wg_k<ns, true><<<grid, dim3(256), shm, st>>>(p);                                                                                 \
+        else vx_jlc_wg_k<ns, false><<<grid, dim3(256), shm, st>>>(p);                                                                                      \
     } while (0)
     if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2); else WG_LAUNCH(1);
 #undef WG_LAUNCH
