@@ -37,6 +37,7 @@ struct TzGeo {          // LDS halo geometry of one source (elements = bf16)
 struct VxTz {
     const float* src[3];            // forward: x; backward: g5, g3, g1
     const uint4* img;               // operand images of this direction
+    const float* esc;               // fp16 two-piece mode: scale exponents of the weight images [G][3] (K = 5, 3, 1)
     const float* bias[3];           // forward (order k = 5, 3, 1); may be null
     const float* res;               // backward: d_o
     const float* w1;                // backward: the 1x1x1 weights (C, C/G)
@@ -62,6 +63,24 @@ __device__ __forceinline__ uint32_t tz_pack(float a, float b) {
 __device__ __forceinline__ unsigned tz_divm(unsigned i, unsigned m) { return m ? __umulhi(i, m) : i; }
 __device__ __forceinline__ float tz_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float tz_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// ---- two fp16 pieces (the "22-bit" mode, pieces knob = 22): x * 2^e = h0 + h1 with e chosen per tile (activations) / per conv group (weights) so that the largest
+// magnitude sits in [2^14, 2^15).  11 + 11 significant bits against the 24 of fp32; a product = THREE MFMAs (h0 k0 + h0 k1 + h1 k0, the neglected h1 k1 <= 2^-22 of the
+// product), half the matrix-pipe work and two thirds of the LDS traffic of the three-bf16-piece scheme.  Small elements fall into fp16's subnormals: absolute error
+// <= 2^-25 in scaled units = 2^-40 of the tile's maximum.  Power-of-two scales: exact, undone on the fp32 accumulators in the epilogue.
+typedef _Float16 tz_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t tz_pack16(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float tz_lo16(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[0]; }
+__device__ __forceinline__ float tz_hi16(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[1]; }
+// exponent e with |m| * 2^e in [2^14, 2^15) (0 for m = 0 or a non-finite m: the values then pass through unscaled)
+__device__ __forceinline__ int tz_exp16(float m) {
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 0;
+    int e = 14 - ilogbf(m);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
 
 // ------------------------------------------------------------------------------------------------------------------ operand images of the weights
 // entry e: K = 5 -> kd*5 + kh (0..24); K = 3 -> 25 + kd*3 + kh; K = 1 -> 34.   img[((((g*35 + e)*MT + mt)*KS + ks)*NS + s)*64 + lane] (uint4 = 8 bf16)
@@ -118,6 +137,70 @@ __global__ void __launch_bounds__(256) vx_tz_prep_k(const float* __restrict__ w1
     }
 }
 
+// scale exponents of the fp16 two-piece weight images: esc[g][c] (c = 0, 1, 2 for K = 5, 3, 1) from the largest magnitude of the (group, K) weight block (contiguous
+// CG * CG * K^3 floats); grid (G, 3)
+__global__ void __launch_bounds__(256) vx_tz_wmax_k(const float* __restrict__ w1, const float* __restrict__ w3, const float* __restrict__ w5, float* __restrict__ esc, int CG) {
+    __shared__ float sm[4];
+    const int g = blockIdx.x, c = blockIdx.y;
+    const int K3 = c == 0 ? 125 : c == 1 ? 27 : 1;
+    const float* __restrict__ wg = (c == 0 ? w5 : c == 1 ? w3 : w1) + (long)g * CG * CG * K3;
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < CG * CG * K3; i += 256) mx = fmaxf(mx, fabsf(wg[i]));
+    mx = vx_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) esc[g * 3 + c] = (float)tz_exp16(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+}
+// the same images as two scaled fp16 pieces (pieces knob = 22): one WAVE per image entry
+template <int CG>
+__global__ void __launch_bounds__(256) vx_tz_prep16_k(const float* __restrict__ w1, const float* __restrict__ w3, const float* __restrict__ w5, uint4* __restrict__ img_f,
+                                                      uint4* __restrict__ img_b, const float* __restrict__ esc, int G) {
+    constexpr int MT = CG / 4, KS = CG / 4;
+    const long total = (long)G * 35 * MT * KS;
+    const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= total) return;
+    const int lane = threadIdx.x & 63;
+    long r = t;
+    const int ks = (int)(r % KS); r /= KS;
+    const int mt = (int)(r % MT); r /= MT;
+    const int e = (int)(r % 35);
+    const int g = (int)(r / 35);
+    int K, kd, kh, c;
+    const float* w;
+    if (e < 25) { K = 5; kd = e / 5; kh = e % 5; w = w5; c = 0; }
+    else if (e < 34) { K = 3; kd = (e - 25) / 3; kh = (e - 25) % 3; w = w3; c = 1; }
+    else { K = 1; kd = 0; kh = 0; w = w1; c = 2; }
+    const int hw = K / 2, K3 = K * K * K;
+    const int ew = (int)esc[g * 3 + c];
+    const float sc = ldexpf(1.0f, ew);
+    const int m = lane & 15, q = lane >> 4;
+    const int a_l = mt * 4 + (m >> 2), wo = m & 3, b_l = ks * 4 + q;
+    float vf[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kw = j - 2 - wo + hw;
+        float f = 0.0f, bwd = 0.0f;
+        if (kw >= 0 && kw < K) {
+            f = w[((long)(g * CG + a_l) * CG + b_l) * K3 + (kd * K + kh) * K + kw] * sc;
+            bwd = w[((long)(g * CG + b_l) * CG + a_l) * K3 + ((K - 1 - kd) * K + (K - 1 - kh)) * K + (K - 1 - kw)] * sc;
+        }
+        vf[j] = f; vb[j] = bwd;
+    }
+    const long o = t * 2 * 64 + lane;
+    uint32_t f0[4], f1[4], b0[4], b1[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+        f0[j2] = tz_pack16(vf[2 * j2], vf[2 * j2 + 1]);
+        f1[j2] = tz_pack16(vf[2 * j2] - tz_lo16(f0[j2]), vf[2 * j2 + 1] - tz_hi16(f0[j2]));
+        b0[j2] = tz_pack16(vb[2 * j2], vb[2 * j2 + 1]);
+        b1[j2] = tz_pack16(vb[2 * j2] - tz_lo16(b0[j2]), vb[2 * j2 + 1] - tz_hi16(b0[j2]));
+    }
+    img_f[o] = make_uint4(f0[0], f0[1], f0[2], f0[3]);
+    img_f[o + 64] = make_uint4(f1[0], f1[1], f1[2], f1[3]);
+    img_b[o] = make_uint4(b0[0], b0[1], b0[2], b0[3]);
+    img_b[o + 64] = make_uint4(b1[0], b1[1], b1[2], b1[3]);
+}
+
 // ------------------------------------------------------------------------------------------------------------------ halo staging
 // Halo of one source in LDS as NS bf16 planes: elem[s][ci][hd][hh][e], e = w - (w0 - 2) in [0, RW).  A thread stages quads (4 consecutive w, one 16-byte load);
 // the pieces of a quad leave as two packed pairs per piece (4-byte LDS stores: e = 4 qd - 2 is even, not a multiple of 4).
@@ -167,6 +250,64 @@ __device__ __forceinline__ void tz_stage(const float* __restrict__ src, unsigned
     }
 }
 
+// fp16 two-piece staging: every quad of the thread is loaded FIRST (<= TZ_NQ16 per thread: host-checked), the tile's largest magnitude is reduced over the block, then
+// the scaled values are split and stored.  Returns the tile's exponent (block-uniform).  `scratch`: >= 9 floats of LDS outside the halo.
+#define TZ_NQ16 16
+template <int CG>
+__device__ __forceinline__ int tz_stage16(const float* __restrict__ src, unsigned char* __restrict__ lds, const VxTz& p, const TzGeo& ge, int hw, int b, int g, int d0, int h0,
+                                          int w0, int nthr, float* __restrict__ scratch) {
+    const int total = ge.nrows * ge.nq;
+    const long chan = (long)p.D * p.H * p.W;
+    const float* __restrict__ sb = src + ((long)b * p.C + (long)g * CG) * chan;
+    float4 v[TZ_NQ16];
+    int eo[TZ_NQ16];
+    float mx = 0.0f;
+#pragma unroll
+    for (int u = 0; u < TZ_NQ16; ++u) {
+        const int it = (int)threadIdx.x + u * nthr;
+        const bool live = it < total;
+        const unsigned iu = live ? (unsigned)it : 0u;
+        const unsigned r1 = tz_divm(iu, ge.mNQ);
+        const int qd = (int)(iu - r1 * ge.nq) + ge.qd0;
+        const unsigned r2 = tz_divm(r1, ge.mHH);
+        const int hh = (int)(r1 - r2 * ge.HH);
+        const unsigned ci = tz_divm(r2, ge.mHD);
+        const int hd = (int)(r2 - ci * ge.HD);
+        const int id = d0 - hw + hd, ih = h0 - hw + hh, iw = w0 - 4 + 4 * qd;
+        const bool ok = live && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const float4 t_ = *reinterpret_cast<const float4*>(sb + (ok ? (long)ci * chan + ((long)id * p.H + ih) * p.W + iw : 0));
+        v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+        // bit 0 / 1 of the low bits: store the first / second pair (quad 0 contributes its last two values only, the last quad its first two)
+        const int e_ = (int)ci * ge.Sc + hd * ge.Sd + hh * p.RW + 4 * qd - 2;
+        eo[u] = live ? ((e_ + 2) << 2) | (qd > 0 ? 1 : 0) | (qd * 4 < p.RW ? 2 : 0) : -1;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+    }
+    mx = vx_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    {
+        const int nw = nthr >> 6;
+        float m2 = 0.0f;
+        for (int i = 0; i < nw; ++i) m2 = fmaxf(m2, scratch[i]);
+        mx = m2;
+    }
+    const int e = tz_exp16(mx);
+    const float sc = ldexpf(1.0f, e);
+#pragma unroll
+    for (int u = 0; u < TZ_NQ16; ++u) {
+        if (eo[u] < 0) continue;
+        const int e0 = (eo[u] >> 2) - 2;
+        const float a0 = v[u].x * sc, a1 = v[u].y * sc, a2 = v[u].z * sc, a3 = v[u].w * sc;
+        const uint32_t lo0 = tz_pack16(a0, a1), hi0 = tz_pack16(a2, a3);
+        const uint32_t lo1 = tz_pack16(a0 - tz_lo16(lo0), a1 - tz_hi16(lo0)), hi1 = tz_pack16(a2 - tz_lo16(hi0), a3 - tz_hi16(hi0));
+        uint32_t* d0_ = reinterpret_cast<uint32_t*>(lds + 2 * (long)e0);
+        uint32_t* d1_ = reinterpret_cast<uint32_t*>(lds + 2 * ((long)ge.Sp + e0));
+        if (eo[u] & 1) { d0_[0] = lo0; d1_[0] = lo1; }
+        if (eo[u] & 2) { d0_[1] = hi0; d1_[1] = hi1; }
+    }
+    return e;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ accumulate one convolution
 // acc[mt][nt] += sum over the K*K (kd, kh) entries and the KS k-steps.  `boff[nt]`: byte offset of the lane's position (and of its q-th channel) in piece 0;
 // `ebase`: byte offset of entry (0, 0) (a K = 3 / 1 convolution reading a K = 5 halo starts one / two rows and planes in).
@@ -187,7 +328,7 @@ __device__ __forceinline__ void tz_read_b(uint4 (&bv)[NTB][NS], const unsigned c
             bv[nt][s] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
         }
 }
-template <int NTB, int MTW, int NS>
+template <int NTB, int MTW, int NS, bool F16>
 __device__ __forceinline__ void tz_mfma(tz_f4 (*acc)[NTB], const uint4 (&a)[MTW][NS], const uint4 (&bv)[NTB][NS]) {
     constexpr int NP = NS == 3 ? 6 : NS == 2 ? 3 : 1;
     // piece pairs (weight piece, activation piece), smallest terms first
@@ -200,7 +341,10 @@ __device__ __forceinline__ void tz_mfma(tz_f4 (*acc)[NTB], const uint4 (&a)[MTW]
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[mt][sw]), __builtin_bit_cast(tz_bf8, bv[nt][sa]), acc[mt][nt], 0, 0, 0);
+                if constexpr (F16)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tz_h8, a[mt][sw]), __builtin_bit_cast(tz_h8, bv[nt][sa]), acc[mt][nt], 0, 0, 0);
+                else
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[mt][sw]), __builtin_bit_cast(tz_bf8, bv[nt][sa]), acc[mt][nt], 0, 0, 0);
     }
 }
 template <int MTW, int NS, int KS>
@@ -210,7 +354,7 @@ __device__ __forceinline__ void tz_read_a(uint4 (&a)[MTW][NS], const uint4* __re
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[mt][s] = ap[((long)mt * KS) * NS * 64 + s * 64];
 }
-template <int K, int CG, int NT, int MTW, int NS>
+template <int K, int CG, int NT, int MTW, int NS, bool F16>
 __device__ __forceinline__ void tz_accumulate(tz_f4 (&acc)[MTW][NT], const uint4* __restrict__ aimg, const unsigned char* __restrict__ lds, const int (&boff)[NT], int ebase,
                                               int Sd, int RW, int Sc, int Sp, int mt0) {
     constexpr int MT = CG / 4, KS = CG / 4;
@@ -250,12 +394,12 @@ __device__ __forceinline__ void tz_accumulate(tz_f4 (&acc)[MTW][NT], const uint4
             tz_read_a<MTW, NS, KS>(a2, a_ptr(st + 2));
             if constexpr (NU == 2) {
                 tz_read_b<NTB, NS>(b1, lds, boff + NTB, off, Sp);
-                tz_mfma<NTB, MTW, NS>(au[0], a0, b0);
+                tz_mfma<NTB, MTW, NS, F16>(au[0], a0, b0);
                 if (more) tz_read_b<NTB, NS>(b0, lds, boff, off_n, Sp);
-                tz_mfma<NTB, MTW, NS>(au[1], a0, b1);
+                tz_mfma<NTB, MTW, NS, F16>(au[1], a0, b1);
             } else {
                 if (more) tz_read_b<NTB, NS>(b1, lds, boff, off_n, Sp);
-                tz_mfma<NTB, MTW, NS>(au[0], a0, b0);
+                tz_mfma<NTB, MTW, NS, F16>(au[0], a0, b0);
 #pragma unroll
                 for (int i = 0; i < NTB; ++i)
 #pragma unroll
@@ -278,7 +422,7 @@ __device__ __forceinline__ void tz_accumulate(tz_f4 (&acc)[MTW][NT], const uint4
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the kernel
-template <int CG, int NT, int MTW, int NS, bool BWD>
+template <int CG, int NT, int MTW, int NS, bool BWD, bool F16>
 __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tz_lds[];
     constexpr int MT = CG / 4, KS = CG / 4, MG = MT / MTW;
@@ -334,7 +478,9 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
 
     if constexpr (!BWD) {
         const TzGeo& ge = p.geo[0];
-        if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+        int ex = 0;                                                          // fp16 mode: the tile's scale exponent
+        if constexpr (F16) ex = tz_stage16<CG>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, reinterpret_cast<float*>(tz_lds + p.red_off));
+        else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
         set_boff(ge);
         __syncthreads();
         float* red = reinterpret_cast<float*>(tz_lds + p.red_off);            // [3][waves][MTW][4][2]
@@ -343,9 +489,16 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
         for (int c = 0; c < 3; ++c) {              // c = 0: K = 5, 1: K = 3, 2: K = 1
             zero();
             if (p.dbg & 2) {}
-            else if (c == 0) tz_accumulate<5, CG, NT, MTW, NS>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
-            else if (c == 1) tz_accumulate<3, CG, NT, MTW, NS>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 2 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
-            else tz_accumulate<1, CG, NT, MTW, NS>(acc, img_g + (long)34 * MT * KS * NS * 64, tz_lds, boff, 4 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            else if (c == 0) tz_accumulate<5, CG, NT, MTW, NS, F16>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            else if (c == 1) tz_accumulate<3, CG, NT, MTW, NS, F16>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 2 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            else tz_accumulate<1, CG, NT, MTW, NS, F16>(acc, img_g + (long)34 * MT * KS * NS * 64, tz_lds, boff, 4 * (ge.Sd + p.RW), ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            if constexpr (F16) {                                             // undo the two power-of-two scales on the fp32 accumulators (exact)
+                const float fs = ldexpf(1.0f, -(ex + (int)p.esc[g * 3 + c]));
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] *= fs;
+            }
             float* __restrict__ y = p.out[c];
             const float* __restrict__ bias = p.bias[c];
 #pragma unroll
@@ -386,20 +539,40 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
         }
     } else {
         zero();
+        tz_f4 acc5[MTW][NT];                                                 // fp16 mode: the K = 5 term in true units while the K = 3 term accumulates (their tiles have different scales)
+        float* scr = reinterpret_cast<float*>(tz_lds + p.red_off);
         {
             const TzGeo& ge = p.geo[0];
-            if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+            int ex = 0;
+            if constexpr (F16) ex = tz_stage16<CG>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, scr);
+            else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
             set_boff(ge);
             __syncthreads();
-            if (!(p.dbg & 2)) tz_accumulate<5, CG, NT, MTW, NS>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            if (!(p.dbg & 2)) tz_accumulate<5, CG, NT, MTW, NS, F16>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            if constexpr (F16) {
+                const float fs = ldexpf(1.0f, -(ex + (int)p.esc[g * 3 + 0]));
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { acc5[mt][nt] = acc[mt][nt] * fs; acc[mt][nt] = (tz_f4){0.f, 0.f, 0.f, 0.f}; }
+            }
         }
         __syncthreads();
         {
             const TzGeo& ge = p.geo[1];
-            if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr);
+            int ex = 0;
+            if constexpr (F16) ex = tz_stage16<CG>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr, scr);
+            else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr);
             set_boff(ge);
             __syncthreads();
-            if (!(p.dbg & 2)) tz_accumulate<3, CG, NT, MTW, NS>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            if (!(p.dbg & 2)) tz_accumulate<3, CG, NT, MTW, NS, F16>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
+            if constexpr (F16) {
+                const float fs = ldexpf(1.0f, -(ex + (int)p.esc[g * 3 + 1]));
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc5[mt][nt] + acc[mt][nt] * fs;
+            }
         }
         // epilogue: + conv1^T(g1) + d_o straight from global memory
         const float* __restrict__ g1 = p.src[2];
@@ -432,7 +605,9 @@ static unsigned tz_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) 
 static int g_tz_pieces = 3;
 static int g_tz_dbg = 0;
 extern "C" int vx_jlc_tz_set_debug(int mask) { g_tz_dbg = mask; return 0; }
-extern "C" int vx_jlc_tz_set_pieces(int ns) { if (ns < 1 || ns > 3) return -1; g_tz_pieces = ns; return 0; }
+// 3 / 2 / 1 bf16 pieces per fp32 operand (6 / 3 / 1 piece products), or 22 = two scaled fp16 pieces (22 significant bits, 3 piece products)
+extern "C" int vx_jlc_tz_set_pieces(int ns) { if (!((ns >= 1 && ns <= 3) || ns == 22)) return -1; g_tz_pieces = ns; return 0; }
+static inline int tz_ns(int pieces) { return pieces == 22 ? 2 : pieces; }
 extern "C" int vx_jlc_tz_pieces(void) { return g_tz_pieces; }
 
 struct TzPlan { int CG, NT, MTW, nwaves; size_t shm; };
@@ -458,7 +633,8 @@ static void tz_geo(TzGeo& ge, const VxTz& p, int CG, int hw) {
 }
 
 // tile / wave plan: a function of (C/G, D, H, W) only -- never of the batch (a sample's partial sums must fold in the same order whatever it is batched with)
-static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W, int NS) {
+static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W, int pieces) {
+    const int NS = tz_ns(pieces);
     if (B <= 0 || C <= 0 || G <= 0 || C % G || D <= 0 || H <= 0 || W <= 0 || (W & 3)) return -1;
     const int CG = C / G;
     if (CG != 4 && CG != 8 && CG != 16) return -1;
@@ -504,6 +680,10 @@ static int tz_plan(VxTz& p, TzPlan& pl, int B, int C, int G, int D, int H, int W
     if (best < 0) return -1;
     pl.nwaves = (MT / pl.MTW) * vx_cdiv(p.nNt, pl.NT);
     if (pl.nwaves > 8) return -1;
+    if (pieces == 22) {             // fp16 two-piece staging holds every quad of a thread in registers while the tile's maximum is reduced
+        const long nthr = 64L * pl.nwaves;
+        if ((long)p.geo[0].nrows * p.geo[0].nq > TZ_NQ16 * nthr || (long)p.geo[1].nrows * p.geo[1].nq > TZ_NQ16 * nthr) return -1;
+    }
     size_t halo = lds_bytes(p.TD, p.TH, p.TWB);
     halo = (halo + 15) & ~(size_t)15;
     p.red_off = (int)halo;
@@ -529,23 +709,34 @@ extern "C" int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W) {
     return p.nTd * p.nTh * p.nTw;
 }
 // uint4 elements of ONE direction's image (+ one spare entry for the operand prefetch); the workspace of vx_jlc_tz_prep holds two (forward, input gradient)
-static long tz_img_elems(int C, int G, int NS) {
+static long tz_img_elems(int C, int G, int pieces) {
+    const int NS = tz_ns(pieces);
     const int CG = C / G, MT = CG / 4;
     return (long)G * 35 * MT * MT * NS * 64 + (long)2 * MT * MT * NS * 64;        // + two spare entries: the operand FIFO reads two steps ahead
 }
-extern "C" int vx_jlc_tz_img_floats(int C, int G) { return (int)(2 * tz_img_elems(C, G, g_tz_pieces) * 4); }
+extern "C" int vx_jlc_tz_img_floats(int C, int G) { return (int)(2 * tz_img_elems(C, G, g_tz_pieces) * 4 + ((3 * G + 3) & ~3)); }       // + the scale exponents of the fp16 mode
 
 extern "C" int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream) {
     VX_REQUIRE(w1 && w3 && w5 && img && G > 0 && C % G == 0, "vx_jlc_tz_prep: bad args");
-    const int CG = C / G, NS = g_tz_pieces;
+    const int CG = C / G, NS = tz_ns(g_tz_pieces);
     VX_REQUIRE(CG == 4 || CG == 8 || CG == 16, "vx_jlc_tz_prep: group width %d", CG);
-    const long ne = tz_img_elems(C, G, NS);
+    const long ne = tz_img_elems(C, G, g_tz_pieces);
     uint4* f = reinterpret_cast<uint4*>(img);
     uint4* bw = f + ne;
     const int MT = CG / 4;
     const long total = (long)G * 35 * MT * MT * 64;
     const dim3 grid((unsigned)vx_cdiv(total, 256));
     hipStream_t st = (hipStream_t)stream;
+    if (g_tz_pieces == 22) {
+        float* esc = img + 2 * ne * 4;
+        const dim3 g16((unsigned)vx_cdiv((long)G * 35 * MT * MT, 4));
+        vx_tz_wmax_k<<<dim3((unsigned)G, 3), dim3(256), 0, st>>>(w1, w3, w5, esc, CG);
+        if (CG == 4) vx_tz_prep16_k<4><<<g16, dim3(256), 0, st>>>(w1, w3, w5, f, bw, esc, G);
+        else if (CG == 8) vx_tz_prep16_k<8><<<g16, dim3(256), 0, st>>>(w1, w3, w5, f, bw, esc, G);
+        else vx_tz_prep16_k<16><<<g16, dim3(256), 0, st>>>(w1, w3, w5, f, bw, esc, G);
+        VX_LAUNCH_CHECK("vx_jlc_tz_prep");
+        return 0;
+    }
 #define TZ_PREP(cg, ns) vx_tz_prep_k<cg, ns><<<grid, dim3(256), 0, st>>>(w1, w3, w5, f, bw, G)
     if (NS == 3) { if (CG == 4) TZ_PREP(4, 3); else if (CG == 8) TZ_PREP(8, 3); else TZ_PREP(16, 3); }
     else if (NS == 2) { if (CG == 4) TZ_PREP(4, 2); else if (CG == 8) TZ_PREP(8, 2); else TZ_PREP(16, 2); }
@@ -555,20 +746,20 @@ extern "C" int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5,
     return 0;
 }
 
-template <int CG, int NT, int MTW, int NS, bool BWD>
+template <int CG, int NT, int MTW, int NS, bool BWD, bool F16>
 static int tz_launch_t(const VxTz& p, const TzPlan& pl, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)vx_tz_k<CG, NT, MTW, NS, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+        if (hipFuncSetAttribute((const void*)vx_tz_k<CG, NT, MTW, NS, BWD, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
         attr = true;
     }
     const dim3 grid((unsigned)(p.nTd * p.nTh * p.nTw * p.G * p.B));
-    vx_tz_k<CG, NT, MTW, NS, BWD><<<grid, dim3(64 * pl.nwaves), pl.shm, st>>>(p);
+    vx_tz_k<CG, NT, MTW, NS, BWD, F16><<<grid, dim3(64 * pl.nwaves), pl.shm, st>>>(p);
     return 0;
 }
-template <int NS, bool BWD>
+template <int NS, bool BWD, bool F16 = false>
 static int tz_launch(const VxTz& p, const TzPlan& pl, hipStream_t st) {
-#define TZ_CASE(cg, nt, mtw) if (pl.CG == cg && pl.NT == nt && pl.MTW == mtw) return tz_launch_t<cg, nt, mtw, NS, BWD>(p, pl, st)
+#define TZ_CASE(cg, nt, mtw) if (pl.CG == cg && pl.NT == nt && pl.MTW == mtw) return tz_launch_t<cg, nt, mtw, NS, BWD, F16>(p, pl, st)
     TZ_CASE(4, 1, 1); TZ_CASE(4, 2, 1); TZ_CASE(4, 4, 1);
     TZ_CASE(8, 1, 1); TZ_CASE(8, 2, 1); TZ_CASE(8, 4, 1); TZ_CASE(8, 1, 2); TZ_CASE(8, 2, 2);
     TZ_CASE(16, 1, 1); TZ_CASE(16, 2, 1); TZ_CASE(16, 4, 1); TZ_CASE(16, 1, 2); TZ_CASE(16, 2, 2); TZ_CASE(16, 1, 4);
@@ -581,12 +772,14 @@ extern "C" int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, 
     VX_REQUIRE(x && img && y1 && y3 && y5 && part, "vx_jlc_tz_fwd: null pointer");
     VxTz p = {};
     TzPlan pl;
-    const int NS = g_tz_pieces;
-    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, NS) == 0, "vx_jlc_tz_fwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    const int NS = tz_ns(g_tz_pieces);
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, g_tz_pieces) == 0, "vx_jlc_tz_fwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.src[0] = x; p.img = reinterpret_cast<const uint4*>(img);
+    p.esc = img + 2 * tz_img_elems(C, G, g_tz_pieces) * 4;
     p.bias[0] = b5; p.bias[1] = b3; p.bias[2] = b1;
     p.out[0] = y5; p.out[1] = y3; p.out[2] = y1; p.part = part; p.dbg = g_tz_dbg;
-    const int rc = NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
+    const int rc = g_tz_pieces == 22 ? tz_launch<2, false, true>(p, pl, (hipStream_t)stream)
+                   : NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_fwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_fwd");
     return 0;
@@ -597,12 +790,14 @@ extern "C" int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, 
     VX_REQUIRE(g1 && g3 && g5 && img && w1 && d_o && dx, "vx_jlc_tz_bwd: null pointer");
     VxTz p = {};
     TzPlan pl;
-    const int NS = g_tz_pieces;
-    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, NS) == 0, "vx_jlc_tz_bwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    const int NS = tz_ns(g_tz_pieces);
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, g_tz_pieces) == 0, "vx_jlc_tz_bwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.src[0] = g5; p.src[1] = g3; p.src[2] = g1;
-    p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, NS);
+    p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, g_tz_pieces);
+    p.esc = img + 2 * tz_img_elems(C, G, g_tz_pieces) * 4;
     p.w1 = w1; p.res = d_o; p.out[0] = dx; p.dbg = g_tz_dbg;
-    const int rc = NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
+    const int rc = g_tz_pieces == 22 ? tz_launch<2, true, true>(p, pl, (hipStream_t)stream)
+                   : NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_bwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_bwd");
     return 0;
@@ -952,7 +1147,7 @@ extern "C" int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W) {
     size_t shm;
     if (g_wg_min_v < 0) { const char* e = getenv("VELOXSEG_WG_TZ_MIN_V"); g_wg_min_v = e ? atol(e) : 0; }
     if ((long)D * H * W < g_wg_min_v) return 0;
-    return wg_plan(p, shm, 1, C, G, D, H, W, g_tz_pieces) == 0 ? 1 : 0;
+    return wg_plan(p, shm, 1, C, G, D, H, W, g_tz_pieces == 22 ? 3 : g_tz_pieces) == 0 ? 1 : 0;
 }
 
 extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
@@ -960,7 +1155,7 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
     VX_REQUIRE(x && g1 && g3 && g5, "vx_jlc_wgrad_tz: null pointer");
     VxWgT p = {};
     size_t shm;
-    const int NS = g_tz_pieces;
+    const int NS = g_tz_pieces == 22 ? 3 : g_tz_pieces;             // (the weight-gradient kernel has no fp16 two-piece mode: three bf16 pieces)
     VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.x = x; p.g1 = g1; p.g3 = g3; p.g5 = g5; p.dw1 = dw1; p.dw3 = dw3; p.dw5 = dw5; p.dbg = g_tz_dbg >> 4;
     const int MT = p.CG / 4;

@@ -251,7 +251,7 @@ def set_precision(mode: str):
     m.set_bf16_expand(mode == "bf16")
     # the JLC grouped convolutions and their weight gradients on the matrix pipe (csrc/jlc_mfma.hip): 3 bf16 pieces per operand (six piece products = the fp32
     # product) in the fp32 mode, ONE piece (plain bf16 operands, fp32 accumulation) in the bf16 mode
-    H.call("vx_jlc_tz_set_pieces", 1 if mode == "bf16" else 3)
+    H.call("vx_jlc_tz_set_pieces", 1 if mode == "bf16" else int(os.environ.get("VELOXSEG_TZ_PIECES", "22")))     # 22 = two scaled fp16 pieces (22 significant bits, three piece products: csrc/jlc_mfma.hip); 3 = three bf16 pieces (A/B)
     _PRECISION = mode
 
 
