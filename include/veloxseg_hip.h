@@ -178,7 +178,8 @@ int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5, const flo
  *   vx_jlc_tz_img_floats    : floats of the operand-image workspace (forward + input-gradient images of the three weight tensors)
  *   vx_jlc_tz_prep          : expands w1 / w3 / w5 into the images (once per step; the backward of the same step reads the second half)
  *   vx_jlc_tz_fwd / _bwd    : drop-in for vx_jlc_conv_fwd / vx_jlc_conv_bwd (same outputs, same `part` layout)
- *   vx_jlc_tz_set_pieces    : bf16 pieces per fp32 operand: 3 (default, six piece products = the fp32 product), 2, or 1 (bf16 opt-in mode) */
+ *   vx_jlc_tz_set_pieces    : pieces per fp32 operand: 3 / 2 / 1 bf16 pieces (six / three / one piece products; 1 = the bf16 opt-in mode) or 22 = two scaled fp16
+ *                             pieces (22 significant bits, three piece products; what veloxseg_amd.functional selects for the fp32 mode) */
 int vx_jlc_tz_ok(int C, int G, int D, int H, int W);
 int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W);
 int vx_jlc_tz_img_floats(int C, int G);
@@ -195,6 +196,7 @@ int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, const float
  * entry; a null dw skips that tensor's store); W <= 32, W % 4 == 0, H % 4 == 0, group width 4 / 8 / 16.  Bias gradients are not computed (zero behind an InstanceNorm). */
 int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W);
 int vx_jlc_wgrad_tz_set_min_voxels(long v);
+int vx_jlc_wgrad_tz_set_f16(int on);     /* with vx_jlc_tz_set_pieces(22): 1 = the weight gradients on two scaled fp16 pieces as well (A/B; default 0 = three bf16 pieces) */
 int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
                     void* stream);
 
@@ -426,8 +428,10 @@ int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws,
                           void* stream);
 
 /* ---- patch-expand (Decoder.py:73-76,150-153) with fp32-ACCURATE products on the bf16 matrix pipe: every operand split into ns bf16 pieces (2: 3 products per pair,
- * ~1e-5 relative; 3: 6 products, the fp32 product), fp32 accumulate, fp32 storage.  Same contracts as vx_expand_fwd_mfma / vx_expand_bwd_data_mfma; wt_ws
- * holds vx_expand_split_ws_floats(Cc, ns) floats; returns 1 (nothing launched) when the shape is not covered. */
+ * ~1e-5 relative; 3: 6 products, the fp32 product), fp32 accumulate, fp32 storage.  ns = 22 (forward and input gradient): two fp16 pieces (22 mantissa bits, 3
+ * products) of the operand scaled by a power of two chosen per staged tile (weights: per tensor), the fp32 accumulators rescaled exactly -- measured closer to fp64
+ * than ns = 3 (4e-7 vs 1.4e-6 of the maximum).  Same contracts as vx_expand_fwd_mfma / vx_expand_bwd_data_mfma; wt_ws holds vx_expand_split_ws_floats(Cc, ns)
+ * floats; returns 1 (nothing launched) when the shape is not covered. */
 int vx_expand_split_ws_floats(int Cc, int ns);
 int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream);
 int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns, void* stream);

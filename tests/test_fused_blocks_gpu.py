@@ -260,7 +260,7 @@ def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
         H.call("vx_jlc_tz_set_min_voxels", 1024)
 
 
-@pytest.mark.parametrize("pieces", [3, 1])
+@pytest.mark.parametrize("pieces", [3, 22, 1])
 @pytest.mark.parametrize("case", [c for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32], ids=[c[0] for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32])
 def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, pieces):
     """vx_jlc_wgrad_tz (the three grouped-conv weight gradients of conv_blocks.py:51-58 in one matrix-pipe launch, csrc/jlc_mfma.hip) against torch's fp64 weight
@@ -269,6 +269,7 @@ def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, piece
     _, B, C, G, (D, Hh, W) = case
     H.LIB.load()
     H.call("vx_jlc_tz_set_pieces", pieces)
+    H.call("vx_jlc_wgrad_tz_set_f16", 1)          # pieces = 22: the two-fp16-piece weight-gradient instance (an A/B variant: the default under 22 is three bf16 pieces)
     try:
         assert H.query("vx_jlc_wgrad_tz_ok", C, G, D, Hh, W) == 1
         torch.manual_seed(11)
@@ -288,10 +289,11 @@ def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, piece
             ref = torch.nn.grad.conv3d_weight(x.double(), shapes[i], g[i].double(), padding=k // 2, groups=G)
             sc = float(ref.abs().max())
             e_new = float(((d_new[i] - init[i]).double() - ref).abs().max()) / sc
-            if pieces == 3:
+            if pieces in (3, 22):
                 e_old = float((d_old[i].double() - ref).abs().max()) / sc if i else 0.0
                 assert e_new <= max(3.0 * e_old, 3e-6), (k, e_old, e_new)
             else:
                 assert e_new <= 2e-2, (k, e_new)
     finally:
         H.call("vx_jlc_tz_set_pieces", 3)
+        H.call("vx_jlc_wgrad_tz_set_f16", 0)

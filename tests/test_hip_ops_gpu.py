@@ -137,6 +137,39 @@ def test_expand_wgrad_split_direct(B, Cc, sp, ns):
     assert torch.equal(outs[0][0], outs[1][0]), "the folded weight gradient is not reproducible"
 
 
+@pytest.mark.parametrize("ns", [3, 22, 2])
+@pytest.mark.parametrize("B,Cc,sp,scale", [(2, 2, (4, 8, 32), 1.0), (1, 1, (4, 4, 24), 1.0), (2, 1, (8, 4, 16), 3.0e4), (1, 3, (4, 4, 4), 2.0e-5)],
+                         ids=["w32", "w24_ragged_tile", "large_values", "tiny_values"])
+def test_expand_fwd_and_input_gradient_split_direct(B, Cc, sp, ns, scale):
+    """C-ABI vx_expand_fwd_mfma_split / vx_expand_bwd_data_mfma_split against an fp64 reference.  ns = 3: three bf16 pieces; ns = 22: two fp16 pieces of the operand
+    scaled by a power of two per staged tile (and per weight tensor), exact rescale of the fp32 accumulators -- both to fp32 round-off of the sums; ns = 2 to ~1e-5.
+    The large / tiny cases put the activations outside fp16's range: the scaling must bring them back."""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    D_, H_, W_ = sp
+    x = (rnd(B, 16, *sp) * scale).to(d)
+    w = rnd(64 * Cc, 16, 3, 3, 3, seed=1, scale=(16 * 27) ** -0.5).to(d)
+    b = rnd(64 * Cc, seed=2, scale=0.1 * scale).to(d)
+    dy = (rnd(B, Cc, 4 * D_, 4 * H_, 4 * W_, seed=5) * scale).to(d)
+    nws = max(64 * Cc * 16 * 27, H.query("vx_expand_split_ws_floats", Cc, ns))
+    ws = torch.empty(nws, device=d)
+    y = torch.full((B, Cc, 4 * D_, 4 * H_, 4 * W_), float("nan"), device=d)
+    rc = H.query("vx_expand_fwd_mfma_split", H.P(x), H.P(w), H.P(b), H.P(ws), H.P(y), B, Cc, D_, H_, W_, ns, H.stream_ptr())
+    assert rc == 0
+    yref = O.pixel_shuffle3d(F.conv3d(x.double(), w.double(), b.double(), padding=1), 4)
+    tol = {2: 4e-5, 3: 4e-6, 22: 1.5e-6}[ns]                 # (measured: 5e-6 / 1.4e-6 / 4e-7; torch's own fp32 convolution: 3e-7)
+    assert float((y.double() - yref).abs().max()) <= tol * float(yref.abs().max()), f"forward ns={ns}"
+    dx = torch.full((B, 16, *sp), float("nan"), device=d)
+    rc = H.query("vx_expand_bwd_data_mfma_split", H.P(dy), H.P(w), H.P(ws), H.P(dx), B, Cc, D_, H_, W_, 0, ns, H.stream_ptr())
+    assert rc == 0
+    dyc = dy.view(B, Cc, D_, 4, H_, 4, W_, 4).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, 64 * Cc, D_, H_, W_)
+    dxref = F.conv_transpose3d(dyc.double(), w.double(), None, padding=1)
+    assert float((dx.double() - dxref).abs().max()) <= tol * float(dxref.abs().max()), f"input gradient ns={ns}"
+    keep = dx.clone()
+    rc = H.query("vx_expand_bwd_data_mfma_split", H.P(dy), H.P(w), H.P(ws), H.P(dx), B, Cc, D_, H_, W_, 1, ns, H.stream_ptr())      # accumulate = 1
+    assert rc == 0 and float((dx.double() - 2 * keep.double()).abs().max()) <= 1e-6 * float(dxref.abs().max())
+
+
 def test_conv3d_concat_nobias():
     VF = _vf()
     x1, x2 = rnd(2, 16, 4, 4, 4), rnd(2, 32, 4, 4, 4, seed=3)

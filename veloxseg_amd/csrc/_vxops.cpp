@@ -297,7 +297,7 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 VX(vx_gconv1_bwd_weight, fp(x), fp(dy), dw, db, B, Cin, G, V, s);
             else if (s1 && ps == 4 && K == 3 && Cin == 16 && G == 1 && F.use_expand_mfma) {
                 int rcw = 1;
-                const int wns = F.bf16_expand ? 1 : F.expand_split;       // bf16 opt-in mode: plain bf16 operands (one piece), fp32 accumulation
+                const int wns = F.bf16_expand ? 1 : (F.expand_split == 22 ? 3 : F.expand_split);       // bf16 opt-in mode: plain bf16 operands (one piece), fp32 accumulation
                 if (wns >= 1 && F.expand_wgrad_split) {                   // fp32 mode: fp32-exact products on the bf16 pipe (expand_mfma.hip vx_expand_wgrad_split_k)
                     const long nws = vx_expand_wgrad_split_ws_floats(B, Cout / 64, D, H, W);
                     auto pws = std::make_shared<Tensor>(at::empty({nws}, x.options()));
@@ -1406,7 +1406,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("set_conv_mfma", [](bool on) { F.use_conv_mfma = on; });
     m.def("set_bf16_expand", [](bool on) { F.bf16_expand = on; });      // bf16 opt-in mode: bf16 MFMA operands in the patch-expand forward / input gradient
     m.def("get_bf16_expand", []() { return F.bf16_expand; });
-    m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3) ? (int)ns : 0; });      // fp32 mode: split-bf16 products in the patch-expand layers (0 = fp32 MFMA)
+    m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3 || ns == 22) ? (int)ns : 0; });      // fp32 mode: split products in the patch-expand layers (2/3 bf16 pieces, 22 = two scaled fp16 pieces; 0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
     m.def("set_tile_min_c", [](int64_t c) { F.tile_min_c = (int)c; });
     m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });

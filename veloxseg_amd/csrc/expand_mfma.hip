@@ -902,15 +902,89 @@ __global__ void __launch_bounds__(256) vx_expand_wimg_split_k(const float* __res
         v[0] -= (float)h[0]; v[1] -= (float)h[1];
     }
 }
+// ---- two scaled fp16 pieces per operand (ns = 22; the scheme of csrc/jlc_mfma.hip): x * 2^e = h0 + h1, 11 + 11 significant bits, a product = three MFMAs (h0 k0 + h0 k1 +
+// h1 k0); e per staged tile (activations / gradients) and per weight tensor, undone on the fp32 accumulators (exact powers of two)
+typedef _Float16 vx_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ vx_h8 vx_as_h8(uint4 v) { return __builtin_bit_cast(vx_h8, v); }
+__device__ __forceinline__ uint32_t vx_pack_h2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float vx_h2_lo(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[0]; }
+__device__ __forceinline__ float vx_h2_hi(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[1]; }
+__device__ __forceinline__ int vx_exp16(float m) {              // |m| * 2^e in [2^14, 2^15); 0 for m = 0 / non-finite
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 0;
+    const int e = 14 - ilogbf(m);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+// scale exponent of a whole weight tensor (one block)
+__global__ void __launch_bounds__(1024) vx_expand_wmax_k(const float* __restrict__ w, long n, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float mx = 0.0f;
+    for (long i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+    mx = vx_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m2 = 0.0f;
+        for (int i = 0; i < 16; ++i) m2 = fmaxf(m2, sm[i]);
+        out[0] = (float)vx_exp16(m2);
+    }
+}
+// the operand-order weight image as two scaled fp16 pieces: img[s][...] as vx_expand_wimg_split_k<2>
+__global__ void __launch_bounds__(256) vx_expand_wimg_f16_k(const float* __restrict__ w, uint32_t* __restrict__ img, const float* __restrict__ ew, int groups, int backward) {
+    const long n = (long)groups * 14 * 64 * 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float sc = ldexpf(1.0f, (int)ew[0]);
+    const int jp = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long t = e >> 8;
+    const int p = (int)(t % 14), g = (int)(t / 14);
+    const int r = lane & 15, q = lane >> 4;
+    const int tap = 2 * p + (q >> 1);
+    float v[2] = {0.f, 0.f};
+    if (tap < 27)
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * jp + u;
+            int co, ci;
+            if (backward) { co = 16 * g + 4 * (2 * (q & 1) + (j >> 2)) + (j & 3); ci = r; }
+            else { co = 16 * g + r; ci = 8 * (q & 1) + j; }
+            v[u] = w[((long)co * 16 + ci) * 27 + tap] * sc;
+        }
+    const uint32_t h0 = vx_pack_h2(v[0], v[1]);
+    img[e] = h0;
+    img[n + e] = vx_pack_h2(v[0] - vx_h2_lo(h0), v[1] - vx_h2_hi(h0));
+}
+// 8 scaled floats -> two fp16 pieces
+__device__ __forceinline__ void vx_split8_h(const float (&v)[8], float sc, uint4 (&out)[2]) {
+    uint32_t p0[4], p1[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+        const float a = v[2 * j2] * sc, b = v[2 * j2 + 1] * sc;
+        p0[j2] = vx_pack_h2(a, b);
+        p1[j2] = vx_pack_h2(a - vx_h2_lo(p0[j2]), b - vx_h2_hi(p0[j2]));
+    }
+    out[0] = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+    out[1] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+}
+// block-wide maximum through `scratch` (>= 4 floats of LDS; 256 threads); contains a barrier
+__device__ __forceinline__ float vx_block_max_256(float m, float* __restrict__ scratch) {
+    m = vx_wave_max(m);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+
 // the piece products that are kept, smallest first: (activation piece, weight piece)
 template <int NS> struct VxSplitTerms;
 template <> struct VxSplitTerms<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int W[1] = {0}; };      // plain bf16 operands (the bf16 opt-in mode's weight gradient)
 template <> struct VxSplitTerms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int W[3] = {0, 1, 0}; };
 template <> struct VxSplitTerms<3> { static constexpr int N = 6; static constexpr int A[6] = {1, 2, 0, 1, 0, 0}; static constexpr int W[6] = {1, 0, 2, 0, 1, 0}; };
 
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias,
-                                                             float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+                                                             float* __restrict__ y, int B, int Cc, int D, int H, int W, const float* __restrict__ ew = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint4 vx_xs[];          // [NS][channel half][6 x 6 x 18 halo voxel] x 8 bf16
     using TT = VxSplitTerms<NS>;
     const int lane = threadIdx.x & 63;
@@ -925,6 +999,38 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __rest
     const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
     const long V = (long)D * H * W;
     const float* __restrict__ xb = x + (long)b * 16 * V;
+    float fscale = 1.0f;                                                   // fp16 mode: 2^-(tile exponent + weight exponent), applied to the accumulators
+    if constexpr (F16) {
+        // every entry of the thread first (6 x 8 floats), the tile's largest magnitude over the block, then the scaled split
+        float v[6][8];
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = (int)threadIdx.x + i * 256;
+            const int ec = e < 2 * 648 ? e : 0;
+            const int hv = ec % 648, half = ec / 648;
+            const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
+            const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + hw;
+            const bool ok = e < 2 * 648 && (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+            const float* __restrict__ src = xb + (long)(8 * half) * V + (ok ? ((long)qd * H + qh) * W + qw : 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t_ = src[(long)j * V]; v[i][j] = ok ? t_ : 0.0f; mx = fmaxf(mx, fabsf(v[i][j])); }
+        }
+        float* scratch = reinterpret_cast<float*>(vx_xs + NS * (2 * 648));
+        const int ex = vx_exp16(vx_block_max_256(mx, scratch));
+        const float sc = ldexpf(1.0f, ex);
+        fscale = ldexpf(1.0f, -(ex + (int)ew[0]));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = (int)threadIdx.x + i * 256;
+            if (e < 2 * 648) {
+                uint4 pk[2];
+                vx_split8_h(v[i], sc, pk);
+                vx_xs[e] = pk[0];
+                vx_xs[2 * 648 + e] = pk[1];
+            }
+        }
+    } else {
     for (int e = threadIdx.x; e < 2 * 648; e += 256) {
         const int hv = e % 648, half = e / 648;
         const int hw = hv % 18, hh = (hv / 18) % 6, hd = hv / 108;
@@ -938,6 +1044,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __rest
         vx_split8<NS>(v, pk);
 #pragma unroll
         for (int s = 0; s < NS; ++s) vx_xs[s * (2 * 648) + e] = pk[s];
+    }
     }
     __syncthreads();
     const long FH = 4L * H, FW = 4L * W;
@@ -966,7 +1073,14 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __rest
 #pragma unroll
             for (int k = 0; k < TT::N; ++k)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[TT::W[k]]), vx_as_bf8(bv[TT::A[k]][m]), acc[m], 0, 0, 0);
+                for (int m = 0; m < 4; ++m) {
+                    if constexpr (F16) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vx_as_h8(av[TT::W[k]]), vx_as_h8(bv[TT::A[k]][m]), acc[m], 0, 0, 0);
+                    else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[TT::W[k]]), vx_as_bf8(bv[TT::A[k]][m]), acc[m], 0, 0, 0);
+                }
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] *= fscale;
         }
         const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
@@ -990,9 +1104,9 @@ __device__ __forceinline__ void vx_split4(const float4 v, uint2 (&out)[NS]) {
 }
 // input gradient: the halo of the fine gradient is split into its NS bf16 pieces ONCE, while it is staged ([piece][(hd, hh, s2) row][18 coarse voxels] x 4 bf16);
 // the A operand of a tap pair is then two 8-byte LDS reads per piece (splitting it again for every tap cost more VALU time than the MFMAs saved)
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
-                                                                  int B, int Cc, int D, int H, int W, int accumulate) {
+                                                                  int B, int Cc, int D, int H, int W, int accumulate, const float* __restrict__ ew = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint2 vx_hs[];          // [NS][144 rows][18]
     using TT = VxSplitTerms<NS>;
     const int lane = threadIdx.x & 63;
@@ -1011,11 +1125,13 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
     const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
     const long wn = (long)Cc * 4 * 14 * 64;
     vx_f4 acc[4];
+    vx_f4 tot[4];                      // fp16 mode: the sum over the (c, s1) groups in true units (every group's staged tile has its own scale)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 4; ++m) { acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f}; tot[m] = (vx_f4){0.f, 0.f, 0.f, 0.f}; }
     for (int c = 0; c < Cc; ++c) {
         for (int s1 = 0; s1 < 4; ++s1) {
             __syncthreads();
+            float gscale = 1.0f;
             {
                 float4 v[11];
 #pragma unroll
@@ -1028,6 +1144,24 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
                     const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
                     v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                if constexpr (F16) {
+                    float mx = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 11; ++u) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));     // (clamped duplicates repeat a valid entry)
+                    const int ex = vx_exp16(vx_block_max_256(mx, reinterpret_cast<float*>(vx_hs + NS * (144 * 18))));
+                    const float sc = ldexpf(1.0f, ex);
+                    gscale = ldexpf(1.0f, -(ex + (int)ew[0]));
+#pragma unroll
+                    for (int u = 0; u < 11; ++u) {
+                        const int e = (int)threadIdx.x + u * 256;
+                        if (e < 144 * 18) {
+                            const float a0 = v[u].x * sc, a1 = v[u].y * sc, a2 = v[u].z * sc, a3 = v[u].w * sc;
+                            const uint32_t l0 = vx_pack_h2(a0, a1), h0 = vx_pack_h2(a2, a3);
+                            vx_hs[e] = make_uint2(l0, h0);
+                            vx_hs[144 * 18 + e] = make_uint2(vx_pack_h2(a0 - vx_h2_lo(l0), a1 - vx_h2_hi(l0)), vx_pack_h2(a2 - vx_h2_lo(h0), a3 - vx_h2_hi(h0)));
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < 11; ++u) {
                     const int e = (int)threadIdx.x + u * 256;
@@ -1037,6 +1171,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
 #pragma unroll
                         for (int s = 0; s < NS; ++s) vx_hs[s * (144 * 18) + e] = pc[s];
                     }
+                }
                 }
             }
             __syncthreads();
@@ -1063,9 +1198,20 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
 #pragma unroll
                 for (int k = 0; k < TT::N; ++k)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[m][TT::A[k]]), vx_as_bf8(bv[TT::W[k]]), acc[m], 0, 0, 0);
+                    for (int m = 0; m < 4; ++m) {
+                        if constexpr (F16) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vx_as_h8(av[m][TT::A[k]]), vx_as_h8(bv[TT::W[k]]), acc[m], 0, 0, 0);
+                        else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[m][TT::A[k]]), vx_as_bf8(bv[TT::W[k]]), acc[m], 0, 0, 0);
+                    }
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { tot[m] += acc[m] * gscale; acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f}; }
             }
         }
+    }
+    if constexpr (F16) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = tot[m];
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1079,17 +1225,23 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
 }
 
 // floats of wt_ws for NS pieces: NS operand-order bf16 images of (Cc * 4) groups x 14 tap pairs x 64 lanes x 16 bytes
-extern "C" int vx_expand_split_ws_floats(int Cc, int ns) { return (Cc <= 0 || ns < 2 || ns > 3) ? -1 : Cc * 4 * 14 * 64 * 4 * ns; }
+// (ns = 22: two scaled fp16 pieces + one float for the weight tensor's scale exponent)
+extern "C" int vx_expand_split_ws_floats(int Cc, int ns) { return (Cc <= 0 || !(ns == 2 || ns == 3 || ns == 22)) ? -1 : Cc * 4 * 14 * 64 * 4 * (ns == 22 ? 2 : ns) + (ns == 22 ? 4 : 0); }
 
 // returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernels), 0 on success.  ns = 2 (3 products) or 3 (6 products: fp32-exact products)
 extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream) {
-    VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_fwd_mfma_split: bad args");
+    VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3 || ns == 22), "vx_expand_fwd_mfma_split: bad args");
     if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
-    const size_t shm = (size_t)ns * 2 * 648 * sizeof(uint4);
-    if (ns == 2) {
+    const size_t shm = (size_t)(ns == 22 ? 2 : ns) * 2 * 648 * sizeof(uint4) + (ns == 22 ? 32 : 0);
+    if (ns == 22) {
+        float* ew = wt_ws + (long)groups * 14 * 64 * 4 * 2;
+        vx_expand_wmax_k<<<1, 1024, 0, st>>>(w, (long)groups * 16 * 16 * 27, ew);
+        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 0);
+        vx_expand_fwd_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W, ew);
+    } else if (ns == 2) {
         vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
         vx_expand_fwd_split_k<2><<<dim3((unsigned)nblk), 256, shm, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
     } else {
@@ -1101,13 +1253,18 @@ extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const fl
 }
 extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
                                              void* stream) {
-    VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3), "vx_expand_bwd_data_mfma_split: bad args");
+    VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3 || ns == 22), "vx_expand_bwd_data_mfma_split: bad args");
     if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
-    const size_t shm = (size_t)ns * 144 * 18 * sizeof(uint2);
-    if (ns == 2) {
+    const size_t shm = (size_t)(ns == 22 ? 2 : ns) * 144 * 18 * sizeof(uint2) + (ns == 22 ? 32 : 0);
+    if (ns == 22) {
+        float* ew = wt_ws + (long)groups * 14 * 64 * 4 * 2;
+        vx_expand_wmax_k<<<1, 1024, 0, st>>>(w, (long)groups * 16 * 16 * 27, ew);
+        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 1);
+        vx_expand_bwd_data_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate, ew);
+    } else if (ns == 2) {
         vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
         vx_expand_bwd_data_split_k<2><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
     } else {

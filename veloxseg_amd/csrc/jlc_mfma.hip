@@ -908,6 +908,54 @@ __device__ __forceinline__ void wg_commit(const float4 (&pf)[WG_NPF], const WgDe
     }
 }
 
+// fp16 two-piece staging of one step (pieces knob = 22).  Every plane gets its OWN power-of-two scale (largest magnitude of the staged tile -> [2^14, 2^15)); the
+// exponents live in LDS: etab[0] = this step's x plane, etab[1 + slot] = the g plane in ring slot `slot` (valid for the five / three / one steps the plane stays).
+// A (g plane, x plane) pair therefore arrives at the accumulators with exponent etab[0] + etab[1 + slot]; the MFMA phase keeps, per accumulator unit, the exponent
+// its tiles currently carry and multiplies them by the (exact) power of two when a new pair differs.  Needs one more barrier per step than the bf16 staging.
+__device__ __forceinline__ void wg_commit16(const float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], unsigned char* lds, const VxWgT& p, int dx, int dg0, int dg1,
+                                            float* __restrict__ mtab, int* __restrict__ etab) {
+    const int l5 = ((dx + 2 + 10) % 5) * p.GP, l3 = (5 + (dx + 1 + 9) % 3) * p.GP, l1 = 8 * p.GP;
+    const int s5 = (dx + 2 + 10) % 5, s3 = 5 + (dx + 1 + 9) % 3;
+    float mk[4] = {0.f, 0.f, 0.f, 0.f};
+    bool on_[WG_NPF];
+#pragma unroll
+    for (int u = 0; u < WG_NPF; ++u) {
+        const int k = ds[u].f & 3;
+        const int pl = dx + wg_dk(k);
+        on_[u] = (ds[u].f & 4) && pl >= (k == 0 ? 0 : dg0) && pl < (k == 0 ? p.D : dg1);
+        const float m_ = on_[u] ? fmaxf(fmaxf(fabsf(pf[u].x), fabsf(pf[u].y)), fmaxf(fabsf(pf[u].z), fabsf(pf[u].w))) : 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) mk[kk] = fmaxf(mk[kk], k == kk ? m_ : 0.0f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) mk[kk] = vx_wave_max(mk[kk]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) mtab[(threadIdx.x >> 6) * 4 + kk] = mk[kk];
+    }
+    __syncthreads();
+    int ek[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ek[kk] = tz_exp16(fmaxf(fmaxf(mtab[kk], mtab[4 + kk]), fmaxf(mtab[8 + kk], mtab[12 + kk])));
+    if (threadIdx.x == 0) {
+        etab[0] = ek[0];
+        etab[1 + s5] = ek[1]; etab[1 + s3] = ek[2]; etab[1 + 8] = ek[3];       // (planes that are not staged this step have no items: their slots are not read before a later staging)
+    }
+#pragma unroll
+    for (int u = 0; u < WG_NPF; ++u) {
+        if (!on_[u]) continue;
+        const int k = ds[u].f & 3;
+        const int lo = k == 0 ? 0 : k == 1 ? l5 : k == 2 ? l3 : l1;
+        const float sc = ldexpf(1.0f, k == 0 ? ek[0] : k == 1 ? ek[1] : k == 2 ? ek[2] : ek[3]);
+        const float a0 = pf[u].x * sc, a1 = pf[u].y * sc, a2 = pf[u].z * sc, a3 = pf[u].w * sc;
+        const uint32_t lo0 = tz_pack16(a0, a1), hi0 = tz_pack16(a2, a3);
+        const uint32_t lo1 = tz_pack16(a0 - tz_lo16(lo0), a1 - tz_hi16(lo0)), hi1 = tz_pack16(a2 - tz_lo16(hi0), a3 - tz_hi16(hi0));
+        const long e0 = (long)ds[u].l + lo;
+        *reinterpret_cast<uint2*>(lds + 2 * e0) = make_uint2(lo0, hi0);
+        *reinterpret_cast<uint2*>(lds + 2 * ((long)p.SP + e0)) = make_uint2(lo1, hi1);
+    }
+}
+
 template <int NS>
 __device__ __forceinline__ void wg_read_a(uint4 (&a)[NS], const unsigned char* lds, const VxWgT& p, int slot, int arow_base, int local, int th_lane) {
     // lane (m = (co, j), q): row local + j of the g block, redirected to the zero row when it is outside the tile
@@ -919,7 +967,7 @@ __device__ __forceinline__ void wg_read_a(uint4 (&a)[NS], const unsigned char* l
         a[s] = *reinterpret_cast<const uint4*>(lds + 2 * ((long)s * p.SP + p.XP + (long)slot * p.GP + (long)arow_base + (long)rr * p.WS));
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void wg_mfma6(tz_f4& acc, const uint4 (&a)[NS], const uint4 (&b)[NS]) {
     constexpr int NP = NS == 3 ? 6 : NS == 2 ? 3 : 1;
     constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
@@ -927,7 +975,8 @@ __device__ __forceinline__ void wg_mfma6(tz_f4& acc, const uint4 (&a)[NS], const
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
         const int sa = NS == 3 ? PW[pr] : NS == 2 ? PW2[pr] : 0, sb = NS == 3 ? PA[pr] : NS == 2 ? PA2[pr] : 0;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[sa]), __builtin_bit_cast(tz_bf8, b[sb]), acc, 0, 0, 0);
+        if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tz_h8, a[sa]), __builtin_bit_cast(tz_h8, b[sb]), acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tz_bf8, a[sa]), __builtin_bit_cast(tz_bf8, b[sb]), acc, 0, 0, 0);
     }
 }
 
@@ -940,7 +989,7 @@ __device__ __forceinline__ uint4 wg_shift(const uint32_t (&w)[8], int o) {
 }
 
 // DBG = true: the timing-experiment build (vx_jlc_tz_set_debug); the production instance carries none of its branches
-template <int NS, bool DBG>
+template <int NS, bool DBG, bool F16 = false>
 __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
     const VxWgT& p = p_;
     const int dbg = DBG ? p_.dbg : 0;
@@ -994,9 +1043,14 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
 #pragma unroll
     for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
     wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+    // fp16 mode: maxima / exponent tables behind the piece planes; the exponent each accumulator unit currently carries (wave-uniform; 0 with zero tiles at the start)
+    float* mtab = reinterpret_cast<float*>(wg_lds + 2 * (long)NS * p.SP);
+    int* etab = reinterpret_cast<int*>(mtab + 16);
+    int ecur[5] = {0, 0, 0, 0, 0};
     for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
         __syncthreads();                 // the previous step's reads of the x buffer and of the ring slots overwritten below are done
-        if (!(dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
+        if constexpr (F16) wg_commit16(pf, ds, wg_lds, p, dx, dg0, dg1, mtab, etab);
+        else if (!(dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
         __syncthreads();
         if (dx + 1 <= dg1 + 1 && !(dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
         if (dbg & 2) continue;
@@ -1010,6 +1064,31 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
         const int pl0 = dx - kd0 + 2, pl1 = k3w ? dx - kd1 + 1 : dx - kd1 + 2;
         const bool ok0 = pl0 >= dg0 && pl0 < dg1, ok1 = pl1 >= dg0 && pl1 < dg1, okc = wave == 0 && dx >= dg0 && dx < dg1;
         const int so0 = ((pl0 + 10) % 5), so1 = k3w ? 5 + (pl1 + 9) % 3 : (pl1 + 10) % 5;
+        if constexpr (F16) {
+            // bring each accumulator slot to the exponent of this step's (g plane, x plane) pair: an exact power-of-two multiply of its tiles, once per step and only
+            // when the exponent differs from the one the tiles carry (planes of one tensor mostly share it).  ecur[0] / [1] / [4]: slot 0 / slot 1 / the K1 tile
+            const int e_x = __builtin_amdgcn_readfirstlane(etab[0]);
+            auto bring = [&](int which, int slot, int lo, int n_) {
+                const int ep = e_x + __builtin_amdgcn_readfirstlane(etab[1 + slot]);
+                if (ep == ecur[which]) return;
+                const int dd = ep - ecur[which];
+                const float f = ldexpf(1.0f, dd > 120 ? 120 : (dd < -120 ? -120 : dd));
+#pragma unroll
+                for (int t = 0; t < 20; ++t)
+                    if (t >= lo && t < lo + n_ && !(which == 1 && k3w && (t == 13 || t == 14 || t == 18 || t == 19))) acc[t] *= f;
+                ecur[which] = ep;
+            };
+            if (ok0) bring(0, so0, 0, 10);
+            if (ok1) bring(1, so1, 10, 10);
+            if (okc) {
+                const int ep = e_x + __builtin_amdgcn_readfirstlane(etab[1 + 8]);
+                if (ep != ecur[4]) {
+                    const int dd = ep - ecur[4];
+                    acc[13] *= ldexpf(1.0f, dd > 120 ? 120 : (dd < -120 ? -120 : dd));
+                    ecur[4] = ep;
+                }
+            }
+        }
         for (int xb = 0; xb < p.nXB; ++xb) {
             // the lane's 16-element window of x row 4 xb + i, every piece
             uint32_t w[NS][8];
@@ -1039,12 +1118,12 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (k >= 3 && k3) continue;
-                    if (!(dbg & 8)) wg_mfma6<NS>(acc[5 * u + k], a, sh[sl ? (k + 1) % 5 : k]);
+                    if (!(dbg & 8)) wg_mfma6<NS, F16>(acc[5 * u + k], a, sh[sl ? (k + 1) % 5 : k]);
                 }
             }
             if (okc) {
                 wg_read_a<NS>(a, wg_lds, p, 8, arow_base, 4 * xb - 2, th_lane);
-                wg_mfma6<NS>(acc[13], a, sh[2]);
+                wg_mfma6<NS, F16>(acc[13], a, sh[2]);
             }
         }
     }
@@ -1054,6 +1133,15 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
     // per lane were 13 us of this kernel), then one thread per weight sums its <= 8 entries and issues ONE global atomic.  Two rounds (wave slot 0, then slot 1):
     // [wave 4][tile 10][column n = (ci, i) 16][row m = (co, j) 16] floats = 40 KB per round, inside the dead staging area.
     float* tl = reinterpret_cast<float*>(wg_lds);
+    if constexpr (F16) {                 // the tiles back in true units
+        const float f0 = ldexpf(1.0f, -ecur[0]), f1 = ldexpf(1.0f, -ecur[1]), f13 = ldexpf(1.0f, -ecur[4]);
+#pragma unroll
+        for (int t = 0; t < 20; ++t) {
+            if (t < 10) acc[t] *= f0;
+            else if (wave < 3 && (t == 13 || t == 14 || t == 18 || t == 19)) { if (t == 13) acc[t] *= f13; }      // (K3 slots own 3 tiles per type; 13 is wave 0's K1 tile, zero elsewhere)
+            else acc[t] *= f1;
+        }
+    }
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         __syncthreads();
@@ -1134,13 +1222,15 @@ static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int
     p.DC = vx_cdiv(D, nchunks);
     p.nDc = vx_cdiv(D, p.DC);
     if ((long)p.nb * 4 * (p.TH + 4) * (p.XR / 4) + 3L * p.nb * 4 * p.TH * (p.WS / 4) > (long)WG_NPF * 256) return -1;      // one step's staging list must fit the per-thread items
-    shm = (size_t)NS * p.SP * 2;
+    shm = (size_t)NS * p.SP * 2 + 128;              // (+ the maxima / exponent tables of the fp16 mode)
     if (shm < 4 * 10 * 256 * sizeof(float)) shm = 4 * 10 * 256 * sizeof(float);      // the epilogue's tile area
     if (shm > 150 * 1024) return -1;
     return 0;
 }
 
 static long g_wg_min_v = -1;
+static int g_wg_f16 = 0;
+extern "C" int vx_jlc_wgrad_tz_set_f16(int on) { g_wg_f16 = on ? 1 : 0; return 0; }
 extern "C" int vx_jlc_wgrad_tz_set_min_voxels(long v) { g_wg_min_v = v < 0 ? 0 : v; return 0; }
 extern "C" int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W) {
     VxWgT p = {};
@@ -1155,7 +1245,13 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
     VX_REQUIRE(x && g1 && g3 && g5, "vx_jlc_wgrad_tz: null pointer");
     VxWgT p = {};
     size_t shm;
-    const int NS = g_tz_pieces == 22 ? 3 : g_tz_pieces;             // (the weight-gradient kernel has no fp16 two-piece mode: three bf16 pieces)
+    // pieces = 22 (two scaled fp16 pieces): the weight-gradient kernel has that mode too (per-plane exponents, exact accumulator rescaling), but it is 4 us SLOWER at
+    // 32^3 than three bf16 pieces (68 vs 64 us): the MFMAs are 16 of the kernel's 64 us, and the per-step maxima + the extra barrier cost more than halving them
+    // saves.  VELOXSEG_WG_TZ_F16=1 selects it (A/B, tests); default: three bf16 pieces.
+    static int wg16 = -1;
+    if (wg16 < 0) { const char* e = getenv("VELOXSEG_WG_TZ_F16"); wg16 = (e && e[0] == '1') ? 1 : 0; }
+    const bool f16 = g_tz_pieces == 22 && (wg16 == 1 || g_wg_f16 == 1);
+    const int NS = f16 ? 2 : (g_tz_pieces == 22 ? 3 : g_tz_pieces);
     VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.x = x; p.g1 = g1; p.g3 = g3; p.g5 = g5; p.dw1 = dw1; p.dw3 = dw3; p.dw5 = dw5; p.dbg = g_tz_dbg >> 4;
     const int MT = p.CG / 4;
@@ -1172,7 +1268,11 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
         if (p.dbg) vx_jlc_wg_k<ns, true><<<grid, dim3(256), shm, st>>>(p);                                                                                 \
         else vx_jlc_wg_k<ns, false><<<grid, dim3(256), shm, st>>>(p);                                                                                      \
     } while (0)
-    if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2); else WG_LAUNCH(1);
+    if (f16) {
+        static bool attr16 = false;
+        if (!attr16) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attr16 = true; }
+        vx_jlc_wg_k<2, false, true><<<grid, dim3(256), shm, st>>>(p);
+    } else if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2); else WG_LAUNCH(1);
 #undef WG_LAUNCH
     VX_LAUNCH_CHECK("vx_jlc_wgrad_tz");
     return 0;

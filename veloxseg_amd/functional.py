@@ -22,7 +22,7 @@ WGRAD_ENTRY = "vx_conv3d_bwd_weight_tiled"    # "vx_conv3d_bwd_weight" = untiled
 USE_EXPAND_MFMA = True                        # patch-expand input gradient on fp32 MFMA (False = conv_s1 VALU kernel)
 # fp32 mode of the patch-expand layers (forward + input gradient, 49 % of the training FLOPs): 3 = every fp32 operand as three bf16 pieces, six bf16 MFMAs per
 # pair (the fp32 product to 2^-27; 2.7 x fewer matrix-pipe clocks than v_mfma_f32_16x16x4_f32), 2 = two pieces / three MFMAs (~1e-5 relative), 0 = fp32 MFMA
-EXPAND_SPLIT = int(os.environ.get("VELOXSEG_EXPAND_SPLIT", "3"))
+EXPAND_SPLIT = int(os.environ.get("VELOXSEG_EXPAND_SPLIT", "22"))      # 22 = two scaled fp16 pieces (3 MFMAs per product, closer to fp64 than 3 bf16 pieces); 3 / 2 = bf16 pieces; 0 = fp32 MFMA
 USE_S1 = True                                 # register-blocked stride-1 conv kernel (False = generic kernels, for A/B tests)
 USE_IN_ROW = True                             # InstanceNorm of short rows (V <= 4096): statistics + application in one launch
 IN_ROW_MAX = 4096
