@@ -338,6 +338,13 @@ int vx_pwa_attn_bwd_nofold_mb(const float* q, const float* k, const float* v, co
                               const void* seed_ptr, unsigned long long dstream, float p_drop, const void* mbits, void* stream);
 int vx_pwa_attn_mfma_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
 int vx_pwa_attn_set_mfma(int on);
+/* One-pass backward on the 16x16x32 f16 matrix pipe (csrc/pwa_mfma.hip vx_pwa_attn_bwd1h_k; PWA.py:308-327): windows of 64 / 512 tokens (l % 64 == 0), M = 2,
+ * head widths (4, 4) and (8, 8) -- levels 1 and 2 of the 128^3 configurations.  Every operand enters as TWO fp16 pieces of the value scaled by a power of two
+ * taken from the block's own maxima (22 mantissa bits, exact rescale of the fp32 accumulators); the four piece products of S and dP share ONE MFMA (the
+ * reduction dimension is only 4 / 8 wide).  With p_drop > 0 it reads the forward's keep bits (vx_pwa_attn_mbits_useful answers 1; without them the fp32
+ * kernels run).  vx_pwa_attn_set_f16_bwd(0): A/B knob, those geometries back on the fp32 kernels; default 1 (selected when bit 1 of vx_pwa_attn_set_mfma is set). */
+int vx_pwa_attn_bwd1h_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+int vx_pwa_attn_set_f16_bwd(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss side (utils/loss.py:30-66, common_function.py:8-14, VeloxSeg.py:177-184)

@@ -726,6 +726,49 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
             close(a, b, 3e-5 * max(1.0, float(b.abs().max())), 2e-4, f"mfma (mask {on}) vs valu tensor {i}")
 
 
+@pytest.mark.parametrize("p_attn", [0.2, 0.0], ids=["dropout", "no_dropout"])
+@pytest.mark.parametrize("scale", [1.0, 300.0, 1e-4], ids=["unit", "large", "tiny"])
+@pytest.mark.parametrize("grid,big,heads,mdh,C,B", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([16, 16, 16], [4, 4, 4], 1, 4, 12, 2), ([8, 8, 8], [8, 8, 8], 2, 8, 8, 1),
+                                                    ([8, 8, 8], [4, 4, 4], 1, 4, 8, 3)],
+                         ids=["L2_512tok_c8", "L1_64tok_c4", "L2_one_window_per_head", "L1_small_grid"])
+def test_pwa_attention_f16_pipe_backward_equals_the_fp32_kernels(grid, big, heads, mdh, C, B, scale, p_attn):
+    """The one-pass attention backward on the 16x16x32 f16 matrix pipe (csrc/pwa_mfma.hip vx_pwa_attn_bwd1h_k: levels 1 / 2 of the 128^3 configurations -- windows of
+    64 / 512 tokens, two modalities, head widths 4 / 8) against the fp32-VALU kernels of the same library on the same inputs and the same dropout mask (the f16
+    kernel reads the keep bits the forward stored, the VALU kernels draw the same Philox words): dq / dk / dv and the bias-table gradient agree to fp32 summation
+    noise.  Every operand enters the MFMAs as two fp16 pieces of the value scaled by a power of two from the block's maxima: the `large` / `tiny` cases put the
+    incoming gradient (x scale) and the values (x 30 / x 0.03) far outside fp16's comfortable range -- the scaling has to bring them back."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    M = 2
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    pp = H.ctypes.addressof(plan)
+    assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == 1 and H.query("vx_pwa_attn_mbits_useful", pp, B, M, pl["c_qk"], pl["c_v"]) == 1
+    n = pl["n"]
+    vs = 30.0 if scale > 1 else (0.03 if scale < 1 else 1.0)
+    base = []
+    for m in range(M):
+        base += [rnd(B, pl["ch_qk"], *grid, seed=10 + m), rnd(B, pl["ch_qk"], *grid, seed=20 + m), rnd(B, pl["ch_v"], *grid, seed=30 + m) * vs]
+    res = {}
+    try:
+        for f16 in (1, 0):
+            H.call("vx_pwa_attn_set_f16_bwd", f16)
+            VF.manual_seed(77, d)
+            table = (rnd((2 * n[0] - 1) * (2 * n[1] - 1) * (2 * n[2] - 1), heads, seed=4, scale=0.5)).to(d).requires_grad_(True)
+            t = [b.clone().to(d).requires_grad_(True) for b in base]
+            outs = VF.pwa_core(table, plan, pl["c_qk"], pl["c_v"], t, p_attn=p_attn, site=9)
+            gouts = [rnd(*o.shape, seed=50 + i).to(d) * scale for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, gouts)
+            torch.cuda.synchronize()
+            res[f16] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
+    finally:
+        H.call("vx_pwa_attn_set_f16_bwd", 1)
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        assert torch.isfinite(a).all()
+        close(a, b, 1e-5 * float(b.abs().max()), 2e-4, f"f16 pipe vs fp32 kernels, tensor {i}")
+
+
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 1),
                                                     ([8, 8, 16], [4, 4, 8], 2, 8, 32, 3)],
                          ids=["L2_512tok", "L1_64tok", "M1", "M3_aniso"])
@@ -746,6 +789,7 @@ def test_pwa_attention_valu_backward_reads_the_forwards_keep_bits(grid, big, hea
         base += [rnd(2, pl["ch_qk"], *grid, seed=10 + m), rnd(2, pl["ch_qk"], *grid, seed=20 + m), rnd(2, pl["ch_v"], *grid, seed=30 + m)]
     res = {}
     try:
+        H.call("vx_pwa_attn_set_f16_bwd", 0)               # (levels 1 / 2 would otherwise take the f16-pipe one-pass backward)
         for bits in (1, 0):
             H.call("vx_pwa_attn_set_valu_bits", bits)
             assert H.query("vx_pwa_attn_bwd1_ok", pp, 2, M, pl["c_qk"], pl["c_v"]) == 0          # the default rule keeps these geometries on the VALU backward
@@ -760,6 +804,7 @@ def test_pwa_attention_valu_backward_reads_the_forwards_keep_bits(grid, big, hea
             res[bits] = [o.detach() for o in outs] + [x.grad for x in t] + [table.grad.clone()]
     finally:
         H.call("vx_pwa_attn_set_valu_bits", 0)
+        H.call("vx_pwa_attn_set_f16_bwd", 1)
     for i, (a, b) in enumerate(zip(res[1], res[0])):
         if i < M:
             assert torch.equal(a, b), f"output {i}: the forward must not depend on whether it stores the keep bits"

@@ -34,6 +34,31 @@ for name, levels in LEVELS.items():
         nws = H.query("vx_pwa_attn_bwd_ws_floats", pp, B, M)
         ws = torch.empty(nws, device=d)
         dq, dk, dv, dt = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv), torch.zeros_like(table)
+        # the f16-pipe one-pass kernel (levels 1 / 2 of 128^3) against the fp32 VALU kernels: time and the largest difference of dq / dk / dv / d(table)
+        if H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, cq, cv) == 1:
+            res = {}
+            for f16 in (1, 0):
+                H.call("vx_pwa_attn_set_f16_bwd", (1 + int(os.environ.get("VX_F16_QS", "0"))) if f16 else 0)      # (VX_F16_QS: A/B of the query splits per key chunk)
+                dt.zero_()
+
+                def run():
+                    H.call("vx_pwa_attn_bwd_mb", H.P(tq), H.P(tk), H.P(tv), H.P(table), H.P(Oo), H.P(lse), H.P(dO), H.P(dq), H.P(dk), H.P(dv), H.P(dt), H.P(ws), pp, B, M, cq, cv,
+                           H.P(rs, torch.int64), 5, p, H.P(mbits, torch.int16) if f16 else None, st)
+                run()
+                torch.cuda.synchronize()
+                res[f16] = [x.clone() for x in (dq, dk, dv, dt)]
+                for _ in range(3):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                res[f16].append(e0.elapsed_time(e1) / 20 * 1e3)
+            err = [float((a - b).abs().max()) / max(1e-30, float(b.abs().max())) for a, b in zip(res[1][:4], res[0][:4])]
+            print(f"      f16-pipe one-pass backward {res[1][4]:7.1f} us  vs fp32 kernels {res[0][4]:7.1f} us   max |diff| / max: dq {err[0]:.1e} dk {err[1]:.1e} dv {err[2]:.1e} dtable {err[3]:.1e}", flush=True)
+            H.call("vx_pwa_attn_set_f16_bwd", 0)
         out = []
         for mask in (11, 11.5, 5, 0):            # 11 = one pass (forced for every geometry) with the forward's mask bits, 11.5 = one pass drawing the Philox words again
             H.call("vx_pwa_attn_set_mfma", int(mask))
@@ -72,5 +97,6 @@ for name, levels in LEVELS.items():
             vb.append(e0.elapsed_time(e1) / 20 * 1e3)
         H.call("vx_pwa_attn_set_mfma", 3)
         print(f"      VALU backward with the forward's keep bits {vb[0]:7.1f} us, re-drawing {vb[1]:7.1f} us")
+        H.call("vx_pwa_attn_set_f16_bwd", 1)
         pairs = B * heads * Nt * ML * ML
         print(f"{name}^3 L{L}: l={plan.l:4d} ML={ML:5d} windows={B * heads * Nt:5d} c_qk/c_v={cq}/{cv}  pairs={pairs / 1e6:7.1f}M   one-pass {out[0]} us (Philox again: {out[1]}) | two-kernel MFMA {out[2]} us | VALU {out[3]} us", flush=True)

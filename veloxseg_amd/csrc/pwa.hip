@@ -1304,6 +1304,9 @@ int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float
 int vx_pwa_attn_mfma_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
                          float* dK, float* dV, float* dtable, float* delta, float* rep, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d,
                          void* stream);
+extern "C" int vx_pwa_attn_bwd1h_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
+int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
+                      float* dK, float* dV, float* rep, const unsigned short* mbits, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d, void* stream);
 
 // OFF by default: the VALU backward is bound by the latency of its LDS slab reads (53 % / 31 % of the wave cycles in s_waitcnt, profiles/r02_sq_wave_breakdown.txt),
 // not by its VALU work -- with the bits read back the step is unchanged (746-749 vs 748-751 patches/s): the path stays as a tested A/B variant
@@ -1320,6 +1323,7 @@ extern "C" int vx_pwa_attn_mbits_words(const VxPwaPlan* plan, int B, int M) {
 // ELEMENT (l % 4 != 0: the 4 queries of a lane do not share a counter); with aligned windows re-drawing costs the same as reading the bits back
 extern "C" int vx_pwa_attn_mbits_useful(const VxPwaPlan* plan, int B, int M, int cq, int cv) {
     if (plan == nullptr) return 0;
+    if (vx_pwa_attn_bwd1h_ok(plan, B, M, cq, cv) == 1) return 1;        // the f16-pipe backward has no Philox path: it reads the forward's bits
     if (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv) == 1) return (plan->l & 3) != 0 ? 1 : 0;
     // the fp32-VALU backward evaluates the soft-max side of a pair TWICE (dQ pass, dK/dV pass): with aligned windows both passes read the bits back
     if (vx_attn_valu_bits && (plan->l & 3) == 0 && !(vx_pwa_attn_mfma_ok(plan, B, M, cq, cv) & 2)) return 1;
@@ -1476,6 +1480,14 @@ static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, c
     const long rep_floats = (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
     const unsigned nblk = (unsigned)vx_cdiv(units, 4 / S);
     vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
+    if (vx_pwa_attn_bwd1h_ok(plan, B, M, cq, cv) && (!(p_drop > 0 && seed_ptr) || mbits != nullptr)) {      // one pass, two fp16 pieces per operand on the 16x16x32 pipe (csrc/pwa_mfma.hip)
+        const int rc = vx_pwa_attn_bwd1h(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, mbits, plan, B, M, cq, cv, d, stream);
+        if (rc) VX_FAIL(rc, "vx_pwa_attn_bwd: f16-pipe one-pass kernel could not be launched");
+        const long nt = (long)Tsz * A.heads;
+        if (fold) vx_attn_fold_k<<<dim3((unsigned)vx_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream>>>(rep, dtable, nt, VX_DTABLE_REPLICAS);
+        VX_LAUNCH_CHECK("vx_pwa_attn_bwd (one pass, f16 pipe)");
+        return 0;
+    }
     if (vx_pwa_attn_bwd1_ok(plan, B, M, cq, cv)) {             // one evaluation of the soft-max side per pair, every GEMM on MFMA (csrc/pwa_mfma.hip)
         const int rc = vx_pwa_attn_bwd1(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, mbits, plan, B, M, cq, cv, d, stream);
         if (rc) VX_FAIL(rc, "vx_pwa_attn_bwd: one-pass kernel could not be launched");

@@ -719,6 +719,409 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd1_k(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------- backward, ONE pass, 16x16x32 f16 pipe
+// The one-pass decomposition above (key-owner waves, 4 key tiles x 4 query tiles per block, both modalities folded) with every GEMM on the 16-clock
+// v_mfma_f32_16x16x32_f16 instead of the 32-clock fp32 16x16x4 form (16 fp32 MFMAs = 512 clocks per 16 x 16 score tile -> 5 f16 MFMAs = 80), and the operand
+// traffic of the fp32 form (one register move per MFMA operand) gone.  fp32 accuracy is kept by splitting every operand into TWO fp16 pieces (22 mantissa
+// bits) of the value scaled by a power of two chosen per block from the block's own maxima (exact rescale of the fp32 results):
+//   S, dP      the reduction dimension is the head width (4 / 8), an MFMA reduces over 32 slots: the four piece products hi*hi, hi*lo, lo*hi, lo*lo sit side by side
+//              in the slots (lane group G of the A operand reads the piece (G >> 1), of the B operand the piece (G & 1)) -> ONE MFMA per tile, all four products
+//   dV, dK     reduction over 32 queries (the two modalities' tiles of a step: slot 4 g + i <-> accumulator register i of tile g, so the accumulators ARE the
+//              B operand after the split); the A operand stacks the hi piece (rows 0 .. C-1) and the lo piece (rows C .. 2C-1) of dO^T / Q^T, the two row blocks
+//              are added once after the loop: 2 MFMAs (B hi, B lo) per key tile
+//   dQ         reduction over the wave's 32 keys; dS reaches the B operand transposed through a 16 x 20 LDS patch as ONE dword (hi | lo << 16) per element
+//              (4 ds_write_b32 + 1 ds_read_b128 per tile, two v_perm_b32 per register pair split the halves again); K^T hi / lo are loop-invariant registers
+// A block = 4 waves = 4 key tiles (x 2 modalities) and walks QCB chunks of 4 query tiles: per chunk the query-side operands (64 tokens x 2 modalities: Q, dO
+// as pieces, row-major for S / dP and channel-major for dK / dV) are converted ONCE into LDS (the next chunk's rows are already in flight); the scales of Q / dO
+// are per chunk, so dK / dV leave the MFMA accumulators after every chunk into fp32 totals in true units.  128^3 level 2 (32 query tiles): 2 blocks per key
+// chunk -> two float atomics per dK / dV element instead of eight with one chunk per block (the atomics were 55 of 208 us), and the key side is set up once; soft-max side: p = exp2(fma(S, c, bias2[bin] - lse2)) with log2(e) folded into the staged bias window and lse; the dropout keep bits come from
+// the forward (vx_pwa_attn_fwd_mb; 8 bytes = the 4 query rows of a lane per tile).  Geometry: l % 16 == 0, M = 2, head widths (4, 4) and (8, 8) -- the
+// 128^3 levels 1 and 2; everything else keeps the kernels above.  d(bias), dQ images, atomics across blocks: as in vx_pwa_attn_bwd1_k.
+typedef _Float16 vx_ah8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vx_ah2 __attribute__((ext_vector_type(2)));
+typedef float vx_af2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vx_au4 __attribute__((ext_vector_type(4)));
+#define VX_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vx_ah8, (a)), __builtin_bit_cast(vx_ah8, (b)), (c), 0, 0, 0)
+// (a, b) -> the packed hi pieces and the packed lo pieces (hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32)
+__device__ __forceinline__ void vx_a_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const vx_af2 v = {a, b};
+    const vx_ah2 h = __builtin_convertvector(v, vx_ah2);
+    const vx_ah2 l = __builtin_convertvector(v - __builtin_convertvector(h, vx_af2), vx_ah2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+// exponent e with max * 2^e in [2^(target-1), 2^target) (0 for max = 0 / inf / nan)
+__device__ __forceinline__ int vx_a_exp(float mx, int target) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, mx);
+    const int be = (int)((b >> 23) & 0xff);
+    if (be == 0 || be == 255) return 0;
+    int e = target - (be - 126);
+    return e > 60 ? 60 : (e < -60 ? -60 : e);
+}
+#define VX_BH_RS 40        // halfs per row of the row-major piece image (32 used + 8 zeros: 80-byte rows, conflict-free ds_read_b128 over 16 rows)
+#define VX_BH_TS 136       // halfs per row of the channel-major piece image (128 queries + 8: 272-byte rows)
+template <int CQ, int CV, bool DROP>
+__global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                           const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
+                                                           const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                           float* __restrict__ dtable_rep, VxAttnM A, float inv_keep, int atomic_dq, int QS, int QCB,
+                                                           const unsigned short* __restrict__ mbits) {
+    static_assert(CQ == CV && (CQ == 4 || CQ == 8), "head widths (4, 4) and (8, 8)");
+    constexpr int C = CQ, TS = 20, NTq = 4, nq = 64, NR = 2 * nq;              // NR: query rows of a chunk (2 modalities x 64 tokens)
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) float vx_am_lds[];
+    int* __restrict__ lin = reinterpret_cast<int*>(vx_am_lds);                  // [l]
+    float* __restrict__ bias = vx_am_lds + A.l;                                  // [Tsz] the head's bias column x log2(e)
+    float* __restrict__ gwin = bias + ((A.Tsz + 3) & ~3);                        // [4 waves][4 lane groups][256] bias-gradient windows
+    float* __restrict__ lse_s = gwin + 16 * VX_B1_WIN;                            // [NR]  lse * log2(e)
+    float* __restrict__ del_s = lse_s + NR;                                      // [NR]  delta in the units of dS
+    float* __restrict__ dqw = del_s + NR;                                        // [4 waves][NR][C]
+    uint32_t* __restrict__ trb = reinterpret_cast<uint32_t*>(dqw + 4 * NR * C);  // [4 waves][2][16 * TS]
+    _Float16* __restrict__ rq = reinterpret_cast<_Float16*>(trb + 4 * 2 * 16 * TS);      // [NR][VX_BH_RS]: Q hi | Q lo | dO hi | dO lo | 0
+    _Float16* __restrict__ tq = rq + NR * VX_BH_RS;                              // [2 (Q, dO)][16][VX_BH_TS]: rows 0..C-1 hi, C..2C-1 lo, rest 0
+    float* __restrict__ red = reinterpret_cast<float*>(tq + 2 * 16 * VX_BH_TS);  // [16] block maxima, [16..19] the waves' window offsets
+    const long win = blockIdx.y;
+    const int a = (int)((win / A.Nt) % A.heads);
+    const long wrow = win * A.ML;
+    const int qsi = blockIdx.x % QS;
+    const int kc = blockIdx.x / QS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
+    for (int t = threadIdx.x; t < A.l; t += 256) {
+        const int t2 = t % A.n[2], t1 = (t / A.n[2]) % A.n[1], t0 = t / (A.n[2] * A.n[1]);
+        lin[t] = (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
+    }
+    for (int e = threadIdx.x; e < 4 * NR * C; e += 256) dqw[e] = 0.0f;
+    for (int e = threadIdx.x; e < 16 * VX_B1_WIN; e += 256) gwin[e] = 0.0f;
+    for (int k0 = threadIdx.x; k0 < A.Tsz; k0 += 256 * 8) {           // (8 independent loads per thread in flight)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * 256; v[u] = table[(long)(k < A.Tsz ? k : 0) * A.heads + a]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * 256; if (k < A.Tsz) bias[k] = v[u] * LOG2E; }
+    }
+    {   // zero padding of the piece images (uint32 granules)
+        uint32_t* z = reinterpret_cast<uint32_t*>(rq);
+        for (int e = threadIdx.x; e < (NR * VX_BH_RS + 2 * 16 * VX_BH_TS) / 2; e += 256) z[e] = 0u;
+    }
+    // ---- this wave's keys
+    const int kt = kc * 4 + wave;                             // key tile (of both modalities)
+    const int kcol = 16 * kt + m;
+    float kmax = 0.0f, vmax = 0.0f;
+    vx_au4 kop[2], vop[2], kth, ktl;
+    {
+        float kv[2][C], vv[2][C], t8[8];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const long kr = wrow + (long)f * A.l + kcol;
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(K + kr * C + 4 * c4), v4 = *reinterpret_cast<const float4*>(Vt + kr * C + 4 * c4);
+                kv[f][4 * c4] = k4.x; kv[f][4 * c4 + 1] = k4.y; kv[f][4 * c4 + 2] = k4.z; kv[f][4 * c4 + 3] = k4.w;
+                vv[f][4 * c4] = v4.x; vv[f][4 * c4 + 1] = v4.y; vv[f][4 * c4 + 2] = v4.z; vv[f][4 * c4 + 3] = v4.w;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { kmax = fmaxf(kmax, fabsf(kv[f][c])); vmax = fmaxf(vmax, fabsf(vv[f][c])); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {       // A of dQ^T: lane (row = channel m, slots 4 f + j <-> key 4 qg + j of tile f)
+                const float t_ = K[(wrow + (long)f * A.l + 16 * kt + 4 * qg + j) * C + (m < C ? m : 0)];
+                t8[4 * f + j] = m < C ? t_ : 0.0f;
+            }
+        }
+        kmax = vx_wave_max(kmax); vmax = vx_wave_max(vmax);
+        if (lane == 0) { red[8 + wave] = kmax; red[12 + wave] = vmax; }
+        __syncthreads();
+        kmax = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+        vmax = fmaxf(fmaxf(red[12], red[13]), fmaxf(red[14], red[15]));
+        const float sk = ldexpf(1.0f, vx_a_exp(kmax, 10)), sv = ldexpf(1.0f, vx_a_exp(vmax, 5));
+        // B of S / dP: lane (key m of tile f, group G) = the piece (G & 1) of K / V  [C = 4: groups 0, 1 hold hi | lo, groups 2, 3 nothing]
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            uint32_t kh[C / 2], kl[C / 2], vh[C / 2], vl[C / 2];
+#pragma unroll
+            for (int c = 0; c < C; c += 2) {
+                vx_a_split2(kv[f][c] * sk, kv[f][c + 1] * sk, kh[c / 2], kl[c / 2]);
+                vx_a_split2(vv[f][c] * sv, vv[f][c + 1] * sv, vh[c / 2], vl[c / 2]);
+            }
+            if constexpr (C == 8) {
+                const bool lo_ = (qg & 1) != 0;
+                kop[f] = (vx_au4){lo_ ? kl[0] : kh[0], lo_ ? kl[1] : kh[1], lo_ ? kl[2] : kh[2], lo_ ? kl[3] : kh[3]};
+                vop[f] = (vx_au4){lo_ ? vl[0] : vh[0], lo_ ? vl[1] : vh[1], lo_ ? vl[2] : vh[2], lo_ ? vl[3] : vh[3]};
+            } else {
+                const bool on = qg < 2;
+                kop[f] = on ? (vx_au4){kh[0], kh[1], kl[0], kl[1]} : (vx_au4){0u, 0u, 0u, 0u};
+                vop[f] = on ? (vx_au4){vh[0], vh[1], vl[0], vl[1]} : (vx_au4){0u, 0u, 0u, 0u};
+            }
+        }
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vx_a_split2(t8[2 * p] * sk, t8[2 * p + 1] * sk, h[p], l[p]);
+        kth = (vx_au4){h[0], h[1], h[2], h[3]};
+        ktl = (vx_au4){l[0], l[1], l[2], l[3]};
+    }
+    const int ek = vx_a_exp(kmax, 10), ev = vx_a_exp(vmax, 5);
+    const float sv = ldexpf(1.0f, ev);
+    uint32_t* __restrict__ tr = trb + wave * (2 * 16 * TS);
+    float* __restrict__ dqm = dqw + wave * (NR * C);
+    float* __restrict__ gw = gwin + (wave * 4 + qg) * VX_B1_WIN;                // this lane group's window: its 16 lanes are 16 keys of ONE query -> 16 different bins
+    const int lin_k = lin[kcol];
+    int kmaxb, kmaxw;                                        // largest linear coordinate of the block's / this wave's keys
+    {
+        kmaxb = lin[min(16 * kc * 4 + lane, A.l - 1)]; kmaxw = lin_k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { kmaxb = max(kmaxb, __shfl_xor(kmaxb, o, 64)); kmaxw = max(kmaxw, __shfl_xor(kmaxw, o, 64)); }
+    }
+    // offsets (halfs) of this lane group's pieces inside a row of rq: Q for S, dO for dP  (C = 4, groups 2 / 3: the row's zero padding)
+    const int poffS = C == 8 ? ((qg >> 1) ? 8 : 0) : (qg == 0 ? 0 : (qg == 1 ? 8 : 32));
+    const int poffP = (C == 4 && qg >= 2) ? 32 : 16 + poffS;
+    float totk[2][4], totv[2][4];                             // dK / dV of this wave's keys in true units (rows still stacked hi | lo)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { totk[f][i] = 0.0f; totv[f][i] = 0.0f; }
+    const int NW16 = A.ML >> 4;
+    const unsigned short* __restrict__ mbw = DROP ? mbits + win * NW16 * A.ML : nullptr;
+    const float keepf = inv_keep;
+    float* __restrict__ dtab_dst = dtable_rep + (long)((blockIdx.x + gridDim.x * blockIdx.y) % VX_DTABLE_REPLICAS) * A.Tsz * A.heads;
+    // ---- the chunk's query rows: threads 0..127 one Q row each, threads 128..255 one dO / O row each (loaded one chunk ahead)
+    const int rr = threadIdx.x & 127;
+    const int rf = rr / nq, rloc = rr - rf * nq;
+    float xv[C], lse_r = 0.0f, del_r = 0.0f, omax = 0.0f;
+    auto load_rows = [&](int qc) {
+        const long grow = wrow + (long)rf * A.l + 64 * qc + rloc;
+        del_r = 0.0f; omax = 0.0f;
+        if (threadIdx.x < 128) {
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(Q + grow * C + 4 * c4);
+                xv[4 * c4] = q4.x; xv[4 * c4 + 1] = q4.y; xv[4 * c4 + 2] = q4.z; xv[4 * c4 + 3] = q4.w;
+            }
+        } else {
+            lse_r = LSE[grow];
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(dO + grow * C + 4 * c4), o4 = *reinterpret_cast<const float4*>(O + grow * C + 4 * c4);
+                xv[4 * c4] = g4.x; xv[4 * c4 + 1] = g4.y; xv[4 * c4 + 2] = g4.z; xv[4 * c4 + 3] = g4.w;
+                del_r = fmaf(g4.x, o4.x, fmaf(g4.y, o4.y, fmaf(g4.z, o4.z, fmaf(g4.w, o4.w, del_r))));
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
+            }
+        }
+    };
+    load_rows(qsi * QCB);
+#pragma unroll 1
+    for (int qc = qsi * QCB; qc < (qsi + 1) * QCB; ++qc) {
+        const int q_lo = 4 * qc;
+        // ---- scales of the chunk: Q to < 2^10; dO to < 2^5 and such that |delta| < C 2^10 in the units of dS = 2^(ed + ev) (|dP| < C 2^10 by the scales of dO and V)
+        float amax = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) amax = fmaxf(amax, fabsf(xv[c]));
+        amax = vx_wave_max(amax);
+        const float om = vx_wave_max(omax);
+        if (lane == 0) { red[wave] = amax; red[4 + wave] = om; }
+        __syncthreads();                                     // (also: the previous chunk's flush is complete)
+        const float qmx = fmaxf(red[0], red[1]), domx = fmaxf(red[2], red[3]), omx = fmaxf(red[6], red[7]);
+        const int eq = vx_a_exp(qmx, 10), ed = min(vx_a_exp(domx, 5), vx_a_exp(domx * omx * sv, 10));
+        const float sq = ldexpf(1.0f, eq), sd = ldexpf(1.0f, ed);
+        const float cS = A.scale * LOG2E * ldexpf(1.0f, -(eq + ek));
+        {   // piece images of the row
+            uint32_t hi[C / 2], lo[C / 2];
+            const float sc = threadIdx.x < 128 ? sq : sd;
+#pragma unroll
+            for (int c = 0; c < C; c += 2) vx_a_split2(xv[c] * sc, xv[c + 1] * sc, hi[c / 2], lo[c / 2]);
+            uint32_t* rrow = reinterpret_cast<uint32_t*>(rq + rr * VX_BH_RS) + (threadIdx.x < 128 ? 0 : 8);
+            if constexpr (C == 8) {
+                *reinterpret_cast<vx_au4*>(rrow) = (vx_au4){hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<vx_au4*>(rrow + 4) = (vx_au4){lo[0], lo[1], lo[2], lo[3]};
+            } else {            // slots of a lane group: [piece | piece] against the key side's [hi | lo]
+                *reinterpret_cast<vx_au4*>(rrow) = (vx_au4){hi[0], hi[1], hi[0], hi[1]};
+                *reinterpret_cast<vx_au4*>(rrow + 4) = (vx_au4){lo[0], lo[1], lo[0], lo[1]};
+            }
+            unsigned short* tcol = reinterpret_cast<unsigned short*>(tq + (threadIdx.x < 128 ? 0 : 16 * VX_BH_TS) + rr);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const uint32_t h = hi[c / 2], l = lo[c / 2];
+                tcol[c * VX_BH_TS] = (unsigned short)((c & 1) ? (h >> 16) : (h & 0xffffu));
+                tcol[(C + c) * VX_BH_TS] = (unsigned short)((c & 1) ? (l >> 16) : (l & 0xffffu));
+            }
+            if (threadIdx.x >= 128) { lse_s[rr] = lse_r * LOG2E; del_s[rr] = del_r * sd * sv; }
+        }
+        // bin windows of the chunk (as vx_pwa_attn_bwd1_k): raw bin = lin_q - lin_k
+        int qmin = lin[64 * qc + lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qmin = min(qmin, __shfl_xor(qmin, o, 64));
+        const int bbase = qmin - kmaxb, wbase = qmin - kmaxw;
+        if (lane == 0) reinterpret_cast<int*>(red)[16 + wave] = wbase - bbase;
+        if (qc + 1 < (qsi + 1) * QCB) load_rows(qc + 1);     // the next chunk's rows travel while this one is worked on
+        __syncthreads();
+        vx_f32x4 dk[2], dv[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) { dk[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; dv[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int mrow0 = 16 * q_lo + 4 * qg;                 // (+ g * l + 16 j): first of this lane's 4 query rows
+        uint2 mk[2][2];
+        auto load_bits = [&](int j) {
+            if constexpr (DROP) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        mk[g][f] = *reinterpret_cast<const uint2*>(mbw + (long)(f * (A.l >> 4) + kt) * A.ML + g * A.l + mrow0 + 16 * j);
+            }
+        };
+        load_bits(0);
+#pragma unroll 1
+        for (int j = 0; j < NTq; ++j) {
+            const int qt = q_lo + j;
+            const int4 lq = *reinterpret_cast<const int4*>(&lin[16 * qt + 4 * qg]);
+            const int raw[4] = {lq.x - lin_k, lq.y - lin_k, lq.z - lin_k, lq.w - lin_k};
+            float bs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bs[i] = bias[raw[i] + A.lin_cst];
+            uint2 mkc[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) mkc[g][f] = mk[g][f];
+            if (j + 1 < NTq) load_bits(j + 1);
+            float dssum[4] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t pmh[2][4], pml[2][4], dsh[2][4], dsl[2][4];          // [f][2 g + pair]: B operands of dV / dK (slots 4 g + i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const _Float16* rrow = rq + (g * nq + 16 * j + m) * VX_BH_RS;
+                const vx_au4 aS = *reinterpret_cast<const vx_au4*>(rrow + poffS), aP = *reinterpret_cast<const vx_au4*>(rrow + poffP);
+                const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[g * nq + 16 * j + 4 * qg]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&del_s[g * nq + 16 * j + 4 * qg]);
+                const float bl[4] = {bs[0] - l4.x, bs[1] - l4.y, bs[2] - l4.z, bs[3] - l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
+                vx_f32x4 sv_[2], dp[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    sv_[f] = VX_MFMA_H(aS, kop[f], ((vx_f32x4){0.f, 0.f, 0.f, 0.f}));
+                    dp[f] = VX_MFMA_H(aP, vop[f], ((vx_f32x4){0.f, 0.f, 0.f, 0.f}));
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    float pm[4], ds[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sv_[f][i], cS, bl[i]));
+                        float mkf = 1.0f;
+                        if constexpr (DROP) {
+                            const uint32_t w = (i < 2) ? mkc[g][f].x : mkc[g][f].y;
+                            mkf = ((w >> (m + 16 * (i & 1))) & 1u) ? keepf : 0.0f;
+                        }
+                        pm[i] = p * mkf;
+                        ds[i] = p * fmaf(dp[f][i], mkf, -del[i]);
+                        dssum[i] += ds[i];
+                    }
+                    vx_a_split2(pm[0], pm[1], pmh[f][2 * g], pml[f][2 * g]);
+                    vx_a_split2(pm[2], pm[3], pmh[f][2 * g + 1], pml[f][2 * g + 1]);
+                    vx_a_split2(ds[0], ds[1], dsh[f][2 * g], dsl[f][2 * g]);
+                    vx_a_split2(ds[2], ds[3], dsh[f][2 * g + 1], dsl[f][2 * g + 1]);
+                }
+                // dQ^T of query tile g: dS transposed through the wave's two patches (one per key tile), one dword = (hi | lo << 16) per element
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t h = dsh[f][2 * g + (i >> 1)], l = dsl[f][2 * g + (i >> 1)];
+                        tr[f * (16 * TS) + (4 * qg + i) * TS + m] = (i & 1) ? __builtin_amdgcn_perm(l, h, 0x07060302u) : __builtin_amdgcn_perm(l, h, 0x05040100u);
+                    }
+                __builtin_amdgcn_wave_barrier();
+                const vx_au4 r0 = *reinterpret_cast<const vx_au4*>(&tr[m * TS + 4 * qg]), r1 = *reinterpret_cast<const vx_au4*>(&tr[16 * TS + m * TS + 4 * qg]);
+                __builtin_amdgcn_wave_barrier();
+                const vx_au4 bh = {__builtin_amdgcn_perm(r0[1], r0[0], 0x05040100u), __builtin_amdgcn_perm(r0[3], r0[2], 0x05040100u),
+                                   __builtin_amdgcn_perm(r1[1], r1[0], 0x05040100u), __builtin_amdgcn_perm(r1[3], r1[2], 0x05040100u)};
+                const vx_au4 bl_ = {__builtin_amdgcn_perm(r0[1], r0[0], 0x07060302u), __builtin_amdgcn_perm(r0[3], r0[2], 0x07060302u),
+                                    __builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+                vx_f32x4 dqT = VX_MFMA_H(kth, bh, ((vx_f32x4){0.f, 0.f, 0.f, 0.f}));
+                dqT = VX_MFMA_H(ktl, bh, dqT);
+                dqT = VX_MFMA_H(kth, bl_, dqT);
+                if (4 * qg < C) {          // lane (q = m, channels 4 qg ..): this wave's dQ image  (LDS float atomics instead: 165 -> 220 us)
+                    float4* dst = reinterpret_cast<float4*>(&dqm[(g * nq + 16 * j + m) * C + 4 * qg]);
+                    float4 o4 = *dst;
+                    o4.x += dqT[0]; o4.y += dqT[1]; o4.z += dqT[2]; o4.w += dqT[3];
+                    *dst = o4;
+                }
+            }
+            // dV^T += [dO hi; dO lo]^T (P*M),  dK^T += [Q hi; Q lo]^T dS: A = channel-major pieces of the step's 32 query rows (slots 4 g + i <-> row 4 qg + i of tile g)
+            {
+                const _Float16* tcol = tq + m * VX_BH_TS + 16 * j + 4 * qg;
+                const uint2 q0 = *reinterpret_cast<const uint2*>(tcol), q1 = *reinterpret_cast<const uint2*>(tcol + nq);
+                const uint2 o0 = *reinterpret_cast<const uint2*>(tcol + 16 * VX_BH_TS), o1 = *reinterpret_cast<const uint2*>(tcol + 16 * VX_BH_TS + nq);
+                const vx_au4 aQ = {q0.x, q0.y, q1.x, q1.y}, aO = {o0.x, o0.y, o1.x, o1.y};
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    dv[f] = VX_MFMA_H(aO, ((vx_au4){pmh[f][0], pmh[f][1], pmh[f][2], pmh[f][3]}), dv[f]);
+                    dv[f] = VX_MFMA_H(aO, ((vx_au4){pml[f][0], pml[f][1], pml[f][2], pml[f][3]}), dv[f]);
+                    dk[f] = VX_MFMA_H(aQ, ((vx_au4){dsh[f][0], dsh[f][1], dsh[f][2], dsh[f][3]}), dk[f]);
+                    dk[f] = VX_MFMA_H(aQ, ((vx_au4){dsl[f][0], dsl[f][1], dsl[f][2], dsl[f][3]}), dk[f]);
+                }
+            }
+            // d(bias): plain read-add-write in the lane group's own window (one LDS round trip per step; a window shared by the wave needed four, group by group)
+            // (the bins of a lane's 4 queries overlap those of its neighbours' -> one query at a time)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gw[raw[i] - wbase] += dssum[i]; __builtin_amdgcn_wave_barrier(); }
+        }
+        // ---- the chunk's results: dK / dV into the totals (true units); the four dQ images and the bias-gradient windows leave (and are zeroed for the next chunk)
+        const float fK = A.scale * ldexpf(1.0f, -(eq + ed + ev)), fV = ldexpf(1.0f, -ed), fQ = A.scale * ldexpf(1.0f, -(ek + ed + ev)), fB = ldexpf(1.0f, -(ed + ev));
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { totk[f][i] = fmaf(dk[f][i], fK, totk[f][i]); totv[f][i] = fmaf(dv[f][i], fV, totv[f][i]); }
+        __syncthreads();
+        constexpr int img = NR * C;
+        for (int e = threadIdx.x; e < img; e += 256) {
+            const int c = e % C, r2 = e / C, f = r2 / nq, t = 16 * q_lo + (r2 - f * nq);
+            float* dst = dQ + (wrow + (long)f * A.l + t) * C + c;
+            const float v = ((dqw[e] + dqw[img + e]) + (dqw[2 * img + e] + dqw[3 * img + e])) * fQ;
+            dqw[e] = 0.0f; dqw[img + e] = 0.0f; dqw[2 * img + e] = 0.0f; dqw[3 * img + e] = 0.0f;
+            if (atomic_dq) atomicAdd(dst, v); else *dst = v;
+        }
+        {
+            const int* wb_s = reinterpret_cast<const int*>(red) + 16;
+            float gsum[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int x = threadIdx.x + 256 * u;
+                float g = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int y = x - wb_s[w];
+                    if (y >= 0 && y < VX_B1_WIN) g += (gwin[(4 * w) * VX_B1_WIN + y] + gwin[(4 * w + 1) * VX_B1_WIN + y]) + (gwin[(4 * w + 2) * VX_B1_WIN + y] + gwin[(4 * w + 3) * VX_B1_WIN + y]);
+                }
+                gsum[u] = g;
+            }
+            __syncthreads();                                 // every thread has read the windows: they can be zeroed
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int x = threadIdx.x + 256 * u;
+                const int k = bbase + x + A.lin_cst;
+                if (gsum[u] != 0.0f && k >= 0 && k < A.Tsz) atomicAdd(dtab_dst + (long)k * A.heads + a, gsum[u] * fB);
+            }
+            for (int e = threadIdx.x; e < 16 * VX_B1_WIN; e += 256) gwin[e] = 0.0f;
+        }
+    }
+    // ---- dK / dV: rows 0..C-1 (hi piece of the A operand) + rows C..2C-1 (lo piece) = lanes l and l ^ (4 C)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const long kr = wrow + (long)f * A.l + kcol;
+        float k4[4], v4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k4[i] = totk[f][i] + __shfl_xor(totk[f][i], 4 * C, 64);
+            v4[i] = totv[f][i] + __shfl_xor(totv[f][i], 4 * C, 64);
+        }
+        if (4 * qg < C) {
+            if (QS == 1) {
+                *reinterpret_cast<float4*>(dK + kr * C + 4 * qg) = make_float4(k4[0], k4[1], k4[2], k4[3]);
+                *reinterpret_cast<float4*>(dV + kr * C + 4 * qg) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { atomicAdd(dK + kr * C + 4 * qg + i, k4[i]); atomicAdd(dV + kr * C + 4 * qg + i, v4[i]); }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------- host
 static bool vx_am_fill(VxAttnM& A, const VxPwaPlan* P, int B, int M, int cq) {
     A.BH = B * P->heads; A.heads = P->heads; A.Nt = P->Ntot; A.l = P->l; A.M = M; A.ML = M * P->l;
@@ -869,5 +1272,57 @@ int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float
 #undef VX_B1W
 #undef VX_B1
     });
+    return 0;
+}
+
+// ---- one-pass backward on the f16 matrix pipe (vx_pwa_attn_bwd1h_k): 128^3 levels 1 / 2 (windows of 64 / 512 tokens, two modalities, head widths (4, 4) / (8, 8)).
+// Knob (A/B, tests): vx_pwa_attn_set_f16_bwd(0) returns those geometries to the fp32 kernels.  With dropout on the kernel needs the forward's keep bits.
+static int vx_am_f16_bwd = 1;
+static int vx_am_f16_qs = 0;            // (A/B) query splits per window and key chunk; 0 = the rule below
+extern "C" int vx_pwa_attn_set_f16_bwd(int on) { vx_am_f16_bwd = on ? 1 : 0; vx_am_f16_qs = on > 1 ? on - 1 : 0; return 0; }
+static size_t vx_b1h_shm(const VxAttnM& A, int c) {
+    return ((size_t)A.l + (size_t)((A.Tsz + 3) & ~3) + 16 * VX_B1_WIN + 2 * 128 + (size_t)4 * 128 * c + 4 * 2 * 16 * 20 + 32) * sizeof(float) + ((size_t)128 * VX_BH_RS + 2 * 16 * VX_BH_TS) * 2;
+}
+extern "C" int vx_pwa_attn_bwd1h_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
+    if (!vx_am_f16_bwd || !(vx_am_enabled & 2) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M != 2) return 0;
+    if (P->l % 64 != 0 || !((cq == 4 && cv == 4) || (cq == 8 && cv == 8))) return 0;
+    VxAttnM A;
+    vx_am_fill(A, P, B, M, cq);
+    const VxB1Geo g = vx_b1_geo(A, cq, M);
+    return (g.win && g.waves_used == 4 && g.NTq == 4 && vx_b1h_shm(A, cq) <= 80 * 1024) ? 1 : 0;
+}
+int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
+                      float* dK, float* dV, float* rep, const unsigned short* mbits, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d, void* stream) {
+    VxAttnM A;
+    vx_am_fill(A, plan, B, M, cq);
+    const VxB1Geo g = vx_b1_geo(A, cq, M);
+    const long nwin = (long)A.BH * A.Nt;
+    const int nchunk = g.NT / 4;                          // key chunks = query chunks per window (4 tiles each)
+    // query splits: as few as fill the chip (every split costs one more float atomic per dK / dV element): >= 4 blocks per CU
+    int QS = 1;
+    while (QS < nchunk && nwin * nchunk * QS < 4 * 256) QS *= 2;
+    if (vx_am_f16_qs) { QS = vx_am_f16_qs; while (nchunk % QS) --QS; }
+    const dim3 grid((unsigned)(nchunk * QS), (unsigned)nwin);
+    const int atomic_dq = nchunk > 1 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = nwin * A.ML;
+    const bool drop = d.seed_ptr != nullptr && d.p > 0.0f;
+    if (drop && mbits == nullptr) return -3;
+    if (atomic_dq && hipMemsetAsync(dQ, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess) return -2;
+    if (QS > 1 && (hipMemsetAsync(dK, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess || hipMemsetAsync(dV, 0, (size_t)rows * cv * sizeof(float), st) != hipSuccess)) return -2;
+    const float inv_keep = drop ? 1.0f / (1.0f - d.p) : 1.0f;
+    const size_t shm = vx_b1h_shm(A, cq);
+#define VX_B1H(C_, D_)                                                                                                                            \
+    {                                                                                                                                             \
+        static bool once = false;                                                                                                                 \
+        if (!once) {                                                                                                                              \
+            if (hipFuncSetAttribute((const void*)vx_pwa_attn_bwd1h_k<C_, C_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            once = true;                                                                                                                          \
+        }                                                                                                                                         \
+        vx_pwa_attn_bwd1h_k<C_, C_, D_><<<grid, dim3(256), shm, st>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, A, inv_keep, atomic_dq, QS, nchunk / QS, mbits); \
+    }
+    if (cq == 8) { if (drop) VX_B1H(8, true) else VX_B1H(8, false) }
+    else { if (drop) VX_B1H(4, true) else VX_B1H(4, false) }
+#undef VX_B1H
     return 0;
 }
