@@ -571,7 +571,7 @@ _pmc_traffic.workload = None
 
 # C-ABI entry -> regular expression of the device kernel(s) behind it in a rocprofv3 kernel summary
 DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_tz_fwd": r"vx_tz_k<.*, false>", "vx_jlc_tz_bwd": r"vx_tz_k<.*, true>", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
-                 "vx_jlc_conv_bwd": r"vx_jlc_conv_bwd_k<", "vx_pwa_attn_bwd": r"vx_pwa_attn_bwd_(both|q|kv)_k<|vx_pwa_attn_bwd1_k", "vx_pwa_attn_fwd": r"vx_pwa_attn_(mfma_)?fwd_k<",
+                 "vx_jlc_conv_bwd": r"vx_jlc_conv_bwd_k<", "vx_pwa_attn_bwd": r"vx_pwa_attn_bwd_(both|q|kv)_k<|vx_pwa_attn_bwd1h?_k", "vx_pwa_attn_fwd": r"vx_pwa_attn_(mfma_)?fwd_k<",
                  "vx_expand_fwd_mfma_split": r"vx_expand_fwd_split_k<", "vx_expand_bwd_data_mfma_split": r"vx_expand_bwd_data_split_k<", "vx_expand_wgrad_mfma_split": r"vx_expand_wgrad_split_k<",
                  "vx_mlp_fwd": r"vx_mlp_fwd_k<", "vx_mlp_bwd": r"vx_mlp_bwd_k<", "vx_seg_loss_ds_fwd": r"vx_seg_loss_ds_fwd_k<", "vx_seg_loss_ds_bwd": r"vx_seg_loss_ds_bwd_k<",
                  "vx_conv_mfma_fwd": r"vx_conv_mfma_fwd_k<", "vx_conv_mfma_bwd_data": r"vx_conv_mfma_bwd_data_k<"}
@@ -656,6 +656,18 @@ def _attn_mfma_util(name, plan, B, M, cq, cv, pairs, ms):
         on = bool(H.query("vx_pwa_attn_mfma_ok", pp, B, M, cq, cv) & 1) if fwd else bool(H.query("vx_pwa_attn_bwd1_ok", pp, B, M, cq, cv))
         lpad = (plan.l + 15) // 16 * 16
         tiles = B * plan.heads * plan.Ntot * (M * lpad // 16) ** 2
+        if not fwd and H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, cq, cv) == 1:
+            # the one-pass backward on the f16 pipe (vx_pwa_attn_bwd1h_k): per 16 x 16 score tile 1 (S) + 1 (dP) + 1 (dV: 2 per key tile and 32 queries) + 1 (dK) +
+            # 1.5 (dQ: 3 per query tile and 32 keys) v_mfma_f32_16x16x32_f16 of 16384 flop; the reduction dimension of S / dP is the head width (4 / 8) times the
+            # four piece products, the rest of the 32 slots is padding -- priced against the dense 16-bit peak
+            raw = pairs * (6.0 * cq + 4.0 * cv)
+            padded = tiles * 5.5 * 16384.0
+            sec = ms * 1e-3
+            return {"on_mfma": True, "pipe": "v_mfma_f32_16x16x32_f16, two scaled fp16 pieces per operand", "mfma_per_tile": 5.5, "tiles": tiles,
+                    "mfma_util_raw": round(raw / sec / 1e12 / BF16_PEAK_TFLOPS, 4), "mfma_util_padded": round(padded / sec / 1e12 / BF16_PEAK_TFLOPS, 4),
+                    "fp32_equivalent_util": round(raw / sec / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    "note": "utilisations against the dense 16-bit peak (2500 TFLOP/s); fp32_equivalent_util = algorithmic flops against the fp32 MFMA peak, "
+                            "comparable with the fp32 kernels' figures"}
         cvb = (cv + 15) // 16
         per_tile = (cq // 4 + 4 * cvb) if fwd else (cq // 4 + cv // 4 + 4 * cvb + 4 + 4)      # S (+ dP) k-steps, then 4 k-steps per 16-row output block of PV / dV, dK, dQ
         raw = pairs * ((2.0 * cq + 2.0 * cv) if fwd else (6.0 * cq + 4.0 * cv))
@@ -718,7 +730,8 @@ def roofline_for(name, key, ms_per_launch, model=None):
                 r["mfma"] = _attn_mfma_util(name, plan, B, M, cq, cv, pairs, ms_per_launch)
                 # (the kernels behind the entry: MFMA forward where the geometry allows it; the one-launch backward, else its two passes)
                 cands = ([[f"vx_pwa_attn_mfma_fwd_k<{cq}, {cv}>"], [f"vx_pwa_attn_fwd_k<{cq}, {cv}>"]] if name == "vx_pwa_attn_fwd" else
-                         [[f"vx_pwa_attn_bwd_both_k<{cq}, {cv}>"], [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"]])
+                         [[f"vx_pwa_attn_bwd1h_k<{cq}, {cv}, true>"], [f"vx_pwa_attn_bwd1h_k<{cq}, {cv}, false>"], [f"vx_pwa_attn_bwd_both_k<{cq}, {cv}>"],
+                          [f"vx_pwa_attn_bwd_q_k<{cq}, {cv}>", f"vx_pwa_attn_bwd_kv_k<{cq}, {cv}>"]])
                 for kn in cands:
                     r["traffic"], r["traffic_source"] = _pmc_traffic(kn, B)
                     if r["traffic"] is not None:

@@ -192,6 +192,19 @@ int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, const float
                   int B, int C, int G, int D, int H, int W, void* stream);
 int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
                   int B, int C, int G, int D, int H, int W, void* stream);
+/* The coarse levels (<= 8 voxels per axis: 8^3 / 4^3 of the 128^3 configurations, 6^3 / 3^3 of the 96^3 ones; group width 8 / 16) as channels-last implicit GEMMs on
+ * the f16 matrix pipe, two scaled fp16 pieces per operand (csrc/jlc_cl.hip; conv_blocks.py:51-58,72-75) -- the shapes the Toeplitz kernels above do not take.  Same
+ * contracts: _ok / _ntiles answers, _img_floats + _prep the per-step weight images, _fwd / _bwd drop-ins for vx_jlc_conv_fwd / vx_jlc_conv_bwd (same outputs, same
+ * `part` layout with vx_jlc_cl_ntiles rows per (b, c)).  vx_jlc_cl_set_enabled(0): A/B knob (vx_jlc_cl_ok then answers 0). */
+int vx_jlc_cl_ok(int C, int G, int D, int H, int W);
+int vx_jlc_cl_ntiles(int C, int G, int D, int H, int W);
+int vx_jlc_cl_img_floats(int C, int G);
+int vx_jlc_cl_set_enabled(int on);
+int vx_jlc_cl_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream);
+int vx_jlc_cl_fwd(const float* x, const float* img, const float* b1, const float* b3, const float* b5, float* y1, float* y3, float* y5, double* part,
+                  int B, int C, int G, int D, int H, int W, void* stream);
+int vx_jlc_cl_bwd(const float* g1, const float* g3, const float* g5, const float* img, const float* d_o, float* dx, int B, int C, int G, int D, int H, int W,
+                  void* stream);
 /* the three weight gradients of the same convolutions in ONE launch on the matrix pipe (accumulated into dw1 / dw3 / dw5 with float atomics, like every weight-gradient
  * entry; a null dw skips that tensor's store); W <= 32, W % 4 == 0, H % 4 == 0, group width 4 / 8 / 16.  Bias gradients are not computed (zero behind an InstanceNorm). */
 int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W);

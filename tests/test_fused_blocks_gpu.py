@@ -260,6 +260,71 @@ def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
         H.call("vx_jlc_tz_set_min_voxels", 1024)
 
 
+CL_CASES = [
+    # name, B, C, groups, spatial, scale of the inputs   (group widths 8 / 16, <= 8 voxels per axis; ragged last tile; values far outside fp16's range)
+    ("L3_w8_8cube", 2, 64, 8, (8, 8, 8), 1.0),
+    ("L4_w16_4cube", 2, 128, 8, (4, 4, 4), 1.0),
+    ("L3_96_6cube", 1, 64, 8, (6, 6, 6), 1.0),
+    ("L4_96_3cube", 3, 128, 8, (3, 3, 3), 1.0),
+    ("aniso", 1, 64, 8, (8, 4, 6), 1.0),
+    ("ragged_w8", 1, 32, 4, (5, 7, 3), 1.0),
+    ("large_values", 1, 64, 8, (8, 8, 8), 3.0e4),
+    ("tiny_values", 1, 128, 8, (4, 4, 4), 2.0e-6),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CL_CASES, ids=[c[0] for c in CL_CASES])
+def test_jlc_channels_last_f16_convs_vs_fp64_and_valu_kernels(case):
+    """csrc/jlc_cl.hip (the three grouped convs of conv_blocks.py:51-58 and their input gradient at the coarse levels, channels-last implicit GEMMs on the f16 matrix
+    pipe with two scaled fp16 pieces per operand) against an fp64 torch convolution and against the fp32 VALU kernels of csrc/jlc.hip through the C ABI: error within
+    3x the VALU kernels' own (fp32 summation noise), the per-wave (sum, sum of squares) partials fold to the statistics of the stored tensor, every element written."""
+    import torch.nn.functional as TF
+    from veloxseg_amd import _hip as H
+    _, B, C, G, (D, Hh, W), scale = case
+    H.LIB.load()
+    assert H.query("vx_jlc_cl_ok", C, G, D, Hh, W) == 1
+    torch.manual_seed(5)
+    Cg = C // G
+    x = torch.randn(B, C, D, Hh, W, device="cuda") * scale
+    ws = [torch.randn(C, Cg, k, k, k, device="cuda") * (1.0 / (Cg * k ** 3) ** 0.5) for k in (1, 3, 5)]
+    bs = [torch.randn(C, device="cuda") * 0.1 * scale for _ in range(3)]
+    st = torch.cuda.current_stream().cuda_stream
+    y_old, y_new = torch.empty(3, *x.shape, device="cuda"), torch.full((3, *x.shape), float("nan"), device="cuda")
+    nt_old, nt_new = H.query("vx_jlc_ntiles", B, C, G, D, Hh, W), H.query("vx_jlc_cl_ntiles", C, G, D, Hh, W)
+    p_old = torch.empty(3, B * C, nt_old, 2, device="cuda", dtype=torch.float64)
+    p_new = torch.full((3, B * C, nt_new, 2), float("nan"), device="cuda", dtype=torch.float64)
+    img = torch.empty(H.query("vx_jlc_cl_img_floats", C, G), device="cuda")
+    H.call("vx_jlc_conv_fwd", H.P(x), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_old[0].data_ptr(), y_old[1].data_ptr(), y_old[2].data_ptr(),
+           p_old.data_ptr(), B, C, G, D, Hh, W, st)
+    H.call("vx_jlc_cl_prep", H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(img), C, G, st)
+    H.call("vx_jlc_cl_fwd", H.P(x), H.P(img), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_new[0].data_ptr(), y_new[1].data_ptr(), y_new[2].data_ptr(), p_new.data_ptr(),
+           B, C, G, D, Hh, W, st)
+    g = torch.randn(3, *x.shape, device="cuda") * scale
+    g[1] *= 7.0                                   # (the three gradient tensors have scales of their own)
+    g[0] *= 0.01
+    d_o = torch.randn_like(x) * scale
+    dx_old, dx_new = torch.empty_like(x), torch.full_like(x, float("nan"))
+    H.call("vx_jlc_conv_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(d_o), H.P(dx_old), B, C, G, D, Hh, W, st)
+    H.call("vx_jlc_cl_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(img), H.P(d_o), H.P(dx_new), B, C, G, D, Hh, W, st)
+    torch.cuda.synchronize()
+    for i, k in enumerate((1, 3, 5)):
+        ref = TF.conv3d(x.double(), ws[i].double(), bs[i].double(), padding=k // 2, groups=G)
+        sc = float(ref.abs().max())
+        e_old, e_new = float((y_old[i].double() - ref).abs().max()) / sc, float((y_new[i].double() - ref).abs().max()) / sc
+        assert e_new <= max(3.0 * e_old, 2e-6), (k, e_old, e_new)
+        s_new = p_new[i].sum(1).view(B, C, 2)
+        yk = y_new[i].double()
+        assert torch.allclose(s_new[..., 0], yk.sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * sc)
+        assert torch.allclose(s_new[..., 1], (yk * yk).sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * sc * sc)
+    ref = d_o.double()
+    for i, k in enumerate((1, 3, 5)):
+        ref = ref + TF.conv_transpose3d(g[i].double(), ws[i].double(), None, padding=k // 2, groups=G)
+    sc = float(ref.abs().max())
+    e_old, e_new = float((dx_old.double() - ref).abs().max()) / sc, float((dx_new.double() - ref).abs().max()) / sc
+    assert e_new <= max(3.0 * e_old, 2e-6), (e_old, e_new)
+
+
 @pytest.mark.parametrize("pieces", [3, 22, 1])
 @pytest.mark.parametrize("case", [c for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32], ids=[c[0] for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32])
 def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, pieces):

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--levels", default="1,2,3,4")
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--cl", action="store_true", help="levels the channels-last kernels cover (<= 8 voxels per axis) run those instead of the Toeplitz kernels")
     args = ap.parse_args()
     H.LIB.load()
     H.call("vx_jlc_tz_set_pieces", args.pieces)
@@ -46,8 +47,10 @@ def main():
         C, G, S = levels[L]
         D = Hh = W = S
         ok = H.query("vx_jlc_tz_ok", C, G, D, Hh, W)
-        print(f"--- level {L}: B={B} C={C} G={G} {D}x{Hh}x{W}  tz_ok={ok}")
-        if not ok:
+        use_cl = args.cl and H.query("vx_jlc_cl_ok", C, G, D, Hh, W) == 1          # the coarse levels: channels-last kernels of csrc/jlc_cl.hip instead
+        pre = "vx_jlc_cl" if use_cl else "vx_jlc_tz"
+        print(f"--- level {L}: B={B} C={C} G={G} {D}x{Hh}x{W}  tz_ok={ok}  kernels: {pre}")
+        if not ok and not use_cl:
             continue
         torch.manual_seed(L)
         Cg = C // G
@@ -58,20 +61,20 @@ def main():
         # ---------------- forward
         y_old, y_new = torch.empty(3, *x.shape, device="cuda"), torch.empty(3, *x.shape, device="cuda")
         nt_old = H.query("vx_jlc_ntiles", B, C, G, D, Hh, W)
-        nt_new = H.query("vx_jlc_tz_ntiles", C, G, D, Hh, W)
+        nt_new = H.query(pre + "_ntiles", C, G, D, Hh, W)
         p_old = torch.empty(3, B * C, nt_old, 2, device="cuda", dtype=torch.float64)
         p_new = torch.empty(3, B * C, nt_new, 2, device="cuda", dtype=torch.float64)
-        img = torch.empty(H.query("vx_jlc_tz_img_floats", C, G), device="cuda")
+        img = torch.empty(H.query(pre + "_img_floats", C, G), device="cuda")
 
         def f_old():
             H.call("vx_jlc_conv_fwd", H.P(x), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_old[0].data_ptr(), y_old[1].data_ptr(),
                    y_old[2].data_ptr(), p_old.data_ptr(), B, C, G, D, Hh, W, st)
 
         def f_prep():
-            H.call("vx_jlc_tz_prep", H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(img), C, G, st)
+            H.call(pre + "_prep", H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(img), C, G, st)
 
         def f_new():
-            H.call("vx_jlc_tz_fwd", H.P(x), H.P(img), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_new[0].data_ptr(), y_new[1].data_ptr(), y_new[2].data_ptr(),
+            H.call(pre + "_fwd", H.P(x), H.P(img), H.P(bs[0]), H.P(bs[1]), H.P(bs[2]), y_new[0].data_ptr(), y_new[1].data_ptr(), y_new[2].data_ptr(),
                    p_new.data_ptr(), B, C, G, D, Hh, W, st)
 
         f_old(); f_prep(); f_new()
@@ -96,7 +99,10 @@ def main():
             H.call("vx_jlc_conv_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(ws[0]), H.P(ws[1]), H.P(ws[2]), H.P(d_o), H.P(dx_old), B, C, G, D, Hh, W, st)
 
         def b_new():
-            H.call("vx_jlc_tz_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(img), H.P(ws[0]), H.P(d_o), H.P(dx_new), B, C, G, D, Hh, W, st)
+            if use_cl:
+                H.call("vx_jlc_cl_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(img), H.P(d_o), H.P(dx_new), B, C, G, D, Hh, W, st)
+            else:
+                H.call("vx_jlc_tz_bwd", g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), H.P(img), H.P(ws[0]), H.P(d_o), H.P(dx_new), B, C, G, D, Hh, W, st)
 
         b_old(); b_new()
         torch.cuda.synchronize()

@@ -532,6 +532,7 @@ inline Tensor sum3(const Tensor& a, const Tensor& b, const Tensor& c, void* stre
 // state of the fused block kernels (jlc.hip + mlp.hip): what the backward pass recomputes from
 struct JLCFusedState {
     Tensor x, y, o, stats_y, stats_o;            // y: (3, B, C, D, H, W) = the three conv outputs
+    bool img_cl = false;                         // ... of csrc/jlc_cl.hip (coarse levels) instead
     Tensor img;                                  // operand images of the three weight tensors (vx_jlc_tz_prep) when the convolutions ran on jlc_mfma.hip
     Tensor w1, w3, w5, b1, b3, b5, l1w, l1b, l2w, l2b;
     int B = 0, C = 0, G = 0, D = 0, H = 0, W = 0, R = 0, nch = 0;
@@ -932,7 +933,8 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 f.B = B; f.C = C; f.G = G; f.D = D; f.H = H; f.W = W; f.R = R; f.p = p; f.site = site; f.rs = p > 0 ? sp(rs) : nullptr;
                 const long BC = (long)B * C;
                 const bool tz = F.jlc_tz && vx_jlc_tz_ok(C, G, D, H, W);
-                const int nty = tz ? vx_jlc_tz_ntiles(C, G, D, H, W) : vx_jlc_ntiles(B, C, G, D, H, W);
+                const bool cl = !tz && F.jlc_tz && vx_jlc_cl_ok(C, G, D, H, W);          // the coarse levels: channels-last implicit GEMM on the f16 pipe (csrc/jlc_cl.hip)
+                const int nty = tz ? vx_jlc_tz_ntiles(C, G, D, H, W) : cl ? vx_jlc_cl_ntiles(C, G, D, H, W) : vx_jlc_ntiles(B, C, G, D, H, W);
                 TORCH_CHECK(nty > 0, "vx_jlc_ntiles failed");
                 f.nch = vx_jlc_nchunks(BC, V);
                 auto dopt = f.x.options().dtype(at::kDouble);
@@ -944,6 +946,11 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                     f.img = at::empty({(long)vx_jlc_tz_img_floats(C, G)}, f.x.options());
                     VX(vx_jlc_tz_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
                     VX(vx_jlc_tz_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
+                } else if (cl) {
+                    f.img = at::empty({(long)vx_jlc_cl_img_floats(C, G)}, f.x.options());
+                    f.img_cl = true;
+                    VX(vx_jlc_cl_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
+                    VX(vx_jlc_cl_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 } else
                 VX(vx_jlc_conv_fwd, fp(f.x), fp(f.w1), fp(f.w3), fp(f.w5), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 f.stats_y = at::empty({3, BC, 2}, f.x.options());
@@ -1017,7 +1024,8 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             Tensor dx;
             if (need_x) {
                 dx = dn;                                      // dn is dead after vx_jlc_mid_bwd: reuse its storage
-                if (f.img.defined()) VX(vx_jlc_tz_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                if (f.img.defined() && f.img_cl) VX(vx_jlc_cl_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                else if (f.img.defined()) VX(vx_jlc_tz_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
                 else
                 VX(vx_jlc_conv_bwd, gp, gp + n1, gp + 2 * n1, fp(f.w1), fp(f.w3), fp(f.w5), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
             }
