@@ -358,14 +358,17 @@ def main():
                else f"training patches/s ({args.workload})",
                "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions (fp32 accumulate, fp32 storage, fp32 everywhere else)",
+               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions of the 32^3 / 16^3 levels (fp32 accumulate, fp32 storage, fp32-level arithmetic everywhere else)",
                "data": "synthetic (randn volumes, rand>0.97 labels, random-init weights, seed 12345)",
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "arithmetic": ("fp32 storage, fp32 accumulation everywhere; the patch-expand layers form every fp32 product from %d bf16 pieces per operand on the "
-                                         "bf16 matrix pipe (same error against fp64 as the fp32 MFMA kernels: profiles/r03_expand_split_probe.txt), every other kernel "
-                                         "computes in fp32" % _expand_split()) if args.dtype == "f32" and _expand_split() else "fp32",
+                          "arithmetic": ("fp32 storage, fp32 accumulation everywhere.  The kernels that sit on the matrix pipe form every fp32 product from 16-bit pieces of "
+                                         "the operands with fp32-level results (errors against fp64 at the level of the fp32 kernels: tests/test_hip_ops_gpu.py, "
+                                         "tests/test_fused_blocks_gpu.py): patch-expand forward / input gradient, JLC grouped convolutions and the attention backward at the "
+                                         "64- / 512-token windows from two fp16 pieces of the operand scaled by a power of two (22 mantissa bits, exact rescale); the JLC and "
+                                         "patch-expand weight gradients from three bf16 pieces.  Every other kernel computes in fp32 (patch-expand pieces knob: %d)"
+                                         % _expand_split()) if args.dtype == "f32" and _expand_split() else "fp32",
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None),
                           "lane_on_caller_queue": (H.query("vx_tape_lane_on_caller_queue") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     if rank == 0 and comm is not None:
@@ -570,7 +573,7 @@ _pmc_traffic.workload = None
 
 
 # C-ABI entry -> regular expression of the device kernel(s) behind it in a rocprofv3 kernel summary
-DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_tz_fwd": r"vx_tz_k<.*, false>", "vx_jlc_tz_bwd": r"vx_tz_k<.*, true>", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
+DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_cl_fwd": r"vx_jlc_cl_fwd_k<", "vx_jlc_cl_bwd": r"vx_jlc_cl_bwd_k<", "vx_jlc_tz_fwd": r"vx_tz_k<.*, false>", "vx_jlc_tz_bwd": r"vx_tz_k<.*, true>", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
                  "vx_jlc_conv_bwd": r"vx_jlc_conv_bwd_k<", "vx_pwa_attn_bwd": r"vx_pwa_attn_bwd_(both|q|kv)_k<|vx_pwa_attn_bwd1h?_k", "vx_pwa_attn_fwd": r"vx_pwa_attn_(mfma_)?fwd_k<",
                  "vx_expand_fwd_mfma_split": r"vx_expand_fwd_split_k<", "vx_expand_bwd_data_mfma_split": r"vx_expand_bwd_data_split_k<", "vx_expand_wgrad_mfma_split": r"vx_expand_wgrad_split_k<",
                  "vx_mlp_fwd": r"vx_mlp_fwd_k<", "vx_mlp_bwd": r"vx_mlp_bwd_k<", "vx_seg_loss_ds_fwd": r"vx_seg_loss_ds_fwd_k<", "vx_seg_loss_ds_bwd": r"vx_seg_loss_ds_bwd_k<",
@@ -710,9 +713,12 @@ def roofline_for(name, key, ms_per_launch, model=None):
             B, Cc, D, H, W = k[-7:-2] if name == "vx_expand_bwd_data_mfma_split" else k[-6:-1]
             v = B * D * H * W
             flops, bytes_ = 2.0 * v * 64 * Cc * 16 * 27, 4.0 * (v * (16 + 64 * Cc) + 64 * Cc * 16 * 27)
+            if ns == 22 and name == "vx_expand_wgrad_mfma_split":
+                ns = 3                                 # (the weight gradient keeps three bf16 pieces under the fp16 mode of the forward / input gradient)
             r["split"] = {"pieces": ns, "bf16_mfma_per_pair": 6 if ns == 3 else 3, "peak_tflops": round(BF16_PEAK_TFLOPS / (6 if ns == 3 else 3), 1)}
-            kn = {"vx_expand_fwd_mfma_split": f"vx_expand_fwd_split_k<{ns}>", "vx_expand_bwd_data_mfma_split": f"vx_expand_bwd_data_split_k<{ns}>",
-                  "vx_expand_wgrad_mfma_split": f"vx_expand_wgrad_split_k<{ns}>"}[name]
+            targ = "2, true" if ns == 22 else (f"{ns}, false" if name != "vx_expand_wgrad_mfma_split" else f"{ns}")      # (kernel template arguments: pieces[, fp16 mode])
+            kn = {"vx_expand_fwd_mfma_split": f"vx_expand_fwd_split_k<{targ}>", "vx_expand_bwd_data_mfma_split": f"vx_expand_bwd_data_split_k<{targ}>",
+                  "vx_expand_wgrad_mfma_split": f"vx_expand_wgrad_split_k<{targ}>"}[name]
             r["traffic"], src = _pmc_traffic_by_grid(kn, B, "max" if Cc >= 2 else "min")
             if src:
                 r["traffic_source"] = src
@@ -745,23 +751,29 @@ def roofline_for(name, key, ms_per_launch, model=None):
             r["traffic"], src = _pmc_traffic_by_grid("vx_jlc_conv_fwd_k<4>" if name == "vx_jlc_conv_fwd" else "vx_jlc_conv_bwd_k<4>", B, "max" if D * H * W >= 16384 else "min")
             if src:
                 r["traffic_source"] = src
-        elif name in ("vx_jlc_tz_fwd", "vx_jlc_tz_bwd", "vx_jlc_wgrad_tz"):
+        elif name in ("vx_jlc_tz_fwd", "vx_jlc_tz_bwd", "vx_jlc_wgrad_tz", "vx_jlc_cl_fwd", "vx_jlc_cl_bwd"):
             # the same three grouped convolutions (forward / input gradient / the three weight gradients in one launch) as Toeplitz GEMMs on the bf16 matrix pipe
             # with fp32-exact products (csrc/jlc_mfma.hip): algorithmic flops = the layer's fp32 flops, ceiling = dense bf16 peak / 6 piece products
             B, C, G, D, H, W = k[:6]
             v = B * D * H * W
             flops = 2.0 * v * C * (C // G) * (1 + 27 + 125)
             # forward: x read, y1 / y3 / y5 written; input gradient: g1 / g3 / g5 and d_o read, dx written; weight gradients: x and g1 / g3 / g5 read
-            bytes_ = 4.0 * (v * C * (5 if name == "vx_jlc_tz_bwd" else 4) + C * (C // G) * 153)
+            bytes_ = 4.0 * (v * C * (5 if name in ("vx_jlc_tz_bwd", "vx_jlc_cl_bwd") else 4) + C * (C // G) * 153)
             ns = 3
             try:
                 from veloxseg_amd import _hip as _H
                 ns = int(_H.query("vx_jlc_tz_pieces"))
             except Exception:
                 pass
-            npair = {3: 6, 2: 3, 1: 1}[ns]
-            r["split"] = {"pieces": ns, "bf16_mfma_per_pair": npair, "peak_tflops": round(BF16_PEAK_TFLOPS / npair, 1),
-                          "mfma_fill": "62.5 % of the multipliers of a k = 5 issue carry a product (37.5 % at k = 3): Toeplitz band 5 of 8"}
+            if name.startswith("vx_jlc_cl_"):
+                ns = 22                                # csrc/jlc_cl.hip: always two scaled fp16 pieces
+            elif name == "vx_jlc_wgrad_tz" and ns == 22:
+                ns = 3                                 # (under the fp16 mode of the convolutions the weight gradients keep three bf16 pieces: DESIGN.md section 9)
+            npair = {3: 6, 2: 3, 1: 1, 22: 3}[ns]
+            r["split"] = {"pieces": ns, "mfma_per_pair": npair, "peak_tflops": round(BF16_PEAK_TFLOPS / npair, 1),
+                          "mfma_fill": ("channels-last implicit GEMM: every multiplier of an issue carries a product at group width 16, half of the rows at group width 8"
+                                        if name.startswith("vx_jlc_cl_") else
+                                        "62.5 % of the multipliers of a k = 5 issue carry a product (37.5 % at k = 3): Toeplitz band 5 of 8")}
         elif name in ("vx_mlp_fwd", "vx_mlp_bwd"):
             ints = [int(a) for a in k]
             B, C, R, V = ints[2:6] if name == "vx_mlp_fwd" else ints[1:5]      # (norm, nparts, B, C, R, V, ...) / (norm, B, C, R, V, ...)
@@ -797,8 +809,8 @@ def roofline_for(name, key, ms_per_launch, model=None):
         ach = flops / (ms_per_launch * 1e-3) / 1e12
         pk = r["split"]["peak_tflops"]
         r.update({"bound": "mfma", "achieved": round(ach, 3), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_PEAK_TFLOPS, 4),
-                  "note": "fp32-exact products from bf16 pieces: peak = dense bf16 MFMA peak (%.0f TFLOP/s, MI355X_MICROARCH.md) / %d piece products per pair; "
-                          "achieved = the layer's fp32 flops / time" % (BF16_PEAK_TFLOPS, r["split"]["bf16_mfma_per_pair"])})
+                  "note": "fp32-accurate products from 16-bit pieces (bf16 x 3 / x 2, or two scaled fp16 pieces): peak = dense 16-bit MFMA peak (%.0f TFLOP/s, MI355X_MICROARCH.md) / %d piece products per pair; "
+                          "achieved = the layer's fp32 flops / time" % (BF16_PEAK_TFLOPS, r["split"].get("bf16_mfma_per_pair", r["split"].get("mfma_per_pair")))})
     elif flops / bytes_ > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
         ach = flops / (ms_per_launch * 1e-3) / 1e12
         r.update({"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),

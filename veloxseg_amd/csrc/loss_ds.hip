@@ -9,6 +9,7 @@
 //                                   of their coarse column), along H into per-wave LDS accumulators of the block's Z slice; a small second kernel
 //                                   (vx_seg_loss_ds_adj_z) finishes the adjoint along D for all heads.  2 launches instead of 10.
 #include "vx_common.h"
+#include <stdlib.h>
 #include "../../include/veloxseg_hip.h"
 
 __device__ __forceinline__ int vx_lab(const void* lab, int kind, long i) {
@@ -204,13 +205,13 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_k(VxDs P, const void* 
                     for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
                     float e[C], se = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) { e[c] = expf(z[c][j] - mx); se += e[c]; }
-                    const float inv = 1.0f / se;
+                    for (int c = 0; c < C; ++c) { e[c] = __expf(z[c][j] - mx); se += e[c]; }      // (v_exp_f32 / v_rcp_f32 / v_log_f32: 1 ulp; the library calls were half of the kernel's issue slots)
+                    const float inv = __frcp_rn(se);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         const float pc = e[c] * inv;
                         S[h][1 + C + c] += pc;
-                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + logf(se)) - z[c][j]; }
+                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + __logf(se)) - z[c][j]; }
                     }
                 }
             }
@@ -250,7 +251,8 @@ template <int C>
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* __restrict__ lab, int lab_kind, const float* __restrict__ coef, int coef_stride,
                                                             const float* __restrict__ gout, int nacc) {
     extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
-    const int b = blockIdx.y, Z = blockIdx.x;
+    const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
+    const int y_lo = (int)((long)P.H * part / P.nsplit), y_hi = (int)((long)P.H * (part + 1) / P.nsplit);      // this block's rows of the slice
     const int W4 = P.W >> 2, RPW = 64 / W4, nlow = P.nh - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long V = (long)P.D * P.H * P.W;
@@ -294,9 +296,9 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     int aoff[3];                                                                                // offsets of the heads inside accw
     { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += C * P.ld[hh][1] * P.ld[hh][2]; } }
     const int rsl = lane / W4, X0 = (lane % W4) * 4;                                            // row slot of this lane, first voxel
-    for (int Y0 = wave * RPW; Y0 < P.H; Y0 += 4 * RPW) {
+    for (int Y0 = y_lo + wave * RPW; Y0 < y_hi; Y0 += 4 * RPW) {
         const int Y = Y0 + rsl;
-        const bool rowok = rsl < RPW && Y < P.H;
+        const bool rowok = rsl < RPW && Y < y_hi;
         if (rowok) {
             int y[4];
             vx_lab4(lab, lab_kind, (long)b * V + ((long)Z * P.H + Y) * P.W + X0, y);
@@ -323,8 +325,8 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                     for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
                     float se = 0.0f, dot = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) { z[c][j] = expf(z[c][j] - mx); se += z[c][j]; }
-                    const float inv = 1.0f / se;
+                    for (int c = 0; c < C; ++c) { z[c][j] = __expf(z[c][j] - mx); se += z[c][j]; }
+                    const float inv = __frcp_rn(se);
 #pragma unroll
                     for (int c = 0; c < C; ++c) { z[c][j] *= inv; dot = fmaf(z[c][j], (c == y[j] ? al[c] : 0.0f) + be[c], dot); }
 #pragma unroll
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                 const float* __restrict__ wt = wtab + toff[hh] + xl * nb;
                 for (int r = 0; r < RPW; ++r) {
                     const int Yr = Y0 + r;
-                    if (Yr >= P.H) break;
+                    if (Yr >= y_hi) break;
                     const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * C + c) * P.W;
                     float s = 0.0f;
 #pragma unroll 4
@@ -386,13 +388,13 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
         for (int e = threadIdx.x; e < n; e += 256) {
             const int c = e / (hl * wl), r = e - c * hl * wl;
             const float s = (vx_ds_lds[aoff[hh] + e] + vx_ds_lds[nacc + aoff[hh] + e]) + (vx_ds_lds[2 * nacc + aoff[hh] + e] + vx_ds_lds[3 * nacc + aoff[hh] + e]);
-            P.t2[hh][(((long)b * C + c) * P.D + Z) * hl * wl + r] = s;
+            P.t2[hh][((((long)b * C + c) * P.D + Z) * P.nsplit + part) * hl * wl + r] = s;
         }
     }
 }
 
 // adjoint along D for all heads: dlow_h[b, c, z, y, x] = sum_Z A[Z][z] t2_h[b, c, Z, y, x].  One thread per output element.
-struct VxDsZ { const float* t2[3]; float* out[3]; int ld[3][3]; int nlow, BC, D; long n[3]; };
+struct VxDsZ { const float* t2[3]; float* out[3]; int ld[3][3]; int nlow, BC, D, nsplit; long n[3]; };
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
     long e = (long)blockIdx.x * 256 + threadIdx.x;
     int hh = 0;
@@ -407,13 +409,15 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
         lo = (int)ceilf(((float)z - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
         hi = (int)floorf(((float)z + 1.0f) / ratio) + 1; if (hi > P.D - 1) hi = P.D - 1;
     }
-    const float* __restrict__ src = P.t2[hh] + bc * P.D * hw + r;
+    const float* __restrict__ src = P.t2[hh] + bc * P.D * P.nsplit * hw + r;
     float s = 0.0f;
     for (int Z = lo; Z <= hi; ++Z) {
         int i0, i1; float lam;
         vx_ds_coord(Z, d, P.D, i0, i1, lam);
         const float wgt = (i0 == z ? 1.0f - lam : 0.0f) + (i1 == z ? lam : 0.0f);
-        s = fmaf(wgt, src[(long)Z * hw], s);
+        float t = 0.0f;
+        for (int q = 0; q < P.nsplit; ++q) t += src[((long)Z * P.nsplit + q) * hw];          // the slice's row parts (one block each)
+        s = fmaf(wgt, t, s);
     }
     P.out[hh][e] = s;
 }
@@ -471,10 +475,11 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     return 0;
 }
 
-// workspace (floats) of vx_seg_loss_ds_bwd: the (B, C, D, h, w) partial gradients of heads 1..
+// workspace (floats) of vx_seg_loss_ds_bwd: the (B, C, D x row parts, h, w) partial gradients of heads 1.. (sized for the largest split)
+#define VX_DS_MAX_SPLIT 8
 extern "C" int vx_seg_loss_ds_ws_floats(const int* low_dims, int nh, int B, int C, int D) {
     long n = 0;
-    for (int hh = 0; hh < nh - 1; ++hh) n += (long)B * C * D * low_dims[3 * hh + 1] * low_dims[3 * hh + 2];
+    for (int hh = 0; hh < nh - 1; ++hh) n += (long)B * C * D * VX_DS_MAX_SPLIT * low_dims[3 * hh + 1] * low_dims[3 * hh + 2];
     VX_REQUIRE(n < 0x7fffffffL, "vx_seg_loss_ds_ws_floats: workspace too large");
     return (int)n;
 }
@@ -497,11 +502,16 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
         for (int k = 0; k < 3; ++k) Zp.ld[hh][k] = P.ld[hh][k];
         Zp.n[hh] = (long)B * C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2];
         total += Zp.n[hh];
-        off += (long)B * C * D * P.ld[hh][1] * P.ld[hh][2];
+        off += (long)B * C * D * VX_DS_MAX_SPLIT * P.ld[hh][1] * P.ld[hh][2];
         nacc += C * P.ld[hh][1] * P.ld[hh][2];
     }
-    Zp.nlow = nh - 1; Zp.BC = B * C; Zp.D = D;
     const int RPW = 64 / (W >> 2);
+    // blocks per Z slice (row parts): a block is one long serial program per wave (soft-max side, then the W / H adjoints through LDS) -- with one block per slice the
+    // 128^3 x 4 patch is 512 blocks = 2 waves per SIMD and the kernel waits on its LDS round trips (198 us); every part keeps >= 2 steps of 4 waves x RPW rows
+    P.nsplit = 1;
+    // (measured, 128^3 x 4: 1 / 4 parts = 181 / 158 us, but the D adjoint behind it then reads 4 x the partial sums: 20 -> 57 us -- the default stays at one part)
+    if (const char* e = getenv("VELOXSEG_DS_BWD_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= VX_DS_MAX_SPLIT && H / v >= 1) P.nsplit = v; }
+    Zp.nlow = nh - 1; Zp.BC = B * C; Zp.D = D; Zp.nsplit = P.nsplit;
     size_t ntab = 0;
     for (int hh = 0; hh < nh - 1; ++hh) {
         const int wl = P.ld[hh][2];
@@ -514,7 +524,7 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
     const size_t shm = shm_base + (P.stage ? vx_ds_slice_floats(P, C) * sizeof(float) : 0);
     VX_REQUIRE(shm <= 150 * 1024, "vx_seg_loss_ds_bwd: the low-resolution grids do not fit LDS (%zu bytes)", shm);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(D, B), blk(256);
+    const dim3 grid(D * P.nsplit, B), blk(256);
 #define VX_DS_BWD(CC)                                                                                                                 \
     {                                                                                                                                 \
         static size_t cap = 64 * 1024;                                                                                                \
