@@ -116,14 +116,20 @@ __device__ __forceinline__ void vx_ds_stage_slice(const VxDs& P, int b, int Z, f
         lows[hh] = lds + off;
         if (hh >= P.nh - 1) continue;
         const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
-        const int n = C * hw;
+        const int n = (C == 2 ? 1 : C) * hw;
         const float* __restrict__ src = P.low[hh] + (long)b * C * d * hw;
         int a0, b0; float l0;
         vx_ds_coord(Z, d, P.D, a0, b0, l0);
         const float k0 = 1.0f - l0;
         for (int e = threadIdx.x; e < n; e += 256) {
-            const int c = e / hw, r = e - c * hw;
-            lds[off + e] = k0 * src[((long)c * d + a0) * hw + r] + l0 * src[((long)c * d + b0) * hw + r];
+            if constexpr (C == 2) {
+                // two classes: soft-max, cross-entropy and the Dice terms only see z1 - z0, and the interpolation is linear -- ONE grid (the difference) is staged
+                // and interpolated, the logits of a voxel are (0, difference); the gradients of the two classes are opposite, one of them goes through the adjoint
+                lds[off + e] = (k0 * src[((long)d + a0) * hw + e] + l0 * src[((long)d + b0) * hw + e]) - (k0 * src[(long)a0 * hw + e] + l0 * src[(long)b0 * hw + e]);
+            } else {
+                const int c = e / hw, r = e - c * hw;
+                lds[off + e] = k0 * src[((long)c * d + a0) * hw + r] + l0 * src[((long)c * d + b0) * hw + r];
+            }
         }
         off += (n + 3) & ~3;
     }
@@ -144,6 +150,16 @@ __device__ __forceinline__ void vx_ds_interp2(const VxDs& P, int hh, const float
     // time) these 16 gathers per class were FLAT loads, which are slower than ds_read and count on both wait counters
     typedef const __attribute__((address_space(3))) float* lds_cf;
     lds_cf sl3 = (lds_cf)sl;
+    if constexpr (C == 2) {          // the staged slice is the difference grid (vx_ds_stage_slice)
+        lds_cf r0 = sl3 + a1 * w;
+        lds_cf r1 = sl3 + b1 * w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float k2 = 1.0f - l2[j];
+            z[0][j] = 0.0f;
+            z[1][j] = k1 * (k2 * r0[a2[j]] + l2[j] * r0[b2[j]]) + l1 * (k2 * r1[a2[j]] + l2[j] * r1[b2[j]]);
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         lds_cf r0 = sl3 + (c * h + a1) * w;
@@ -153,6 +169,7 @@ __device__ __forceinline__ void vx_ds_interp2(const VxDs& P, int hh, const float
             const float k2 = 1.0f - l2[j];
             z[c][j] = k1 * (k2 * r0[a2[j]] + l2[j] * r0[b2[j]]) + l1 * (k2 * r1[a2[j]] + l2[j] * r1[b2[j]]);
         }
+    }
     }
 }
 
@@ -256,6 +273,8 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     const int W4 = P.W >> 2, RPW = 64 / W4, nlow = P.nh - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long V = (long)P.D * P.H * P.W;
+    // two classes with staged slices: the gradients at the up-sampled logits are opposite (g0 = -g1) -- only class 1 goes through the adjoints, class 0 is its negative
+    const int c_lo = (C == 2 && P.stage) ? 1 : 0, CA = C - c_lo;
     float* __restrict__ accw = vx_ds_lds + (long)wave * nacc;                                   // [head][c][y][x]
     float* __restrict__ gbuf = vx_ds_lds + 4L * nacc + (long)wave * (RPW * 3 * C * P.W);        // [row][head][c][X]
     // banded adjoint tables of the W axis: coarse column xl of head hh collects the fine columns lo .. lo + BW - 1 with weights wtab (zero past the band)
@@ -294,7 +313,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     __syncthreads();
     const float go = gout ? gout[0] : 1.0f;
     int aoff[3];                                                                                // offsets of the heads inside accw
-    { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += C * P.ld[hh][1] * P.ld[hh][2]; } }
+    { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += CA * P.ld[hh][1] * P.ld[hh][2]; } }
     const int rsl = lane / W4, X0 = (lane % W4) * 4;                                            // row slot of this lane, first voxel
     for (int Y0 = y_lo + wave * RPW; Y0 < y_hi; Y0 += 4 * RPW) {
         const int Y = Y0 + rsl;
@@ -338,7 +357,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (h == 0) *reinterpret_cast<float4*>(P.dl0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
-                    else *reinterpret_cast<float4*>(gbuf + (((long)rsl * 3 + (h - 1)) * C + c) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
+                    else if (c >= c_lo) *reinterpret_cast<float4*>(gbuf + (((long)rsl * 3 + (h - 1)) * CA + (c - c_lo)) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
                 }
             }
         }
@@ -349,7 +368,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
         // Owners walk the step's rows one after the other, so two rows never add into one accumulator at the same time.
         for (int hh = 0; hh < nlow; ++hh) {
             const int hl = P.ld[hh][1], wl = P.ld[hh][2];
-            const int nown = C * wl;
+            const int nown = CA * wl;
             int sp = 1;
             while (sp < 64 && nown * (sp * 2) <= 64) sp *= 2;
             const int part = lane & (sp - 1);
@@ -363,7 +382,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
                 for (int r = 0; r < RPW; ++r) {
                     const int Yr = Y0 + r;
                     if (Yr >= y_hi) break;
-                    const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * C + c) * P.W;
+                    const float* __restrict__ gr = gbuf + (((long)r * 3 + hh) * CA + c) * P.W;
                     float s = 0.0f;
 #pragma unroll 4
                     for (int k = part; k < nb; k += sp) s = fmaf(wt[k], gr[min(lo + k, P.W - 1)], s);      // independent LDS reads: the band's weights are zero past its end
@@ -384,11 +403,12 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     __syncthreads();
     // sum the 4 waves' accumulators and store this Z slice of the (B, C, D, h, w) partial gradients
     for (int hh = 0; hh < nlow; ++hh) {
-        const int hl = P.ld[hh][1], wl = P.ld[hh][2], n = C * hl * wl;
+        const int hl = P.ld[hh][1], wl = P.ld[hh][2], n = CA * hl * wl;
         for (int e = threadIdx.x; e < n; e += 256) {
             const int c = e / (hl * wl), r = e - c * hl * wl;
             const float s = (vx_ds_lds[aoff[hh] + e] + vx_ds_lds[nacc + aoff[hh] + e]) + (vx_ds_lds[2 * nacc + aoff[hh] + e] + vx_ds_lds[3 * nacc + aoff[hh] + e]);
-            P.t2[hh][((((long)b * C + c) * P.D + Z) * P.nsplit + part) * hl * wl + r] = s;
+            P.t2[hh][((((long)b * C + c + c_lo) * P.D + Z) * P.nsplit + part) * hl * wl + r] = s;
+            if (c_lo) P.t2[hh][((((long)b * C) * P.D + Z) * P.nsplit + part) * hl * wl + r] = -s;
         }
     }
 }
@@ -503,7 +523,7 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
         Zp.n[hh] = (long)B * C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2];
         total += Zp.n[hh];
         off += (long)B * C * D * VX_DS_MAX_SPLIT * P.ld[hh][1] * P.ld[hh][2];
-        nacc += C * P.ld[hh][1] * P.ld[hh][2];
+        nacc += C * P.ld[hh][1] * P.ld[hh][2];          // (two classes + staged slices: the kernel uses half of it)
     }
     const int RPW = 64 / (W >> 2);
     // blocks per Z slice (row parts): a block is one long serial program per wave (soft-max side, then the W / H adjoints through LDS) -- with one block per slice the
