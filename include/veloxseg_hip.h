@@ -99,6 +99,7 @@ int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt
  * axis for the weight gradient.  w: (Cout, Cin).  Same concat / accumulate conventions as vx_conv3d_*. */
 int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
                    int B, int Cin, int Cout, long V, void* stream);
+int vx_pw_conv_set_v4(int on);   /* A/B knob (default 1): large volumes (V >= 16384, Cout % 16 == 0, Cin <= 64) take the one-wave kernel with 16-byte accesses and the weight tile in LDS */
 int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int C1,
                         int B, int Cin, int Cout, long V, int accumulate, void* stream);
 int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,

@@ -73,6 +73,52 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
     }
 }
 
+// The same product for the large volumes (V >= 16 K voxels per sample: the 32^3 level), where the kernel above spends its time on scalar weight loads between the FMAs
+// (64 s_load_dwordx4 + waits per 16 input channels) with 4-byte activation loads: one WAVE per block, 4 consecutive voxels per lane (16-byte loads / stores, every input
+// channel's load in flight before the first FMA), the 16 x Cin weight tile transposed in LDS and read as broadcast ds_read_b128.  Cout % 16 == 0, Cin <= 64, V % 4 == 0.
+template <int CINB>
+__global__ void __launch_bounds__(64) vx_pw_fwd_v4_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+                                                     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int Cout, long V) {
+    __shared__ __attribute__((aligned(16))) float wt[64 * 16];          // [ci][16 output channels]
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f4* gf4;
+    const int lane = threadIdx.x;
+    const long v = ((long)blockIdx.x * 64 + lane) * 4;
+    const int co0 = blockIdx.y * 16, b = blockIdx.z;
+    for (int e = lane; e < 16 * Cin; e += 64) { const int co = e / Cin, ci = e - co * Cin; wt[ci * 16 + co] = w[(long)(co0 + co) * Cin + ci]; }
+    f4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float bj = bias ? bias[co0 + j] : 0.0f; acc[j] = (f4){bj, bj, bj, bj}; }
+    __syncthreads();
+    if (v >= V) return;
+    for (int c0 = 0; c0 < Cin; c0 += CINB) {
+        f4 xv[CINB];
+#pragma unroll
+        for (int u = 0; u < CINB; ++u) {
+            const int c = c0 + u;
+            // (address arithmetic on integers + an explicit global address space: a pointer select between x and x2 would make these FLAT loads)
+            const unsigned long long base = (c < C1) ? (unsigned long long)(x + ((long)b * C1 + c) * V) : (unsigned long long)(x2 + ((long)b * (Cin - C1) + (c - C1)) * V);
+            xv[u] = (c < Cin) ? *(gf4)(base + (unsigned long long)v * 4ull) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < CINB; ++u) {
+            if (c0 + u < Cin) {
+                const f4* wr = reinterpret_cast<const f4*>(wt + (c0 + u) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 w4 = wr[q];
+                    acc[4 * q + 0] += w4[0] * xv[u];
+                    acc[4 * q + 1] += w4[1] * xv[u];
+                    acc[4 * q + 2] += w4[2] * xv[u];
+                    acc[4 * q + 3] += w4[3] * xv[u];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) *reinterpret_cast<f4*>(y + ((long)b * Cout + co0 + j) * V + v) = acc[j];
+}
+
 // dx[b,ci,v] (=|+=) sum_co w[co,ci] * dy[b,co,v]              (CIT input channels per thread, CIT % 4 == 0)
 template <int CIT>
 __device__ __forceinline__ void vx_pw_bwd_data_body(const int vbx, const int vby, const int vbz, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
@@ -199,6 +245,8 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x
 
 template <int N> using vx_ic3 = std::integral_constant<int, N>;
 
+static int vx_pw_v4 = 1;
+extern "C" int vx_pw_conv_set_v4(int on) { vx_pw_v4 = on ? 1 : 0; return 0; }      // A/B knob: the one-wave 16-byte forward kernel for large volumes (vx_pw_fwd_v4_k)
 static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
                                int B, int Cin, int Cout, long V, void* stream, const VxPwEpi& epi) {
     VX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_fwd: bad args");
@@ -207,9 +255,16 @@ static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const fl
     VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_fwd: x2 missing");
     VX_REQUIRE(C1 % 4 == 0, "vx_pw_conv_fwd: concat split must be a multiple of 4");
     int T = (Cout % 16 == 0) ? 16 : (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (vx_pw_v4 && epi.mode == 0 && Cout % 16 == 0 && Cin <= 64 && V % 4 == 0 && V >= 16384) {
+        const dim3 g4(vx_cdiv(V, 256), Cout / 16, B);
+        if (Cin <= 32) vx_pw_fwd_v4_k<32><<<g4, 64, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V);
+        else vx_pw_fwd_v4_k<16><<<g4, 64, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V);
+        VX_LAUNCH_CHECK("vx_pw_conv_fwd (v4)");
+        return 0;
+    }
     while (T > 1 && (long)vx_cdiv(V, 256) * (Cout / T) * B < 512) T >>= 1;     // small volumes: trade register blocking for more blocks
     dim3 grid(vx_cdiv(V, 256), Cout / T, B);
-    hipStream_t st = (hipStream_t)stream;
     switch (T) {
         case 16: vx_pw_fwd_k<16><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
         case 8: vx_pw_fwd_k<8><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
