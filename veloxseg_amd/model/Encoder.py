@@ -163,7 +163,7 @@ class Encoder(nn.Module):
                 if side is not None:
                     ctx.__exit__(None, None, None)
             a_i, cur_feats = ta.layers[i](cur_feats)
-            attn.append(a_i)
+            attn.append(getattr(a_i, "for_decoders", a_i))      # (training: the decoders get aliases of their own, functional.fan_out)
             if side is not None:
                 side.wait_stream(main)
                 for t_ in a_i:
@@ -174,10 +174,13 @@ class Encoder(nn.Module):
                 a_raw = self._mix(i, a_i)
                 fused = VF.instnorm_sum([d_raw, a_raw])                  # IN(down) + IN(mix)  (Encoder.py:351-360)
                 prev = getattr(self.encoder_conv, f"layer{i + 1}")(fused)
+                prev_dec = prev
+                if i < 3 and self.training and torch.is_grad_enabled():
+                    (prev_dec, prev), = VF.fan_out([prev], 2)              # consumers: the decoders and the next level's DownConv
             finally:
                 if side is not None:
                     ctx.__exit__(None, None, None)
-            encs.append(prev)
+            encs.append(prev_dec)
         if side is not None:
             main.wait_stream(side)
             for e in encs:

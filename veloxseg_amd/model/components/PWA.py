@@ -193,6 +193,10 @@ class Paired_Windows_TransformerBlock(nn.Module):
         return self.attn(xs, residual_scale=2.0, tail=tail, ffn=(self.norms, self.ffns))
 
 
+class _FeatureList(list):
+    """a list of per-modality features that can carry the aliases meant for the decoders (functional.fan_out)"""
+
+
 class Transformer_BasicLayer(nn.Module):
     """depth x block, then optional PatchMerging per modality (PWA.py:444-511)."""
 
@@ -216,14 +220,25 @@ class Transformer_BasicLayer(nn.Module):
     def forward(self, xs):
         for blk in self.blocks:
             xs = blk(xs)
-        if self.downs is None:
-            return xs, None
+        if self.training and torch.is_grad_enabled():
+            # the level's features have three consumers (the modal mixer, the decoders, the next level's patch merge; two at the last level): one alias each, so that
+            # their gradients are summed in one launch (functional.fan_out) -- `for_decoders` travels with the returned list (model/Encoder.py)
+            al = VF.fan_out(xs, 2 if self.downs is None else 3)
+            out = _FeatureList(a[0] for a in al)
+            out.for_decoders = [a[1] for a in al]
+            if self.downs is None:
+                return out, None
+            xs = [a[2] for a in al]
+        else:
+            out = xs
+            if self.downs is None:
+                return xs, None
         M = self.num_modalities
         if (VF.USE_PWA_FUSED and xs[0].is_cuda and 1 <= M <= 4 and len({d.in_ch for d in self.downs}) == 1
                 and all(v % 2 == 0 for v in xs[0].shape[2:]) and VF.ln_pw_ok(8 * self.downs[0].in_ch, [2 * self.downs[0].in_ch], xs[0][0, 0].numel() // 8, True)):
-            return xs, VF.patch_merge_all(xs, self.downs)          # gather + LN(8C) + reduction of every modality: one launch
+            return out, VF.patch_merge_all(xs, self.downs)          # gather + LN(8C) + reduction of every modality: one launch
         if VF.MODALITY_STREAMS >= 2 and VF.BRANCH_STREAMS and M > 1 and xs[0].is_cuda:       # PatchMerging is per modality too
             down = VF.run_branches([(lambda m=m: self.downs[m](xs[m])) for m in range(M)], xs[0].device, tag="modalities", uses=[[xs[m]] for m in range(M)])
         else:
             down = [self.downs[m](xs[m]) for m in range(M)]
-        return xs, down
+        return out, down
