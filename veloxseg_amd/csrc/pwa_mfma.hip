@@ -786,6 +786,55 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     const int qsi = blockIdx.x % QS;
     const int kc = blockIdx.x / QS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
+    // ---- this wave's keys
+    const int kt = kc * 4 + wave;                             // key tile (of both modalities)
+    const int kcol = 16 * kt + m;
+    float kmax = 0.0f, vmax = 0.0f;
+    vx_au4 kop[2], vop[2], kth, ktl;
+    float kv[2][C], vv[2][C], t8[8];
+    // every global load of the block's start is issued before the first wait: the key rows here, the first chunk's query rows below, then the LDS tables are built
+    // (one exposed memory latency per block instead of three: 83 -> see DESIGN.md section 9.5)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const long kr = wrow + (long)f * A.l + kcol;
+#pragma unroll
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(K + kr * C + 4 * c4), v4 = *reinterpret_cast<const float4*>(Vt + kr * C + 4 * c4);
+            kv[f][4 * c4] = k4.x; kv[f][4 * c4 + 1] = k4.y; kv[f][4 * c4 + 2] = k4.z; kv[f][4 * c4 + 3] = k4.w;
+            vv[f][4 * c4] = v4.x; vv[f][4 * c4 + 1] = v4.y; vv[f][4 * c4 + 2] = v4.z; vv[f][4 * c4 + 3] = v4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {       // A of dQ^T: lane (row = channel m, slots 4 f + j <-> key 4 qg + j of tile f)
+            const float t_ = K[(wrow + (long)f * A.l + 16 * kt + 4 * qg + j) * C + (m < C ? m : 0)];
+            t8[4 * f + j] = m < C ? t_ : 0.0f;
+        }
+    }
+    // ---- the chunk's query rows: threads 0..127 one Q row each, threads 128..255 one dO / O row each (loaded one chunk ahead)
+    const int rr = threadIdx.x & 127;
+    const int rf = rr / nq, rloc = rr - rf * nq;
+    float xv[C], lse_r = 0.0f, del_r = 0.0f, omax = 0.0f;
+    auto load_rows = [&](int qc) {
+        const long grow = wrow + (long)rf * A.l + 64 * qc + rloc;
+        del_r = 0.0f; omax = 0.0f;
+        if (threadIdx.x < 128) {
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(Q + grow * C + 4 * c4);
+                xv[4 * c4] = q4.x; xv[4 * c4 + 1] = q4.y; xv[4 * c4 + 2] = q4.z; xv[4 * c4 + 3] = q4.w;
+            }
+        } else {
+            lse_r = LSE[grow];
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(dO + grow * C + 4 * c4), o4 = *reinterpret_cast<const float4*>(O + grow * C + 4 * c4);
+                xv[4 * c4] = g4.x; xv[4 * c4 + 1] = g4.y; xv[4 * c4 + 2] = g4.z; xv[4 * c4 + 3] = g4.w;
+                del_r = fmaf(g4.x, o4.x, fmaf(g4.y, o4.y, fmaf(g4.z, o4.z, fmaf(g4.w, o4.w, del_r))));
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
+            }
+        }
+    };
+    load_rows(qsi * QCB);
+    // ---- LDS tables (while the loads above travel)
     for (int t = threadIdx.x; t < A.l; t += 256) {
         const int t2 = t % A.n[2], t1 = (t / A.n[2]) % A.n[1], t0 = t / (A.n[2] * A.n[1]);
         lin[t] = (t0 * (2 * A.n[1] - 1) + t1) * (2 * A.n[2] - 1) + t2;
@@ -803,29 +852,11 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         uint32_t* z = reinterpret_cast<uint32_t*>(rq);
         for (int e = threadIdx.x; e < (NR * VX_BH_RS + 2 * 16 * VX_BH_TS) / 2; e += 256) z[e] = 0u;
     }
-    // ---- this wave's keys
-    const int kt = kc * 4 + wave;                             // key tile (of both modalities)
-    const int kcol = 16 * kt + m;
-    float kmax = 0.0f, vmax = 0.0f;
-    vx_au4 kop[2], vop[2], kth, ktl;
     {
-        float kv[2][C], vv[2][C], t8[8];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const long kr = wrow + (long)f * A.l + kcol;
-#pragma unroll
-            for (int c4 = 0; c4 < C / 4; ++c4) {
-                const float4 k4 = *reinterpret_cast<const float4*>(K + kr * C + 4 * c4), v4 = *reinterpret_cast<const float4*>(Vt + kr * C + 4 * c4);
-                kv[f][4 * c4] = k4.x; kv[f][4 * c4 + 1] = k4.y; kv[f][4 * c4 + 2] = k4.z; kv[f][4 * c4 + 3] = k4.w;
-                vv[f][4 * c4] = v4.x; vv[f][4 * c4 + 1] = v4.y; vv[f][4 * c4 + 2] = v4.z; vv[f][4 * c4 + 3] = v4.w;
-            }
 #pragma unroll
             for (int c = 0; c < C; ++c) { kmax = fmaxf(kmax, fabsf(kv[f][c])); vmax = fmaxf(vmax, fabsf(vv[f][c])); }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {       // A of dQ^T: lane (row = channel m, slots 4 f + j <-> key 4 qg + j of tile f)
-                const float t_ = K[(wrow + (long)f * A.l + 16 * kt + 4 * qg + j) * C + (m < C ? m : 0)];
-                t8[4 * f + j] = m < C ? t_ : 0.0f;
-            }
         }
         kmax = vx_wave_max(kmax); vmax = vx_wave_max(vmax);
         if (lane == 0) { red[8 + wave] = kmax; red[12 + wave] = vmax; }
@@ -882,34 +913,21 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     const unsigned short* __restrict__ mbw = DROP ? mbits + win * NW16 * A.ML : nullptr;
     const float keepf = inv_keep;
     float* __restrict__ dtab_dst = dtable_rep + (long)((blockIdx.x + gridDim.x * blockIdx.y) % VX_DTABLE_REPLICAS) * A.Tsz * A.heads;
-    // ---- the chunk's query rows: threads 0..127 one Q row each, threads 128..255 one dO / O row each (loaded one chunk ahead)
-    const int rr = threadIdx.x & 127;
-    const int rf = rr / nq, rloc = rr - rf * nq;
-    float xv[C], lse_r = 0.0f, del_r = 0.0f, omax = 0.0f;
-    auto load_rows = [&](int qc) {
-        const long grow = wrow + (long)rf * A.l + 64 * qc + rloc;
-        del_r = 0.0f; omax = 0.0f;
-        if (threadIdx.x < 128) {
-#pragma unroll
-            for (int c4 = 0; c4 < C / 4; ++c4) {
-                const float4 q4 = *reinterpret_cast<const float4*>(Q + grow * C + 4 * c4);
-                xv[4 * c4] = q4.x; xv[4 * c4 + 1] = q4.y; xv[4 * c4 + 2] = q4.z; xv[4 * c4 + 3] = q4.w;
-            }
-        } else {
-            lse_r = LSE[grow];
-#pragma unroll
-            for (int c4 = 0; c4 < C / 4; ++c4) {
-                const float4 g4 = *reinterpret_cast<const float4*>(dO + grow * C + 4 * c4), o4 = *reinterpret_cast<const float4*>(O + grow * C + 4 * c4);
-                xv[4 * c4] = g4.x; xv[4 * c4 + 1] = g4.y; xv[4 * c4 + 2] = g4.z; xv[4 * c4 + 3] = g4.w;
-                del_r = fmaf(g4.x, o4.x, fmaf(g4.y, o4.y, fmaf(g4.z, o4.z, fmaf(g4.w, o4.w, del_r))));
-                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
-            }
-        }
-    };
-    load_rows(qsi * QCB);
 #pragma unroll 1
     for (int qc = qsi * QCB; qc < (qsi + 1) * QCB; ++qc) {
         const int q_lo = 4 * qc;
+        const int mrow0 = 16 * q_lo + 4 * qg;                 // (+ g * l + 16 j): first of this lane's 4 query rows
+        uint2 mk[2][2];
+        auto load_bits = [&](int j) {
+            if constexpr (DROP) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        mk[g][f] = *reinterpret_cast<const uint2*>(mbw + (long)(f * (A.l >> 4) + kt) * A.ML + g * A.l + mrow0 + 16 * j);
+            }
+        };
+        load_bits(0);                                        // (the keep bits of the chunk's first step travel during the staging below)
         // ---- scales of the chunk: Q to < 2^10; dO to < 2^5 and such that |delta| < C 2^10 in the units of dS = 2^(ed + ev) (|dP| < C 2^10 by the scales of dO and V)
         float amax = 0.0f;
 #pragma unroll
@@ -955,18 +973,6 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         vx_f32x4 dk[2], dv[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) { dk[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; dv[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; }
-        const int mrow0 = 16 * q_lo + 4 * qg;                 // (+ g * l + 16 j): first of this lane's 4 query rows
-        uint2 mk[2][2];
-        auto load_bits = [&](int j) {
-            if constexpr (DROP) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        mk[g][f] = *reinterpret_cast<const uint2*>(mbw + (long)(f * (A.l >> 4) + kt) * A.ML + g * A.l + mrow0 + 16 * j);
-            }
-        };
-        load_bits(0);
 #pragma unroll 1
         for (int j = 0; j < NTq; ++j) {
             const int qt = q_lo + j;
@@ -1277,6 +1283,16 @@ int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float
 
 // ---- one-pass backward on the f16 matrix pipe (vx_pwa_attn_bwd1h_k): 128^3 levels 1 / 2 (windows of 64 / 512 tokens, two modalities, head widths (4, 4) / (8, 8)).
 // Knob (A/B, tests): vx_pwa_attn_set_f16_bwd(0) returns those geometries to the fp32 kernels.  With dropout on the kernel needs the forward's keep bits.
+struct VxZeroMany { float4* p[4]; long n4[4]; };
+__global__ void __launch_bounds__(256) vx_zero_many_k(VxZeroMany z) {
+    float4* __restrict__ p = z.p[blockIdx.y];
+    const long n = z.n4[blockIdx.y];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = ((long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (i < n) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 static int vx_am_f16_bwd = 1;
 static int vx_am_f16_qs = 0;            // (A/B) query splits per window and key chunk; 0 = the rule below
 extern "C" int vx_pwa_attn_set_f16_bwd(int on) { vx_am_f16_bwd = on ? 1 : 0; vx_am_f16_qs = on > 1 ? on - 1 : 0; return 0; }
@@ -1308,8 +1324,17 @@ int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const floa
     const long rows = nwin * A.ML;
     const bool drop = d.seed_ptr != nullptr && d.p > 0.0f;
     if (drop && mbits == nullptr) return -3;
-    if (atomic_dq && hipMemsetAsync(dQ, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess) return -2;
-    if (QS > 1 && (hipMemsetAsync(dK, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess || hipMemsetAsync(dV, 0, (size_t)rows * cv * sizeof(float), st) != hipSuccess)) return -2;
+    // dQ (several key chunks per window) and dK / dV (several query splits) are summed with float atomics: zeroed in ONE launch (three memsets were 12 us of
+    // launch latency in front of a 120 us kernel)
+    if (atomic_dq || QS > 1) {
+        VxZeroMany z = {};
+        int nz = 0;
+        if (atomic_dq) { z.p[nz] = reinterpret_cast<float4*>(dQ); z.n4[nz] = rows * cq / 4; ++nz; }
+        if (QS > 1) { z.p[nz] = reinterpret_cast<float4*>(dK); z.n4[nz] = rows * cq / 4; ++nz; z.p[nz] = reinterpret_cast<float4*>(dV); z.n4[nz] = rows * cv / 4; ++nz; }
+        long mx = 0;
+        for (int i = 0; i < nz; ++i) mx = z.n4[i] > mx ? z.n4[i] : mx;
+        vx_zero_many_k<<<dim3((unsigned)vx_cdiv(mx, 256 * 4), (unsigned)nz), dim3(256), 0, st>>>(z);
+    }
     const float inv_keep = drop ? 1.0f / (1.0f - d.p) : 1.0f;
     const size_t shm = vx_b1h_shm(A, cq);
 #define VX_B1H(C_, D_)                                                                                                                            \
