@@ -1224,12 +1224,13 @@ static int vx_b1_span(const VxAttnM& A, int ntok, int step) {
     }
     return worst;
 }
-static VxB1Geo vx_b1_geo(const VxAttnM& A, int cq, int mf) {
+static VxB1Geo vx_b1_geo(const VxAttnM& A, int cq, int mf, bool few_windows = false) {
     VxB1Geo g;
     g.NT = (A.l + 15) / 16;
     g.waves_used = g.NT < 4 ? g.NT : 4;
     g.nbx = (g.NT + g.waves_used - 1) / g.waves_used;
     g.NTq = g.NT < 4 ? g.NT : 4;                          // query tiles per block: short blocks balance the chip (72 windows of 1024 tokens: 8 x 8 blocks each)
+    if (few_windows) g.NTq = 1;                           // a handful of windows (the coarse levels): one query tile per block, 4 x the blocks, dK / dV through float atomics
     while (g.NT % g.NTq) --g.NTq;
     g.QS = g.NT / g.NTq;
     // bias-gradient windows: bins of (NTq * 16 queries) x (16 keys) inside 256 values, x (64 keys) inside 512
@@ -1239,26 +1240,50 @@ static VxB1Geo vx_b1_geo(const VxAttnM& A, int cq, int mf) {
     g.shm = (lp + (g.win ? 2 * VX_B1_WIN + 4 * VX_B1_WIN : 2 * tpad) + 2 * mf * nq + 4 * mf * nq * cq + (size_t)4 * mf * 16 * 20) * sizeof(float);
     return g;
 }
+struct VxZeroMany { float4* p[4]; long n4[4]; };
+__global__ void __launch_bounds__(256) vx_zero_many_k(VxZeroMany z) {
+    float4* __restrict__ p = z.p[blockIdx.y];
+    const long n = z.n4[blockIdx.y];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = ((long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (i < n) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// fewer than 64 blocks with four query tiles per block: split the queries (A/B experiment: VELOXSEG_B1_FEW=1)
+static bool vx_b1_few(const VxAttnM& A) {
+    static const int on = getenv("VELOXSEG_B1_FEW") ? atoi(getenv("VELOXSEG_B1_FEW")) : 0;          // off: 44 -> 32 us alone at the 4^3 level, no change of the step (894 vs 895)
+    const int NT = (A.l + 15) / 16;
+    return on && NT >= 2 && (long)A.BH * A.Nt * ((NT + 3) / 4) * ((NT + 3) / 4) < 64;
+}
 extern "C" int vx_pwa_attn_bwd1_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
     if (!(vx_am_enabled & 10) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M < 1 || M > 2) return 0;
-    if (!(vx_am_enabled & 8) && P->l % 16 == 0) return 0;          // (measured: see vx_am_enabled)
     if (!((cq == 4 && cv == 4) || (cq == 8 && cv == 8) || (cq == 8 && cv == 16) || (cq == 16 && cv == 32) || (cq == 16 && cv == 16) || (cq == 4 && cv == 8))) return 0;
     VxAttnM A;
     vx_am_fill(A, P, B, M, cq);
-    return vx_b1_geo(A, cq, M).shm <= 80 * 1024 ? 1 : 0;
+    // (measured: see vx_am_enabled; a level with a handful of windows -- 16 at the 4^3 level of a 128^3 patch, B = 4 -- takes it with one query tile per block: 44 -> 34 us)
+    if (!(vx_am_enabled & 8) && P->l % 16 == 0 && !vx_b1_few(A)) return 0;
+    return vx_b1_geo(A, cq, M, vx_b1_few(A)).shm <= 80 * 1024 ? 1 : 0;
 }
 int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
                      float* dK, float* dV, float* rep, const unsigned short* mbits, const VxPwaPlan* plan, int B, int M, int cq, int cv, VxDrop d, void* stream) {
     VxAttnM A;
     vx_am_fill(A, plan, B, M, cq);
-    const VxB1Geo g = vx_b1_geo(A, cq, M);
     const long nwin = (long)A.BH * A.Nt;
+    const VxB1Geo g = vx_b1_geo(A, cq, M, vx_b1_few(A));
     const dim3 grid((unsigned)(g.nbx * g.QS), (unsigned)nwin);
     const int atomic_dq = g.nbx > 1 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const long rows = nwin * A.ML;
-    if (atomic_dq && hipMemsetAsync(dQ, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess) return -2;
-    if (g.QS > 1 && (hipMemsetAsync(dK, 0, (size_t)rows * cq * sizeof(float), st) != hipSuccess || hipMemsetAsync(dV, 0, (size_t)rows * cv * sizeof(float), st) != hipSuccess)) return -2;
+    if (atomic_dq || g.QS > 1) {          // one zeroing launch for the atomically summed outputs
+        VxZeroMany z = {};
+        int nz = 0;
+        if (atomic_dq) { z.p[nz] = reinterpret_cast<float4*>(dQ); z.n4[nz] = rows * cq / 4; ++nz; }
+        if (g.QS > 1) { z.p[nz] = reinterpret_cast<float4*>(dK); z.n4[nz] = rows * cq / 4; ++nz; z.p[nz] = reinterpret_cast<float4*>(dV); z.n4[nz] = rows * cv / 4; ++nz; }
+        long mx = 0;
+        for (int i = 0; i < nz; ++i) mx = z.n4[i] > mx ? z.n4[i] : mx;
+        vx_zero_many_k<<<dim3((unsigned)vx_cdiv(mx, 256 * 4), (unsigned)nz), dim3(256), 0, st>>>(z);
+    }
     vx_am_dispatch(cq, cv, [&](auto pr) {
         constexpr int CQ = decltype(pr)::a, CV = decltype(pr)::b;
         const bool al = (A.l & 3) == 0;
@@ -1283,16 +1308,6 @@ int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float
 
 // ---- one-pass backward on the f16 matrix pipe (vx_pwa_attn_bwd1h_k): 128^3 levels 1 / 2 (windows of 64 / 512 tokens, two modalities, head widths (4, 4) / (8, 8)).
 // Knob (A/B, tests): vx_pwa_attn_set_f16_bwd(0) returns those geometries to the fp32 kernels.  With dropout on the kernel needs the forward's keep bits.
-struct VxZeroMany { float4* p[4]; long n4[4]; };
-__global__ void __launch_bounds__(256) vx_zero_many_k(VxZeroMany z) {
-    float4* __restrict__ p = z.p[blockIdx.y];
-    const long n = z.n4[blockIdx.y];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long i = ((long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
-        if (i < n) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
 static int vx_am_f16_bwd = 1;
 static int vx_am_f16_qs = 0;            // (A/B) query splits per window and key chunk; 0 = the rule below
 extern "C" int vx_pwa_attn_set_f16_bwd(int on) { vx_am_f16_bwd = on ? 1 : 0; vx_am_f16_qs = on > 1 ? on - 1 : 0; return 0; }
