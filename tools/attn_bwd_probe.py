@@ -38,7 +38,7 @@ for name, levels in LEVELS.items():
         if H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, cq, cv) == 1:
             res = {}
             for f16 in (1, 0):
-                H.call("vx_pwa_attn_set_f16_bwd", (1 + int(os.environ.get("VX_F16_QS", "0"))) if f16 else 0)      # (VX_F16_QS: A/B of the query splits per key chunk)
+                H.call("vx_pwa_attn_set_f16_bwd", 1 if f16 else 0)      # (VELOXSEG_F16_BWD_QS in the environment: A/B of the query splits per key chunk)
                 dt.zero_()
 
                 def run():

@@ -1309,8 +1309,7 @@ int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float
 // ---- one-pass backward on the f16 matrix pipe (vx_pwa_attn_bwd1h_k): 128^3 levels 1 / 2 (windows of 64 / 512 tokens, two modalities, head widths (4, 4) / (8, 8)).
 // Knob (A/B, tests): vx_pwa_attn_set_f16_bwd(0) returns those geometries to the fp32 kernels.  With dropout on the kernel needs the forward's keep bits.
 static int vx_am_f16_bwd = 1;
-static int vx_am_f16_qs = 0;            // (A/B) query splits per window and key chunk; 0 = the rule below
-extern "C" int vx_pwa_attn_set_f16_bwd(int on) { vx_am_f16_bwd = on ? 1 : 0; vx_am_f16_qs = on > 1 ? on - 1 : 0; return 0; }
+extern "C" int vx_pwa_attn_set_f16_bwd(int on) { vx_am_f16_bwd = on ? 1 : 0; return 0; }
 static size_t vx_b1h_shm(const VxAttnM& A, int c) {
     return ((size_t)A.l + (size_t)((A.Tsz + 3) & ~3) + 16 * VX_B1_WIN + 2 * 128 + (size_t)4 * 128 * c + 4 * 2 * 16 * 20 + 32) * sizeof(float) + ((size_t)128 * VX_BH_RS + 2 * 16 * VX_BH_TS) * 2;
 }
@@ -1332,7 +1331,8 @@ int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const floa
     // query splits: as few as fill the chip (every split costs one more float atomic per dK / dV element): >= 4 blocks per CU
     int QS = 1;
     while (QS < nchunk && nwin * nchunk * QS < 4 * 256) QS *= 2;
-    if (vx_am_f16_qs) { QS = vx_am_f16_qs; while (nchunk % QS) --QS; }
+    static const int qs_env = getenv("VELOXSEG_F16_BWD_QS") ? atoi(getenv("VELOXSEG_F16_BWD_QS")) : 0;          // (A/B: query splits per window and key chunk; 0 = the rule above)
+    if (qs_env > 0) { QS = qs_env < nchunk ? qs_env : nchunk; while (nchunk % QS) --QS; }
     const dim3 grid((unsigned)(nchunk * QS), (unsigned)nwin);
     const int atomic_dq = nchunk > 1 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
