@@ -177,6 +177,54 @@ def test_conv3d_concat_nobias():
     run_pair(lambda a, b, w: VF.conv3d(a, w, None, x2=b), lambda a, b, w: F.conv3d(torch.cat([a, b], 1), w), [x1, x2], [w], what="concat")
 
 
+@pytest.mark.parametrize("C1,C2,Co,concat", [(16, 16, 16, True), (64, 0, 16, False), (32, 0, 32, False)], ids=["concat_16_16_to_16", "64_to_16", "32_to_32"])
+def test_conv3d_1x1_large_volume_kernel(C1, C2, Co, concat):
+    """1x1 convolutions of the 32^3 level (V = 32768 per sample: the one-wave kernel with 16-byte accesses and the weight tile in LDS, pointwise.hip vx_pw_fwd_v4_k)
+    against torch, forward and every gradient, with and without the in-kernel channel concat; and against the one-voxel-per-thread kernel of the same library
+    (vx_pw_conv_set_v4(0)): same products, fp32 summation noise."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    x1 = rnd(2, C1, 32, 32, 32)
+    w = rnd(Co, C1 + C2, 1, 1, 1, seed=4, scale=(C1 + C2) ** -0.5)
+    b = rnd(Co, seed=5, scale=0.1)
+    if concat:
+        x2 = rnd(2, C2, 32, 32, 32, seed=3)
+        run_pair(lambda a, c, w, b: VF.conv3d(a, w, b, x2=c), lambda a, c, w, b: F.conv3d(torch.cat([a, c], 1), w, b), [x1, x2], [w, b], what="1x1 v4 concat")
+    else:
+        run_pair(lambda a, w, b: VF.conv3d(a, w, b), lambda a, w, b: F.conv3d(a, w, b), [x1], [w, b], what="1x1 v4")
+    d = dev()
+    outs = []
+    try:
+        for on in (1, 0):
+            H.call("vx_pw_conv_set_v4", on)
+            with torch.no_grad():
+                outs.append(VF.conv3d(x1.to(d), w.to(d), b.to(d), x2=(x2.to(d) if concat else None)))
+    finally:
+        H.call("vx_pw_conv_set_v4", 1)
+    close(outs[0], outs[1], 2e-6 * float(outs[1].abs().max()), 1e-5, "v4 kernel vs one-voxel-per-thread kernel")
+
+
+def test_fan_out_gradients_meet_in_one_sum():
+    """functional.fan_out (one alias of a tensor per consumer, the consumers' gradients summed in one vx_add_many launch for the whole list) against plain autograd
+    accumulation: same forward values, same gradients, for two tensors with three consumers each and one with two."""
+    VF = _vf()
+    d = dev()
+    xs = [rnd(2, 8, 4, 4, 4, seed=i).to(d).requires_grad_(True) for i in range(2)]
+    ys = [x.detach().clone().requires_grad_(True) for x in xs]
+    ws = [rnd(2, 8, 4, 4, 4, seed=10 + i).to(d) for i in range(3)]
+    al = VF.fan_out([x * 1.0 for x in xs], 3)
+    assert all(torch.equal(a[j], xs[i].detach()) for i, a in enumerate(al) for j in range(3))
+    loss = sum((al[i][j] * ws[j]).sum() * (i + 1) for i in range(2) for j in range(3))
+    ref = sum((y * ws[j]).sum() * (i + 1) for i, y in enumerate(ys) for j in range(3))
+    loss.backward()
+    ref.backward()
+    for x, y in zip(xs, ys):
+        close(x.grad, y.grad, 1e-5, 1e-5, "fan_out gradient")
+    (a2,) = VF.fan_out([xs[0] * 2.0], 2)
+    g = torch.autograd.grad((a2[0] * ws[0]).sum() + (a2[1] * ws[1]).sum(), xs[0])[0]
+    close(g, 2.0 * (ws[0] + ws[1]), 1e-5, 1e-5, "fan_out of two")
+
+
 @pytest.mark.parametrize("B,Ci,Co,sp", [(2, 32, 16, (3, 4, 5)), (4, 128, 64, (4, 4, 4)), (3, 64, 32, (8, 8, 8)), (2, 32, 16, (16, 16, 16)), (1, 24, 8, (3, 3, 3))],
                          ids=["ragged", "L4_to_L3", "L3_to_L2", "L2_to_L1", "odd_channels"])
 def test_conv_transpose(B, Ci, Co, sp):
