@@ -204,6 +204,31 @@ def test_conv3d_1x1_large_volume_kernel(C1, C2, Co, concat):
     close(outs[0], outs[1], 2e-6 * float(outs[1].abs().max()), 1e-5, "v4 kernel vs one-voxel-per-thread kernel")
 
 
+@pytest.mark.parametrize("B,Cin,sp,scale", [(2, 2, (16, 16, 64), 1.0), (1, 1, (8, 32, 128), 1.0), (1, 4, (8, 16, 64), 1.0), (1, 2, (12, 16, 64), 2.0e4), (1, 2, (8, 16, 64), 1.0e-5)],
+                         ids=["two_modalities", "one_channel_wide", "four_channels", "large_values", "tiny_values"])
+def test_stem_conv_on_the_f16_pipe(B, Cin, sp, scale):
+    """The stem convolution (k = 7, s = 4, p = 3, 16 channels: conv_mfma.hip vx_stem_fwd_k, input rows staged once in LDS as two scaled fp16 pieces, Toeplitz GEMM along
+    W) against torch's fp64 convolution and against the fp32 gather kernel it replaces (vx_conv_mfma_set_stem_f16(0)): error at the level of the fp32 kernel's."""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    x = (rnd(B, Cin, *sp) * scale).to(d)
+    w = rnd(16, Cin, 7, 7, 7, seed=1, scale=(Cin * 343) ** -0.5).to(d)
+    b = (rnd(16, seed=2, scale=0.1) * scale).to(d)
+    ref = F.conv3d(x.double(), w.double(), b.double(), stride=4, padding=3)
+    outs = []
+    try:
+        for on in (1, 0):
+            H.call("vx_conv_mfma_set_stem_f16", on)
+            with torch.no_grad():
+                outs.append(VF.conv3d(x, w, b, stride=4, padding=3))
+    finally:
+        H.call("vx_conv_mfma_set_stem_f16", 1)
+    sc = float(ref.abs().max())
+    e_new, e_old = float((outs[0].double() - ref).abs().max()) / sc, float((outs[1].double() - ref).abs().max()) / sc
+    assert e_new <= max(3.0 * e_old, 2e-6), (e_new, e_old)
+
+
 def test_fan_out_gradients_meet_in_one_sum():
     """functional.fan_out (one alias of a tensor per consumer, the consumers' gradients summed in one vx_add_many launch for the whole list) against plain autograd
     accumulation: same forward values, same gradients, for two tensors with three consumers each and one with two."""

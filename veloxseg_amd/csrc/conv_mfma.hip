@@ -255,10 +255,155 @@ extern "C" int vx_conv_mfma_ok(int Cin, int Cout, int D, int H, int W, int K, in
 
 static int cm_ksteps_fwd(int Cin, int K) { return (Cin * K * K * K + 3) / 4; }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------- the stem on the f16 pipe
+// k = 7, s = 4, p = 3, Cout = 16 (DownConv 1 of the conv encoder: Encoder.py:29-58): the gather kernel above re-reads every input voxel ~5 times from L2 with 4-byte
+// loads (360 MB of gather traffic for a 67 MB input: 109 us).  Here a block stages the input rows of (1 x 4 x 16) outputs in LDS ONCE, as two fp16 pieces of x * 2^ex
+// (ex from the tile's maximum), and the product is a Toeplitz GEMM along W:  rows = the 16 output channels, columns = 16 outputs along W, reduction = (ci, kd, kh) rows
+// x 8 kw slots (7 taps + one zero weight): a lane's 8 reduction values are the 8 CONSECUTIVE inputs 4 ow - 3 .. 4 ow + 4 of one input row -- two ds_read_b64 (the address
+// is 8-byte aligned) -- and four (ci, kd, kh) rows fill a v_mfma_f32_16x16x32_f16.  Weight images (two pieces of w * 2^ew) in operand order, prepared per launch.
+typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
+typedef float cm_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cm_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cm_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const cm_f2 v = {a, b};
+    const cm_h2 h = __builtin_convertvector(v, cm_h2);
+    const cm_h2 l = __builtin_convertvector(v - __builtin_convertvector(h, cm_f2), cm_h2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ int cm_exp16(float m) {
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 0;
+    int e = 13 - ilogbf(m);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+#define VX_STEM_RL 72          // halfs per staged input row (67 used)
+// img[(step * 2 + piece) * 64 + lane]: lane (co = lane & 15, G = lane >> 4): row r = 4 step + G = (ci * 7 + kd) * 7 + kh, the 8 halfs = w[co][ci][kd][kh][0..6], 0
+__global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict__ w, cm_u4* __restrict__ img, float* __restrict__ esc, int Cin, int nsteps) {
+    __shared__ float sm[16];
+    const int n = 16 * Cin * 343;
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+    mx = vx_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    float m2 = sm[threadIdx.x & 15];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+    const int ew = cm_exp16(m2);
+    if (threadIdx.x == 0) esc[0] = (float)ew;
+    const float sc = ldexpf(1.0f, ew);
+    for (int t = threadIdx.x; t < nsteps * 64; t += 1024) {
+        const int lane = t & 63, step = t >> 6;
+        const int co = lane & 15, r = 4 * step + (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (r < Cin * 49 && j < 7) ? w[((long)co * Cin * 49 + r) * 7 + j] * sc : 0.0f;
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cm_split2(v[2 * q], v[2 * q + 1], h[q], l[q]);
+        img[(step * 2) * 64 + lane] = (cm_u4){h[0], h[1], h[2], h[3]};
+        img[(step * 2 + 1) * 64 + lane] = (cm_u4){l[0], l[1], l[2], l[3]};
+    }
+}
+// block = (b, od, 4 output rows oh0.., 16 outputs ow0..); wave = one output row
+template <int CIN>
+__global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x, const cm_u4* __restrict__ img, const float* __restrict__ esc, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+    constexpr int NROW = CIN * 7 * 19, NSTEP = (CIN * 49 + 3) / 4, NIT = (NROW * (VX_STEM_RL / 4) + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    _Float16* __restrict__ xh = reinterpret_cast<_Float16*>(cm_lds);                   // [NROW][72] hi pieces, then the lo pieces
+    _Float16* __restrict__ xl = xh + NROW * VX_STEM_RL;
+    int* __restrict__ rowoff = reinterpret_cast<int*>(xl + NROW * VX_STEM_RL);         // [4 NSTEP]: staged row of reduction row r (for output row 0), in halfs
+    float* __restrict__ red = reinterpret_cast<float*>(rowoff + 4 * NSTEP);            // [4]
+    const int nwb = Wo / 16, nhb = Ho / 4;
+    int t = blockIdx.x;
+    const int wb = t % nwb; t /= nwb;
+    const int hb = t % nhb; t /= nhb;
+    const int od = t % Do;
+    const int b = t / Do;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, G = lane >> 4;
+    for (int r = threadIdx.x; r < 4 * NSTEP; r += 256) {
+        const int ci = r / 49, kd = (r / 7) % 7, kh = r % 7;
+        rowoff[r] = r < CIN * 49 ? ((ci * 7 + kd) * 19 + kh) * VX_STEM_RL : 0;
+    }
+    // ---- stage: item = (staged row, 4 consecutive inputs); the rows start at input w = 64 wb - 3
+    const long Vi = (long)Di * Hi * Wi;
+    const float* __restrict__ xb = x + (long)b * CIN * Vi;
+    float v[NIT][4];
+    float mx = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int it = threadIdx.x + u * 256;
+        const int row = it / (VX_STEM_RL / 4), seg = it - row * (VX_STEM_RL / 4);
+        const int ci = row / (7 * 19), hd = (row / 19) % 7, hh = row % 19;
+        const int id = 4 * od - 3 + hd, ih = 16 * hb - 3 + hh, iw0 = 64 * wb - 3 + 4 * seg;
+        const bool rok = it < NROW * (VX_STEM_RL / 4) && (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi;
+        const float* __restrict__ src = xb + (long)ci * Vi + ((long)(rok ? id : 0) * Hi + (rok ? ih : 0)) * Wi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = iw0 + j;
+            const float t_ = src[(unsigned)iw < (unsigned)Wi ? iw : 0];
+            v[u][j] = (rok && (unsigned)iw < (unsigned)Wi) ? t_ : 0.0f;
+            mx = fmaxf(mx, fabsf(v[u][j]));
+        }
+    }
+    mx = vx_wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const int ex = cm_exp16(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    const float sc = ldexpf(1.0f, ex);
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int it = threadIdx.x + u * 256;
+        if (it < NROW * (VX_STEM_RL / 4)) {
+            uint32_t h0, l0, h1, l1;
+            cm_split2(v[u][0] * sc, v[u][1] * sc, h0, l0);
+            cm_split2(v[u][2] * sc, v[u][3] * sc, h1, l1);
+            *reinterpret_cast<uint2*>(xh + (long)it * 4) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(xl + (long)it * 4) = make_uint2(l0, l1);
+        }
+    }
+    __syncthreads();
+    // ---- this wave's output row oh = 4 hb + wave: lane (output ow = 16 wb + n, rows of step s: 4 s + G)
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const int base = (4 * wave) * VX_STEM_RL + 4 * n;                                 // (+ rowoff[r]): first of the lane's 8 inputs
+    const cm_u4* __restrict__ ig = img + lane;
+    cm_u4 ah = ig[0], al = ig[64];
+#pragma unroll 2
+    for (int s = 0; s < NSTEP; ++s) {
+        cm_u4 nh = ah, nl = al;
+        if (s + 1 < NSTEP) { nh = ig[(s + 1) * 128]; nl = ig[(s + 1) * 128 + 64]; }
+        const int o = rowoff[4 * s + G] + base;
+        const uint2 b0 = *reinterpret_cast<const uint2*>(xh + o), b1 = *reinterpret_cast<const uint2*>(xh + o + 4);
+        const uint2 c0 = *reinterpret_cast<const uint2*>(xl + o), c1 = *reinterpret_cast<const uint2*>(xl + o + 4);
+        const cm_u4 bh = {b0.x, b0.y, b1.x, b1.y}, bl = {c0.x, c0.y, c1.x, c1.y};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, ah), __builtin_bit_cast(cm_h8, bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, ah), __builtin_bit_cast(cm_h8, bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, al), __builtin_bit_cast(cm_h8, bh), acc, 0, 0, 0);
+        ah = nh; al = nl;
+    }
+    const float f = ldexpf(1.0f, -(ex + (int)esc[0]));
+    const long Vo = (long)Do * Ho * Wo;
+    const long o0 = ((long)od * Ho + 4 * hb + wave) * Wo + 16 * wb + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = 4 * G + i;
+        y[((long)b * 16 + co) * Vo + o0] = fmaf(acc[i], f, bias ? bias[co] : 0.0f);
+    }
+}
+static int vx_stem_f16 = 1;
+extern "C" int vx_conv_mfma_set_stem_f16(int on) { vx_stem_f16 = on ? 1 : 0; return 0; }      // A/B knob: the stem (k7 s4, 16 channels) on the f16 pipe (default) or the fp32 gather kernel
+static bool vx_stem_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P) {
+    return vx_stem_f16 && K == 7 && S == 4 && P == 3 && Cout == 16 && (Cin == 1 || Cin == 2 || Cin == 4) && (W / 4) % 16 == 0 && (H / 4) % 4 == 0 && D % 4 == 0;
+}
 extern "C" int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward) {
     const int K3 = K * K * K;
     if (backward) return K3 * (Cout / 4) * ((Cin + 15) / 16) * 64;
-    return cm_ksteps_fwd(Cin, K) * ((Cout + 15) / 16) * 64;
+    const int n = cm_ksteps_fwd(Cin, K) * ((Cout + 15) / 16) * 64;
+    const int stem = (K == 7 && Cout == 16) ? ((Cin * 49 + 3) / 4) * 2 * 64 * 4 + 4 : 0;          // (the f16-pipe stem: two-piece images + the scale exponent)
+    return n > stem ? n : stem;
 }
 
 extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P,
@@ -266,6 +411,20 @@ extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bia
     VX_REQUIRE(x && w && y && ws && B > 0, "vx_conv_mfma_fwd: null argument");
     VX_REQUIRE(vx_conv_mfma_ok(Cin, Cout, D, H, W, K, S, P, 1, 1), "vx_conv_mfma_fwd: unsupported shape Cin=%d Cout=%d %dx%dx%d K=%d S=%d P=%d", Cin, Cout, D, H, W, K, S, P);
     hipStream_t st = (hipStream_t)stream;
+    if (vx_stem_ok(Cin, Cout, D, H, W, K, S, P)) {
+        const int nsteps = (Cin * 49 + 3) / 4, Do = D / 4, Ho = H / 4, Wo = W / 4;
+        cm_u4* img = reinterpret_cast<cm_u4*>(ws);
+        float* esc = ws + (long)nsteps * 2 * 64 * 4;
+        vx_stem_wprep_k<<<dim3(1), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps);
+        const size_t shm = (size_t)Cin * 7 * 19 * VX_STEM_RL * 2 * 2 + (size_t)4 * nsteps * 4 + 64;
+        const dim3 grid((unsigned)((long)B * Do * (Ho / 4) * (Wo / 16)));
+#define VX_STEM(CI) { static bool once = false; if (!once) { if (hipFuncSetAttribute((const void*)vx_stem_fwd_k<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); once = true; } \
+        vx_stem_fwd_k<CI><<<grid, dim3(256), shm, st>>>(x, img, esc, bias, y, B, D, H, W, Do, Ho, Wo); }
+        if (Cin == 1) VX_STEM(1) else if (Cin == 2) VX_STEM(2) else VX_STEM(4)
+#undef VX_STEM
+        VX_LAUNCH_CHECK("vx_conv_mfma_fwd (stem, f16 pipe)");
+        return 0;
+    }
     VxCm A;
     A.x = x; A.bias = bias; A.y = y; A.wop = ws;
     A.B = B; A.Cin = Cin; A.Di = D; A.Hi = H; A.Wi = W; A.Cout = Cout;
