@@ -292,9 +292,10 @@ __global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict_
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
     const int ew = cm_exp16(m2);
-    if (threadIdx.x == 0) esc[0] = (float)ew;
+    if (threadIdx.x == 0 && blockIdx.x == 0) esc[0] = (float)ew;
     const float sc = ldexpf(1.0f, ew);
-    for (int t = threadIdx.x; t < nsteps * 64; t += 1024) {
+    // one block per reduction step (every block finds the tensor's maximum itself: 22 K floats from L2)
+    for (int t = blockIdx.x * 64 + threadIdx.x; t < (blockIdx.x + 1) * 64 && threadIdx.x < 64; t += 1024) {
         const int lane = t & 63, step = t >> 6;
         const int co = lane & 15, r = 4 * step + (lane >> 4);
         float v[8];
@@ -417,7 +418,7 @@ extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bia
         const int nsteps = (Cin * 49 + 3) / 4, Do = D / 4, Ho = H / 4, Wo = W / 4;
         cm_u4* img = reinterpret_cast<cm_u4*>(ws);
         float* esc = ws + (long)nsteps * 2 * 64 * 4;
-        vx_stem_wprep_k<<<dim3(1), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps);
+        vx_stem_wprep_k<<<dim3((unsigned)nsteps), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps);
         const size_t shm = (size_t)Cin * 7 * 19 * VX_STEM_RL * 2 * 2 + (size_t)4 * nsteps * 4 + 64;
         const dim3 grid((unsigned)((long)B * Do * (Ho / 4) * ((Wo + 15) / 16)));
 #define VX_STEM(CI) { static bool once = false; if (!once) { if (hipFuncSetAttribute((const void*)vx_stem_fwd_k<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); once = true; } \
