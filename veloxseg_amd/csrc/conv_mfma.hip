@@ -397,9 +397,9 @@ __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x
     }
 }
 static int vx_stem_f16 = 1;
-extern "C" int vx_conv_mfma_set_stem_f16(int on) { vx_stem_f16 = on ? 1 : 0; return 0; }      // A/B knob: the stem (k7 s4, 16 channels) on the f16 pipe (default) or the fp32 gather kernel
+extern "C" int vx_conv_mfma_set_stem_f16(int on) { vx_stem_f16 = on < 0 ? 0 : on; return 0; }      // A/B knob: the stem (k7 s4, 16 channels) on the f16 pipe (default) or the fp32 gather kernel
 static bool vx_stem_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P) {
-    return vx_stem_f16 && K == 7 && S == 4 && P == 3 && Cout == 16 && (Cin == 1 || Cin == 2 || Cin == 4) && W % 64 == 0 && H % 16 == 0 && D % 4 == 0;      // (rows of 24 outputs -- the 96^3 patches -- measured no gain: 1207 vs 1216, 724 vs 731 patches/s)
+    return vx_stem_f16 && K == 7 && S == 4 && P == 3 && Cout == 16 && (Cin == 1 || Cin == 2 || (Cin == 4 && vx_stem_f16 > 1)) && W % 64 == 0 && H % 16 == 0 && D % 4 == 0;      // (4 input channels = 153 KB of LDS, one block per CU: brats128 B = 4 851 vs 864 patches/s, off unless the knob is 2)      // (rows of 24 outputs -- the 96^3 patches -- measured no gain: 1207 vs 1216, 724 vs 731 patches/s)
 }
 extern "C" int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward) {
     const int K3 = K * K * K;
