@@ -15,6 +15,12 @@ cfg, B = WORKLOADS[wl]
 if len(sys.argv) > 2:
     B = int(sys.argv[2])
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+# A/B: VX_SOAK_OFF=f16bwd,cl,v4 switches the named kernel families back to their predecessors (to find the source of run-to-run deviations); VELOXSEG_STEM_F16=1 turns the
+# opt-in stem kernel on
+from veloxseg_amd import _hip as H
+H.LIB.load()
+for name in filter(None, os.environ.get("VX_SOAK_OFF", "").split(",")):
+    H.call({"f16bwd": "vx_pwa_attn_set_f16_bwd", "cl": "vx_jlc_cl_set_enabled", "v4": "vx_pw_conv_set_v4"}[name], 0)
 torch.manual_seed(12345)
 model = VeloxSeg(**cfg).cuda()
 crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, None, num_modal=len(cfg["in_ch"]))
@@ -40,6 +46,11 @@ for i in range(n):
         else:
             d = float((g - ref[1]).abs().max()) / ref[2]
             worst = max(worst, d)
+            if (os.environ.get("VX_SOAK_VERBOSE") and i < 12) or d > 5e-6:
+                j = int((g - ref[1]).abs().argmax())
+                name = next((n_ for n_ in eng.flat.names if eng.flat.slices[n_][0] <= j < eng.flat.slices[n_][0] + eng.flat.slices[n_][1]), "?")
+                o_, k_ = eng.flat.slices[name] if name != "?" else (0, 0)
+                print(f"replay {i}: deviation {d:.3e} at flat index {j} ({name}: element {j - o_} of {k_}; got {float(g[j]):.9e} ref {float(ref[1][j]):.9e})")
             if d > 1e-4 or float(eng.loss) != ref[0]:
                 bad += 1
                 print(f"replay {i}: loss {float(eng.loss)} vs {ref[0]}, max |dgrad| / max|grad| = {d:.3e}")
