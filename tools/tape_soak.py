@@ -51,6 +51,16 @@ for i in range(n):
                 name = next((n_ for n_ in eng.flat.names if eng.flat.slices[n_][0] <= j < eng.flat.slices[n_][0] + eng.flat.slices[n_][1]), "?")
                 o_, k_ = eng.flat.slices[name] if name != "?" else (0, 0)
                 print(f"replay {i}: deviation {d:.3e} at flat index {j} ({name}: element {j - o_} of {k_}; got {float(g[j]):.9e} ref {float(ref[1][j]):.9e})")
+                if d > 5e-6:
+                    idx = torch.nonzero((g - ref[1]).abs() > 2e-6 * ref[2]).flatten().tolist()
+                    print(f"    {len(idx)} elements deviate by more than 2e-6 of the largest gradient: {idx[:24]}")
+                    dd = (g - ref[1]).abs() / ref[2]
+                    per = sorted(((float(dd[eng.flat.slices[n_][0]:eng.flat.slices[n_][0] + eng.flat.slices[n_][1]].max()), n_) for n_ in eng.flat.names), reverse=True)
+                    print("    largest deviation per parameter: " + "; ".join(f"{n_} {v:.1e}" for v, n_ in per[:14]))
+                    clean = [n_ for v, n_ in per if v < 1e-6 and ("layers.2" in n_ or "layers.3" in n_ or "layer3" in n_ or "layer4" in n_)]
+                    print(f"    level-3 / level-4 encoder parameters WITHOUT a deviation: {len(clean)}: {clean[:40]}")
+                    if os.environ.get("VX_SOAK_STOP"):
+                        break
             if d > 1e-4 or float(eng.loss) != ref[0]:
                 bad += 1
                 print(f"replay {i}: loss {float(eng.loss)} vs {ref[0]}, max |dgrad| / max|grad| = {d:.3e}")
