@@ -535,6 +535,18 @@ int vx_tape_has_marker(const VxTape* tape, int id);
  * computed are those of a replay), and the layout of the tape: lane, workgroups, up to 4 cross-lane waits (-1 padded) and the kernel name per node */
 int vx_tape_profile(VxTape* tape, void* stream, int reps, float* us);
 int vx_tape_describe(const VxTape* tape, int* lane, int* grid, int* waits4, char* names, int name_stride);
+/* schedule audit (veloxseg_amd/tape_audit.py; no counterpart in the reference, whose eager step is ordered by one stream, utils/train_brats2021.py:235-239):
+ * vx_tape_waits: every cross-lane wait of every node (-1 padded to `stride`; an error if a node has more);  vx_tape_launch_node: node i alone on `stream` --
+ * the audit launches a whole step node by node on ONE stream in random orders that respect lane order + waits, and every such order must give the same result;
+ * vx_tape_set_fuzz: multi-lane replays put a 0 .. max_us spin kernel in front of a node with probability `prob` (seeded; max_us = 0 turns it off). */
+int vx_tape_waits(const VxTape* tape, int* waits, int stride);
+int vx_tape_launch_node(VxTape* tape, int node, void* stream);
+int vx_tape_set_fuzz(int seed, float max_us, float prob);
+/* raw bytes of launch parameter k of node i (at most `cap`, at most the host allocation that holds it; *got = bytes copied; memset nodes: k = 0 -> {dst, bytes});
+ * vx_tape_node_kind: answer -- 0 kernel, 1 memset, 2 copy, 3 marker */
+int vx_tape_node_param(const VxTape* tape, int node, int k, void* out, int cap, int* got);
+int vx_tape_node_kind(const VxTape* tape, int node);
+int vx_tape_replay_prefix(VxTape* tape, void* stream, int k);   /* the first k nodes as vx_tape_replay runs them, the rest one after the other on `stream` behind the join */
 /* the process-wide stream of lane `lane` (lane % 4).  The four lane streams are chosen at first use so that they sit on different hardware
  * queues (measured with a spinning kernel: streams that share one of ROCm's 4 hardware queues never overlap, and neither does the NULL stream
  * with anything).  A tape with one lane replays on the caller's stream; a tape with more replays on the lane streams, gated by and joined

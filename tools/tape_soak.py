@@ -31,13 +31,37 @@ torch.cuda.synchronize()
 assert eng.use_graph and eng.graphs is not None, "capture failed"
 rng = VF.rng_state(eng.dev)
 rng0 = rng.clone()
+# VX_SOAK_SERIAL=N: first the deterministic audit (veloxseg_amd/tape_audit.py) -- the step node by node on ONE stream in N random orders that respect the tape's
+# dependencies; an order whose result deviates is bisected to the unordered pair of kernels
+if int(os.environ.get("VX_SOAK_SERIAL", "0")) > 0:
+    from veloxseg_amd.tape_audit import serial_audit
+    finds, noise = serial_audit(eng, range(1, int(os.environ["VX_SOAK_SERIAL"]) + 1), verbose=bool(os.environ.get("VX_SOAK_VERBOSE")),
+                                exhaustive=os.environ.get("VX_SOAK_EXHAUSTIVE") == "1")
+    print(f"{wl} B={B}: serial audit, {os.environ['VX_SOAK_SERIAL']} random admissible orders on one stream: {len(finds)} deviate (same-order noise {noise:.1e})")
+    for f in finds:
+        print("   ", f)
+    if finds:
+        sys.exit(1)
+# VX_SOAK_FUZZ="max_us,prob": every replay puts random spin kernels in front of its nodes (csrc/tape.hip vx_tape_set_fuzz), a different pattern per replay
+fuzz = [float(v) for v in os.environ.get("VX_SOAK_FUZZ", "0,0").split(",")]
+# VX_SOAK_HYBRID=enc_bwd,dec_wg_beside: only the named stages run concurrently (multi-lane tapes / fans), the others node by node on one stream (tape_audit.hybrid_replay)
+hybrid = None
+if os.environ.get("VX_SOAK_HYBRID") is not None:
+    from veloxseg_amd.tape_audit import hybrid_replay
+    hybrid = [k for k in os.environ["VX_SOAK_HYBRID"].split(",") if k]
 ref = None
 worst = 0.0
 bad = 0
+ndev = 0
 sync_every = int(os.environ.get("VX_SYNC_EVERY", "1"))
 for i in range(n):
     rng.copy_(rng0)
-    eng._replay(comm=False)
+    if fuzz[0] > 0:
+        H.call("vx_tape_set_fuzz", i + 1, fuzz[0], fuzz[1])
+    if hybrid is not None:
+        hybrid_replay(eng, hybrid)
+    else:
+        eng._replay(comm=False)
     if (i + 1) % sync_every == 0 or i == n - 1:
         torch.cuda.synchronize()
         g = eng.flat.grad
@@ -52,6 +76,8 @@ for i in range(n):
                 o_, k_ = eng.flat.slices[name] if name != "?" else (0, 0)
                 print(f"replay {i}: deviation {d:.3e} at flat index {j} ({name}: element {j - o_} of {k_}; got {float(g[j]):.9e} ref {float(ref[1][j]):.9e})")
                 if d > 5e-6:
+                    ndev += 1
+                if d > 5e-6 and not os.environ.get("VX_SOAK_QUIET"):
                     idx = torch.nonzero((g - ref[1]).abs() > 2e-6 * ref[2]).flatten().tolist()
                     print(f"    {len(idx)} elements deviate by more than 2e-6 of the largest gradient: {idx[:24]}")
                     dd = (g - ref[1]).abs() / ref[2]
@@ -64,5 +90,6 @@ for i in range(n):
             if d > 1e-4 or float(eng.loss) != ref[0]:
                 bad += 1
                 print(f"replay {i}: loss {float(eng.loss)} vs {ref[0]}, max |dgrad| / max|grad| = {d:.3e}")
-print(f"{wl} B={B}: {n} replays, {bad} outliers, worst relative gradient deviation {worst:.3e}")
-sys.exit(1 if bad else 0)
+H.call("vx_tape_set_fuzz", 0, 0.0, 0.0)
+print(f"{wl} B={B}: {'hybrid ' + ','.join(hybrid) + ': ' if hybrid is not None else ''}{n} replays{' (fuzzed: up to %g us in front of %g of the nodes)' % (fuzz[0], fuzz[1]) if fuzz[0] > 0 else ''}, {bad} outliers, {ndev} replays deviate by more than 5e-6, worst relative gradient deviation {worst:.3e}")
+sys.exit(1 if (bad or ndev) else 0)

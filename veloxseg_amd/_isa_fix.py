@@ -1,0 +1,126 @@
+"""Build-time work-around for a gfx950 register-read hazard (found in round 5: tools/pk_opsel_probe.hip).
+
+On MI355X a packed-fp32 VALU instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose op_sel bit for SRC1 is set -- the LOW result half reads the HIGH
+register of the second source pair -- computes that low half, in lanes 48-63, with the operand read as 0.0 whenever a wave of ANY kernel issues one of the
+128-bit-operand matrix instructions (v_mfma_f32_16x16x32_f16 / _bf16, v_mfma_f32_32x32x16_f16) on the same SIMD at that moment.  Alone, or beside fp32 / fp8 /
+K = 16 MFMAs, LDS traffic or packed VALU work, the same instruction is always right; op_sel on src0 or src2, op_sel_hi on any source, and the high half are never wrong.
+hipcc emits the form freely (a scalar that lives in the odd register of a 64-bit load, broadcast or swapped into a packed operation), e.g. for
+`float4(acc0 + b, acc1 + b, acc2 + b, acc3 + b)` in the epilogue of csrc/pwa_fused.hip vx_ln_pw_fwd_k -- which dropped the bias of rows 13 / 15 in a few tiles whenever
+the f16-pipe stem kernel ran on the other lane: the "timing-dependent hazard of the taped step" of round 4.
+
+The reference has no counterpart (it runs stock PyTorch kernels, one stream: utils/train_brats2021.py:235-239); this file is build infrastructure of the HIP library:
+
+* `scan(asm)`   -> the hazardous instructions of a device assembly listing (what `__graft_entry__.build()` asserts to be empty for every kernel it ships);
+* `fix(asm)`    -> the listing with every hazardous instruction rewritten: src0 <-> src1 swapped (with their op_sel / op_sel_hi / neg_lo / neg_hi bits) when both are
+                   VGPR pairs and src0's own op_sel bit is clear -- add, mul and the product of fma commute, op_sel on src0 is safe: zero cost -- otherwise split
+                   into the two scalar instructions of its halves (one more VALU issue).
+"""
+from __future__ import annotations
+
+import re
+from typing import List, Tuple
+
+_PK = re.compile(r"^(\s*)(v_pk_(?:add|mul|fma)_f32)\s+(.*?)\s*(;.*)?$")
+_MOD = re.compile(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]")
+_SCALAR = {"v_pk_add_f32": "v_add_f32_e64", "v_pk_mul_f32": "v_mul_f32_e64", "v_pk_fma_f32": "v_fma_f32"}
+
+
+def _parse(rest: str):
+    """'v[0:1], v[2:3], v[4:5] op_sel:[0,1] neg_lo:[1,0]' -> (operands, mods)"""
+    mods = {m.group(1): [int(x) for x in m.group(2).split(",")] for m in _MOD.finditer(rest)}
+    ops_part = _MOD.sub("", rest).strip()
+    extra = ""
+    ops = [o.strip() for o in ops_part.split(",") if o.strip()]
+    # anything left behind the last operand that is not a known modifier (clamp ...) makes the instruction unsupported
+    tail = ops[-1].split()
+    if len(tail) > 1:
+        ops[-1], extra = tail[0], " ".join(tail[1:])
+    return ops, mods, extra
+
+
+def _is_hazard(mods, nsrc) -> bool:
+    sel = mods.get("op_sel", [0] * nsrc)
+    return len(sel) > 1 and sel[1] == 1
+
+
+def scan(asm: str) -> List[Tuple[int, str]]:
+    out = []
+    for n, line in enumerate(asm.split("\n"), 1):
+        m = _PK.match(line)
+        if not m:
+            continue
+        ops, mods, _extra = _parse(m.group(3))
+        if _is_hazard(mods, len(ops) - 1):
+            out.append((n, line.strip()))
+    return out
+
+
+def _half(op: str, hi: int) -> str:
+    """the 32-bit register (or constant) a 64-bit operand supplies to one half"""
+    m = re.match(r"^([vsa])\[(\d+):(\d+)\]$", op)
+    if m:
+        return f"{m.group(1)}{int(m.group(2)) + hi}"
+    if op in ("vcc", "exec"):
+        return f"{op}_{'hi' if hi else 'lo'}"
+    return op                                  # inline constant: both halves read it
+
+
+def _fmt_mods(mods, order=("op_sel", "op_sel_hi", "neg_lo", "neg_hi"), nsrc=2) -> str:
+    parts = []
+    for k in order:
+        if k not in mods:
+            continue
+        v = mods[k]
+        default = [1] * nsrc if k == "op_sel_hi" else [0] * nsrc
+        if v != default:
+            parts.append(f"{k}:[{','.join(str(x) for x in v)}]")
+    return (" " + " ".join(parts)) if parts else ""
+
+
+def fix(asm: str):
+    """-> (fixed listing, {"swapped": n, "split": n})"""
+    out, stats = [], {"swapped": 0, "split": 0}
+    for line in asm.split("\n"):
+        m = _PK.match(line)
+        if not m:
+            out.append(line)
+            continue
+        indent, opc, rest = m.group(1), m.group(2), m.group(3)
+        ops, mods, extra = _parse(rest)
+        nsrc = len(ops) - 1
+        if not _is_hazard(mods, nsrc):
+            out.append(line)
+            continue
+        if extra:
+            raise RuntimeError(f"_isa_fix: unsupported modifier on a hazardous packed instruction: {line.strip()}")
+        dst, srcs = ops[0], ops[1:]
+        full = {k: list(mods.get(k, [1] * nsrc if k == "op_sel_hi" else [0] * nsrc)) for k in ("op_sel", "op_sel_hi", "neg_lo", "neg_hi")}
+        both_vgpr = all(re.match(r"^v\[\d+:\d+\]$", s) for s in srcs[:2])
+        if both_vgpr and full["op_sel"][0] == 0:
+            srcs[0], srcs[1] = srcs[1], srcs[0]
+            for k in full:
+                full[k][0], full[k][1] = full[k][1], full[k][0]
+            out.append(f"{indent}{opc} {dst}, {', '.join(srcs)}{_fmt_mods(full, nsrc=nsrc)}   ; _isa_fix: src0 <-> src1 (op_sel on src1 is hazardous beside 128-bit-operand MFMAs)")
+            stats["swapped"] += 1
+            continue
+        # split into the two halves
+        md = re.match(r"^v\[(\d+):(\d+)\]$", dst)
+        if not md:
+            raise RuntimeError(f"_isa_fix: cannot split {line.strip()}")
+        halves = []
+        for hi in (0, 1):
+            sel = full["op_sel_hi"] if hi else full["op_sel"]
+            neg = full["neg_hi"] if hi else full["neg_lo"]
+            rs = [("-" if neg[j] else "") + _half(srcs[j], sel[j]) for j in range(nsrc)]
+            halves.append((f"v{int(md.group(1)) + hi}", rs))
+        reads = lambda h: {r.lstrip("-") for r in h[1]}
+        order = [0, 1]
+        if halves[0][0] in reads(halves[1]):           # the high half reads what the low half writes: high half first
+            order = [1, 0]
+            if halves[1][0] in reads(halves[0]):
+                raise RuntimeError(f"_isa_fix: the halves of {line.strip()} read each other's destination (needs a temporary)")
+        for j in order:
+            d, rs = halves[j]
+            out.append(f"{indent}{_SCALAR[opc]} {d}, {', '.join(rs)}   ; _isa_fix: {'high' if j else 'low'} half of {opc} ... {_fmt_mods(mods, nsrc=nsrc).strip()}")
+        stats["split"] += 1
+    return "\n".join(out), stats

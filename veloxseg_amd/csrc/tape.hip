@@ -14,6 +14,8 @@
 #include "vx_common.h"
 #include "../../include/veloxseg_hip.h"
 #include <stdlib.h>
+#include <string.h>
+#include <malloc.h>
 #include <vector>
 #include <algorithm>
 #include <unordered_map>
@@ -552,6 +554,24 @@ extern "C" int vx_tape_info(const VxTape* T, int* n_nodes, int* n_kernels, int* 
     return 0;
 }
 
+// Schedule fuzzing (tests / tools/tape_soak.py): with probability `prob` a replay puts a 0 .. max_us spin kernel in front of a node on its lane, so that the lanes
+// drift against each other in a different way in every replay -- a dependency the tape does not carry then shows in tens of replays instead of thousands,
+// whatever the durations of the kernels around it happen to be.  Seeded (the sequence of delays is reproducible), off by default.
+static unsigned g_fuzz_state = 0;
+static float g_fuzz_max_us = 0.0f, g_fuzz_prob = 0.0f;
+static inline float fuzz_u01() { g_fuzz_state = g_fuzz_state * 1664525u + 1013904223u; return (float)(g_fuzz_state >> 8) * (1.0f / 16777216.0f); }
+extern "C" int vx_tape_set_fuzz(int seed, float max_us, float prob) {
+    VX_REQUIRE(max_us >= 0.0f && max_us <= 1e4f && prob >= 0.0f && prob <= 1.0f, "vx_tape_set_fuzz: max_us 0 .. 1e4, prob 0 .. 1");
+    g_fuzz_state = (unsigned)seed * 2654435761u + 12345u;
+    g_fuzz_max_us = max_us;
+    g_fuzz_prob = prob;
+    return 0;
+}
+static inline void fuzz_delay(hipStream_t s) {
+    if (g_fuzz_max_us > 0.0f && fuzz_u01() < g_fuzz_prob)
+        hipLaunchKernelGGL(vx_spin_k, dim3(1), dim3(64), 0, s, (long long)(fuzz_u01() * g_fuzz_max_us * 100.0f));
+}
+
 static int tape_launch(TapeNode& nd, hipStream_t s) {
     if (nd.type == T_KERNEL) {
         const hipKernelNodeParams& k = nd.k;
@@ -577,8 +597,9 @@ static int tape_launch(TapeNode& nd, hipStream_t s) {
     return 0;
 }
 
-static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq) {
+static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq, int limit = -1, bool tail = true) {
     const size_t L = T->lanes.size();
+    int ni = 0;
     if (L > 1) {
         if (fl) {
             if (T->last_s0 && T->last_s0 != s0) (void)hipStreamSynchronize(T->last_s0);      // another caller stream than last time (rare): its set kernel must not be overtaken
@@ -594,12 +615,14 @@ static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq) {
     // cross-lane dependencies: flag kernels (~2 us of queue time per hop) instead of event record + stream wait (~14 us: tools/event_hop_probe.py);
     // see the comment at vx_flag_set_k for why this cannot deadlock and when it is used
     for (TapeNode& nd : T->nodes) {
+        if (limit >= 0 && ni++ >= limit) break;            // (vx_tape_replay_prefix: the rest follows on the caller's stream after the join)
         hipStream_t s = T->lanes[nd.lane];
         for (int w : nd.waits) {
             const TapeNode& src = T->nodes[w];
             if (fl && src.flag >= 0) flag_wait(s, (const unsigned*)(T->flags + src.flag), seq);
             else HIPQ(hipStreamWaitEvent(s, src.ev, 0), "hipStreamWaitEvent");
         }
+        if (L > 1) fuzz_delay(s);
         if (nd.marker < 0) { int rc = tape_launch(nd, s); if (rc) return rc; }
         if (nd.marker >= 0 || (nd.record && !(fl && nd.flag >= 0))) HIPQ(hipEventRecord(nd.ev, s), "hipEventRecord");
         else if (nd.record) flag_set(s, T->flags + nd.flag, seq);
@@ -616,10 +639,21 @@ static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq) {
                     HIPQ(hipStreamWaitEvent(s0, T->lane_end[l], 0), "hipStreamWaitEvent");
                 }
             }
+    if (limit >= 0 && tail)
+        for (size_t i = (size_t)limit; i < T->nodes.size(); ++i)
+            if (T->nodes[i].marker < 0) { int rc = tape_launch(T->nodes[i], s0); if (rc) return rc; }
     return 0;
 }
 
-extern "C" int vx_tape_replay(VxTape* T, void* stream) {
+static int tape_replay_impl(VxTape* T, void* stream, int limit, bool tail);
+extern "C" int vx_tape_replay(VxTape* T, void* stream) { return tape_replay_impl(T, stream, -1, true); }      // (-1 = the whole tape)
+// diagnostics (tools/tape_memdiff.py): the first `k` nodes the way vx_tape_replay runs them (lanes, cross-lane waits), the lanes joined, then the remaining nodes one after
+// the other on the caller's stream -- a binary search over k finds the launch from which on a timing-dependent deviation exists
+extern "C" int vx_tape_replay_prefix(VxTape* T, void* stream, int k) {
+    VX_REQUIRE(T, "vx_tape_replay_prefix: bad arguments");
+    return tape_replay_impl(T, stream, k < 0 ? -k : k, k >= 0);            // (k < 0: the first -k nodes only, nothing after the join)
+}
+static int tape_replay_impl(VxTape* T, void* stream, int limit, bool tail) {
     VX_REQUIRE(T, "vx_tape_replay: null tape");
     if (T->nodes.empty()) return 0;
     if (int nto = vx_tape_flag_timeouts()) VX_FAIL(-3, "vx_tape_replay: %d cross-lane poll(s) of an earlier replay gave up after the flag timeout (results of that step are not trustworthy)", nto);
@@ -633,7 +667,7 @@ extern "C" int vx_tape_replay(VxTape* T, void* stream) {
     }
     const bool fl = flags_ok() && T->flags != nullptr;
     const unsigned seq = ++T->seq;
-    const int rc = tape_replay_body(T, s0, fl, seq);
+    const int rc = tape_replay_body(T, s0, fl, seq, limit, tail);
     if (rc != 0 && fl) {
         // a launch failed half-way: polls may already be queued whose set kernels never will be.  Release them (every word of this tape >= seq) from a
         // stream of its own, so that the queues drain instead of spinning into the timeout.
@@ -696,6 +730,52 @@ extern "C" int vx_tape_profile(VxTape* T, void* stream, int reps, float* us) {
         }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// One node of the tape on `stream` (markers launch nothing): the building block of the serial re-ordering audit (veloxseg_amd/tape_audit.py), which launches the
+// nodes of a step one after the other on ONE stream in a random order that respects lane order + cross-lane waits -- every such order must give the same result.
+extern "C" int vx_tape_launch_node(VxTape* T, int i, void* stream) {
+    VX_REQUIRE(T && i >= 0 && i < (int)T->nodes.size(), "vx_tape_launch_node: bad arguments");
+    TapeNode& nd = T->nodes[i];
+    if (nd.marker >= 0) return 0;
+    return tape_launch(nd, (hipStream_t)stream);
+}
+// Raw bytes of launch parameter k of kernel node i (memset nodes: k = 0 -> {dst, width * elementSize} as two 8-byte words).  The graph node owns one host allocation per
+// parameter and HIP does not expose the sizes: at most malloc_usable_size() bytes are copied (an upper bound of the parameter's size), *got = how many.  The caller knows
+// the parameter list from the kernel's (demangled) name: veloxseg_amd/tape_audit.py node_pointers().
+extern "C" int vx_tape_node_param(const VxTape* T, int i, int k, void* out, int cap, int* got) {
+    VX_REQUIRE(T && out && got && cap > 0 && k >= 0 && i >= 0 && i < (int)T->nodes.size(), "vx_tape_node_param: bad arguments");
+    const TapeNode& nd = T->nodes[i];
+    *got = 0;
+    if (nd.type == T_MEMSET) {
+        VX_REQUIRE(k == 0 && cap >= 16, "vx_tape_node_param: a memset node has one pseudo parameter of 16 bytes");
+        unsigned long long v[2] = {(unsigned long long)nd.ms.dst, (unsigned long long)nd.ms.width * nd.ms.elementSize};
+        memcpy(out, v, 16);
+        *got = 16;
+        return 0;
+    }
+    if (nd.type != T_KERNEL || !nd.k.kernelParams || !nd.k.kernelParams[k]) return 0;
+    const size_t us = malloc_usable_size(nd.k.kernelParams[k]);
+    const size_t n = us < (size_t)cap ? us : (size_t)cap;
+    memcpy(out, nd.k.kernelParams[k], n);
+    *got = (int)n;
+    return 0;
+}
+/* 0 kernel, 1 memset, 2 copy (one-node graph), 3 marker */
+extern "C" int vx_tape_node_kind(const VxTape* T, int i) {
+    if (!T || i < 0 || i >= (int)T->nodes.size()) return -1;
+    return T->nodes[i].marker >= 0 ? 3 : T->nodes[i].type;
+}
+
+/* waits[i * stride + w]: the nodes (on other lanes) node i waits for, -1 padded */
+extern "C" int vx_tape_waits(const VxTape* T, int* waits, int stride) {
+    VX_REQUIRE(T && waits && stride >= 1, "vx_tape_waits: bad arguments");
+    for (size_t i = 0; i < T->nodes.size(); ++i) {
+        const TapeNode& nd = T->nodes[i];
+        VX_REQUIRE((int)nd.waits.size() <= stride, "vx_tape_waits: node %d waits for %d nodes, stride %d", (int)i, (int)nd.waits.size(), stride);
+        for (int w = 0; w < stride; ++w) waits[i * stride + w] = w < (int)nd.waits.size() ? nd.waits[w] : -1;
+    }
     return 0;
 }
 
