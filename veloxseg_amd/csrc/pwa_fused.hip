@@ -17,7 +17,6 @@
 // LayerNorm over the channel axis runs on the LDS tile (two-pass mean / variance as the reference's u = mean, s = mean((x - u)^2)).
 // Dropout masks are those of the per-operator kernels (element index of the (B, C, V) tensor of that site; vx_common.h), GELU is vx_cdf_pdf.
 #include "vx_common.h"
-#include <stdlib.h>
 #include "../../include/veloxseg_hip.h"
 
 typedef float vx_f32x4 __attribute__((ext_vector_type(4)));
@@ -227,7 +226,7 @@ __device__ __forceinline__ void stage_vec(float* __restrict__ dst, const float* 
     for (int i = threadIdx.x; i < n; i += 64 * NW) dst[i] = src ? src[i] : fill;
 }
 
-template <int T, int NW, int VAR = 0>
+template <int T, int NW>
 __global__ void __launch_bounds__(64 * NW) vx_ln_pw_fwd_k(VxLnPw p) {
     constexpr int NT = Geo<T>::NT, S = Geo<T>::S, NP = 64 * NW / NT;
     extern __shared__ __attribute__((aligned(16))) float vx_pf_lds[];
@@ -275,15 +274,9 @@ __global__ void __launch_bounds__(64 * NW) vx_ln_pw_fwd_k(VxLnPw p) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = 16 * mt + 4 * q + reg;
-                const float bb = VAR == 3 ? (M.b[sg] ? M.b[sg][m] : 0.0f) : bias[m];
+                const float bb = bias[m];
                 if constexpr (T == 4) {
                     const long v = v0 + 4 * r;
-                    if constexpr (VAR == 1) {
-                        float o[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) asm volatile("v_add_f32 %0, %1, %2" : "=v"(o[j]) : "v"(acc[j][reg]), "v"(bb));
-                        if (v < V) *reinterpret_cast<float4*>(out + (long)m * V + v) = make_float4(o[0], o[1], o[2], o[3]);
-                    } else
                     if (v < V) *reinterpret_cast<float4*>(out + (long)m * V + v) = make_float4(acc[0][reg] + bb, acc[1][reg] + bb, acc[2][reg] + bb, acc[3][reg] + bb);
                 } else {
                     const long v = v0 + r;
@@ -692,11 +685,7 @@ extern "C" int vx_ln_pw_fwd(const void* const* ptrs, int M, int NS, const int* J
     int Jt = 0;
     for (int s = 0; s < NS; ++s) Jt += J[s];
     const size_t extra = 2 * C + Jt;                      // gamma, beta, biases
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("VX_LNPW_VARIANT"); var = e ? atoi(e) : 0; }
-    if (T == 4 && var == 1) pf_launch<4, 4>(vx_ln_pw_fwd_k<4, 4, 1>, p, grid, ((size_t)C * S + 4 * 64 + extra) * sizeof(float), st);
-    else if (T == 4 && var == 3) pf_launch<4, 4>(vx_ln_pw_fwd_k<4, 4, 3>, p, grid, ((size_t)C * S + 4 * 64 + extra) * sizeof(float), st);
-    else if (T == 4) pf_launch<4, 4>(vx_ln_pw_fwd_k<4, 4>, p, grid, ((size_t)C * S + 4 * 64 + extra) * sizeof(float), st);
+    if (T == 4) pf_launch<4, 4>(vx_ln_pw_fwd_k<4, 4>, p, grid, ((size_t)C * S + 4 * 64 + extra) * sizeof(float), st);
     else if (pf_nw(blocks * M) == 8) pf_launch<1, 8>(vx_ln_pw_fwd_k<1, 8>, p, grid, ((size_t)C * S + 32 * 16 + extra) * sizeof(float), st);
     else pf_launch<1, 4>(vx_ln_pw_fwd_k<1, 4>, p, grid, ((size_t)C * S + 16 * 16 + extra) * sizeof(float), st);
     VX_LAUNCH_CHECK("vx_ln_pw_fwd");

@@ -230,27 +230,55 @@ class StepDag:
         return v, u, moved(hi2), moved(lo2)
 
 
-def serial_audit(engine, seeds: Sequence[int], tol: float = 5e-6, verbose: bool = False, bisect: bool = True, exhaustive: bool = False):
-    """Run the step once in tape order and once per seed in a random admissible order, all on the current stream; compare loss and flat gradient.
-    exhaustive: additionally one order per launch of the step (StepDag.early: that launch as early as its dependencies allow), which flips every unordered pair.
-    Returns (findings, noise): findings = dicts with seed (or node), deviation and -- after bisection -- the unordered pair; empty = every order agrees."""
+def make_runner(engine, dag: "StepDag", scramble: bool = True):
+    """run(order) -> (loss, flat gradient clone): the step launched in `order` on the current stream from the engine's inputs and the dropout state at the time of
+    this call.  scramble: first the SAME step in tape order on different inputs (volume and labels flipped, another dropout seed) -- every buffer of the step then holds
+    the values of another sample, so a launch that runs before its producer reads something that is visibly not its input.  (Replays of identical inputs hide exactly
+    that class of hazard: what the late producer would write is already there from the replay before.)"""
     from . import functional as VF
-    dag = StepDag(engine)
     rng = VF.rng_state(engine.dev)
     rng0 = rng.clone()
+    x0, lab0 = engine.x.clone(), engine.labels.clone()
+    x1, lab1 = x0.flip(2).contiguous(), lab0.flip(2).contiguous()
+    rng1 = rng0.clone()
+    rng1[0] += 12345
+    ident = dag.identity()
 
     def run(order):
+        if scramble:
+            engine.x.copy_(x1)
+            engine.labels.copy_(lab1)
+            rng.copy_(rng1)
+            dag.launch(ident)
+            engine.x.copy_(x0)
+            engine.labels.copy_(lab0)
         rng.copy_(rng0)
         dag.launch(order)
         torch.cuda.synchronize()
         return float(engine.loss), engine.flat.grad.clone()
+
+    def restore():
+        engine.x.copy_(x0)
+        engine.labels.copy_(lab0)
+        rng.copy_(rng0)
+    run.restore = restore
+    return run
+
+
+def serial_audit(engine, seeds: Sequence[int], tol: float = 5e-6, verbose: bool = False, bisect: bool = True, exhaustive: bool = False, scramble: bool = True):
+    """Run the step once in tape order and once per seed in a random admissible order, all on the current stream; compare loss and flat gradient.
+    exhaustive: additionally one order per launch of the step (StepDag.early: that launch as early as its dependencies allow), which flips every unordered pair.
+    scramble: see make_runner (on by default).
+    Returns (findings, noise): findings = dicts with seed (or node), deviation and -- after bisection -- the unordered pair; empty = every order agrees."""
+    dag = StepDag(engine)
+    run = make_runner(engine, dag, scramble)
     ref_loss, ref = run(dag.identity())
     scale = float(ref.abs().max())
     noise = float((run(dag.identity())[1] - ref).abs().max()) / scale          # float-atomic noise of the same order twice
 
     def dev_of(order):
         loss, g = run(order)
-        return max(float((g - ref).abs().max()) / scale, 0.0 if loss == ref_loss else 1.0)
+        return max(float((g - ref).abs().max()) / scale, 0.0 if abs(loss - ref_loss) <= 1e-6 * abs(ref_loss) else 1.0)
     findings = []
     todo = [("seed", int(s)) for s in seeds]
     anc = None
@@ -277,7 +305,7 @@ def serial_audit(engine, seeds: Sequence[int], tol: float = 5e-6, verbose: bool 
             findings.append(f)
             if verbose:
                 print(f"[tape audit]   -> {f}", flush=True)
-    rng.copy_(rng0)
+    run.restore()
     return findings, noise
 
 
