@@ -213,6 +213,17 @@ int vx_jlc_wgrad_tz_set_min_voxels(long v);
 int vx_jlc_wgrad_tz_set_f16(int on);     /* with vx_jlc_tz_set_pieces(22): 1 = the weight gradients on two scaled fp16 pieces as well (A/B; default 0 = three bf16 pieces) */
 int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
                     void* stream);
+/* the same entries with the pieces mode of the operand image given explicitly: the image is laid out for the mode in force when vx_jlc_tz_prep built it, and its
+ * consumers (input gradient, deferred weight gradients) must use that mode whatever the process-wide switch says by then (operator code records vx_jlc_tz_pieces()
+ * at forward time).  Reference: the three grouped convolutions of conv_blocks.py:51-58 and their autograd. */
+int vx_jlc_tz_img_floats_ns(int C, int G, int pieces);
+int vx_jlc_tz_prep_ns(const float* w1, const float* w3, const float* w5, float* img, int C, int G, int pieces, void* stream);
+int vx_jlc_tz_fwd_ns(const float* x, const float* img, const float* b1, const float* b3, const float* b5, float* y1, float* y3, float* y5, double* part,
+                     int B, int C, int G, int D, int H, int W, int pieces, void* stream);
+int vx_jlc_tz_bwd_ns(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
+                     int B, int C, int G, int D, int H, int W, int pieces, void* stream);
+int vx_jlc_wgrad_tz_ns(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                       int pieces, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,

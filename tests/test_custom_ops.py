@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 
 def test_ops_are_registered_and_have_no_cpu_kernel():
+    from veloxseg_amd import functional as VF
+    if VF.cpp_module() is None and os.environ.get("VELOXSEG_NO_CPP") != "1":
+        pytest.skip("the C++ operator module is not built on this box")
     import veloxseg_amd.ops as O
     for name in O.OPS:
         op = getattr(torch.ops.veloxseg, name)

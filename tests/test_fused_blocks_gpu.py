@@ -196,6 +196,38 @@ TZ_CASES = [
 ]
 
 
+def test_jlc_block_backward_uses_the_pieces_mode_of_its_forward():
+    """the operand image of a JLC block is laid out for the pieces mode in force at its forward; if the process-wide switch changes before the backward (another
+    engine's precision, an A/B knob), the input gradient and the deferred weight gradients must still read it with the forward's mode (JLCFusedState.tz_pieces,
+    vx_jlc_tz_bwd_ns / vx_jlc_wgrad_tz_ns) -- before, the backward indexed the image with the new mode's stride."""
+    import veloxseg_amd.functional as VF
+    from veloxseg_amd import _hip as H
+    from veloxseg_amd.model.components.conv_blocks import JLC
+    if VF.cpp_module() is None:
+        pytest.skip("C++ operator module not built")
+    H.LIB.load()
+
+    def grads(switch):
+        torch.manual_seed(3)
+        m = JLC(16, groups=4).cuda().train()
+        x = torch.randn(2, 16, 16, 16, 16, device="cuda", requires_grad=True)
+        H.call("vx_jlc_tz_set_min_voxels", 0)
+        H.call("vx_jlc_tz_set_pieces", 22)
+        y = m(x)
+        if switch:
+            H.call("vx_jlc_tz_set_pieces", 3)            # (image stride 3 pieces instead of 2)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+    try:
+        a, b = grads(False), grads(True)
+        for u, v in zip(a, b):
+            assert torch.allclose(u, v, rtol=1e-5, atol=1e-6 * float(u.abs().max())), float((u - v).abs().max())
+    finally:
+        H.call("vx_jlc_tz_set_pieces", 22)
+        H.call("vx_jlc_tz_set_min_voxels", 1024)
+
+
 @pytest.mark.parametrize("pieces", [3, 22, 1])
 @pytest.mark.parametrize("case", TZ_CASES, ids=[c[0] for c in TZ_CASES])
 def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
@@ -256,7 +288,7 @@ def test_jlc_toeplitz_mfma_convs_vs_fp64_and_valu_kernels(case, pieces):
         else:
             assert e_new <= 2e-2, e_new
     finally:
-        H.call("vx_jlc_tz_set_pieces", 3)
+        H.call("vx_jlc_tz_set_pieces", 22)          # (the library default)
         H.call("vx_jlc_tz_set_min_voxels", 1024)
 
 
@@ -360,5 +392,5 @@ def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, piece
             else:
                 assert e_new <= 2e-2, (k, e_new)
     finally:
-        H.call("vx_jlc_tz_set_pieces", 3)
+        H.call("vx_jlc_tz_set_pieces", 22)          # (the library default)
         H.call("vx_jlc_wgrad_tz_set_f16", 0)

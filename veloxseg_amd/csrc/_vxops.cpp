@@ -533,6 +533,7 @@ inline Tensor sum3(const Tensor& a, const Tensor& b, const Tensor& c, void* stre
 struct JLCFusedState {
     Tensor x, y, o, stats_y, stats_o;            // y: (3, B, C, D, H, W) = the three conv outputs
     bool img_cl = false;                         // ... of csrc/jlc_cl.hip (coarse levels) instead
+    int tz_pieces = 0;                           // the pieces mode `img` was built for (vx_jlc_tz_pieces() at forward time): the backward and the deferred weight gradients use it
     Tensor img;                                  // operand images of the three weight tensors (vx_jlc_tz_prep) when the convolutions ran on jlc_mfma.hip
     Tensor w1, w3, w5, b1, b3, b5, l1w, l1b, l2w, l2b;
     int B = 0, C = 0, G = 0, D = 0, H = 0, W = 0, R = 0, nch = 0;
@@ -943,9 +944,10 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 float* yp = f.y.data_ptr<float>();
                 const long n1 = BC * V;
                 if (tz) {
-                    f.img = at::empty({(long)vx_jlc_tz_img_floats(C, G)}, f.x.options());
-                    VX(vx_jlc_tz_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
-                    VX(vx_jlc_tz_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
+                    f.tz_pieces = vx_jlc_tz_pieces();
+                    f.img = at::empty({(long)vx_jlc_tz_img_floats_ns(C, G, f.tz_pieces)}, f.x.options());
+                    VX(vx_jlc_tz_prep_ns, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, f.tz_pieces, s_);
+                    VX(vx_jlc_tz_fwd_ns, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, f.tz_pieces, s_);
                 } else if (cl) {
                     f.img = at::empty({(long)vx_jlc_cl_img_floats(C, G)}, f.x.options());
                     f.img_cl = true;
@@ -1025,7 +1027,7 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             if (need_x) {
                 dx = dn;                                      // dn is dead after vx_jlc_mid_bwd: reuse its storage
                 if (f.img.defined() && f.img_cl) VX(vx_jlc_cl_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
-                else if (f.img.defined()) VX(vx_jlc_tz_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                else if (f.img.defined()) VX(vx_jlc_tz_bwd_ns, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, f.tz_pieces, s_);
                 else
                 VX(vx_jlc_conv_bwd, gp, gp + n1, gp + 2 * n1, fp(f.w1), fp(f.w3), fp(f.w5), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
             }
@@ -1040,10 +1042,11 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
                 float* dw5 = f.w5.requires_grad() ? grad_ptr(f.w5) : nullptr;
                 const bool g1fast = F.use_gconv1 && (Cg == 4 || Cg == 8 || Cg == 16) && V % 4 == 0;
                 const bool wtz = F.jlc_wg_tz && dw1 && dw3 && dw5 && vx_jlc_wgrad_tz_ok(C, G, D, H, W);
+                const int wg_pieces = f.tz_pieces ? f.tz_pieces : vx_jlc_tz_pieces();          // fixed NOW: the closure may be launched at the end of the encoder backward
                 wgrad_submit(s_, f.x.device().index(), [=](void* s) {
                     const float* gq = gk.data_ptr<float>();
                     if (wtz) {                    // all three weight gradients in one launch on the matrix pipe (csrc/jlc_mfma.hip)
-                        VX(vx_jlc_wgrad_tz, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, s);
+                        VX(vx_jlc_wgrad_tz_ns, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, wg_pieces, s);
                         return;
                     }
                     if (dw1) {

@@ -357,7 +357,7 @@ static ClHalo cl_halo(int D, int H, int W, int P) {
     return h;
 }
 static bool cl_plan(VxCl& p, int B, int C, int G, int D, int H, int W, int& tpw, size_t& shm_f, size_t& shm_b) {
-    if (!g_cl_enabled || B <= 0 || G <= 0 || C % G != 0) return false;
+    if (B <= 0 || G <= 0 || C % G != 0) return false;      // (the enable switch gates vx_jlc_cl_ok only: a block whose forward ran here finishes its backward here)
     const int CG = C / G;
     if ((CG != 8 && CG != 16) || D < 1 || H < 1 || W < 1 || D > 8 || H > 8 || W > 8) return false;
     p.B = B; p.C = C; p.G = G; p.D = D; p.H = H; p.W = W; p.V = D * H * W;
@@ -373,7 +373,7 @@ static bool cl_plan(VxCl& p, int B, int C, int G, int D, int H, int W, int& tpw,
 extern "C" int vx_jlc_cl_set_enabled(int on) { g_cl_enabled = on ? 1 : 0; return 0; }
 extern "C" int vx_jlc_cl_ok(int C, int G, int D, int H, int W) {
     VxCl p; int tpw; size_t sf, sb;
-    return cl_plan(p, 1, C, G, D, H, W, tpw, sf, sb) ? 1 : 0;
+    return (g_cl_enabled && cl_plan(p, 1, C, G, D, H, W, tpw, sf, sb)) ? 1 : 0;
 }
 extern "C" int vx_jlc_cl_ntiles(int C, int G, int D, int H, int W) {
     VxCl p; int tpw; size_t sf, sb;

@@ -602,7 +602,14 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
 // ------------------------------------------------------------------------------------------------------------------ host
 static unsigned tz_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / (unsigned long long)d); }      // see tz_divm
 
-static int g_tz_pieces = 3;
+static int g_tz_pieces = 22;                  // (the mode functional.set_precision("fp32") installs: the default does not depend on whether that was ever called)
+// The operand image of a block (vx_jlc_tz_prep) is laid out for the mode in force when it was built; its consumers -- the input gradient, possibly much later the
+// deferred weight gradients -- must use THAT mode, not whatever the process-wide switch says by then: the *_ns entries take it as an argument, the operator
+// code records it in its state at forward time.  (thread-local override: the bodies below read tz_pieces().)
+static thread_local int t_tz_pieces = 0;
+static inline int tz_pieces() { return t_tz_pieces ? t_tz_pieces : g_tz_pieces; }
+namespace { struct TzPiecesScope { int prev; explicit TzPiecesScope(int ns) : prev(t_tz_pieces) { t_tz_pieces = ns; } ~TzPiecesScope() { t_tz_pieces = prev; } }; }
+static inline bool tz_pieces_valid(int ns) { return (ns >= 1 && ns <= 3) || ns == 22; }
 static int g_tz_dbg = 0;
 extern "C" int vx_jlc_tz_set_debug(int mask) { g_tz_dbg = mask; return 0; }
 // 3 / 2 / 1 bf16 pieces per fp32 operand (6 / 3 / 1 piece products), or 22 = two scaled fp16 pieces (22 significant bits, 3 piece products)
@@ -700,12 +707,12 @@ extern "C" int vx_jlc_tz_ok(int C, int G, int D, int H, int W) {
     VxTz p = {};
     TzPlan pl;
     if ((long)D * H * W < g_tz_min_v) return 0;
-    return tz_plan(p, pl, 1, C, G, D, H, W, g_tz_pieces) == 0 ? 1 : 0;
+    return tz_plan(p, pl, 1, C, G, D, H, W, tz_pieces()) == 0 ? 1 : 0;
 }
 extern "C" int vx_jlc_tz_ntiles(int C, int G, int D, int H, int W) {
     VxTz p = {};
     TzPlan pl;
-    if (tz_plan(p, pl, 1, C, G, D, H, W, g_tz_pieces) != 0) return -1;
+    if (tz_plan(p, pl, 1, C, G, D, H, W, tz_pieces()) != 0) return -1;
     return p.nTd * p.nTh * p.nTw;
 }
 // uint4 elements of ONE direction's image (+ one spare entry for the operand prefetch); the workspace of vx_jlc_tz_prep holds two (forward, input gradient)
@@ -714,20 +721,20 @@ static long tz_img_elems(int C, int G, int pieces) {
     const int CG = C / G, MT = CG / 4;
     return (long)G * 35 * MT * MT * NS * 64 + (long)2 * MT * MT * NS * 64;        // + two spare entries: the operand FIFO reads two steps ahead
 }
-extern "C" int vx_jlc_tz_img_floats(int C, int G) { return (int)(2 * tz_img_elems(C, G, g_tz_pieces) * 4 + ((3 * G + 3) & ~3)); }       // + the scale exponents of the fp16 mode
+extern "C" int vx_jlc_tz_img_floats(int C, int G) { return (int)(2 * tz_img_elems(C, G, tz_pieces()) * 4 + ((3 * G + 3) & ~3)); }       // + the scale exponents of the fp16 mode
 
 extern "C" int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5, float* img, int C, int G, void* stream) {
     VX_REQUIRE(w1 && w3 && w5 && img && G > 0 && C % G == 0, "vx_jlc_tz_prep: bad args");
-    const int CG = C / G, NS = tz_ns(g_tz_pieces);
+    const int CG = C / G, NS = tz_ns(tz_pieces());
     VX_REQUIRE(CG == 4 || CG == 8 || CG == 16, "vx_jlc_tz_prep: group width %d", CG);
-    const long ne = tz_img_elems(C, G, g_tz_pieces);
+    const long ne = tz_img_elems(C, G, tz_pieces());
     uint4* f = reinterpret_cast<uint4*>(img);
     uint4* bw = f + ne;
     const int MT = CG / 4;
     const long total = (long)G * 35 * MT * MT * 64;
     const dim3 grid((unsigned)vx_cdiv(total, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (g_tz_pieces == 22) {
+    if (tz_pieces() == 22) {
         float* esc = img + 2 * ne * 4;
         const dim3 g16((unsigned)vx_cdiv((long)G * 35 * MT * MT, 4));
         vx_tz_wmax_k<<<dim3((unsigned)G, 3), dim3(256), 0, st>>>(w1, w3, w5, esc, CG);
@@ -772,13 +779,13 @@ extern "C" int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, 
     VX_REQUIRE(x && img && y1 && y3 && y5 && part, "vx_jlc_tz_fwd: null pointer");
     VxTz p = {};
     TzPlan pl;
-    const int NS = tz_ns(g_tz_pieces);
-    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, g_tz_pieces) == 0, "vx_jlc_tz_fwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    const int NS = tz_ns(tz_pieces());
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, tz_pieces()) == 0, "vx_jlc_tz_fwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.src[0] = x; p.img = reinterpret_cast<const uint4*>(img);
-    p.esc = img + 2 * tz_img_elems(C, G, g_tz_pieces) * 4;
+    p.esc = img + 2 * tz_img_elems(C, G, tz_pieces()) * 4;
     p.bias[0] = b5; p.bias[1] = b3; p.bias[2] = b1;
     p.out[0] = y5; p.out[1] = y3; p.out[2] = y1; p.part = part; p.dbg = g_tz_dbg;
-    const int rc = g_tz_pieces == 22 ? tz_launch<2, false, true>(p, pl, (hipStream_t)stream)
+    const int rc = tz_pieces() == 22 ? tz_launch<2, false, true>(p, pl, (hipStream_t)stream)
                    : NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_fwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_fwd");
@@ -790,13 +797,13 @@ extern "C" int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, 
     VX_REQUIRE(g1 && g3 && g5 && img && w1 && d_o && dx, "vx_jlc_tz_bwd: null pointer");
     VxTz p = {};
     TzPlan pl;
-    const int NS = tz_ns(g_tz_pieces);
-    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, g_tz_pieces) == 0, "vx_jlc_tz_bwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    const int NS = tz_ns(tz_pieces());
+    VX_REQUIRE(tz_plan(p, pl, B, C, G, D, H, W, tz_pieces()) == 0, "vx_jlc_tz_bwd: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.src[0] = g5; p.src[1] = g3; p.src[2] = g1;
-    p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, g_tz_pieces);
-    p.esc = img + 2 * tz_img_elems(C, G, g_tz_pieces) * 4;
+    p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, tz_pieces());
+    p.esc = img + 2 * tz_img_elems(C, G, tz_pieces()) * 4;
     p.w1 = w1; p.res = d_o; p.out[0] = dx; p.dbg = g_tz_dbg;
-    const int rc = g_tz_pieces == 22 ? tz_launch<2, true, true>(p, pl, (hipStream_t)stream)
+    const int rc = tz_pieces() == 22 ? tz_launch<2, true, true>(p, pl, (hipStream_t)stream)
                    : NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_bwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_bwd");
@@ -1237,7 +1244,7 @@ extern "C" int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W) {
     size_t shm;
     if (g_wg_min_v < 0) { const char* e = getenv("VELOXSEG_WG_TZ_MIN_V"); g_wg_min_v = e ? atol(e) : 0; }
     if ((long)D * H * W < g_wg_min_v) return 0;
-    return wg_plan(p, shm, 1, C, G, D, H, W, g_tz_pieces == 22 ? 3 : g_tz_pieces) == 0 ? 1 : 0;
+    return wg_plan(p, shm, 1, C, G, D, H, W, tz_pieces() == 22 ? 3 : tz_pieces()) == 0 ? 1 : 0;
 }
 
 extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
@@ -1250,8 +1257,8 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
     // saves.  VELOXSEG_WG_TZ_F16=1 selects it (A/B, tests); default: three bf16 pieces.
     static int wg16 = -1;
     if (wg16 < 0) { const char* e = getenv("VELOXSEG_WG_TZ_F16"); wg16 = (e && e[0] == '1') ? 1 : 0; }
-    const bool f16 = g_tz_pieces == 22 && (wg16 == 1 || g_wg_f16 == 1);
-    const int NS = f16 ? 2 : (g_tz_pieces == 22 ? 3 : g_tz_pieces);
+    const bool f16 = tz_pieces() == 22 && (wg16 == 1 || g_wg_f16 == 1);
+    const int NS = f16 ? 2 : (tz_pieces() == 22 ? 3 : tz_pieces());
     VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.x = x; p.g1 = g1; p.g3 = g3; p.g5 = g5; p.dw1 = dw1; p.dw3 = dw3; p.dw5 = dw5; p.dbg = g_tz_dbg >> 4;
     const int MT = p.CG / 4;
@@ -1276,4 +1283,34 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
 #undef WG_LAUNCH
     VX_LAUNCH_CHECK("vx_jlc_wgrad_tz");
     return 0;
+}
+
+// ---- the same entries with the pieces mode of the operand image given explicitly (see t_tz_pieces)
+extern "C" int vx_jlc_tz_img_floats_ns(int C, int G, int pieces) {
+    if (!tz_pieces_valid(pieces)) return -1;
+    TzPiecesScope sc(pieces);
+    return vx_jlc_tz_img_floats(C, G);
+}
+extern "C" int vx_jlc_tz_prep_ns(const float* w1, const float* w3, const float* w5, float* img, int C, int G, int pieces, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_prep_ns: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    return vx_jlc_tz_prep(w1, w3, w5, img, C, G, stream);
+}
+extern "C" int vx_jlc_tz_fwd_ns(const float* x, const float* img, const float* b1, const float* b3, const float* b5, float* y1, float* y3, float* y5, double* part,
+                                int B, int C, int G, int D, int H, int W, int pieces, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_fwd_ns: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    return vx_jlc_tz_fwd(x, img, b1, b3, b5, y1, y3, y5, part, B, C, G, D, H, W, stream);
+}
+extern "C" int vx_jlc_tz_bwd_ns(const float* g1, const float* g3, const float* g5, const float* img, const float* w1, const float* d_o, float* dx,
+                                int B, int C, int G, int D, int H, int W, int pieces, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_bwd_ns: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    return vx_jlc_tz_bwd(g1, g3, g5, img, w1, d_o, dx, B, C, G, D, H, W, stream);
+}
+extern "C" int vx_jlc_wgrad_tz_ns(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                                  int pieces, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_wgrad_tz_ns: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    return vx_jlc_wgrad_tz(x, g1, g3, g5, dw1, dw3, dw5, B, C, G, D, H, W, stream);
 }

@@ -495,11 +495,17 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     return 0;
 }
 
-// workspace (floats) of vx_seg_loss_ds_bwd: the (B, C, D x row parts, h, w) partial gradients of heads 1.. (sized for the largest split)
+// workspace (floats) of vx_seg_loss_ds_bwd: the (B, C, D x row parts, h, w) partial gradients of heads 1.., sized for the ACTIVE split (resolved once per process:
+// 1 by default; VELOXSEG_DS_BWD_SPLIT is an A/B knob that measured slower overall -- sizing for its maximum held 8 x the memory inside the capture pools)
 #define VX_DS_MAX_SPLIT 8
+static int ds_bwd_split() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VELOXSEG_DS_BWD_SPLIT"); const int u = e ? atoi(e) : 1; v = (u >= 1 && u <= VX_DS_MAX_SPLIT) ? u : 1; }
+    return v;
+}
 extern "C" int vx_seg_loss_ds_ws_floats(const int* low_dims, int nh, int B, int C, int D) {
     long n = 0;
-    for (int hh = 0; hh < nh - 1; ++hh) n += (long)B * C * D * VX_DS_MAX_SPLIT * low_dims[3 * hh + 1] * low_dims[3 * hh + 2];
+    for (int hh = 0; hh < nh - 1; ++hh) n += (long)B * C * D * ds_bwd_split() * low_dims[3 * hh + 1] * low_dims[3 * hh + 2];
     VX_REQUIRE(n < 0x7fffffffL, "vx_seg_loss_ds_ws_floats: workspace too large");
     return (int)n;
 }
@@ -522,7 +528,7 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
         for (int k = 0; k < 3; ++k) Zp.ld[hh][k] = P.ld[hh][k];
         Zp.n[hh] = (long)B * C * P.ld[hh][0] * P.ld[hh][1] * P.ld[hh][2];
         total += Zp.n[hh];
-        off += (long)B * C * D * VX_DS_MAX_SPLIT * P.ld[hh][1] * P.ld[hh][2];
+        off += (long)B * C * D * ds_bwd_split() * P.ld[hh][1] * P.ld[hh][2];
         nacc += C * P.ld[hh][1] * P.ld[hh][2];          // (two classes + staged slices: the kernel uses half of it)
     }
     const int RPW = 64 / (W >> 2);
@@ -530,7 +536,8 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
     // 128^3 x 4 patch is 512 blocks = 2 waves per SIMD and the kernel waits on its LDS round trips (198 us); every part keeps >= 2 steps of 4 waves x RPW rows
     P.nsplit = 1;
     // (measured, 128^3 x 4: 1 / 4 parts = 181 / 158 us, but the D adjoint behind it then reads 4 x the partial sums: 20 -> 57 us -- the default stays at one part)
-    if (const char* e = getenv("VELOXSEG_DS_BWD_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= VX_DS_MAX_SPLIT && H / v >= 1) P.nsplit = v; }
+    if (H / ds_bwd_split() >= 1) P.nsplit = ds_bwd_split();          // (the workspace above is laid out for exactly this many parts)
+    else VX_FAIL(-1, "vx_seg_loss_ds_bwd: VELOXSEG_DS_BWD_SPLIT=%d exceeds the %d rows of a slice", ds_bwd_split(), H);
     Zp.nlow = nh - 1; Zp.BC = B * C; Zp.D = D; Zp.nsplit = P.nsplit;
     size_t ntab = 0;
     for (int hh = 0; hh < nh - 1; ++hh) {

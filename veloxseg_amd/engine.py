@@ -375,7 +375,15 @@ class TrainEngine:
             # Data parallel: the start gate of step N+1's tapes is set behind AdamW(N), which waits for all-reduce(N) -- i.e. for the slowest PEER (data loader,
             # rank-0 checkpoint, capture skew).  Collective latency must not count against the cross-lane poll timeout (a poll that gives up lets the kernels
             # behind it run on an unmet dependency); the process group's own timeout / RCCL watchdog bounds a peer that never arrives.
-            H.call("vx_tape_set_flag_timeout_ms", 0)
+            # (not "never" -- a lost cross-lane flag must still surface through vx_tape_flag_timeouts / _check_flag_timeouts instead of spinning for ever,
+            # gloo has no watchdog; the user's VELOXSEG_TAPE_FLAG_TIMEOUT_MS wins, and engines that replay no tapes leave the process-wide setting alone)
+            if use_graph and replay == "tape" and not os.environ.get("VELOXSEG_TAPE_FLAG_TIMEOUT_MS"):
+                pg_s = None
+                try:
+                    pg_s = dist.distributed_c10d._get_default_timeout(dist.get_backend(process_group)).total_seconds()
+                except Exception:
+                    pass
+                H.call("vx_tape_set_flag_timeout_ms", int(min(max(pg_s or 1800.0, 60.0), 7200.0) * 1000))
 
     @contextlib.contextmanager
     def _settings(self, capture: bool = False):

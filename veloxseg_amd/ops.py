@@ -13,7 +13,10 @@ a CPU tensor raises the library's "no CPU path" error -- there is no fallback ke
     torch.ops.veloxseg.pwa_attention(table, qkv, grid, n, heads, small, nwin, cq, cv, p_attn, site)     PWA.py:106-200,308-327
     torch.ops.veloxseg.seg_loss(outputs, labels, sr_labels, head_weights, w_rc, w_f, num_modal)         utils/loss.py:52-66
 
-The modules of veloxseg_amd.model call veloxseg_amd.functional directly (one dispatcher hop less per operator); both routes end in the same node."""
+The modules of veloxseg_amd.model reach the seven C++-registered operators THROUGH the dispatcher (functional.py routes conv3d, conv_transpose_k2s2, instance_norm_sum,
+layer_norm_cf, space_to_depth2, upsample_trilinear and gram to torch.ops.veloxseg.*); the composite operators are called as functions of veloxseg_amd.functional.
+With VELOXSEG_NO_CPP=1 (the documented A/B mode without the C++ module) all eleven schemas are defined here under CompositeImplicitAutograd, as before round 4."""
+import os
 from typing import List, Optional
 
 import torch
@@ -26,14 +29,16 @@ from . import functional as VF
 # registers them.  The operators below need Python-side state (dropout sites and the RNG state tensor, the PWA plan cache, the staged loss) and stay Python bodies
 # under CompositeImplicitAutograd on the same library.
 CPP_OPS = ("conv3d", "conv_transpose_k2s2", "instance_norm_sum", "layer_norm_cf", "space_to_depth2", "upsample_trilinear", "gram")
-if VF.cpp_module() is None:
-    raise RuntimeError("veloxseg_amd.ops: the C++ operator module (veloxseg_amd._vxops) is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+_CPP = VF.cpp_module()
+if _CPP is None and os.environ.get("VELOXSEG_NO_CPP") != "1":
+    raise RuntimeError("veloxseg_amd.ops: the C++ operator module (veloxseg_amd._vxops) is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(VELOXSEG_NO_CPP=1 selects the Python operator bodies on purpose)")
 _lib = torch.library.Library("veloxseg", "FRAGMENT")
 _plans = {}
 
 
 def _define(schema, fn):
-    if schema.split("(")[0] in CPP_OPS:
+    if _CPP is not None and schema.split("(")[0] in CPP_OPS:
         return                              # (kept in the list below as documentation of the schema: C++ owns it)
     _lib.define(schema)
     _lib.impl(schema.split("(")[0], fn, "CompositeImplicitAutograd")
