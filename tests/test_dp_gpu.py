@@ -174,3 +174,54 @@ def test_two_rank_taped_engine_at_the_per_gpu_shape_of_baseline_config_3(tmp_pat
     g_ref = eng.flat.grad.cpu()
     rel = float((dp["grad"] - g_ref).norm() / g_ref.norm())
     assert rel < 2e-5, f"averaged 2-rank gradient differs from the global-batch gradient: rel {rel:.3e}"
+
+
+def _world1_nccl_worker(out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    for mode in ("plain", "nccl_eager", "nccl_tape", "nccl_tape_pipe"):
+        cfg_d, crit, x, lab, model, TrainEngine = _setup(batch=2)
+        eng = TrainEngine(model, crit, (2, 2, 32, 32, 32), use_graph=mode != "nccl_eager", overlap=True, bucket_min_bytes=1 << 14,
+                          force_comm=mode != "plain", pipeline_tail=mode == "nccl_tape_pipe")
+        assert eng.dp == (mode != "plain")
+        losses = []
+        for it in range(3):
+            losses.append(float(eng.step(x.cuda(), lab.cuda())))
+            eng.flush()
+            torch.cuda.synchronize()
+            if it == 0:
+                g0 = eng.flat.grad.detach().cpu().clone()           # (the gradient of the first step: same parameters in every mode)
+        if mode != "plain":
+            cover = sorted(eng._reduced)
+            assert cover[0][0] == 0 and cover[-1][1] == eng.flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), eng._reduced
+        res[mode] = (losses, g0, bool(eng.use_graph))
+        del eng, model
+    dist.destroy_process_group()
+    torch.save(res, os.path.join(out_dir, "w1.pt"))
+
+
+@pytest.mark.timeout(900)
+def test_world_size_one_rccl_group_runs_the_real_collective_path(tmp_path):
+    """torch.distributed "nccl" (= RCCL) with ONE rank on the one MI355X of the test box.  TrainEngine(force_comm=True) then issues its bucketed
+    all-reduces through ProcessGroupNCCL's own stream / events -- eager hooks, the taped step (decoder bucket on the dec_wg lane, encoder bucket after the tape) and
+    the pipelined tail -- and the first step's loss and gradient must equal those of the same engine without a process group (a one-rank sum changes nothing), three steps' losses must track."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_world1_nccl_worker, args=(str(tmp_path),))
+    p.start()
+    p.join(800)
+    assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    res = torch.load(os.path.join(str(tmp_path), "w1.pt"))
+    ref_losses, ref_g, _ = res["plain"]
+    for mode in ("nccl_eager", "nccl_tape", "nccl_tape_pipe"):
+        losses, g0, graph = res[mode]
+        assert graph == (mode != "nccl_eager"), mode
+        # first step: same parameters, so loss and gradient agree to summation-order noise; later steps go through Adam's normalised update, which turns the noise of
+        # near-zero gradient elements into +-lr differences of single parameters: the losses still track
+        assert abs(losses[0] - ref_losses[0]) <= 1e-5 * abs(ref_losses[0]), (mode, losses, ref_losses)
+        assert float((g0 - ref_g).abs().max()) <= 2e-5 * float(ref_g.abs().max()), (mode, float((g0 - ref_g).abs().max()), float(ref_g.abs().max()))
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) <= 2e-3 * abs(b), (mode, losses, ref_losses)

@@ -306,7 +306,7 @@ class TrainEngine:
 
     def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
-                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False, pipeline_tail=False):
+                 replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False, pipeline_tail=False, force_comm=False):
         self.model, self.criterion = model, criterion
         # taped data-parallel steps: True = one all-reduce bucket per encoder level, released by markers inside the encoder-backward tape; False
         # (default) = the decoder bucket during the encoder backward, the encoder's gradients in one bucket after it.  A marker joins every forked
@@ -355,7 +355,11 @@ class TrainEngine:
         if self.comm_placement not in ("lane", "fresh_after", "fresh_before"):
             raise ValueError("VELOXSEG_COMM_PLACEMENT must be lane, fresh_after or fresh_before")
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.overlap = overlap and self.world > 1
+        # `dp`: the step issues its collectives.  Normally world > 1; a process group of ONE rank (VELOXSEG_FORCE_COMM=1 / force_comm) runs the same code path -- the
+        # all-reduces go through ProcessGroupNCCL's own stream and events for real and change no value -- which is how the RCCL path is exercised and its cost beside
+        # the four busy hardware queues measured on a one-GPU box (tests/test_dp_gpu.py, profiles/r05_comm_world1_nccl.json)
+        self.dp = self.world > 1 or ((bool(force_comm) or os.environ.get("VELOXSEG_FORCE_COMM") == "1") and dist.is_available() and dist.is_initialized())
+        self.overlap = overlap and self.dp
         self.use_graph = use_graph
         if replay not in ("tape", "graph"):
             raise ValueError("replay must be 'tape' (csrc/tape.hip launches) or 'graph' (hipGraphLaunch)")
@@ -367,10 +371,10 @@ class TrainEngine:
         self.loss = torch.zeros((), device=self.dev, dtype=torch.float32)
         self.graphs = None
         self.last_outputs = None
-        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.dp else None
         self._warm = warmup_steps
         self.verify_replays = verify_replays
-        if self.world > 1:
+        if self.dp:
             dist.broadcast(self.flat.param, src=0, group=self.pg)      # identical replicas at start
             # Data parallel: the start gate of step N+1's tapes is set behind AdamW(N), which waits for all-reduce(N) -- i.e. for the slowest PEER (data loader,
             # rank-0 checkpoint, capture skew).  Collective latency must not count against the cross-lane poll timeout (a poll that gives up lets the kernels
@@ -546,7 +550,7 @@ class TrainEngine:
         return int(getattr(self.model, "n_classes", 0) or self.model.decoder.n_classes)
 
     def _mark_levels(self):
-        return self.use_graph and self.replay_mode == "tape" and ((self.world > 1 and self.overlap and self.level_buckets) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
+        return self.use_graph and self.replay_mode == "tape" and ((self.dp and self.overlap and self.level_buckets) or os.environ.get("VELOXSEG_FORCE_MARKERS") == "1")
 
     def _drop_level_hooks(self):
         for h in getattr(self, "_level_hooks", []):
@@ -898,7 +902,7 @@ class TrainEngine:
         g = torch.cuda.CUDAGraph(keep_graph=True) if tape else torch.cuda.CUDAGraph()
         # with RCCL running (world > 1) its watchdog thread polls events while we capture: in the default "global" error mode that invalidates the
         # capture; "thread_local" checks only the capturing thread (kernels queued by autograd's device thread are captured either way)
-        mode = "thread_local" if (self.world > 1 or os.environ.get("VELOXSEG_CAPTURE_MODE") == "thread_local") else "global"
+        mode = "thread_local" if (self.dp or os.environ.get("VELOXSEG_CAPTURE_MODE") == "thread_local") else "global"
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
@@ -1036,13 +1040,13 @@ class TrainEngine:
                     t.replay()
         if comm:
             self._reduced = []
-        early = comm and self.world > 1 and self.overlap and self.comm_placement == "fresh_before" and wg_lane is not None
+        early = comm and self.dp and self.overlap and self.comm_placement == "fresh_before" and wg_lane is not None
         if early:                                               # (diagnostic placement: see comm_placement)
             self.comm_stream.wait_stream(wg_lane)
             with torch.cuda.stream(self.comm_stream):
                 self._allreduce(split, n)
         G["enc_bwd"].replay()
-        if comm and self.world > 1:
+        if comm and self.dp:
             if self.overlap:
                 # WHERE the collectives are enqueued decides whether they cost their own duration or a millisecond (tools/comm_standin_probe.py, one MI355X,
                 # a 150 us stand-in kernel for the decoder bucket): ROCm multiplexes every stream onto 4 hardware queues that run their packets in order, so a
@@ -1080,12 +1084,12 @@ class TrainEngine:
                 if wg_lane is not None:
                     cur.wait_stream(wg_lane)
                 self._allreduce(0, n)
-        if pipe and not (comm and self.world > 1 and not self.overlap):
+        if pipe and not (comm and self.dp and not self.overlap):
             # pipelined tail: decoder AdamW on the fourth lane behind dec_wg (and the decoder bucket's all-reduce), encoder AdamW on the caller's stream; the lane is
             # joined before the NEXT decoder forward (hop 42 above) or by flush()
             self._check_flag_timeouts()
             self._adamw_begin()
-            if comm and self.world > 1 and self.overlap and self.comm_placement != "lane":
+            if comm and self.dp and self.overlap and self.comm_placement != "lane":
                 wg_lane.wait_stream(self.comm_stream)          # (diagnostic placements: the decoder bucket was reduced on the comm stream)
             with torch.cuda.stream(wg_lane):
                 self._adamw_range(split, n)
@@ -1122,7 +1126,7 @@ class TrainEngine:
             cur = torch.cuda.current_stream(self.dev)
             self.flat.reattach()
             split, n = self.flat.split, self.flat.numel
-            if self.world == 1:
+            if not self.dp:
                 self._fwd_bwd_single()
             elif not self.overlap:
                 self._fwd_bwd_single()
