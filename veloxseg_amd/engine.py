@@ -27,6 +27,7 @@ TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
 TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
 TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
+WG_EARLY = os.environ.get("VELOXSEG_WG_EARLY", "1") != "0"      # taped steps: dec_wg[k] queued behind dec_bwd[k] instead of behind the join of the decoder-backward fan
 WGRAD_STREAM = os.environ.get("VELOXSEG_WGRAD_STREAM", "0") != "0"      # experiment (off): weight-gradient kernels deferred to a side stream -- measured 13.5 vs 12.0 ms/step, they steal CUs from the critical path
 
 
@@ -1005,6 +1006,14 @@ class TrainEngine:
         else:
             dst.wait_stream(src)
 
+    def wg_order(self):
+        """the order in which the dec_wg tapes are queued on the fourth lane: decoders with the shorter backward tape first (they finish first)"""
+        G = self.graphs
+        o = getattr(self, "_wg_order", None)
+        if o is None:
+            o = self._wg_order = sorted(range(len(G["dec_bwd"])), key=lambda k: (G["dec_bwd"][k].n_nodes, k))
+        return o
+
     def _fan(self, graphs, slot0=0):
         cur = torch.cuda.current_stream(self.dev)
         streams = self._lane_streams(len(graphs)) if self.replay_mode == "tape" else self.branch_streams
@@ -1028,16 +1037,34 @@ class TrainEngine:
             self._tail_pending = False
         self._fan(G["dec_fwd"], 0)
         G["loss"].replay()
-        self._fan(G["dec_bwd"], 16)
         split, n = self.flat.split, self.flat.numel
         wg_lane = None
-        if "dec_wg" in G:
-            # the decoders' weight gradients: one after the other on the lane the encoder backward does not use, while it runs on the other three
+        if "dec_wg" in G and self.replay_mode == "tape" and WG_EARLY and len(G["dec_bwd"]) <= 3:
+            # The decoders' weight gradients run one after the other on the fourth lane, beside the encoder backward on the other three.  dec_wg[k] needs dec_bwd[k]
+            # only, and the fourth lane is idle during the decoder-backward fan: each dec_wg[k] is queued behind ITS decoder's backward (a hop from that lane), the
+            # decoders that finish first (the reconstruction branches: shorter tapes) first -- the weight gradients start while the longest decoder is still in its
+            # backward instead of after the join of all three (the phase "dec_wg beside enc_bwd" was the longest of the step: 1.89 ms of 4.2).
+            streams = self._lane_streams(len(G["dec_bwd"]))
+            for k, (s_, g) in enumerate(zip(streams, G["dec_bwd"])):
+                self._hop(16 + k, cur, s_)
+                with torch.cuda.stream(s_):
+                    g.replay()
             wg_lane = self._lane_streams(4)[3]
-            self._hop(40, cur, wg_lane)
-            with torch.cuda.stream(wg_lane):
-                for t in G["dec_wg"]:
-                    t.replay()
+            for k in self.wg_order():
+                self._hop(44 + k, streams[k], wg_lane)
+                with torch.cuda.stream(wg_lane):
+                    G["dec_wg"][k].replay()
+            for k, s_ in enumerate(streams):
+                self._hop(24 + k, s_, cur)
+        else:
+            self._fan(G["dec_bwd"], 16)
+            if "dec_wg" in G:
+                # the decoders' weight gradients: one after the other on the lane the encoder backward does not use, while it runs on the other three
+                wg_lane = self._lane_streams(4)[3]
+                self._hop(40, cur, wg_lane)
+                with torch.cuda.stream(wg_lane):
+                    for t in G["dec_wg"]:
+                        t.replay()
         if comm:
             self._reduced = []
         early = comm and self.dp and self.overlap and self.comm_placement == "fresh_before" and wg_lane is not None

@@ -6,7 +6,8 @@ dependency the capture never recorded shows as one deviating replay in hundreds,
 explores them on purpose and deterministically:
 
 * `StepDag(engine)`: the partial order the replay enforces -- per tape lane order + cross-lane waits (vx_tape_waits), stage after stage as
-  `_replay` issues them (enc_fwd -> {dec_fwd[k]} -> loss -> {dec_bwd[k]} -> {dec_wg[0] -> dec_wg[1] -> ...  ||  enc_bwd}).
+  `_replay` issues them (enc_fwd -> {dec_fwd[k]} -> loss -> {dec_bwd[k]} -> enc_bwd, with the dec_wg tapes one after the other on the fourth lane, each behind its
+  own decoder's backward).
 * `StepDag.extension(seed)`: a random linear extension of it (even seeds: uniform choice among the ready nodes; odd seeds: random lane
   priorities, i.e. some lanes run as far ahead of the others as the dependencies allow -- the extreme schedules).
 * `StepDag.launch(order)`: the whole step node by node on ONE stream in that order (vx_tape_launch_node).  One stream = no timing, no cross-queue
@@ -75,24 +76,24 @@ class StepDag:
         self.engine = engine
         self.nodes: List[tuple] = []
         self.preds: List[List[int]] = []
-        stages = [[[("enc_fwd", G["enc_fwd"])]],
-                  [[(f"dec_fwd[{k}]", t)] for k, t in enumerate(G["dec_fwd"])],
-                  [[("loss", G["loss"])]],
-                  [[(f"dec_bwd[{k}]", t)] for k, t in enumerate(G["dec_bwd"])]]
-        last = [[("enc_bwd", G["enc_bwd"])]]
-        if "dec_wg" in G:
-            last.append([(f"dec_wg[{k}]", t) for k, t in enumerate(G["dec_wg"])])       # one after the other on the fourth lane, beside the encoder backward
-        stages.append(last)
+        from . import engine as _E
         self.stage_of: List[int] = []
-        gate: Optional[int] = None
-        for si, stage in enumerate(stages):
-            ends = []
-            for chain in stage:
-                prev = gate
-                for tag, tape in chain:
-                    prev = self._add_tape(tag, tape, prev, si)
-                ends.append(prev)
-            gate = self._add(("barrier", None, -1, -1, f"end of stage {si}"), [e for e in ends if e is not None], si)
+        gate = self._add_tape("enc_fwd", G["enc_fwd"], [], 0)
+        ends = [self._add_tape(f"dec_fwd[{k}]", t, [gate], 1) for k, t in enumerate(G["dec_fwd"])]
+        gate = self._add(("barrier", None, -1, -1, "end of the decoder-forward fan"), ends, 1)
+        gate = self._add_tape("loss", G["loss"], [gate], 2)
+        bwd_ends = [self._add_tape(f"dec_bwd[{k}]", t, [gate], 3) for k, t in enumerate(G["dec_bwd"])]
+        fan = self._add(("barrier", None, -1, -1, "end of the decoder-backward fan"), bwd_ends, 3)
+        tails = [self._add_tape("enc_bwd", G["enc_bwd"], [fan], 4)]
+        if "dec_wg" in G:
+            # one after the other on the fourth lane, beside the encoder backward; with engine.WG_EARLY each behind ITS decoder's backward only (engine._replay)
+            early = _E.WG_EARLY and engine.replay_mode == "tape" and len(G["dec_bwd"]) <= 3
+            prev = None
+            for k in (engine.wg_order() if early else range(len(G["dec_wg"]))):
+                gates = [bwd_ends[k] if early else fan] + ([prev] if prev is not None else [])
+                prev = self._add_tape(f"dec_wg[{k}]", G["dec_wg"][k], gates, 4)
+            tails.append(prev)
+        self._add(("barrier", None, -1, -1, "end of the step"), [t for t in tails if t is not None], 4)
 
     def _add(self, node, preds, stage):
         self.nodes.append(node)
@@ -100,8 +101,8 @@ class StepDag:
         self.stage_of.append(stage)
         return len(self.nodes) - 1
 
-    def _add_tape(self, tag, tape, gate, stage):
-        """the nodes of one tape behind `gate`; returns the barrier node that follows all of them"""
+    def _add_tape(self, tag, tape, gates, stage):
+        """the nodes of one tape behind every node of `gates`; returns the barrier node that follows all of them"""
         lane, waits, names, _grid = tape_layout(tape)
         base = len(self.nodes)
         last_on_lane = {}
@@ -109,12 +110,10 @@ class StepDag:
             p = [base + w for w in waits[i]]
             if lane[i] in last_on_lane:
                 p.append(last_on_lane[lane[i]])
-            elif gate is not None:
-                p.append(gate)
-            if gate is not None and not p:
-                p.append(gate)
+            else:
+                p.extend(gates)
             last_on_lane[lane[i]] = self._add((tag, tape, i, lane[i], names[i]), p, stage)
-        ends = list(last_on_lane.values()) or ([gate] if gate is not None else [])
+        ends = list(last_on_lane.values()) or list(gates)
         return self._add(("barrier", None, -1, -1, f"end of {tag}"), ends, stage)
 
     # ---- orders ---------------------------------------------------------------------------------
