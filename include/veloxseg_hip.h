@@ -55,6 +55,7 @@ int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const fl
 int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout);
 int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                        int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
+int vx_down_wgrad_set_f16(int on);   /* A/B (tests): the stem weight gradient on the f16 matrix pipe (default, 128-wide rows, 16 output channels) or the fp32 MFMA kernel */
 int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps);
 int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);

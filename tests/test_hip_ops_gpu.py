@@ -229,6 +229,42 @@ def test_stem_conv_on_the_f16_pipe(B, Cin, sp, scale):
     assert e_new <= max(3.0 * e_old, 2e-6), (e_new, e_old)
 
 
+@pytest.mark.parametrize("B,Cin,sp,scale", [(2, 2, (16, 32, 128), 1.0), (1, 1, (8, 16, 128), 1.0), (1, 4, (12, 16, 128), 1.0), (1, 2, (8, 32, 128), 3.0e4), (1, 2, (8, 16, 128), 2.0e-5)],
+                         ids=["two_modalities", "one_channel", "four_channels", "large_values", "tiny_values"])
+def test_stem_weight_gradient_on_the_f16_pipe(B, Cin, sp, scale):
+    """The stem convolution's weight / bias gradient (conv_wgrad.hip vx_stem_wgrad_f16_k: de-interleaved input rows in LDS, two scaled fp16 pieces per operand, one
+    16x16x32 MFMA per output row and 16 taps) against torch's fp64 gradient and against the fp32-MFMA kernel it replaces (vx_down_wgrad_set_f16(0)), through the C ABI;
+    accumulation into a non-zero dw / db as the engine's flat gradient buffer requires."""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    x = (rnd(B, Cin, *sp) * scale).to(d)
+    Do, Ho, Wo = sp[0] // 4, sp[1] // 4, sp[2] // 4
+    dy = (rnd(B, 16, Do, Ho, Wo, seed=3) * (0.5 * scale)).to(d)
+    w = rnd(16, Cin, 7, 7, 7, seed=1).to(d).double().requires_grad_(True)
+    bb = torch.zeros(16, device=d, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w, bb, stride=4, padding=3).backward(dy.double())
+    ref_w, ref_b = w.grad, bb.grad
+    nws = H.query("vx_down_wgrad_ws_floats", B, Cin, *sp, 16)
+    assert nws > 0
+    outs = []
+    try:
+        for on in (1, 0):
+            H.call("vx_down_wgrad_set_f16", on)
+            dw = torch.full((16, Cin, 7, 7, 7), 0.25, device=d)
+            db = torch.full((16,), -0.5, device=d)
+            ws = torch.empty(nws, device=d)
+            H.call("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, B, Cin, *sp, 16, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append((dw.double() - 0.25, db.double() + 0.5))
+    finally:
+        H.call("vx_down_wgrad_set_f16", 1)
+    sc = float(ref_w.abs().max())
+    e_new, e_old = float((outs[0][0] - ref_w).abs().max()) / sc, float((outs[1][0] - ref_w).abs().max()) / sc
+    assert e_new <= max(3.0 * e_old, 3e-6), (e_new, e_old)
+    scb = float(ref_b.abs().max())
+    assert float((outs[0][1] - ref_b).abs().max()) <= 2e-5 * scb + 2.5e-7          # (db is accumulated into a buffer that holds -0.5: fp32 rounding there)
+
+
 def test_fan_out_gradients_meet_in_one_sum():
     """functional.fan_out (one alias of a tensor per consumer, the consumers' gradients summed in one vx_add_many launch for the whole list) against plain autograd
     accumulation: same forward values, same gradients, for two tensors with three consumers each and one with two."""

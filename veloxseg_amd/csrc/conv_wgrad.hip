@@ -666,6 +666,175 @@ __global__ void __launch_bounds__(256, 2) vx_down_wgrad_mfma_k(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the f16 matrix pipe (round 5; VERDICT r4 item 6: 247 us in the profiled step = 8 % of either roof).
+//   dW[co][ci][kd][kh][kw] = sum_{b,od,oh,ow} dy[b,co,od,oh,ow] * x[b,ci,4od+kd-3,4oh+kh-3,4ow+kw-3]
+// One v_mfma_f32_16x16x32_f16 reduces over the 32 outputs of one output ROW (Wo = 32): rows = the 16 output channels (A = dy, a lane's 8 reduction values are 8
+// consecutive ow: two float4 loads), columns = 16 taps = 2 (kd, kh) rows x 8 kw slots (7 taps + one idle), B = x: a lane needs x[4 ow + kw - 3] for 8 consecutive ow, a
+// stride-4 walk of the input row -- so the halo rows are staged DE-INTERLEAVED, Q[row][kw][j] = x[row][4 j + kw - 3] (7 x 32 halfs per input row: one aligned 16-byte LDS
+// read per operand piece; an input element lands in one or two of the seven arrays).  fp32 accuracy from two fp16 pieces per operand scaled by per-tensor powers of two
+// (three piece products, as in the forward vx_stem_fwd_k; the scales come from a max kernel over x and dy, so that one accumulator set serves every tile).
+// A block = 4 waves = 4 consecutive output rows of one (b, od) for ONE input channel (grid.y = Cin): 7 x 19 staged input rows = 119 KB of LDS (one block per CU), 25
+// accumulator tiles (49 (kd, kh) rows in pairs), tiles of the block's share one after the other; block reduction through LDS, one partial slice per block, vx_wg_reduce_k.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 vx_sw_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vx_sw_h2 __attribute__((ext_vector_type(2)));
+typedef float vx_sw_f2 __attribute__((ext_vector_type(2)));
+#define VX_SW_NROW (7 * 19)
+#define VX_SW_ROWH (7 * 32)
+#define VX_SW_NT 25
+__device__ __forceinline__ void vx_sw_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const vx_sw_f2 v = {a, b};
+    const vx_sw_h2 h = __builtin_convertvector(v, vx_sw_h2);
+    const vx_sw_h2 l = __builtin_convertvector(v - __builtin_convertvector(h, vx_sw_f2), vx_sw_h2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ int vx_sw_exp16(float m) {          // |m| * 2^e in [2^13, 2^14); 0 for m = 0 / non-finite
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 0;
+    int e = 13 - ilogbf(m);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+// mx[0] = max |x|, mx[1] = max |dy| as float bits (non-negative floats order like unsigned integers); mx zeroed by the caller
+__global__ void __launch_bounds__(256) vx_stem_absmax_k(const float4* __restrict__ x, long nx4, const float4* __restrict__ dy, long ny4, unsigned* __restrict__ mx) {
+    const bool second = blockIdx.y == 1;
+    const float4* __restrict__ p = second ? dy : x;
+    const long n = second ? ny4 : nx4;
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float4 v = p[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = vx_wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(mx + (second ? 1 : 0), __float_as_uint(m));
+}
+__global__ void __launch_bounds__(256) vx_stem_wgrad_f16_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, float* __restrict__ db,
+                                                           const unsigned* __restrict__ mx, int B, int Cin, int Di, int Hi, int Do, int Ho, int tiles_per_block, int ntiles) {
+    constexpr int Wi = 128, Wo = 32, U = 9, NIT = (VX_SW_NROW * 32 + 256 * U - 1) / (256 * U);
+    extern __shared__ __attribute__((aligned(16))) unsigned char vx_sw_lds[];
+    unsigned short* __restrict__ qh = reinterpret_cast<unsigned short*>(vx_sw_lds);            // [133][7][32] hi pieces
+    unsigned short* __restrict__ ql = qh + VX_SW_NROW * VX_SW_ROWH;                              // lo pieces
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n = lane & 15, G = lane >> 4;
+    const int ci = blockIdx.y;
+    const int ex = vx_sw_exp16(__uint_as_float(mx[0])), ey = vx_sw_exp16(__uint_as_float(mx[1]));
+    const float sx = ldexpf(1.0f, ex), sy = ldexpf(1.0f, ey);
+    typedef float sw_f4 __attribute__((ext_vector_type(4)));
+    sw_f4 acc[VX_SW_NT];
+#pragma unroll
+    for (int nt = 0; nt < VX_SW_NT; ++nt) acc[nt] = (sw_f4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int kw = (n & 7) < 7 ? (n & 7) : 0;                  // (slot 7 of a row is idle: its column is never stored)
+    const long Vi = (long)Di * Hi * Wi, Vo = (long)Do * Ho * Wo;
+    const int nHg = Ho / 4;
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    for (int t = t_begin; t < t_end; ++t) {
+        int tt = t;
+        const int hg = tt % nHg; tt /= nHg;
+        const int od = tt % Do;
+        const int b = tt / Do;
+        __syncthreads();                                        // the previous tile's operand reads are done
+        // this wave's dy row (A operand): issued before the staging so that it travels with it
+        const float* __restrict__ dyr = dy + ((long)b * 16 + n) * Vo + ((long)od * Ho + 4 * hg + wave) * Wo + 8 * G;
+        const float4 d0 = *reinterpret_cast<const float4*>(dyr), d1 = *reinterpret_cast<const float4*>(dyr + 4);
+        const float* __restrict__ xb = x + ((long)b * Cin + ci) * Vi;
+#pragma unroll 1
+        for (int pass = 0; pass < NIT; ++pass) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = threadIdx.x + (pass * U + u) * 256;
+                const int row = min(it >> 5, VX_SW_NROW - 1), m = it & 31;
+                const int kd = row / 19, hh = row - kd * 19;
+                const int id = 4 * od - 3 + kd, ih = 16 * hg - 3 + hh;
+                const bool ok = (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi;
+                const float4 t_ = *reinterpret_cast<const float4*>(xb + ((long)(ok ? id : 0) * Hi + (ok ? ih : 0)) * Wi + 4 * m);
+                v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = threadIdx.x + (pass * U + u) * 256;
+                if (it < VX_SW_NROW * 32) {
+                    const int row = it >> 5, m = it & 31;
+                    uint32_t h01, l01, h23, l23;
+                    vx_sw_split2(v[u].x * sx, v[u].y * sx, h01, l01);
+                    vx_sw_split2(v[u].z * sx, v[u].w * sx, h23, l23);
+                    const int rb = row * VX_SW_ROWH + m;
+                    // input w = 4 m + e  ->  u = w + 3 = 4 j + p:  e = 0 -> (p 3, j m);  e = 1, 2, 3 -> (p 0, 1, 2, j m + 1) and, as tap p + 4, (j m)
+                    qh[rb + 3 * 32] = (unsigned short)h01;            ql[rb + 3 * 32] = (unsigned short)l01;
+                    qh[rb + 4 * 32] = (unsigned short)(h01 >> 16);    ql[rb + 4 * 32] = (unsigned short)(l01 >> 16);
+                    qh[rb + 5 * 32] = (unsigned short)h23;            ql[rb + 5 * 32] = (unsigned short)l23;
+                    qh[rb + 6 * 32] = (unsigned short)(h23 >> 16);    ql[rb + 6 * 32] = (unsigned short)(l23 >> 16);
+                    if (m < 31) {
+                        qh[rb + 1] = (unsigned short)(h01 >> 16);          ql[rb + 1] = (unsigned short)(l01 >> 16);
+                        qh[rb + 32 + 1] = (unsigned short)h23;             ql[rb + 32 + 1] = (unsigned short)l23;
+                        qh[rb + 64 + 1] = (unsigned short)(h23 >> 16);     ql[rb + 64 + 1] = (unsigned short)(l23 >> 16);
+                    }
+                    if (m == 0) {                                     // left padding: u = 0, 1, 2 are the inputs w = -3, -2, -1
+                        qh[rb] = 0; ql[rb] = 0; qh[rb + 32] = 0; ql[rb + 32] = 0; qh[rb + 64] = 0; ql[rb + 64] = 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        bsum += ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+        uint4 ah, al;
+        vx_sw_split2(d0.x * sy, d0.y * sy, ah.x, al.x);
+        vx_sw_split2(d0.z * sy, d0.w * sy, ah.y, al.y);
+        vx_sw_split2(d1.x * sy, d1.y * sy, ah.z, al.z);
+        vx_sw_split2(d1.z * sy, d1.w * sy, ah.w, al.w);
+        const vx_sw_h8 a_hi = __builtin_bit_cast(vx_sw_h8, ah), a_lo = __builtin_bit_cast(vx_sw_h8, al);
+        int kd = 0, kh = n >> 3;                                // (kd, kh) row c0 = 2 nt + (n >> 3) of this lane's column
+#pragma unroll
+        for (int nt = 0; nt < VX_SW_NT; ++nt) {
+            const int kdc = kd < 7 ? kd : 6;                    // (the 50th row -- tile 24, upper half -- is idle)
+            const int off = ((kdc * 19 + 4 * wave + kh) * 7 + kw) * 32 + 8 * G;
+            const uint4 bh = *reinterpret_cast<const uint4*>(qh + off), bl = *reinterpret_cast<const uint4*>(ql + off);
+            const vx_sw_h8 b_hi = __builtin_bit_cast(vx_sw_h8, bh), b_lo = __builtin_bit_cast(vx_sw_h8, bl);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc[nt], 0, 0, 0);
+            kh += 2;
+            if (kh >= 7) { kh -= 7; ++kd; }
+        }
+    }
+    // block reduction: D row 4 G + reg = co, column n = (row c0 = 2 nt + (n >> 3), tap n & 7)
+    float* __restrict__ red = reinterpret_cast<float*>(vx_sw_lds);                          // [16][25 * 16]
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int nt = 0; nt < VX_SW_NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float* __restrict__ e = &red[(4 * G + reg) * (VX_SW_NT * 16) + nt * 16 + n];
+                    *e = (wv == 0) ? acc[nt][reg] : *e + acc[nt][reg];
+                }
+        }
+    }
+    __syncthreads();
+    const float inv = ldexpf(1.0f, -(ex + ey));
+    const long nw = (long)16 * Cin * 343;
+    float* __restrict__ pd = part + (long)blockIdx.x * nw;
+    for (int e = threadIdx.x; e < 16 * VX_SW_NT * 16; e += 256) {
+        const int co = e / (VX_SW_NT * 16), col = e % (VX_SW_NT * 16);
+        const int c0 = 2 * (col >> 4) + ((col >> 3) & 1), tap = col & 7;
+        if (c0 < 49 && tap < 7) pd[((long)co * Cin + ci) * 343 + c0 * 7 + tap] = red[e] * inv;
+    }
+    if (db != nullptr && ci == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (G == 0) atomicAdd(db + n, bsum);
+    }
+}
+static int vx_stem_wg_f16 = -1;
+static int stem_wg_f16_on() {
+    if (vx_stem_wg_f16 < 0) { const char* e = getenv("VELOXSEG_STEM_WG_F16"); vx_stem_wg_f16 = e ? atoi(e) : 1; if (vx_stem_wg_f16 < 0) vx_stem_wg_f16 = 0; }
+    return vx_stem_wg_f16;
+}
+extern "C" int vx_down_wgrad_set_f16(int on) { vx_stem_wg_f16 = on ? 1 : 0; return 0; }      // A/B knob (tests): the stem weight gradient on the f16 pipe (default) or the fp32 MFMA kernel
+static bool stem_wg_f16_ok(int Cin, int Di, int Hi, int Wi, int Cout) { return Cout == 16 && Wi == 128 && Hi % 16 == 0 && Di % 4 == 0 && Cin >= 1 && Cin <= 8; }
+
 static int vx_down_cfg(int B, int Cin, int Di, int Hi, int Wi, int Cout, int& CB, int& Do, int& Ho, int& Wo, int& ntiles, int& tpb, int& nblk) {
     Do = (Di + 6 - 7) / 4 + 1; Ho = (Hi + 6 - 7) / 4 + 1; Wo = (Wi + 6 - 7) / 4 + 1;
     if (Cout % 16 != 0 || Wo < 1 || Ho % 4 != 0 || Do < 1) return 1;      // rows that are not a multiple of 16 (24: the 96^3 patches) leave part of their last tile idle
@@ -684,7 +853,7 @@ static int vx_down_cfg(int B, int Cin, int Di, int Hi, int Wi, int Cout, int& CB
 extern "C" int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout) {
     int CB, Do, Ho, Wo, ntiles, tpb, nblk;
     if (B <= 0 || Cin <= 0 || Cout <= 0 || vx_down_cfg(B, Cin, Di, Hi, Wi, Cout, CB, Do, Ho, Wo, ntiles, tpb, nblk)) return 0;
-    const long n = (long)nblk * Cout * Cin * 343;
+    const long n = (long)nblk * Cout * Cin * 343 + 64;          // (+ the two maxima of the f16 kernel)
     return n > 0x7fffffffL ? 0 : (int)n;
 }
 // Conv3d(k7, s4, p3) weight + bias gradient (dw +=, db += ; db may be NULL).  Returns 1 (nothing launched) when the shape is not covered.
@@ -696,6 +865,31 @@ extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, fl
     const long nw = (long)Cout * Cin * 343;
     VX_REQUIRE(ws_floats >= (long)nblk * nw, "vx_down_wgrad_mfma: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (stem_wg_f16_on() && stem_wg_f16_ok(Cin, Di, Hi, Wi, Cout) && ws_floats >= (long)nblk * nw + 64) {
+        static bool attr = false;
+        if (!attr) {
+            VX_REQUIRE(hipFuncSetAttribute((const void*)vx_stem_wgrad_f16_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_down_wgrad_mfma: LDS attribute");
+            attr = true;
+        }
+        unsigned* mx = reinterpret_cast<unsigned*>(ws + (long)nblk * nw);
+        VX_REQUIRE(hipMemsetAsync(mx, 0, 8, st) == hipSuccess, "vx_down_wgrad_mfma: memset");
+        const long nx4 = (long)B * Cin * Di * Hi * Wi / 4, ny4 = (long)B * Cout * Do * Ho * Wo / 4;
+        vx_stem_absmax_k<<<dim3(256, 2), dim3(256), 0, st>>>(reinterpret_cast<const float4*>(x), nx4, reinterpret_cast<const float4*>(dy), ny4, mx);
+        const int nt16 = B * Do * (Ho / 4);                        // tiles: (b, od, group of 4 output rows)
+        int nb16 = 256 / Cin;                                       // one block per CU (119 KB of LDS)
+        if (nb16 < 1) nb16 = 1;
+        if (nb16 > nt16) nb16 = nt16;
+        if (nb16 > nblk) nb16 = nblk;                               // (the slices of the workspace)
+        const int tp16 = (nt16 + nb16 - 1) / nb16;
+        nb16 = (nt16 + tp16 - 1) / tp16;
+        const size_t shm16 = (size_t)2 * VX_SW_NROW * VX_SW_ROWH * 2;
+        vx_stem_wgrad_f16_k<<<dim3(nb16, Cin), dim3(256), shm16, st>>>(x, dy, ws, db, mx, B, Cin, Di, Hi, Do, Ho, tp16, nt16);
+        int sc16 = nb16 / 32;
+        if (sc16 < 1) sc16 = 1;
+        vx_wg_reduce_k<<<dim3(vx_cdiv(nw, 256), sc16), dim3(256), 0, st>>>(ws, dw, nw, nb16);
+        VX_LAUNCH_CHECK("vx_down_wgrad_mfma (f16 pipe)");
+        return 0;
+    }
     const size_t shm = sizeof(float) * ((((size_t)CB * VX_DW_PLANE + 3) & ~(size_t)3) + (size_t)(CB == 2 ? 43 : 22) * 16);
     dim3 grid(nblk, Cout / 16, Cin / CB);
     if (CB == 2) vx_down_wgrad_mfma_k<43><<<grid, 256, shm, st>>>(x, dy, ws, db, B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, CB, tpb, ntiles);
