@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
     const long units = (long)A.BH * A.Nt * chunks;
     vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)blockIdx.x * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
     __syncthreads();
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = wave % S;
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_fwd_k(const float* __restrict
         unsigned wb = 0;                               // keep bits of the 16 keys of the current mask word (vx_pwa_attn_mbits_words)
         for (int jj = 0; jj < nk; jj += 4) {
             float m4[4];
-            vx_drop4(dc, drow + j0 + jj, al4, m4);
+            vx_attn_drop4(dc, drow + j0 + jj, al4, m4);
             if (mbits != nullptr && dc.on) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) wb |= (m4[t] != 0.0f ? 1u : 0u) << ((jj + t) & 15);
@@ -753,7 +753,7 @@ __device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* _
     vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? a_blk : -1);
     for (int k = threadIdx.x; k < ntab * Tsz; k += 256) gtabs[k] = 0.0f;
     __syncthreads();
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
     const long u_raw = (long)bid * upb + wave / S;
     const bool active = u_raw < units;
@@ -827,7 +827,7 @@ __device__ __forceinline__ void vx_attn_bwd_q_body(const int bid, const float* _
 #pragma unroll
                     for (int t = 0; t < 4; ++t) m4[t] = ((w >> t) & 1u) ? dc.inv_keep : 0.0f;
                 } else
-                vx_drop4(dc, kidx, al4 && ((A.l & 3) == 0), m4);
+                vx_attn_drop4(dc, kidx, al4 && ((A.l & 3) == 0), m4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (tt + t < nt) {
@@ -937,7 +937,7 @@ __device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbi
     const long units = (long)A.BH * A.Nt * chunks;
     vx_attn_tables(A, table, Tsz, lin, bias_all, one_head ? (int)((((long)bid * (4 / S) / chunks) / A.Nt) % A.heads) : -1);
     __syncthreads();
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     const bool al4 = (A.ML & 3) == 0;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = wave % S;
@@ -998,15 +998,10 @@ __device__ __forceinline__ void vx_attn_bwd_kv_body(const int bid, const int nbi
                 m4[2] = ((w2.y >> sh) & 1u) ? dc.inv_keep : 0.0f;
                 m4[3] = ((w2.y >> (16 + sh)) & 1u) ? dc.inv_keep : 0.0f;
             } else if (al4) {                          // ML % 4 == 0: quads are counter-aligned for every row, nq % 4 == 0
-                uint32_t r[4], w[4];
-                const uint64_t idx = ((uint64_t)(win * A.ML + i0 + ii + qt)) * (uint64_t)A.ML + (uint64_t)(jk & ~3);
-                vx_philox4(dc.seed, dc.stream, idx >> 2, r);
-                vx_quad_transpose4(r, w);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) m4[t] = vx_mask_of_bits(dc, w[t]);
+                vx_attn_masks_rows4(dc, (uint64_t)(win * A.ML + i0 + ii), 1, A.ML, jk, m4);
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) m4[t] = vx_drop1(dc, ((uint64_t)(win * A.ML + min(i0 + ii + t, A.ML - 1))) * (uint64_t)A.ML + jk);
+                for (int t = 0; t < 4; ++t) m4[t] = vx_attn_drop1(dc, ((uint64_t)(win * A.ML + min(i0 + ii + t, A.ML - 1))) * (uint64_t)A.ML + jk);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {

@@ -74,7 +74,7 @@ template <int CQ, int CV>
 __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                               const float* __restrict__ table, float* __restrict__ O, float* __restrict__ LSE,
                                                               VxAttnM A, VxDrop drop, unsigned short* __restrict__ mbits) {
-    constexpr int KSQ = CQ / 4, CVB = (CV + 15) / 16, SV = CV + 2;
+    constexpr int KSQ = CQ / 4, CVB = (CV + 15) / 16, SV = CV + 1;      // (16 SV = 16 mod 64 banks: the four lane groups of a P.V operand read fall on different banks)
     extern __shared__ __attribute__((aligned(16))) float vx_am_lds[];
     int* __restrict__ lin = reinterpret_cast<int*>(vx_am_lds);
     float* __restrict__ bias = vx_am_lds + ((A.l + 3) & ~3);
@@ -85,7 +85,27 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
     vx_am_tables(A, table, a, lin, bias, 512);
-    vx_am_stage_op<CQ>(Kop, kp, A.ML, 1.0f, 512);
+    // K in MFMA operand order for the KEY OWNERSHIP of this kernel: in an iteration of 4 key tiles (64 keys) lane group qg owns the 16 CONSECUTIVE keys 16 qg .. 16 qg + 15
+    // (row m = 4 g + i of tile u is key 16 g + 4 u + i), so that a lane's 16 dropout decisions of an iteration are 16 consecutive elements of its query's row = two
+    // Philox calls (vx_attn_drop16) instead of four, and its keep bits are one whole word of the mask tensor (no cross-lane assembly)
+    {
+        const int n4 = A.ML * KSQ;
+        for (int e0 = threadIdx.x; e0 < n4; e0 += 512 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 512; v[u] = reinterpret_cast<const float4*>(kp)[e < n4 ? e : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 512;
+                if (e < n4) {
+                    const int key = e / KSQ, ks = e - key * KSQ;
+                    const int it = key >> 6, w = key & 63, tu = (w >> 2) & 3, mrow = 4 * (w >> 4) + (w & 3);
+                    float* d = Kop + ((4 * it + tu) * KSQ + ks) * 64 + mrow;
+                    d[0] = v[u].x; d[16] = v[u].y; d[32] = v[u].z; d[48] = v[u].w;
+                }
+            }
+        }
+    }
     for (int e0 = threadIdx.x; e0 < A.ML * (CV / 4); e0 += 512 * 8) {
         float4 v[8];
 #pragma unroll
@@ -100,7 +120,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
     const int q0 = (blockIdx.x * 8 + wave) * 16;
     if (q0 >= A.ML) return;
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     const long row = win * A.ML + q0 + m;
     float qb[KSQ];
 #pragma unroll
@@ -123,7 +143,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             s[u] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
-            lk[u] = *reinterpret_cast<const int4*>(&lin[(16 * (kt0 + u)) % A.l + 4 * qg]);
+            lk[u] = *reinterpret_cast<const int4*>(&lin[(16 * (kt0 + qg)) % A.l + 4 * u]);         // keys 16 (kt0 + qg) + 4 u .. + 3
         }
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks)
@@ -141,18 +161,18 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
         const float alpha = __expf(mrun - mn);
         mrun = mn;
         float psum = 0.0f;
+        float m16[16];
+        vx_attn_drop16(dc, (uint64_t)row * (uint64_t)A.ML + (uint64_t)(16 * (kt0 + qg)), m16);      // this lane's 16 keys of the iteration: element 4 u + i
+        if (mbits != nullptr && dc.on) {               // their keep bits = the word (key tile kt0 + qg, this query) of the mask tensor (read back by the one-pass backward)
+            unsigned w = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w |= (m16[e] != 0.0f ? 1u : 0u) << e;
+            mbits[(win * (A.ML >> 4) + (kt0 + qg)) * A.ML + q0 + m] = (unsigned short)w;
+        }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            float m4[4];
-            vx_masks_vox4(dc, (uint64_t)row, A.ML, 16 * (kt0 + u) + 4 * qg, m4);
-            if (mbits != nullptr && dc.on) {           // the keep bits of this query's 16 keys as one word (read back by the one-pass backward)
-                unsigned w = ((m4[0] != 0.0f ? 1u : 0u) | (m4[1] != 0.0f ? 2u : 0u) | (m4[2] != 0.0f ? 4u : 0u) | (m4[3] != 0.0f ? 8u : 0u)) << (4 * qg);
-                w |= __shfl_xor(w, 16, 64);
-                w |= __shfl_xor(w, 32, 64);
-                if (qg == 0) mbits[(win * (A.ML >> 4) + (kt0 + u)) * A.ML + q0 + m] = (unsigned short)w;
-            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float p = __expf(s[u][i] - mn); psum += p; s[u][i] = p * m4[i]; }
+            for (int i = 0; i < 4; ++i) { const float p = __expf(s[u][i] - mn); psum += p; s[u][i] = p * m16[4 * u + i]; }
         }
         lsum = lsum * alpha + psum;
 #pragma unroll
@@ -164,7 +184,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
 #pragma unroll
                 for (int cb = 0; cb < CVB; ++cb) {
                     const int ch = 16 * cb + m;
-                    const float va = ch < CV ? Vs[(16 * (kt0 + u) + 4 * qg + i) * SV + ch] : 0.0f;
+                    const float va = ch < CV ? Vs[(16 * (kt0 + qg) + 4 * u + i) * SV + ch] : 0.0f;
                     if (u & 1) oacc2[cb] = VX_MFMA(va, s[u][i], oacc2[cb]);      // two accumulators: half the dependent-MFMA chain
                     else oacc[cb] = VX_MFMA(va, s[u][i], oacc[cb]);
                 }
@@ -206,7 +226,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_bwd_q_k(const float* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
     const int q0 = (blockIdx.x * 8 + wave) * 16;
     if (q0 < A.ML) {
-        const VxDropCtx dc = vx_drop_ctx(drop);
+        const VxDropCtx dc = vx_attn_ctx(drop);
         const long row = win * A.ML + q0 + m;
         float qb[KSQ], dob[KSV];
 #pragma unroll
@@ -243,7 +263,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_bwd_q_k(const float* __r
             for (int u = 0; u < KU; ++u) {
                 const int bi[4] = {lin_q - lk[u].x, lin_q - lk[u].y, lin_q - lk[u].z, lin_q - lk[u].w};
                 float m4[4];
-                vx_masks_vox4(dc, (uint64_t)row, A.ML, 16 * (kt0 + u) + 4 * qg, m4);
+                vx_attn_masks_vox4(dc, (uint64_t)row, A.ML, 16 * (kt0 + u) + 4 * qg, m4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float p = __expf(s[u][i] + bias[bi[i]] - lse);
@@ -307,7 +327,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_bwd_kv_k(const float* __
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
     const int k0 = (blockIdx.x * 8 + wave) * 16;
     if (k0 >= A.ML) return;
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     const long krow = win * A.ML + k0 + m;
     float kb[KSQ], vb[KSV];
 #pragma unroll
@@ -344,7 +364,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_bwd_kv_k(const float* __
             const int bi[4] = {lq.x - lin_k, lq.y - lin_k, lq.z - lin_k, lq.w - lin_k};
             const float lse[4] = {l4.x, l4.y, l4.z, l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
             float m4[4];
-            vx_masks_rows4(dc, (uint64_t)(win * A.ML + 16 * qt + 4 * qg), 1, A.ML, k0 + m, m4);
+            vx_attn_masks_rows4(dc, (uint64_t)(win * A.ML + 16 * qt + 4 * qg), 1, A.ML, k0 + m, m4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float p = __expf(s[u][i] + bias[bi[i]] - lse[i]);
@@ -473,7 +493,7 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd1_k(const float* __restric
         }
     }
     __syncthreads();
-    const VxDropCtx dc = vx_drop_ctx(drop);
+    const VxDropCtx dc = vx_attn_ctx(drop);
     float* __restrict__ tr = trb + wave * (MF * 16 * TS);
     float* __restrict__ dqm = dqw + wave * (MF * nq * CQ);
     float* __restrict__ gw = gwin + (WIN ? wave * VX_B1_WIN : 0);
@@ -584,10 +604,10 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd1_k(const float* __restric
                     if (use_bits) {                          // one bit per pair, written by the forward: no Philox in the backward
 #pragma unroll
                         for (int i = 0; i < 4; ++i) m4[i] = ((cur.mk[g][f][i] >> m) & 1u) ? dc.inv_keep : 0.0f;
-                    } else if constexpr (AL) vx_masks_rows4(dc, row0, 1, A.ML, keyc, m4);      // l % 4 == 0: one Philox call per lane and tile (DPP quad transpose)
+                    } else if constexpr (AL) vx_attn_masks_rows4(dc, row0, 1, A.ML, keyc, m4);      // l % 4 == 0: one Philox call per lane and tile (DPP quad transpose)
                     else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) m4[i] = vx_drop1(dc, (row0 + i) * (uint64_t)A.ML + (uint64_t)keyc);
+                        for (int i = 0; i < 4; ++i) m4[i] = vx_attn_drop1(dc, (row0 + i) * (uint64_t)A.ML + (uint64_t)keyc);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1350,7 +1370,7 @@ int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const floa
         for (int i = 0; i < nz; ++i) mx = z.n4[i] > mx ? z.n4[i] : mx;
         vx_zero_many_k<<<dim3((unsigned)vx_cdiv(mx, 256 * 4), (unsigned)nz), dim3(256), 0, st>>>(z);
     }
-    const float inv_keep = drop ? 1.0f / (1.0f - d.p) : 1.0f;
+    const float inv_keep = drop ? vx_attn_keep_scale(d.p) : 1.0f;          // (the forward's 16-bit threshold: vx_common.h vx_attn_ctx)
     const size_t shm = vx_b1h_shm(A, cq);
 #define VX_B1H(C_, D_)                                                                                                                            \
     {                                                                                                                                             \

@@ -147,6 +147,7 @@ struct VxDropCtx {
     uint64_t seed, stream;
     float p, inv_keep;
     bool on;
+    uint32_t thr16;      // attention sites (vx_attn_ctx): keep iff the element's 16 random bits >= thr16
 };
 __device__ __forceinline__ VxDropCtx vx_drop_ctx(const VxDrop& d) {
     VxDropCtx c;
@@ -155,6 +156,7 @@ __device__ __forceinline__ VxDropCtx vx_drop_ctx(const VxDrop& d) {
     c.p = d.p;
     c.inv_keep = c.on ? 1.0f / (1.0f - d.p) : 1.0f;
     c.seed = c.on ? d.seed_ptr[0] + 0x9E3779B97F4A7C15ull * d.seed_ptr[1] : 0ull;
+    c.thr16 = 0;
     return c;
 }
 __device__ __forceinline__ float vx_mask_of_bits(const VxDropCtx& c, uint32_t bits) {
@@ -213,4 +215,79 @@ __device__ __forceinline__ void vx_masks_rows4(const VxDropCtx& dc, uint64_t row
     vx_quad_transpose4(r, w);
 #pragma unroll
     for (int t = 0; t < 4; ++t) m[t] = vx_mask_of_bits(dc, w[t]);
+}
+
+// ---- attention-site dropout: 16 random bits per decision, EIGHT decisions per Philox call (round 5) ---------------------------------
+// The 24-bit scheme above spends one Philox4x32 call (7 rounds of quarter-rate 32-bit multiplies) on four elements; the MFMA attention forward draws one mask per score
+// and the generator was ~40 % of its issue slots.  For the attention site only -- every attention kernel of pwa.hip / pwa_mfma.hip, forward and backward, draws through
+// the helpers below, so the masks agree -- element idx maps to the 16-bit chunk (idx & 7) of philox(seed, stream, idx >> 3): word (idx & 7) >> 1, half idx & 1.
+// p is represented as thr16 / 65536 (p = 0.1 -> 6554 / 65536 = 0.100006) and the keep scale is 1 / (1 - thr16 / 65536), so the mask stays unbiased.
+static inline unsigned vx_attn_thr16(float p) { const float t = p * 65536.0f + 0.5f; return p <= 0.0f ? 0u : (t >= 65535.0f ? 65535u : (unsigned)t); }
+static inline float vx_attn_keep_scale(float p) { return p > 0.0f ? 65536.0f / (65536.0f - (float)vx_attn_thr16(p)) : 1.0f; }      // host side: what a kernel that reads stored keep bits multiplies by
+__device__ __forceinline__ VxDropCtx vx_attn_ctx(const VxDrop& d) {
+    VxDropCtx c = vx_drop_ctx(d);
+    const float t = d.p * 65536.0f + 0.5f;
+    c.thr16 = c.on ? (t >= 65535.0f ? 65535u : (uint32_t)t) : 0u;
+    c.inv_keep = c.on ? 65536.0f / (65536.0f - (float)c.thr16) : 1.0f;
+    return c;
+}
+__device__ __forceinline__ float vx_attn_keep(const VxDropCtx& c, uint32_t v16) { return v16 >= c.thr16 ? c.inv_keep : 0.0f; }
+__device__ __forceinline__ float vx_attn_drop1(const VxDropCtx& c, uint64_t idx) {
+    if (!c.on) return 1.0f;
+    uint32_t r[4];
+    vx_philox4(c.seed, c.stream, idx >> 3, r);
+    const uint32_t cc = (uint32_t)idx & 7u;
+    return vx_attn_keep(c, (r[cc >> 1] >> (16u * (cc & 1u))) & 0xffffu);
+}
+// masks of the elements idx0 .. idx0 + 3; one Philox call when idx0 is a multiple of 4 (`aligned`, wave-uniform), four otherwise
+__device__ __forceinline__ void vx_attn_drop4(const VxDropCtx& c, uint64_t idx0, bool aligned, float (&m)[4]) {
+    if (!c.on) {
+        m[0] = m[1] = m[2] = m[3] = 1.0f;
+    } else if (aligned) {
+        uint32_t r[4];
+        vx_philox4(c.seed, c.stream, idx0 >> 3, r);
+        const bool hi = ((uint32_t)idx0 & 4u) != 0u;
+        const uint32_t w0 = hi ? r[2] : r[0], w1 = hi ? r[3] : r[1];
+        m[0] = vx_attn_keep(c, w0 & 0xffffu); m[1] = vx_attn_keep(c, w0 >> 16); m[2] = vx_attn_keep(c, w1 & 0xffffu); m[3] = vx_attn_keep(c, w1 >> 16);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[t] = vx_attn_drop1(c, idx0 + t);
+    }
+}
+// masks of the 16 consecutive elements idx0 .. idx0 + 15 (idx0 % 8 == 0): two Philox calls
+__device__ __forceinline__ void vx_attn_drop16(const VxDropCtx& c, uint64_t idx0, float (&m)[16]) {
+    if (!c.on) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m[t] = 1.0f;
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t r[4];
+        vx_philox4(c.seed, c.stream, (idx0 >> 3) + h, r);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { m[8 * h + 2 * w] = vx_attn_keep(c, r[w] & 0xffffu); m[8 * h + 2 * w + 1] = vx_attn_keep(c, r[w] >> 16); }
+    }
+}
+__device__ __forceinline__ void vx_attn_masks_vox4(const VxDropCtx& dc, uint64_t row, long V, long vox4, float (&m)[4]) {      // (row, vox4 .. vox4 + 3), V % 4 == 0, vox4 % 4 == 0
+    vx_attn_drop4(dc, row * (uint64_t)V + (uint64_t)vox4, true, m);
+}
+// masks of the elements (row0 + T * rstride, vox), T = 0..3, when the 4 lanes of a quad hold 4 consecutive voxels (vox & 3 == lane & 3) and V % 4 == 0: lane s draws
+// the counter of row T = s, picks the word pair of its 4-element half and the pairs are handed round with DPP quad broadcasts
+__device__ __forceinline__ void vx_attn_masks_rows4(const VxDropCtx& dc, uint64_t row0, uint64_t rstride, long V, long vox, float (&m)[4]) {
+    if (!dc.on) { m[0] = m[1] = m[2] = m[3] = 1.0f; return; }
+    uint32_t r[4];
+    const int s = threadIdx.x & 3;
+    const uint64_t idx = (row0 + (uint64_t)s * rstride) * (uint64_t)V + (uint64_t)vox;
+    vx_philox4(dc.seed, dc.stream, idx >> 3, r);
+    const bool hi = ((uint32_t)idx & 4u) != 0u;
+    const uint32_t w0 = hi ? r[2] : r[0], w1 = hi ? r[3] : r[1];
+#define VX_AQ(T)                                                                                  \
+    {                                                                                             \
+        const uint32_t a0 = VX_QUAD_BCAST(w0, T), a1 = VX_QUAD_BCAST(w1, T);                      \
+        const uint32_t w = (s & 2) ? a1 : a0;                                                     \
+        m[T] = vx_attn_keep(dc, (s & 1) ? (w >> 16) : (w & 0xffffu));                             \
+    }
+    VX_AQ(0) VX_AQ(1) VX_AQ(2) VX_AQ(3)
+#undef VX_AQ
 }
