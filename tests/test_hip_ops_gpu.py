@@ -265,6 +265,34 @@ def test_stem_weight_gradient_on_the_f16_pipe(B, Cin, sp, scale):
     assert float((outs[0][1] - ref_b).abs().max()) <= 2e-5 * scb + 2.5e-7          # (db is accumulated into a buffer that holds -0.5: fp32 rounding there)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,sp", [(4, 16, 32, (32, 32, 32)), (2, 32, 64, (16, 16, 16)), (4, 64, 128, (8, 8, 8)), (1, 16, 32, (24, 24, 24)), (2, 32, 64, (12, 12, 12))],
+                         ids=["down2_128", "down3_128", "down4_128", "down2_96", "down3_96"])
+def test_downconv_weight_gradient_gather_gemm(B, Cin, Cout, sp):
+    """The weight gradient of the level 2 - 4 DownConvs (Conv3d k3 s2 p1, conv_blocks.py:4-21) as a gather-GEMM on the fp32 matrix pipe (conv_wgrad.hip
+    vx_wgrad_gather_mfma_k) against torch's fp64 gradient and the tiled VALU kernel it replaces, through the C ABI; accumulation into a non-zero dw."""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    x = rnd(B, Cin, *sp).to(d)
+    so = tuple((v + 2 - 3) // 2 + 1 for v in sp)
+    dy = rnd(B, Cout, *so, seed=4).to(d)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=1).to(d).double().requires_grad_(True)
+    bb = torch.zeros(Cout, device=d, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w, bb, stride=2, padding=1).backward(dy.double())
+    ref, ref_b = w.grad, bb.grad
+    st = torch.cuda.current_stream().cuda_stream
+    assert H.query("vx_conv_wgrad_gather_ok", B, Cin, *sp, Cout, 3, 2, 1) == 1
+    dw_new = torch.full((Cout, Cin, 3, 3, 3), 0.5, device=d)
+    db_new = torch.full((Cout,), 2.0, device=d)
+    H.call("vx_conv_wgrad_gather_mfma", H.P(x), H.P(dy), H.P(dw_new), H.P(db_new), B, Cin, *sp, Cout, 3, 2, 1, st)
+    dw_old = torch.full((Cout, Cin, 3, 3, 3), 0.5, device=d)
+    H.call("vx_conv3d_bwd_weight_tiled", H.P(x), None, 0, H.P(dy), H.P(dw_old), None, B, Cin, *sp, Cout, 3, 2, 1, 1, 1, st)
+    torch.cuda.synchronize()
+    sc = float(ref.abs().max())
+    e_new, e_old = float((dw_new.double() - 0.5 - ref).abs().max()) / sc, float((dw_old.double() - 0.5 - ref).abs().max()) / sc
+    assert e_new <= max(3.0 * e_old, 3e-6), (e_new, e_old)
+    assert float((db_new.double() - 2.0 - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-6
+
+
 def test_fan_out_gradients_meet_in_one_sum():
     """functional.fan_out (one alias of a tensor per consumer, the consumers' gradients summed in one vx_add_many launch for the whole list) against plain autograd
     accumulation: same forward values, same gradients, for two tensors with three consumers each and one with two."""

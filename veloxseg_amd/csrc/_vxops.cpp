@@ -314,6 +314,8 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 auto ws = std::make_shared<Tensor>(at::empty({(long)nws}, x.options()));
                 WG.done.push_back([ws](void*) {});
                 VX(vx_down_wgrad_mfma, fp(x), fp(dy), dw, db, mp(*ws), nws, B, Cin, D, H, W, Cout, s);
+            } else if (G == 1 && ps == 1 && S > 1 && !x2.defined() && vx_conv_wgrad_gather_ok(B, Cin, D, H, W, Cout, K, S, P) == 1) {
+                VX(vx_conv_wgrad_gather_mfma, fp(x), fp(dy), dw, db, B, Cin, D, H, W, Cout, K, S, P, s);      // DownConv levels 2 - 4: gather-GEMM on the fp32 matrix pipe
             } else if (F.use_wgrad_ws) {
                 const int nws = vx_conv3d_bwd_weight_ws_floats(B, Cin, D, H, W, Cout, K, S, P, G, ps);
                 TORCH_CHECK(nws >= 0, "vx_conv3d_bwd_weight_ws_floats failed");

@@ -902,6 +902,135 @@ extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, fl
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a dense strided Conv3d as a gather-GEMM on the fp32 matrix pipe (round 5): the DownConvs of encoder levels 2 - 4 (Conv3d k3 s2 p1, 16 -> 32 -> 64 ->
+// 128 channels; reference conv_blocks.py:4-21) ran on the tiled VALU kernel above at 78 - 82 us for 0.45 GFLOP each (3.7 % of the fp32 roof), on the critical path of the
+// encoder backward.   dW[co][ci][tap] = sum_{b, v} dy[b, co, v] * x[b, ci, S v + tap - P]      M = Cout, N = (ci, tap) pairs, K = B x Vout output voxels.
+// v_mfma_f32_16x16x4_f32, four k-steps per iteration: step j of lane group q is voxel v0 + 4 q + j, so that a lane's four A values are ONE 16-byte load of its dy row and
+// its four B values are four gathers of its pair's input walk (x is 0.5 - 8 MB at these levels: L2 / MALL resident; out-of-range taps read as zero).  A wave owns one
+// 16-pair tile and every output-channel tile (MT accumulators) over a chunk of a sample's voxels; the four waves of a block take four chunks of the same pair tile and are
+// added through LDS: one float atomic per (weight, block).  Exact fp32 products, fp32 accumulation.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct VxGw {
+    const float *x, *dy;
+    float *dw, *db;          // db (may be NULL): += sum of dy, formed by the waves of pair tile 0 from the A operands they load anyway
+    int B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, K, S, P;
+    int KV, npairs, chunk, nchunk;           // taps per channel, Cin * KV, voxels per wave chunk, chunks per sample
+};
+template <int MT>
+__global__ void __launch_bounds__(256) vx_wgrad_gather_mfma_k(VxGw p) {
+    __shared__ float red[4][MT][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), r = lane & 15, q = lane >> 4;
+    const int nt = blockIdx.x;                                  // pair tile
+    const int cg = blockIdx.y * 4 + wave;                       // (sample, chunk)
+    const int b = cg / p.nchunk, ch = cg - b * p.nchunk;
+    const bool wok = b < p.B;
+    const int n = nt * 16 + r;
+    const bool nok = n < p.npairs;
+    const int nc = nok ? n : 0;
+    const int ci = nc / p.KV, tap = nc - ci * p.KV;
+    const int kw = tap % p.K, kh = (tap / p.K) % p.K, kd = tap / (p.K * p.K);
+    const long Vi = (long)p.Di * p.Hi * p.Wi, Vo = (long)p.Do * p.Ho * p.Wo;
+    const float* __restrict__ xb = p.x + ((long)(wok ? b : 0) * p.Cin + ci) * Vi;
+    const float* __restrict__ dyb = p.dy + (long)(wok ? b : 0) * p.Cout * Vo;
+    vx_wf4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (vx_wf4){0.f, 0.f, 0.f, 0.f};
+    const int HoWo = p.Ho * p.Wo;
+    const long v_lo = (long)ch * p.chunk, v_hi = min((long)(ch + 1) * p.chunk, Vo);
+    const bool bias = p.db != nullptr && nt == 0;
+    float bs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bs[mt] = 0.0f;
+    if (wok)
+        for (long v0 = v_lo; v0 < v_hi; v0 += 16) {
+            const long vq = v0 + 4 * q;                          // this lane group's four voxels vq .. vq + 3 (Vo % 4 == 0: never straddles the end)
+            const bool vok = vq < v_hi;
+            float4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(dyb + (long)(16 * mt + r) * Vo + (vok ? vq : 0));
+            float bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = (int)(vok ? vq + j : 0);
+                const int od = v / HoWo, rem = v - od * HoWo, oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                const int id = od * p.S - p.P + kd, ih = oh * p.S - p.P + kh, iw = ow * p.S - p.P + kw;
+                const bool ok = vok && nok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                const float t_ = xb[ok ? ((long)id * p.Hi + ih) * p.Wi + iw : 0];
+                bv[j] = ok ? t_ : 0.0f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a4[4] = {vok ? av[mt].x : 0.0f, vok ? av[mt].y : 0.0f, vok ? av[mt].z : 0.0f, vok ? av[mt].w : 0.0f};
+                bs[mt] += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bv[j], acc[mt], 0, 0, 0);
+            }
+        }
+    if (bias && wok) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float t_ = bs[mt];
+            t_ += __shfl_xor(t_, 16, 64);
+            t_ += __shfl_xor(t_, 32, 64);
+            if (q == 0) atomicAdd(p.db + 16 * mt + r, t_);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wave][mt][reg][lane] = acc[mt][reg];
+    __syncthreads();
+    // D row 4 q + reg = co of tile mt, column r = pair n
+    for (int e = threadIdx.x; e < MT * 4 * 64; e += 256) {
+        const int l = e & 63, reg = (e >> 6) & 3, mt = e >> 8;
+        const int co = 16 * mt + 4 * (l >> 4) + reg, nn = nt * 16 + (l & 15);
+        if (nn < p.npairs) {
+            const float v = (red[0][mt][reg][l] + red[1][mt][reg][l]) + (red[2][mt][reg][l] + red[3][mt][reg][l]);
+            atomicAdd(p.dw + (long)co * p.npairs + nn, v);
+        }
+    }
+}
+static int vx_wg_gather = -1;
+extern "C" int vx_conv_wgrad_gather_set(int on) { vx_wg_gather = on ? 1 : 0; return 0; }       // A/B knob (tests)
+extern "C" int vx_conv_wgrad_gather_ok(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P) {
+    if (vx_wg_gather < 0) { const char* e = getenv("VELOXSEG_WGRAD_GATHER"); vx_wg_gather = e ? atoi(e) : 1; }
+    if (!vx_wg_gather || B <= 0 || Cin <= 0 || K < 1 || K > 5 || S < 1 || P < 0) return 0;
+    if (Cout != 32 && Cout != 64 && Cout != 128) return 0;
+    const int Do = (Di + 2 * P - K) / S + 1, Ho = (Hi + 2 * P - K) / S + 1, Wo = (Wi + 2 * P - K) / S + 1;
+    if (Do < 1 || Ho < 1 || Wo < 1) return 0;
+    const long Vo = (long)Do * Ho * Wo;
+    return (Vo % 4 == 0 && Vo <= (1L << 20) && (long)Cin * K * K * K <= (1L << 20)) ? 1 : 0;
+}
+/* dw += the weight gradient of Conv3d(Cin -> Cout, kernel K, stride S, padding P, no groups), db += the bias gradient (db may be NULL); exact fp32 products on
+   v_mfma_f32_16x16x4_f32.  Shapes: vx_conv_wgrad_gather_ok. */
+extern "C" int vx_conv_wgrad_gather_mfma(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, void* stream) {
+    VX_REQUIRE(x && dy && dw, "vx_conv_wgrad_gather_mfma: null pointer");
+    VX_REQUIRE(vx_conv_wgrad_gather_ok(B, Cin, Di, Hi, Wi, Cout, K, S, P) == 1, "vx_conv_wgrad_gather_mfma: shape not covered (Cin=%d Cout=%d k%d s%d p%d %dx%dx%d)", Cin, Cout, K, S, P, Di, Hi, Wi);
+    VxGw p = {};
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.B = B; p.Cin = Cin; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.Cout = Cout; p.K = K; p.S = S; p.P = P;
+    p.Do = (Di + 2 * P - K) / S + 1; p.Ho = (Hi + 2 * P - K) / S + 1; p.Wo = (Wi + 2 * P - K) / S + 1;
+    p.KV = K * K * K; p.npairs = Cin * p.KV;
+    const long Vo = (long)p.Do * p.Ho * p.Wo;
+    const int ntile = vx_cdiv(p.npairs, 16);
+    // waves = pair tiles x (B x chunks): aim at ~2 k waves (two per SIMD), chunks of >= 64 voxels (multiples of 16)
+    long nch = 2048 / ((long)ntile * B);
+    if (nch < 1) nch = 1;
+    long chunk = (Vo + nch - 1) / nch;
+    chunk = (chunk + 15) / 16 * 16;
+    if (chunk < 64) chunk = 64;
+    p.chunk = (int)chunk;
+    p.nchunk = (int)((Vo + chunk - 1) / chunk);
+    const dim3 grid((unsigned)ntile, (unsigned)vx_cdiv(B * p.nchunk, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout == 32) vx_wgrad_gather_mfma_k<2><<<grid, dim3(256), 0, st>>>(p);
+    else if (Cout == 64) vx_wgrad_gather_mfma_k<4><<<grid, dim3(256), 0, st>>>(p);
+    else vx_wgrad_gather_mfma_k<8><<<grid, dim3(256), 0, st>>>(p);
+    VX_LAUNCH_CHECK("vx_conv_wgrad_gather_mfma");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1x1x1 GROUPED conv (the k = 1 member of the JLC spatial convs, conv_blocks.py:51-58): weight + bias gradient in one pass.
 //   dw[g*CG + co, ci] += sum_{b,v} dy[b, g*CG + co, v] * x[b, g*CG + ci, v];  db[co] += sum dy

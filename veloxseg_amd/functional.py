@@ -434,6 +434,9 @@ class _Conv3dFn(torch.autograd.Function):
                 nws = H.query("vx_down_wgrad_ws_floats", B, Cin, D, Hh, W, Cout)
                 ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
                 H.call("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(grad_buf(w)), H.P(db), H.P(ws), nws, B, Cin, D, Hh, W, Cout, st)
+            elif (G == 1 and ps == 1 and S > 1 and x2 is None and WGRAD_ENTRY == "vx_conv3d_bwd_weight_tiled"
+                  and H.query("vx_conv_wgrad_gather_ok", B, Cin, D, Hh, W, Cout, K, S, P) == 1):
+                H.call("vx_conv_wgrad_gather_mfma", H.P(x), H.P(dy), H.P(grad_buf(w)), H.P(db), B, Cin, D, Hh, W, Cout, K, S, P, st)
             elif WGRAD_ENTRY == "vx_conv3d_bwd_weight_tiled" and USE_WGRAD_WS:
                 key = (B, Cin, D, Hh, W, Cout, K, S, P, G, ps)
                 nws = _wgrad_ws.get(key)
