@@ -396,7 +396,10 @@ def main():
         # `roofline` = the kernel with the most time per step, AGGREGATED BY ENTRY over every shape it is launched with (the top row of the rocprofv3 summary, which is
         # by kernel name): sum of algorithmic flops / sum of launch time.  avg_launch_ms / achieved / frac are measured live (HIP events on the launch stream, above);
         # `profile` repeats them from the committed rocprofv3 --kernel-trace --stats summary so that frac can be recomputed from profiles/ alone.
-        alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd"}
+        alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd",
+                 # (round 5: the operator code calls the entries that take the pieces mode explicitly -- same kernels, one more trailing integer in the key)
+                 "vx_jlc_wgrad_tz_ns": "vx_jlc_wgrad_tz", "vx_jlc_tz_fwd_ns": "vx_jlc_tz_fwd", "vx_jlc_tz_bwd_ns": "vx_jlc_tz_bwd", "vx_jlc_tz_prep_ns": "vx_jlc_tz_prep"}
+        rows = [(t_, n_, (alias.get(nm, nm) if nm.endswith("_ns") else nm, (tuple(k_[:-1]) if nm.endswith("_ns") and nm != "vx_jlc_tz_prep_ns" else k_))) for t_, n_, (nm, k_) in rows]
         fam = {}
         for tot_ms, n, (name, key) in rows:
             base = alias.get(name, name)

@@ -57,10 +57,15 @@ int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, fl
                        int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
 int vx_down_wgrad_set_f16(int on);   /* A/B (tests): the stem weight gradient on the f16 matrix pipe (default, 128-wide rows, 16 output channels) or the fp32 MFMA kernel */
 /* Weight gradient of a dense strided Conv3d (the DownConvs of encoder levels 2 - 4: Conv3d k3 s2 p1, conv_blocks.py:4-21) as a gather-GEMM on v_mfma_f32_16x16x4_f32: exact
- * fp32 products, dw +=, db += (db may be NULL).  _ok: 1 when the shape is covered (Cout 32 / 64 / 128, output voxels % 4 == 0). */
+ * fp32 products, dw +=, db += (db may be NULL).  _ok: 1 when the shape is covered (Cout 32 / 64 / 128). */
 int vx_conv_wgrad_gather_ok(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P);
 int vx_conv_wgrad_gather_mfma(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, void* stream);
 int vx_conv_wgrad_gather_set(int on);   /* A/B (tests) */
+/* The three weight gradients of a JLC block (grouped convolutions k = 5 / 3 / 1, conv_blocks.py:51-58) at small volumes (<= 512 voxels per sample: the 8^3 / 4^3 levels of
+ * the 128^3 configurations, 6^3 / 3^3 of the 96^3 ones) as gather-GEMMs on v_mfma_f32_16x16x4_f32 in ONE launch; dw += ; exact fp32 products. */
+int vx_jlc_wgrad_gather_ok(int C, int G, int D, int H, int W);
+int vx_jlc_wgrad_gather(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W, void* stream);
+int vx_jlc_wgrad_gather_set(int on);   /* A/B (tests) */
 int vx_conv3d_bwd_weight_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps);
 int vx_conv3d_bwd_weight_tiled_ws(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int B, int Cin, int Di, int Hi, int Wi, int Cout, int K, int S, int P, int G, int ps, void* stream);

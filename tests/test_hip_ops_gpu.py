@@ -229,8 +229,9 @@ def test_stem_conv_on_the_f16_pipe(B, Cin, sp, scale):
     assert e_new <= max(3.0 * e_old, 2e-6), (e_new, e_old)
 
 
-@pytest.mark.parametrize("B,Cin,sp,scale", [(2, 2, (16, 32, 128), 1.0), (1, 1, (8, 16, 128), 1.0), (1, 4, (12, 16, 128), 1.0), (1, 2, (8, 32, 128), 3.0e4), (1, 2, (8, 16, 128), 2.0e-5)],
-                         ids=["two_modalities", "one_channel", "four_channels", "large_values", "tiny_values"])
+@pytest.mark.parametrize("B,Cin,sp,scale", [(2, 2, (16, 32, 128), 1.0), (1, 1, (8, 16, 128), 1.0), (1, 4, (12, 16, 128), 1.0), (1, 2, (8, 32, 128), 3.0e4), (1, 2, (8, 16, 128), 2.0e-5),
+                                            (2, 2, (8, 32, 96), 1.0), (1, 4, (12, 16, 96), 1.0)],
+                         ids=["two_modalities", "one_channel", "four_channels", "large_values", "tiny_values", "rows_of_96", "rows_of_96_four_channels"])
 def test_stem_weight_gradient_on_the_f16_pipe(B, Cin, sp, scale):
     """The stem convolution's weight / bias gradient (conv_wgrad.hip vx_stem_wgrad_f16_k: de-interleaved input rows in LDS, two scaled fp16 pieces per operand, one
     16x16x32 MFMA per output row and 16 taps) against torch's fp64 gradient and against the fp32-MFMA kernel it replaces (vx_down_wgrad_set_f16(0)), through the C ABI;
@@ -265,8 +266,8 @@ def test_stem_weight_gradient_on_the_f16_pipe(B, Cin, sp, scale):
     assert float((outs[0][1] - ref_b).abs().max()) <= 2e-5 * scb + 2.5e-7          # (db is accumulated into a buffer that holds -0.5: fp32 rounding there)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,sp", [(4, 16, 32, (32, 32, 32)), (2, 32, 64, (16, 16, 16)), (4, 64, 128, (8, 8, 8)), (1, 16, 32, (24, 24, 24)), (2, 32, 64, (12, 12, 12))],
-                         ids=["down2_128", "down3_128", "down4_128", "down2_96", "down3_96"])
+@pytest.mark.parametrize("B,Cin,Cout,sp", [(4, 16, 32, (32, 32, 32)), (2, 32, 64, (16, 16, 16)), (4, 64, 128, (8, 8, 8)), (1, 16, 32, (24, 24, 24)), (2, 32, 64, (12, 12, 12)), (2, 64, 128, (6, 6, 6))],
+                         ids=["down2_128", "down3_128", "down4_128", "down2_96", "down3_96", "down4_96"])
 def test_downconv_weight_gradient_gather_gemm(B, Cin, Cout, sp):
     """The weight gradient of the level 2 - 4 DownConvs (Conv3d k3 s2 p1, conv_blocks.py:4-21) as a gather-GEMM on the fp32 matrix pipe (conv_wgrad.hip
     vx_wgrad_gather_mfma_k) against torch's fp64 gradient and the tiled VALU kernel it replaces, through the C ABI; accumulation into a non-zero dw."""
@@ -291,6 +292,31 @@ def test_downconv_weight_gradient_gather_gemm(B, Cin, Cout, sp):
     e_new, e_old = float((dw_new.double() - 0.5 - ref).abs().max()) / sc, float((dw_old.double() - 0.5 - ref).abs().max()) / sc
     assert e_new <= max(3.0 * e_old, 3e-6), (e_new, e_old)
     assert float((db_new.double() - 2.0 - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("B,C,G,sp", [(4, 64, 8, (8, 8, 8)), (4, 128, 8, (4, 4, 4)), (2, 64, 8, (6, 6, 6)), (2, 128, 8, (3, 3, 3)), (1, 32, 4, (6, 6, 6)), (2, 16, 4, (4, 6, 8))],
+                         ids=["level3_128", "level4_128", "level3_96", "level4_96", "group_of_8_small", "group_of_4_aniso"])
+def test_jlc_weight_gradients_small_volume_gather_gemm(B, C, G, sp):
+    """The three weight gradients of a JLC block (grouped k = 5 / 3 / 1 convolutions, conv_blocks.py:51-58) at small volumes in one gather-GEMM launch (conv_wgrad.hip
+    vx_jlc_wgrad_gather_k: the 8^3 / 4^3 levels at 128^3, and the 6^3 / 3^3 levels of the shipped 96^3 configurations that the Toeplitz kernel does not cover) against
+    torch's fp64 gradients, through the C ABI; accumulation into non-zero buffers."""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    CG = C // G
+    x = rnd(B, C, *sp).to(d)
+    gs = [rnd(B, C, *sp, seed=10 + k).to(d) for k in (1, 3, 5)]
+    refs = []
+    for g_, k in zip(gs, (1, 3, 5)):
+        w = torch.zeros(C, CG, k, k, k, device=d, dtype=torch.float64, requires_grad=True)
+        F.conv3d(x.double(), w, None, padding=k // 2, groups=G).backward(g_.double())
+        refs.append(w.grad)
+    assert H.query("vx_jlc_wgrad_gather_ok", C, G, *sp) == 1
+    dws = [torch.full((C, CG, k, k, k), 0.125, device=d) for k in (1, 3, 5)]
+    H.call("vx_jlc_wgrad_gather", H.P(x), H.P(gs[0]), H.P(gs[1]), H.P(gs[2]), H.P(dws[0]), H.P(dws[1]), H.P(dws[2]), B, C, G, *sp, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for dw, ref, k in zip(dws, refs, (1, 3, 5)):
+        sc = float(ref.abs().max())
+        assert float((dw.double() - 0.125 - ref).abs().max()) <= 3e-6 * sc + 1e-6, (k, float((dw.double() - 0.125 - ref).abs().max()), sc)
 
 
 def test_fan_out_gradients_meet_in_one_sum():

@@ -1043,10 +1043,18 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
                 float* dw3 = f.w3.requires_grad() ? grad_ptr(f.w3) : nullptr;
                 float* dw5 = f.w5.requires_grad() ? grad_ptr(f.w5) : nullptr;
                 const bool g1fast = F.use_gconv1 && (Cg == 4 || Cg == 8 || Cg == 16) && V % 4 == 0;
-                const bool wtz = F.jlc_wg_tz && dw1 && dw3 && dw5 && vx_jlc_wgrad_tz_ok(C, G, D, H, W);
+                // small volumes: gather-GEMMs in one launch (conv_wgrad.hip) -- where the Toeplitz kernel does not reach (W % 4: the 6^3 / 3^3 levels of the 96^3 configurations)
+                // and at <= 64 voxels, where it is the faster one (4^3: 16 vs 27 us; at 8^3 the Toeplitz kernel wins 40 vs 57 us)
+                const bool tzok = F.jlc_wg_tz && dw1 && dw3 && dw5 && vx_jlc_wgrad_tz_ok(C, G, D, H, W);
+                const bool wga = F.jlc_wg_tz && dw1 && dw3 && dw5 && vx_jlc_wgrad_gather_ok(C, G, D, H, W) == 1 && (!tzok || V <= 64);
+                const bool wtz = !wga && tzok;
                 const int wg_pieces = f.tz_pieces ? f.tz_pieces : vx_jlc_tz_pieces();          // fixed NOW: the closure may be launched at the end of the encoder backward
                 wgrad_submit(s_, f.x.device().index(), [=](void* s) {
                     const float* gq = gk.data_ptr<float>();
+                    if (wga) {
+                        VX(vx_jlc_wgrad_gather, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, s);
+                        return;
+                    }
                     if (wtz) {                    // all three weight gradients in one launch on the matrix pipe (csrc/jlc_mfma.hip)
                         VX(vx_jlc_wgrad_tz_ns, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, wg_pieces, s);
                         return;

@@ -710,8 +710,9 @@ __global__ void __launch_bounds__(256) vx_stem_absmax_k(const float4* __restrict
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(mx + (second ? 1 : 0), __float_as_uint(m));
 }
 __global__ void __launch_bounds__(256) vx_stem_wgrad_f16_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, float* __restrict__ db,
-                                                           const unsigned* __restrict__ mx, int B, int Cin, int Di, int Hi, int Do, int Ho, int tiles_per_block, int ntiles) {
-    constexpr int Wi = 128, Wo = 32, U = 9, NIT = (VX_SW_NROW * 32 + 256 * U - 1) / (256 * U);
+                                                           const unsigned* __restrict__ mx, int B, int Cin, int Di, int Hi, int Wi, int Do, int Ho, int tiles_per_block, int ntiles) {
+    constexpr int U = 9, NIT = (VX_SW_NROW * 32 + 256 * U - 1) / (256 * U);
+    const int Wo = Wi >> 2, nq = Wi >> 2;              // 128-wide rows: 32 outputs = the 32 reduction slots; 96-wide rows (the shipped 96^3 patches): 24, the last lane group idles on zeros
     extern __shared__ __attribute__((aligned(16))) unsigned char vx_sw_lds[];
     unsigned short* __restrict__ qh = reinterpret_cast<unsigned short*>(vx_sw_lds);            // [133][7][32] hi pieces
     unsigned short* __restrict__ ql = qh + VX_SW_NROW * VX_SW_ROWH;                              // lo pieces
@@ -735,8 +736,11 @@ __global__ void __launch_bounds__(256) vx_stem_wgrad_f16_k(const float* __restri
         const int b = tt / Do;
         __syncthreads();                                        // the previous tile's operand reads are done
         // this wave's dy row (A operand): issued before the staging so that it travels with it
-        const float* __restrict__ dyr = dy + ((long)b * 16 + n) * Vo + ((long)od * Ho + 4 * hg + wave) * Wo + 8 * G;
-        const float4 d0 = *reinterpret_cast<const float4*>(dyr), d1 = *reinterpret_cast<const float4*>(dyr + 4);
+        const bool gok = 8 * G < Wo;
+        const float* __restrict__ dyr = dy + ((long)b * 16 + n) * Vo + ((long)od * Ho + 4 * hg + wave) * Wo + (gok ? 8 * G : 0);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 d0r = *reinterpret_cast<const float4*>(dyr), d1r = *reinterpret_cast<const float4*>(dyr + 4);
+        const float4 d0 = gok ? d0r : z4, d1 = gok ? d1r : z4;
         const float* __restrict__ xb = x + ((long)b * Cin + ci) * Vi;
 #pragma unroll 1
         for (int pass = 0; pass < NIT; ++pass) {
@@ -747,8 +751,8 @@ __global__ void __launch_bounds__(256) vx_stem_wgrad_f16_k(const float* __restri
                 const int row = min(it >> 5, VX_SW_NROW - 1), m = it & 31;
                 const int kd = row / 19, hh = row - kd * 19;
                 const int id = 4 * od - 3 + kd, ih = 16 * hg - 3 + hh;
-                const bool ok = (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi;
-                const float4 t_ = *reinterpret_cast<const float4*>(xb + ((long)(ok ? id : 0) * Hi + (ok ? ih : 0)) * Wi + 4 * m);
+                const bool ok = (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi && m < nq;          // (m >= Wi / 4: beyond the row -- zeros, so that no slot holds stale LDS)
+                const float4 t_ = *reinterpret_cast<const float4*>(xb + ((long)(ok ? id : 0) * Hi + (ok ? ih : 0)) * Wi + (ok ? 4 * m : 0));
                 v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -833,7 +837,7 @@ static int stem_wg_f16_on() {
     return vx_stem_wg_f16;
 }
 extern "C" int vx_down_wgrad_set_f16(int on) { vx_stem_wg_f16 = on ? 1 : 0; return 0; }      // A/B knob (tests): the stem weight gradient on the f16 pipe (default) or the fp32 MFMA kernel
-static bool stem_wg_f16_ok(int Cin, int Di, int Hi, int Wi, int Cout) { return Cout == 16 && Wi == 128 && Hi % 16 == 0 && Di % 4 == 0 && Cin >= 1 && Cin <= 8; }
+static bool stem_wg_f16_ok(int Cin, int Di, int Hi, int Wi, int Cout) { return Cout == 16 && (Wi == 128 || Wi == 96 || Wi == 64) && Hi % 16 == 0 && Di % 4 == 0 && Cin >= 1 && Cin <= 8; }
 
 static int vx_down_cfg(int B, int Cin, int Di, int Hi, int Wi, int Cout, int& CB, int& Do, int& Ho, int& Wo, int& ntiles, int& tpb, int& nblk) {
     Do = (Di + 6 - 7) / 4 + 1; Ho = (Hi + 6 - 7) / 4 + 1; Wo = (Wi + 6 - 7) / 4 + 1;
@@ -883,7 +887,7 @@ extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, fl
         const int tp16 = (nt16 + nb16 - 1) / nb16;
         nb16 = (nt16 + tp16 - 1) / tp16;
         const size_t shm16 = (size_t)2 * VX_SW_NROW * VX_SW_ROWH * 2;
-        vx_stem_wgrad_f16_k<<<dim3(nb16, Cin), dim3(256), shm16, st>>>(x, dy, ws, db, mx, B, Cin, Di, Hi, Do, Ho, tp16, nt16);
+        vx_stem_wgrad_f16_k<<<dim3(nb16, Cin), dim3(256), shm16, st>>>(x, dy, ws, db, mx, B, Cin, Di, Hi, Wi, Do, Ho, tp16, nt16);
         int sc16 = nb16 / 32;
         if (sc16 < 1) sc16 = 1;
         vx_wg_reduce_k<<<dim3(vx_cdiv(nw, 256), sc16), dim3(256), 0, st>>>(ws, dw, nw, nb16);
@@ -916,7 +920,7 @@ struct VxGw {
     const float *x, *dy;
     float *dw, *db;          // db (may be NULL): += sum of dy, formed by the waves of pair tile 0 from the A operands they load anyway
     int B, Cin, Di, Hi, Wi, Cout, Do, Ho, Wo, K, S, P;
-    int KV, npairs, chunk, nchunk;           // taps per channel, Cin * KV, voxels per wave chunk, chunks per sample
+    int KV, npairs, chunk, nchunk, al4;      // taps per channel, Cin * KV, voxels per wave chunk, chunks per sample, output rows 16-byte loadable
 };
 template <int MT>
 __global__ void __launch_bounds__(256) vx_wgrad_gather_mfma_k(VxGw p) {
@@ -948,15 +952,25 @@ __global__ void __launch_bounds__(256) vx_wgrad_gather_mfma_k(VxGw p) {
             const long vq = v0 + 4 * q;                          // this lane group's four voxels vq .. vq + 3 (Vo % 4 == 0: never straddles the end)
             const bool vok = vq < v_hi;
             float4 av[MT];
+            if (p.al4) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(dyb + (long)(16 * mt + r) * Vo + (vok ? vq : 0));
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(dyb + (long)(16 * mt + r) * Vo + (vok ? vq : 0));
+            } else {                                              // rows whose length is not a multiple of 4 (3^3 outputs: the 96^3 patches): four scalar loads
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float* __restrict__ rp = dyb + (long)(16 * mt + r) * Vo;
+                    const float t0 = rp[vq < v_hi ? vq : 0], t1 = rp[vq + 1 < v_hi ? vq + 1 : 0], t2 = rp[vq + 2 < v_hi ? vq + 2 : 0], t3 = rp[vq + 3 < v_hi ? vq + 3 : 0];
+                    av[mt] = make_float4(vq < v_hi ? t0 : 0.f, vq + 1 < v_hi ? t1 : 0.f, vq + 2 < v_hi ? t2 : 0.f, vq + 3 < v_hi ? t3 : 0.f);
+                }
+            }
             float bv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int v = (int)(vok ? vq + j : 0);
+                const bool vj = vok && vq + j < v_hi;
+                const int v = (int)(vj ? vq + j : 0);
                 const int od = v / HoWo, rem = v - od * HoWo, oh = rem / p.Wo, ow = rem - oh * p.Wo;
                 const int id = od * p.S - p.P + kd, ih = oh * p.S - p.P + kh, iw = ow * p.S - p.P + kw;
-                const bool ok = vok && nok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                const bool ok = vj && nok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
                 const float t_ = xb[ok ? ((long)id * p.Hi + ih) * p.Wi + iw : 0];
                 bv[j] = ok ? t_ : 0.0f;
             }
@@ -1001,7 +1015,7 @@ extern "C" int vx_conv_wgrad_gather_ok(int B, int Cin, int Di, int Hi, int Wi, i
     const int Do = (Di + 2 * P - K) / S + 1, Ho = (Hi + 2 * P - K) / S + 1, Wo = (Wi + 2 * P - K) / S + 1;
     if (Do < 1 || Ho < 1 || Wo < 1) return 0;
     const long Vo = (long)Do * Ho * Wo;
-    return (Vo % 4 == 0 && Vo <= (1L << 20) && (long)Cin * K * K * K <= (1L << 20)) ? 1 : 0;
+    return (Vo <= (1L << 20) && (long)Cin * K * K * K <= (1L << 20)) ? 1 : 0;
 }
 /* dw += the weight gradient of Conv3d(Cin -> Cout, kernel K, stride S, padding P, no groups), db += the bias gradient (db may be NULL); exact fp32 products on
    v_mfma_f32_16x16x4_f32.  Shapes: vx_conv_wgrad_gather_ok. */
@@ -1013,6 +1027,7 @@ extern "C" int vx_conv_wgrad_gather_mfma(const float* x, const float* dy, float*
     p.Do = (Di + 2 * P - K) / S + 1; p.Ho = (Hi + 2 * P - K) / S + 1; p.Wo = (Wi + 2 * P - K) / S + 1;
     p.KV = K * K * K; p.npairs = Cin * p.KV;
     const long Vo = (long)p.Do * p.Ho * p.Wo;
+    p.al4 = (Vo % 4 == 0) ? 1 : 0;
     const int ntile = vx_cdiv(p.npairs, 16);
     // waves = pair tiles x (B x chunks): aim at ~2 k waves (two per SIMD), chunks of >= 64 voxels (multiples of 16)
     long nch = 2048 / ((long)ntile * B);
@@ -1028,6 +1043,113 @@ extern "C" int vx_conv_wgrad_gather_mfma(const float* x, const float* dy, float*
     else if (Cout == 64) vx_wgrad_gather_mfma_k<4><<<grid, dim3(256), 0, st>>>(p);
     else vx_wgrad_gather_mfma_k<8><<<grid, dim3(256), 0, st>>>(p);
     VX_LAUNCH_CHECK("vx_conv_wgrad_gather_mfma");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The three weight gradients of a JLC block (grouped convolutions k = 5 / 3 / 1, stride 1, "same" padding: conv_blocks.py:51-58) at SMALL volumes as gather-GEMMs in one
+// launch -- the 8^3 / 4^3 levels of the 128^3 configurations, where the Toeplitz kernel of jlc_mfma.hip spends 41 / 29 us on 0.3 / 0.16 GFLOP (a march over planes with two
+// barriers per plane for a handful of blocks), and the 6^3 / 3^3 levels of the 96^3 configurations, which it does not cover at all (W % 4).  Same scheme as
+// vx_wgrad_gather_mfma_k: rows = the output channels of ONE group (16 rows; a group of 8 fills half of them), columns = 16 (input channel, tap) pairs of that group,
+// reduction = the voxels of a sample chunk, four per iteration; blockIdx.x walks the pair tiles of k = 5, then k = 3, then k = 1; blockIdx.z = group.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct VxJg {
+    const float* x;
+    const float* g[3];           // g5, g3, g1
+    float* dw[3];
+    int B, C, G, CG, D, H, W;
+    int t3, t1;                  // first pair tile of k = 3 / k = 1
+    int chunk, nchunk;
+};
+__global__ void __launch_bounds__(256) vx_jlc_wgrad_gather_k(VxJg p) {
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), r = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int sel = tile >= p.t1 ? 2 : (tile >= p.t3 ? 1 : 0);
+    const int K = sel == 0 ? 5 : (sel == 1 ? 3 : 1), KV = K * K * K, P = K >> 1;
+    const int nt = tile - (sel == 2 ? p.t1 : (sel == 1 ? p.t3 : 0));
+    const int npairs = p.CG * KV;
+    const int grp = blockIdx.z;
+    const int cg = blockIdx.y * 4 + wave;
+    const int b = cg / p.nchunk, ch = cg - b * p.nchunk;
+    const bool wok = b < p.B;
+    const int n = nt * 16 + r;
+    const bool nok = n < npairs;
+    const int nc = nok ? n : 0;
+    const int ci = nc / KV, tap = nc - ci * KV;
+    const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+    const long V = (long)p.D * p.H * p.W;
+    const float* __restrict__ xb = p.x + ((long)(wok ? b : 0) * p.C + grp * p.CG + ci) * V;
+    const bool rok = r < p.CG;                                   // (a group of 8: rows 8 .. 15 idle)
+    const float* __restrict__ dyr = p.g[sel] + ((long)(wok ? b : 0) * p.C + grp * p.CG + (rok ? r : 0)) * V;
+    vx_wf4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int HW = p.H * p.W;
+    const long v_lo = (long)ch * p.chunk, v_hi = min((long)(ch + 1) * p.chunk, V);
+    if (wok)
+        for (long v0 = v_lo; v0 < v_hi; v0 += 16) {
+            const long vq = v0 + 4 * q;
+            float a4[4], bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long v = vq + j;
+                const bool vok = v < v_hi;                          // (V need not be a multiple of 4 here: 3^3 = 27)
+                const int vi = (int)(vok ? v : 0);
+                const float ta = dyr[vi];
+                a4[j] = (vok && rok) ? ta : 0.0f;
+                const int od = vi / HW, rem = vi - od * HW, oh = rem / p.W, ow = rem - oh * p.W;
+                const int id = od - P + kd, ih = oh - P + kh, iw = ow - P + kw;
+                const bool ok = vok && nok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const float tb = xb[ok ? (id * p.H + ih) * p.W + iw : 0];
+                bv[j] = ok ? tb : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bv[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[wave][reg][lane] = acc[reg];
+    __syncthreads();
+    {
+        const int l = threadIdx.x & 63, reg = threadIdx.x >> 6;
+        const int co = 4 * (l >> 4) + reg, nn = nt * 16 + (l & 15);
+        if (co < p.CG && nn < npairs) {
+            const float v = (red[0][reg][l] + red[1][reg][l]) + (red[2][reg][l] + red[3][reg][l]);
+            atomicAdd(p.dw[sel] + (long)(grp * p.CG + co) * npairs + nn, v);          // dw_K layout (C, CG, K, K, K)
+        }
+    }
+}
+static int vx_jg_on = -1;
+static long vx_jg_max_v = 512;
+extern "C" int vx_jlc_wgrad_gather_set(int on) { vx_jg_on = on ? 1 : 0; return 0; }      // A/B knob (tests)
+extern "C" int vx_jlc_wgrad_gather_ok(int C, int G, int D, int H, int W) {
+    if (vx_jg_on < 0) { const char* e = getenv("VELOXSEG_JLC_WG_GATHER"); vx_jg_on = e ? atoi(e) : 1; const char* m = getenv("VELOXSEG_JLC_WG_GATHER_MAX_V"); if (m) vx_jg_max_v = atol(m); }
+    if (!vx_jg_on || C <= 0 || G <= 0 || C % G) return 0;
+    const int CG = C / G;
+    return ((CG == 8 || CG == 16 || CG == 4) && (long)D * H * W <= vx_jg_max_v && D > 0 && H > 0 && W > 0) ? 1 : 0;
+}
+/* dw1 / dw3 / dw5 += the weight gradients of the three grouped convolutions of a JLC block (any of the three may be NULL); x, g1, g3, g5: (B, C, D, H, W) */
+extern "C" int vx_jlc_wgrad_gather(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                                   void* stream) {
+    VX_REQUIRE(x && g1 && g3 && g5 && B > 0, "vx_jlc_wgrad_gather: null pointer");
+    VX_REQUIRE(vx_jlc_wgrad_gather_ok(C, G, D, H, W) == 1, "vx_jlc_wgrad_gather: shape not covered (C=%d G=%d %dx%dx%d)", C, G, D, H, W);
+    VX_REQUIRE(dw1 && dw3 && dw5, "vx_jlc_wgrad_gather: the three weight gradients are formed together");
+    VxJg p = {};
+    p.x = x; p.g[0] = g5; p.g[1] = g3; p.g[2] = g1; p.dw[0] = dw5; p.dw[1] = dw3; p.dw[2] = dw1;
+    p.B = B; p.C = C; p.G = G; p.CG = C / G; p.D = D; p.H = H; p.W = W;
+    const int n5 = vx_cdiv(p.CG * 125, 16), n3 = vx_cdiv(p.CG * 27, 16), n1 = vx_cdiv(p.CG, 16);
+    p.t3 = n5; p.t1 = n5 + n3;
+    const int ntile = n5 + n3 + n1;
+    const long V = (long)D * H * W;
+    long nch = 4096 / ((long)ntile * G * B);
+    if (nch < 1) nch = 1;
+    long chunk = (V + nch - 1) / nch;
+    chunk = (chunk + 15) / 16 * 16;
+    if (chunk < 64) chunk = 64;
+    p.chunk = (int)chunk;
+    p.nchunk = (int)((V + chunk - 1) / chunk);
+    const dim3 grid((unsigned)ntile, (unsigned)vx_cdiv(B * p.nchunk, 4), (unsigned)G);
+    vx_jlc_wgrad_gather_k<<<grid, dim3(256), 0, (hipStream_t)stream>>>(p);
+    VX_LAUNCH_CHECK("vx_jlc_wgrad_gather");
     return 0;
 }
 
