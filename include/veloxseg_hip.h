@@ -394,6 +394,8 @@ int vx_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* str
  * reconstruction decoders add into one accumulator from their own streams */
 int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, void* stream);
 int vx_mse_bwd_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, const float* coef, const float* gout, float* da, void* stream);
+/* the sum of squares of vx_sqdiff_sum_bs AND da = scale (a - b) in one pass (staged loss: scale = 2 w_rc / N_rc is known at forward time, utils/loss.py:52-66) */
+int vx_sqdiff_sum_grad_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, float* da, void* stream);
 int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
                      const double* rc_acc, long n_rc, float w_rc,
                      const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,

@@ -1540,16 +1540,26 @@ class StagedLoss:
         return x.data_ptr() + 4 * ch_off * Vx, x.shape[1] * Vx, ch_n * Vx
 
     def rc_forward(self, rc, x, ch_off):
+        """this branch's sum of squares against its channels of the input AND -- the coefficient 2 w_rc / N_rc is known already: the reconstructions cover the input, so
+        N_rc = x.numel() (checked in finalize) -- its MSE gradient, in one pass (vx_sqdiff_sum_grad_bs); rc_backward hands the stored gradient out"""
+        import numpy as _np
         rc = _c(rc)
         ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
         assert rc[0].numel() == n and x.is_contiguous()
-        H.call("vx_sqdiff_sum_bs", H.P(rc), ptr, n, bstride, rc.shape[0], H.P(self.rc_acc, torch.float64), H.stream_ptr())
+        self.n_rc_expected = int(x.numel())
+        scale = float(_np.float32(2.0 * self.w_rc / float(self.n_rc_expected))) if self.w_rc != 0.0 else 0.0
+        drc = torch.empty_like(rc)
+        H.call("vx_sqdiff_sum_grad_bs", H.P(rc), ptr, n, bstride, rc.shape[0], H.P(self.rc_acc, torch.float64), scale, H.P(drc), H.stream_ptr())
+        self._drc = getattr(self, "_drc", {})
+        self._drc[int(ch_off)] = drc
         return rc
 
     def finalize(self, gram_seg, grams_rc, n_rc):
         """-> scalar loss (device tensor); keeps the coefficients and the Gram gradients for the backward fans"""
         dev = self.seg_acc.device
         nh, B, C, M = self.nh, self.B, self.C, self.M
+        if getattr(self, "n_rc_expected", None) is not None and int(n_rc) != self.n_rc_expected:
+            raise RuntimeError(f"staged loss: the reconstruction branches cover {int(n_rc)} elements, the input has {self.n_rc_expected}: the MSE gradient formed in the forward used the wrong 1 / N")
         st = H.stream_ptr()
         hw = _head_weights(self.head_weights, dev)
         self.coef = torch.empty((nh * (1 + B * C * 2) + 2,), device=dev, dtype=torch.float32)
@@ -1586,6 +1596,9 @@ class StagedLoss:
         return grads
 
     def rc_backward(self, rc, x, ch_off):
+        drc = getattr(self, "_drc", {}).get(int(ch_off))
+        if drc is not None and drc.shape == rc.shape:
+            return drc                                   # formed by rc_forward
         ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
         drc = torch.empty_like(rc)
         H.call("vx_mse_bwd_bs", H.P(rc), ptr, n, bstride, rc.shape[0], self.misc, None, H.P(drc), H.stream_ptr())
