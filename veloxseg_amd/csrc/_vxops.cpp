@@ -1203,6 +1203,114 @@ struct FFNFn : public torch::autograd::Function<FFNFn> {
     }
 };
 
+
+// The VeloxSeg loss (utils/loss.py:52-66: sum_h w_h (CE + Dice)(logits_h) + w_rc MSE(rcs, x) + w_f / M sum_m MSE(G_seg, G_m)) as a C++ autograd node: the same C-ABI
+// sequence as functional._VeloxLossFn (deep-supervision heads on coarser grids are interpolated inside the kernels of loss_ds.hip), no interpreter, no Python state.
+// outputs = nh logits [+ rcs, G_seg, G_rc x M]
+struct LossState {
+    std::vector<Tensor> logits, tail;          // tail: rcs, sr, G_seg, G_m...
+    Tensor labels, coef;
+    std::vector<int> dims;                     // fused deep supervision: (d, h, w) of heads 1..
+    int nh = 0, M = 0, B = 0, C = 0, D = 0, H = 0, W = 0, lab_kind = 0;
+    long V = 0;
+    bool ds = false, has_tail = false;
+};
+inline int lab_kind_of(const Tensor& labels) {
+    if (labels.scalar_type() == at::kLong) return 0;
+    if (labels.scalar_type() == at::kInt) return 1;
+    if (labels.scalar_type() == at::kByte) return 2;
+    TORCH_CHECK(false, "veloxseg::seg_loss: labels must be int64 / int32 / uint8, got ", labels.scalar_type());
+}
+struct LossFn : public torch::autograd::Function<LossFn> {
+    static Tensor forward(AutogradContext* ctx, at::TensorList outs, const Tensor& labels_in, const OptT& sr_in, std::vector<double> head_w, double w_rc, double w_f, int64_t num_modal) {
+        auto h = put_state<LossState>(ctx);
+        LossState& st = h->s;
+        const int M = (int)num_modal;
+        const int nh = (int)outs.size() - (M > 0 ? 2 + M : 0);
+        TORCH_CHECK(nh >= 1 && nh <= 4 && (int)head_w.size() == nh, "veloxseg::seg_loss: 1..4 deep-supervision heads with one weight each (got ", nh, " heads, ", head_w.size(), " weights)");
+        check_in(outs[0], "seg_loss");
+        for (int i = 0; i < nh; ++i) st.logits.push_back(contig(outs[i]));
+        const Tensor& l0 = st.logits[0];
+        TORCH_CHECK(l0.dim() == 5, "veloxseg::seg_loss: logits are (B, C, D, H, W)");
+        st.nh = nh; st.M = M; st.B = (int)l0.size(0); st.C = (int)l0.size(1); st.D = (int)l0.size(2); st.H = (int)l0.size(3); st.W = (int)l0.size(4);
+        st.V = (long)st.D * st.H * st.W;
+        st.labels = contig(labels_in);
+        st.lab_kind = lab_kind_of(st.labels);
+        TORCH_CHECK(st.labels.is_cuda() && st.labels.numel() == (long)st.B * st.V, "veloxseg::seg_loss: labels must be a CUDA tensor of B x D x H x W elements");
+        void* s_ = cur_stream(l0);
+        const int B = st.B, C = st.C;
+        auto fopt = l0.options();
+        Tensor hw = at::tensor(std::vector<float>(head_w.begin(), head_w.end()), at::TensorOptions().dtype(at::kFloat)).to(l0.device(), /*non_blocking=*/false);
+        Tensor seg_acc = at::empty({(long)nh * (1 + (long)B * C * 3)}, fopt.dtype(at::kDouble));
+        const float* lp[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < nh; ++i) lp[i] = fp(st.logits[i]);
+        for (int i = 1; i < nh; ++i) if (st.logits[i].sizes().slice(2) != l0.sizes().slice(2)) st.ds = true;
+        if (st.ds) {
+            TORCH_CHECK(vx_seg_loss_ds_ok(C, st.D, st.H, st.W) == 1, "veloxseg::seg_loss: deep-supervision heads on coarser grids need C in 2..4 and W % 4 == 0 with W / 4 dividing 64; up-sample them first");
+            for (int i = 1; i < nh; ++i) for (int k = 2; k < 5; ++k) st.dims.push_back((int)st.logits[i].size(k));
+            if (st.dims.empty()) st.dims.assign(3, 1);
+            VX(vx_seg_loss_ds_fwd, lp[0], lp[1], lp[2], lp[3], st.dims.data(), nh, (const void*)st.labels.data_ptr(), st.lab_kind, seg_acc.data_ptr<double>(), B, C, st.D, st.H, st.W, s_);
+        } else
+            VX(vx_seg_loss_fwd, lp[0], lp[1], lp[2], lp[3], nh, (const void*)st.labels.data_ptr(), st.lab_kind, seg_acc.data_ptr<double>(), B, C, st.V, s_);
+        st.has_tail = M > 0;
+        Tensor rc_acc;
+        if (st.has_tail) {
+            TORCH_CHECK(sr_in.has_value() && sr_in->defined(), "veloxseg::seg_loss: sr_labels (the network input) is needed for the reconstruction term");
+            Tensor rcs = contig(outs[nh]), sr = contig(*sr_in);
+            TORCH_CHECK(rcs.sizes() == sr.sizes(), "veloxseg::seg_loss: reconstructions and sr_labels differ in shape");
+            st.tail.push_back(rcs); st.tail.push_back(sr);
+            for (int i = 0; i < 1 + M; ++i) st.tail.push_back(contig(outs[nh + 1 + i]));
+            rc_acc = at::empty({1}, fopt.dtype(at::kDouble));
+            VX(vx_sqdiff_sum, fp(rcs), fp(sr), (long)rcs.numel(), rc_acc.data_ptr<double>(), s_);
+        }
+        st.coef = at::empty({(long)nh * (1 + (long)B * C * 2) + 2}, fopt);
+        Tensor loss = at::empty({}, fopt);                    // 0-dim (NOT loss.view({}): the empty braces pick view(ScalarType) with dtype Byte)
+        const float* gp[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int m = 0; m < M && m < 4; ++m) gp[m] = fp(st.tail[3 + m]);
+        VX(vx_loss_finalize, seg_acc.data_ptr<double>(), nh, B, C, st.V, fp(hw), st.has_tail ? rc_acc.data_ptr<double>() : (const double*)nullptr, st.has_tail ? (long)st.tail[0].numel() : 1L, (float)w_rc,
+           st.has_tail ? fp(st.tail[2]) : (const float*)nullptr, gp[0], gp[1], gp[2], gp[3], st.has_tail ? M : 0, st.has_tail ? (int)st.tail[2].size(1) : 0, (float)w_f, mp(loss), mp(st.coef), s_);
+        return loss;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        LossState& st = get_state<LossState>(ctx);
+        const int nh = st.nh, M = st.M, B = st.B, C = st.C;
+        void* s_ = cur_stream(g[0]);
+        Tensor go = contig(g[0].reshape({1}).to(at::kFloat));
+        const int nout = nh + (st.has_tail ? 2 + M : 0);
+        variable_list out(nout + 6);                          // the list's tensors first (argument order), then labels, sr, head_w, w_rc, w_f, num_modal
+        const long stride = 1 + (long)B * C * 2;
+        std::vector<Tensor> grads;
+        const float* lp[4] = {nullptr, nullptr, nullptr, nullptr};
+        float* dp[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < nh; ++i) { grads.push_back(at::empty_like(st.logits[i])); lp[i] = fp(st.logits[i]); dp[i] = grads[i].data_ptr<float>(); }
+        if (st.ds) {
+            const int nws = vx_seg_loss_ds_ws_floats(st.dims.data(), nh, B, C, st.D);
+            TORCH_CHECK(nws >= 0, "vx_seg_loss_ds_ws_floats failed");
+            Tensor ws = at::empty({(long)std::max(nws, 1)}, st.coef.options());
+            VX(vx_seg_loss_ds_bwd, lp[0], lp[1], lp[2], lp[3], st.dims.data(), nh, (const void*)st.labels.data_ptr(), st.lab_kind, fp(st.coef), (int)stride, fp(go), dp[0], dp[1], dp[2], dp[3], mp(ws),
+               B, C, st.D, st.H, st.W, s_);
+        } else
+            VX(vx_seg_loss_bwd4, lp[0], lp[1], lp[2], lp[3], nh, (const void*)st.labels.data_ptr(), st.lab_kind, fp(st.coef), (int)stride, fp(go), dp[0], dp[1], dp[2], dp[3], B, C, st.V, s_);
+        for (int i = 0; i < nh; ++i) out[i] = grads[i];
+        if (st.has_tail) {
+            const float* misc = fp(st.coef) + (long)nh * stride;
+            Tensor drc = at::empty_like(st.tail[0]);
+            VX(vx_mse_bwd, fp(st.tail[0]), fp(st.tail[1]), misc, fp(go), mp(drc), (long)drc.numel(), s_);
+            out[nh] = drc;
+            Tensor dgs = at::empty_like(st.tail[2]);
+            std::vector<Tensor> dgm;
+            const float* gp[4] = {nullptr, nullptr, nullptr, nullptr};
+            float* dgp[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int m = 0; m < M && m < 4; ++m) { dgm.push_back(at::empty_like(st.tail[3 + m])); gp[m] = fp(st.tail[3 + m]); dgp[m] = dgm[m].data_ptr<float>(); }
+            VX(vx_gram_mse_bwd, fp(st.tail[2]), gp[0], gp[1], gp[2], gp[3], M, misc + 1, fp(go), mp(dgs), dgp[0], dgp[1], dgp[2], dgp[3], (long)dgs.numel(), s_);
+            out[nh + 1] = dgs;
+            for (int m = 0; m < M; ++m) out[nh + 2 + m] = dgm[m];
+        }
+        ctx->saved_data.clear();
+        return out;
+    }
+};
+
 }  // namespace
 
 // =================================================================================================================== python surface
@@ -1274,6 +1382,79 @@ Tensor op_gram_meta(const Tensor& x) { return at::empty({x.size(0), x.size(1), x
 Tensor op_gram_cpu(const Tensor&) { op_no_cpu("gram"); }
 }  // namespace
 
+// ---- the operators north_star names: PWA attention (PWA.py:329), the JLC block (conv_blocks.py:72), the FFN tail (attention_utils.py:45-71), the loss (utils/loss.py:50-66).
+// Everything they need arrives as an argument -- the window plan as integer lists, the dropout site and the {seed, step} RNG-state tensor (veloxseg_amd.functional.rng_state)
+// -- so no Python state stands behind any key.
+namespace {
+const void* rs_of(const OptT& rng_state, double p, const char* what) {
+    if (p <= 0.0) return nullptr;
+    TORCH_CHECK(rng_state.has_value() && rng_state->defined(), "veloxseg::", what, ": dropout p > 0 needs rng_state = the {seed, step} int64 device tensor (veloxseg_amd.functional.rng_state(device))");
+    TORCH_CHECK(rng_state->is_cuda() && rng_state->scalar_type() == at::kLong && rng_state->numel() >= 2 && rng_state->is_contiguous(), "veloxseg::", what, ": rng_state must be a contiguous CUDA int64 tensor {seed, step}");
+    return rng_state->data_ptr();
+}
+VxPwaPlan plan_of(at::IntArrayRef grid, at::IntArrayRef n, int64_t heads, at::IntArrayRef small, at::IntArrayRef nwin) {
+    TORCH_CHECK(grid.size() == 3 && n.size() == 3 && small.size() % 3 == 0 && small.size() == nwin.size() && small.size() >= 3 && small.size() <= 12,
+                "veloxseg::pwa_attention: grid / n are 3 integers, small / nwin 3 per window scale (1..4 scales)");
+    VxPwaPlan pl = {};
+    const int nb = (int)small.size() / 3;
+    for (int k = 0; k < 3; ++k) { pl.grid[k] = (int)grid[k]; pl.n[k] = (int)n[k]; }
+    pl.heads = (int)heads; pl.nb = nb;
+    int off = 0;
+    for (int i = 0; i < nb; ++i) {
+        for (int k = 0; k < 3; ++k) { pl.small[i][k] = (int)small[3 * i + k]; pl.nwin[i][k] = (int)nwin[3 * i + k]; }
+        pl.woff[i] = off;
+        off += (int)(nwin[3 * i] * nwin[3 * i + 1] * nwin[3 * i + 2]);
+    }
+    pl.Ntot = off;
+    pl.l = (int)(n[0] * n[1] * n[2]);
+    return pl;
+}
+std::vector<Tensor> op_pwa_meta(const Tensor&, at::TensorList qkv, at::IntArrayRef grid, at::IntArrayRef, int64_t heads, at::IntArrayRef small, at::IntArrayRef, int64_t, int64_t cv, double, int64_t, const OptT&) {
+    TORCH_CHECK(qkv.size() >= 3 && qkv.size() % 3 == 0, "veloxseg::pwa_attention: qkv = (q, k, v) per modality");
+    std::vector<Tensor> out;
+    for (size_t m = 0; m < qkv.size() / 3; ++m) out.push_back(at::empty({qkv[0].size(0), (int64_t)(small.size() / 3) * heads * cv, grid[0], grid[1], grid[2]}, qkv[0].options()));
+    return out;
+}
+std::vector<Tensor> op_pwa(const Tensor& table, at::TensorList qkv, at::IntArrayRef grid, at::IntArrayRef n, int64_t heads, at::IntArrayRef small, at::IntArrayRef nwin, int64_t cq, int64_t cv,
+                           double p_attn, int64_t site, const OptT& rng_state) {
+    TORCH_CHECK(qkv.size() >= 3 && qkv.size() % 3 == 0, "veloxseg::pwa_attention: qkv = (q, k, v) per modality");
+    if (qkv[0].is_meta()) return op_pwa_meta(table, qkv, grid, n, heads, small, nwin, cq, cv, p_attn, site, rng_state);
+    if (!qkv[0].is_cuda()) op_no_cpu("pwa_attention");
+    VxPwaPlan pl = plan_of(grid, n, heads, small, nwin);
+    return PwaCoreFn::apply(table, (int64_t)reinterpret_cast<intptr_t>(&pl), cq, cv, p_attn, site, (int64_t)reinterpret_cast<intptr_t>(rs_of(rng_state, p_attn, "pwa_attention")), qkv);
+}
+std::vector<Tensor> op_pwa_cpu(const Tensor&, at::TensorList, at::IntArrayRef, at::IntArrayRef, int64_t, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t, double, int64_t, const OptT&) { op_no_cpu("pwa_attention"); }
+
+Tensor op_jlc_meta(const Tensor& x, at::TensorList, at::TensorList, int64_t, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, int64_t, const OptT&) { return at::empty_like(x); }
+Tensor op_jlc(const Tensor& x, at::TensorList ws, at::TensorList bs, int64_t groups, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site,
+              const OptT& rng_state) {
+    TORCH_CHECK(ws.size() >= 1 && ws.size() <= 3 && bs.size() == ws.size(), "veloxseg::jlc_block: 1..3 grouped convolutions with one bias each");
+    if (x.is_meta()) return op_jlc_meta(x, ws, bs, groups, l1w, l1b, l2w, l2b, p, site, rng_state);
+    if (!x.is_cuda()) op_no_cpu("jlc_block");
+    return JLCFn::apply(x, ws[0], ws.size() > 1 ? OptT(ws[1]) : OptT(), ws.size() > 2 ? OptT(ws[2]) : OptT(), bs[0], bs.size() > 1 ? OptT(bs[1]) : OptT(), bs.size() > 2 ? OptT(bs[2]) : OptT(), groups,
+                        l1w, l1b, l2w, l2b, p, site, (int64_t)reinterpret_cast<intptr_t>(rs_of(rng_state, p, "jlc_block")));
+}
+Tensor op_jlc_cpu(const Tensor&, at::TensorList, at::TensorList, int64_t, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, int64_t, const OptT&) { op_no_cpu("jlc_block"); }
+
+Tensor op_ffn_meta(const Tensor& y, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, int64_t, int64_t, const OptT&) { return at::empty_like(y); }
+Tensor op_ffn(const Tensor& y, const Tensor& gamma, const Tensor& beta, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, double p, int64_t site1, int64_t site2,
+              const OptT& rng_state) {
+    if (y.is_meta()) return op_ffn_meta(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rng_state);
+    if (!y.is_cuda()) op_no_cpu("ffn_tail");
+    return FFNFn::apply(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, (int64_t)reinterpret_cast<intptr_t>(rs_of(rng_state, p, "ffn_tail")));
+}
+Tensor op_ffn_cpu(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, int64_t, int64_t, const OptT&) { op_no_cpu("ffn_tail"); }
+
+Tensor op_loss_meta(at::TensorList outs, const Tensor&, const OptT&, at::ArrayRef<double>, double, double, int64_t) { return at::empty({}, outs[0].options()); }
+Tensor op_loss(at::TensorList outs, const Tensor& labels, const OptT& sr, at::ArrayRef<double> head_w, double w_rc, double w_f, int64_t num_modal) {
+    TORCH_CHECK(outs.size() >= 1, "veloxseg::seg_loss: no outputs");
+    if (outs[0].is_meta()) return op_loss_meta(outs, labels, sr, head_w, w_rc, w_f, num_modal);
+    if (!outs[0].is_cuda()) op_no_cpu("seg_loss");
+    return LossFn::apply(outs, labels, sr, head_w.vec(), w_rc, w_f, num_modal);
+}
+Tensor op_loss_cpu(at::TensorList, const Tensor&, const OptT&, at::ArrayRef<double>, double, double, int64_t) { op_no_cpu("seg_loss"); }
+}  // namespace
+
 TORCH_LIBRARY(veloxseg, m) {
     m.def("conv3d(Tensor x, Tensor w, Tensor? b, int stride, int padding, int groups, int pixel_shuffle) -> Tensor");
     m.def("conv_transpose_k2s2(Tensor x, Tensor w, Tensor b) -> Tensor");
@@ -1282,6 +1463,10 @@ TORCH_LIBRARY(veloxseg, m) {
     m.def("space_to_depth2(Tensor x) -> Tensor");
     m.def("upsample_trilinear(Tensor x, int[] size) -> Tensor");
     m.def("gram(Tensor x) -> Tensor");
+    m.def("pwa_attention(Tensor table, Tensor[] qkv, int[] grid, int[] n, int heads, int[] small, int[] nwin, int cq, int cv, float p_attn, int site, Tensor? rng_state=None) -> Tensor[]");
+    m.def("jlc_block(Tensor x, Tensor[] ws, Tensor[] bs, int groups, Tensor l1w, Tensor l1b, Tensor l2w, Tensor l2b, float p, int site, Tensor? rng_state=None) -> Tensor");
+    m.def("ffn_tail(Tensor y, Tensor gamma, Tensor beta, Tensor w1, Tensor b1, Tensor w2, Tensor b2, float p, int site1, int site2, Tensor? rng_state=None) -> Tensor");
+    m.def("seg_loss(Tensor[] outputs, Tensor labels, Tensor? sr_labels, float[] head_weights, float w_rc, float w_f, int num_modal) -> Tensor");
 }
 #define VX_OP_IMPLS(KEY, SUF)                                 \
     TORCH_LIBRARY_IMPL(veloxseg, KEY, m) {                    \
@@ -1292,6 +1477,10 @@ TORCH_LIBRARY(veloxseg, m) {
         m.impl("space_to_depth2", op_s2d##SUF);               \
         m.impl("upsample_trilinear", op_up##SUF);             \
         m.impl("gram", op_gram##SUF);                         \
+        m.impl("pwa_attention", op_pwa##SUF);                 \
+        m.impl("jlc_block", op_jlc##SUF);                     \
+        m.impl("ffn_tail", op_ffn##SUF);                      \
+        m.impl("seg_loss", op_loss##SUF);                     \
     }
 VX_OP_IMPLS(Autograd, )
 VX_OP_IMPLS(CUDA, )

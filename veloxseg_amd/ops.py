@@ -10,8 +10,10 @@ a CPU tensor raises the library's "no CPU path" error -- there is no fallback ke
     torch.ops.veloxseg.layer_norm_cf(x, gamma, beta)                                  channels-first LayerNorm, attention_utils.py:29-43
     torch.ops.veloxseg.gelu_dropout(a, p, site) / residual_dropout(x, z, alpha, p, site)
     torch.ops.veloxseg.space_to_depth2(x) / upsample_trilinear(x, size) / gram(x)
-    torch.ops.veloxseg.pwa_attention(table, qkv, grid, n, heads, small, nwin, cq, cv, p_attn, site)     PWA.py:106-200,308-327
-    torch.ops.veloxseg.seg_loss(outputs, labels, sr_labels, head_weights, w_rc, w_f, num_modal)         utils/loss.py:52-66
+    torch.ops.veloxseg.pwa_attention(table, qkv, grid, n, heads, small, nwin, cq, cv, p_attn, site, rng_state=None)     PWA.py:106-200,308-327
+    torch.ops.veloxseg.jlc_block(x, ws, bs, groups, l1w, l1b, l2w, l2b, p, site, rng_state=None)                         conv_blocks.py:41-75
+    torch.ops.veloxseg.ffn_tail(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rng_state=None)                         attention_utils.py:45-71 (LN + FFN + residual)
+    torch.ops.veloxseg.seg_loss(outputs, labels, sr_labels, head_weights, w_rc, w_f, num_modal)                          utils/loss.py:52-66
 
 The modules of veloxseg_amd.model reach the seven C++-registered operators THROUGH the dispatcher (functional.py routes conv3d, conv_transpose_k2s2, instance_norm_sum,
 layer_norm_cf, space_to_depth2, upsample_trilinear and gram to torch.ops.veloxseg.*); the composite operators are called as functions of veloxseg_amd.functional.
@@ -24,11 +26,12 @@ import torch
 from . import _hip as H
 from . import functional as VF
 
-# The seven operators whose bodies are pure C++ (conv3d, conv_transpose_k2s2, instance_norm_sum, layer_norm_cf, space_to_depth2, upsample_trilinear, gram) are
-# DEFINED AND REGISTERED IN C++ (csrc/_vxops.cpp: TORCH_LIBRARY(veloxseg) with Autograd / CUDA / Meta keys and a CPU key that raises): importing the extension
-# registers them.  The operators below need Python-side state (dropout sites and the RNG state tensor, the PWA plan cache, the staged loss) and stay Python bodies
-# under CompositeImplicitAutograd on the same library.
-CPP_OPS = ("conv3d", "conv_transpose_k2s2", "instance_norm_sum", "layer_norm_cf", "space_to_depth2", "upsample_trilinear", "gram")
+# Eleven operators are DEFINED AND REGISTERED IN C++ (csrc/_vxops.cpp: TORCH_LIBRARY(veloxseg) with Autograd / CUDA / Meta keys and a CPU key that raises): the seven
+# generic ones (conv3d, conv_transpose_k2s2, instance_norm_sum, layer_norm_cf, space_to_depth2, upsample_trilinear, gram) and, since round 5, the four north_star names --
+# pwa_attention (the window plan as integer lists, the dropout site and the {seed, step} RNG-state tensor as arguments), jlc_block, ffn_tail, seg_loss.  Importing the
+# extension registers them.  gelu_dropout / residual_dropout stay Python bodies under CompositeImplicitAutograd (they fetch the RNG-state tensor themselves).
+CPP_OPS = ("conv3d", "conv_transpose_k2s2", "instance_norm_sum", "layer_norm_cf", "space_to_depth2", "upsample_trilinear", "gram",
+           "pwa_attention", "jlc_block", "ffn_tail", "seg_loss")          # (round 5: the four operators north_star names are C++ dispatcher ops too)
 _CPP = VF.cpp_module()
 if _CPP is None and os.environ.get("VELOXSEG_NO_CPP") != "1":
     raise RuntimeError("veloxseg_amd.ops: the C++ operator module (veloxseg_amd._vxops) is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -81,4 +84,4 @@ _define("pwa_attention(Tensor table, Tensor[] qkv, int[] grid, int[] n, int head
 _define("seg_loss(Tensor[] outputs, Tensor labels, Tensor? sr_labels, float[] head_weights, float w_rc, float w_f, int num_modal) -> Tensor", _seg_loss)
 
 OPS = ("conv3d", "conv_transpose_k2s2", "instance_norm_sum", "layer_norm_cf", "gelu_dropout", "residual_dropout", "space_to_depth2", "upsample_trilinear", "gram",
-       "pwa_attention", "seg_loss")
+       "pwa_attention", "seg_loss") + (("jlc_block", "ffn_tail") if _CPP is not None else ())
