@@ -1012,14 +1012,28 @@ def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big,
             close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 1e-4, f"gradient {i}")      # (2e-5 of the maximum is seen run to run with EITHER form)
 
 
-@pytest.mark.parametrize("ncls,B,S,labdtype", [(2, 2, (32, 32, 32), torch.int64), (4, 1, (32, 48, 64), torch.uint8), (3, 2, (16, 16, 128), torch.int32),
-                                               (2, 2, (24, 24, 96), torch.int64), (4, 1, (16, 24, 48), torch.uint8)], ids=["c2", "c4_aniso", "c3", "c2_w96", "c4_w48"])
-def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype):
+@pytest.mark.parametrize("ncls,B,S,labdtype,factors", [(2, 2, (32, 32, 32), torch.int64, (2, 4, 8)), (4, 1, (32, 48, 64), torch.uint8, (2, 4, 8)), (3, 2, (16, 16, 128), torch.int32, (2, 4, 8)),
+                                                       (2, 2, (24, 24, 96), torch.int64, (2, 4, 8)), (4, 1, (16, 24, 48), torch.uint8, (2, 4, 8)),
+                                                       (2, 2, (32, 64, 128), torch.uint8, (8, 16, 32)), (3, 1, (16, 40, 64), torch.int64, (4, 8, 16))],
+                         ids=["c2", "c4_aniso", "c3", "c2_w96", "c4_w48", "c2_model_ratios", "c3_ragged_rows"])
+@pytest.mark.parametrize("columns", [1, 0], ids=["columns", "rows"])
+def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype, factors, columns):
     """veloxseg_loss on heads that stay on their own grids (csrc/loss_ds.hip interpolates inside the kernels) == up-sample (vx_upsample_trilinear) then
-    veloxseg_loss == the oracle (F.interpolate + CE + Dice): loss 1e-5 relative, gradients of every head 1e-4 of their scale."""
+    veloxseg_loss == the oracle (F.interpolate + CE + Dice): loss 1e-5 relative, gradients of every head 1e-4 of their scale.  Both thread maps of the fused kernels:
+    column owners (W/4 divides 256; the 128^3 patches with heads at 1/8, 1/16, 1/32 -- `c2_model_ratios` -- and every W = 32 / 64 / 128 case) and the row sweep
+    (the only one for W = 96 / 48)."""
     VF = _vf()
+    from veloxseg_amd import _hip as H
     d = dev()
-    heads = [rnd(B, ncls, *S, seed=1)] + [rnd(B, ncls, *[max(s // f, 2) for s in S], seed=2 + k) for k, f in enumerate((2, 4, 8))]
+    H.call("vx_seg_loss_ds_set_columns", columns)
+    try:
+        _ds_loss_case(VF, d, ncls, B, S, labdtype, factors)
+    finally:
+        H.call("vx_seg_loss_ds_set_columns", 1)
+
+
+def _ds_loss_case(VF, d, ncls, B, S, labdtype, factors):
+    heads = [rnd(B, ncls, *S, seed=1)] + [rnd(B, ncls, *[max(s // f, 2) for s in S], seed=2 + k) for k, f in enumerate(factors)]
     lab = torch.randint(0, ncls, (B, 1, *S), generator=torch.Generator().manual_seed(3)).to(labdtype)
     w = (0.25, 0.25, 0.25, 0.25)
     res = []

@@ -70,7 +70,8 @@ def analyse(tag, tape):
     lanes = collections.Counter()
     for i in range(n):
         lanes[lane[i]] += us[i]
-    return dict(tag=tag, n=n, total=sum(us), cp=fin[end], lanes=dict(lanes), path=[(nm[i], us[i], grid[i]) for i in reversed(path)], all=[(nm[i], us[i], grid[i]) for i in range(n)])
+    return dict(tag=tag, n=n, total=sum(us), cp=fin[end], lanes=dict(lanes), path=[(nm[i], us[i], grid[i]) for i in reversed(path)], all=[(nm[i], us[i], grid[i]) for i in range(n)],
+                sched=[(i, lane[i], nm[i], us[i], fin[i] - us[i], [waits[4 * i + w] for w in range(4) if waits[4 * i + w] >= 0], i in path) for i in range(n)])
 
 
 def measure(fn):
@@ -107,6 +108,10 @@ for tag, tapes, fn in stages:
     if verbose:
         for nm, u, g in worst["path"]:
             print(f"      {u:7.1f} us  g{g:<6d} {nm}")
+    if os.environ.get("VX_VERBOSE", "0") == "2":
+        # the whole schedule of the stage's longest tape: node, lane, earliest start, duration, cross-lane waits, * = on the critical path
+        for i, ln, nm, u, t0, ws, onp in worst["sched"]:
+            print(f"   {'*' if onp else ' '} #{i:<3d} lane {ln}  start {t0:7.1f}  {u:6.1f} us  {nm}" + (f"   waits {ws}" if ws else ""))
 print(f"stages one after the other: measured {step_meas:.0f} us, sum of stage critical paths {step_cp:.0f} us")
 if "dec_wg" in G:
     # the decoders' weight gradients run on the fourth lane BESIDE the encoder backward: that phase is as long as the two together need

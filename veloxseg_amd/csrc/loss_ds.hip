@@ -442,6 +442,382 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
     P.out[hh][e] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------ column-owner kernels
+// The same two sweeps with a different thread -> voxel map (round 5).  A thread owns ONE quad column X0 of the block's Z slice and walks consecutive rows
+// (256 / (W/4) row groups per block; W/4 must divide 256), so everything that depends on X only is computed ONCE per thread instead of once per quad:
+//   * per low-resolution head the NK (3 or 4) coarse columns i0 .. i0 + NK - 1 that the quad's four voxels interpolate from, and a dense 4 x NK weight matrix
+//     cw[j][k] (two non-zeros per row): a voxel's logit is  sum_k cw[j][k] * (k1 * row_a[i0 + k] + l1 * row_b[i0 + k])  -- 2 NK LDS reads per head and grid
+//     instead of 16 gathers with their index arithmetic (the old kernels spent most of their issue slots on vx_ds_coord and address math);
+//   * backward: the ADJOINT of that interpolation is the transposed matrix: the quad's gradient collapses to NK column sums (registers), which are accumulated over
+//     the thread's consecutive rows in two register rows (coarse rows a1 and a1 + 1) and flushed to the wave's LDS accumulators with ds_add_f32 only when a1 advances
+//     (every 1 / scale rows): ~40 LDS atomics per thread and slice replace the gradient staging buffer, the band tables and their ~300 dependent LDS round trips per step.
+// Everything else (soft-max arithmetic, accumulator layout, the D adjoint behind it) is unchanged; vx_seg_loss_ds_set_columns(0) / VELOXSEG_DS_COLUMNS=0 selects the
+// row-sweep kernels above (the only ones for W/4 = 24 / 12: the 96^3 patches).
+template <int NK>
+__device__ __forceinline__ void vx_ds_col_setup(int X0, int wl, int W, int& i0, float (&cw)[4][NK]) {
+    int a[4], b[4];
+    float l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, wl, W, a[j], b[j], l[j]);
+    i0 = a[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) cw[j][k] = ((a[j] - i0) == k ? 1.0f - l[j] : 0.0f) + ((b[j] - i0) == k ? l[j] : 0.0f);
+}
+
+// the Z-interpolated slices as vx_ds_stage_slice, each followed by 4 zeroed floats (a thread reads NK columns from i0 on: past the end of a row the weights are zero,
+// the values must be finite)
+template <int C>
+__device__ __forceinline__ void vx_ds_stage_slice_pad(const VxDs& P, int b, int Z, float* __restrict__ lds, int (&loff)[3]) {
+    int off = 0;
+    for (int hh = 0; hh < 3; ++hh) {
+        loff[hh] = off;
+        if (hh >= P.nh - 1) continue;
+        const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
+        const int n = (C == 2 ? 1 : C) * hw;
+        const float* __restrict__ src = P.low[hh] + (long)b * C * d * hw;
+        int a0, b0; float l0;
+        vx_ds_coord(Z, d, P.D, a0, b0, l0);
+        const float k0 = 1.0f - l0;
+        for (int e = threadIdx.x; e < n + 4; e += 256) {
+            float v = 0.0f;
+            if (e < n) {
+                if constexpr (C == 2) v = (k0 * src[((long)d + a0) * hw + e] + l0 * src[((long)d + b0) * hw + e]) - (k0 * src[(long)a0 * hw + e] + l0 * src[(long)b0 * hw + e]);
+                else { const int c = e / hw, r = e - c * hw; v = k0 * src[((long)c * d + a0) * hw + r] + l0 * src[((long)c * d + b0) * hw + r]; }
+            }
+            lds[off + e] = v;
+        }
+        off += (n + 4 + 3) & ~3;
+    }
+}
+static size_t vx_ds_slice_pad_floats(const VxDs& P, int C) {
+    size_t n = 0;
+    for (int hh = 0; hh < P.nh - 1; ++hh) n += ((size_t)(C == 2 ? 1 : C) * P.ld[hh][1] * P.ld[hh][2] + 4 + 3) & ~(size_t)3;
+    return n;
+}
+
+// logits of head hh at the thread's quad in row Y: z[c][j]; (a1, l1) of the row are returned for the adjoint
+template <int C, int NK>
+__device__ __forceinline__ void vx_ds_interp_col(const VxDs& P, int hh, const float* __restrict__ sl, int Y, int i0, const float (&cw)[4][NK], float (&z)[C][4], int& a1, float& l1) {
+    const int h = P.ld[hh][1], w = P.ld[hh][2];
+    int b1;
+    vx_ds_coord(Y, h, P.H, a1, b1, l1);
+    const float k1 = 1.0f - l1;
+    typedef const __attribute__((address_space(3))) float* lds_cf;
+    lds_cf s3 = (lds_cf)sl;
+    constexpr int NG = C == 2 ? 1 : C;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        lds_cf r0 = s3 + (g * h + a1) * w + i0;
+        lds_cf r1 = s3 + (g * h + b1) * w + i0;
+        float v[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) v[k] = k1 * r0[k] + l1 * r1[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) t = fmaf(cw[j][k], v[k], t);
+            if constexpr (C == 2) { z[0][j] = 0.0f; z[1][j] = t; }
+            else z[g][j] = t;
+        }
+    }
+}
+
+template <int C, int NK>
+__global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const void* __restrict__ lab, int lab_kind, double* __restrict__ acc) {
+    constexpr int NS = 1 + 2 * C;
+    extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
+    const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
+    const int W4 = P.W >> 2, NRG = 256 / W4;
+    const long V = (long)P.D * P.H * P.W;
+    int loff[3];
+    vx_ds_stage_slice_pad<C>(P, b, Z, vx_ds_lds, loff);
+    const int y_lo = (int)((long)P.H * part / P.nsplit), y_hi = (int)((long)P.H * (part + 1) / P.nsplit);
+    const int RG = (y_hi - y_lo + NRG - 1) / NRG;
+    const int X0 = ((int)threadIdx.x % W4) * 4, yg = (int)threadIdx.x / W4;
+    const int y0 = y_lo + yg * RG, y1 = min(y_hi, y0 + RG);
+    int i0[3];
+    float cw[3][4][NK];
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) {
+        if (hh < P.nh - 1) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.W, i0[hh], cw[hh]);
+        else { i0[hh] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) cw[hh][j][k] = 0.0f; }
+    }
+    __syncthreads();
+    float S[4][NS], T[C];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) S[h][k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) T[c] = 0.0f;
+    // the row's global operands one row ahead of the arithmetic
+    int yn[4] = {0, 0, 0, 0};
+    float4 ln[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ln[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int Y) {
+        const long o = ((long)Z * P.H + Y) * P.W + X0;
+        vx_lab4(lab, lab_kind, (long)b * V + o, yn);
+#pragma unroll
+        for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
+    };
+    if (y0 < y1) fetch(y0);
+    for (int Y = y0; Y < y1; ++Y) {
+        int y[4] = {yn[0], yn[1], yn[2], yn[3]};
+        float z0[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { z0[c][0] = ln[c].x; z0[c][1] = ln[c].y; z0[c][2] = ln[c].z; z0[c][3] = ln[c].w; }
+        if (Y + 1 < y1) fetch(Y + 1);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[c] += (y[j] == c) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (h < P.nh) {
+                float z[C][4];
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[c][j] = z0[c][j];
+                } else {
+                    int a1; float l1;
+                    vx_ds_interp_col<C, NK>(P, h - 1, vx_ds_lds + loff[h - 1], Y, i0[h - 1], cw[h - 1], z, a1, l1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mx = z[0][j];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                    float e[C], se = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { e[c] = __expf(z[c][j] - mx); se += e[c]; }
+                    const float inv = __frcp_rn(se);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float pc = e[c] * inv;
+                        S[h][1 + C + c] += pc;
+                        if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + __logf(se)) - z[c][j]; }
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float red[4][4 * NS + C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { const float v = vx_wave_sum(S[h][k]); if (lane == 0) red[wid][h * NS + k] = v; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = vx_wave_sum(T[c]); if (lane == 0) red[wid][4 * NS + c] = v; }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 4 * NS + C) {
+        const double v = (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k];
+        if (k < 4 * NS) {
+            const int h = k / NS, r = k % NS;
+            if (h < P.nh) {
+                double* __restrict__ ah = acc + (long)h * (1 + (long)P.B * C * 3);
+                if (r == 0) atomicAdd(ah, v);
+                else if (r <= C) atomicAdd(ah + 1 + ((long)b * C + (r - 1)) * 3, v);
+                else atomicAdd(ah + 1 + ((long)b * C + (r - 1 - C)) * 3 + 1, v);
+            }
+        } else {
+            const int c = k - 4 * NS;
+            for (int h = 0; h < P.nh; ++h) atomicAdd(acc + (long)h * (1 + (long)P.B * C * 3) + 1 + ((long)b * C + c) * 3 + 2, v);
+        }
+    }
+}
+
+// backward, column owners.  LDS: accw[wave][nacc] (layout [head][ca][y][x], as the row-sweep kernel) | padded slices
+template <int C, int NK>
+__global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const void* __restrict__ lab, int lab_kind, const float* __restrict__ coef, int coef_stride,
+                                                                const float* __restrict__ gout, int nacc) {
+    extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
+    const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
+    const int W4 = P.W >> 2, NRG = 256 / W4, nlow = P.nh - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long V = (long)P.D * P.H * P.W;
+    constexpr int c_lo = C == 2 ? 1 : 0, CA = C - c_lo;
+    float* __restrict__ accw = vx_ds_lds + (long)wave * nacc;
+    float* __restrict__ slices = vx_ds_lds + 4L * nacc;
+    int loff[3];
+    vx_ds_stage_slice_pad<C>(P, b, Z, slices, loff);
+    for (int k = lane; k < nacc; k += 64) accw[k] = 0.0f;
+    const int y_lo = (int)((long)P.H * part / P.nsplit), y_hi = (int)((long)P.H * (part + 1) / P.nsplit);
+    const int RG = (y_hi - y_lo + NRG - 1) / NRG;
+    const int X0 = ((int)threadIdx.x % W4) * 4, yg = (int)threadIdx.x / W4;
+    const int y0 = y_lo + yg * RG, y1 = min(y_hi, y0 + RG);
+    int i0[3], aoff[3];
+    float cw[3][4][NK];
+    { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += CA * P.ld[hh][1] * P.ld[hh][2]; } }
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) {
+        if (hh < nlow) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.W, i0[hh], cw[hh]);
+        else { i0[hh] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) cw[hh][j][k] = 0.0f; }
+    }
+    __syncthreads();
+    const float go = gout ? gout[0] : 1.0f;
+    // per head: the two coarse rows (cur, cur + 1) this thread is accumulating into
+    float aA[3][CA][NK], aB[3][CA][NK];
+    int cur[3] = {-1, -1, -1};
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { aA[hh][c][k] = 0.0f; aB[hh][c][k] = 0.0f; }
+    auto flush_row = [&](int hh, int row, const float (&a)[CA][NK]) {
+        const int hl = P.ld[hh][1], wl = P.ld[hh][2];
+        if ((unsigned)row >= (unsigned)hl) return;
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                if (i0[hh] + k < wl && a[c][k] != 0.0f) atomicAdd(accw + aoff[hh] + ((long)c * hl + row) * wl + i0[hh] + k, a[c][k]);
+    };
+    int yn[4] = {0, 0, 0, 0};
+    float4 ln[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ln[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int Y) {
+        const long o = ((long)Z * P.H + Y) * P.W + X0;
+        vx_lab4(lab, lab_kind, (long)b * V + o, yn);
+#pragma unroll
+        for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
+    };
+    if (y0 < y1) fetch(y0);
+    for (int Y = y0; Y < y1; ++Y) {
+        int y[4] = {yn[0], yn[1], yn[2], yn[3]};
+        float z0[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { z0[c][0] = ln[c].x; z0[c][1] = ln[c].y; z0[c][2] = ln[c].z; z0[c][3] = ln[c].w; }
+        if (Y + 1 < y1) fetch(Y + 1);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (h < P.nh) {
+                float z[C][4];
+                int a1 = 0; float l1 = 0.0f;
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[c][j] = z0[c][j];
+                } else vx_ds_interp_col<C, NK>(P, h - 1, slices + loff[h - 1], Y, i0[h - 1], cw[h - 1], z, a1, l1);
+                const float* __restrict__ coef_h = coef + (long)h * coef_stride;
+                const float wce = coef_h[0];
+                float al[C], be[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) { al[c] = coef_h[1 + ((long)b * C + c) * 2]; be[c] = coef_h[2 + ((long)b * C + c) * 2]; }
+                float g[C][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mx = z[0][j];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                    float se = 0.0f, dot = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { z[c][j] = __expf(z[c][j] - mx); se += z[c][j]; }
+                    const float inv = __frcp_rn(se);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { z[c][j] *= inv; dot = fmaf(z[c][j], (c == y[j] ? al[c] : 0.0f) + be[c], dot); }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float gg = (c == y[j] ? al[c] : 0.0f) + be[c];
+                        g[c][j] = go * (wce * (z[c][j] - (c == y[j] ? 1.0f : 0.0f)) + z[c][j] * (gg - dot));
+                    }
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        *reinterpret_cast<float4*>(P.dl0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
+                } else {
+                    const int hh = h - 1;
+                    if (a1 != cur[hh]) {                                   // the row pair moves on (by one row, every 1 / scale rows): the finished coarse row leaves the registers
+                        if (cur[hh] >= 0) flush_row(hh, cur[hh], aA[hh]);
+                        if (a1 == cur[hh] + 1) {
+#pragma unroll
+                            for (int c = 0; c < CA; ++c)
+#pragma unroll
+                                for (int k = 0; k < NK; ++k) { aA[hh][c][k] = aB[hh][c][k]; aB[hh][c][k] = 0.0f; }
+                        } else {
+                            if (cur[hh] >= 0) flush_row(hh, cur[hh] + 1, aB[hh]);
+#pragma unroll
+                            for (int c = 0; c < CA; ++c)
+#pragma unroll
+                                for (int k = 0; k < NK; ++k) { aA[hh][c][k] = 0.0f; aB[hh][c][k] = 0.0f; }
+                        }
+                        cur[hh] = a1;
+                    }
+                    const float k1 = 1.0f - l1;
+#pragma unroll
+                    for (int c = 0; c < CA; ++c)
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            float ck = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ck = fmaf(cw[hh][j][k], g[c + c_lo][j], ck);
+                            aA[hh][c][k] = fmaf(k1, ck, aA[hh][c][k]);
+                            aB[hh][c][k] = fmaf(l1, ck, aB[hh][c][k]);
+                        }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh)
+        if (hh < nlow && cur[hh] >= 0) { flush_row(hh, cur[hh], aA[hh]); flush_row(hh, cur[hh] + 1, aB[hh]); }
+    __syncthreads();
+    for (int hh = 0; hh < nlow; ++hh) {
+        const int hl = P.ld[hh][1], wl = P.ld[hh][2], n = CA * hl * wl;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int c = e / (hl * wl), r = e - c * hl * wl;
+            const float s = (vx_ds_lds[aoff[hh] + e] + vx_ds_lds[nacc + aoff[hh] + e]) + (vx_ds_lds[2 * nacc + aoff[hh] + e] + vx_ds_lds[3 * nacc + aoff[hh] + e]);
+            P.t2[hh][((((long)b * C + c + c_lo) * P.D + Z) * P.nsplit + part) * hl * wl + r] = s;
+            if (c_lo) P.t2[hh][((((long)b * C) * P.D + Z) * P.nsplit + part) * hl * wl + r] = -s;
+        }
+    }
+}
+
+// does the column-owner map cover this geometry?  W/4 a divisor of 256, every head narrower than the volume, and a quad never touching more than NK coarse columns
+// (returns NK = 3 or 4, or 0)
+static int g_ds_columns = -1;
+extern "C" int vx_seg_loss_ds_set_columns(int on) { g_ds_columns = on ? 1 : 0; return 0; }
+static int vx_ds_columns_nk(const VxDs& P) {
+    if (g_ds_columns < 0) { const char* e = getenv("VELOXSEG_DS_COLUMNS"); g_ds_columns = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_ds_columns || P.nh < 2) return 0;
+    const int W4 = P.W >> 2;
+    if (W4 <= 0 || 256 % W4 != 0) return 0;
+    int nk = 3;
+    for (int hh = 0; hh < P.nh - 1; ++hh) {
+        const int wl = P.ld[hh][2];
+        if (wl >= P.W || P.ld[hh][1] > P.H) return 0;
+        const float ratio = P.W > 1 ? (float)(wl - 1) / (float)(P.W - 1) : 0.0f;
+        for (int X0 = 0; X0 < P.W; X0 += 4) {
+            const int a0 = (int)(ratio * (float)X0);
+            const int a3 = (int)(ratio * (float)(X0 + 3));
+            const int b3 = a3 + (a3 < wl - 1 ? 1 : 0);
+            const int span = b3 - a0 + 1;
+            if (span > 4) return 0;
+            if (span > nk) nk = span;
+        }
+    }
+    return nk;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------ host
 static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2, const float* l3, const int* dims, int nh, int B, int C, int D, int H, int W, const char* who) {
     VX_REQUIRE(nh >= 1 && nh <= 4 && l0 && B > 0 && (C == 2 || C == 3 || C == 4) && D > 0 && H > 0 && W > 0, "%s: bad args (C must be 2..4)", who);
@@ -488,6 +864,17 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
         static size_t cap = 64 * 1024;          /* the kernel also has static LDS: raise the dynamic limit only as far as needed */            \
         if (shm > cap) { if (hipFuncSetAttribute((const void*)vx_seg_loss_ds_fwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) { (void)hipGetLastError(); VX_FAIL(-2, "vx_seg_loss_ds_fwd: cannot reserve %zu bytes of LDS", shm); } cap = shm; } \
         vx_seg_loss_ds_fwd_k<CC><<<grid, blk, shm, st>>>(P, labels, lab_kind, acc);                                                   \
+    }
+    const int nk = P.stage ? vx_ds_columns_nk(P) : 0;
+    const size_t shm_col = vx_ds_slice_pad_floats(P, C) * sizeof(float);
+    if (nk && shm_col <= 48 * 1024) {          // column-owner map (see above)
+#define VX_DS_FWD_COL(CC)                                                                                                              \
+        { if (nk == 3) vx_seg_loss_ds_fwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc);                            \
+          else vx_seg_loss_ds_fwd_col_k<CC, 4><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc); }
+        if (C == 2) VX_DS_FWD_COL(2) else if (C == 3) VX_DS_FWD_COL(3) else VX_DS_FWD_COL(4)
+#undef VX_DS_FWD_COL
+        VX_LAUNCH_CHECK("vx_seg_loss_ds_fwd (columns)");
+        return 0;
     }
     if (C == 2) VX_DS_FWD(2) else if (C == 3) VX_DS_FWD(3) else VX_DS_FWD(4)
 #undef VX_DS_FWD
@@ -558,6 +945,15 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
         if (shm > cap) { if (hipFuncSetAttribute((const void*)vx_seg_loss_ds_bwd_k<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) { (void)hipGetLastError(); VX_FAIL(-2, "vx_seg_loss_ds_bwd: cannot reserve %zu bytes of LDS", shm); } cap = shm; } \
         vx_seg_loss_ds_bwd_k<CC><<<grid, blk, shm, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);                         \
     }
+    const int nk = P.stage ? vx_ds_columns_nk(P) : 0;
+    const size_t shm_col = ((size_t)4 * nacc + vx_ds_slice_pad_floats(P, C)) * sizeof(float);
+    if (nk && shm_col <= 48 * 1024) {
+#define VX_DS_BWD_COL(CC)                                                                                                              \
+        { if (nk == 3) vx_seg_loss_ds_bwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);   \
+          else vx_seg_loss_ds_bwd_col_k<CC, 4><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc); }
+        if (C == 2) VX_DS_BWD_COL(2) else if (C == 3) VX_DS_BWD_COL(3) else VX_DS_BWD_COL(4)
+#undef VX_DS_BWD_COL
+    } else
     if (C == 2) VX_DS_BWD(2) else if (C == 3) VX_DS_BWD(3) else VX_DS_BWD(4)
 #undef VX_DS_BWD
     if (nh > 1) vx_seg_loss_ds_adj_z_k<<<dim3(vx_cdiv(total, 256)), blk, 0, st>>>(Zp);

@@ -305,7 +305,7 @@ class TrainEngine:
         self._last_outputs = v
         self._last_parts = None
 
-    def __init__(self, model, criterion, batch_shape, label_dtype=torch.int64, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
+    def __init__(self, model, criterion, batch_shape, label_dtype=None, lr=2.5e-4, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-8, use_graph=False, overlap=True, process_group=None, warmup_steps=2, verify_replays=3, optimizer=None, fuse_ds=True,
                  replay="tape", tape_lanes=6, precision="fp32", bucket_min_bytes=1 << 20, level_buckets=False, pipeline_tail=False, force_comm=False):
         self.model, self.criterion = model, criterion
@@ -368,6 +368,13 @@ class TrainEngine:
         self._setup_branch_loss()
         B = batch_shape[0]
         self.x = torch.zeros(batch_shape, device=self.dev, dtype=torch.float32)
+        if label_dtype is None:
+            # the engine's own copy of the label volume: step() converts whatever the loader hands over (int64 in the reference: utils/train_autopet.py:239) while
+            # it copies.  One byte per voxel when the library's loss kernels read it and the class count allows: at 128^3 x 4 the int64 labels were HALF of the
+            # bytes the loss forward reads (67 of 137 MB) and a third of its backward's (VELOXSEG_LABELS=int64 for the A/B)
+            from .utils.loss import Loss as _Loss2
+            small = isinstance(criterion, _Loss2) and int(getattr(model, "n_classes", 1 << 30)) <= 255 and os.environ.get("VELOXSEG_LABELS", "u8") != "int64"
+            label_dtype = torch.uint8 if small else torch.int64
         self.labels = torch.zeros((B, 1, *batch_shape[2:]), device=self.dev, dtype=label_dtype)
         self.loss = torch.zeros((), device=self.dev, dtype=torch.float32)
         self.graphs = None

@@ -136,7 +136,7 @@ def run_train(args, train_config, model_config, train_loader: Optional[Iterable]
     size = list(mcfg["input_size"])
     x_shape = (batch, sum(mcfg["in_ch"]), *size)
     # per-head metrics (show_deep_metric) need every head at full resolution in engine.last_outputs: then the up-sampling is not fused into the loss
-    engine = TrainEngine(model, criterion, x_shape, label_dtype=torch.int64, optimizer=optimizer, use_graph=getattr(args, "use_graph", False),
+    engine = TrainEngine(model, criterion, x_shape, label_dtype=None, optimizer=optimizer, use_graph=getattr(args, "use_graph", False),
                          fuse_ds=not train_config.get("show_deep_metric", False), precision=getattr(args, "precision", "fp32"),
                          pipeline_tail=getattr(args, "pipeline_tail", False))  # (opt-in: the decoder tail of step N beside the encoder forward of step N + 1; flush() below)
     show_deep_metrics = _metric_fns(args.dataset_name)
