@@ -7,7 +7,7 @@ from veloxseg_amd import functional as VF
 d = torch.device("cuda:0")
 B, C, S = 4, 2, 128
 heads = [torch.randn(B, C, S, S, S, device=d, requires_grad=True)] + [torch.randn(B, C, s, s, s, device=d, requires_grad=True) for s in (16, 8, 4)]
-lab = (torch.rand(B, 1, S, S, S, device=d) > 0.97).long()
+lab = (torch.rand(B, 1, S, S, S, device=d) > 0.97).to(torch.uint8 if os.environ.get("VX_LAB", "u8") == "u8" else torch.int64)
 w = (0.25,) * 4
 tf = tb = 0.0
 for it in range(8):

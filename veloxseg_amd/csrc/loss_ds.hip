@@ -39,6 +39,14 @@ __device__ __forceinline__ void vx_ds_coord(int j, int nin, int nout, int& i0, i
     i1 = i0 + (i0 < nin - 1 ? 1 : 0);
 }
 
+// the same with the ratio (nin - 1) / (nout - 1) given (an IEEE fp32 quotient on the host equals the device's)
+__device__ __forceinline__ void vx_ds_coord_r(int j, int nin, float ratio, int& i0, int& i1, float& lam) {
+    const float s = ratio * (float)j;
+    i0 = (int)s;
+    lam = s - (float)i0;
+    i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+}
+
 struct VxDs {
     const float* l0;            // head 0, full resolution (B, C, D, H, W)
     const float* low[3];        // heads 1..nh-1 on their own grids
@@ -48,6 +56,8 @@ struct VxDs {
     int nh, B, D, H, W;
     int stage;                  // 1: the Z-interpolated slices of a sample's grids are staged in LDS (they fit); 0: 8 taps gathered from global memory
     int nsplit;                 // forward: blocks per Z slice
+    int dbg;                    // timing experiments (VX_DS_DBG): bit 0 no final atomics, bit 1 no low-resolution heads
+    float rh[3], rw[3];         // column-owner kernels: (h - 1) / (H - 1), (w - 1) / (W - 1) of heads 1.. (the quotient vx_ds_coord forms, computed once on the host)
 };
 
 // logits of head hh (>= 1) at the 4 voxels (Z, Y, X0..X0+3): z[c][j]
@@ -413,33 +423,40 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_k(VxDs P, const void* 
     }
 }
 
-// adjoint along D for all heads: dlow_h[b, c, z, y, x] = sum_Z A[Z][z] t2_h[b, c, Z, y, x].  One thread per output element.
+// adjoint along D for all heads: dlow_h[b, c, z, y, x] = sum_Z A[Z][z] t2_h[b, c, Z, y, x].  A block = 32 consecutive output elements x 8 parts of their Z band
+// (one thread per element walked its whole band -- up to 2 * D / d + 2 planes -- alone: 23 us of dependent loads for 1.4 MB; the parts meet in LDS)
 struct VxDsZ { const float* t2[3]; float* out[3]; int ld[3][3]; int nlow, BC, D, nsplit; long n[3]; };
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
-    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][32];
+    const int l32 = threadIdx.x & 31, zp = threadIdx.x >> 5;
+    long e = (long)blockIdx.x * 32 + l32;
     int hh = 0;
     while (hh < P.nlow && e >= P.n[hh]) { e -= P.n[hh]; ++hh; }
-    if (hh >= P.nlow) return;
-    const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
-    const int r = (int)(e % hw), z = (int)((e / hw) % d);
-    const long bc = e / ((long)hw * d);
-    const float ratio = P.D > 1 ? (float)(d - 1) / (float)(P.D - 1) : 0.0f;
-    int lo = 0, hi = P.D - 1;
-    if (d != P.D && ratio > 0.0f) {
-        lo = (int)ceilf(((float)z - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
-        hi = (int)floorf(((float)z + 1.0f) / ratio) + 1; if (hi > P.D - 1) hi = P.D - 1;
-    }
-    const float* __restrict__ src = P.t2[hh] + bc * P.D * P.nsplit * hw + r;
+    const bool live = hh < P.nlow;
     float s = 0.0f;
-    for (int Z = lo; Z <= hi; ++Z) {
-        int i0, i1; float lam;
-        vx_ds_coord(Z, d, P.D, i0, i1, lam);
-        const float wgt = (i0 == z ? 1.0f - lam : 0.0f) + (i1 == z ? lam : 0.0f);
-        float t = 0.0f;
-        for (int q = 0; q < P.nsplit; ++q) t += src[((long)Z * P.nsplit + q) * hw];          // the slice's row parts (one block each)
-        s = fmaf(wgt, t, s);
+    if (live) {
+        const int d = P.ld[hh][0], hw = P.ld[hh][1] * P.ld[hh][2];
+        const int r = (int)(e % hw), z = (int)((e / hw) % d);
+        const long bc = e / ((long)hw * d);
+        const float ratio = P.D > 1 ? (float)(d - 1) / (float)(P.D - 1) : 0.0f;
+        int lo = 0, hi = P.D - 1;
+        if (d != P.D && ratio > 0.0f) {
+            lo = (int)ceilf(((float)z - 1.0f) / ratio) - 1; if (lo < 0) lo = 0;
+            hi = (int)floorf(((float)z + 1.0f) / ratio) + 1; if (hi > P.D - 1) hi = P.D - 1;
+        }
+        const float* __restrict__ src = P.t2[hh] + bc * P.D * P.nsplit * hw + r;
+        for (int Z = lo + zp; Z <= hi; Z += 8) {
+            int i0, i1; float lam;
+            vx_ds_coord(Z, d, P.D, i0, i1, lam);
+            const float wgt = (i0 == z ? 1.0f - lam : 0.0f) + (i1 == z ? lam : 0.0f);
+            float t = 0.0f;
+            for (int q = 0; q < P.nsplit; ++q) t += src[((long)Z * P.nsplit + q) * hw];          // the slice's row parts (one block each)
+            s = fmaf(wgt, t, s);
+        }
     }
-    P.out[hh][e] = s;
+    red[zp][l32] = s;
+    __syncthreads();
+    if (zp == 0 && live) P.out[hh][e] = ((red[0][l32] + red[1][l32]) + (red[2][l32] + red[3][l32])) + ((red[4][l32] + red[5][l32]) + (red[6][l32] + red[7][l32]));
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------ column-owner kernels
@@ -454,11 +471,11 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
 // Everything else (soft-max arithmetic, accumulator layout, the D adjoint behind it) is unchanged; vx_seg_loss_ds_set_columns(0) / VELOXSEG_DS_COLUMNS=0 selects the
 // row-sweep kernels above (the only ones for W/4 = 24 / 12: the 96^3 patches).
 template <int NK>
-__device__ __forceinline__ void vx_ds_col_setup(int X0, int wl, int W, int& i0, float (&cw)[4][NK]) {
+__device__ __forceinline__ void vx_ds_col_setup(int X0, int wl, float ratio, int& i0, float (&cw)[4][NK]) {
     int a[4], b[4];
     float l[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vx_ds_coord(X0 + j, wl, W, a[j], b[j], l[j]);
+    for (int j = 0; j < 4; ++j) vx_ds_coord_r(X0 + j, wl, ratio, a[j], b[j], l[j]);
     i0 = a[0];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -502,7 +519,7 @@ template <int C, int NK>
 __device__ __forceinline__ void vx_ds_interp_col(const VxDs& P, int hh, const float* __restrict__ sl, int Y, int i0, const float (&cw)[4][NK], float (&z)[C][4], int& a1, float& l1) {
     const int h = P.ld[hh][1], w = P.ld[hh][2];
     int b1;
-    vx_ds_coord(Y, h, P.H, a1, b1, l1);
+    vx_ds_coord_r(Y, h, P.rh[hh], a1, b1, l1);
     const float k1 = 1.0f - l1;
     typedef const __attribute__((address_space(3))) float* lds_cf;
     lds_cf s3 = (lds_cf)sl;
@@ -542,7 +559,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
     float cw[3][4][NK];
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) {
-        if (hh < P.nh - 1) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.W, i0[hh], cw[hh]);
+        if (hh < P.nh - 1) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.rw[hh], i0[hh], cw[hh]);
         else { i0[hh] = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -550,7 +567,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
                 for (int k = 0; k < NK; ++k) cw[hh][j][k] = 0.0f; }
     }
     __syncthreads();
-    float S[4][NS], T[C];
+    float S[4][NS], T[C], nrows = 0.0f;
 #pragma unroll
     for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -558,30 +575,36 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
 #pragma unroll
     for (int c = 0; c < C; ++c) T[c] = 0.0f;
     // the row's global operands one row ahead of the arithmetic
-    int yn[4] = {0, 0, 0, 0};
-    float4 ln[C];
+    // the rows' global operands TWO rows ahead of the arithmetic (two register buffers, used alternately: a wave keeps two rows of loads in flight)
+    int ynA[4] = {0, 0, 0, 0}, ynB[4] = {0, 0, 0, 0};
+    float4 lnA[C], lnB[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) ln[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int Y) {
+    for (int c = 0; c < C; ++c) { lnA[c] = make_float4(0.f, 0.f, 0.f, 0.f); lnB[c] = lnA[c]; }
+    auto fetch = [&](int Y, int (&yn)[4], float4 (&ln)[C]) {
         const long o = ((long)Z * P.H + Y) * P.W + X0;
         vx_lab4(lab, lab_kind, (long)b * V + o, yn);
 #pragma unroll
         for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
     };
-    if (y0 < y1) fetch(y0);
-    for (int Y = y0; Y < y1; ++Y) {
+    if (y0 < y1) fetch(y0, ynA, lnA);
+    if (y0 + 1 < y1) fetch(y0 + 1, ynB, lnB);
+    auto row = [&](int Y, int (&yn)[4], float4 (&ln)[C]) {
         int y[4] = {yn[0], yn[1], yn[2], yn[3]};
         float z0[C][4];
 #pragma unroll
         for (int c = 0; c < C; ++c) { z0[c][0] = ln[c].x; z0[c][1] = ln[c].y; z0[c][2] = ln[c].z; z0[c][3] = ln[c].w; }
-        if (Y + 1 < y1) fetch(Y + 1);
+        if (Y + 2 < y1) fetch(Y + 2, yn, ln);
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) T[c] += (y[j] == c) ? 1.0f : 0.0f;
+        float m0[4], m1[4];          // (two classes) the label as two 0 / 1 factors, shared by the four heads
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m0[j] = y[j] == 0 ? 1.0f : 0.0f; m1[j] = y[j] == 1 ? 1.0f : 0.0f; }
+        nrows += 1.0f;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            if (h < P.nh) {
+            if (h < P.nh && !((P.dbg & 2) && h > 0)) {
                 float z[C][4];
                 if (h == 0) {
 #pragma unroll
@@ -592,6 +615,25 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
                     int a1; float l1;
                     vx_ds_interp_col<C, NK>(P, h - 1, vx_ds_lds + loff[h - 1], Y, i0[h - 1], cw[h - 1], z, a1, l1);
                 }
+                if constexpr (C == 2) {
+                    // two classes: soft-max = logistic of d = z1 - z0.  One exponential and one reciprocal per voxel, and ONE logarithm per quad: the cross-entropy
+                    // terms log(1 + e_j) of the four voxels are the logarithm of the product (1 + e in (1, 2]: the product stays below 16).  Only the class-1 sums are
+                    // accumulated here -- S[h][1 + C + 1] = sum p1, S[h][1 + 1] = sum_{y = 1} p1, S[h][1 + 0] = sum_{y = 0} p1 -- the class-0 ones follow from
+                    // p0 = 1 - p1 after the loop (sum p0 = voxels - sum p1, sum_{y = 0} p0 = T0 - sum_{y = 0} p1)
+                    float prod = 1.0f, extra = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dd = z[1][j] - z[0][j];
+                        const float e = __expf(-fabsf(dd)), inv = __builtin_amdgcn_rcpf(1.0f + e);
+                        const float p1 = dd >= 0.0f ? inv : e * inv;
+                        S[h][1 + C + 1] += p1;
+                        S[h][1 + 1] = fmaf(p1, m1[j], S[h][1 + 1]);
+                        S[h][1 + 0] = fmaf(p1, m0[j], S[h][1 + 0]);
+                        prod *= fmaf(e, m0[j] + m1[j], 1.0f);
+                        extra += fmaxf(dd * (m0[j] - m1[j]), 0.0f);          // lse - z_y = log(1 + e) + max(0, -(d * (2y - 1)))
+                    }
+                    S[h][0] += __logf(prod) + extra;
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float mx = z[0][j];
@@ -600,7 +642,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
                     float e[C], se = 0.0f;
 #pragma unroll
                     for (int c = 0; c < C; ++c) { e[c] = __expf(z[c][j] - mx); se += e[c]; }
-                    const float inv = __frcp_rn(se);
+                    const float inv = __builtin_amdgcn_rcpf(se);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         const float pc = e[c] * inv;
@@ -608,7 +650,19 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
                         if (c == y[j]) { S[h][1 + c] += pc; S[h][0] += (mx + __logf(se)) - z[c][j]; }
                     }
                 }
+                }
             }
+        }
+    };
+    for (int Y = y0; Y < y1; Y += 2) {
+        row(Y, ynA, lnA);
+        if (Y + 1 < y1) row(Y + 1, ynB, lnB);
+    }
+    if constexpr (C == 2) {          // class-0 sums from the class-1 ones (see the loop)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            S[h][1 + C + 0] = 4.0f * nrows - S[h][1 + C + 1];
+            S[h][1 + 0] = T[0] - S[h][1 + 0];
         }
     }
     __shared__ float red[4][4 * NS + C];
@@ -621,7 +675,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
     for (int c = 0; c < C; ++c) { const float v = vx_wave_sum(T[c]); if (lane == 0) red[wid][4 * NS + c] = v; }
     __syncthreads();
     const int k = threadIdx.x;
-    if (k < 4 * NS + C) {
+    if (k < 4 * NS + C && !(P.dbg & 1)) {
         const double v = (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k];
         if (k < 4 * NS) {
             const int h = k / NS, r = k % NS;
@@ -662,7 +716,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
     { int o = 0; for (int hh = 0; hh < 3; ++hh) { aoff[hh] = o; if (hh < nlow) o += CA * P.ld[hh][1] * P.ld[hh][2]; } }
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) {
-        if (hh < nlow) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.W, i0[hh], cw[hh]);
+        if (hh < nlow) vx_ds_col_setup<NK>(X0, P.ld[hh][2], P.rw[hh], i0[hh], cw[hh]);
         else { i0[hh] = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -700,7 +754,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
         for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
     };
     if (y0 < y1) fetch(y0);
-    for (int Y = y0; Y < y1; ++Y) {
+    for (int Y = y0; Y < y1; ++Y) {          // (the row's global operands one row ahead of the arithmetic; two rows ahead -- two register buffers -- costs 60 VGPRs here and gains nothing)
         int y[4] = {yn[0], yn[1], yn[2], yn[3]};
         float z0[C][4];
 #pragma unroll
@@ -725,15 +779,26 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
                 float g[C][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float mx = z[0][j];
+                    float dot = 0.0f;
+                    if constexpr (C == 2) {          // logistic form: one exponential per voxel
+                        const float dd = z[1][j] - z[0][j];
+                        const float e = __expf(-fabsf(dd)), inv = __builtin_amdgcn_rcpf(1.0f + e);
+                        const float pb = inv, ps = e * inv;
+                        z[1][j] = dd >= 0.0f ? pb : ps;
+                        z[0][j] = dd >= 0.0f ? ps : pb;
+                    } else {
+                        float mx = z[0][j];
 #pragma unroll
-                    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
-                    float se = 0.0f, dot = 0.0f;
+                        for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c][j]);
+                        float se = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) { z[c][j] = __expf(z[c][j] - mx); se += z[c][j]; }
-                    const float inv = __frcp_rn(se);
+                        for (int c = 0; c < C; ++c) { z[c][j] = __expf(z[c][j] - mx); se += z[c][j]; }
+                        const float inv = __builtin_amdgcn_rcpf(se);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) { z[c][j] *= inv; dot = fmaf(z[c][j], (c == y[j] ? al[c] : 0.0f) + be[c], dot); }
+                        for (int c = 0; c < C; ++c) z[c][j] *= inv;
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dot = fmaf(z[c][j], (c == y[j] ? al[c] : 0.0f) + be[c], dot);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         const float gg = (c == y[j] ? al[c] : 0.0f) + be[c];
@@ -825,6 +890,8 @@ static int vx_ds_fill(VxDs& P, const float* l0, const float* l1, const float* l2
     P.l0 = l0; P.low[0] = l1; P.low[1] = l2; P.low[2] = l3; P.nh = nh; P.B = B; P.D = D; P.H = H; P.W = W;
     for (int hh = 0; hh < 3; ++hh) {
         for (int k = 0; k < 3; ++k) P.ld[hh][k] = hh < nh - 1 ? dims[3 * hh + k] : 1;
+        P.rh[hh] = H > 1 ? (float)(P.ld[hh][1] - 1) / (float)(H - 1) : 0.0f;
+        P.rw[hh] = W > 1 ? (float)(P.ld[hh][2] - 1) / (float)(W - 1) : 0.0f;
         if (hh < nh - 1) VX_REQUIRE(P.low[hh] && P.ld[hh][0] > 0 && P.ld[hh][0] <= D && P.ld[hh][1] > 0 && P.ld[hh][1] <= H && P.ld[hh][2] > 0 && P.ld[hh][2] <= W,
                                     "%s: head %d: bad grid", who, hh + 1);
     }
@@ -868,6 +935,13 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
     const int nk = P.stage ? vx_ds_columns_nk(P) : 0;
     const size_t shm_col = vx_ds_slice_pad_floats(P, C) * sizeof(float);
     if (nk && shm_col <= 48 * 1024) {          // column-owner map (see above)
+        // two blocks per slice (VELOXSEG_DS_FWD_SPLIT; measured at 128^3 x 4: 1 / 2 / 4 parts = 64 / 61 / 91 us): a thread's set-up (column weights) is amortised over
+        // its rows, and every block ends in ~20 double atomics on the same few accumulators
+        static int fsplit = -1;
+        if (fsplit < 0) { const char* e = getenv("VELOXSEG_DS_FWD_SPLIT"); fsplit = e ? atoi(e) : 2; if (fsplit < 1 || fsplit > 8) fsplit = 2; }
+        P.nsplit = fsplit;
+        { const char* e = getenv("VX_DS_DBG"); P.dbg = e ? atoi(e) : 0; }
+        const dim3 grid(D * P.nsplit, B);
 #define VX_DS_FWD_COL(CC)                                                                                                              \
         { if (nk == 3) vx_seg_loss_ds_fwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc);                            \
           else vx_seg_loss_ds_fwd_col_k<CC, 4><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc); }
@@ -956,7 +1030,7 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
     } else
     if (C == 2) VX_DS_BWD(2) else if (C == 3) VX_DS_BWD(3) else VX_DS_BWD(4)
 #undef VX_DS_BWD
-    if (nh > 1) vx_seg_loss_ds_adj_z_k<<<dim3(vx_cdiv(total, 256)), blk, 0, st>>>(Zp);
+    if (nh > 1) vx_seg_loss_ds_adj_z_k<<<dim3(vx_cdiv(total, 32)), blk, 0, st>>>(Zp);
     VX_LAUNCH_CHECK("vx_seg_loss_ds_bwd");
     return 0;
 }
