@@ -411,7 +411,7 @@ int vx_seg_loss_bwd4(const float* lg0, const float* lg1, const float* lg2, const
  * vx_seg_loss_bwd4.  Backward: dl0 full resolution, dl1..dl3 on the heads' grids (the adjoint of the interpolation runs inside the kernels);
  * ws = vx_seg_loss_ds_ws_floats(...) floats of workspace.  vx_seg_loss_ds_ok: 1 when the shape is covered (C in 2..4, W % 4 == 0, W/4 divides 64). */
 int vx_seg_loss_ds_ok(int C, int D, int H, int W);
-int vx_seg_loss_ds_set_columns(int on);      /* 1 (default; VELOXSEG_DS_COLUMNS): the column-owner kernels where W/4 divides 256; 0: the row-sweep kernels everywhere (A/B, tests) */
+int vx_seg_loss_ds_set_columns(int on);      /* 1 (default; VELOXSEG_DS_COLUMNS): the column-owner kernels; 0: the row-sweep kernels (A/B, tests) */
 int vx_seg_loss_ds_ws_floats(const int* low_dims, int nh, int B, int C, int D);
 int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
                        double* acc, int B, int C, int D, int H, int W, void* stream);

@@ -1020,8 +1020,8 @@ def test_pwa_channel_vectorised_gather_equals_the_per_channel_kernels(grid, big,
 def test_loss_with_fused_deep_supervision_upsampling(ncls, B, S, labdtype, factors, columns):
     """veloxseg_loss on heads that stay on their own grids (csrc/loss_ds.hip interpolates inside the kernels) == up-sample (vx_upsample_trilinear) then
     veloxseg_loss == the oracle (F.interpolate + CE + Dice): loss 1e-5 relative, gradients of every head 1e-4 of their scale.  Both thread maps of the fused kernels:
-    column owners (W/4 divides 256; the 128^3 patches with heads at 1/8, 1/16, 1/32 -- `c2_model_ratios` -- and every W = 32 / 64 / 128 case) and the row sweep
-    (the only one for W = 96 / 48)."""
+    column owners (the 128^3 patches with heads at 1/8, 1/16, 1/32 -- `c2_model_ratios` -- and W = 96 / 48, where the last 256 % (W/4) threads of a block idle) and
+    the row sweep."""
     VF = _vf()
     from veloxseg_amd import _hip as H
     d = dev()

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
 
 // ------------------------------------------------------------------------------------------------------------------------------ column-owner kernels
 // The same two sweeps with a different thread -> voxel map (round 5).  A thread owns ONE quad column X0 of the block's Z slice and walks consecutive rows
-// (256 / (W/4) row groups per block; W/4 must divide 256), so everything that depends on X only is computed ONCE per thread instead of once per quad:
+// (256 / (W/4) row groups per block), so everything that depends on X only is computed ONCE per thread instead of once per quad:
 //   * per low-resolution head the NK (3 or 4) coarse columns i0 .. i0 + NK - 1 that the quad's four voxels interpolate from, and a dense 4 x NK weight matrix
 //     cw[j][k] (two non-zeros per row): a voxel's logit is  sum_k cw[j][k] * (k1 * row_a[i0 + k] + l1 * row_b[i0 + k])  -- 2 NK LDS reads per head and grid
 //     instead of 16 gathers with their index arithmetic (the old kernels spent most of their issue slots on vx_ds_coord and address math);
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_adj_z_k(VxDsZ P) {
 //     the thread's consecutive rows in two register rows (coarse rows a1 and a1 + 1) and flushed to the wave's LDS accumulators with ds_add_f32 only when a1 advances
 //     (every 1 / scale rows): ~40 LDS atomics per thread and slice replace the gradient staging buffer, the band tables and their ~300 dependent LDS round trips per step.
 // Everything else (soft-max arithmetic, accumulator layout, the D adjoint behind it) is unchanged; vx_seg_loss_ds_set_columns(0) / VELOXSEG_DS_COLUMNS=0 selects the
-// row-sweep kernels above (the only ones for W/4 = 24 / 12: the 96^3 patches).
+// row-sweep kernels above.
 template <int NK>
 __device__ __forceinline__ void vx_ds_col_setup(int X0, int wl, float ratio, int& i0, float (&cw)[4][NK]) {
     int a[4], b[4];
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
     }
 }
 
-// does the column-owner map cover this geometry?  W/4 a divisor of 256, every head narrower than the volume, and a quad never touching more than NK coarse columns
+// does the column-owner map cover this geometry?  W/4 <= 64, every head narrower than the volume, and a quad never touching more than NK coarse columns
 // (returns NK = 3 or 4, or 0)
 static int g_ds_columns = -1;
 extern "C" int vx_seg_loss_ds_set_columns(int on) { g_ds_columns = on ? 1 : 0; return 0; }
@@ -865,7 +865,7 @@ static int vx_ds_columns_nk(const VxDs& P) {
     if (g_ds_columns < 0) { const char* e = getenv("VELOXSEG_DS_COLUMNS"); g_ds_columns = (e && e[0] == '0') ? 0 : 1; }
     if (!g_ds_columns || P.nh < 2) return 0;
     const int W4 = P.W >> 2;
-    if (W4 <= 0 || 256 % W4 != 0) return 0;
+    if (W4 <= 0 || W4 > 64) return 0;          // (W/4 = 24 / 12 -- the 96^3 patches: 256 / (W/4) row groups, the block's last 256 % (W/4) threads get no rows)
     int nk = 3;
     for (int hh = 0; hh < P.nh - 1; ++hh) {
         const int wl = P.ld[hh][2];
