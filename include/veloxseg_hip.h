@@ -428,6 +428,7 @@ int vx_upsample_trilinear_fwd(const float* x, float* out, long BC, int d, int h,
 int vx_upsample_trilinear_bwd(const float* dout, float* dx, float* ws, long BC, int d, int h, int w, int D, int H, int W, void* stream);
 
 /* ConvTranspose3d(k=2, s=2) specialised (conv_blocks.py:29-35): w = (Ci, Co, 2,2,2); x: (B,Ci,d,h,w); y: (B,Co,2d,2h,2w) */
+int vx_upconv_set_mfma4(int on);      /* 1 (default; VELOXSEG_UPCONV_MFMA4): 16 x 64 MFMA tiles with 16-byte accesses on the coarse levels when the row length is a multiple of 4; 0: the 16 x 16 tiles (A/B, tests) */
 int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream);
 int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* dx, int B, int Ci, int Co, int d, int h, int wd, void* stream);
 /* weight gradient of the same layer as one MFMA GEMM (M = Ci, N = Co * 8 taps, K = B * d * h * wd): dw (Ci, Co, 2, 2, 2) +=.  Ci, Co multiples of 16, Ci <= 128 */

@@ -340,11 +340,13 @@ def test_fan_out_gradients_meet_in_one_sum():
     close(g, 2.0 * (ws[0] + ws[1]), 1e-5, 1e-5, "fan_out of two")
 
 
-@pytest.mark.parametrize("B,Ci,Co,sp", [(2, 32, 16, (3, 4, 5)), (4, 128, 64, (4, 4, 4)), (3, 64, 32, (8, 8, 8)), (2, 32, 16, (16, 16, 16)), (1, 24, 8, (3, 3, 3))],
-                         ids=["ragged", "L4_to_L3", "L3_to_L2", "L2_to_L1", "odd_channels"])
+@pytest.mark.parametrize("B,Ci,Co,sp", [(2, 32, 16, (3, 4, 5)), (4, 128, 64, (4, 4, 4)), (3, 64, 32, (8, 8, 8)), (2, 32, 16, (16, 16, 16)), (1, 24, 8, (3, 3, 3)),
+                                        (2, 48, 24, (3, 5, 8)), (1, 20, 6, (2, 3, 12))],
+                         ids=["ragged", "L4_to_L3", "L3_to_L2", "L2_to_L1", "odd_channels", "rows_of_8_ragged_tiles", "rows_of_12_partial_row_tiles"])
 def test_conv_transpose(B, Ci, Co, sp):
     """ConvTranspose3d(k2, s2): forward, input gradient, and the weight gradient as one MFMA GEMM (pointwise.hip vx_upconv_k2s2_wgrad; channel counts that
-    are not multiples of 16 keep the generic kernel)"""
+    are not multiples of 16 keep the generic kernel).  Rows of 4 k voxels run the 16 x 64 tiles with 16-byte accesses (vx_upconv_mfma4_k: partial row / voxel
+    tiles, channel counts that are not multiples of 16), other widths the 16 x 16 tiles."""
     VF = _vf()
     x = rnd(B, Ci, *sp)
     w = rnd(Ci, Co, 2, 2, 2, seed=5, scale=0.2)

@@ -841,10 +841,129 @@ extern "C" int vx_pw_conv_res_fwd(const float* x, const float* w, const float* b
     return vx_pw_conv_fwd_impl(x, nullptr, Cin, w, bias, out, B, Cin, Cout, V, stream, e);
 }
 
+// ConvTranspose3d(k = 2, s = 2) on the coarse decoder levels (conv_blocks.py:29-35) as the 16 x 64 tiles of vx_pw_mfma4_body (round 5): a lane owns FOUR consecutive
+// coarse voxels of one row (wd % 4 == 0), so
+//   FWD  (rows m = co * 8 + tap, reduction over ci): the B operand is one 16-byte load of x per reduction row, and the lane's accumulators of the tap pair
+//        (.., kk = 0), (.., kk = 1) -- registers reg, reg + 1 -- are EIGHT consecutive fine voxels of y: two 16-byte stores instead of eight scattered 4-byte ones;
+//   BWD  (rows m = ci, reduction over k = co * 8 + tap): the B operand of (co, tap) is the stride-2 gather dy[2 w + kk + 2 j]: two 16-byte loads of the 8 fine voxels,
+//        even or odd elements picked in registers; the result rows leave as 16-byte stores.
+// The 16-voxel tiles of vx_pw_mfma_k did all of this with 4-byte accesses and a division chain per element: 18 launches of 11 - 29 us per pass, 0.32 ms.
+template <int BWD>
+__global__ void __launch_bounds__(256) vx_upconv_mfma4_k(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
+                                                         int Ci, int Co, int cd, int ch, int cw, int B, int n_vt, int ksplit) {
+    __shared__ float vx_ksum4[4][16 * 64];
+    const int Mch = BWD ? Ci : Co * 8, Kch = BWD ? Co * 8 : Ci;
+    const long V = (long)cd * ch * cw;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ks = ksplit > 1 ? wave : 0;
+    const long tile_raw = ksplit > 1 ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;           // over (b, 64-voxel tile)
+    const bool live = tile_raw < (long)B * n_vt;
+    if (!live && ksplit == 1) return;
+    const long tile = live ? tile_raw : 0;
+    const int b = (int)(tile / n_vt);
+    const long v0 = (tile % n_vt) * 64;
+    const int mt = blockIdx.y;
+    const int r = lane & 15, q = lane >> 4;
+    const int m_a = mt * 16 + r;
+    const bool m_ok = m_a < Mch;
+    const long v_b = v0 + 4 * r;                               // this lane's 4 coarse voxels: one row (cw % 4 == 0)
+    const bool v_ok = v_b < V;
+    const long vc = v_ok ? v_b : 0;
+    const int xw = (int)(vc % cw), xh = (int)((vc / cw) % ch), xd = (int)(vc / ((long)cw * ch));
+    const long fH = 2L * ch, fW = 2L * cw;
+    const long fbase = ((long)(2 * xd) * fH + 2 * xh) * fW + 2 * xw;      // fine voxel (2 xd, 2 xh, 2 xw)
+    const int kper = ksplit > 1 ? ((Kch + 4 * 16 - 1) / (4 * 16)) * 16 : Kch;
+    const int kbeg = ks * kper, kend = min(Kch, kbeg + kper);
+    vx_f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (vx_f32x4){0.f, 0.f, 0.f, 0.f};
+    // A(m, k): forward w[ci = k][co * 8 + tap = m] (row stride 1, k stride Co * 8); backward w[ci = m][k]
+    const float* __restrict__ wrow = w + (BWD ? (long)(m_ok ? m_a : 0) * Kch : (long)(m_ok ? m_a : 0));
+    const long wsk = BWD ? 1 : (long)Co * 8;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        float av[4];
+        float4 bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * s + q;
+            const bool k_ok = k < kend;
+            av[s] = (m_ok && k_ok) ? wrow[(long)k * wsk] : 0.0f;
+            if (BWD) {
+                const int kc = k_ok ? k : 0;
+                const int co = kc >> 3, tp = kc & 7;
+                const float* __restrict__ fp_ = src + ((long)b * Co + co) * (8 * V) + fbase + (long)(tp >> 2) * fH * fW + (long)((tp >> 1) & 1) * fW;
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (v_ok && k_ok) { lo = *reinterpret_cast<const float4*>(fp_); hi = *reinterpret_cast<const float4*>(fp_ + 4); }
+                bv[s] = (tp & 1) ? make_float4(lo.y, lo.w, hi.y, hi.w) : make_float4(lo.x, lo.z, hi.x, hi.z);
+            } else {
+                bv[s] = (v_ok && k_ok) ? *reinterpret_cast<const float4*>(src + ((long)b * Ci + k) * V + v_b) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+        }
+    }
+    if (ksplit > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) vx_ksum4[wave][(j * 4 + reg) * 64 + lane] = acc[j][reg];
+        __syncthreads();
+        if (wave != 0 || !live) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int e = (j * 4 + reg) * 64 + lane;
+                acc[j][reg] = (vx_ksum4[0][e] + vx_ksum4[1][e]) + (vx_ksum4[2][e] + vx_ksum4[3][e]);
+            }
+    }
+    if (!v_ok) return;
+    if (BWD) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = mt * 16 + 4 * q + reg;
+            if (m < Mch) *reinterpret_cast<float4*>(dst + ((long)b * Ci + m) * V + v_b) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+        }
+    } else {
+        // registers (reg, reg + 1), reg even = taps (i, jj, kk = 0 / 1) of one output channel: 8 consecutive fine voxels of the row (2 xd + i, 2 xh + jj)
+#pragma unroll
+        for (int rp = 0; rp < 4; rp += 2) {
+            const int m = mt * 16 + 4 * q + rp;
+            if (m < Mch) {
+                const int co = m >> 3, tp = m & 7;
+                const float bb = bias ? bias[co] : 0.0f;
+                float* __restrict__ op = dst + ((long)b * Co + co) * (8 * V) + fbase + (long)(tp >> 2) * fH * fW + (long)((tp >> 1) & 1) * fW;
+                *reinterpret_cast<float4*>(op) = make_float4(acc[0][rp] + bb, acc[0][rp + 1] + bb, acc[1][rp] + bb, acc[1][rp + 1] + bb);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(acc[2][rp] + bb, acc[2][rp + 1] + bb, acc[3][rp] + bb, acc[3][rp + 1] + bb);
+            }
+        }
+    }
+}
+static int vx_upconv_mfma4_on = -1;
+extern "C" int vx_upconv_set_mfma4(int on) { vx_upconv_mfma4_on = on ? 1 : 0; return 0; }
+static bool vx_upconv_mfma4_ok(int wd) {
+    if (vx_upconv_mfma4_on < 0) { const char* e = getenv("VELOXSEG_UPCONV_MFMA4"); vx_upconv_mfma4_on = (e && e[0] == '0') ? 0 : 1; }
+    return vx_upconv_mfma4_on == 1 && (wd & 3) == 0;
+}
+
 extern "C" int vx_upconv_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, int d, int h, int wd, void* stream) {
     VX_REQUIRE(x && w && y && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     const long Vc = (long)d * h * wd;
+    if (Vc <= 4096 && vx_upconv_mfma4_ok(wd)) {   // coarse levels, rows of 4 k voxels: 16 x 64 MFMA tiles with 16-byte accesses
+        const int n_vt4 = vx_cdiv(Vc, 64);
+        const int ks4 = vx_pw_ksplit((long)B * n_vt4 * vx_cdiv(Co * 8, 16), Ci);
+        dim3 g4(ks4 > 1 ? (unsigned)((long)B * n_vt4) : vx_cdiv((long)B * n_vt4, 4), vx_cdiv(Co * 8, 16));
+        vx_upconv_mfma4_k<0><<<g4, 256, 0, st>>>(x, w, bias, y, Ci, Co, d, h, wd, B, n_vt4, ks4);
+        VX_LAUNCH_CHECK("vx_upconv_k2s2_fwd");
+        return 0;
+    }
     if (Vc <= 4096) {   // coarse levels: MFMA tiles, rows m = co*8 + tap stored depth-to-space
         const int n_vt = vx_cdiv(Vc, 16);
         const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Co * 8, 16), Ci);
@@ -869,6 +988,14 @@ extern "C" int vx_upconv_k2s2_bwd_data(const float* dy, const float* w, float* d
     VX_REQUIRE(dy && w && dx && B > 0 && Ci > 0 && Co > 0 && d > 0 && h > 0 && wd > 0, "vx_upconv_k2s2_bwd_data: bad args");
     hipStream_t st = (hipStream_t)stream;
     const long Vc = (long)d * h * wd;
+    if (Vc <= 4096 && vx_upconv_mfma4_ok(wd)) {
+        const int n_vt4 = vx_cdiv(Vc, 64);
+        const int ks4 = vx_pw_ksplit((long)B * n_vt4 * vx_cdiv(Ci, 16), Co * 8);
+        dim3 g4(ks4 > 1 ? (unsigned)((long)B * n_vt4) : vx_cdiv((long)B * n_vt4, 4), vx_cdiv(Ci, 16));
+        vx_upconv_mfma4_k<1><<<g4, 256, 0, st>>>(dy, w, nullptr, dx, Ci, Co, d, h, wd, B, n_vt4, ks4);
+        VX_LAUNCH_CHECK("vx_upconv_k2s2_bwd_data");
+        return 0;
+    }
     if (Vc <= 4096) {   // coarse levels: MFMA tiles, reduction rows k = co*8 + tap gathered space-to-depth from dy
         const int n_vt = vx_cdiv(Vc, 16);
         const int ksplit = vx_pw_ksplit((long)B * n_vt * vx_cdiv(Ci, 16), Co * 8);
