@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_k(VxGatherPtrs ptrs
     const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
     const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
     const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + cc;
-    dsrc[((long)b * (P.nb * P.heads * c) + ch) * V + v] = (tix[ti] == (int)v) ? dtok[ti] : 0.0f;
+    const bool ident = P.small[i][0] * P.small[i][1] * P.small[i][2] == 1;       // 1 x 1 x 1 cells: the arg-max is the voxel itself (the vectorised forward stores no index there)
+    dsrc[((long)b * (P.nb * P.heads * c) + ch) * V + v] = (ident || tix[ti] == (int)v) ? dtok[ti] : 0.0f;
 }
 
 
@@ -232,7 +233,9 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_v_k(VxGatherPtrs pt
 #pragma unroll
         for (int k = 0; k < CH; k += 4) {
             *reinterpret_cast<float4*>(tok + ti + k) = make_float4(best[k], best[k + 1], best[k + 2], best[k + 3]);
-            *reinterpret_cast<int4*>(tix + ti + k) = make_int4(bidx[k], bidx[k + 1], bidx[k + 2], bidx[k + 3]);
+            // 1 x 1 x 1 cells (the first scale of every shipped config): the arg-max is the voxel itself -- vx_pwa_gather_all_bwd_v_k knows that too, and the index
+            // tensor (as large as the tokens) is neither written nor read for this scale
+            if (csz > 1) *reinterpret_cast<int4*>(tix + ti + k) = make_int4(bidx[k], bidx[k + 1], bidx[k + 2], bidx[k + 3]);
         }
     }
 }
@@ -264,10 +267,11 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
     const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + chunk * CH;
     const int ch0 = (i * P.heads + a) * c + chunk * CH;
     float* __restrict__ dc = dsrc + ((long)b * (P.nb * P.heads * c) + ch0) * V + v;
+    const bool ident = P.small[i][0] * P.small[i][1] * P.small[i][2] == 1;       // (see the forward: no indices for 1 x 1 x 1 cells)
 #pragma unroll
     for (int k = 0; k < CH; k += 4) {
         const float4 g = *reinterpret_cast<const float4*>(dtok + ti + k);
-        const int4 ix = *reinterpret_cast<const int4*>(tix + ti + k);
+        const int4 ix = ident ? make_int4((int)v, (int)v, (int)v, (int)v) : *reinterpret_cast<const int4*>(tix + ti + k);
         dc[(long)(k + 0) * V] = ix.x == (int)v ? g.x : 0.0f;
         dc[(long)(k + 1) * V] = ix.y == (int)v ? g.y : 0.0f;
         dc[(long)(k + 2) * V] = ix.z == (int)v ? g.z : 0.0f;
