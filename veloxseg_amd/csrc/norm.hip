@@ -747,18 +747,21 @@ __device__ __forceinline__ void vx_block_sum2_f64(double& a, double& c, double* 
     c = sm[4] + sm[5] + sm[6] + sm[7];
 }
 
+// NK inputs, R = ceil(V / 256) elements per thread: both compile-time (round 5) -- the input / statistics pointers were picked from arrays with a run-time index
+// (generic-address FLAT loads, which also count on the LDS wait counter) and every row walked all 16 element slots of the longest row (4^3 rows: 15 of 16 predicated off)
+template <int NK, int R>
 __global__ void __launch_bounds__(256) vx_in_row_fwd_k(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
                                                        float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2,
-                                                       int nk, int act, const float* __restrict__ res, float* __restrict__ out, int V, float eps) {
+                                                       int act, const float* __restrict__ res, float* __restrict__ out, int V, float eps) {
     __shared__ double sm[8];
     const long bc = blockIdx.x;
-    const float* ys[3] = {y0, y1, y2};
-    float* ss[3] = {s0, s1, s2};
-    constexpr int R = VX_IN_ROW_MAX / 256;
+    const float* const ys[3] = {y0, y1, y2};
+    float* const ss[3] = {s0, s1, s2};
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; acc[r] = (res && v < V) ? res[bc * V + v] : 0.0f; }
-    for (int k = 0; k < nk; ++k) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
         const float* __restrict__ row = ys[k] + bc * V;
         float x[R];
         double a = 0.0, c = 0.0;
@@ -786,23 +789,24 @@ __global__ void __launch_bounds__(256) vx_in_row_fwd_k(const float* __restrict__
     for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; if (v < V) out[bc * V + v] = acc[r]; }
 }
 
+template <int NK, int R>
 __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__ dout, const float* __restrict__ y0, const float* __restrict__ y1,
                                                        const float* __restrict__ y2, const float* __restrict__ s0, const float* __restrict__ s1,
-                                                       const float* __restrict__ s2, int nk, int act, float* __restrict__ d0, float* __restrict__ d1,
+                                                       const float* __restrict__ s2, int act, float* __restrict__ d0, float* __restrict__ d1,
                                                        float* __restrict__ d2, int V, float* __restrict__ b0, float* __restrict__ b1, float* __restrict__ b2, int C,
                                                        const float* __restrict__ add0) {
     __shared__ double sm[8];
     __shared__ float smf[4];
     const long bc = blockIdx.x;
-    const float* ys[3] = {y0, y1, y2};
-    const float* ss[3] = {s0, s1, s2};
-    float* ds[3] = {d0, d1, d2};
-    float* dbs[3] = {b0, b1, b2};
-    constexpr int R = VX_IN_ROW_MAX / 256;
+    const float* const ys[3] = {y0, y1, y2};
+    const float* const ss[3] = {s0, s1, s2};
+    float* const ds[3] = {d0, d1, d2};
+    float* const dbs[3] = {b0, b1, b2};
     float g[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int v = r * 256 + threadIdx.x; g[r] = v < V ? dout[bc * V + v] : 0.0f; }
-    for (int k = 0; k < nk; ++k) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
         if (ds[k] == nullptr) continue;                 // this input needs no gradient (block-uniform)
         const float* __restrict__ row = ys[k] + bc * V;
         const float mean = ss[k][2 * bc], rstd = ss[k][2 * bc + 1];
@@ -835,11 +839,25 @@ __global__ void __launch_bounds__(256) vx_in_row_bwd_k(const float* __restrict__
     }
 }
 
+// <NK, R> instance for (nk, V): R = 1, 2, 4, 8 or 16 elements per thread
+#define VX_IN_ROW_DISPATCH(KERNEL, nk_, V_, ...)                                                                              \
+    do {                                                                                                                      \
+        const int r_ = (V_) <= 256 ? 1 : (V_) <= 512 ? 2 : (V_) <= 1024 ? 4 : (V_) <= 2048 ? 8 : 16;                          \
+        switch ((nk_) * 100 + r_) {                                                                                           \
+            case 101: KERNEL<1, 1> __VA_ARGS__; break; case 102: KERNEL<1, 2> __VA_ARGS__; break; case 104: KERNEL<1, 4> __VA_ARGS__; break;   \
+            case 108: KERNEL<1, 8> __VA_ARGS__; break; case 116: KERNEL<1, 16> __VA_ARGS__; break;                             \
+            case 201: KERNEL<2, 1> __VA_ARGS__; break; case 202: KERNEL<2, 2> __VA_ARGS__; break; case 204: KERNEL<2, 4> __VA_ARGS__; break;   \
+            case 208: KERNEL<2, 8> __VA_ARGS__; break; case 216: KERNEL<2, 16> __VA_ARGS__; break;                             \
+            case 301: KERNEL<3, 1> __VA_ARGS__; break; case 302: KERNEL<3, 2> __VA_ARGS__; break; case 304: KERNEL<3, 4> __VA_ARGS__; break;   \
+            case 308: KERNEL<3, 8> __VA_ARGS__; break; default: KERNEL<3, 16> __VA_ARGS__; break;                              \
+        }                                                                                                                     \
+    } while (0)
+
 // d0 = add0 + InstanceNorm backward (single input): folds the add of a residual-branch gradient into the row kernel
 extern "C" int vx_in_row_bwd_add(const float* dout, const float* y0, const float* s0, int act, const float* add0, float* d0, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && add0 && d0 && add0 != d0 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd_add: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, nullptr, nullptr, s0, nullptr, nullptr, 1, act, d0, nullptr, nullptr, (int)V, nullptr,
-                                                                                nullptr, nullptr, 1, add0);
+    VX_IN_ROW_DISPATCH(vx_in_row_bwd_k, 1, V, <<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, nullptr, nullptr, s0, nullptr, nullptr, act, d0, nullptr, nullptr, (int)V,
+                                                                                                            nullptr, nullptr, nullptr, 1, add0));
     VX_LAUNCH_CHECK("vx_in_row_bwd_add");
     return 0;
 }
@@ -852,7 +870,7 @@ extern "C" int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, 
     VX_REQUIRE(V > 1, "vx_in_row_fwd: InstanceNorm needs more than 1 spatial element per channel (got %ld), as nn.InstanceNorm3d does", V);
     VX_REQUIRE(V <= VX_IN_ROW_MAX, "vx_in_row_fwd: rows of at most %d elements (got %ld): use vx_in_stats + vx_in_apply_fwd", VX_IN_ROW_MAX, V);
     VX_REQUIRE((nk < 2 || (y1 && s1)) && (nk < 3 || (y2 && s2)), "vx_in_row_fwd: missing input");
-    vx_in_row_fwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(y0, y1, y2, s0, s1, s2, nk, act, res, out, (int)V, eps);
+    VX_IN_ROW_DISPATCH(vx_in_row_fwd_k, nk, V, <<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(y0, y1, y2, s0, s1, s2, act, res, out, (int)V, eps));
     VX_LAUNCH_CHECK("vx_in_row_fwd");
     return 0;
 }
@@ -860,14 +878,14 @@ extern "C" int vx_in_row_fwd(const float* y0, const float* y1, const float* y2, 
 extern "C" int vx_in_row_bwd(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                              int nk, int act, float* d0, float* d1, float* d2, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX, "vx_in_row_bwd: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, nullptr, nullptr, nullptr, 1, nullptr);
+    VX_IN_ROW_DISPATCH(vx_in_row_bwd_k, nk, V, <<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, act, d0, d1, d2, (int)V, nullptr, nullptr, nullptr, 1, nullptr));
     VX_LAUNCH_CHECK("vx_in_row_bwd");
     return 0;
 }
 extern "C" int vx_in_row_bwd_db(const float* dout, const float* y0, const float* y1, const float* y2, const float* s0, const float* s1, const float* s2,
                                 int nk, int act, float* d0, float* d1, float* d2, float* db0, float* db1, float* db2, int C, long BC, long V, void* stream) {
     VX_REQUIRE(dout && y0 && s0 && nk >= 1 && nk <= 3 && BC > 0 && V > 1 && V <= VX_IN_ROW_MAX && C > 0 && BC % C == 0, "vx_in_row_bwd_db: bad args");
-    vx_in_row_bwd_k<<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, nk, act, d0, d1, d2, (int)V, db0, db1, db2, C, nullptr);
+    VX_IN_ROW_DISPATCH(vx_in_row_bwd_k, nk, V, <<<dim3((unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(dout, y0, y1, y2, s0, s1, s2, act, d0, d1, d2, (int)V, db0, db1, db2, C, nullptr));
     VX_LAUNCH_CHECK("vx_in_row_bwd_db");
     return 0;
 }
