@@ -39,13 +39,18 @@ __device__ __forceinline__ void tile_gemm(int nseg, const float* const (&w)[3], 
         // chunks of 64 k (4 x 16-byte A loads per lane), software-pipelined: the loads of chunk n + 1 are issued before the MFMAs of chunk n
         int kin = 0;
         float a[4][4], an[4][4];
-        auto load_a = [&](float (&dst)[4][4], const float* __restrict__ wrow, int K, int k0) {
+        // (the weight pointer is picked from w[] with a run-time index: say that it is GLOBAL memory, or the loads become FLAT -- slower, and counted on the LDS wait
+        // counter as well, so that every wait for a B operand also waited for the weight prefetch)
+        typedef const __attribute__((address_space(1))) float* gcf;
+        typedef const __attribute__((address_space(1))) vx_f32x4* gcf4;
+        auto load_a = [&](float (&dst)[4][4], const float* __restrict__ wrow_, int K, int k0) {
+            gcf wrow = (gcf)(unsigned long long)wrow_;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int kb = min(k0 + 16 * c, K - 16) + 4 * q;          // clamped: chunks beyond K reload the last one (never used)
                 if (!TR) {
-                    const float4 t = *reinterpret_cast<const float4*>(wrow + kb);
-                    dst[c][0] = t.x; dst[c][1] = t.y; dst[c][2] = t.z; dst[c][3] = t.w;
+                    const vx_f32x4 t = *(gcf4)(wrow + kb);
+                    dst[c][0] = t[0]; dst[c][1] = t[1]; dst[c][2] = t[2]; dst[c][3] = t[3];
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dst[c][i] = wrow[(long)(kb + i) * wsk];
