@@ -588,6 +588,8 @@ def _latest_profile(pattern):
     import re as _re
     best = None
     for f in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        if _re.search(r"autopet96|brats", os.path.basename(f)):      # summaries of the other workloads (profiles/r05_kernel_stats_autopet96.csv): not the headline's
+            continue
         m = _re.match(r"r(\d+)", os.path.basename(f))
         if m and (best is None or (int(m.group(1)), f) > best):
             best = (int(m.group(1)), f)
