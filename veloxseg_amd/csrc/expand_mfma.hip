@@ -1128,20 +1128,33 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
     vx_f4 tot[4];                      // fp16 mode: the sum over the (c, s1) groups in true units (every group's staged tile has its own scale)
 #pragma unroll
     for (int m = 0; m < 4; ++m) { acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f}; tot[m] = (vx_f4){0.f, 0.f, 0.f, 0.f}; }
+    // the staging list of a thread (11 quads of the 144 x 18 halo tile) does not depend on (c, s1): element offsets inside a channel's fine volume at s1 = 0 and the
+    // inside-the-volume flags, once (round 5: the index arithmetic -- two divisions by constants and a 64-bit multiply-add per quad, 65 quarter-rate multiplies per
+    // (c, s1) iteration -- was a third of the kernel's issue slots)
+    int soff[11];
+    unsigned okm = 0;
+#pragma unroll
+    for (int u = 0; u < 11; ++u) {
+        const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+        const int f4 = e % 18, row = e / 18;
+        const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+        const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+        soff[u] = ok ? (int)(((long)(4 * qd) * FH + 4 * qh + s2) * FW + 4 * qw) : 0;          // (< 2^31: a channel's fine volume is at most 2^31 elements where this kernel is used)
+        okm |= (ok ? 1u : 0u) << u;
+    }
+    const long s1stride = FH * FW;
     for (int c = 0; c < Cc; ++c) {
         for (int s1 = 0; s1 < 4; ++s1) {
             __syncthreads();
             float gscale = 1.0f;
             {
                 float4 v[11];
+                const float* __restrict__ cb_ = dyb + (long)c * fplane + (long)s1 * s1stride;
 #pragma unroll
                 for (int u = 0; u < 11; ++u) {
-                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
-                    const int f4 = e % 18, row = e / 18;
-                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
-                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
-                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
-                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    const bool ok = (okm >> u) & 1u;
+                    const float4 t_ = *reinterpret_cast<const float4*>(ok ? cb_ + soff[u] : dyb);
                     v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if constexpr (F16) {
