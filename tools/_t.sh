@@ -1,2 +1,2 @@
-python -m pytest tests/test_hip_ops_gpu.py -q -k "expand" 2>&1 | tail -2
+python -m pytest tests/test_pwa_fused_gpu.py tests/test_fused_blocks_gpu.py -q 2>&1 | tail -2
 for t in 1 2; do python bench.py --no-eager-baseline --no-cpu-baseline --steps 200 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['kernel_pass']['total_ms'])"; done

@@ -206,21 +206,29 @@ __device__ __forceinline__ void load_tile_s2d(float* __restrict__ dst, const flo
     const bool ok = v < V;
     const long vc = ok ? v : 0;
     const int w_ = (int)(vc % gw), h_ = (int)((vc / gw) % gh), d_ = (int)(vc / ((long)gw * gh));
-    const long HW2 = (long)(2 * gh) * (2 * gw);
+    const int HW2 = (2 * gh) * (2 * gw);
     const long gd2 = 2 * (V / ((long)gh * gw));
-    const long base = (long)(2 * d_) * HW2 + (long)(2 * h_) * (2 * gw) + 2 * w_;
-    for (int row0 = threadIdx.x >> 4; row0 < C; row0 += U * RP) {
+    const long cstride = gd2 * HW2;                                   // one input channel (fine volume)
+    const float* __restrict__ xv = xb + (long)(2 * d_) * HW2 + (long)(2 * h_) * (2 * gw) + 2 * w_;
+    // row = sub * C0 + c walked with a running (sub, c) pair: the division by C0 and the 64-bit products per element were most of this loop's instructions
+    int row = threadIdx.x >> 4;
+    int sub = row / C0, c = row - sub * C0;                           // (once per thread)
+    for (int row0 = row; row0 < C; row0 += U * RP) {
         float t[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int row = min(row0 + u * RP, C - 1);
-            const int sub = row / C0, c = row - sub * C0;
-            t[u] = xb[(long)c * gd2 * HW2 + base + (long)(sub >> 2) * HW2 + (long)((sub >> 1) & 1) * (2 * gw) + (sub & 1)];
+            const bool in = row0 + u * RP < C;                        // rows beyond C: reload the thread's last valid row (never stored)
+            const int so = (sub >> 2) * HW2 + ((sub >> 1) & 1) * (2 * gw) + (sub & 1);
+            t[u] = xv[(long)c * cstride + so];
+            if (in && row0 + (u + 1) * RP < C) {                      // advance (sub, c) by RP rows (for u = U - 1: to the next batch's first row)
+                c += RP;
+                while (c >= C0) { c -= C0; ++sub; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int row = row0 + u * RP;
-            if (row < C) dst[row * S + cg] = ok ? t[u] : 0.0f;
+            const int rw = row0 + u * RP;
+            if (rw < C) dst[rw * S + cg] = ok ? t[u] : 0.0f;
         }
     }
 }
@@ -384,6 +392,8 @@ __global__ void __launch_bounds__(64 * NW) vx_ln_pw_bwd_k(VxLnPwBwd p) {
         gd2 = 2 * (V / ((long)p.gh * p.gw));
         s2d_base = (long)b * C * V + (long)(2 * d_) * HW2 + (long)(2 * h_) * (2 * p.gw) + 2 * w_;
     }
+    int ssub = p.s2d ? part / p.C0 : 0, sc0 = p.s2d ? part - ssub * p.C0 : 0;      // s2d: channel c = ssub * C0 + sc0, walked without a division per channel
+    const long cstr2 = gd2 * HW2;
     for (int c = part; c < C; c += NP) {
         const float xh = (X[c * S + col] - mean) * rstd;
         const float dn = G[c * S + col];
@@ -395,14 +405,14 @@ __global__ void __launch_bounds__(64 * NW) vx_ln_pw_bwd_k(VxLnPwBwd p) {
         if (live) {
             float dxv = rstd * (g - t1 - xh * t2);
             if (p.s2d) {
-                const int sub = c / p.C0, c0 = c - sub * p.C0;
-                M.dx[s2d_base + (long)c0 * gd2 * HW2 + (long)(sub >> 2) * HW2 + (long)((sub >> 1) & 1) * (2 * p.gw) + (sub & 1)] = dxv;
+                M.dx[s2d_base + (long)sc0 * cstr2 + (long)(ssub >> 2) * HW2 + (long)((ssub >> 1) & 1) * (2 * p.gw) + (ssub & 1)] = dxv;
             } else {
                 if (has_res) dxv += D[c * S + col];
                 else if (M.dres) dxv += M.dres[((long)b * C + c) * V + v0 + col];
                 M.dx[((long)b * C + c) * V + v0 + col] = dxv;
             }
         }
+        if (p.s2d) { sc0 += NP; while (sc0 >= p.C0) { sc0 -= p.C0; ++ssub; } }
     }
 }
 
