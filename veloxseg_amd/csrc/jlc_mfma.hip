@@ -1224,9 +1224,16 @@ static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int
     // this kernel is a SINK that runs beside the backward chains of the other lanes: at 74 KB of LDS and 248 VGPRs per block, two blocks per CU leave those chains
     // nothing to run on -- the step is 774 patches/s with 512 blocks, 798 with 256, 782 with the VALU weight-gradient kernels (VELOXSEG_WG_TZ_BLOCKS for the A/B)
     int nchunks = (int)((target + base_blocks - 1) / base_blocks);
-    if (nchunks > D / 2) nchunks = D / 2;
+    // at least two owned planes per chunk (a chunk walks its planes + 4: one-plane chunks do 5 steps for one plane's work).  On the 8-plane level one plane per chunk
+    // (VELOXSEG_WG_TZ_MINDC8=1: 256 blocks instead of 128) is FASTER ALONE -- 31.9 vs 39.2 us, tools/jlc_wg_probe.py -- and SLOWER IN THE STEP (1020 vs 1028 patches/s,
+    // same box, twice): this kernel is a sink beside the other lanes' chains, and what it costs them is CUs, not microseconds (as with 512 blocks at 32^3 in round 4)
+    static int mindc8 = 0;
+    if (!mindc8) { const char* e = getenv("VELOXSEG_WG_TZ_MINDC8"); mindc8 = (e && atoi(e) == 1) ? 1 : 2; }
+    const int min_dc = D <= 8 ? mindc8 : 2;
+    if (nchunks > D / min_dc) nchunks = D / min_dc;
     if (nchunks < 1) nchunks = 1;
     p.DC = vx_cdiv(D, nchunks);
+    { static int dc_env = -1; if (dc_env < 0) { const char* e = getenv("VELOXSEG_WG_TZ_DC"); dc_env = e ? atoi(e) : 0; } if (dc_env > 0 && dc_env <= D) p.DC = dc_env; }      // (experiments)
     p.nDc = vx_cdiv(D, p.DC);
     if ((long)p.nb * 4 * (p.TH + 4) * (p.XR / 4) + 3L * p.nb * 4 * p.TH * (p.WS / 4) > (long)WG_NPF * 256) return -1;      // one step's staging list must fit the per-thread items
     shm = (size_t)NS * p.SP * 2 + 128;              // (+ the maxima / exponent tables of the fp16 mode)
