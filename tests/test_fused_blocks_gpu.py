@@ -357,14 +357,17 @@ def test_jlc_channels_last_f16_convs_vs_fp64_and_valu_kernels(case):
     assert e_new <= max(3.0 * e_old, 2e-6), (e_old, e_new)
 
 
-@pytest.mark.parametrize("pieces", [3, 22, 1])
+@pytest.mark.parametrize("pieces", [3, 22, 1, -3], ids=["3", "22", "1", "3_one_role"])
 @pytest.mark.parametrize("case", [c for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32], ids=[c[0] for c in TZ_CASES if c[4][1] % 4 == 0 and c[4][2] <= 32])
 def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, pieces):
     """vx_jlc_wgrad_tz (the three grouped-conv weight gradients of conv_blocks.py:51-58 in one matrix-pipe launch, csrc/jlc_mfma.hip) against torch's fp64 weight
-    gradient and the fp32 VALU kernels (csrc/conv_wgrad.hip); the entry ACCUMULATES into dw (float atomics), checked by a non-zero start value."""
+    gradient and the fp32 VALU kernels (csrc/conv_wgrad.hip); the entry ACCUMULATES into dw (float atomics), checked by a non-zero start value.  pieces = 3 is the
+    default instance with producer / consumer waves (512 threads, deeper staging); "3_one_role" the same arithmetic on the one-role kernel (vx_jlc_wgrad_tz_set_spec(0))."""
     from veloxseg_amd import _hip as H
     _, B, C, G, (D, Hh, W) = case
     H.LIB.load()
+    H.call("vx_jlc_wgrad_tz_set_spec", 0 if pieces < 0 else 1)
+    pieces = abs(pieces)
     H.call("vx_jlc_tz_set_pieces", pieces)
     H.call("vx_jlc_wgrad_tz_set_f16", 1)          # pieces = 22: the two-fp16-piece weight-gradient instance (an A/B variant: the default under 22 is three bf16 pieces)
     try:
@@ -394,3 +397,4 @@ def test_jlc_toeplitz_mfma_weight_gradients_vs_fp64_and_valu_kernels(case, piece
     finally:
         H.call("vx_jlc_tz_set_pieces", 22)          # (the library default)
         H.call("vx_jlc_wgrad_tz_set_f16", 0)
+        H.call("vx_jlc_wgrad_tz_set_spec", 1)

@@ -828,7 +828,8 @@ struct VxWgT {
     int WS, nb, nsg;                 // slots per sample, samples per reduction chunk, sample groups
     int TH, nHt, DC, nDc, nXB;       // H tile (multiple of 4), D chunk, x row blocks per tile (TH / 4 + 1)
     int XR;                          // x row length in LDS (WS + 8: e = w + 4)
-    int XP, GP, SP;                  // elements: x plane / one g plane / piece stride (XP + 9 GP)
+    int XP, GP, SP;                  // elements: x plane / one g plane / piece stride (XB XP + (R5 + R3 + R1) GP)
+    int XB, R5, R3, R1, GB;          // x buffers (1; 2 with producer waves), ring slots of g5 / g3 / g1 (5 / 3 / 1; one more each with producer waves), element offset of slot 0 (XB XP)
     int dbg;                         // timing experiments: bit 0 no staging, bit 1 no MFMA phase, bit 2 no fold / atomics
 };
 
@@ -881,11 +882,17 @@ __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int co
     const bool ok = b < p.B && ih < p.H && iw < p.W;
     r.f = (kind + 1) | 4 | (ok ? 8 : 0);
     r.b = (kind == 0 ? p.g5 : kind == 1 ? p.g3 : p.g1) + (ok ? (long)(b * p.C + cob + co) * chan + ih * p.W + iw : 0);
-    r.l = p.XP + ((s * 4 + co) * (p.TH + 1) + row) * p.WS + 4 * qd;
+    r.l = p.GB + ((s * 4 + co) * (p.TH + 1) + row) * p.WS + 4 * qd;
     return r;
 }
 // plane of item kind k at step dx: x: dx; g5: dx + 2; g3: dx + 1; g1: dx  (no table: (0x18 >> 2k) & 3 = 0, 2, 1, 0)
 __device__ __forceinline__ int wg_dk(int k) { return (0x18 >> (2 * k)) & 3; }
+// ring slot of g plane pl / element offset of the x buffer of step dx (planes from -2 on: + 60 keeps the dividend positive and is a multiple of every ring size used)
+// (SP = producer waves: 6 / 4 / 2 slots and two x buffers, else 5 / 3 / 1 and one -- compile-time, or the remainders cost a division each and the kernel spills)
+template <bool SP> __device__ __forceinline__ int wg_s5(const VxWgT&, int pl) { return (pl + 60) % (SP ? 6 : 5); }
+template <bool SP> __device__ __forceinline__ int wg_s3(const VxWgT&, int pl) { return (SP ? 6 : 5) + (pl + 60) % (SP ? 4 : 3); }
+template <bool SP> __device__ __forceinline__ int wg_s1(const VxWgT&, int pl) { return SP ? 10 + ((pl + 60) & 1) : 8; }
+template <bool SP> __device__ __forceinline__ int wg_xo(const VxWgT& p, int dx) { return SP ? ((dx + 60) & 1) * p.XP : 0; }
 __device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], const VxWgT& p, int dx, int dg0, int dg1) {
     const long HW = (long)p.H * p.W;
 #pragma unroll
@@ -901,16 +908,16 @@ __device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (
         pf[u] = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-template <int NS>
+template <int NS, bool SP = false>
 __device__ __forceinline__ void wg_commit(const float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], unsigned char* lds, const VxWgT& p, int dx, int dg0, int dg1) {
     // ring slots of the planes that arrive at this step (wave-uniform, once per step)
-    const int l5 = ((dx + 2 + 10) % 5) * p.GP, l3 = (5 + (dx + 1 + 9) % 3) * p.GP, l1 = 8 * p.GP;
+    const int l5 = wg_s5<SP>(p, dx + 2) * p.GP, l3 = wg_s3<SP>(p, dx + 1) * p.GP, l1 = wg_s1<SP>(p, dx) * p.GP, lx = wg_xo<SP>(p, dx);
 #pragma unroll
     for (int u = 0; u < WG_NPF; ++u) {
         const int k = ds[u].f & 3;
         const int pl = dx + wg_dk(k);
         const bool on = (ds[u].f & 4) && pl >= (k == 0 ? 0 : dg0) && pl < (k == 0 ? p.D : dg1);
-        const int lo = k == 0 ? 0 : k == 1 ? l5 : k == 2 ? l3 : l1;
+        const int lo = k == 0 ? lx : k == 1 ? l5 : k == 2 ? l3 : l1;
         if (on) wg_split_store<NS>(pf[u], lds, (long)ds[u].l + lo, p.SP);
     }
 }
@@ -921,8 +928,8 @@ __device__ __forceinline__ void wg_commit(const float4 (&pf)[WG_NPF], const WgDe
 // its tiles currently carry and multiplies them by the (exact) power of two when a new pair differs.  Needs one more barrier per step than the bf16 staging.
 __device__ __forceinline__ void wg_commit16(const float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], unsigned char* lds, const VxWgT& p, int dx, int dg0, int dg1,
                                             float* __restrict__ mtab, int* __restrict__ etab) {
-    const int l5 = ((dx + 2 + 10) % 5) * p.GP, l3 = (5 + (dx + 1 + 9) % 3) * p.GP, l1 = 8 * p.GP;
-    const int s5 = (dx + 2 + 10) % 5, s3 = 5 + (dx + 1 + 9) % 3;
+    const int s5 = wg_s5<false>(p, dx + 2), s3 = wg_s3<false>(p, dx + 1), s1_ = wg_s1<false>(p, dx);
+    const int l5 = s5 * p.GP, l3 = s3 * p.GP, l1 = s1_ * p.GP;
     float mk[4] = {0.f, 0.f, 0.f, 0.f};
     bool on_[WG_NPF];
 #pragma unroll
@@ -946,7 +953,7 @@ __device__ __forceinline__ void wg_commit16(const float4 (&pf)[WG_NPF], const Wg
     for (int kk = 0; kk < 4; ++kk) ek[kk] = tz_exp16(fmaxf(fmaxf(mtab[kk], mtab[4 + kk]), fmaxf(mtab[8 + kk], mtab[12 + kk])));
     if (threadIdx.x == 0) {
         etab[0] = ek[0];
-        etab[1 + s5] = ek[1]; etab[1 + s3] = ek[2]; etab[1 + 8] = ek[3];       // (planes that are not staged this step have no items: their slots are not read before a later staging)
+        etab[1 + s5] = ek[1]; etab[1 + s3] = ek[2]; etab[1 + s1_] = ek[3];       // (planes that are not staged this step have no items: their slots are not read before a later staging)
     }
 #pragma unroll
     for (int u = 0; u < WG_NPF; ++u) {
@@ -971,7 +978,7 @@ __device__ __forceinline__ void wg_read_a(uint4 (&a)[NS], const unsigned char* l
     const int rr = (unsigned)r < (unsigned)th_lane ? r : p.TH;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        a[s] = *reinterpret_cast<const uint4*>(lds + 2 * ((long)s * p.SP + p.XP + (long)slot * p.GP + (long)arow_base + (long)rr * p.WS));
+        a[s] = *reinterpret_cast<const uint4*>(lds + 2 * ((long)s * p.SP + p.GB + (long)slot * p.GP + (long)arow_base + (long)rr * p.WS));
 }
 
 template <int NS, bool F16 = false>
@@ -996,8 +1003,11 @@ __device__ __forceinline__ uint4 wg_shift(const uint32_t (&w)[8], int o) {
 }
 
 // DBG = true: the timing-experiment build (vx_jlc_tz_set_debug); the production instance carries none of its branches
-template <int NS, bool DBG, bool F16 = false>
-__global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
+// SPEC = true (round 5): 512 threads.  Waves 4..7 are PRODUCERS -- they load, split and store the operands of step dx + 1 (second x buffer, one more slot per g ring) while
+// waves 0..3 run the MFMA phase of step dx; one barrier per step.  The one-role kernel spent two thirds of a step outside its MFMAs: the barrier pair around the commit,
+// the piece splitting and the exposed latency of the next plane's loads (tools/jlc_wg_probe.py), with one wave per SIMD to hide none of it.
+template <int NS, bool DBG, bool F16 = false, bool SPEC = false>
+__global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(VxWgT p_) {
     const VxWgT& p = p_;
     const int dbg = DBG ? p_.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
@@ -1017,12 +1027,13 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
     const int cob = g * p.CG + ch * 4, cib = g * p.CG + ih * 4;
 
     // zero rows of every g slot (never overwritten)
-    for (int it = threadIdx.x; it < 9 * p.nb * 4 * (p.WS / 2) * NS; it += blockDim.x) {
+    constexpr int nslot = SPEC ? 12 : 9;
+    for (int it = threadIdx.x; it < nslot * p.nb * 4 * (p.WS / 2) * NS; it += blockDim.x) {
         int r = it;
         const int e2 = r % (p.WS / 2); r /= (p.WS / 2);
         const int sc = r % (p.nb * 4); r /= (p.nb * 4);
-        const int slot = r % 9, s = r / 9;
-        *reinterpret_cast<uint32_t*>(wg_lds + 2 * ((long)s * p.SP + p.XP + (long)slot * p.GP + ((long)sc * (p.TH + 1) + p.TH) * p.WS + 2 * e2)) = 0u;
+        const int slot = r % nslot, s = r / nslot;
+        *reinterpret_cast<uint32_t*>(wg_lds + 2 * ((long)s * p.SP + p.GB + (long)slot * p.GP + ((long)sc * (p.TH + 1) + p.TH) * p.WS + 2 * e2)) = 0u;
     }
     // lane constants: sample / column of the lane's 8 reduction slots
     // (WS = 24: slots 24..31 belong to no sample -- those lanes read the zero row as their g operand, whatever x operand they pair it with)
@@ -1036,25 +1047,50 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
     // 20 accumulator tiles per wave, one register set for both roles.  waves 0..2: [t*5 + kw] = K5 (kd = wave), [10 + t*3 + kw] = K3 (kd = wave), [16] = K1 (wave 0);
     // wave 3: [kk*10 + t*5 + kw] = K5 (kd = 3 + kk)
     tz_f4 acc[20];
-#pragma unroll
-    for (int t = 0; t < 20; ++t) acc[t] = (tz_f4){0.f, 0.f, 0.f, 0.f};
-
-    auto slot5 = [&](int pl) { return (pl + 10) % 5; };
-    auto slot3 = [&](int pl) { return 5 + (pl + 9) % 3; };
-    auto owned = [&](int pl) { return pl >= dg0 && pl < dg1; };
-
-    // the march: x planes dg0 - 2 .. dg1 + 1 (every owned g plane arrives exactly when its first partner does: g5[dx + 2], g3[dx + 1], g1[dx]); a step whose
-    // x plane lies outside the volume only stages
-    float4 pf[WG_NPF];
-    WgDesc ds[WG_NPF];
-#pragma unroll
-    for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
-    wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
     // fp16 mode: maxima / exponent tables behind the piece planes; the exponent each accumulator unit currently carries (wave-uniform; 0 with zero tiles at the start)
     float* mtab = reinterpret_cast<float*>(wg_lds + 2 * (long)NS * p.SP);
     int* etab = reinterpret_cast<int*>(mtab + 16);
     int ecur[5] = {0, 0, 0, 0, 0};
+    const bool producer = SPEC && wave >= 4;
+    // The two roles are two separate loops (the same number of barriers each): in ONE loop the staging registers of the producers and the 80 accumulator registers of the
+    // consumers were live together and the kernel spilled 164 VGPRs.  The accumulators exist on the consumers' path only.
+    if (SPEC && producer) {
+        float4 pf[WG_NPF];
+        WgDesc ds[WG_NPF];
+#pragma unroll
+        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)(threadIdx.x & 255) + u * 256, sg, cob, cib, h0);
+        wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+        __syncthreads();                 // (the zero rows)
+        wg_commit<NS, true>(pf, ds, wg_lds, p, dg0 - 2, dg0, dg1);        // the first step's operands; the second step's loads in flight
+        wg_prefetch(pf, ds, p, dg0 - 1, dg0, dg1);
+        __syncthreads();
+        for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
+            // step dx + 1: its x buffer and ring slots are not read by the consumers' step dx (one more buffer / slot than the planes in use)
+            if (dx + 1 <= dg1 + 1) {
+                wg_commit<NS, true>(pf, ds, wg_lds, p, dx + 1, dg0, dg1);
+                if (dx + 2 <= dg1 + 1) wg_prefetch(pf, ds, p, dx + 2, dg0, dg1);
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+    for (int t = 0; t < 20; ++t) acc[t] = (tz_f4){0.f, 0.f, 0.f, 0.f};
+    // the march: x planes dg0 - 2 .. dg1 + 1 (every owned g plane arrives exactly when its first partner does: g5[dx + 2], g3[dx + 1], g1[dx]); a step whose
+    // x plane lies outside the volume only stages
+    float4 pf[WG_NPF];
+    WgDesc ds[WG_NPF];
+    if constexpr (!SPEC) {
+#pragma unroll
+        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
+        wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+    } else {
+        __syncthreads();
+        __syncthreads();
+    }
     for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
+        if constexpr (SPEC) {
+            if ((unsigned)dx >= (unsigned)p.D) { __syncthreads(); continue; }
+        } else {
         __syncthreads();                 // the previous step's reads of the x buffer and of the ring slots overwritten below are done
         if constexpr (F16) wg_commit16(pf, ds, wg_lds, p, dx, dg0, dg1, mtab, etab);
         else if (!(dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
@@ -1062,6 +1098,7 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
         if (dx + 1 <= dg1 + 1 && !(dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
         if (dbg & 2) continue;
         if ((unsigned)dx >= (unsigned)p.D) continue;
+        }
         // wave-uniform data of the step (hoisted: ring-slot arithmetic per x block was a visible share of the kernel).  A wave has two "slots" of accumulators:
         //   waves 0..2: slot 0 = K5 at kd = wave, slot 1 = K3 at kd = wave;   wave 3: slot 0 = K5 at kd = 3, slot 1 = K5 at kd = 4;   wave 0 also K1 -> acc[13]
         // slot-1 tiles hold tap kw = (k + 1) % 5 in acc[.. + k] (K3: kw3 = k), so that BOTH kinds of slot-1 unit read the x operand shifted by k + 1 and no
@@ -1070,7 +1107,8 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
         const int kd0 = k3w ? wave : 3, kd1 = k3w ? wave : 4;
         const int pl0 = dx - kd0 + 2, pl1 = k3w ? dx - kd1 + 1 : dx - kd1 + 2;
         const bool ok0 = pl0 >= dg0 && pl0 < dg1, ok1 = pl1 >= dg0 && pl1 < dg1, okc = wave == 0 && dx >= dg0 && dx < dg1;
-        const int so0 = ((pl0 + 10) % 5), so1 = k3w ? 5 + (pl1 + 9) % 3 : (pl1 + 10) % 5;
+        const int so0 = wg_s5<SPEC>(p, pl0), so1 = k3w ? wg_s3<SPEC>(p, pl1) : wg_s5<SPEC>(p, pl1);
+        const int xo8 = wg_xo<SPEC>(p, dx) >> 3;                               // this step's x buffer (element offset / 8)
         if constexpr (F16) {
             // bring each accumulator slot to the exponent of this step's (g plane, x plane) pair: an exact power-of-two multiply of its tiles, once per step and only
             // when the exponent differs from the one the tiles carry (planes of one tensor mostly share it).  ecur[0] / [1] / [4]: slot 0 / slot 1 / the K1 tile
@@ -1088,7 +1126,7 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
             if (ok0) bring(0, so0, 0, 10);
             if (ok1) bring(1, so1, 10, 10);
             if (okc) {
-                const int ep = e_x + __builtin_amdgcn_readfirstlane(etab[1 + 8]);
+                const int ep = e_x + __builtin_amdgcn_readfirstlane(etab[1 + wg_s1<SPEC>(p, dx)]);
                 if (ep != ecur[4]) {
                     const int dd = ep - ecur[4];
                     acc[13] *= ldexpf(1.0f, dd > 120 ? 120 : (dd < -120 ? -120 : dd));
@@ -1102,7 +1140,7 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 // (element offsets are multiples of 8: XR, SP, brow_base -- say so, or the reads become 4-byte ds_read2_b32)
-                const int eo = ((s * (p.SP >> 3) + (brow_base >> 3) + 4 * xb * (p.XR >> 3)) << 3);
+                const int eo = ((s * (p.SP >> 3) + xo8 + (brow_base >> 3) + 4 * xb * (p.XR >> 3)) << 3);
                 const uint4* bp = reinterpret_cast<const uint4*>(wg_lds + 2 * (long)eo);
                 const uint4 lo = bp[0], hi = bp[1];
                 w[s][0] = lo.x; w[s][1] = lo.y; w[s][2] = lo.z; w[s][3] = lo.w; w[s][4] = hi.x; w[s][5] = hi.y; w[s][6] = hi.z; w[s][7] = hi.w;
@@ -1129,10 +1167,12 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
                 }
             }
             if (okc) {
-                wg_read_a<NS>(a, wg_lds, p, 8, arow_base, 4 * xb - 2, th_lane);
+                wg_read_a<NS>(a, wg_lds, p, wg_s1<SPEC>(p, dx), arow_base, 4 * xb - 2, th_lane);
                 wg_mfma6<NS, F16>(acc[13], a, sh[2]);
             }
         }
+        if constexpr (SPEC) __syncthreads();          // step dx is read, step dx + 1 is staged
+    }
     }
     if (dbg & 4) return;
     // Epilogue.  A tile holds every (g row j, x row i) pair of its two 4-row blocks; tap kh = i - j (+ 4 for the second block type) collects a diagonal, and the two
@@ -1152,9 +1192,11 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         __syncthreads();
+        if (!SPEC || wave < 4) {
 #pragma unroll
         for (int t = 0; t < 10; ++t)
             *reinterpret_cast<float4*>(tl + (((wave * 10 + t) * 16 + r16) * 16 + 4 * q)) = make_float4(acc[sl * 10 + t][0], acc[sl * 10 + t][1], acc[sl * 10 + t][2], acc[sl * 10 + t][3]);
+        }
         __syncthreads();
         // outputs of this round in ADDRESS order (a wave-instruction of atomics then covers whole runs of one (co, ci) row: scattered 4-byte atomics are several
         // times slower per element): round 0 = K5 taps kd 0..3 (100 contiguous floats per pair), round 1 = K5 kd 4 (25 per pair) and all of K3 (27 per pair)
@@ -1199,7 +1241,13 @@ __global__ void __launch_bounds__(256, 2) vx_jlc_wg_k(VxWgT p_) {
     }
 }
 
-static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int W, int NS) {
+static int g_wg_spec = -1;
+extern "C" int vx_jlc_wgrad_tz_set_spec(int on) { g_wg_spec = on ? 1 : 0; return 0; }      // A/B: producer / consumer waves (default on; VELOXSEG_WG_SPEC)
+static bool wg_spec_on() {
+    if (g_wg_spec < 0) { const char* e = getenv("VELOXSEG_WG_SPEC"); g_wg_spec = (e && e[0] == '0') ? 0 : 1; }
+    return g_wg_spec == 1;
+}
+static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int W, int NS, bool spec = false) {
     if (B <= 0 || C <= 0 || G <= 0 || C % G || D <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3) || W > 32) return -1;
     const int CG = C / G;
     if (CG != 4 && CG != 8 && CG != 16) return -1;
@@ -1215,7 +1263,9 @@ static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int
     p.XR = p.WS + 8;
     p.XP = p.nb * 4 * (p.TH + 4) * p.XR;
     p.GP = p.nb * 4 * (p.TH + 1) * p.WS;
-    p.SP = p.XP + 9 * p.GP;
+    p.XB = spec ? 2 : 1; p.R5 = spec ? 6 : 5; p.R3 = spec ? 4 : 3; p.R1 = spec ? 2 : 1;
+    p.GB = p.XB * p.XP;
+    p.SP = p.GB + (p.R5 + p.R3 + p.R1) * p.GP;
     const int MT = CG / 4;
     const long base_blocks = (long)p.nsg * G * MT * MT * p.nHt;
     static int target = 0;
@@ -1266,7 +1316,10 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
     if (wg16 < 0) { const char* e = getenv("VELOXSEG_WG_TZ_F16"); wg16 = (e && e[0] == '1') ? 1 : 0; }
     const bool f16 = tz_pieces() == 22 && (wg16 == 1 || g_wg_f16 == 1);
     const int NS = f16 ? 2 : (tz_pieces() == 22 ? 3 : tz_pieces());
-    VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
+    // producer / consumer waves: the default (three bf16 pieces) instance, when its deeper staging (two x buffers, one more slot per ring) fits
+    bool spec = !f16 && NS == 3 && (g_tz_dbg >> 4) == 0 && wg_spec_on();
+    if (spec) { VxWgT q = {}; size_t sh2; spec = wg_plan(q, sh2, B, C, G, D, H, W, NS, true) == 0; }
+    VX_REQUIRE(wg_plan(p, shm, B, C, G, D, H, W, NS, spec) == 0, "vx_jlc_wgrad_tz: unsupported shape C=%d G=%d %dx%dx%d", C, G, D, H, W);
     p.x = x; p.g1 = g1; p.g3 = g3; p.g5 = g5; p.dw1 = dw1; p.dw3 = dw3; p.dw5 = dw5; p.dbg = g_tz_dbg >> 4;
     const int MT = p.CG / 4;
     const dim3 grid((unsigned)((long)p.nsg * G * MT * MT * p.nHt * p.nDc));
@@ -1282,7 +1335,11 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
         if (p.dbg) vx_jlc_wg_k<ns, true><<<grid, dim3(256), shm, st>>>(p);                                                                                 \
         else vx_jlc_wg_k<ns, false><<<grid, dim3(256), shm, st>>>(p);                                                                                      \
     } while (0)
-    if (f16) {
+    if (spec) {
+        static bool attrs = false;
+        if (!attrs) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attrs = true; }
+        vx_jlc_wg_k<3, false, false, true><<<grid, dim3(512), shm, st>>>(p);
+    } else if (f16) {
         static bool attr16 = false;
         if (!attr16) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attr16 = true; }
         vx_jlc_wg_k<2, false, true><<<grid, dim3(256), shm, st>>>(p);
