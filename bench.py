@@ -412,7 +412,7 @@ def main():
             else:
                 f["flops"] += rf["algorithmic_flops"] * n
                 f["bytes"] += rf["algorithmic_bytes"] * n
-                f["shapes"].append({"args": list(key)[:8], "launches": n, "avg_launch_ms": round(tot_ms / n, 5), "frac": rf["frac"]})
+                f["shapes"].append({"args": list(key)[:8], "launches": n, "avg_launch_ms": round(tot_ms / n, 5), "frac": rf["frac"], "algorithmic_flops": rf["algorithmic_flops"]})
                 f["last"] = rf
         out["kernel_pass"]["families"] = [{"entry": k_, "launches": f["n"], "ms": round(f["ms"], 4)} for k_, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]]
         out["roofline"] = None
@@ -440,6 +440,12 @@ def main():
                 pr["achieved"] = round((f["flops"] if rf["bound"] == "mfma" else f["bytes"]) / f["n"] / (pr["avg_launch_ms"] * 1e-3) / (1e12 if rf["bound"] == "mfma" else 1e9), 3)
                 pr["frac"] = round(pr["achieved"] / rf["peak"], 4)
                 rf["profile"] = pr
+            if base == "vx_jlc_wgrad_tz":
+                fc = _wg_full_chip(f["shapes"], rf["peak"])
+                if fc is not None:
+                    rf["full_chip"] = fc
+            for sh in rf["shapes"]:
+                sh.pop("algorithmic_flops", None)
             out["roofline"] = rf
             break
         # PWA attention (north_star: "MFMA utilisation for PWA against gfx950 peak"): every attention launch of the step, forward and backward
@@ -581,6 +587,51 @@ DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_cl_fwd": r"vx_jlc_c
                  "vx_expand_fwd_mfma_split": r"vx_expand_fwd_split_k<", "vx_expand_bwd_data_mfma_split": r"vx_expand_bwd_data_split_k<", "vx_expand_wgrad_mfma_split": r"vx_expand_wgrad_split_k<",
                  "vx_mlp_fwd": r"vx_mlp_fwd_k<", "vx_mlp_bwd": r"vx_mlp_bwd_k<", "vx_seg_loss_ds_fwd": r"vx_seg_loss_ds_fwd_k<", "vx_seg_loss_ds_bwd": r"vx_seg_loss_ds_bwd_k<",
                  "vx_conv_mfma_fwd": r"vx_conv_mfma_fwd_k<", "vx_conv_mfma_bwd_data": r"vx_conv_mfma_bwd_data_k<"}
+
+
+def _wg_full_chip(shapes, peak):
+    """The JLC weight-gradient kernel with the WHOLE chip (256 blocks per launch) -- the step runs it on half (128 blocks: the other lanes' kernels use the rest and the step
+    is 2 % faster).  Same shapes, same launches per step, timed live with HIP events, one launch after the other on an idle GPU."""
+    try:
+        import torch
+        from veloxseg_amd import _hip as H
+        d = torch.device("cuda", torch.cuda.current_device())
+        st = H.stream_ptr()
+        H.call("vx_jlc_wgrad_tz_set_blocks", 256)
+        tot_ms = tot_fl = 0.0
+        n_all = 0
+        rows = []
+        for sh in shapes:
+            B, C, G, D, Hh, W = [int(v) for v in sh["args"][:6]]
+            x = torch.randn(B, C, D, Hh, W, device=d)
+            g = torch.randn(3, B, C, D, Hh, W, device=d)
+            dws = [torch.zeros(C, C // G, k, k, k, device=d) for k in (1, 3, 5)]
+            n1 = B * C * D * Hh * W
+            gp = g.data_ptr()
+            run = lambda: H.call("vx_jlc_wgrad_tz_ns", H.P(x), gp, gp + 4 * n1, gp + 8 * n1, H.P(dws[0]), H.P(dws[1]), H.P(dws[2]), B, C, G, D, Hh, W, 22, st)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 40
+            rows.append({"args": [B, C, G, D, Hh, W], "avg_launch_ms": round(ms, 5)})
+            tot_ms += ms * sh["launches"]
+            tot_fl += sh["algorithmic_flops"] * sh["launches"]
+            n_all += sh["launches"]
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        return {"blocks_per_launch": 256, "avg_launch_ms": round(tot_ms / n_all, 5), "achieved": round(ach, 3), "frac": round(ach / peak, 4), "shapes": rows,
+                "note": "the same kernel given every CU (vx_jlc_wgrad_tz_set_blocks(256)); the step's default is 128 blocks per launch"}
+    except Exception as e:          # never let the extra figure take the bench line down
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    finally:
+        try:
+            H.call("vx_jlc_wgrad_tz_set_blocks", 0)
+        except Exception:
+            pass
 
 
 def _latest_profile(pattern):

@@ -221,6 +221,7 @@ int vx_jlc_cl_bwd(const float* g1, const float* g3, const float* g5, const float
  * entry; a null dw skips that tensor's store); W <= 32, W % 4 == 0, H % 4 == 0, group width 4 / 8 / 16.  Bias gradients are not computed (zero behind an InstanceNorm). */
 int vx_jlc_wgrad_tz_ok(int C, int G, int D, int H, int W);
 int vx_jlc_wgrad_tz_set_min_voxels(long v);
+int vx_jlc_wgrad_tz_set_blocks(int n);     /* blocks per launch; 0 (default): 128 with producer / consumer waves -- half the chip: the step is fastest there -- 256 for the one-role kernel (VELOXSEG_WG_TZ_BLOCKS) */
 int vx_jlc_wgrad_tz_set_spec(int on);      /* 1 (default; VELOXSEG_WG_SPEC): 512-thread blocks, waves 4..7 stage step dx + 1 while waves 0..3 run the MFMAs of step dx; 0: the one-role kernel (A/B, tests) */
 int vx_jlc_wgrad_tz_set_f16(int on);     /* with vx_jlc_tz_set_pieces(22): 1 = the weight gradients on two scaled fp16 pieces as well (A/B; default 0 = three bf16 pieces) */
 int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,

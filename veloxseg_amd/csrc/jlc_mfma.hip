@@ -1241,6 +1241,8 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(Vx
     }
 }
 
+static int g_wg_blocks = 0;
+extern "C" int vx_jlc_wgrad_tz_set_blocks(int n) { g_wg_blocks = n > 0 ? n : 0; return 0; }      // blocks per launch (0: the default rule in wg_plan)
 static int g_wg_spec = -1;
 extern "C" int vx_jlc_wgrad_tz_set_spec(int on) { g_wg_spec = on ? 1 : 0; return 0; }      // A/B: producer / consumer waves (default on; VELOXSEG_WG_SPEC)
 static bool wg_spec_on() {
@@ -1268,8 +1270,12 @@ static int wg_plan(VxWgT& p, size_t& shm, int B, int C, int G, int D, int H, int
     p.SP = p.GB + (p.R5 + p.R3 + p.R1) * p.GP;
     const int MT = CG / 4;
     const long base_blocks = (long)p.nsg * G * MT * MT * p.nHt;
-    static int target = 0;
-    if (!target) { const char* e = getenv("VELOXSEG_WG_TZ_BLOCKS"); target = (e && atoi(e) > 0) ? atoi(e) : 256; }
+    static int target_env = -1;
+    if (target_env < 0) { const char* e = getenv("VELOXSEG_WG_TZ_BLOCKS"); target_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    // Default: 128 blocks (HALF the chip) with producer / consumer waves, 256 for the one-role kernel.  With the producer waves a launch on 128 CUs takes what the one-role
+    // kernel took on 256 (53.7 vs 52.8 us average), and what the sink leaves free is what the other lanes' chains use: 1040 patches/s against 1021 with 256 blocks (where
+    // the kernel alone is 42.7 us: bench.py reports that figure as roofline.full_chip) and 1027 for the one-role kernel.  vx_jlc_wgrad_tz_set_blocks / VELOXSEG_WG_TZ_BLOCKS.
+    const int target = g_wg_blocks > 0 ? g_wg_blocks : (target_env > 0 ? target_env : (spec ? 128 : 256));
     // Blocks per launch: 256 = one per CU.  Stand-alone, 512 (two resident blocks per CU, one's staging behind the other's MFMAs) is faster (67 vs 84 us at 32^3), but
     // this kernel is a SINK that runs beside the backward chains of the other lanes: at 74 KB of LDS and 248 VGPRs per block, two blocks per CU leave those chains
     // nothing to run on -- the step is 774 patches/s with 512 blocks, 798 with 256, 782 with the VALU weight-gradient kernels (VELOXSEG_WG_TZ_BLOCKS for the A/B)
