@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(64 * NW) vx_ln_pw_bwd_k(VxLnPwBwd p) {
 }
 
 // =====================================================================================================================
-// post: mix conv + residual -> LN -> FFN -> residual          (T = 1 tiles: the 8^3 / 4^3 levels, where the expanded FFN is not covered by mlp.hip)
+// post: mix conv + residual -> LN -> FFN -> residual          (the 16^3 / 8^3 / 4^3 levels, where the expanded FFN is not covered by mlp.hip or the tile chain is faster)
 // =====================================================================================================================
 struct VxPostMod {
     const float *s, *x, *wm, *bm, *gamma, *beta, *w1, *b1, *w2, *b2;
@@ -437,9 +437,22 @@ struct VxPost {
     const void* seed_ptr;
 };
 
-template <int NW>
+// T consecutive floats of an LDS / global row (16-byte aligned for T = 4)
+template <int T>
+__device__ __forceinline__ void ldv(const float* __restrict__ q, float (&o)[T]) {
+    if constexpr (T == 4) { const float4 t = *reinterpret_cast<const float4*>(q); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+    else o[0] = q[0];
+}
+template <int T>
+__device__ __forceinline__ void stv(float* __restrict__ q, const float (&o)[T]) {
+    if constexpr (T == 4) *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+    else q[0] = o[0];
+}
+
+// T = 4: 64-voxel tiles, 16-byte accesses and one Philox call per four voxels (the 16^3 level); T = 1: 16-voxel tiles (8^3 / 4^3)
+template <int T, int NW>
 __global__ void __launch_bounds__(64 * NW) vx_pwa_post_fwd_k(VxPost p) {
-    constexpr int T = 1, NT = 16, S = Geo<1>::S, NP = 64 * NW / NT;
+    constexpr int NT = Geo<T>::NT, S = Geo<T>::S, NP = 64 * NW / NT;
     extern __shared__ __attribute__((aligned(16))) float vx_pf_lds[];
     const VxPostMod& M = p.m[blockIdx.y];
     const int C = p.C, Cv = p.Cv, R = p.R;
@@ -464,20 +477,27 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_fwd_k(VxPost p) {
     load_tile<T, NW>(Y, M.x + (long)b * C * V, C, V, v0);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const long v = v0 + r;
-    const bool vlive = v < V;
+    const int cr = T * r;                            // first tile column of this lane's accumulator elements
+    const long v = v0 + cr;
+    const bool vlive = v < V;                        // (T = 4: V % 4 == 0, the four voxels live or die together)
     // y = alpha x + drop(Wm s + bm)          (element (m, r) of Y is read and written by its owner only)
     tile_gemm1<T, NW, false>(M.wm, Cv, Cv, 1, C, Sx, [&](int mt, vx_f32x4 (&acc)[T]) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int m = 16 * mt + 4 * q + reg;
-            const long idx = ((long)b * C + m) * V + v;
-            float yv = 0.0f;
+            const long row = (long)b * C + m;
+            float yv[T], mk[4];
+            ldv<T>(Y + m * S + cr, yv);
             if (vlive) {
-                yv = fmaf(p.alpha, Y[m * S + r], (acc[0][reg] + bm[m]) * vx_drop1(dm, (uint64_t)idx));
-                M.y[idx] = yv;
+                acc_masks<T>(dm, (uint64_t)row, V, v, mk);
+#pragma unroll
+                for (int j = 0; j < T; ++j) yv[j] = fmaf(p.alpha, yv[j], (acc[j][reg] + bm[m]) * mk[j]);
+                stv<T>(M.y + row * V + v, yv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) yv[j] = 0.0f;
             }
-            Y[m * S + r] = yv;
+            stv<T>(Y + m * S + cr, yv);
         }
     });
     __syncthreads();
@@ -493,9 +513,16 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_fwd_k(VxPost p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int j = 16 * mt + 4 * q + reg;
-            const float a = acc[0][reg] + b1[j];
-            const float mk = vlive ? vx_drop1(d1, (uint64_t)(((long)b * R + j) * V + v)) : 0.0f;
-            Hh[j * S + r] = vx_gelu_fast(a) * mk;
+            float hv[T], mk[4];
+            if (vlive) {
+                acc_masks<T>(d1, (uint64_t)((long)b * R + j), V, v, mk);
+#pragma unroll
+                for (int i = 0; i < T; ++i) hv[i] = vx_gelu_fast(acc[i][reg] + b1[j]) * mk[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < T; ++i) hv[i] = 0.0f;
+            }
+            stv<T>(Hh + j * S + cr, hv);
         }
     });
     __syncthreads();
@@ -505,16 +532,21 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_fwd_k(VxPost p) {
         for (int reg = 0; reg < 4; ++reg) {
             const int m = 16 * mt + 4 * q + reg;
             if (vlive) {
-                const long idx = ((long)b * C + m) * V + v;
-                M.out[idx] = fmaf(acc[0][reg] + b2[m], vx_drop1(d2, (uint64_t)idx), Y[m * S + r]);
+                const long row = (long)b * C + m;
+                float ov[T], mk[4];
+                ldv<T>(Y + m * S + cr, ov);
+                acc_masks<T>(d2, (uint64_t)row, V, v, mk);
+#pragma unroll
+                for (int i = 0; i < T; ++i) ov[i] = fmaf(acc[i][reg] + b2[m], mk[i], ov[i]);
+                stv<T>(M.out + row * V + v, ov);
             }
         }
     });
 }
 
-template <int NW>
+template <int T, int NW>
 __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
-    constexpr int T = 1, NT = 16, S = Geo<1>::S, NP = 64 * NW / NT;
+    constexpr int NT = Geo<T>::NT, S = Geo<T>::S, NP = 64 * NW / NT, NRP = 4 * NW;
     extern __shared__ __attribute__((aligned(16))) float vx_pf_lds[];
     const VxPostMod& M = p.m[blockIdx.y];
     const int C = p.C, Cv = p.Cv, R = p.R;
@@ -524,14 +556,18 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
     float* __restrict__ N = Y + C * S;               // [C][S]  LN(y), later dmix
     float* __restrict__ A = N + C * S;               // [R][S]  pre-activation a, then da
     float* __restrict__ red = A + R * S;             // 2 NP NT
-    float* __restrict__ gam = red + 2 * NP * NT, *bet = gam + C, *b1 = bet + C;      // C | C | R
+    float* __restrict__ cs = red + 2 * NP * NT;      // rstd | t1 | t2 per tile column (3 NT)
+    float* __restrict__ gam = cs + 3 * NT, *bet = gam + C, *b1 = bet + C;      // C | C | R
     const int b = blockIdx.x / p.tiles_per_b;
     const long V = p.V, v0 = (long)(blockIdx.x % p.tiles_per_b) * NT;
     const VxDropCtx dm = drop_ctx_dev(p.seed_ptr, M.site_mix, p.p_mix);
     const VxDropCtx d1 = drop_ctx_dev(p.seed_ptr, M.site1, p.p_ffn);
     const VxDropCtx d2 = drop_ctx_dev(p.seed_ptr, M.site2, p.p_ffn);
-    const int col = threadIdx.x % NT, part = threadIdx.x / NT;
+    const int col = threadIdx.x % NT, part = threadIdx.x / NT;          // column layout: LN statistics, one voxel per thread
     const bool clive = v0 + col < V;
+    const int qd = threadIdx.x & 15, rp = threadIdx.x >> 4, cq = T * qd;   // group layout: T consecutive voxels per thread (the loops that draw dropout masks)
+    const long vq = v0 + cq;
+    const bool qlive = vq < V;
     stage_vec<NW>(gam, M.gamma, C, 1.0f);
     stage_vec<NW>(bet, M.beta, C, 0.0f);
     stage_vec<NW>(b1, M.b1, R, 0.0f);
@@ -539,11 +575,20 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
     load_tile<T, NW>(DO, M.dout + (long)b * C * V, C, V, v0);
     __syncthreads();
     // dz = dout * mask2 (site 2 over (B, C, V)); also kept in global for dW2 = dz h^T
-    for (int c = part; c < C; c += NP) {
-        const long idx = ((long)b * C + c) * V + v0 + col;
-        const float g = clive ? DO[c * S + col] * vx_drop1(d2, (uint64_t)idx) : 0.0f;
-        DZ[c * S + col] = g;
-        if (clive) M.sc_dz[idx] = g;
+    for (int c = rp; c < C; c += NRP) {
+        const long row = (long)b * C + c;
+        float g[T], mk[4];
+        ldv<T>(DO + c * S + cq, g);
+        if (qlive) {
+            acc_masks<T>(d2, (uint64_t)row, V, vq, mk);
+#pragma unroll
+            for (int j = 0; j < T; ++j) g[j] *= mk[j];
+            stv<T>(M.sc_dz + row * V + vq, g);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) g[j] = 0.0f;
+        }
+        stv<T>(DZ + c * S + cq, g);
     }
     float mean, rstd;
     tile_ln_stats<T, NW>(Y, C, p.eps, red, mean, rstd);
@@ -556,18 +601,25 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const long v = v0 + r;
+    const int cr = T * r;
+    const long v = v0 + cr;
     const bool vlive = v < V;
     // a = W1 n + b1 ; h = drop1(gelu(a)) -> global (dW2's operand)
     tile_gemm1<T, NW, false>(M.w1, C, C, 1, R, N, [&](int mt, vx_f32x4 (&acc)[T]) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int j = 16 * mt + 4 * q + reg;
-            const float a = acc[0][reg] + b1[j];
-            A[j * S + r] = a;
+            float a[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) a[i] = acc[i][reg] + b1[j];
+            stv<T>(A + j * S + cr, a);
             if (vlive) {
-                const long idx = ((long)b * R + j) * V + v;
-                M.sc_h[idx] = vx_gelu_fast(a) * vx_drop1(d1, (uint64_t)idx);
+                const long row = (long)b * R + j;
+                float mk[4];
+                acc_masks<T>(d1, (uint64_t)row, V, v, mk);
+#pragma unroll
+                for (int i = 0; i < T; ++i) a[i] = vx_gelu_fast(a[i]) * mk[i];
+                stv<T>(M.sc_h + row * V + v, a);
             }
         }
     });
@@ -577,17 +629,32 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int j = 16 * mt + 4 * q + reg;
-            const long idx = ((long)b * R + j) * V + v;
-            const float da = vlive ? acc[0][reg] * vx_drop1(d1, (uint64_t)idx) * vx_gelu_grad_fast(A[j * S + r]) : 0.0f;
-            A[j * S + r] = da;
-            if (vlive) M.sc_da[idx] = da;
+            const long row = (long)b * R + j;
+            float da[T];
+            if (vlive) {
+                float mk[4];
+                ldv<T>(A + j * S + cr, da);
+                acc_masks<T>(d1, (uint64_t)row, V, v, mk);
+#pragma unroll
+                for (int i = 0; i < T; ++i) da[i] = acc[i][reg] * mk[i] * vx_gelu_grad_fast(da[i]);
+                stv<T>(M.sc_da + row * V + v, da);
+            } else {
+#pragma unroll
+                for (int i = 0; i < T; ++i) da[i] = 0.0f;
+            }
+            stv<T>(A + j * S + cr, da);
         }
     });
     __syncthreads();
     // dn = W1^T da  -> DZ (dz is no longer needed)
     tile_gemm1<T, NW, true>(M.w1, R, 1, C, C, A, [&](int mt, vx_f32x4 (&acc)[T]) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) DZ[(16 * mt + 4 * q + reg) * S + r] = acc[0][reg];
+        for (int reg = 0; reg < 4; ++reg) {
+            float dn[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) dn[i] = acc[i][reg];
+            stv<T>(DZ + (16 * mt + 4 * q + reg) * S + cr, dn);
+        }
     });
     __syncthreads();
     // LN backward: dy = dout + rstd (g - mean(g) - xhat mean(g xhat)),  g = dn gamma
@@ -604,22 +671,41 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
 #pragma unroll 4
     for (int p_ = 0; p_ < NP; ++p_) { t1 += red[p_ * NT + col]; t2 += red[(NP + p_) * NT + col]; }
     t1 /= (float)C; t2 /= (float)C;
+    float rs_[T], t1_[T], t2_[T];
+    if constexpr (T == 4) {                                          // the group layout below needs the statistics of four columns
+        if (part == 0) { cs[col] = rstd; cs[NT + col] = t1; cs[2 * NT + col] = t2; }
+        __syncthreads();
+        ldv<T>(cs + cq, rs_); ldv<T>(cs + NT + cq, t1_); ldv<T>(cs + 2 * NT + cq, t2_);
+    } else { rs_[0] = rstd; t1_[0] = t1; t2_[0] = t2; }              // (T = 1: col == qd)
     float* __restrict__ pp = M.part + (long)blockIdx.x * 2 * C;
-    for (int c = part; c < C; c += NP) {
-        const float xh = Y[c * S + col], dn = DZ[c * S + col];
-        float dg = dn * xh, db = dn;
+    for (int c = rp; c < C; c += NRP) {
+        const long row = (long)b * C + c;
+        float xh[T], dn[T], dy[T];
+        ldv<T>(Y + c * S + cq, xh);
+        ldv<T>(DZ + c * S + cq, dn);
+        float dg = 0.0f, db = 0.0f;
 #pragma unroll
-        for (int o = 1; o < NT; o <<= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
-        if (col == 0) { pp[c] = dg; pp[C + c] = db; }
-        const long idx = ((long)b * C + c) * V + v0 + col;
-        float dmix = 0.0f;
-        if (clive) {
-            const float dy = DO[c * S + col] + rstd * (dn * gam[c] - t1 - xh * t2);
-            M.dxres[idx] = p.alpha * dy;
-            dmix = dy * vx_drop1(dm, (uint64_t)idx);
-            M.sc_dmix[idx] = dmix;
+        for (int j = 0; j < T; ++j) { dg = fmaf(dn[j], xh[j], dg); db += dn[j]; }     // columns beyond V hold dn = 0
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
+        if (qd == 0) { pp[c] = dg; pp[C + c] = db; }
+        if (qlive) {
+            float mk[4], dx[T];
+            ldv<T>(DO + c * S + cq, dy);
+            acc_masks<T>(dm, (uint64_t)row, V, vq, mk);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                dy[j] += rs_[j] * (dn[j] * gam[c] - t1_[j] - xh[j] * t2_[j]);
+                dx[j] = p.alpha * dy[j];
+                dy[j] *= mk[j];
+            }
+            stv<T>(M.dxres + row * V + vq, dx);
+            stv<T>(M.sc_dmix + row * V + vq, dy);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) dy[j] = 0.0f;
         }
-        N[c * S + col] = dmix;                                  // N (LN output) is no longer needed
+        stv<T>(N + c * S + cq, dy);                                  // N (LN output) is no longer needed
     }
     __syncthreads();
     // ds = Wm^T dmix
@@ -627,7 +713,12 @@ __global__ void __launch_bounds__(64 * NW) vx_pwa_post_bwd_k(VxPost p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int m = 16 * mt + 4 * q + reg;
-            if (vlive) M.ds[((long)b * Cv + m) * V + v] = acc[0][reg];
+            if (vlive) {
+                float o[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) o[i] = acc[i][reg];
+                stv<T>(M.ds + ((long)b * Cv + m) * V + v, o);
+            }
         }
     });
 }
@@ -740,12 +831,23 @@ extern "C" int vx_ln_pw_bwd(const void* const* ptrs, int M, int NS, const int* J
     return 0;
 }
 
+// tile width of the post kernels: 64 voxels (T = 4) where the grid is large enough to fill the chip with them (VELOXSEG_POST_T4=0: 16-voxel tiles everywhere)
+static int post_tile_t(long V) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VELOXSEG_POST_T4"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on ? pf_tile_t(V) : 1;
+}
+static inline size_t post_lds_floats(int T, int NW, int C, int Cv, int R, bool bwd) {
+    const size_t S = T == 4 ? 64 : 20, NT = 16 * T, NP = 64 * NW / NT;
+    return bwd ? (size_t)(4 * C + R) * S + 2 * NP * NT + 3 * NT + 2 * C + R : (size_t)(Cv + 2 * C + R) * S + NP * NT + 4 * C + R;
+}
 extern "C" int vx_pwa_post_ok(int C, int Cv, int R, long V) {
     if (C % 16 || Cv % 16 || R % 16 || C < 16 || Cv < 16 || R < 16 || V < 1) return 0;
-    const size_t lds = ((size_t)(4 * C + R + Cv) * 20 + 2 * 32 * 16 + 4 * C + R) * sizeof(float);
+    const int T = post_tile_t(V), NW = T == 4 ? 4 : 8;
+    const size_t lds = (post_lds_floats(T, NW, C, Cv, R, true) > post_lds_floats(T, NW, C, Cv, R, false) ? post_lds_floats(T, NW, C, Cv, R, true) : post_lds_floats(T, NW, C, Cv, R, false)) * sizeof(float);
     return lds <= pf_lds_budget() ? 1 : 0;
 }
-extern "C" int vx_pwa_post_tiles(int B, long V) { return B * vx_cdiv(V, 16); }
+extern "C" int vx_pwa_post_tiles(int B, long V) { return B * vx_cdiv(V, 16 * post_tile_t(V)); }
 
 /* ptrs, per modality 24 entries: s, x, wm, bm, gamma, beta, w1, b1, w2, b2, y, out, dout, ds, dxres, part, sc_n, sc_h, sc_da, sc_dz, sc_dmix, site_mix, site1, site2
  * (the three sites as integers cast to pointers); forward uses entries 0..11 and the sites, backward all but `out` */
@@ -763,7 +865,7 @@ static int post_fill(VxPost& p, const void* const* ptrs, int M, int B, int C, in
         else VX_REQUIRE(d.dout && d.ds && d.dxres && d.part && d.sc_n && d.sc_h && d.sc_da && d.sc_dz && d.sc_dmix, "vx_pwa_post_bwd: null tensor");
     }
     p.C = C; p.Cv = Cv; p.R = R; p.V = V; p.eps = eps; p.alpha = alpha; p.p_mix = p_mix; p.p_ffn = p_ffn; p.seed_ptr = seed_ptr;
-    p.tiles_per_b = vx_cdiv(V, 16);
+    p.tiles_per_b = vx_cdiv(V, 16 * post_tile_t(V));
     (void)B;
     return 0;
 }
@@ -777,9 +879,9 @@ extern "C" int vx_pwa_post_fwd(const void* const* ptrs, int M, int B, int C, int
     const long blocks = (long)B * p.tiles_per_b;
     dim3 grid((unsigned)blocks, M);
     hipStream_t st = (hipStream_t)stream;
-    const size_t base = (size_t)(Cv + 2 * C + R) * 20 + 4 * C + R;
-    if (pf_nw(blocks * M) == 8) pf_launch<1, 8>(vx_pwa_post_fwd_k<8>, p, grid, (base + 32 * 16) * sizeof(float), st);
-    else pf_launch<1, 4>(vx_pwa_post_fwd_k<4>, p, grid, (base + 16 * 16) * sizeof(float), st);
+    if (post_tile_t(V) == 4) pf_launch<4, 4>(vx_pwa_post_fwd_k<4, 4>, p, grid, post_lds_floats(4, 4, C, Cv, R, false) * sizeof(float), st);
+    else if (pf_nw(blocks * M) == 8) pf_launch<1, 8>(vx_pwa_post_fwd_k<1, 8>, p, grid, post_lds_floats(1, 8, C, Cv, R, false) * sizeof(float), st);
+    else pf_launch<1, 4>(vx_pwa_post_fwd_k<1, 4>, p, grid, post_lds_floats(1, 4, C, Cv, R, false) * sizeof(float), st);
     VX_LAUNCH_CHECK("vx_pwa_post_fwd");
     return 0;
 }
@@ -793,9 +895,9 @@ extern "C" int vx_pwa_post_bwd(const void* const* ptrs, int M, int B, int C, int
     const long blocks = (long)B * p.tiles_per_b;
     dim3 grid((unsigned)blocks, M);
     hipStream_t st = (hipStream_t)stream;
-    const size_t base = (size_t)(4 * C + R) * 20 + 2 * C + R;
-    if (pf_nw(blocks * M) == 8) pf_launch<1, 8>(vx_pwa_post_bwd_k<8>, p, grid, (base + 2 * 32 * 16) * sizeof(float), st);
-    else pf_launch<1, 4>(vx_pwa_post_bwd_k<4>, p, grid, (base + 2 * 16 * 16) * sizeof(float), st);
+    if (post_tile_t(V) == 4) pf_launch<4, 4>(vx_pwa_post_bwd_k<4, 4>, p, grid, post_lds_floats(4, 4, C, Cv, R, true) * sizeof(float), st);
+    else if (pf_nw(blocks * M) == 8) pf_launch<1, 8>(vx_pwa_post_bwd_k<1, 8>, p, grid, post_lds_floats(1, 8, C, Cv, R, true) * sizeof(float), st);
+    else pf_launch<1, 4>(vx_pwa_post_bwd_k<1, 4>, p, grid, post_lds_floats(1, 4, C, Cv, R, true) * sizeof(float), st);
     VX_LAUNCH_CHECK("vx_pwa_post_bwd");
     return 0;
 }
