@@ -9,6 +9,25 @@
 #include "vx_common.h"
 #include "../../include/veloxseg_hip.h"
 
+// Index arithmetic of the gather / scatter kernels.  Their divisors are run-time plan constants (grid, cell and window extents), and the compiler's 32-bit integer
+// division is ~30 instructions with four quarter-rate multiplies: with 10-15 of them per thread these memory movers were bound by their index math (920 instructions
+// to move four floats in vx_pwa_gather_all_bwd_v_k).  For 0 <= a < 2^22 the quotient is floor(float(a) * rb) or one less when rb is the reciprocal rounded DOWN by
+// 2^-22 (never above a / b: the two roundings are 2^-24 each, the reciprocal's 2^-23), so one conditional step finishes it: ~9 full-rate instructions.
+struct VxFd { int b; float rb; };
+__device__ __forceinline__ VxFd vx_fd(int b) { VxFd d; d.b = b; d.rb = __builtin_amdgcn_rcpf((float)b) * 0.99999976f; return d; }
+__device__ __forceinline__ int vx_fdivmod(int a, const VxFd& d, int& r) {          // 0 <= a < 2^22
+    int q = (int)((float)a * d.rb);
+    r = a - __mul24(q, d.b);
+    if (r >= d.b) { ++q; r -= d.b; }
+    return q;
+}
+__device__ __forceinline__ int vx_fdiv(int a, const VxFd& d) { int r; return vx_fdivmod(a, d, r); }
+// voxel / cell index of a volume -> (x0, x1, x2) for extents (., e1, e2); `small` = the volume has fewer than 2^22 elements (block-uniform)
+__device__ __forceinline__ void vx_unflatten(long v, int e1, int e2, bool small, int& x0, int& x1, int& x2) {
+    if (small) x0 = vx_fdivmod(vx_fdivmod((int)v, vx_fd(e2), x2), vx_fd(e1), x1);
+    else { x2 = (int)(v % e2); x1 = (int)((v / e2) % e1); x0 = (int)(v / ((long)e2 * e1)); }
+}
+
 __device__ __forceinline__ int vx_scale_of_window(const VxPwaPlan& P, int N) {
     int i = 0;
 #pragma unroll
@@ -177,11 +196,11 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_v_k(VxGatherPtrs pt
                                                                  VxPwaPlan P, int cq, int cv, int M) {
     // blockIdx.y enumerates (m, kind, branch i, head a, channel chunk) with the chunk count of the widest kind; narrower kinds leave early
     const int nchq = cq / CH, nchv = cv / CH, nchm = nchq > nchv ? nchq : nchv;
-    int y = blockIdx.y;
-    const int chunk = y % nchm; y /= nchm;
-    const int a = y % P.heads; y /= P.heads;
-    const int i = y % P.nb; y /= P.nb;
-    const int kind = y % 3, m = y / 3;
+    int y = blockIdx.y, chunk, a, i, kind;
+    y = vx_fdivmod(y, vx_fd(nchm), chunk);
+    y = vx_fdivmod(y, vx_fd(P.heads), a);
+    y = vx_fdivmod(y, vx_fd(P.nb), i);
+    const int m = vx_fdivmod(y, vx_fd(3), kind);
     const int c = kind == 2 ? cv : cq;
     if (chunk * CH >= c) return;
     const int b = blockIdx.z;
@@ -190,27 +209,31 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_v_k(VxGatherPtrs pt
     int* __restrict__ tix = kind == 0 ? iq : (kind == 1 ? ik : iv);
     const int s0 = P.small[i][0], s1 = P.small[i][1], s2 = P.small[i][2];
     const int csz = s0 * s1 * s2;
-    int T = 1;
-    while (T < 64 && T < csz) T <<= 1;
-    const int p0n = P.grid[0] / s0, p1n = P.grid[1] / s1, p2n = P.grid[2] / s2;
+    int T = 1, lt = 0;
+    while (T < 64 && T < csz) { T <<= 1; ++lt; }
+    const int p0n = vx_fdiv(P.grid[0], vx_fd(s0)), p1n = vx_fdiv(P.grid[1], vx_fd(s1)), p2n = vx_fdiv(P.grid[2], vx_fd(s2));
     const int ncell = p0n * p1n * p2n;
-    const int cells_per_block = 256 / T;
+    const int cells_per_block = 256 >> lt;
     if ((long)blockIdx.x * cells_per_block >= ncell) return;
-    const int sub = threadIdx.x % T;
-    const int cell = blockIdx.x * cells_per_block + threadIdx.x / T;
+    const int sub = threadIdx.x & (T - 1);
+    const int cell = blockIdx.x * cells_per_block + (threadIdx.x >> lt);
     const bool cok = cell < ncell;
     const int cl = cok ? cell : 0;
-    const int p2 = cl % p2n, p1 = (cl / p2n) % p1n, p0 = cl / (p2n * p1n);
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
+    int p2, p1, p0;
+    vx_unflatten(cl, p1n, p2n, V < (1 << 22), p0, p1, p2);
     const int ch0 = (i * P.heads + a) * c + chunk * CH;
     const float* __restrict__ sc = src + ((long)b * (P.nb * P.heads * c) + ch0) * V;
     float best[CH];
     int bidx[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) { best[k] = -INFINITY; bidx[k] = 0x7fffffff; }
+    const VxFd f2 = vx_fd(s2), f1 = vx_fd(s1);
+    const int base = (p0 * s0 * P.grid[1] + p1 * s1) * P.grid[2] + p2 * s2;
     for (int e = sub; e < csz; e += T) {
-        const int w = e % s2, h = (e / s2) % s1, d = e / (s2 * s1);
-        const int idx = ((p0 * s0 + d) * P.grid[1] + (p1 * s1 + h)) * P.grid[2] + (p2 * s2 + w);
+        int w, h;
+        const int d = vx_fdivmod(vx_fdivmod(e, f2, w), f1, h);
+        const int idx = base + (d * P.grid[1] + h) * P.grid[2] + w;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const float val = sc[(long)k * V + idx];
@@ -226,7 +249,8 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_fwd_v_k(VxGatherPtrs pt
         }
     }
     if (cok && sub == 0) {
-        const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+        int t0, t1, t2;
+        const int W0 = vx_fdivmod(p0, vx_fd(P.n[0]), t0), W1 = vx_fdivmod(p1, vx_fd(P.n[1]), t1), W2 = vx_fdivmod(p2, vx_fd(P.n[2]), t2);
         const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
         const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
         const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + chunk * CH;
@@ -245,11 +269,11 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
                                                                  const int* __restrict__ iq, const int* __restrict__ ik, const int* __restrict__ iv,
                                                                  VxPwaPlan P, int cq, int cv, int M) {
     const int nchq = cq / CH, nchv = cv / CH, nchm = nchq > nchv ? nchq : nchv;
-    int y = blockIdx.y;
-    const int chunk = y % nchm; y /= nchm;
-    const int a = y % P.heads; y /= P.heads;
-    const int i = y % P.nb; y /= P.nb;
-    const int kind = y % 3, m = y / 3;
+    int y = blockIdx.y, chunk, a, i, kind;
+    y = vx_fdivmod(y, vx_fd(nchm), chunk);
+    y = vx_fdivmod(y, vx_fd(P.heads), a);
+    y = vx_fdivmod(y, vx_fd(P.nb), i);
+    const int m = vx_fdivmod(y, vx_fd(3), kind);
     const int c = kind == 2 ? cv : cq;
     if (chunk * CH >= c) return;
     const int b = blockIdx.z;
@@ -259,9 +283,13 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
-    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
-    const int p0 = x0 / P.small[i][0], p1 = x1 / P.small[i][1], p2 = x2 / P.small[i][2];
-    const int W0 = p0 / P.n[0], t0 = p0 % P.n[0], W1 = p1 / P.n[1], t1 = p1 % P.n[1], W2 = p2 / P.n[2], t2 = p2 % P.n[2];
+    int x2, x1, x0;
+    vx_unflatten(v, P.grid[1], P.grid[2], V < (1 << 22), x0, x1, x2);
+    // cell -> (window, token) per axis: x / small = p,  p / n = W,  p % n = t
+    int t0, t1, t2;
+    const int W0 = vx_fdivmod(vx_fdiv(x0, vx_fd(P.small[i][0])), vx_fd(P.n[0]), t0);
+    const int W1 = vx_fdivmod(vx_fdiv(x1, vx_fd(P.small[i][1])), vx_fd(P.n[1]), t1);
+    const int W2 = vx_fdivmod(vx_fdiv(x2, vx_fd(P.small[i][2])), vx_fd(P.n[2]), t2);
     const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
     const int t = (t0 * P.n[1] + t1) * P.n[2] + t2;
     const long ti = ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l + t) * c + chunk * CH;
@@ -322,7 +350,8 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_k(const float* __restr
 
 // the same with 4 channels per lane (c % 4 == 0): the 8 taps of a voxel are 8 float4 reads of whole token rows instead of 32 scalar reads at stride c
 __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __restrict__ tok, VxScPtrs ptrs, VxPwaPlan P, int c, int m0, int M, int nx) {
-    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    int bx;
+    const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
     float* __restrict__ out = ptrs.out[mm];
     const int c4 = c >> 2;
@@ -330,15 +359,18 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_fwd_v_k(const float* __res
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const long v = (long)bx * 256 + threadIdx.x;
     if (v >= V) return;
-    const int i = chq / (P.heads * c4), a = (chq / c4) % P.heads, q4 = chq % c4;
-    const int x2 = (int)(v % P.grid[2]), x1 = (int)((v / P.grid[2]) % P.grid[1]), x0 = (int)(v / ((long)P.grid[2] * P.grid[1]));
+    int q4, a;
+    const int i = vx_fdivmod(vx_fdivmod(chq, vx_fd(c4), q4), vx_fd(P.heads), a);
+    int x2, x1, x0;
+    vx_unflatten(v, P.grid[1], P.grid[2], V < (1 << 22), x0, x1, x2);
     const int bw0 = P.n[0] * P.small[i][0], bw1 = P.n[1] * P.small[i][1], bw2 = P.n[2] * P.small[i][2];
-    const int W0 = x0 / bw0, W1 = x1 / bw1, W2 = x2 / bw2;
+    int j0, j1, j2;
+    const int W0 = vx_fdivmod(x0, vx_fd(bw0), j0), W1 = vx_fdivmod(x1, vx_fd(bw1), j1), W2 = vx_fdivmod(x2, vx_fd(bw2), j2);
     int a0, b0, a1, b1, a2, b2;
     float l0, l1, l2;
-    vx_src_coord(x0 % bw0, P.n[0], bw0, a0, b0, l0);
-    vx_src_coord(x1 % bw1, P.n[1], bw1, a1, b1, l1);
-    vx_src_coord(x2 % bw2, P.n[2], bw2, a2, b2, l2);
+    vx_src_coord(j0, P.n[0], bw0, a0, b0, l0);
+    vx_src_coord(j1, P.n[1], bw1, a1, b1, l1);
+    vx_src_coord(j2, P.n[2], bw2, a2, b2, l2);
     const int N = P.woff[i] + (W0 * P.nwin[i][1] + W1) * P.nwin[i][2] + W2;
     const float* __restrict__ tw = tok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * P.l) + (long)m * P.l) * c + 4 * q4;
     auto T = [&](int t0, int t1, int t2) { return *reinterpret_cast<const float4*>(tw + (long)((t0 * P.n[1] + t1) * P.n[2] + t2) * c); };
@@ -402,26 +434,32 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(VxScPtrs ptrs, float
 // is a transpose of the window's (c, voxels) slab into its (tokens, c) rows -- staged through LDS (pitch c + 1), coalesced on both sides, no atomics.
 // One block = one (b, head, window); every element of the destination rows is written exactly once, which equals "+=" on the zeroed buffer.
 __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int nx) {
-    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    int bx;
+    const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
     const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [l][c + 1]
-    const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
+    int a;
+    const int b = vx_fdivmod(blockIdx.y, vx_fd(P.heads), a);
     const int i = scale;
     const int Nl = bx, N = P.woff[i] + Nl;
     const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
-    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    int W2, W1;
+    const int W0 = vx_fdivmod(vx_fdivmod(Nl, vx_fd(P.nwin[i][2]), W2), vx_fd(P.nwin[i][1]), W1);
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c) * V;
     const int l = P.l, pitch = c + 1;
+    const VxFd fl = vx_fd(l), fn2 = vx_fd(n2), fn1 = vx_fd(n1), fc = vx_fd(c);
+    const long wbase = ((long)(W0 * n0) * P.grid[1] + W1 * n1) * P.grid[2] + W2 * n2;
     for (int e = threadIdx.x; e < l * c; e += 256) {
-        const int vox = e % l, cc = e / l;
-        const int j2 = vox % n2, j1 = (vox / n2) % n1, j0 = vox / (n2 * n1);
-        vx_sacc[vox * pitch + cc] = db[(long)cc * V + ((long)(W0 * n0 + j0) * P.grid[1] + (W1 * n1 + j1)) * P.grid[2] + (W2 * n2 + j2)];
+        int vox, j2, j1;
+        const int cc = vx_fdivmod(e, fl, vox);
+        const int j0 = vx_fdivmod(vx_fdivmod(vox, fn2, j2), fn1, j1);
+        vx_sacc[vox * pitch + cc] = db[(long)cc * V + wbase + ((long)j0 * P.grid[1] + j1) * P.grid[2] + j2];
     }
     __syncthreads();
     float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * l) + (long)m * l) * c;
-    for (int k = threadIdx.x; k < l * c; k += 256) dt[k] += vx_sacc[(k / c) * pitch + (k % c)];       // sole owner of these rows: "+=" without atomics
+    for (int k = threadIdx.x; k < l * c; k += 256) { int kc; const int kt = vx_fdivmod(k, fc, kc); dt[k] += vx_sacc[kt * pitch + kc]; }       // sole owner of these rows: "+=" without atomics
 }
 
 // General small window (2x2x2 .. 4x4x4): the adjoint as a GATHER, one block = one (window, b*head, channel).  Every token collects, per axis, the
@@ -430,11 +468,13 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs,
 // ds_add_f32 per voxel of the atomic kernel below (45 us per launch at the second scale) by 8 LDS reads per voxel.
 #define VX_SC_TAPS 12
 __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int PT, int nx) {
-    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    int bx;
+    const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
     const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];      // [nv] slab | taps
-    const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
+    int a;
+    const int b = vx_fdivmod(blockIdx.y, vx_fd(P.heads), a);
     const int cc = blockIdx.z;
     const int i = scale;
     const int Nl = bx, N = P.woff[i] + Nl;
@@ -461,18 +501,23 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs
             }
         }
     }
-    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    int W2, W1;
+    const int W0 = vx_fdivmod(vx_fdivmod(Nl, vx_fd(P.nwin[i][2]), W2), vx_fd(P.nwin[i][1]), W1);
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c + cc) * V;
+    const VxFd fb2 = vx_fd(bw2), fb1 = vx_fd(bw1), fn2 = vx_fd(n2), fn1 = vx_fd(n1);
     for (int e = threadIdx.x; e < nv; e += 256) {
-        const int j2 = e % bw2, j1 = (e / bw2) % bw1, j0 = e / (bw2 * bw1);
+        int j2, j1;
+        const int j0 = vx_fdivmod(vx_fdivmod(e, fb2, j2), fb1, j1);
         slab[e] = db[((long)(W0 * bw0 + j0) * P.grid[1] + (W1 * bw1 + j1)) * P.grid[2] + (W2 * bw2 + j2)];
     }
     __syncthreads();
     float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * l) + (long)m * l) * c + cc;
-    const int sub = threadIdx.x % PT;                       // PT threads (adjacent lanes) per token: they split the taps of axis 0
-    for (int t = threadIdx.x / PT; t < l; t += 256 / PT) {
-        const int t2 = t % n2, t1 = (t / n2) % n1, t0 = t / (n2 * n1);
+    int sub;                                                // PT threads (adjacent lanes) per token: they split the taps of axis 0
+    const int tfirst = vx_fdivmod(threadIdx.x, vx_fd(PT), sub), tstep = vx_fdiv(256, vx_fd(PT));
+    for (int t = tfirst; t < l; t += tstep) {
+        int t2, t1;
+        const int t0 = vx_fdivmod(vx_fdivmod(t, fn2, t2), fn1, t1);
         const int c0 = tapn[t0], c1 = tapn[nmax + t1], c2 = tapn[2 * nmax + t2];
         const int* __restrict__ J0 = tapj + t0 * VX_SC_TAPS; const float* __restrict__ Wt0 = tapw + t0 * VX_SC_TAPS;
         const int* __restrict__ J1 = tapj + (nmax + t1) * VX_SC_TAPS; const float* __restrict__ Wt1 = tapw + (nmax + t1) * VX_SC_TAPS;
@@ -498,13 +543,16 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs
 // add the plane's n1 x n2 result into the block's n0 x n1 x n2 accumulator with the two D weights of that plane; one float atomic per token
 // element and block at the end.  Replaces 8 scattered ds_add_f32 per voxel of vx_pwa_scatter_bwd_k (58 us per launch there) by plain LDS reads.
 __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int ZC, int nx) {
-    const int mm = blockIdx.x / nx, bx = blockIdx.x - mm * nx;
+    int bx;
+    const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
     const float* __restrict__ dout = ptrs.in[mm];
     extern __shared__ __attribute__((aligned(16))) float vx_sacc[];
-    const int b = blockIdx.y / P.heads, a = blockIdx.y % P.heads;
+    int a;
+    const int b = vx_fdivmod(blockIdx.y, vx_fd(P.heads), a);
     const int i = scale;
-    const int cc = blockIdx.z % c, zc = blockIdx.z / c;
+    int cc;
+    const int zc = vx_fdivmod(blockIdx.z, vx_fd(c), cc);
     const int Nl = bx, N = P.woff[i] + Nl;
     const int n0 = P.n[0], n1 = P.n[1], n2 = P.n[2];
     const int bw0 = n0 * P.small[i][0], bw1 = n1 * P.small[i][1], bw2 = n2 * P.small[i][2];
@@ -513,20 +561,24 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(VxScPtrs ptrs, f
     float* __restrict__ acc = tmp + bw1 * n2;                   // [n0][n1][n2]
     float* __restrict__ A2 = acc + n0 * n1 * n2;                // [n2][bw2]  weight of fine column j2 for coarse column t2
     float* __restrict__ A1 = A2 + n2 * bw2;                     // [n1][bw1]
+    const VxFd fb2 = vx_fd(bw2), fb1 = vx_fd(bw1), fn2 = vx_fd(n2);
     for (int e = threadIdx.x; e < n2 * bw2; e += 256) {
-        const int t = e / bw2, j = e - t * bw2;
+        int j;
+        const int t = vx_fdivmod(e, fb2, j);
         int i0, i1; float lam;
         vx_src_coord(j, n2, bw2, i0, i1, lam);
         A2[e] = (i0 == t ? 1.0f - lam : 0.0f) + (i1 == t ? lam : 0.0f);
     }
     for (int e = threadIdx.x; e < n1 * bw1; e += 256) {
-        const int t = e / bw1, j = e - t * bw1;
+        int j;
+        const int t = vx_fdivmod(e, fb1, j);
         int i0, i1; float lam;
         vx_src_coord(j, n1, bw1, i0, i1, lam);
         A1[e] = (i0 == t ? 1.0f - lam : 0.0f) + (i1 == t ? lam : 0.0f);
     }
     for (int e = threadIdx.x; e < n0 * n1 * n2; e += 256) acc[e] = 0.0f;
-    const int W2 = Nl % P.nwin[i][2], W1 = (Nl / P.nwin[i][2]) % P.nwin[i][1], W0 = Nl / (P.nwin[i][2] * P.nwin[i][1]);
+    int W2, W1;
+    const int W0 = vx_fdivmod(vx_fdivmod(Nl, vx_fd(P.nwin[i][2]), W2), vx_fd(P.nwin[i][1]), W1);
     const long V = (long)P.grid[0] * P.grid[1] * P.grid[2];
     const float* __restrict__ db = dout + ((long)b * (P.nb * P.heads * c) + (long)(i * P.heads + a) * c + cc) * V;
     const int jz0 = zc * ZC, jz1 = min(bw0, jz0 + ZC);
@@ -534,12 +586,14 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(VxScPtrs ptrs, f
         __syncthreads();
         const float* __restrict__ src = db + ((long)(W0 * bw0 + j0) * P.grid[1] + W1 * bw1) * P.grid[2] + W2 * bw2;
         for (int e = threadIdx.x; e < bw1 * bw2; e += 256) {
-            const int j1 = e / bw2, j2 = e - j1 * bw2;
+            int j2;
+            const int j1 = vx_fdivmod(e, fb2, j2);
             plane[e] = src[(long)j1 * P.grid[2] + j2];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < bw1 * n2; e += 256) {      // along W
-            const int j1 = e / n2, t2 = e - j1 * n2;
+            int t2;
+            const int j1 = vx_fdivmod(e, fn2, t2);
             const float* __restrict__ row = plane + j1 * bw2;
             const float* __restrict__ w2 = A2 + t2 * bw2;
             float s_ = 0.0f;
@@ -550,7 +604,8 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_sep_k(VxScPtrs ptrs, f
         int t0a, t0b; float l0;
         vx_src_coord(j0, n0, bw0, t0a, t0b, l0);
         for (int e = threadIdx.x; e < n1 * n2; e += 256) {       // along H, then into the two coarse planes this fine plane touches
-            const int t1 = e / n2, t2 = e - t1 * n2;
+            int t2;
+            const int t1 = vx_fdivmod(e, fn2, t2);
             const float* __restrict__ w1 = A1 + t1 * bw1;
             float s_ = 0.0f;
             for (int j1 = 0; j1 < bw1; ++j1) s_ = fmaf(w1[j1], tmp[j1 * n2 + t2], s_);
