@@ -275,6 +275,13 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
         for (int i = 0; i < 4; ++i) { S1[cb][i] = 0.0f; S2[cb][i] = 0.0f; }
     }
 
+    // The dropout masks are needed twice per element: in the N layout (voxels on the MFMA columns: the input-gradient chain) and in the T layout (voxels on the rows:
+    // the weight-gradient products).  Drawing them twice was 32 Philox calls per lane and trip -- over a third of this kernel's issue slots.  They are drawn once, in the
+    // N layout; every lane leaves its keep bits (bit 16 rb + 4 i + t: row 16 rb + 4 q + i of site 1, bit 16 RB + 4 ks + t: channel 4 ks + q of site 2; voxel vl + t) in
+    // a per-wave LDS record, and the T pass picks the nibbles of its own (row, 4 voxels) out of the records of the four lanes that drew them.  (`red` is idle until
+    // the flush; LDS operations of one wave are executed in order.)
+    constexpr int MB2 = 16 * RB, MDW = (16 * RB + 4 * KS + 31) / 32;
+    uint32_t* __restrict__ mrec = reinterpret_cast<uint32_t*>(red) + wave * 64 * MDW;      // [MDW][64 lanes]
     for (int it = 0; it < p.iters; ++it) {
         const long v0 = (((long)blockIdx.x * p.iters + it) * 4 + wave) * GV;
         if (v0 >= V) break;                                    // wave-uniform
@@ -282,6 +289,9 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
         const bool live = vl < V;
         const long vc = live ? vl : V - VS;
         const float lz = live ? 1.0f : 0.0f;
+        uint32_t rec[MDW];
+#pragma unroll
+        for (int k = 0; k < MDW; ++k) rec[k] = 0u;
         // ---- N-layout operands: channel 4ks + q, voxels vl .. vl + TPW - 1
         float n[KS][TPW], dz[KS][TPW], uu[TPW], rr[TPW];
         vx_mlp_load_n<C, NORM, TPW>(xs, V, vc, q, mu_s, rs_s, p.eps, n, uu, rr);
@@ -293,7 +303,10 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
                 float m2[4];
                 vx_masks_vox4(d2, (uint64_t)b * C + 4 * ks + q, V, vc, m2);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dz[ks][t] *= m2[t] * lz;
+                for (int t = 0; t < 4; ++t) {
+                    dz[ks][t] *= m2[t] * lz;
+                    rec[(MB2 + 4 * ks + t) >> 5] |= (m2[t] != 0.0f ? 1u : 0u) << ((MB2 + 4 * ks + t) & 31);
+                }
             }
         } else {
 #pragma unroll
@@ -331,7 +344,10 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
                     float m1[4];
                     vx_masks_vox4(d1, (uint64_t)b * R + 16 * rb + 4 * q + i, V, vc, m1);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dh[t][i] *= m1[t] * vx_gelu_grad_fast(a[t][i]);
+                    for (int t = 0; t < 4; ++t) {
+                        dh[t][i] *= m1[t] * vx_gelu_grad_fast(a[t][i]);
+                        rec[(16 * rb + 4 * i + t) >> 5] |= (m1[t] != 0.0f ? 1u : 0u) << ((16 * rb + 4 * i + t) & 31);
+                    }
                 }
             } else {
                 float m1[4];
@@ -410,6 +426,13 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
         // ---- T pass: voxels on the rows.  Tile t = voxels {v0 + VS*m' + t}; accumulator reg i <-> m' = 4q + i <-> voxel v0 + VS*(4q+i) + t.
         //      T-layout global operands: channel 16cb + m, the lane's 4*TPW consecutive voxels v0 + 4*VS*q ..
         const long vt = v0 + 4 * VS * q;                       // multiple of 4
+        if constexpr (TPW == 4) {
+            if (d1.on || d2.on) {
+#pragma unroll
+                for (int k = 0; k < MDW; ++k) mrec[k * 64 + lane] = rec[k];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         float dzT[CB][TPW][4], nT[CB][TPW][4];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
@@ -423,7 +446,14 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
                 const float4 g4 = *reinterpret_cast<const float4*>(gs + (long)ch * V + va);
                 const float4 x4 = *reinterpret_cast<const float4*>(xs + (long)ch * V + va);
                 float m2[4];
-                vx_masks_vox4(d2, (uint64_t)b * C + ch, V, va, m2);
+                if constexpr (TPW == 4) {
+                    // voxels v0 + 4 (4 q + f) + e of channel 16 cb + m = 4 ks + q': drawn by lane (m' = 4 q + f, q' = m & 3), ks = 4 cb + (m >> 2)
+                    if (d2.on) {
+                        const uint32_t nib = mrec[((MB2 + 16 * cb) >> 5) * 64 + 16 * (m & 3) + 4 * q + f] >> (((MB2 + 16 * cb) & 31) + 4 * (m >> 2));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m2[e] = ((nib >> e) & 1u) ? d2.inv_keep : 0.0f;
+                    } else { m2[0] = m2[1] = m2[2] = m2[3] = 1.0f; }
+                } else vx_masks_vox4(d2, (uint64_t)b * C + ch, V, va, m2);
                 const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -459,7 +489,15 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
                 const long vf = vt + 4 * f;
                 const long va = vf < V ? vf : V - 4;
                 float m1[4];
-                vx_masks_vox4(d1, (uint64_t)b * R + 16 * jb + m, V, va, m1);
+                if constexpr (TPW == 4) {
+                    // row 16 jb + m = 16 rb + 4 q' + i: drawn by lane (m' = 4 q + f, q' = m >> 2) with i = m & 3
+                    if (d1.on) {
+                        const uint32_t nib = mrec[((16 * jb) >> 5) * 64 + 16 * (m >> 2) + 4 * q + f] >> (((16 * jb) & 31) + 4 * (m & 3));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m1[e] = ((nib >> e) & 1u) ? d1.inv_keep : 0.0f;
+                    } else { m1[0] = m1[1] = m1[2] = m1[3] = 1.0f; }
+                    (void)va;
+                } else vx_masks_vox4(d1, (uint64_t)b * R + 16 * jb + m, V, va, m1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = TPW == 4 ? e : 0, i = TPW == 4 ? f : e;
