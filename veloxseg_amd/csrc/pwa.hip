@@ -11,13 +11,16 @@
 
 // Index arithmetic of the gather / scatter kernels.  Their divisors are run-time plan constants (grid, cell and window extents), and the compiler's 32-bit integer
 // division is ~30 instructions with four quarter-rate multiplies: with 10-15 of them per thread these memory movers were bound by their index math (920 instructions
-// to move four floats in vx_pwa_gather_all_bwd_v_k).  For 0 <= a < 2^22 the quotient is floor(float(a) * rb) or one less when rb is the reciprocal rounded DOWN by
-// 2^-22 (never above a / b: the two roundings are 2^-24 each, the reciprocal's 2^-23), so one conditional step finishes it: ~9 full-rate instructions.
+// to move four floats in vx_pwa_gather_all_bwd_v_k).  For 0 <= a < 2^22: with rb = the reciprocal (v_rcp_f32: 1 ulp) scaled DOWN by 2^-22, float(a) * rb is never
+// above a / b (the reciprocal's ulp and the two roundings are 2^-23 + 2^-24 + 2^-24 = 2^-22 at most) and below it by less than (a / b) 2^-21 + 1 <= 3, so the truncated
+// product is the quotient or up to two below it: two conditional steps finish it (~12 full-rate instructions).  tests/test_index_math_cpu.py checks the claim in float32
+// arithmetic for every reciprocal within 1 ulp.
 struct VxFd { int b; float rb; };
 __device__ __forceinline__ VxFd vx_fd(int b) { VxFd d; d.b = b; d.rb = __builtin_amdgcn_rcpf((float)b) * 0.99999976f; return d; }
 __device__ __forceinline__ int vx_fdivmod(int a, const VxFd& d, int& r) {          // 0 <= a < 2^22
     int q = (int)((float)a * d.rb);
     r = a - __mul24(q, d.b);
+    if (r >= d.b) { ++q; r -= d.b; }
     if (r >= d.b) { ++q; r -= d.b; }
     return q;
 }
