@@ -129,6 +129,25 @@ if "dec_wg" in G:
         G["enc_bwd"].replay()
         eng._hop(41, lane, cur)
     m_both = measure(both)
+    # which of the two ends the phase: finish times of the weight-gradient lane and of the encoder backward, from a common start
+    fin = []
+    for _ in range(20):
+        lane = eng._lane_streams(4)[3]
+        cur = torch.cuda.current_stream()
+        e0, e_wg, e_enc = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize()
+        e0.record(cur)
+        eng._hop(40, cur, lane)
+        with torch.cuda.stream(lane):
+            wg_only()
+            e_wg.record(lane)
+        G["enc_bwd"].replay()
+        e_enc.record(cur)
+        eng._hop(41, lane, cur)
+        torch.cuda.synchronize()
+        fin.append((e0.elapsed_time(e_wg) * 1e3, e0.elapsed_time(e_enc) * 1e3))
+    fin.sort()
+    print(f"          in that phase the weight-gradient lane finishes after {fin[len(fin) // 2][0]:7.1f} us, the encoder backward after {sorted(f[1] for f in fin)[len(fin) // 2]:7.1f} us (medians of 20)")
     print(f"dec_wg  : measured {m_wg:7.1f} us alone | kernel-time sum {sum(r['total'] for r in res):7.1f} us over {sum(r['n'] for r in res)} nodes | dec_wg || enc_bwd together: {m_both:7.1f} us")
     wgk = collections.Counter()
     for r in res:
