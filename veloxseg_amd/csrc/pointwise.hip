@@ -756,6 +756,14 @@ extern "C" int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int 
         blk += F.nblk;
     }
     VX_REQUIRE(blk < 0x7fffffffL, "vx_pw_wgrad_group: grid too large");
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("VX_WGG_DBG"); dbg = (e && e[0] == '1') ? 1 : 0; }
+    if (dbg) {
+        fprintf(stderr, "[wgg] %d jobs %d folds %ld blocks:", nj, nf, blk);
+        for (int k = 0; k < nj; ++k) fprintf(stderr, " (%d->%d V=%ld B=%d vpw=%d blk=%d)", g.j[k].Cin, g.j[k].Cout, g.j[k].V, g.j[k].B, g.j[k].vpw, g.j[k].nblk);
+        for (int k = 0; k < nf; ++k) fprintf(stderr, " [fold C=%d rows=%d]", g.f[k].C, g.f[k].rows);
+        fprintf(stderr, "\n");
+    }
     vx_pw_wgrad_group_k<<<dim3((unsigned)blk), 256, 0, (hipStream_t)stream>>>(g);
     VX_LAUNCH_CHECK("vx_pw_wgrad_group");
     return 0;
