@@ -711,13 +711,24 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_group_k(VxWgGroup g) {
     for (int k = 0; k < g.nf; ++k) {
         const VxFoldJob& F = g.f[k];
         if (id >= F.blk0 && id < F.blk0 + F.nblk) {
+            // 64 rows of width n = 2C per block.  Narrow rows (n < 256: the 32-wide rows of the 32^3 level) are shared by 256 / n thread groups that take every G-th row, and
+            // eight loads are in flight per thread: one column per thread walking its 64 rows two at a time was a chain of 32 memory round trips -- the longest block of the
+            // launch that closes the encoder backward
             const int r0 = (id - F.blk0) * 64, r1 = min(F.rows, r0 + 64), n = 2 * F.C;
-            for (int i = threadIdx.x; i < n; i += 256) {
-                float s0 = 0.0f, s1 = 0.0f;
-                int rr = r0;
-                for (; rr + 1 < r1; rr += 2) { s0 += F.part[(long)rr * n + i]; s1 += F.part[(long)(rr + 1) * n + i]; }
-                if (rr < r1) s0 += F.part[(long)rr * n + i];
-                atomicAdd(i < F.C ? F.dg + i : F.dbeta + (i - F.C), s0 + s1);
+            const int P = n < 256 ? n : 256, G = 256 / P;
+            const int ci = threadIdx.x % P, gi = threadIdx.x / P;
+            if (gi >= G) return;
+            for (int i = ci; i < n; i += P) {
+                float acc = 0.0f;
+                int rr = r0 + gi;
+                for (; rr + 7 * G < r1; rr += 8 * G) {
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = F.part[(long)(rr + u * G) * n + i];
+                    acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+                }
+                for (; rr < r1; rr += G) acc += F.part[(long)rr * n + i];
+                atomicAdd(i < F.C ? F.dg + i : F.dbeta + (i - F.C), acc);
             }
             return;
         }
