@@ -748,11 +748,14 @@ extern "C" int vx_pw_wgrad_group(const void* const* ptrs, const long* dims, int 
         J.Cin = (int)dims[4 * k]; J.Cout = (int)dims[4 * k + 1]; J.V = dims[4 * k + 2]; J.B = (int)dims[4 * k + 3];
         VX_REQUIRE(J.x && J.dy && J.dw && J.Cin > 0 && J.Cout > 0 && J.V > 0 && J.B > 0, "vx_pw_wgrad_group: bad job %d", k);
         const int mt = vx_cdiv(J.Cout, 16), nt = vx_cdiv(J.Cin, 16);
-        long waves_per_tile = 1024 / ((long)mt * nt);
+        static int wgg_waves = -1, wgg_minv = -1;
+        if (wgg_waves < 0) { const char* e = getenv("VELOXSEG_WGG_WAVES"); wgg_waves = (e && atoi(e) > 0) ? atoi(e) : 1024; }
+        if (wgg_minv < 0) { const char* e = getenv("VELOXSEG_WGG_MINV"); wgg_minv = (e && atoi(e) > 0) ? atoi(e) : 256; }
+        long waves_per_tile = wgg_waves / ((long)mt * nt);
         if (waves_per_tile < 4) waves_per_tile = 4;
         long vpw = ((long)J.B * J.V + waves_per_tile - 1) / waves_per_tile;
         vpw = (vpw + 63) / 64 * 64;
-        if (vpw < 256) vpw = 256;
+        if (vpw < wgg_minv) vpw = wgg_minv;
         J.vpw = (int)vpw; J.chunks_per_b = vx_cdiv(J.V, vpw); J.nt = nt;
         J.gx = vx_cdiv((long)J.B * J.chunks_per_b, 4);
         J.blk0 = (int)blk; J.nblk = J.gx * mt * nt;
