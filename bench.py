@@ -31,6 +31,7 @@ BASE = dict(patch_size=4, base_ch=16, conv_depths=[1, 1, 1, 1], kernel_sizes=[1,
             min_dim_head=[4, 8, 8, 16], ffn_expansion_ratio=[3, 3, 2, 2], num_heads=[1, 2, 2, 4], proj_drop=0.1, conv_drop=0.1, spatial_dim=3)
 W128 = [[4] * 3, [8] * 3, [4] * 3, [4] * 3]      # [3,6,3,3] does not tile the 32^3 token grid of a 128^3 patch
 W96 = [[3] * 3, [6] * 3, [3] * 3, [3] * 3]
+WHECK = [[4, 4, 2], [8, 8, 4], [4, 4, 2], [4, 4, 2]]     # config/models_config_hecktor2022.json "VeloxSeg": anisotropic windows on a 128 x 128 x 64 patch (l = 32 / 256 tokens)
 WORKLOADS = {
     # name: (model kwargs, default per-GPU batch)
     # B = 4 per GPU = the reference's effective step batch (batch_size 2 x RandCropByPosNegLabeld num_samples 2) and BASELINE configs[2,3]
@@ -38,10 +39,16 @@ WORKLOADS = {
     "autopet96": (dict(BASE, input_size=[96] * 3, in_ch=[1, 1], n_classes=2, min_big_window_sizes=W96), 4),
     "brats128": (dict(BASE, input_size=[128] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W128), 2),
     "brats96": (dict(BASE, input_size=[96] * 3, in_ch=[4], n_classes=4, min_big_window_sizes=W96), 2),
+    "hecktor": (dict(BASE, input_size=[128, 128, 64], in_ch=[1, 1], n_classes=2, min_big_window_sizes=WHECK), 4),
 }
 # Algorithmic work per PATCH of a full training step (FlopCounterMode fwd+bwd; block-boundary activation traffic, fp32),
 # and optimizer traffic per STEP (32 B per parameter): (GFLOP / patch, MB / patch, MB optimizer / step)
-STEP_WORK = {"autopet128": (58.50, 569.1, 73.0), "autopet96": (24.11, 240.1, 73.0), "brats128": (71.55, 916.5, 60.0), "brats96": (30.04, 386.6, 60.0)}
+STEP_WORK = {"autopet128": (58.50, 569.1, 73.0), "autopet96": (24.11, 240.1, 73.0), "brats128": (71.55, 916.5, 60.0), "brats96": (30.04, 386.6, 60.0),
+             # hecktor: FlopCounterMode over the oracle's fwd + loss + bwd at (1, 2, 128, 128, 64) (round 6: 28.83 GFLOP); block-boundary elements 16.96 V per sample
+             "hecktor": (28.83, 284.6, 73.3)}
+EVAL_GFLOP = {"autopet96": 3.50, "autopet128": 8.75, "brats96": 5.13, "brats128": 12.26, "hecktor": 4.19}      # eval forward, 2 x MAC per patch (hecktor: round 6, same method)
+PUBLISHED_EVAL = {"autopet96": 599.06}      # README.md:215 (RTX 3090, autocast, batch <= 16, 10 s + 60 s: speed_test.py:117-134) -- the reference's only GPU number
+BF16_DTYPE = "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions of the 32^3 / 16^3 levels (fp32 accumulate, fp32 storage, fp32-level arithmetic everywhere else)"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector / fp32-input MFMA peak
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is NOT used)
@@ -186,9 +193,16 @@ def _tapes(eng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="autopet128", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
+    ap.add_argument("--mode", default="train", choices=["train", "eval", "sliding"],
+                    help="train (default): the headline training step.  eval: the reference's one published GPU protocol (speed_test.py:117-134: eval forward, batch <= 16, "
+                         "T0 s warm-up + T1 s timed, a device synchronise per forward; default workload autopet96) through engine.TapedPredictor.  sliding: BASELINE configs[4], "
+                         "sliding-window inference of a synthetic (1, 4, 240, 240, 155) volume, overlap 0.5, sw_batch 2, arg-max + BraTS Dice included (utils/inference_brats.py:190-218)")
+    ap.add_argument("--t0", type=float, default=10.0, help="eval / sliding: warm-up seconds (speed_test.py:10)")
+    ap.add_argument("--t1", type=float, default=60.0, help="eval / sliding: timed seconds (speed_test.py:12); --steps K > 0 with --mode eval / sliding times exactly K forwards / volumes instead")
+    ap.add_argument("--roi", type=int, default=128, choices=[96, 128], help="sliding: window edge (96 = the shipped BraTS config: 48 windows; 128: 18 windows)")
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: workload default)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = the opt-in mode of BASELINE configs[1]: bf16 MFMA operands (fp32 accumulate, fp32 storage) in the patch-expand layers; a separate line, never the headline")
     ap.add_argument("--eager", action="store_true", help="launch every step through autograd (host-bound: ~10 ms of enqueue per step) instead of replaying the captured launch tapes")
@@ -203,6 +217,10 @@ def main():
     ap.add_argument("--dispersion-steps", type=int, default=300, help="extra steps after the timed region whose per-step times give p10 / p50 / p90 (0 = skip)")
     ap.add_argument("--lane-probe", action="store_true", help="diagnostic: after the timed region, time dispatch-heavy kernels on every pair of tape lanes (lanes that share a dispatch pipe overlap worse)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = {"train": "autopet128", "eval": "autopet96", "sliding": "brats128" if args.roi == 128 else "brats96"}[args.mode]
+    if args.steps is None:
+        args.steps = 300 if args.mode == "train" else 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))          # plain `python bench.py --gpus N`: one child process per GPU, started before anything touches HIP
@@ -232,6 +250,11 @@ def main():
     from veloxseg_amd.utils.loss import Loss
 
     cfg, defB = WORKLOADS[args.workload]
+    if args.mode != "train":
+        assert world == 1, "--mode eval / sliding run on one GPU (replicas only: independent windows / batches, no exchange step)"
+        out = (_eval_mode if args.mode == "eval" else _sliding_mode)(args, cfg, dev)
+        print(json.dumps(out), flush=True)
+        return
     B = args.batch or defB
     torch.manual_seed(12345)                                   # reference seed (utils/seed.py:6)
     model = VeloxSeg(**cfg).to(dev)
@@ -358,7 +381,7 @@ def main():
                else f"training patches/s ({args.workload})",
                "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions of the 32^3 / 16^3 levels (fp32 accumulate, fp32 storage, fp32-level arithmetic everywhere else)",
+               "dtype": _dtype_string(args),
                "data": "synthetic (randn volumes, rand>0.97 labels, random-init weights, seed 12345)",
                "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} "
                                       f"windows {cfg['min_big_window_sizes']} dropout proj/conv/attn 0.1, full SDKT train step",
@@ -389,84 +412,7 @@ def main():
             eng._fwd_bwd_single()
             prof = H.profile_end()
         VF.BRANCH_STREAMS = True
-        rows = sorted(((v[1], v[0], k) for k, v in prof.items()), reverse=True)
-        total = sum(r[0] for r in rows)
-        top = rows[0]
-        out["kernel_pass"] = {"total_ms": round(total, 3), "top": [{"entry": r[2][0], "key": list(r[2][1]), "launches": r[1], "ms": round(r[0], 4)} for r in rows[:8]]}
-        # `roofline` = the kernel with the most time per step, AGGREGATED BY ENTRY over every shape it is launched with (the top row of the rocprofv3 summary, which is
-        # by kernel name): sum of algorithmic flops / sum of launch time.  avg_launch_ms / achieved / frac are measured live (HIP events on the launch stream, above);
-        # `profile` repeats them from the committed rocprofv3 --kernel-trace --stats summary so that frac can be recomputed from profiles/ alone.
-        alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd",
-                 # (round 5: the operator code calls the entries that take the pieces mode explicitly -- same kernels, one more trailing integer in the key)
-                 "vx_jlc_wgrad_tz_ns": "vx_jlc_wgrad_tz", "vx_jlc_tz_fwd_ns": "vx_jlc_tz_fwd", "vx_jlc_tz_bwd_ns": "vx_jlc_tz_bwd", "vx_jlc_tz_prep_ns": "vx_jlc_tz_prep"}
-        rows = [(t_, n_, (alias.get(nm, nm) if nm.endswith("_ns") else nm, (tuple(k_[:-1]) if nm.endswith("_ns") and nm != "vx_jlc_tz_prep_ns" else k_))) for t_, n_, (nm, k_) in rows]
-        fam = {}
-        for tot_ms, n, (name, key) in rows:
-            base = alias.get(name, name)
-            rf = roofline_for(base, key, tot_ms / n, model)
-            f = fam.setdefault(base, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "known": True, "shapes": [], "last": None})
-            f["ms"] += tot_ms
-            f["n"] += n
-            if rf.get("achieved") is None:
-                f["known"] = False
-            else:
-                f["flops"] += rf["algorithmic_flops"] * n
-                f["bytes"] += rf["algorithmic_bytes"] * n
-                f["shapes"].append({"args": list(key)[:8], "launches": n, "avg_launch_ms": round(tot_ms / n, 5), "frac": rf["frac"], "algorithmic_flops": rf["algorithmic_flops"]})
-                f["last"] = rf
-        out["kernel_pass"]["families"] = [{"entry": k_, "launches": f["n"], "ms": round(f["ms"], 4)} for k_, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]]
-        out["roofline"] = None
-        for base, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
-            if not f["known"] or f["last"] is None:
-                continue
-            rf = dict(f["last"])
-            for drop in ("args", "traffic_source", "pairs", "kernels", "mfma"):
-                rf.pop(drop, None)
-            sec = f["ms"] * 1e-3
-            rf.update({"kernel": base, "device_kernel": DEVICE_KERNEL.get(base, base), "launches_per_step": f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 5),
-                       "algorithmic_flops": f["flops"] / f["n"], "algorithmic_bytes": f["bytes"] / f["n"], "share_of_step": round(f["ms"] / total, 4), "shapes": f["shapes"]})
-            if rf["bound"] == "mfma":
-                ach = f["flops"] / sec / 1e12
-            else:
-                ach = f["bytes"] / sec / 1e9
-            rf["achieved"], rf["frac"] = round(ach, 3), round(ach / rf["peak"], 4)
-            if "frac_of_fp32_mfma_peak" in rf:
-                rf["frac_of_fp32_mfma_peak"] = round(ach / FP32_PEAK_TFLOPS, 4)
-            rf["traffic"], tsrc = _pmc_traffic_family(DEVICE_KERNEL.get(base, base), B)
-            if tsrc:
-                rf["traffic_source"] = tsrc
-            pr = _profile_row(DEVICE_KERNEL.get(base, base), args.workload, B)
-            if pr is not None:
-                pr["achieved"] = round((f["flops"] if rf["bound"] == "mfma" else f["bytes"]) / f["n"] / (pr["avg_launch_ms"] * 1e-3) / (1e12 if rf["bound"] == "mfma" else 1e9), 3)
-                pr["frac"] = round(pr["achieved"] / rf["peak"], 4)
-                rf["profile"] = pr
-            if base == "vx_jlc_wgrad_tz":
-                fc = _wg_full_chip(f["shapes"], rf["peak"])
-                if fc is not None:
-                    rf["full_chip"] = fc
-            for sh in rf["shapes"]:
-                sh.pop("algorithmic_flops", None)
-            out["roofline"] = rf
-            break
-        # PWA attention (north_star: "MFMA utilisation for PWA against gfx950 peak"): every attention launch of the step, forward and backward
-        att = []
-        for tot_ms, n, (name, key) in rows:
-            if name in ("vx_pwa_attn_fwd", "vx_pwa_attn_bwd", "vx_pwa_attn_fwd_mb", "vx_pwa_attn_bwd_mb", "vx_pwa_attn_bwd_nofold_mb", "vx_pwa_attn_bwd_nofold"):
-                base = "vx_pwa_attn_fwd" if "fwd" in name else "vx_pwa_attn_bwd"
-                ra = roofline_for(base, key, tot_ms / n, model)
-                if ra.get("achieved") is not None:
-                    att.append({"pass": "forward" if "fwd" in name else "backward", "c_qk": key[2], "c_v": key[3], "pairs": ra.get("pairs"), "avg_launch_ms": ra["avg_launch_ms"],
-                                "achieved_tflops": ra["achieved"], "frac_fp32_peak": ra["frac"], **(ra.get("mfma") or {})})
-        if att:
-            out["roofline_pwa"] = att
-        # the JLC spatial stage (the reference's Johnson-Lindenstrauss block, conv_blocks.py:51-58) at level 1: its own roofline object with PMC traffic
-        jname = "vx_jlc_tz_fwd" if any(name == "vx_jlc_tz_fwd" for _, _, (name, _k) in rows) else "vx_jlc_conv_fwd"
-        jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == jname]
-        if jl:
-            ms1, n1, key1 = max(jl, key=lambda t: t[2][3] * t[2][4] * t[2][5])
-            rj = roofline_for(jname, key1, ms1, model)
-            rj["launches_per_step"] = n1
-            out["roofline_jlc"] = rj
+        _kernel_pass(out, prof, model, args.workload, B)
     if rank == 0:
         gf, mb, opt_mb = STEP_WORK[args.workload]
         flops = gf * 1e9 * B * world
@@ -495,6 +441,279 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _timed_loop(fn, t0_s, t1_s, steps, sync_each):
+    """speed_test.py:117-134: run `fn` for t0_s seconds untimed, then until the per-call times sum to t1_s (or exactly `steps` calls when steps > 0).
+    sync_each: a device synchronise inside every timed call (the reference's protocol); else ONE synchronise around the whole timed run (pipelined launches).
+    -> (calls, seconds)"""
+    torch.cuda.synchronize()
+    t = time.time()
+    while time.time() - t < t0_s:
+        fn()
+        torch.cuda.synchronize()
+    if sync_each:
+        timing = []
+        while (len(timing) < steps) if steps > 0 else (sum(timing) < t1_s):
+            a = time.time()
+            fn()
+            torch.cuda.synchronize()
+            timing.append(time.time() - a)
+        return len(timing), sum(timing)
+    n = steps if steps > 0 else None
+    if n is None:                                   # size the run from a short probe so that it lasts about t1_s
+        a = time.time()
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+        n = max(8, int(t1_s / max((time.time() - a) / 8, 1e-6)))
+    torch.cuda.synchronize()
+    a = time.time()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return n, time.time() - a
+
+
+def _cpu_eval_baseline(cfg, budget_s=15.0):
+    """the reference's CPU protocol (speed_test.py:64-70,102-115: eval forward, ONE thread, batch 1; README.md:216 quotes 6.67 patches/s at 96^3) on the oracle"""
+    from oracle import veloxseg_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipe import fill_state_dict
+    ocfg = O.OracleConfig(**cfg)
+    sd = fill_state_dict(O.state_dict_template(ocfg), seed=7)
+    x1 = torch.randn(1, sum(cfg["in_ch"]), *cfg["input_size"], generator=torch.Generator().manual_seed(12345))
+    prev = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        with torch.no_grad():
+            O.forward(x1, sd, ocfg, training=False)
+            t0, n1 = time.time(), 0
+            while n1 < 8 and time.time() - t0 < budget_s:
+                O.forward(x1, sd, ocfg, training=False)
+                n1 += 1
+        return {"value": round(n1 / (time.time() - t0), 4), "unit": "patches/s", "cores": 1, "kind": "port",
+                "sample": f"{n1} eval forwards of the same workload, 1 thread, batch 1, fp32 (speed_test.py:27,68-69,102-115), after 1 warm-up forward",
+                "host_cores": os.cpu_count(), "cpu_model": _cpu_model()}
+    finally:
+        torch.set_num_threads(prev)
+
+
+def _forward_kernel_pass(out, model, x, workload, B):
+    """per-kernel table + rooflines of ONE eager eval forward (HIP events around every C-ABI call, one stream)"""
+    from veloxseg_amd import _hip as H
+    from veloxseg_amd import functional as VF
+    _pmc_traffic.workload = None             # the committed PMC passes are of the training step: no traffic figure is attached to these launches
+    VF.BRANCH_STREAMS = False
+    try:
+        with torch.no_grad():
+            model(x)
+            H.profile_begin()
+            model(x)
+            prof = H.profile_end()
+    finally:
+        VF.BRANCH_STREAMS = True
+    _kernel_pass(out, prof, model, workload, B)
+
+
+def _dtype_string(args):
+    return "f32" if args.dtype == "f32" else BF16_DTYPE
+
+
+def _eval_mode(args, cfg, dev):
+    """The reference's published GPU protocol (README.md:215 = 599.06 patches/s on an RTX 3090): eval forward, batch 16, T0 s warm-up + T1 s timed with a device
+    synchronise per forward (speed_test.py:117-134, there under torch.amp.autocast -- here --dtype bf16 is the reduced-precision leg, f32 the parity mode)."""
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.engine import TapedPredictor
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    B = args.batch or 16                                       # speed_test.py:28,30-50: largest power of two <= 16 that fits (16 fits 288 GB with room)
+    torch.manual_seed(12345)
+    model = VeloxSeg(**cfg).to(dev).eval()
+    VF.set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    x = torch.randn(B, sum(cfg["in_ch"]), *cfg["input_size"], device=dev)
+    pred = TapedPredictor(model)
+    with torch.inference_mode():
+        y = pred(x)                                            # capture (+ the replay == eager check of TapedPredictor)
+        assert bool(torch.isfinite(y).all())
+        n_s, sec_s = _timed_loop(lambda: pred(x), args.t0, args.t1, args.steps, sync_each=True)
+        n_p, sec_p = _timed_loop(lambda: pred(x), 0.5, min(args.t1, 10.0), args.steps, sync_each=False)
+    value = B * n_s / sec_s
+    gf = EVAL_GFLOP.get(args.workload)
+    pub = PUBLISHED_EVAL.get(args.workload) if B == 16 else None
+    out = {"metric": f"eval forward patches/s ({args.workload}; protocol of the reference's speed_test.py)", "value": round(value, 2), "unit": "patches/s", "n_gpus": 1,
+           "steps": n_s, "warmup": f"{args.t0} s", "ms_per_step": round(sec_s / n_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": round(value / pub, 2) if pub else None,
+           "vs_baseline_note": ("README.md:215 publishes 599.06 patches/s for this protocol on an RTX 3090 (other hardware; autocast)" if pub else None),
+           "dtype": _dtype_string(args), "data": "synthetic (randn volumes, random-init weights, seed 12345)",
+           "config": {"workload": f"{args.workload}: VeloxSeg in_ch={cfg['in_ch']} n_classes={cfg['n_classes']} patch {cfg['input_size']} windows {cfg['min_big_window_sizes']}, "
+                                  f"eval forward (logits of the main head), batch {B}", "batch_per_gpu": B, "protocol": "speed_test.py:117-134: T0 warm-up, then forwards with a device synchronise "
+                                  f"after each until their times sum to T1 (T0 = {args.t0} s, T1 = {args.t1} s)" + (f"; --steps {args.steps}" if args.steps > 0 else ""),
+                      "launch": "engine.TapedPredictor: the forward of this batch shape captured once, replayed as a launch tape (csrc/tape.hip)"},
+           "pipelined": {"value": round(B * n_p / sec_p, 2), "unit": "patches/s", "forwards": n_p,
+                         "note": "the same forwards enqueued back to back, ONE synchronise at the end (what a serving loop does); the headline keeps the reference's per-forward synchronise"}}
+    if gf:
+        out["step_roofline"] = {"algorithmic_flops": gf * 1e9 * B, "achieved_tflops": round(gf * B / (sec_s / n_s) / 1e3, 2),
+                                "frac_fp32": round(gf * B / (sec_s / n_s) / 1e3 / FP32_PEAK_TFLOPS, 4), "note": "eval-forward flops (2 x MAC, SURVEY.md 8d) against the fp32 vector / MFMA peak"}
+    if not args.no_kernel_pass:
+        _forward_kernel_pass(out, model, x, args.workload, B)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_eval_baseline(cfg)
+    return out
+
+
+def _sliding_mode(args, cfg, dev):
+    """BASELINE configs[4]: sliding-window inference on a synthetic full BraTS volume (1, 4, 240, 240, 155), overlap 0.5, sw_batch_size 2, arg-max + BraTS Dice included
+    (utils/inference_brats.py:190-218 with train_config batch_size 2) -> volumes/s"""
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils import inference_runtime as IR
+    from veloxseg_amd.utils.metric.metrics_brats import cal_dice
+    roi, overlap = int(args.roi), 0.5
+    torch.manual_seed(12345)
+    model = VeloxSeg(**cfg).to(dev).eval()
+    VF.set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    vol = torch.randn(1, 4, 240, 240, 155, device=dev)
+    label = torch.randint(0, 4, (1, 1, 240, 240, 155), device=dev)
+    starts = IR.window_starts((240, 240, 155), (roi,) * 3, IR.scan_interval((240, 240, 155), (roi,) * 3, overlap))
+    res = {}
+
+    def one():
+        logits, labels = IR.infer_volume(model, vol, (roi,) * 3, 2, overlap)
+        res["dice"] = cal_dice(labels, label)
+    with torch.inference_mode():
+        one()
+        n, sec = _timed_loop(one, min(args.t0, 3.0), min(args.t1, 20.0), args.steps, sync_each=True)
+    gf = EVAL_GFLOP.get(args.workload)
+    out = {"metric": "sliding-window inference volumes/s (4x240x240x155, overlap 0.5, sw_batch 2; arg-max + BraTS Dice included)", "value": round(n / sec, 3), "unit": "volumes/s",
+           "n_gpus": 1, "steps": n, "warmup": f"{min(args.t0, 3.0)} s", "ms_per_step": round(sec / n * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": _dtype_string(args), "data": "synthetic (randn volume, random labels, random-init weights, seed 12345)",
+           "config": {"workload": f"brats sliding window: volume (1, 4, 240, 240, 155), roi {roi}^3, overlap {overlap}, sw_batch_size 2 -> {len(starts)} windows; VeloxSeg in_ch=[4] n_classes=4 "
+                                  f"windows {cfg['min_big_window_sizes']}", "windows": len(starts), "windows_per_s": round(len(starts) * n / sec, 1),
+                      "launch": "utils.inference_runtime.infer_volume: window planner on the host, vx_sw_extract / accumulate / finalize (+ fused uint8 arg-max), the window batch's forward replayed as a launch tape"},
+           "dice_vs_random_labels": [round(float(v), 4) for v in res["dice"]]}
+    if gf:
+        fl = gf * 1e9 * len(starts)
+        out["step_roofline"] = {"algorithmic_flops": fl, "achieved_tflops": round(fl / (sec / n) / 1e12, 2), "frac_fp32": round(fl / (sec / n) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                "note": "eval-forward flops of every window (2 x MAC) against the fp32 vector / MFMA peak; blending / arg-max / Dice are HBM passes"}
+    if not args.no_kernel_pass:
+        xw = torch.randn(2, 4, roi, roi, roi, device=dev)
+        _forward_kernel_pass(out, model, xw, args.workload, 2)
+    if not args.no_cpu_baseline:
+        # the oracle's driver (oracle/sliding_window_oracle.py) on the host cores: ONE window batch of the same roi (bounded sample), scaled to the volume's window count
+        from oracle import veloxseg_oracle as O
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from recipe import fill_state_dict
+        ocfg = O.OracleConfig(**cfg)
+        sd = fill_state_dict(O.state_dict_template(ocfg), seed=7)
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        xw = torch.randn(2, 4, roi, roi, roi)
+        with torch.no_grad():
+            O.forward(xw[:1], sd, ocfg, training=False)
+            t0 = time.time()
+            O.forward(xw, sd, ocfg, training=False)
+            dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / (dt * len(starts) / 2), 5), "unit": "volumes/s", "cores": cores, "kind": "port",
+                               "sample": f"one window batch (2 x 4 x {roi}^3) through the oracle's forward, scaled to the volume's {len(starts)} windows (blending / arg-max not included)",
+                               "host_cores": os.cpu_count(), "cpu_model": _cpu_model()}
+    return out
+
+
+def _kernel_pass(out, prof, model, workload, B):
+    """per-kernel table of one eager pass (`prof` = _hip.profile_end(): HIP events around every C-ABI call on its launch stream) -> out["kernel_pass"], the `roofline`
+    object of the dominant kernel family, `roofline_pwa` (MFMA utilisation of every attention launch) and `roofline_jlc` (the JLC spatial stage at level 1)"""
+    from veloxseg_amd import _hip as H      # noqa: F401
+    args = type("A", (), {"workload": workload})()
+    rows = sorted(((v[1], v[0], k) for k, v in prof.items()), reverse=True)
+    total = sum(r[0] for r in rows)
+    top = rows[0]
+    out["kernel_pass"] = {"total_ms": round(total, 3), "top": [{"entry": r[2][0], "key": list(r[2][1]), "launches": r[1], "ms": round(r[0], 4)} for r in rows[:8]]}
+    # `roofline` = the kernel with the most time per step, AGGREGATED BY ENTRY over every shape it is launched with (the top row of the rocprofv3 summary, which is
+    # by kernel name): sum of algorithmic flops / sum of launch time.  avg_launch_ms / achieved / frac are measured live (HIP events on the launch stream, above);
+    # `profile` repeats them from the committed rocprofv3 --kernel-trace --stats summary so that frac can be recomputed from profiles/ alone.
+    alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd",
+             # (round 5: the operator code calls the entries that take the pieces mode explicitly -- same kernels, one more trailing integer in the key)
+             "vx_jlc_wgrad_tz_ns": "vx_jlc_wgrad_tz", "vx_jlc_tz_fwd_ns": "vx_jlc_tz_fwd", "vx_jlc_tz_bwd_ns": "vx_jlc_tz_bwd", "vx_jlc_tz_prep_ns": "vx_jlc_tz_prep"}
+    rows = [(t_, n_, (alias.get(nm, nm) if nm.endswith("_ns") else nm, (tuple(k_[:-1]) if nm.endswith("_ns") and nm != "vx_jlc_tz_prep_ns" else k_))) for t_, n_, (nm, k_) in rows]
+    fam = {}
+    for tot_ms, n, (name, key) in rows:
+        base = alias.get(name, name)
+        rf = roofline_for(base, key, tot_ms / n, model)
+        f = fam.setdefault(base, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "known": True, "shapes": [], "last": None})
+        f["ms"] += tot_ms
+        f["n"] += n
+        if rf.get("achieved") is None:
+            f["known"] = False
+        else:
+            f["flops"] += rf["algorithmic_flops"] * n
+            f["bytes"] += rf["algorithmic_bytes"] * n
+            f["shapes"].append({"args": list(key)[:8], "launches": n, "avg_launch_ms": round(tot_ms / n, 5), "frac": rf["frac"], "algorithmic_flops": rf["algorithmic_flops"]})
+            f["last"] = rf
+    out["kernel_pass"]["families"] = [{"entry": k_, "launches": f["n"], "ms": round(f["ms"], 4)} for k_, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]]
+    out["roofline"] = None
+    for base, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        if not f["known"] or f["last"] is None:
+            continue
+        rf = dict(f["last"])
+        for drop in ("args", "traffic_source", "pairs", "kernels", "mfma"):
+            rf.pop(drop, None)
+        sec = f["ms"] * 1e-3
+        rf.update({"kernel": base, "device_kernel": DEVICE_KERNEL.get(base, base), "launches_per_step": f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 5),
+                   "algorithmic_flops": f["flops"] / f["n"], "algorithmic_bytes": f["bytes"] / f["n"], "share_of_step": round(f["ms"] / total, 4), "shapes": f["shapes"]})
+        if rf["bound"] == "mfma":
+            ach = f["flops"] / sec / 1e12
+        else:
+            ach = f["bytes"] / sec / 1e9
+        rf["achieved"], rf["frac"] = round(ach, 3), round(ach / rf["peak"], 4)
+        if "frac_of_fp32_mfma_peak" in rf:
+            rf["frac_of_fp32_mfma_peak"] = round(ach / FP32_PEAK_TFLOPS, 4)
+        rf["traffic"], tsrc = _pmc_traffic_family(DEVICE_KERNEL.get(base, base), B)
+        if tsrc:
+            rf["traffic_source"] = tsrc
+        pr = _profile_row(DEVICE_KERNEL.get(base, base), args.workload, B)
+        if pr is not None:
+            pr["achieved"] = round((f["flops"] if rf["bound"] == "mfma" else f["bytes"]) / f["n"] / (pr["avg_launch_ms"] * 1e-3) / (1e12 if rf["bound"] == "mfma" else 1e9), 3)
+            pr["frac"] = round(pr["achieved"] / rf["peak"], 4)
+            rf["profile"] = pr
+        if base == "vx_jlc_wgrad_tz":
+            fc = _wg_full_chip(f["shapes"], rf["peak"])
+            if fc is not None:
+                rf["full_chip"] = fc
+        for sh in rf["shapes"]:
+            sh.pop("algorithmic_flops", None)
+        out["roofline"] = rf
+        break
+    # PWA attention (north_star: "MFMA utilisation for PWA against gfx950 peak"): every attention launch of the step, forward and backward
+    att = []
+    for tot_ms, n, (name, key) in rows:
+        if name in ("vx_pwa_attn_fwd", "vx_pwa_attn_bwd", "vx_pwa_attn_fwd_mb", "vx_pwa_attn_bwd_mb", "vx_pwa_attn_bwd_nofold_mb", "vx_pwa_attn_bwd_nofold"):
+            base = "vx_pwa_attn_fwd" if "fwd" in name else "vx_pwa_attn_bwd"
+            ra = roofline_for(base, key, tot_ms / n, model)
+            if ra.get("achieved") is not None:
+                att.append({"pass": "forward" if "fwd" in name else "backward", "c_qk": key[2], "c_v": key[3], "pairs": ra.get("pairs"), "avg_launch_ms": ra["avg_launch_ms"],
+                            "achieved_tflops": ra["achieved"], "frac_fp32_peak": ra["frac"], **(ra.get("mfma") or {})})
+    if att:
+        out["roofline_pwa"] = att
+    # the JLC spatial stage (the reference's Johnson-Lindenstrauss block, conv_blocks.py:51-58) at level 1: its own roofline object with PMC traffic
+    jname = "vx_jlc_tz_fwd" if any(name == "vx_jlc_tz_fwd" for _, _, (name, _k) in rows) else "vx_jlc_conv_fwd"
+    jl = [(tot_ms / n, n, key) for tot_ms, n, (name, key) in rows if name == jname]
+    if jl:
+        ms1, n1, key1 = max(jl, key=lambda t: t[2][3] * t[2][4] * t[2][5])
+        rj = roofline_for(jname, key1, ms1, model)
+        rj["launches_per_step"] = n1
+        if rj.get("traffic") is None and jname == "vx_jlc_tz_fwd":
+            # north_star: "rocprof-reported achieved HBM GB/s for JLC" -- the counter bytes of THIS launch shape (group width = first template argument of vx_tz_k) from the
+            # committed PMC passes over the launch time measured live
+            cg = int(key1[1]) // max(int(key1[2]), 1)
+            tr, src = _pmc_traffic_family(r"vx_tz_k<%d, \d+, \d+, \d+, false, " % cg, B)
+            if tr is not None:
+                rj["traffic"], rj["traffic_source"] = tr, src
+        if rj.get("traffic") is not None:
+            rj["achieved_gbs"] = round(rj["traffic"] / (ms1 * 1e-3) / 1e9, 1)
+            rj["frac_hbm"] = round(rj["achieved_gbs"] / HBM_PEAK_GBS, 4)
+            if rj.get("algorithmic_bytes"):
+                rj["traffic_over_algorithmic"] = round(rj["traffic"] / rj["algorithmic_bytes"], 3)
+        out["roofline_jlc"] = rj
 
 
 def _newest_pmc():
@@ -582,7 +801,7 @@ _pmc_traffic.workload = None
 
 
 # C-ABI entry -> regular expression of the device kernel(s) behind it in a rocprofv3 kernel summary
-DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_cl_fwd": r"vx_jlc_cl_fwd_k<", "vx_jlc_cl_bwd": r"vx_jlc_cl_bwd_k<", "vx_jlc_tz_fwd": r"vx_tz_k<.*, false>", "vx_jlc_tz_bwd": r"vx_tz_k<.*, true>", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
+DEVICE_KERNEL = {"vx_jlc_wgrad_tz": r"vx_jlc_wg_k<", "vx_jlc_cl_fwd": r"vx_jlc_cl_fwd_k<", "vx_jlc_cl_bwd": r"vx_jlc_cl_bwd_k<", "vx_jlc_tz_fwd": r"vx_tz_k<\d+, \d+, \d+, \d+, false, ", "vx_jlc_tz_bwd": r"vx_tz_k<\d+, \d+, \d+, \d+, true, ", "vx_jlc_conv_fwd": r"vx_jlc_conv_fwd_k<",
                  "vx_jlc_conv_bwd": r"vx_jlc_conv_bwd_k<", "vx_pwa_attn_bwd": r"vx_pwa_attn_bwd_(both|q|kv)_k<|vx_pwa_attn_bwd1h?_k", "vx_pwa_attn_fwd": r"vx_pwa_attn_(mfma_)?fwd_k<",
                  "vx_expand_fwd_mfma_split": r"vx_expand_fwd_split_k<", "vx_expand_bwd_data_mfma_split": r"vx_expand_bwd_data_split_k<", "vx_expand_wgrad_mfma_split": r"vx_expand_wgrad_split_k<",
                  "vx_mlp_fwd": r"vx_mlp_fwd_k<", "vx_mlp_bwd": r"vx_mlp_bwd_k<", "vx_seg_loss_ds_fwd": r"vx_seg_loss_ds_fwd_k<", "vx_seg_loss_ds_bwd": r"vx_seg_loss_ds_bwd_k<",

@@ -572,7 +572,7 @@ int vx_tape_launch_node(VxTape* tape, int node, void* stream);
 int vx_tape_set_fuzz(int seed, float max_us, float prob);
 /* raw bytes of launch parameter k of node i (at most `cap`, at most the host allocation that holds it; *got = bytes copied; memset nodes: k = 0 -> {dst, bytes});
  * vx_tape_node_kind: answer -- 0 kernel, 1 memset, 2 copy, 3 marker */
-int vx_tape_node_param(const VxTape* tape, int node, int k, void* out, int cap, int* got);
+int vx_tape_node_param(const VxTape* tape, int node, int k, int nparams, int size, void* out, int cap, int* got);
 int vx_tape_node_kind(const VxTape* tape, int node);
 int vx_tape_replay_prefix(VxTape* tape, void* stream, int k);   /* the first k nodes as vx_tape_replay runs them, the rest one after the other on `stream` behind the join */
 /* the process-wide stream of lane `lane` (lane % 4).  The four lane streams are chosen at first use so that they sit on different hardware

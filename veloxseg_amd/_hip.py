@@ -70,6 +70,12 @@ class _Lib:
             raise RuntimeError(
                 f"veloxseg_amd: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for the VeloxSeg hot path.")
+        # the gfx950 packed-fp32 op_sel hazard (veloxseg_amd/_isa_fix.py): a library without a valid stamp -- not scanned since it was (re)built or copied in -- is
+        # disassembled and checked ONCE (about 10 s) before any of its kernels can run; a hazardous library raises.  VELOXSEG_SKIP_ISA_CHECK=1 skips (debugging only).
+        if os.environ.get("VELOXSEG_SKIP_ISA_CHECK") != "1":
+            from . import _isa_fix
+            if not _isa_fix.stamp_ok(LIB_PATH):
+                _isa_fix.check_library(LIB_PATH, verbose=False)
         dll = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)          # AttributeError here = header/library drift

@@ -710,7 +710,14 @@ struct AxpyFn : public torch::autograd::Function<AxpyFn> {
 
 // Paired-Window Attention core (gather -> attention -> scatter for all modalities, PWA.py:106-200,308-327) as ONE C++ autograd node: no interpreter
 // between its ~6 forward / ~9 backward launches.  qkv = (q0, k0, v0, q1, k1, v1, ...), (B, nb*heads*c, g0, g1, g2) each.
+// the dispatcher ops receive the {seed, step} tensor from the caller; the states keep a REFERENCE to it (not only its address), so a temporary the caller drops
+// before backward stays alive and the backward regenerates the masks of the forward.  The slot is filled by op_pwa / op_jlc / op_ffn right before apply() and taken
+// by the node's forward on the same thread.
+thread_local Tensor RNG_KEEP;
+inline Tensor take_rng_keep() { Tensor t = RNG_KEEP; RNG_KEEP = Tensor(); return t; }
+
 struct PwaState {
+    Tensor rs_keep;
     VxPwaPlan plan;
     Tensor tq, tk, tv, O, lse, tbl, iq, ik, iv, table, mbits;      // mbits: the forward's dropout keep bits (1 per score element), read by the one-pass backward
     std::vector<std::vector<int64_t>> shapes;
@@ -722,6 +729,7 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
                                  at::TensorList qkv) {
         auto h = put_state<PwaState>(ctx);
         PwaState& st = h->s;
+        st.rs_keep = take_rng_keep();
         st.plan = *reinterpret_cast<const VxPwaPlan*>(plan_ptr);
         const VxPwaPlan* pp = &st.plan;
         const int M = (int)qkv.size() / 3;
@@ -1175,6 +1183,7 @@ struct JLCFn : public torch::autograd::Function<JLCFn> {
         if (w2.has_value() && w2->defined()) { ws.push_back(*w2); bs.push_back(b2.value()); }
         auto r = jlc_fwd_f(x, ws, bs, (int)G, l1w, l1b, l2w, l2b, p, site, rs, (int64_t)cur_stream(x));
         put_state<std::shared_ptr<JLCState>>(ctx)->s = r.second;
+        ctx->saved_data["rng"] = take_rng_keep();
         return r.first;
     }
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -1191,6 +1200,7 @@ struct FFNFn : public torch::autograd::Function<FFNFn> {
                           double p, int64_t site1, int64_t site2, int64_t rs) {
         auto r = ffn_fwd_f(y, gamma, beta, w1, b1, w2, b2, p, site1, site2, rs, (int64_t)cur_stream(y));
         put_state<std::shared_ptr<FFNState>>(ctx)->s = r.second;
+        ctx->saved_data["rng"] = take_rng_keep();
         return r.first;
     }
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -1221,6 +1231,17 @@ inline int lab_kind_of(const Tensor& labels) {
     if (labels.scalar_type() == at::kByte) return 2;
     TORCH_CHECK(false, "veloxseg::seg_loss: labels must be int64 / int32 / uint8, got ", labels.scalar_type());
 }
+// the (at most four) head weights as a device tensor, cached per (values, device) as functional._head_weights does: a blocking pageable H2D copy per call would stall the
+// stream and is illegal inside a stream capture.  The first call of a new weight set must happen outside a capture (TrainEngine's warm-up pass does).
+inline Tensor head_weights_on(const std::vector<float>& w, const c10::Device& dev) {
+    static std::map<std::pair<std::vector<float>, int>, Tensor> cache;
+    auto key = std::make_pair(w, (int)dev.index());
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    Tensor t = at::tensor(w, at::TensorOptions().dtype(at::kFloat)).to(dev, /*non_blocking=*/false);
+    cache.emplace(key, t);
+    return t;
+}
 struct LossFn : public torch::autograd::Function<LossFn> {
     static Tensor forward(AutogradContext* ctx, at::TensorList outs, const Tensor& labels_in, const OptT& sr_in, std::vector<double> head_w, double w_rc, double w_f, int64_t num_modal) {
         auto h = put_state<LossState>(ctx);
@@ -1240,7 +1261,7 @@ struct LossFn : public torch::autograd::Function<LossFn> {
         void* s_ = cur_stream(l0);
         const int B = st.B, C = st.C;
         auto fopt = l0.options();
-        Tensor hw = at::tensor(std::vector<float>(head_w.begin(), head_w.end()), at::TensorOptions().dtype(at::kFloat)).to(l0.device(), /*non_blocking=*/false);
+        Tensor hw = head_weights_on(std::vector<float>(head_w.begin(), head_w.end()), l0.device());
         Tensor seg_acc = at::empty({(long)nh * (1 + (long)B * C * 3)}, fopt.dtype(at::kDouble));
         const float* lp[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int i = 0; i < nh; ++i) lp[i] = fp(st.logits[i]);
@@ -1390,6 +1411,7 @@ const void* rs_of(const OptT& rng_state, double p, const char* what) {
     if (p <= 0.0) return nullptr;
     TORCH_CHECK(rng_state.has_value() && rng_state->defined(), "veloxseg::", what, ": dropout p > 0 needs rng_state = the {seed, step} int64 device tensor (veloxseg_amd.functional.rng_state(device))");
     TORCH_CHECK(rng_state->is_cuda() && rng_state->scalar_type() == at::kLong && rng_state->numel() >= 2 && rng_state->is_contiguous(), "veloxseg::", what, ": rng_state must be a contiguous CUDA int64 tensor {seed, step}");
+    RNG_KEEP = *rng_state;          // the node's state takes a reference: the backward reads {seed, step} through this tensor's address
     return rng_state->data_ptr();
 }
 VxPwaPlan plan_of(at::IntArrayRef grid, at::IntArrayRef n, int64_t heads, at::IntArrayRef small, at::IntArrayRef nwin) {

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <malloc.h>
+#include <atomic>
 #include <vector>
 #include <algorithm>
 #include <unordered_map>
@@ -557,12 +558,18 @@ extern "C" int vx_tape_info(const VxTape* T, int* n_nodes, int* n_kernels, int* 
 // Schedule fuzzing (tests / tools/tape_soak.py): with probability `prob` a replay puts a 0 .. max_us spin kernel in front of a node on its lane, so that the lanes
 // drift against each other in a different way in every replay -- a dependency the tape does not carry then shows in tens of replays instead of thousands,
 // whatever the durations of the kernels around it happen to be.  Seeded (the sequence of delays is reproducible), off by default.
-static unsigned g_fuzz_state = 0;
+// (replays may come from several host threads -- data-parallel ranks in one process, tests: the generator state is an atomic, and with fuzzing off -- the default --
+// fuzz_delay returns before touching it)
+static std::atomic<unsigned> g_fuzz_state{0};
 static float g_fuzz_max_us = 0.0f, g_fuzz_prob = 0.0f;
-static inline float fuzz_u01() { g_fuzz_state = g_fuzz_state * 1664525u + 1013904223u; return (float)(g_fuzz_state >> 8) * (1.0f / 16777216.0f); }
+static inline float fuzz_u01() {
+    unsigned o = g_fuzz_state.load(std::memory_order_relaxed), n;
+    do { n = o * 1664525u + 1013904223u; } while (!g_fuzz_state.compare_exchange_weak(o, n, std::memory_order_relaxed));
+    return (float)(n >> 8) * (1.0f / 16777216.0f);
+}
 extern "C" int vx_tape_set_fuzz(int seed, float max_us, float prob) {
     VX_REQUIRE(max_us >= 0.0f && max_us <= 1e4f && prob >= 0.0f && prob <= 1.0f, "vx_tape_set_fuzz: max_us 0 .. 1e4, prob 0 .. 1");
-    g_fuzz_state = (unsigned)seed * 2654435761u + 12345u;
+    g_fuzz_state.store((unsigned)seed * 2654435761u + 12345u, std::memory_order_relaxed);
     g_fuzz_max_us = max_us;
     g_fuzz_prob = prob;
     return 0;
@@ -744,7 +751,7 @@ extern "C" int vx_tape_launch_node(VxTape* T, int i, void* stream) {
 // Raw bytes of launch parameter k of kernel node i (memset nodes: k = 0 -> {dst, width * elementSize} as two 8-byte words).  The graph node owns one host allocation per
 // parameter and HIP does not expose the sizes: at most malloc_usable_size() bytes are copied (an upper bound of the parameter's size), *got = how many.  The caller knows
 // the parameter list from the kernel's (demangled) name: veloxseg_amd/tape_audit.py node_pointers().
-extern "C" int vx_tape_node_param(const VxTape* T, int i, int k, void* out, int cap, int* got) {
+extern "C" int vx_tape_node_param(const VxTape* T, int i, int k, int nparams, int size, void* out, int cap, int* got) {
     VX_REQUIRE(T && out && got && cap > 0 && k >= 0 && i >= 0 && i < (int)T->nodes.size(), "vx_tape_node_param: bad arguments");
     const TapeNode& nd = T->nodes[i];
     *got = 0;
@@ -755,9 +762,13 @@ extern "C" int vx_tape_node_param(const VxTape* T, int i, int k, void* out, int 
         *got = 16;
         return 0;
     }
+    /* the parameter array has as many entries as the kernel's signature (the caller parsed it: nparams); `size` = the parameter's byte size when the caller knows it
+       (8 for a pointer).  size 0 = a by-value struct whose size the demangled name does not give: the runtime keeps every captured parameter in a malloc block of its
+       own (ROCclr GraphKernelNode::copyParams), so the block size bounds the copy -- diagnostics only (tape_audit.py), never on a launch path */
+    VX_REQUIRE(nparams > 0 && k < nparams, "vx_tape_node_param: parameter %d of a kernel with %d parameters", k, nparams);
     if (nd.type != T_KERNEL || !nd.k.kernelParams || !nd.k.kernelParams[k]) return 0;
-    const size_t us = malloc_usable_size(nd.k.kernelParams[k]);
-    const size_t n = us < (size_t)cap ? us : (size_t)cap;
+    size_t n = size > 0 ? (size_t)size : malloc_usable_size(nd.k.kernelParams[k]);
+    if (n > (size_t)cap) n = (size_t)cap;
     memcpy(out, nd.k.kernelParams[k], n);
     *got = (int)n;
     return 0;

@@ -1136,12 +1136,30 @@ class TrainEngine:
             self._check_flag_timeouts()
             self._adamw()
 
+    def _check_labels(self, labels):
+        """The engine's label volume is uint8 when the class count allows (one byte per voxel instead of the loader's int64): a narrowing copy would WRAP an
+        out-of-range value (a 255 / -1 ignore label, BraTS label 4 left unmapped) into a valid class id, where the reference's CrossEntropyLoss raises a device assert
+        (utils/loss.py:17).  The first label batches (VELOXSEG_LABEL_CHECK: "first" = 4 batches, the default; "always"; "off") are range-checked before the copy -- one
+        small reduction + a host read each; VELOXSEG_LABELS=int64 keeps the loader's dtype instead."""
+        mode = os.environ.get("VELOXSEG_LABEL_CHECK", "first")
+        n = getattr(self, "_label_checks", 0)
+        if mode == "off" or (mode != "always" and n >= 4) or labels.dtype == self.labels.dtype:
+            return
+        self._label_checks = n + 1
+        ncls = self._n_classes() if hasattr(self.model, "n_classes") or hasattr(self.model, "decoder") else None
+        lo, hi = int(labels.min()), int(labels.max())
+        top = (ncls - 1) if ncls else torch.iinfo(self.labels.dtype).max
+        if lo < 0 or hi > top:
+            raise ValueError(f"TrainEngine.step: label values span [{lo}, {hi}] but the model has classes 0..{top}; the engine's {self.labels.dtype} label buffer would wrap them "
+                             "silently (map ignore / raw labels first, e.g. BraTS 4 -> 3, or run with VELOXSEG_LABELS=int64)")
+
     # ---- public ---------------------------------------------------------------------------------
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One optimisation step.  x / labels are copied into the engine's static buffers (None = reuse their contents)."""
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if labels is not None:
+            self._check_labels(labels)
             self.labels.copy_(labels, non_blocking=True)
         if not self.model.training:
             self.model.train()

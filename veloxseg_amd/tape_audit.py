@@ -417,16 +417,18 @@ def node_pointers(tape, i: int, sig: str, segments: Sequence[Tuple[int, int]]):
         j = _b.bisect_right(bases, v) - 1
         return j >= 0 and v < segments[j][0] + segments[j][1]
     if kind == 1:
-        H.call("vx_tape_node_param", tape.handle, int(i), 0, ctypes.addressof(buf), 4096, ctypes.addressof(got))
+        H.call("vx_tape_node_param", tape.handle, int(i), 0, 1, 16, ctypes.addressof(buf), 4096, ctypes.addressof(got))
         v = int.from_bytes(bytes(buf[0:8]), "little")
         return [(0, "memset dst", False, v)]
     if kind != 0:
         return res
-    for k, ty in enumerate(_split_params(sig)):
+    params = _split_params(sig)
+    for k, ty in enumerate(params):
         t = ty.replace(" __restrict__", "").strip()
         if t in _SCALARS or t.replace("const ", "").replace(" const", "") in _SCALARS:
             continue
-        H.call("vx_tape_node_param", tape.handle, int(i), k, ctypes.addressof(buf), 4096, ctypes.addressof(got))
+        is_ptr = t.endswith("*") and "(" not in t
+        H.call("vx_tape_node_param", tape.handle, int(i), k, len(params), 8 if is_ptr else 0, ctypes.addressof(buf), 4096, ctypes.addressof(got))
         nb = got.value
         if t.endswith("*") and "(" not in t:
             if nb >= 8:
