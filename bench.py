@@ -393,7 +393,7 @@ def main():
                                          "patch-expand weight gradients from three bf16 pieces.  Every other kernel computes in fp32 (patch-expand pieces knob: %d)"
                                          % _expand_split()) if args.dtype == "f32" and _expand_split() else "fp32",
                           "hip_graph": bool(eng.use_graph), "lanes_on_distinct_hw_queues": (H.query("vx_tape_lanes_distinct") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None),
-                          "lane_on_caller_queue": (H.query("vx_tape_lane_on_caller_queue") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
+                          "lane_calibration_spin_us": (H.query("vx_tape_spin_us") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "lane_on_caller_queue": (H.query("vx_tape_lane_on_caller_queue") if (eng.use_graph and getattr(eng, "replay_mode", "") == "tape") else None), "launch": (("launch tape per captured stage (csrc/tape.hip): %d kernel nodes on up to %d HIP streams, %d cross-stream dependencies (flag kernels: a store on the producing stream, a poll on the waiting one; events with VELOXSEG_TAPE_FLAGS=0)" % (sum(t.n_kernels for t in _tapes(eng)), max(t.n_lanes for t in _tapes(eng)), sum(t.n_events for t in _tapes(eng)))) if getattr(eng, "replay_mode", "") == "tape" else "hipGraph per stage") if eng.use_graph else "eager; decoder branches, encoder conv chain and per-modality PWA halves on forked HIP streams", "final_loss": round(loss, 5)}}
     if rank == 0 and comm is not None:
         out["comm"] = comm
     if rank == 0 and lane_probe is not None:

@@ -153,7 +153,7 @@ int vx_pw_mfma_set_wide(int on);
  *   norm 1 = channels-first LayerNorm(gamma, beta, eps): FFN tail of a PWA block, PWA.py:437 with attention_utils.py:45-71.  Backward: dx is the
  *            complete input gradient INCLUDING the residual branch (dout + ...); dgamma / dbeta are accumulated.
  *   dw1, db1, dw2, db2 are accumulated (float atomics, one per element and block).  Dropout: site1 / p1 on the hidden activation (masks of
- *   vx_gelu_drop_*), site2 / p2 on the output (masks of vx_axpy_drop_*).  vx_mlp_supported: (C, R) in {(16,48), (32,96), (16,32), (32,64)}, V % 4 == 0.
+ *   vx_gelu_drop_*), site2 / p2 on the output (masks of vx_axpy_drop_*).  vx_mlp_supported: (C, R) in {(16,48), (16,32)}, V % 4 == 0 (C >= 32 runs on the tile-GEMM chains, vx_inmlp_*).
  * --------------------------------------------------------------------------------------------- */
 int vx_mlp_supported(int C, int R, long V);
 int vx_mlp_bwd_nparts(int B, int C, long V);
@@ -183,6 +183,24 @@ int vx_jlc_gk(const float* d_o, const float* y1, const float* y3, const float* y
               float* g5, long BC, long V, void* stream);
 int vx_jlc_conv_bwd(const float* g1, const float* g3, const float* g5, const float* w1, const float* w3, const float* w5, const float* d_o,
                     float* dx, int B, int C, int G, int D, int H, int W, void* stream);
+/* bf16 STORAGE mode (round 6; BASELINE configs[1], reference speed_test.py:122,127 = torch.amp.autocast: 16-bit conv outputs, fp32 statistics and sums).  The *_h
+ * entries are the entries above with the BLOCK-INTERNAL tensors of a JLC block -- the conv outputs y_k, o, and in the backward pass dn, d_o and the g_k -- as arrays of
+ * 16-bit bf16 elements (`void*`) when h16 != 0 (h16 = 0: exactly the fp32 entries); the block's input x, its output and the incoming gradient dout stay fp32.  A stored
+ * value is the round-to-nearest-even bf16 of the fp32 result; InstanceNorm statistics are taken over the ROUNDED values (what every reader loads). */
+int vx_jlc_mid_fwd_h(const float* x, const void* y1, const void* y3, const void* y5, const double* part_y, int nty, float* stats_y, void* o,
+                     double* part_o, long BC, long V, float eps, int h16, void* stream);
+int vx_jlc_mid_bwd_h(const float* dout, const void* dn, const float* part_dn, int npd, const void* o, const float* stats_o, const void* y1,
+                     const void* y3, const void* y5, const float* stats_y, void* d_o, float* part_t, long BC, long V, int h16, void* stream);
+int vx_jlc_gk_h(const void* d_o, const void* y1, const void* y3, const void* y5, const float* stats_y, const float* part_t, void* g1, void* g3,
+                void* g5, long BC, long V, int h16, void* stream);
+/* vx_mlp_fwd / vx_mlp_bwd with x (the block's o) and the returned dx (= dn) as bf16 arrays (norm = 0, the JLC form, only) */
+int vx_mlp_fwd_h(const void* x, int norm, const double* part, int nparts, float* stats, const float* gamma, const float* beta,
+                 const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int C, int R, long V, float eps,
+                 const void* seed_ptr, unsigned long long site1, float p1, unsigned long long site2, float p2, int h16, void* stream);
+int vx_mlp_bwd_h(const void* x, int norm, const float* stats, const float* gamma, const float* beta, const float* w1, const float* b1,
+                 const float* w2, const float* dout, void* dx, float* part_out, float* dgamma, float* dbeta, float* dw1, float* db1,
+                 float* dw2, float* db2, int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site1, float p1,
+                 unsigned long long site2, float p2, int h16, void* stream);
 
 /* The same three grouped convolutions (conv_blocks.py:51-58) and their input gradient as Toeplitz GEMMs on the bf16 matrix pipe with fp32-exact products
  * (csrc/jlc_mfma.hip; group width 4 / 8 / 16, W % 4 == 0):
@@ -237,6 +255,14 @@ int vx_jlc_tz_bwd_ns(const float* g1, const float* g3, const float* g5, const fl
                      int B, int C, int G, int D, int H, int W, int pieces, void* stream);
 int vx_jlc_wgrad_tz_ns(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
                        int pieces, void* stream);
+/* bf16 storage mode (h16 != 0 needs pieces = 1, plain bf16 operands): y_k (forward outputs), g_k and d_o (backward inputs) as bf16 arrays; x, dx and the weight
+ * gradients stay fp32 */
+int vx_jlc_tz_fwd_h(const float* x, const float* img, const float* b1, const float* b3, const float* b5, void* y1, void* y3, void* y5, double* part,
+                    int B, int C, int G, int D, int H, int W, int pieces, int h16, void* stream);
+int vx_jlc_tz_bwd_h(const void* g1, const void* g3, const void* g5, const float* img, const float* w1, const void* d_o, float* dx,
+                    int B, int C, int G, int D, int H, int W, int pieces, int h16, void* stream);
+int vx_jlc_wgrad_tz_h(const float* x, const void* g1, const void* g3, const void* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                      int pieces, int h16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(affine=False, eps) = stats + apply  (common_function.py:63-66; used at conv_blocks.py:18,36,54,65,
@@ -582,6 +608,7 @@ int vx_tape_replay_prefix(VxTape* tape, void* stream, int k);   /* the first k n
 int vx_tape_lane_stream(void* any_stream, int lane, void** out);
 int vx_spin_us(float us, void* stream);   /* diagnostic: one wave spins for `us` microseconds on `stream` (stand-in for a collective: tools/comm_standin_probe.py) */
 int vx_tape_lanes_distinct(void);
+int vx_tape_spin_us(void);                        /* answer: spin length (us) of the lane calibration: 60, or longer when one spin alone measured > 80 us (slow launches / event hops: a profiler) */
 int vx_tape_lane_on_caller_queue(void);           /* answer: the lane whose stream shares the hardware queue of the stream the lanes were chosen from (placed on lane 2); 4 = none found, 5 = lanes not chosen yet */
 int vx_tape_permute_lanes(const int* perm4);      /* lane k is served by the stream that served lane perm4[k] (a permutation of 0..3); diagnostics */      /* answer, not a status: how many of the 4 lane streams were measured to overlap pairwise (-1 before the first use) */
 

@@ -98,3 +98,58 @@ def test_bf16_training_tracks_fp32_training():
     for a, r in zip(losses["bf16"], losses["fp32"]):
         assert abs(a - r) <= 1e-2 * abs(r), losses
     assert losses["bf16"][-1] < losses["bf16"][0]
+
+
+# ---- round 6: the bf16 STORAGE mode (16-bit tensors in HBM, not only 16-bit matrix-pipe operands) --------------------------------------------------------------
+def _rel(a, r):
+    a, r = a.detach().double().cpu(), r.detach().double().cpu()
+    return float((a - r).norm() / r.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("case", [("L1_32cube", 2, 16, 4, 3, (32, 32, 32)), ("L1_aniso", 1, 16, 4, 3, (8, 12, 20)), ("hecktor_L1", 1, 16, 4, 3, (32, 32, 16))], ids=lambda c: c[0])
+def test_jlc_block_with_16bit_internal_tensors_vs_oracle(case):
+    """JLC block (conv_blocks.py:41-75) of the 32^3 level in the bf16 storage mode: y_k, o, dn, d_o, g_k are bf16 arrays, bf16 MFMA operands.  Against the fp32 CPU
+    oracle: relative RMS error of the output and of every gradient <= 1e-2 (bf16 rounding = 2^-9 per stored element / operand, fp32 sums); and the 16-bit storage must
+    not be much worse than the operand-only mode of rounds 2-5 (VELOXSEG_BF16_STORAGE=0), which shares its matrix-pipe arithmetic."""
+    from oracle import veloxseg_oracle as O
+    from test_fused_blocks_gpu import _jlc_module, _oracle_sd
+    from veloxseg_amd import functional as VF
+    _, B, C, G, r, sp = case
+    cm = VF.cpp_module()
+    x = torch.randn(B, C, *sp, generator=torch.Generator().manual_seed(5))
+    gy = None
+    res = {}
+    for storage in (True, False):
+        VF.BF16_STORAGE = storage
+        try:
+            VF.set_precision("bf16")
+            assert cm.get_act_bf16() == storage
+            m = _jlc_module(C, G, r, 0.0, 3).cuda().train()
+            xg = x.cuda().requires_grad_(True)
+            out = m(xg)
+            if gy is None:
+                gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(6))
+            out.backward(gy.cuda())
+            torch.cuda.synchronize()
+            res[storage] = (out.detach().cpu(), xg.grad.cpu(), {k: p.grad.cpu().clone() for k, p in m.named_parameters()}, m)
+        finally:
+            VF.BF16_STORAGE = True
+            VF.set_precision("fp32")
+    m = res[True][3]
+    sd = _oracle_sd(m)
+    xc = x.clone().requires_grad_(True)
+    ref = O.jlc(xc, sd, "blk.", G, 0.0, True)
+    ref.backward(gy)
+    errs = {}
+    for storage in (True, False):
+        out, dx, gr, _ = res[storage]
+        e = {"out": _rel(out, ref), "dx": _rel(dx, xc.grad)}
+        for k, g in gr.items():
+            if "spatial_convs" in k and k.endswith("bias"):
+                continue          # behind an InstanceNorm: zero by construction, not computed
+            e["d" + k] = _rel(g, sd["blk." + k].grad)
+        errs[storage] = e
+    assert float((res[True][0] - res[False][0]).abs().max()) > 0, "the storage mode must take the 16-bit kernels"
+    for k, v in errs[True].items():
+        assert v <= 1e-2, (k, v, errs)
+        assert v <= 3.0 * errs[False][k] + 2e-3, (k, v, errs[False][k])

@@ -41,6 +41,7 @@ struct Flags {
     bool jlc_wg_tz = true;            // the three JLC weight gradients in one matrix-pipe launch (csrc/jlc_mfma.hip vx_jlc_wgrad_tz); 0 = the VALU kernels of conv_wgrad.hip
     bool jlc_tile = true;             // JLC blocks of the C = 64 / 128 levels on the fused spatial kernels + the tile-GEMM channel stage (A/B: 0 = per-operator launches)
     bool expand_wgrad_split = true;   // (A/B) the patch-expand weight gradient follows expand_split too
+    bool act_bf16 = false;     // bf16 STORAGE mode (round 6): block-internal tensors of the JLC blocks and the full-resolution heads / their gradients are bf16 arrays (set_act_bf16; functional.set_precision("bf16"))
     int expand_split = 0;      // fp32 mode: patch-expand products as 3 (2 pieces) / 6 (3 pieces) bf16 MFMAs per pair instead of fp32 MFMAs (csrc/expand_mfma.hip, fp32-accurate)
     double in_eps = 1e-5, ln_eps = 1e-6;
 } F;
@@ -540,6 +541,7 @@ struct JLCFusedState {
     Tensor w1, w3, w5, b1, b3, b5, l1w, l1b, l2w, l2b;
     int B = 0, C = 0, G = 0, D = 0, H = 0, W = 0, R = 0, nch = 0;
     bool tile = false;                           // channel stage on the tile-GEMM kernels (pwa_fused.hip vx_inmlp_*: C = 64 / 128) instead of mlp.hip
+    bool h16 = false;                            // bf16 storage mode: y, o (and dn, d_o, g in the backward pass) are bf16 arrays
     double p = 0; int64_t site = 0; const void* rs = nullptr;
 };
 struct JLCState {
@@ -950,32 +952,37 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 f.nch = vx_jlc_nchunks(BC, V);
                 auto dopt = f.x.options().dtype(at::kDouble);
                 Tensor part_y = at::empty({3, BC, nty, 2}, dopt), part_o = at::empty({BC, (long)f.nch, 2}, dopt);
-                f.y = at::empty({3, B, C, D, H, W}, f.x.options());
-                float* yp = f.y.data_ptr<float>();
+                // bf16 storage mode: the block-internal tensors as bf16 arrays where the whole chain has 16-bit instances (Toeplitz convs with plain bf16 operands + mlp.hip channel stage)
+                f.tile = tile_ok;
+                f.tz_pieces = tz ? vx_jlc_tz_pieces() : 0;
+                f.h16 = F.act_bf16 && tz && !tile_ok && f.tz_pieces == 1 && F.jlc_wg_tz && vx_jlc_wgrad_tz_ok(C, G, D, H, W) == 1 && V > 64;
+                auto iopt = f.h16 ? f.x.options().dtype(at::kBFloat16) : f.x.options();
+                const long esz = f.h16 ? 2 : 4;
+                f.y = at::empty({3, B, C, D, H, W}, iopt);
+                char* yp = (char*)f.y.data_ptr();
                 const long n1 = BC * V;
+                void *y1 = yp, *y3 = yp + esz * n1, *y5 = yp + 2 * esz * n1;
                 if (tz) {
-                    f.tz_pieces = vx_jlc_tz_pieces();
                     f.img = at::empty({(long)vx_jlc_tz_img_floats_ns(C, G, f.tz_pieces)}, f.x.options());
                     VX(vx_jlc_tz_prep_ns, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, f.tz_pieces, s_);
-                    VX(vx_jlc_tz_fwd_ns, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, f.tz_pieces, s_);
+                    VX(vx_jlc_tz_fwd_h, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), y1, y3, y5, part_y.data_ptr<double>(), B, C, G, D, H, W, f.tz_pieces, (int)f.h16, s_);
                 } else if (cl) {
                     f.img = at::empty({(long)vx_jlc_cl_img_floats(C, G)}, f.x.options());
                     f.img_cl = true;
                     VX(vx_jlc_cl_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
-                    VX(vx_jlc_cl_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
+                    VX(vx_jlc_cl_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), (float*)y1, (float*)y3, (float*)y5, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 } else
-                VX(vx_jlc_conv_fwd, fp(f.x), fp(f.w1), fp(f.w3), fp(f.w5), fp(f.b1), fp(f.b3), fp(f.b5), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
+                VX(vx_jlc_conv_fwd, fp(f.x), fp(f.w1), fp(f.w3), fp(f.w5), fp(f.b1), fp(f.b3), fp(f.b5), (float*)y1, (float*)y3, (float*)y5, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 f.stats_y = at::empty({3, BC, 2}, f.x.options());
                 f.stats_o = at::empty({BC, 2}, f.x.options());
-                f.o = at::empty_like(f.x);
-                VX(vx_jlc_mid_fwd, fp(f.x), yp, yp + n1, yp + 2 * n1, part_y.data_ptr<double>(), nty, mp(f.stats_y), mp(f.o), part_o.data_ptr<double>(), BC, V, (float)F.in_eps, s_);
+                f.o = at::empty(f.x.sizes(), iopt);
+                VX(vx_jlc_mid_fwd_h, fp(f.x), (const void*)y1, (const void*)y3, (const void*)y5, part_y.data_ptr<double>(), nty, mp(f.stats_y), f.o.data_ptr(), part_o.data_ptr<double>(), BC, V, (float)F.in_eps, (int)f.h16, s_);
                 Tensor out = at::empty_like(f.x);
-                f.tile = tile_ok;
                 if (tile_ok) VX(vx_inmlp_fwd, fp(f.o), part_o.data_ptr<double>(), f.nch, mp(f.stats_o), fp(l1w), fp(l1b), fp(l2w), fp(l2b), mp(out), B, C, R, V, (float)F.in_eps,
                                 f.rs, (unsigned long long)site, (float)p, s_);
                 else
-                VX(vx_mlp_fwd, fp(f.o), 0, part_o.data_ptr<double>(), f.nch, mp(f.stats_o), nullptr, nullptr, fp(l1w), fp(l1b), fp(l2w), fp(l2b), mp(out), B, C, R, V,
-                               (float)F.in_eps, f.rs, 0ull, 0.0f, (unsigned long long)site, (float)p, s_);
+                VX(vx_mlp_fwd_h, (const void*)f.o.data_ptr(), 0, part_o.data_ptr<double>(), f.nch, mp(f.stats_o), nullptr, nullptr, fp(l1w), fp(l1b), fp(l2w), fp(l2b), mp(out), B, C, R, V,
+                               (float)F.in_eps, f.rs, 0ull, 0.0f, (unsigned long long)site, (float)p, (int)f.h16, s_);
                 return {out, st};
             }
         }
@@ -1011,7 +1018,10 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
             const int B = f.B, C = f.C, G = f.G, D = f.D, H = f.H, W = f.W, R = f.R;
             const long V = (long)D * H * W, BC = (long)B * C, n1 = BC * V;
             const int npd = f.tile ? vx_inmlp_tiles(V) : vx_mlp_bwd_nparts(B, C, V);
-            Tensor dn = at::empty_like(f.x), part_dn = at::empty({BC, (long)npd, 2}, f.x.options());
+            auto iopt = f.h16 ? f.x.options().dtype(at::kBFloat16) : f.x.options();
+            const long esz = f.h16 ? 2 : 4;
+            const int h16 = f.h16 ? 1 : 0;
+            Tensor dn = at::empty(f.x.sizes(), iopt), part_dn = at::empty({BC, (long)npd, 2}, f.x.options());
             if (f.tile) {
                 // scratch operands of the two weight gradients (dW2 = dz h^T, dW1 = da nhat^T): one grouped launch, a sink of the pass
                 Tensor sc_n = at::empty_like(f.x), sc_dz = at::empty_like(f.x), sc_h = at::empty({B, R, D, H, W}, f.x.options()), sc_da = at::empty({B, R, D, H, W}, f.x.options());
@@ -1024,22 +1034,24 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
                     VX(vx_pw_wgrad_group, ptrs, dims, 2, nullptr, nullptr, 0, s);
                 });
             } else
-            VX(vx_mlp_bwd, fp(f.o), 0, fp(f.stats_o), nullptr, nullptr, fp(f.l1w), fp(f.l1b), fp(f.l2w), fp(dout), mp(dn), mp(part_dn), nullptr, nullptr,
+            VX(vx_mlp_bwd_h, (const void*)f.o.data_ptr(), 0, fp(f.stats_o), nullptr, nullptr, fp(f.l1w), fp(f.l1b), fp(f.l2w), fp(dout), dn.data_ptr(), mp(part_dn), nullptr, nullptr,
                            grad_ptr(f.l1w), grad_ptr(f.l1b), grad_ptr(f.l2w), grad_ptr(f.l2b), B, C, R, V, (float)F.in_eps, f.rs, 0ull, 0.0f,
-                           (unsigned long long)f.site, (float)f.p, s_);
-            const float* yp = f.y.data_ptr<float>();
-            Tensor d_o = at::empty_like(f.x), part_t = at::empty({3, BC, (long)f.nch, 2}, f.x.options());
-            VX(vx_jlc_mid_bwd, fp(dout), fp(dn), fp(part_dn), npd, fp(f.o), fp(f.stats_o), yp, yp + n1, yp + 2 * n1, fp(f.stats_y), mp(d_o), mp(part_t), BC, V, s_);
-            Tensor g = at::empty({3, B, C, D, H, W}, f.x.options());
-            float* gp = g.data_ptr<float>();
-            VX(vx_jlc_gk, fp(d_o), yp, yp + n1, yp + 2 * n1, fp(f.stats_y), fp(part_t), gp, gp + n1, gp + 2 * n1, BC, V, s_);
+                           (unsigned long long)f.site, (float)f.p, h16, s_);
+            const char* yp = (const char*)f.y.data_ptr();
+            const void *y1 = yp, *y3 = yp + esz * n1, *y5 = yp + 2 * esz * n1;
+            Tensor d_o = at::empty(f.x.sizes(), iopt), part_t = at::empty({3, BC, (long)f.nch, 2}, f.x.options());
+            VX(vx_jlc_mid_bwd_h, fp(dout), (const void*)dn.data_ptr(), fp(part_dn), npd, (const void*)f.o.data_ptr(), fp(f.stats_o), y1, y3, y5, fp(f.stats_y), d_o.data_ptr(), mp(part_t), BC, V, h16, s_);
+            Tensor g = at::empty({3, B, C, D, H, W}, iopt);
+            char* gp = (char*)g.data_ptr();
+            void *g1 = gp, *g3 = gp + esz * n1, *g5 = gp + 2 * esz * n1;
+            VX(vx_jlc_gk_h, (const void*)d_o.data_ptr(), y1, y3, y5, fp(f.stats_y), fp(part_t), g1, g3, g5, BC, V, h16, s_);
             Tensor dx;
             if (need_x) {
-                dx = dn;                                      // dn is dead after vx_jlc_mid_bwd: reuse its storage
-                if (f.img.defined() && f.img_cl) VX(vx_jlc_cl_bwd, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
-                else if (f.img.defined()) VX(vx_jlc_tz_bwd_ns, gp, gp + n1, gp + 2 * n1, fp(f.img), fp(f.w1), fp(d_o), mp(dx), B, C, G, D, H, W, f.tz_pieces, s_);
+                dx = f.h16 ? at::empty_like(f.x) : dn;           // fp32 storage: dn is dead after vx_jlc_mid_bwd, reuse it (the 16-bit dn cannot hold the block's fp32 input gradient)
+                if (f.img.defined() && f.img_cl) VX(vx_jlc_cl_bwd, (const float*)g1, (const float*)g3, (const float*)g5, fp(f.img), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                else if (f.img.defined()) VX(vx_jlc_tz_bwd_h, (const void*)g1, (const void*)g3, (const void*)g5, fp(f.img), fp(f.w1), (const void*)d_o.data_ptr(), mp(dx), B, C, G, D, H, W, f.tz_pieces, h16, s_);
                 else
-                VX(vx_jlc_conv_bwd, gp, gp + n1, gp + 2 * n1, fp(f.w1), fp(f.w3), fp(f.w5), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
+                VX(vx_jlc_conv_bwd, (const float*)g1, (const float*)g3, (const float*)g5, fp(f.w1), fp(f.w3), fp(f.w5), fp(d_o), mp(dx), B, C, G, D, H, W, s_);
             }
             // weight gradients (the bias gradients behind an InstanceNorm are zero by construction: see below)
             grad_ptr(f.b1); grad_ptr(f.b3); grad_ptr(f.b5);
@@ -1058,6 +1070,12 @@ static Tensor jlc_bwd_f(std::shared_ptr<JLCState> st, const Tensor& dout_in, boo
                 const bool wtz = !wga && tzok;
                 const int wg_pieces = f.tz_pieces ? f.tz_pieces : vx_jlc_tz_pieces();          // fixed NOW: the closure may be launched at the end of the encoder backward
                 wgrad_submit(s_, f.x.device().index(), [=](void* s) {
+                    if (h16) {                    // bf16 storage mode (Toeplitz kernels only: f.h16 implies tz)
+                        const char* gh = (const char*)gk.data_ptr();
+                        TORCH_CHECK(wtz, "veloxseg_amd.jlc: the 16-bit g_k of the bf16 storage mode need the matrix-pipe weight-gradient kernel");
+                        VX(vx_jlc_wgrad_tz_h, fp(xk), (const void*)gh, (const void*)(gh + 2 * n1), (const void*)(gh + 4 * n1), dw1, dw3, dw5, B, C, G, D, H, W, wg_pieces, 1, s);
+                        return;
+                    }
                     const float* gq = gk.data_ptr<float>();
                     if (wga) {
                         VX(vx_jlc_wgrad_gather, fp(xk), gq, gq + n1, gq + 2 * n1, dw1, dw3, dw5, B, C, G, D, H, W, s);
@@ -1641,6 +1659,8 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("set_expand_split", [](int64_t ns) { F.expand_split = (ns == 2 || ns == 3 || ns == 22) ? (int)ns : 0; });      // fp32 mode: split products in the patch-expand layers (2/3 bf16 pieces, 22 = two scaled fp16 pieces; 0 = fp32 MFMA)
     m.def("get_expand_split", []() { return F.expand_split; });
     m.def("set_tile_min_c", [](int64_t c) { F.tile_min_c = (int)c; });
+    m.def("set_act_bf16", [](bool on) { F.act_bf16 = on; }, "bf16 STORAGE mode: block-internal tensors of the JLC blocks / full-resolution heads and their gradients as bf16 arrays (with set_bf16_expand and vx_jlc_tz_set_pieces(1): functional.set_precision('bf16'))");
+    m.def("get_act_bf16", []() { return F.act_bf16; });
     m.def("set_upconv_wgrad_mfma", [](bool on) { F.upconv_wgrad_mfma = on; });
     m.def("set_jlc_tz", [](bool on) { F.jlc_tz = on; });          // A/B (tests): JLC grouped convs on the matrix pipe (default) or the fp32 VALU kernels
     m.def("get_jlc_tz", []() { return F.jlc_tz; });

@@ -362,13 +362,17 @@ __global__ void __launch_bounds__(512) vx_jlc_conv_bwd_k(VxJlc p) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------- element-wise stages
+// TI = element type of the block-INTERNAL tensors (y_k, o, dn, d_o, g_k): float, or vx_bf16 in the bf16 storage mode (they are `const void*` here, typed by the
+// kernel's template argument); the block's input x and the incoming gradient dout are fp32 in both modes
 struct VxJlcMid {
-    const float *x, *y1, *y3, *y5, *o, *dout, *dn, *d_o;
+    const float *x, *dout;
+    const void *y1, *y3, *y5, *o, *dn, *d_o;
     const double *part_y;        // [3][BC][nty][2]
     const float *part_dn;        // [BC][npd][2]   (sum dn, sum dn*nhat)   from vx_mlp_bwd
     const float *part_t_in;      // [3][BC][nch][2] (sum t, sum t*yhat)
     const float *stats_y, *stats_o;    // [3][BC][2], [BC][2]  (mean, rstd)
-    float *out_o, *out_do, *g1, *g3, *g5, *stats_y_out, *part_t;
+    void *out_o, *out_do, *g1, *g3, *g5;
+    float *stats_y_out, *part_t;
     double* part_o;              // [BC][nch][2]
     long BC, V, chunk;
     int nty, npd, nch;
@@ -390,10 +394,12 @@ __device__ __forceinline__ void vx_fold_f(const float* __restrict__ pp, int n, f
     s = vx_wave_sum(s);
     q = vx_wave_sum(q);
 }
-__device__ __forceinline__ float4 vx_ld4(const float* p, long i) { return *reinterpret_cast<const float4*>(p + i); }
 
 // o = x + sum_k GELU((y_k - mean_k) * rstd_k); partial (sum, sumsq) of o per chunk.  grid (nch, BC)
+template <typename TI>
 __global__ void __launch_bounds__(256) vx_jlc_mid_fwd_k(VxJlcMid p) {
+    const TI* __restrict__ y1 = (const TI*)p.y1; const TI* __restrict__ y3 = (const TI*)p.y3; const TI* __restrict__ y5 = (const TI*)p.y5;
+    TI* __restrict__ out_o = (TI*)p.out_o;
     __shared__ float st[6];
     __shared__ double redd[8];
     const long bc = blockIdx.y;
@@ -417,13 +423,15 @@ __global__ void __launch_bounds__(256) vx_jlc_mid_fwd_k(VxJlcMid p) {
     const long c1 = c0 + p.chunk < p.V ? c0 + p.chunk : p.V;
     float s = 0.0f, q = 0.0f;
     for (long i = c0 + 4 * tid; i < c1; i += 1024) {
-        const float4 xv = vx_ld4(p.x, base + i), a = vx_ld4(p.y1, base + i), b3 = vx_ld4(p.y3, base + i), c5 = vx_ld4(p.y5, base + i);
+        const float4 xv = vx_ld4(p.x, base + i), a = vx_ld4(y1, base + i), b3 = vx_ld4(y3, base + i), c5 = vx_ld4(y5, base + i);
         float4 o;
         o.x = xv.x + vx_gelu_fast((a.x - m1) * r1) + vx_gelu_fast((b3.x - m3) * r3) + vx_gelu_fast((c5.x - m5) * r5);
         o.y = xv.y + vx_gelu_fast((a.y - m1) * r1) + vx_gelu_fast((b3.y - m3) * r3) + vx_gelu_fast((c5.y - m5) * r5);
         o.z = xv.z + vx_gelu_fast((a.z - m1) * r1) + vx_gelu_fast((b3.z - m3) * r3) + vx_gelu_fast((c5.z - m5) * r5);
         o.w = xv.w + vx_gelu_fast((a.w - m1) * r1) + vx_gelu_fast((b3.w - m3) * r3) + vx_gelu_fast((c5.w - m5) * r5);
-        *reinterpret_cast<float4*>(p.out_o + base + i) = o;
+        // (16-bit o: the statistics of the following norm are those of the values its readers load)
+        o.x = vx_round_as<TI>(o.x); o.y = vx_round_as<TI>(o.y); o.z = vx_round_as<TI>(o.z); o.w = vx_round_as<TI>(o.w);
+        vx_st4(out_o, base + i, o);
         s += (o.x + o.y) + (o.z + o.w);
         q = fmaf(o.x, o.x, q); q = fmaf(o.y, o.y, q); q = fmaf(o.z, o.z, q); q = fmaf(o.w, o.w, q);
     }
@@ -439,7 +447,11 @@ __global__ void __launch_bounds__(256) vx_jlc_mid_fwd_k(VxJlcMid p) {
 }
 
 // d_o = dout + rstd_o * (dn - mean(dn) - nhat * mean(dn * nhat)); partial sums of t_k = d_o * GELU'(yhat_k) and t_k * yhat_k.  grid (nch, BC)
+template <typename TI>
 __global__ void __launch_bounds__(256) vx_jlc_mid_bwd_k(VxJlcMid p) {
+    const TI* __restrict__ y1 = (const TI*)p.y1; const TI* __restrict__ y3 = (const TI*)p.y3; const TI* __restrict__ y5 = (const TI*)p.y5;
+    const TI* __restrict__ o_ = (const TI*)p.o; const TI* __restrict__ dn_ = (const TI*)p.dn;
+    TI* __restrict__ out_do = (TI*)p.out_do;
     __shared__ float mm[2];
     __shared__ float redf[4][6];
     const long bc = blockIdx.y;
@@ -459,15 +471,15 @@ __global__ void __launch_bounds__(256) vx_jlc_mid_bwd_k(VxJlcMid p) {
     const long c1 = c0 + p.chunk < p.V ? c0 + p.chunk : p.V;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long i = c0 + 4 * tid; i < c1; i += 1024) {
-        const float4 go = vx_ld4(p.dout, base + i), dn = vx_ld4(p.dn, base + i), ov = vx_ld4(p.o, base + i);
-        const float4 a = vx_ld4(p.y1, base + i), b3 = vx_ld4(p.y3, base + i), c5 = vx_ld4(p.y5, base + i);
+        const float4 go = vx_ld4(p.dout, base + i), dn = vx_ld4(dn_, base + i), ov = vx_ld4(o_, base + i);
+        const float4 a = vx_ld4(y1, base + i), b3 = vx_ld4(y3, base + i), c5 = vx_ld4(y5, base + i);
         const float gov[4] = {go.x, go.y, go.z, go.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
         const float yv[3][4] = {{a.x, a.y, a.z, a.w}, {b3.x, b3.y, b3.z, b3.w}, {c5.x, c5.y, c5.z, c5.w}};
         float dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float nh = (oo[u] - mo) * ro;
-            dv[u] = gov[u] + ro * (dnv[u] - dm1 - nh * dm2);
+            dv[u] = vx_round_as<TI>(gov[u] + ro * (dnv[u] - dm1 - nh * dm2));      // (16-bit d_o: vx_jlc_gk recomputes t_k from the stored value)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float yh = (yv[k][u] - mk[k]) * rk[k];
@@ -476,7 +488,7 @@ __global__ void __launch_bounds__(256) vx_jlc_mid_bwd_k(VxJlcMid p) {
                 acc[2 * k + 1] = fmaf(t, yh, acc[2 * k + 1]);
             }
         }
-        *reinterpret_cast<float4*>(p.out_do + base + i) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        vx_st4(out_do, base + i, make_float4(dv[0], dv[1], dv[2], dv[3]));
     }
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
@@ -491,7 +503,11 @@ __global__ void __launch_bounds__(256) vx_jlc_mid_bwd_k(VxJlcMid p) {
 }
 
 // g_k = rstd_k * (t_k - mean(t_k) - yhat_k * mean(t_k * yhat_k)), t_k recomputed from d_o and y_k.  grid (nch, BC)
+template <typename TI>
 __global__ void __launch_bounds__(256) vx_jlc_gk_k(VxJlcMid p) {
+    const TI* __restrict__ y1 = (const TI*)p.y1; const TI* __restrict__ y3 = (const TI*)p.y3; const TI* __restrict__ y5 = (const TI*)p.y5;
+    const TI* __restrict__ d_o = (const TI*)p.d_o;
+    TI* __restrict__ g1 = (TI*)p.g1; TI* __restrict__ g3 = (TI*)p.g3; TI* __restrict__ g5 = (TI*)p.g5;
     __shared__ float mm[6];
     const long bc = blockIdx.y;
     const int tid = threadIdx.x;
@@ -511,8 +527,8 @@ __global__ void __launch_bounds__(256) vx_jlc_gk_k(VxJlcMid p) {
     const long base = bc * p.V, c0 = (long)blockIdx.x * p.chunk;
     const long c1 = c0 + p.chunk < p.V ? c0 + p.chunk : p.V;
     for (long i = c0 + 4 * tid; i < c1; i += 1024) {
-        const float4 dv = vx_ld4(p.d_o, base + i);
-        const float4 a = vx_ld4(p.y1, base + i), b3 = vx_ld4(p.y3, base + i), c5 = vx_ld4(p.y5, base + i);
+        const float4 dv = vx_ld4(d_o, base + i);
+        const float4 a = vx_ld4(y1, base + i), b3 = vx_ld4(y3, base + i), c5 = vx_ld4(y5, base + i);
         const float d4[4] = {dv.x, dv.y, dv.z, dv.w};
         const float yv[3][4] = {{a.x, a.y, a.z, a.w}, {b3.x, b3.y, b3.z, b3.w}, {c5.x, c5.y, c5.z, c5.w}};
         float gk[3][4];
@@ -524,9 +540,9 @@ __global__ void __launch_bounds__(256) vx_jlc_gk_k(VxJlcMid p) {
                 const float t = d4[u] * vx_gelu_grad_fast(yh);
                 gk[k][u] = rk[k] * (t - t1[k] - yh * t2[k]);
             }
-        *reinterpret_cast<float4*>(p.g1 + base + i) = make_float4(gk[0][0], gk[0][1], gk[0][2], gk[0][3]);
-        *reinterpret_cast<float4*>(p.g3 + base + i) = make_float4(gk[1][0], gk[1][1], gk[1][2], gk[1][3]);
-        *reinterpret_cast<float4*>(p.g5 + base + i) = make_float4(gk[2][0], gk[2][1], gk[2][2], gk[2][3]);
+        vx_st4(g1, base + i, make_float4(gk[0][0], gk[0][1], gk[0][2], gk[0][3]));
+        vx_st4(g3, base + i, make_float4(gk[1][0], gk[1][1], gk[1][2], gk[1][3]));
+        vx_st4(g5, base + i, make_float4(gk[2][0], gk[2][1], gk[2][2], gk[2][3]));
     }
 }
 
@@ -619,35 +635,51 @@ static long vx_jlc_chunk(long BC, long V) {
 }
 extern "C" int vx_jlc_nchunks(long BC, long V) { return vx_cdiv(V, vx_jlc_chunk(BC, V)); }
 
-extern "C" int vx_jlc_mid_fwd(const float* x, const float* y1, const float* y3, const float* y5, const double* part_y, int nty, float* stats_y, float* o,
-                              double* part_o, long BC, long V, float eps, void* stream) {
+// `h16` != 0: the block-internal tensors (y_k, o, dn, d_o, g_k) are vx_bf16 arrays (bf16 storage mode); x and dout are fp32 either way
+extern "C" int vx_jlc_mid_fwd_h(const float* x, const void* y1, const void* y3, const void* y5, const double* part_y, int nty, float* stats_y, void* o,
+                                double* part_o, long BC, long V, float eps, int h16, void* stream) {
     VX_REQUIRE(x && y1 && y3 && y5 && part_y && stats_y && o && part_o && BC > 0 && V > 0 && V % 4 == 0, "vx_jlc_mid_fwd: bad args");
     VxJlcMid p = {};
     p.x = x; p.y1 = y1; p.y3 = y3; p.y5 = y5; p.part_y = part_y; p.nty = nty; p.stats_y_out = stats_y; p.out_o = o; p.part_o = part_o;
     p.BC = BC; p.V = V; p.eps = eps; p.chunk = vx_jlc_chunk(BC, V); p.nch = vx_cdiv(V, p.chunk);
-    vx_jlc_mid_fwd_k<<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (h16) vx_jlc_mid_fwd_k<vx_bf16><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    else vx_jlc_mid_fwd_k<float><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_mid_fwd");
     return 0;
 }
+extern "C" int vx_jlc_mid_fwd(const float* x, const float* y1, const float* y3, const float* y5, const double* part_y, int nty, float* stats_y, float* o,
+                              double* part_o, long BC, long V, float eps, void* stream) {
+    return vx_jlc_mid_fwd_h(x, y1, y3, y5, part_y, nty, stats_y, o, part_o, BC, V, eps, 0, stream);
+}
 
-extern "C" int vx_jlc_mid_bwd(const float* dout, const float* dn, const float* part_dn, int npd, const float* o, const float* stats_o, const float* y1,
-                              const float* y3, const float* y5, const float* stats_y, float* d_o, float* part_t, long BC, long V, void* stream) {
+extern "C" int vx_jlc_mid_bwd_h(const float* dout, const void* dn, const float* part_dn, int npd, const void* o, const float* stats_o, const void* y1,
+                                const void* y3, const void* y5, const float* stats_y, void* d_o, float* part_t, long BC, long V, int h16, void* stream) {
     VX_REQUIRE(dout && dn && part_dn && o && stats_o && y1 && y3 && y5 && stats_y && d_o && part_t && BC > 0 && V > 0 && V % 4 == 0, "vx_jlc_mid_bwd: bad args");
     VxJlcMid p = {};
     p.dout = dout; p.dn = dn; p.part_dn = part_dn; p.npd = npd; p.o = o; p.stats_o = stats_o; p.y1 = y1; p.y3 = y3; p.y5 = y5; p.stats_y = stats_y;
     p.out_do = d_o; p.part_t = part_t; p.BC = BC; p.V = V; p.chunk = vx_jlc_chunk(BC, V); p.nch = vx_cdiv(V, p.chunk);
-    vx_jlc_mid_bwd_k<<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (h16) vx_jlc_mid_bwd_k<vx_bf16><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    else vx_jlc_mid_bwd_k<float><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_mid_bwd");
     return 0;
 }
+extern "C" int vx_jlc_mid_bwd(const float* dout, const float* dn, const float* part_dn, int npd, const float* o, const float* stats_o, const float* y1,
+                              const float* y3, const float* y5, const float* stats_y, float* d_o, float* part_t, long BC, long V, void* stream) {
+    return vx_jlc_mid_bwd_h(dout, dn, part_dn, npd, o, stats_o, y1, y3, y5, stats_y, d_o, part_t, BC, V, 0, stream);
+}
 
-extern "C" int vx_jlc_gk(const float* d_o, const float* y1, const float* y3, const float* y5, const float* stats_y, const float* part_t, float* g1, float* g3,
-                         float* g5, long BC, long V, void* stream) {
+extern "C" int vx_jlc_gk_h(const void* d_o, const void* y1, const void* y3, const void* y5, const float* stats_y, const float* part_t, void* g1, void* g3,
+                           void* g5, long BC, long V, int h16, void* stream) {
     VX_REQUIRE(d_o && y1 && y3 && y5 && stats_y && part_t && g1 && g3 && g5 && BC > 0 && V > 0 && V % 4 == 0, "vx_jlc_gk: bad args");
     VxJlcMid p = {};
     p.d_o = d_o; p.y1 = y1; p.y3 = y3; p.y5 = y5; p.stats_y = stats_y; p.part_t_in = part_t; p.g1 = g1; p.g3 = g3; p.g5 = g5;
     p.BC = BC; p.V = V; p.chunk = vx_jlc_chunk(BC, V); p.nch = vx_cdiv(V, p.chunk);
-    vx_jlc_gk_k<<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    if (h16) vx_jlc_gk_k<vx_bf16><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
+    else vx_jlc_gk_k<float><<<dim3(p.nch, (unsigned)BC), dim3(256), 0, (hipStream_t)stream>>>(p);
     VX_LAUNCH_CHECK("vx_jlc_gk");
     return 0;
+}
+extern "C" int vx_jlc_gk(const float* d_o, const float* y1, const float* y3, const float* y5, const float* stats_y, const float* part_t, float* g1, float* g3,
+                         float* g5, long BC, long V, void* stream) {
+    return vx_jlc_gk_h(d_o, y1, y3, y5, stats_y, part_t, g1, g3, g5, BC, V, 0, stream);
 }

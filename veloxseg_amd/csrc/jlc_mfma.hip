@@ -20,6 +20,7 @@
 // backward: dx = d_o + conv5^T(g5) + conv3^T(g3) + conv1^T(g1): g5 and g3 are staged one after the other (halo 2 / 1) into the same accumulators, the
 //           1x1x1 term and the residual are added from global memory in the epilogue.
 #include "vx_common.h"
+#include <type_traits>
 #include "../../include/veloxseg_hip.h"
 
 typedef __bf16 tz_bf8 __attribute__((ext_vector_type(8)));
@@ -35,13 +36,13 @@ struct TzGeo {          // LDS halo geometry of one source (elements = bf16)
 };
 
 struct VxTz {
-    const float* src[3];            // forward: x; backward: g5, g3, g1
+    const void* src[3];             // forward: x (fp32); backward: g5, g3, g1 (fp32, or vx_bf16 when the kernel's H16 argument is set)
     const uint4* img;               // operand images of this direction
     const float* esc;               // fp16 two-piece mode: scale exponents of the weight images [G][3] (K = 5, 3, 1)
     const float* bias[3];           // forward (order k = 5, 3, 1); may be null
-    const float* res;               // backward: d_o
+    const void* res;                // backward: d_o (fp32 / vx_bf16 as the g_k)
     const float* w1;                // backward: the 1x1x1 weights (C, C/G)
-    float* out[3];                  // forward: y5, y3, y1; backward: dx
+    void* out[3];                   // forward: y5, y3, y1 (fp32 / vx_bf16); backward: dx (fp32)
     double* part;                   // forward: [3][B*C][ntiles][2], k = 0 -> y1, 1 -> y3, 2 -> y5 (layout of vx_jlc_conv_fwd)
     int B, C, G, D, H, W;
     int TD, TH, TWB;                // tile: TD x TH x 4*TWB outputs
@@ -204,12 +205,12 @@ __global__ void __launch_bounds__(256) vx_tz_prep16_k(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------------ halo staging
 // Halo of one source in LDS as NS bf16 planes: elem[s][ci][hd][hh][e], e = w - (w0 - 2) in [0, RW).  A thread stages quads (4 consecutive w, one 16-byte load);
 // the pieces of a quad leave as two packed pairs per piece (4-byte LDS stores: e = 4 qd - 2 is even, not a multiple of 4).
-template <int CG, int NS>
-__device__ __forceinline__ void tz_stage(const float* __restrict__ src, unsigned char* __restrict__ lds, const VxTz& p, const TzGeo& ge, int hw, int b, int g, int d0, int h0,
+template <int CG, int NS, typename TS = float>
+__device__ __forceinline__ void tz_stage(const TS* __restrict__ src, unsigned char* __restrict__ lds, const VxTz& p, const TzGeo& ge, int hw, int b, int g, int d0, int h0,
                                          int w0, int nthr) {
     const int total = ge.nrows * ge.nq;
     const long chan = (long)p.D * p.H * p.W;
-    const float* __restrict__ sb = src + ((long)b * p.C + (long)g * CG) * chan;
+    const TS* __restrict__ sb = src + ((long)b * p.C + (long)g * CG) * chan;
     constexpr int SU = 4;
     for (int it0 = threadIdx.x; it0 < total; it0 += nthr * SU) {
         float4 v[SU];
@@ -228,7 +229,7 @@ __device__ __forceinline__ void tz_stage(const float* __restrict__ src, unsigned
             const int hd = (int)(r2 - ci * ge.HD);
             const int id = d0 - hw + hd, ih = h0 - hw + hh, iw = w0 - 4 + 4 * qd;
             const bool ok = live && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const float4 t_ = *reinterpret_cast<const float4*>(sb + (ok ? (long)ci * chan + ((long)id * p.H + ih) * p.W + iw : 0));
+            const float4 t_ = vx_ld4(sb, ok ? (long)ci * chan + ((long)id * p.H + ih) * p.W + iw : 0L);
             v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
             eo[u] = live ? (int)ci * ge.Sc + hd * ge.Sd + hh * p.RW + 4 * qd - 2 : -(1 << 30);
             qd_[u] = qd;
@@ -422,8 +423,11 @@ __device__ __forceinline__ void tz_accumulate(tz_f4 (&acc)[MTW][NT], const uint4
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the kernel
-template <int CG, int NT, int MTW, int NS, bool BWD, bool F16>
+// H16 (round 6, bf16 storage mode): the block-internal tensors this kernel touches -- forward: the outputs y_k; backward: g_k and d_o -- are vx_bf16 arrays
+template <int CG, int NT, int MTW, int NS, bool BWD, bool F16, bool H16 = false>
 __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
+    static_assert(!H16 || !F16, "16-bit storage is a mode of the bf16-operand kernels");
+    typedef typename std::conditional<H16, vx_bf16, float>::type TI;
     extern __shared__ __attribute__((aligned(16))) unsigned char tz_lds[];
     constexpr int MT = CG / 4, KS = CG / 4, MG = MT / MTW;
     const int lane = threadIdx.x & 63;
@@ -479,8 +483,8 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
     if constexpr (!BWD) {
         const TzGeo& ge = p.geo[0];
         int ex = 0;                                                          // fp16 mode: the tile's scale exponent
-        if constexpr (F16) ex = tz_stage16<CG>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, reinterpret_cast<float*>(tz_lds + p.red_off));
-        else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+        if constexpr (F16) ex = tz_stage16<CG>((const float*)p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, reinterpret_cast<float*>(tz_lds + p.red_off));
+        else if (!(p.dbg & 1)) tz_stage<CG, NS>((const float*)p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
         set_boff(ge);
         __syncthreads();
         float* red = reinterpret_cast<float*>(tz_lds + p.red_off);            // [3][waves][MTW][4][2]
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] *= fs;
             }
-            float* __restrict__ y = p.out[c];
+            TI* __restrict__ y = (TI*)p.out[c];
             const float* __restrict__ bias = p.bias[c];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
@@ -509,8 +513,9 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if (live[nt]) {
-                        const float o0 = acc[mt][nt][0] + bv, o1 = acc[mt][nt][1] + bv, o2 = acc[mt][nt][2] + bv, o3 = acc[mt][nt][3] + bv;
-                        *reinterpret_cast<float4*>(y + ((long)b * p.C + co) * chan + ((long)(d0 + pd[nt]) * p.H + h0 + ph[nt]) * p.W + w0 + pw[nt]) = make_float4(o0, o1, o2, o3);
+                        // (16-bit y: the InstanceNorm statistics are those of the values the readers load)
+                        const float o0 = vx_round_as<TI>(acc[mt][nt][0] + bv), o1 = vx_round_as<TI>(acc[mt][nt][1] + bv), o2 = vx_round_as<TI>(acc[mt][nt][2] + bv), o3 = vx_round_as<TI>(acc[mt][nt][3] + bv);
+                        vx_st4(y, ((long)b * p.C + co) * chan + ((long)(d0 + pd[nt]) * p.H + h0 + ph[nt]) * p.W + w0 + pw[nt], make_float4(o0, o1, o2, o3));
                         s += (o0 + o1) + (o2 + o3);
                         s2 = fmaf(o0, o0, s2); s2 = fmaf(o1, o1, s2); s2 = fmaf(o2, o2, s2); s2 = fmaf(o3, o3, s2);
                     }
@@ -544,8 +549,8 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
         {
             const TzGeo& ge = p.geo[0];
             int ex = 0;
-            if constexpr (F16) ex = tz_stage16<CG>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, scr);
-            else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
+            if constexpr (F16) ex = tz_stage16<CG>((const float*)p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr, scr);
+            else if (!(p.dbg & 1)) tz_stage<CG, NS, TI>((const TI*)p.src[0], tz_lds, p, ge, 2, b, g, d0, h0, w0, nthr);
             set_boff(ge);
             __syncthreads();
             if (!(p.dbg & 2)) tz_accumulate<5, CG, NT, MTW, NS, F16>(acc, img_g, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
@@ -561,8 +566,8 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
         {
             const TzGeo& ge = p.geo[1];
             int ex = 0;
-            if constexpr (F16) ex = tz_stage16<CG>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr, scr);
-            else if (!(p.dbg & 1)) tz_stage<CG, NS>(p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr);
+            if constexpr (F16) ex = tz_stage16<CG>((const float*)p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr, scr);
+            else if (!(p.dbg & 1)) tz_stage<CG, NS, TI>((const TI*)p.src[1], tz_lds, p, ge, 1, b, g, d0, h0, w0, nthr);
             set_boff(ge);
             __syncthreads();
             if (!(p.dbg & 2)) tz_accumulate<3, CG, NT, MTW, NS, F16>(acc, img_g + (long)25 * MT * KS * NS * 64, tz_lds, boff, 0, ge.Sd, p.RW, ge.Sc, ge.Sp, mt0);
@@ -575,13 +580,15 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
             }
         }
         // epilogue: + conv1^T(g1) + d_o straight from global memory
-        const float* __restrict__ g1 = p.src[2];
+        const TI* __restrict__ g1 = (const TI*)p.src[2];
+        const TI* __restrict__ res = (const TI*)p.res;
+        float* __restrict__ dxo = (float*)p.out[0];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (!live[nt]) continue;
             const long sp_off = ((long)(d0 + pd[nt]) * p.H + h0 + ph[nt]) * p.W + w0 + pw[nt];
             for (int cc = 0; cc < CG; ++cc) {
-                const float4 gv = *reinterpret_cast<const float4*>(g1 + ((long)b * p.C + g * CG + cc) * chan + sp_off);
+                const float4 gv = vx_ld4(g1, ((long)b * p.C + g * CG + cc) * chan + sp_off);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
                     const float wv = p.w1[(long)(g * CG + cc) * CG + (mt0 + mt) * 4 + q];
@@ -592,8 +599,8 @@ __global__ void __launch_bounds__(512) vx_tz_k(VxTz p) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const long off = ((long)b * p.C + g * CG + (mt0 + mt) * 4 + q) * chan + sp_off;
-                const float4 r = *reinterpret_cast<const float4*>(p.res + off);
-                *reinterpret_cast<float4*>(p.out[0] + off) = make_float4(acc[mt][nt][0] + r.x, acc[mt][nt][1] + r.y, acc[mt][nt][2] + r.z, acc[mt][nt][3] + r.w);
+                const float4 r = vx_ld4(res, off);
+                *reinterpret_cast<float4*>(dxo + off) = make_float4(acc[mt][nt][0] + r.x, acc[mt][nt][1] + r.y, acc[mt][nt][2] + r.z, acc[mt][nt][3] + r.w);
             }
         }
     }
@@ -610,6 +617,9 @@ static thread_local int t_tz_pieces = 0;
 static inline int tz_pieces() { return t_tz_pieces ? t_tz_pieces : g_tz_pieces; }
 namespace { struct TzPiecesScope { int prev; explicit TzPiecesScope(int ns) : prev(t_tz_pieces) { t_tz_pieces = ns; } ~TzPiecesScope() { t_tz_pieces = prev; } }; }
 static inline bool tz_pieces_valid(int ns) { return (ns >= 1 && ns <= 3) || ns == 22; }
+// bf16 storage of the block-internal tensors (the *_h entries, round 6): a call-scoped flag like the pieces mode; only with plain bf16 operands (pieces = 1)
+static thread_local int t_tz_h16 = 0;
+namespace { struct TzH16Scope { int prev; explicit TzH16Scope(int h) : prev(t_tz_h16) { t_tz_h16 = h; } ~TzH16Scope() { t_tz_h16 = prev; } }; }
 static int g_tz_dbg = 0;
 extern "C" int vx_jlc_tz_set_debug(int mask) { g_tz_dbg = mask; return 0; }
 // 3 / 2 / 1 bf16 pieces per fp32 operand (6 / 3 / 1 piece products), or 22 = two scaled fp16 pieces (22 significant bits, 3 piece products)
@@ -753,20 +763,20 @@ extern "C" int vx_jlc_tz_prep(const float* w1, const float* w3, const float* w5,
     return 0;
 }
 
-template <int CG, int NT, int MTW, int NS, bool BWD, bool F16>
+template <int CG, int NT, int MTW, int NS, bool BWD, bool F16, bool H16 = false>
 static int tz_launch_t(const VxTz& p, const TzPlan& pl, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)vx_tz_k<CG, NT, MTW, NS, BWD, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+        if (hipFuncSetAttribute((const void*)vx_tz_k<CG, NT, MTW, NS, BWD, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
         attr = true;
     }
     const dim3 grid((unsigned)(p.nTd * p.nTh * p.nTw * p.G * p.B));
-    vx_tz_k<CG, NT, MTW, NS, BWD, F16><<<grid, dim3(64 * pl.nwaves), pl.shm, st>>>(p);
+    vx_tz_k<CG, NT, MTW, NS, BWD, F16, H16><<<grid, dim3(64 * pl.nwaves), pl.shm, st>>>(p);
     return 0;
 }
-template <int NS, bool BWD, bool F16 = false>
+template <int NS, bool BWD, bool F16 = false, bool H16 = false>
 static int tz_launch(const VxTz& p, const TzPlan& pl, hipStream_t st) {
-#define TZ_CASE(cg, nt, mtw) if (pl.CG == cg && pl.NT == nt && pl.MTW == mtw) return tz_launch_t<cg, nt, mtw, NS, BWD, F16>(p, pl, st)
+#define TZ_CASE(cg, nt, mtw) if (pl.CG == cg && pl.NT == nt && pl.MTW == mtw) return tz_launch_t<cg, nt, mtw, NS, BWD, F16, H16>(p, pl, st)
     TZ_CASE(4, 1, 1); TZ_CASE(4, 2, 1); TZ_CASE(4, 4, 1);
     TZ_CASE(8, 1, 1); TZ_CASE(8, 2, 1); TZ_CASE(8, 4, 1); TZ_CASE(8, 1, 2); TZ_CASE(8, 2, 2);
     TZ_CASE(16, 1, 1); TZ_CASE(16, 2, 1); TZ_CASE(16, 4, 1); TZ_CASE(16, 1, 2); TZ_CASE(16, 2, 2); TZ_CASE(16, 1, 4);
@@ -785,8 +795,10 @@ extern "C" int vx_jlc_tz_fwd(const float* x, const float* img, const float* b1, 
     p.esc = img + 2 * tz_img_elems(C, G, tz_pieces()) * 4;
     p.bias[0] = b5; p.bias[1] = b3; p.bias[2] = b1;
     p.out[0] = y5; p.out[1] = y3; p.out[2] = y1; p.part = part; p.dbg = g_tz_dbg;
+    VX_REQUIRE(!t_tz_h16 || tz_pieces() == 1, "vx_jlc_tz_fwd: 16-bit outputs need plain bf16 operands (pieces = 1, the bf16 mode)");
     const int rc = tz_pieces() == 22 ? tz_launch<2, false, true>(p, pl, (hipStream_t)stream)
-                   : NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
+                   : NS == 3 ? tz_launch<3, false>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, false>(p, pl, (hipStream_t)stream)
+                   : t_tz_h16 ? tz_launch<1, false, false, true>(p, pl, (hipStream_t)stream) : tz_launch<1, false>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_fwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_fwd");
     return 0;
@@ -803,8 +815,10 @@ extern "C" int vx_jlc_tz_bwd(const float* g1, const float* g3, const float* g5, 
     p.img = reinterpret_cast<const uint4*>(img) + tz_img_elems(C, G, tz_pieces());
     p.esc = img + 2 * tz_img_elems(C, G, tz_pieces()) * 4;
     p.w1 = w1; p.res = d_o; p.out[0] = dx; p.dbg = g_tz_dbg;
+    VX_REQUIRE(!t_tz_h16 || tz_pieces() == 1, "vx_jlc_tz_bwd: 16-bit inputs need plain bf16 operands (pieces = 1, the bf16 mode)");
     const int rc = tz_pieces() == 22 ? tz_launch<2, true, true>(p, pl, (hipStream_t)stream)
-                   : NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
+                   : NS == 3 ? tz_launch<3, true>(p, pl, (hipStream_t)stream) : NS == 2 ? tz_launch<2, true>(p, pl, (hipStream_t)stream)
+                   : t_tz_h16 ? tz_launch<1, true, false, true>(p, pl, (hipStream_t)stream) : tz_launch<1, true>(p, pl, (hipStream_t)stream);
     VX_REQUIRE(rc == 0, "vx_jlc_tz_bwd: no kernel instance (rc %d) for group width %d, NT %d, MTW %d", rc, pl.CG, pl.NT, pl.MTW);
     VX_LAUNCH_CHECK("vx_jlc_tz_bwd");
     return 0;
@@ -851,10 +865,12 @@ __device__ __forceinline__ void wg_split_store(float4 v, unsigned char* lds, lon
 // one descriptor per (thread, item), decoded ONCE (the divisions cost more than a step's arithmetic when repeated every step): `g` = element offset inside plane 0 of the
 // source tensor (the plane term pl * H * W is added per step), `l` = LDS element offset inside slot 0 (x: the x buffer), flags: bits 0..1 kind (0 x, 1 g5, 2 g3, 3 g1),
 // bit 2 live (the item exists), bit 3 ok (inside the volume; else zeros are stored)
-struct WgDesc { const float* b; int l, f; };      // b: the item's element in plane 0 of ITS tensor (pointer chosen once: a per-step pointer select goes through a scratch table)
+// (H16: the g_k tensors are vx_bf16 arrays -- their items' addresses advance 2 bytes per element and are fetched with 8-byte loads; x is fp32 either way)
+struct WgDesc { const char* b; int l, f; };      // b: the item's element in plane 0 of ITS tensor (pointer chosen once: a per-step pointer select goes through a scratch table)
+template <bool H16 = false>
 __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int cob, int cib, int h0) {
     WgDesc r;
-    r.b = p.x; r.l = 0; r.f = 0;
+    r.b = (const char*)p.x; r.l = 0; r.f = 0;
     const int nqx = p.XR / 4, rows = p.TH + 4;
     const int nx = p.nb * 4 * rows * nqx;
     const int chan = p.D * p.H * p.W;
@@ -865,7 +881,7 @@ __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int co
         const int b = sg * p.nb + s, ih = h0 - 2 + row, iw = 4 * qd - 4;
         const bool ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         r.f = 4 | (ok ? 8 : 0);
-        r.b = p.x + (ok ? (long)(b * p.C + cib + ci) * chan + ih * p.W + iw : 0);
+        r.b = (const char*)(p.x + (ok ? (long)(b * p.C + cib + ci) * chan + ih * p.W + iw : 0));
         r.l = ((s * 4 + ci) * rows + row) * p.XR + 4 * qd;
         return r;
     }
@@ -881,7 +897,7 @@ __device__ __forceinline__ WgDesc wg_desc(const VxWgT& p, int it, int sg, int co
     const int b = sg * p.nb + s, ih = h0 + row, iw = 4 * qd;
     const bool ok = b < p.B && ih < p.H && iw < p.W;
     r.f = (kind + 1) | 4 | (ok ? 8 : 0);
-    r.b = (kind == 0 ? p.g5 : kind == 1 ? p.g3 : p.g1) + (ok ? (long)(b * p.C + cob + co) * chan + ih * p.W + iw : 0);
+    r.b = (const char*)(kind == 0 ? p.g5 : kind == 1 ? p.g3 : p.g1) + (H16 ? 2L : 4L) * (ok ? (long)(b * p.C + cob + co) * chan + ih * p.W + iw : 0);
     r.l = p.GB + ((s * 4 + co) * (p.TH + 1) + row) * p.WS + 4 * qd;
     return r;
 }
@@ -893,6 +909,7 @@ template <bool SP> __device__ __forceinline__ int wg_s5(const VxWgT&, int pl) { 
 template <bool SP> __device__ __forceinline__ int wg_s3(const VxWgT&, int pl) { return (SP ? 6 : 5) + (pl + 60) % (SP ? 4 : 3); }
 template <bool SP> __device__ __forceinline__ int wg_s1(const VxWgT&, int pl) { return SP ? 10 + ((pl + 60) & 1) : 8; }
 template <bool SP> __device__ __forceinline__ int wg_xo(const VxWgT& p, int dx) { return SP ? ((dx + 60) & 1) * p.XP : 0; }
+template <bool H16 = false>
 __device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (&ds)[WG_NPF], const VxWgT& p, int dx, int dg0, int dg1) {
     const long HW = (long)p.H * p.W;
 #pragma unroll
@@ -903,9 +920,20 @@ __device__ __forceinline__ void wg_prefetch(float4 (&pf)[WG_NPF], const WgDesc (
         // explicit GLOBAL address space (a generic pointer makes FLAT loads, which count on lgkmcnt as well: every LDS wait of the MFMA phase would then also wait for
         // this step's prefetch)
         typedef const __attribute__((address_space(1))) tz_f4* wg_gptr;
+        if constexpr (H16) {
+            typedef unsigned int wg_u2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(1))) wg_u2* wg_gptr2;
+            const bool isx = k == 0;
+            const unsigned long long ga = (unsigned long long)ds[u].b + (isx ? 4ull : 2ull) * (unsigned long long)(on ? (long)pl * HW : 0);
+            float4 r;
+            if (isx) { const tz_f4 v = *(wg_gptr)ga; r = make_float4(v[0], v[1], v[2], v[3]); }
+            else { const wg_u2 v = *(wg_gptr2)ga; r = make_float4(vx_bf16_lo(v[0]), vx_bf16_hi(v[0]), vx_bf16_lo(v[1]), vx_bf16_hi(v[1])); }
+            pf[u] = on ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
         const unsigned long long ga = (unsigned long long)ds[u].b + 4ull * (unsigned long long)(on ? (long)pl * HW : 0);      // (dead items read a valid address)
         const tz_f4 v = *(wg_gptr)ga;
         pf[u] = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 template <int NS, bool SP = false>
@@ -1006,7 +1034,7 @@ __device__ __forceinline__ uint4 wg_shift(const uint32_t (&w)[8], int o) {
 // SPEC = true (round 5): 512 threads.  Waves 4..7 are PRODUCERS -- they load, split and store the operands of step dx + 1 (second x buffer, one more slot per g ring) while
 // waves 0..3 run the MFMA phase of step dx; one barrier per step.  The one-role kernel spent two thirds of a step outside its MFMAs: the barrier pair around the commit,
 // the piece splitting and the exposed latency of the next plane's loads (tools/jlc_wg_probe.py), with one wave per SIMD to hide none of it.
-template <int NS, bool DBG, bool F16 = false, bool SPEC = false>
+template <int NS, bool DBG, bool F16 = false, bool SPEC = false, bool H16 = false>
 __global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(VxWgT p_) {
     const VxWgT& p = p_;
     const int dbg = DBG ? p_.dbg : 0;
@@ -1058,17 +1086,17 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(Vx
         float4 pf[WG_NPF];
         WgDesc ds[WG_NPF];
 #pragma unroll
-        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)(threadIdx.x & 255) + u * 256, sg, cob, cib, h0);
-        wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc<H16>(p, (int)(threadIdx.x & 255) + u * 256, sg, cob, cib, h0);
+        wg_prefetch<H16>(pf, ds, p, dg0 - 2, dg0, dg1);
         __syncthreads();                 // (the zero rows)
         wg_commit<NS, true>(pf, ds, wg_lds, p, dg0 - 2, dg0, dg1);        // the first step's operands; the second step's loads in flight
-        wg_prefetch(pf, ds, p, dg0 - 1, dg0, dg1);
+        wg_prefetch<H16>(pf, ds, p, dg0 - 1, dg0, dg1);
         __syncthreads();
         for (int dx = dg0 - 2; dx <= dg1 + 1; ++dx) {
             // step dx + 1: its x buffer and ring slots are not read by the consumers' step dx (one more buffer / slot than the planes in use)
             if (dx + 1 <= dg1 + 1) {
                 wg_commit<NS, true>(pf, ds, wg_lds, p, dx + 1, dg0, dg1);
-                if (dx + 2 <= dg1 + 1) wg_prefetch(pf, ds, p, dx + 2, dg0, dg1);
+                if (dx + 2 <= dg1 + 1) wg_prefetch<H16>(pf, ds, p, dx + 2, dg0, dg1);
             }
             __syncthreads();
         }
@@ -1081,8 +1109,8 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(Vx
     WgDesc ds[WG_NPF];
     if constexpr (!SPEC) {
 #pragma unroll
-        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
-        wg_prefetch(pf, ds, p, dg0 - 2, dg0, dg1);
+        for (int u = 0; u < WG_NPF; ++u) ds[u] = wg_desc<H16>(p, (int)threadIdx.x + u * 256, sg, cob, cib, h0);
+        wg_prefetch<H16>(pf, ds, p, dg0 - 2, dg0, dg1);
     } else {
         __syncthreads();
         __syncthreads();
@@ -1095,7 +1123,7 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) vx_jlc_wg_k(Vx
         if constexpr (F16) wg_commit16(pf, ds, wg_lds, p, dx, dg0, dg1, mtab, etab);
         else if (!(dbg & 1)) wg_commit<NS>(pf, ds, wg_lds, p, dx, dg0, dg1);
         __syncthreads();
-        if (dx + 1 <= dg1 + 1 && !(dbg & 1)) wg_prefetch(pf, ds, p, dx + 1, dg0, dg1);
+        if (dx + 1 <= dg1 + 1 && !(dbg & 1)) wg_prefetch<H16>(pf, ds, p, dx + 1, dg0, dg1);
         if (dbg & 2) continue;
         if ((unsigned)dx >= (unsigned)p.D) continue;
         }
@@ -1322,6 +1350,7 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
     if (wg16 < 0) { const char* e = getenv("VELOXSEG_WG_TZ_F16"); wg16 = (e && e[0] == '1') ? 1 : 0; }
     const bool f16 = tz_pieces() == 22 && (wg16 == 1 || g_wg_f16 == 1);
     const int NS = f16 ? 2 : (tz_pieces() == 22 ? 3 : tz_pieces());
+    VX_REQUIRE(!t_tz_h16 || NS == 1, "vx_jlc_wgrad_tz: 16-bit g_k need plain bf16 operands (pieces = 1, the bf16 mode)");
     // producer / consumer waves: the default (three bf16 pieces) instance, when its deeper staging (two x buffers, one more slot per ring) fits
     bool spec = !f16 && NS == 3 && (g_tz_dbg >> 4) == 0 && wg_spec_on();
     if (spec) { VxWgT q = {}; size_t sh2; spec = wg_plan(q, sh2, B, C, G, D, H, W, NS, true) == 0; }
@@ -1349,7 +1378,12 @@ extern "C" int vx_jlc_wgrad_tz(const float* x, const float* g1, const float* g3,
         static bool attr16 = false;
         if (!attr16) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attr16 = true; }
         vx_jlc_wg_k<2, false, true><<<grid, dim3(256), shm, st>>>(p);
-    } else if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2); else WG_LAUNCH(1);
+    } else if (NS == 3) WG_LAUNCH(3); else if (NS == 2) WG_LAUNCH(2);
+    else if (t_tz_h16) {                 // bf16 storage mode: g_k are vx_bf16 arrays (plain bf16 operands)
+        static bool attrh = false;
+        if (!attrh) { VX_REQUIRE(hipFuncSetAttribute((const void*)vx_jlc_wg_k<1, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "vx_jlc_wgrad_tz: LDS attribute"); attrh = true; }
+        vx_jlc_wg_k<1, false, false, false, true><<<grid, dim3(256), shm, st>>>(p);
+    } else WG_LAUNCH(1);
 #undef WG_LAUNCH
     VX_LAUNCH_CHECK("vx_jlc_wgrad_tz");
     return 0;
@@ -1377,6 +1411,28 @@ extern "C" int vx_jlc_tz_bwd_ns(const float* g1, const float* g3, const float* g
     VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_bwd_ns: pieces %d", pieces);
     TzPiecesScope sc(pieces);
     return vx_jlc_tz_bwd(g1, g3, g5, img, w1, d_o, dx, B, C, G, D, H, W, stream);
+}
+// bf16 storage mode (h16 != 0; pieces must be 1): y_k / g_k / d_o are vx_bf16 arrays, x and dx stay fp32
+extern "C" int vx_jlc_tz_fwd_h(const float* x, const float* img, const float* b1, const float* b3, const float* b5, void* y1, void* y3, void* y5, double* part,
+                               int B, int C, int G, int D, int H, int W, int pieces, int h16, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_fwd_h: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    TzH16Scope hs(h16 ? 1 : 0);
+    return vx_jlc_tz_fwd(x, img, b1, b3, b5, (float*)y1, (float*)y3, (float*)y5, part, B, C, G, D, H, W, stream);
+}
+extern "C" int vx_jlc_tz_bwd_h(const void* g1, const void* g3, const void* g5, const float* img, const float* w1, const void* d_o, float* dx,
+                               int B, int C, int G, int D, int H, int W, int pieces, int h16, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_tz_bwd_h: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    TzH16Scope hs(h16 ? 1 : 0);
+    return vx_jlc_tz_bwd((const float*)g1, (const float*)g3, (const float*)g5, img, w1, (const float*)d_o, dx, B, C, G, D, H, W, stream);
+}
+extern "C" int vx_jlc_wgrad_tz_h(const float* x, const void* g1, const void* g3, const void* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
+                                 int pieces, int h16, void* stream) {
+    VX_REQUIRE(tz_pieces_valid(pieces), "vx_jlc_wgrad_tz_h: pieces %d", pieces);
+    TzPiecesScope sc(pieces);
+    TzH16Scope hs(h16 ? 1 : 0);
+    return vx_jlc_wgrad_tz(x, (const float*)g1, (const float*)g3, (const float*)g5, dw1, dw3, dw5, B, C, G, D, H, W, stream);
 }
 extern "C" int vx_jlc_wgrad_tz_ns(const float* x, const float* g1, const float* g3, const float* g5, float* dw1, float* dw3, float* dw5, int B, int C, int G, int D, int H, int W,
                                   int pieces, void* stream) {

@@ -22,11 +22,16 @@
 typedef float vx_f32x4 __attribute__((ext_vector_type(4)));
 #define VX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// TI = element type of x and (backward) of the returned input gradient dn: float, or vx_bf16 when the block-internal tensors of a JLC block are kept in bf16
+// (round 6, bf16 storage mode: x = o, dn are internal to the block; out / dout are the block's fp32 boundary tensors).  `x` / `dn` are void* typed by the kernel.
 struct VxMlp {
-    const float *x, *gamma, *beta, *w1, *b1, *w2, *b2, *dout;
+    const void* x;
+    const float *gamma, *beta, *w1, *b1, *w2, *b2, *dout;
     const double* part;      // NORM 0 forward: partial (sum, sumsq) pairs of x per (b,c): [B*C][nparts][2]; null -> stats holds (mean, rstd)
     float* stats;            // NORM 0: (B*C, 2) mean, rstd -- written by the forward when part != null, read otherwise
-    float *out, *dn, *part_out, *dgamma, *dbeta, *dw1, *db1, *dw2, *db2;
+    float* out;
+    void* dn;
+    float *part_out, *dgamma, *dbeta, *dw1, *db1, *dw2, *db2;
     long V;
     int nparts, iters;
     float eps;
@@ -94,18 +99,18 @@ __device__ __forceinline__ void vx_mlp_stage_acc(float* __restrict__ dst, const 
     for (int k = 0; k < R * C / 256; ++k) dst[threadIdx.x + 256 * k] = v[k];
 }
 
-template <int TPW> __device__ __forceinline__ void vx_ldt(const float* __restrict__ p, float (&o)[TPW]) {
-    if constexpr (TPW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
-    else o[0] = p[0];
+template <int TPW, typename T> __device__ __forceinline__ void vx_ldt(const T* __restrict__ p, float (&o)[TPW]) {
+    if constexpr (TPW == 4) { const float4 t = vx_ld4(p, 0L); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+    else o[0] = vx_ld1(p, 0L);
 }
-template <int TPW> __device__ __forceinline__ void vx_stt(float* __restrict__ p, const float (&o)[TPW]) {
-    if constexpr (TPW == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
-    else p[0] = o[0];
+template <int TPW, typename T> __device__ __forceinline__ void vx_stt(T* __restrict__ p, const float (&o)[TPW]) {
+    if constexpr (TPW == 4) vx_st4(p, 0L, make_float4(o[0], o[1], o[2], o[3]));
+    else vx_st1(p, 0L, o[0]);
 }
 
 // N-layout input of a wave's voxel group: n[ks][t] = norm(x)[channel 4ks + q][voxel vc + t]; LN also returns the per-voxel (mean, rstd)
-template <int C, int NORM, int TPW>
-__device__ __forceinline__ void vx_mlp_load_n(const float* __restrict__ xs, long V, long vc, int q, const float* __restrict__ c0, const float* __restrict__ c1, float eps,
+template <int C, int NORM, int TPW, typename TI = float>
+__device__ __forceinline__ void vx_mlp_load_n(const TI* __restrict__ xs, long V, long vc, int q, const float* __restrict__ c0, const float* __restrict__ c1, float eps,
                                               float (&n)[C / 4][TPW], float (&uu)[TPW], float (&rr)[TPW]) {
     constexpr int KS = C / 4;
 #pragma unroll
@@ -140,7 +145,7 @@ __device__ __forceinline__ void vx_mlp_load_n(const float* __restrict__ xs, long
 }
 
 // --------------------------------------------------------------------------------------------------------------------- forward
-template <int C, int R, int NORM, int TPW>
+template <int C, int R, int NORM, int TPW, typename TI = float>
 __global__ void __launch_bounds__(256) vx_mlp_fwd_k(VxMlp p) {
     constexpr int KS = C / 4, RB = R / 16, CB = C / 16, VS = TPW, GV = 16 * TPW;
     __shared__ float A1[R * C], A2[R * C], b1s[R], b2s[C], mu_s[C], rs_s[C];
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256) vx_mlp_fwd_k(VxMlp p) {
     __syncthreads();
     const long V = p.V;
     const VxDropCtx d1 = vx_drop_ctx(p.d1), d2 = vx_drop_ctx(p.d2);
-    const float* __restrict__ xs = p.x + (long)b * C * V;
+    const TI* __restrict__ xs = (const TI*)p.x + (long)b * C * V;
     float* __restrict__ os = p.out + (long)b * C * V;
     for (int it = 0; it < p.iters; ++it) {
         const long v0 = (((long)blockIdx.x * p.iters + it) * 4 + wave) * GV;
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(256) vx_mlp_fwd_k(VxMlp p) {
         const bool live = vl < V;
         const long vc = live ? vl : V - VS;                    // idle lanes load a valid address and store nothing
         float n[KS][TPW], uu[TPW], rr[TPW];
-        vx_mlp_load_n<C, NORM, TPW>(xs, V, vc, q, mu_s, rs_s, p.eps, n, uu, rr);
+        vx_mlp_load_n<C, NORM, TPW, TI>(xs, V, vc, q, mu_s, rs_s, p.eps, n, uu, rr);
         vx_f32x4 z[CB][TPW];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(256) vx_mlp_fwd_k(VxMlp p) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------- backward
-template <int C, int R, int NORM, int TPW>
+template <int C, int R, int NORM, int TPW, typename TI = float>
 __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
     constexpr int KS = C / 4, RB = R / 16, CB = C / 16, VS = TPW, GV = 16 * TPW;
     extern __shared__ __attribute__((aligned(16))) float vx_mlp_lds[];
@@ -256,9 +261,9 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
     __syncthreads();
     const long V = p.V;
     const VxDropCtx d1 = vx_drop_ctx(p.d1), d2 = vx_drop_ctx(p.d2);
-    const float* __restrict__ xs = p.x + (long)b * C * V;
+    const TI* __restrict__ xs = (const TI*)p.x + (long)b * C * V;
     const float* __restrict__ gs = p.dout + (long)b * C * V;
-    float* __restrict__ os = p.dn + (long)b * C * V;
+    TI* __restrict__ os = (TI*)p.dn + (long)b * C * V;
 
     vx_f32x4 aW2[RB][CB], aW1[RB][CB];                      // D tiles: reg i = (j = 16jb + 4q + i, c = 16cb + m)
     float sb1[RB], sb2[CB], S1[CB][4], S2[CB][4];           // lane partials: db1 (j = 16jb + m), db2 (c = 16cb + m), norm sums (c = 16cb + 4q + i)
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
         for (int k = 0; k < MDW; ++k) rec[k] = 0u;
         // ---- N-layout operands: channel 4ks + q, voxels vl .. vl + TPW - 1
         float n[KS][TPW], dz[KS][TPW], uu[TPW], rr[TPW];
-        vx_mlp_load_n<C, NORM, TPW>(xs, V, vc, q, mu_s, rs_s, p.eps, n, uu, rr);
+        vx_mlp_load_n<C, NORM, TPW, TI>(xs, V, vc, q, mu_s, rs_s, p.eps, n, uu, rr);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vx_ldt<TPW>(gs + (long)(4 * ks + q) * V + vc, dz[ks]);
         if constexpr (TPW == 4) {
@@ -444,7 +449,7 @@ __global__ void __launch_bounds__(256) vx_mlp_bwd_k(VxMlp p) {
                 const bool lf = vf < V;
                 const long va = lf ? vf : V - 4;
                 const float4 g4 = *reinterpret_cast<const float4*>(gs + (long)ch * V + va);
-                const float4 x4 = *reinterpret_cast<const float4*>(xs + (long)ch * V + va);
+                const float4 x4 = vx_ld4(xs, (long)ch * V + va);
                 float m2[4];
                 if constexpr (TPW == 4) {
                     // voxels v0 + 4 (4 q + f) + e of channel 16 cb + m = 4 ks + q': drawn by lane (m' = 4 q + f, q' = m & 3), ks = 4 cb + (m >> 2)
@@ -610,13 +615,15 @@ extern "C" int vx_mlp_bwd_nparts(int B, int C, long V) {
 
 #define VX_MLP_SHAPES(X) X(16, 48) X(16, 32)
 
-extern "C" int vx_mlp_fwd(const float* x, int norm, const double* part, int nparts, float* stats, const float* gamma, const float* beta,
-                          const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int C, int R, long V, float eps,
-                          const void* seed_ptr, unsigned long long site1, float p1, unsigned long long site2, float p2, void* stream) {
+// h16 != 0 (norm = 0 only): x is a vx_bf16 array -- the o tensor of a JLC block in the bf16 storage mode; out stays fp32
+extern "C" int vx_mlp_fwd_h(const void* x, int norm, const double* part, int nparts, float* stats, const float* gamma, const float* beta,
+                            const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int C, int R, long V, float eps,
+                            const void* seed_ptr, unsigned long long site1, float p1, unsigned long long site2, float p2, int h16, void* stream) {
     VX_REQUIRE(x && w1 && b1 && w2 && b2 && out && B > 0, "vx_mlp_fwd: bad args");
+    VX_REQUIRE(!h16 || !norm, "vx_mlp_fwd: 16-bit input exists for the InstanceNorm (JLC) form only");
     VX_REQUIRE(vx_mlp_supported(C, R, V), "vx_mlp_fwd: unsupported shape C=%d R=%d V=%ld", C, R, V);
     VX_REQUIRE(norm ? (gamma && beta) : (stats != nullptr || part != nullptr), "vx_mlp_fwd: norm parameters missing");
-    VX_REQUIRE(x != out, "vx_mlp_fwd: in-place is not supported");
+    VX_REQUIRE(x != (const void*)out, "vx_mlp_fwd: in-place is not supported");
     VxMlp p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
     p.part = part; p.nparts = nparts; p.stats = stats; p.out = out; p.V = V; p.eps = eps; p.iters = 1;      // forward: no cross-block sums, more waves hide the global round trips
@@ -630,6 +637,7 @@ extern "C" int vx_mlp_fwd(const float* x, int norm, const double* part, int npar
     if (!done && C == CC && R == RR) {                                                                         \
         done = true;                                                                                           \
         if (norm) { if (tpw == 4) vx_mlp_fwd_k<CC, RR, 1, 4><<<grid, dim3(256), 0, st>>>(p); else vx_mlp_fwd_k<CC, RR, 1, 1><<<grid, dim3(256), 0, st>>>(p); } \
+        else if (h16) { if (tpw == 4) vx_mlp_fwd_k<CC, RR, 0, 4, vx_bf16><<<grid, dim3(256), 0, st>>>(p); else vx_mlp_fwd_k<CC, RR, 0, 1, vx_bf16><<<grid, dim3(256), 0, st>>>(p); } \
         else { if (tpw == 4) vx_mlp_fwd_k<CC, RR, 0, 4><<<grid, dim3(256), 0, st>>>(p); else vx_mlp_fwd_k<CC, RR, 0, 1><<<grid, dim3(256), 0, st>>>(p); }      \
     }
     VX_MLP_SHAPES(VX_MLP_FWD)
@@ -637,19 +645,26 @@ extern "C" int vx_mlp_fwd(const float* x, int norm, const double* part, int npar
     VX_LAUNCH_CHECK("vx_mlp_fwd");
     return 0;
 }
-
-template <int C, int R, int NORM, int TPW>
-static void vx_mlp_bwd_launch(const VxMlp& p, dim3 grid, size_t shm, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)vx_mlp_bwd_k<C, R, NORM, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    vx_mlp_bwd_k<C, R, NORM, TPW><<<grid, dim3(256), shm, st>>>(p);
+extern "C" int vx_mlp_fwd(const float* x, int norm, const double* part, int nparts, float* stats, const float* gamma, const float* beta,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int C, int R, long V, float eps,
+                          const void* seed_ptr, unsigned long long site1, float p1, unsigned long long site2, float p2, void* stream) {
+    return vx_mlp_fwd_h(x, norm, part, nparts, stats, gamma, beta, w1, b1, w2, b2, out, B, C, R, V, eps, seed_ptr, site1, p1, site2, p2, 0, stream);
 }
 
-extern "C" int vx_mlp_bwd(const float* x, int norm, const float* stats, const float* gamma, const float* beta, const float* w1, const float* b1,
-                          const float* w2, const float* dout, float* dx, float* part_out, float* dgamma, float* dbeta, float* dw1, float* db1,
-                          float* dw2, float* db2, int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site1, float p1,
-                          unsigned long long site2, float p2, void* stream) {
+template <int C, int R, int NORM, int TPW, typename TI = float>
+static void vx_mlp_bwd_launch(const VxMlp& p, dim3 grid, size_t shm, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)vx_mlp_bwd_k<C, R, NORM, TPW, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vx_mlp_bwd_k<C, R, NORM, TPW, TI><<<grid, dim3(256), shm, st>>>(p);
+}
+
+// h16 != 0 (norm = 0 only): x (= o of the JLC block) and the returned dx (= dn) are vx_bf16 arrays; dout stays fp32
+extern "C" int vx_mlp_bwd_h(const void* x, int norm, const float* stats, const float* gamma, const float* beta, const float* w1, const float* b1,
+                            const float* w2, const float* dout, void* dx, float* part_out, float* dgamma, float* dbeta, float* dw1, float* db1,
+                            float* dw2, float* db2, int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site1, float p1,
+                            unsigned long long site2, float p2, int h16, void* stream) {
     VX_REQUIRE(x && w1 && b1 && w2 && dout && dx && dw1 && db1 && dw2 && db2 && B > 0, "vx_mlp_bwd: bad args");
+    VX_REQUIRE(!h16 || !norm, "vx_mlp_bwd: 16-bit tensors exist for the InstanceNorm (JLC) form only");
     VX_REQUIRE(vx_mlp_supported(C, R, V), "vx_mlp_bwd: unsupported shape C=%d R=%d V=%ld", C, R, V);
     VX_REQUIRE(norm ? (gamma && beta && dgamma && dbeta) : (stats && part_out), "vx_mlp_bwd: norm parameters missing");
     VxMlp p = {};
@@ -668,10 +683,17 @@ extern "C" int vx_mlp_bwd(const float* x, int norm, const float* stats, const fl
     if (!done && C == CC && R == RR) {                                                                         \
         done = true;                                                                                           \
         if (norm) { if (tpw == 4) vx_mlp_bwd_launch<CC, RR, 1, 4>(p, grid, shm, st); else vx_mlp_bwd_launch<CC, RR, 1, 1>(p, grid, shm, st); } \
+        else if (h16) { if (tpw == 4) vx_mlp_bwd_launch<CC, RR, 0, 4, vx_bf16>(p, grid, shm, st); else vx_mlp_bwd_launch<CC, RR, 0, 1, vx_bf16>(p, grid, shm, st); } \
         else { if (tpw == 4) vx_mlp_bwd_launch<CC, RR, 0, 4>(p, grid, shm, st); else vx_mlp_bwd_launch<CC, RR, 0, 1>(p, grid, shm, st); }      \
     }
     VX_MLP_SHAPES(VX_MLP_BWD)
 #undef VX_MLP_BWD
     VX_LAUNCH_CHECK("vx_mlp_bwd");
     return 0;
+}
+extern "C" int vx_mlp_bwd(const float* x, int norm, const float* stats, const float* gamma, const float* beta, const float* w1, const float* b1,
+                          const float* w2, const float* dout, float* dx, float* part_out, float* dgamma, float* dbeta, float* dw1, float* db1,
+                          float* dw2, float* db2, int B, int C, int R, long V, float eps, const void* seed_ptr, unsigned long long site1, float p1,
+                          unsigned long long site2, float p2, void* stream) {
+    return vx_mlp_bwd_h(x, norm, stats, gamma, beta, w1, b1, w2, dout, dx, part_out, dgamma, dbeta, dw1, db1, dw2, db2, B, C, R, V, eps, seed_ptr, site1, p1, site2, p2, 0, stream);
 }

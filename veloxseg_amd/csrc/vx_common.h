@@ -55,6 +55,33 @@ __device__ __forceinline__ float vx_block_sum_256(float v, float* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// ---- 16-bit storage of activations (round 6: the bf16 STORAGE mode of BASELINE configs[1]; reference speed_test.py:122,127 = torch.amp.autocast) ---------------
+// A tensor kept in HBM as bf16 is an array of `vx_bf16` (storage only: every kernel converts to fp32 on load and rounds to nearest-even on store; sums, statistics,
+// soft-max and the loss stay fp32).  Kernels are templated on the element type of the tensors that may be 16-bit and reach memory through the overloads below, so the
+// fp32 instances are the unchanged code.  4 consecutive elements = one 16-byte (fp32) or 8-byte (bf16) access.
+struct vx_bf16 { unsigned short v; };
+__device__ __forceinline__ uint32_t vx_pack_bf16x2(float a, float b) {      // (a -> low half, b -> high half), round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+    typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+    const bf2_ v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float vx_bf16_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float vx_bf16_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ float4 vx_ld4(const float* p, long i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ float4 vx_ld4(const vx_bf16* p, long i) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + i);
+    return make_float4(vx_bf16_lo(v.x), vx_bf16_hi(v.x), vx_bf16_lo(v.y), vx_bf16_hi(v.y));
+}
+__device__ __forceinline__ void vx_st4(float* p, long i, float4 v) { *reinterpret_cast<float4*>(p + i) = v; }
+__device__ __forceinline__ void vx_st4(vx_bf16* p, long i, float4 v) { *reinterpret_cast<uint2*>(p + i) = make_uint2(vx_pack_bf16x2(v.x, v.y), vx_pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ float vx_ld1(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float vx_ld1(const vx_bf16* p, long i) { return __builtin_bit_cast(float, (uint32_t)p[i].v << 16); }
+__device__ __forceinline__ void vx_st1(float* p, long i, float v) { p[i] = v; }
+__device__ __forceinline__ void vx_st1(vx_bf16* p, long i, float v) { p[i].v = (unsigned short)(vx_pack_bf16x2(v, 0.0f) & 0xffffu); }
+// what a value becomes when it is stored as T and loaded again (statistics of a tensor that is kept in bf16 are taken over the ROUNDED values its readers will see)
+template <typename T> __device__ __forceinline__ float vx_round_as(float v) { return v; }
+template <> __device__ __forceinline__ float vx_round_as<vx_bf16>(float v) { return vx_bf16_lo(vx_pack_bf16x2(v, 0.0f)); }
+
 // ---- exact-erf GELU (nn.GELU() default) ---------------------------------------------------
 __device__ __forceinline__ float vx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float vx_gelu_grad(float x) {

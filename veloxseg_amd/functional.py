@@ -234,6 +234,7 @@ def cpp_module(reload: bool = False):
 
 
 _PRECISION = "fp32"
+BF16_STORAGE = os.environ.get("VELOXSEG_BF16_STORAGE", "1") != "0"
 
 
 def set_precision(mode: str):
@@ -249,6 +250,10 @@ def set_precision(mode: str):
             raise RuntimeError("veloxseg_amd: the bf16 mode lives in the C++ operator path (veloxseg_amd._vxops), which is not built / enabled")
         return
     m.set_bf16_expand(mode == "bf16")
+    # round 6: the bf16 mode also STORES 16-bit tensors (VELOXSEG_BF16_STORAGE=0: operands only, the mode of rounds 2-5, for the A/B): the block-internal tensors of the JLC blocks
+    # at the 32^3 level (y_k, o, dn, d_o, g_k) and the full-resolution heads / reconstructions with their gradients; fp32: statistics, sums, soft-max, loss, master weights,
+    # flat gradients, AdamW, every block-boundary tensor
+    m.set_act_bf16(mode == "bf16" and BF16_STORAGE)
     # the JLC grouped convolutions and their weight gradients on the matrix pipe (csrc/jlc_mfma.hip): 3 bf16 pieces per operand (six piece products = the fp32
     # product) in the fp32 mode, ONE piece (plain bf16 operands, fp32 accumulation) in the bf16 mode
     H.call("vx_jlc_tz_set_pieces", 1 if mode == "bf16" else int(os.environ.get("VELOXSEG_TZ_PIECES", "22")))     # 22 = two scaled fp16 pieces (22 significant bits, three piece products: csrc/jlc_mfma.hip); 3 = three bf16 pieces (A/B)
