@@ -101,6 +101,11 @@ int vx_expand_wgrad_mfma(const float* x, float* xcl_ws, const float* dy_fine, fl
 int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int W);
 int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
                                int ns, void* stream);
+/* bf16 storage mode of the patch-expand layers (bf16 operands): the pixel-shuffled output y (forward) / the fine gradient dy (input and weight gradients) as bf16 arrays */
+int vx_expand_fwd_mfma_bf16_h(const float* x, const float* w, const float* bias, float* wt_ws, void* y, int B, int Cc, int D, int H, int W, int y_h16, void* stream);
+int vx_expand_bwd_data_mfma_bf16_h(const void* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int dy_h16, void* stream);
+int vx_expand_wgrad_mfma_split_h(const float* x, const void* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
+                                 int ns, int dy_h16, void* stream);
 /* bf16 opt-in mode (BASELINE configs[1]: the BraTS bf16 line): the same two layers with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16), fp32
  * accumulation and fp32 tensors in HBM; weights and activations are rounded to bf16 (nearest-even) on their way into the MFMA.  Same arguments and
  * workspaces as the fp32 entries above; return 1 = shape not covered (D, H % 4, W % 16), the caller then uses the fp32 entry. */
@@ -424,6 +429,8 @@ int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sample, long b_b
 int vx_mse_bwd_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, const float* coef, const float* gout, float* da, void* stream);
 /* the sum of squares of vx_sqdiff_sum_bs AND da = scale (a - b) in one pass (staged loss: scale = 2 w_rc / N_rc is known at forward time, utils/loss.py:52-66) */
 int vx_sqdiff_sum_grad_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, float* da, void* stream);
+/* bf16 storage mode: a (the reconstruction) and da as bf16 arrays when a_h16 != 0; b (the network input) stays fp32 */
+int vx_sqdiff_sum_grad_bs_h(const void* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, void* da, int a_h16, void* stream);
 int vx_loss_finalize(const double* seg_acc, int nh, int B, int C, long V, const float* head_weights,
                      const double* rc_acc, long n_rc, float w_rc,
                      const float* gram_seg, const float* g0, const float* g1, const float* g2, const float* g3, int M, int Cg, float w_f,
@@ -446,6 +453,14 @@ int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float* l2, const 
 int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
                        const float* coef, int coef_stride, const float* gout, float* dl0, float* dl1, float* dl2, float* dl3, float* ws,
                        int B, int C, int D, int H, int W, void* stream);
+/* bf16 storage mode: head 0 (the full-resolution logits) and its gradient dl0 as bf16 arrays when l0_h16 != 0 (column-owner kernels only: vx_seg_loss_ds_h16_ok answers 1
+ * when both directions run them at this geometry); the low-resolution heads, accumulators, coefficients and the workspace stay fp32 */
+int vx_seg_loss_ds_h16_ok(const int* low_dims, int nh, int B, int C, int D, int H, int W);
+int vx_seg_loss_ds_fwd_h(const void* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                         double* acc, int B, int C, int D, int H, int W, int l0_h16, void* stream);
+int vx_seg_loss_ds_bwd_h(const void* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                         const float* coef, int coef_stride, const float* gout, void* dl0, float* dl1, float* dl2, float* dl3, float* ws,
+                         int B, int C, int D, int H, int W, int l0_h16, void* stream);
 int vx_mse_bwd(const float* a, const float* b, const float* coef, const float* gout, float* da, long n, void* stream);
 int vx_gram_mse_bwd(const float* gs, const float* g0, const float* g1, const float* g2, const float* g3, int M, const float* coef,
                     const float* gout, float* dgs, float* d0, float* d1, float* d2, float* d3, long n, void* stream);

@@ -153,3 +153,61 @@ def test_jlc_block_with_16bit_internal_tensors_vs_oracle(case):
     for k, v in errs[True].items():
         assert v <= 1e-2, (k, v, errs)
         assert v <= 3.0 * errs[False][k] + 2e-3, (k, v, errs[False][k])
+
+
+@pytest.mark.parametrize("name,B", [("g6_128_brats", 2), ("g5_128_m2", 2), ("g7_96_m2", 2)])
+def test_bf16_storage_mode_taped_step_vs_oracle(name, B):
+    """BASELINE configs[1] (BraTS 128^3, batch 2) and the headline model (M = 2, 128^3; and the shipped 96^3 geometry) in the bf16 STORAGE mode -- 16-bit full-resolution
+    heads / reconstructions and their gradients, 16-bit block-internal tensors of the 32^3-level JLC blocks, bf16 matrix-pipe operands; fp32 statistics, sums, soft-max,
+    loss, master weights and flat gradients (reference speed_test.py:122,127: torch.amp.autocast) -- through TrainEngine's launch tapes (the path bench.py --dtype bf16
+    times), against the fp32 CPU ORACLE on the same weights and batch (dropout 0, as every oracle comparison).  Gates: logits relative RMS <= 1e-2,
+    per-class Dice of the arg-max masks against the labels within 1e-3 of the oracle's, loss within 1 %; and the flat gradient within 3e-2 relative RMS."""
+    from oracle import veloxseg_oracle as O
+    from recipe import CASES, LOSS_CFG, fill_state_dict, make_inputs
+    from veloxseg_amd import functional as VF
+    from veloxseg_amd.engine import TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg_d, _ = CASES[name]
+    model = VeloxSeg(**cfg_d)
+    sd = fill_state_dict(model.state_dict(), seed=7)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    x, labels = make_inputs(cfg_d, B)
+    cfg = O.OracleConfig(**cfg_d)
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), LOSS_CFG, torch.device("cuda"), num_modal=cfg.M)
+    eng = TrainEngine(model, crit, (B, sum(cfg_d["in_ch"]), *cfg_d["input_size"]), lr=0.0, weight_decay=0.0, use_graph=True, overlap=False, precision="bf16")
+    eng.step(x.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert eng.use_graph and eng.graphs is not None, "the capture's self-check failed: the step did not run as launch tapes"
+    loss = float(eng.step())                 # a REPLAYED step (lr = 0: same parameters)
+    torch.cuda.synchronize()
+    outs = eng.last_outputs
+    assert outs[0].dtype == torch.bfloat16, "the full-resolution logits must be a 16-bit tensor in this mode"
+    assert outs[4].dtype == torch.bfloat16, "the reconstructions must be 16-bit tensors in this mode"
+    flat = eng.flat.grad.detach().cpu().double()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(params)
+    ro = O.forward(x, full, cfg, training=True)
+    rl = O.loss(ro, labels, x, cfg.M, LOSS_CFG)
+    rl.backward()
+    assert abs(loss - float(rl)) <= 1e-2 * abs(float(rl)), (loss, float(rl))
+    lg, ref = outs[0].float().cpu(), ro[0].detach()
+    rel = float((lg - ref).norm() / ref.norm())
+    assert rel <= 1e-2, rel
+    rc, rref = outs[4].float().cpu(), ro[4].detach()
+    assert float((rc - rref).norm() / rref.norm()) <= 1e-2
+    am, amr, gt = lg.argmax(1), ref.argmax(1), labels[:, 0]
+
+    def dice(p, q, c):
+        return 2.0 * float(((p == c) & (q == c)).sum()) / max(1.0, float((p == c).sum() + (q == c).sum()))
+    for c in range(1, lg.shape[1]):
+        assert abs(dice(am, gt, c) - dice(amr, gt, c)) < 1e-3, (c, dice(am, gt, c), dice(amr, gt, c))
+    gref = torch.zeros_like(flat)
+    for n, p in zip(eng.flat.names, eng.flat.params):
+        o, k = eng.flat.slices[n]
+        gref[o:o + k] = params[n].grad.double().reshape(-1)
+    grel = float((flat - gref).norm() / gref.norm())
+    assert grel <= 3e-2, grel
+    print(f"[bf16 storage vs oracle] {name} B={B}: loss {loss:.6f} vs {float(rl):.6f}, logits rel RMS {rel:.2e}, arg-max differs on {float((am != amr).float().mean()):.2e}, flat gradient rel RMS {grel:.2e}")

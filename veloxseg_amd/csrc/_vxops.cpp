@@ -168,6 +168,8 @@ inline void wgrad_submit(void* cur, int dev, std::function<void(void*)> launch) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------- convolution
+// bf16 storage mode: the caller of the NEXT patch-expand forward on this thread asks for a 16-bit output (m.conv_h); consumed by conv_fwd_impl
+thread_local bool CONV_OUT_H16 = false;
 struct ConvState {
     Tensor x, x2, w, b;
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
@@ -187,7 +189,13 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     const int Cin = C1 + (x2.defined() ? (int)x2.size(1) : 0), Cout = w.size(0);
     TORCH_CHECK(w.size(1) * G == Cin && w.size(2) == K, "conv3d: weight shape does not match the input");
     const int Do = (D + 2 * P - K) / S + 1, Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
-    Tensor y = ps == 1 ? at::empty({B, Cout, Do, Ho, Wo}, x.options()) : at::empty({B, Cout / (ps * ps * ps), Do * ps, Ho * ps, Wo * ps}, x.options());
+    // 16-bit output: only where the bf16-operand patch-expand kernel runs (its _h entry stores bf16); any other convolution ignores the request
+    const bool want_h16 = CONV_OUT_H16;
+    CONV_OUT_H16 = false;
+    const bool y_h16 = want_h16 && F.act_bf16 && F.bf16_expand && F.use_expand_mfma && !x2_in.defined() && ps == 4 && K == 3 && S == 1 && P == 1 && Cin == 16 && G == 1 && Cout % 64 == 0 &&
+                       D % 4 == 0 && H % 4 == 0 && W % 4 == 0 && F.use_s1;
+    auto yopt = y_h16 ? x.options().dtype(at::kBFloat16) : x.options();
+    Tensor y = ps == 1 ? at::empty({B, Cout, Do, Ho, Wo}, yopt) : at::empty({B, Cout / (ps * ps * ps), Do * ps, Ho * ps, Wo * ps}, yopt);
     const long V = (long)D * H * W;
     st.pw = (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1 && Cin % 4 == 0 && C1 % 4 == 0);
     st.s1 = (!x2.defined() && S == 1 && (K == 3 || K == 5) && P == K / 2 && (Cout / G) % 4 == 0 && (Cin / G) % 4 == 0 && F.use_s1);
@@ -215,7 +223,8 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
             const long wsn = std::max<long>((long)Cout * 16 * 27, F.expand_split ? (long)vx_expand_split_ws_floats(Cout / 64, F.expand_split) : 0);
             Tensor wt = at::empty({wsn}, x.options());
             if (F.bf16_expand) {
-                rc = VXR(vx_expand_fwd_mfma_bf16, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
+                rc = VXR(vx_expand_fwd_mfma_bf16_h, fp(x), fp(w), fp(b), mp(wt), y.data_ptr(), B, Cout / 64, D, H, W, (int)y_h16, stream);
+                TORCH_CHECK(rc == 0 || !y_h16, "conv3d: the 16-bit patch-expand output needs the bf16-operand kernel");
             } else if (F.expand_split) {
                 rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
             }
@@ -237,6 +246,11 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
 // acc_into (optional, only without a concat input): the input gradient is ADDED to this tensor in place and returned as dx
 void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, Tensor& dx2, void* stream, const Tensor& acc_into = Tensor(), bool skip_bias = false) {
     Tensor dy = contig(dy_in);
+    const bool dy_h16 = dy.scalar_type() == at::kBFloat16;           // bf16 storage mode: the gradient of a 16-bit patch-expand output
+    if (dy_h16) {
+        TORCH_CHECK(st.s1 && st.ps == 4 && st.K == 3 && st.Cin == 16 && st.G == 1 && F.use_expand_mfma && F.bf16_expand && st.D % 4 == 0 && st.H % 4 == 0 && st.W % 4 == 0 && !st.x2.defined(),
+                    "conv3d backward: a bfloat16 gradient exists for the patch-expand layers in the bf16 mode only");
+    }
     const int B = st.B, C1 = st.C1, Cin = st.Cin, D = st.D, H = st.H, W = st.W, Cout = st.Cout, K = st.K, S = st.S, P = st.P, G = st.G, ps = st.ps;
     const long V = (long)D * H * W;
     const Tensor& x = st.x; const Tensor& x2 = st.x2; const Tensor& w = st.w; const Tensor& b = st.b;
@@ -275,7 +289,8 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
             Tensor wt = at::empty({wsn}, x.options());
             int rcb = 1;
             if (F.bf16_expand) {
-                rcb = VXR(vx_expand_bwd_data_mfma_bf16, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
+                rcb = VXR(vx_expand_bwd_data_mfma_bf16_h, (const void*)dy.data_ptr(), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, (int)dy_h16, stream);
+                TORCH_CHECK(rcb == 0 || !dy_h16, "conv3d backward: the 16-bit gradient needs the bf16-operand kernel");
             } else if (F.expand_split) {
                 rcb = VXR(vx_expand_bwd_data_mfma_split, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, stream);
             }
@@ -303,8 +318,9 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                     const long nws = vx_expand_wgrad_split_ws_floats(B, Cout / 64, D, H, W);
                     auto pws = std::make_shared<Tensor>(at::empty({nws}, x.options()));
                     WG.done.push_back([pws](void*) {});
-                    rcw = VXR(vx_expand_wgrad_mfma_split, fp(x), fp(dy), dw, db, mp(*pws), (long)nws, B, Cout / 64, D, H, W, wns, s);
+                    rcw = VXR(vx_expand_wgrad_mfma_split_h, fp(x), (const void*)dy.data_ptr(), dw, db, mp(*pws), (long)nws, B, Cout / 64, D, H, W, wns, (int)dy_h16, s);
                 }
+                TORCH_CHECK(rcw == 0 || !dy_h16, "conv3d backward: the 16-bit gradient needs the split weight-gradient kernel");
                 if (rcw == 1) {
                     auto xcl = std::make_shared<Tensor>(at::empty({(long)B * V * 16}, x.options()));
                     WG.done.push_back([xcl](void*) {});          // keeps the temporary alive as long as the launches of this pass
@@ -1547,6 +1563,13 @@ PYBIND11_MODULE(_vxops, m) {
     // C++ autograd nodes: return tensors that already carry their grad_fn
     m.def("conv", [](const Tensor& x, const OptT& x2, const Tensor& w, const OptT& b, int64_t K, int64_t S, int64_t P, int64_t G, int64_t ps) {
         return ConvFn::apply(x, x2, w, b, K, S, P, G, ps);
+    });
+    // the same node; a patch-expand layer in the bf16 storage mode returns a bfloat16 tensor (any other convolution: fp32 as always)
+    m.def("conv_h", [](const Tensor& x, const Tensor& w, const OptT& b, int64_t K, int64_t S, int64_t P, int64_t G, int64_t ps) {
+        CONV_OUT_H16 = true;
+        auto y = ConvFn::apply(x, OptT(), w, b, K, S, P, G, ps);
+        CONV_OUT_H16 = false;
+        return y;
     });
     m.def("instnorm", [](const OptT& res, bool act, const Tensor& y0, const OptT& y1, const OptT& y2) { return InstNormFn::apply(res, act, y0, y1, y2); });
     m.def("pw_res", [](const Tensor& x, const Tensor& w, const OptT& b, const Tensor& res, double alpha, double p, int64_t site, int64_t rs) {

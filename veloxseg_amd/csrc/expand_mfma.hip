@@ -681,8 +681,10 @@ __global__ void __launch_bounds__(256) vx_expand_wimg_bf16_k(const float* __rest
     img[e] = vx_pack_bf16(v[0], v[1]);
 }
 
+// TY = element type of the pixel-shuffled output (float, or vx_bf16 in the bf16 storage mode: the full-resolution logits / reconstructions)
+template <typename TY>
 __global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias,
-                                                            float* __restrict__ y, int B, int Cc, int D, int H, int W) {
+                                                            TY* __restrict__ y, int B, int Cc, int D, int H, int W) {
     __shared__ uint4 xh[2 * 648];                       // [channel half][6 x 6 x 18 halo voxel] x 8 bf16
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -735,28 +737,34 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restr
         }
         // D: row 4q+reg = (s2 = q, s3 = reg), col r = voxel w0 + r
         const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + co_base + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
+        TY* __restrict__ yb = y + ((long)b * Cc + c) * fplane + ((long)(4 * (d0 + wave) + s1) * FH + q) * FW + 4 * (w0 + r);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            if (w0 + r < W) *reinterpret_cast<float4*>(yb + (long)(4 * (h0 + m)) * FW) = make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w);
+            if (w0 + r < W) vx_st4(yb, (long)(4 * (h0 + m)) * FW, make_float4(acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w));
     }
 }
 
-extern "C" int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
+// y_h16 != 0: y is a vx_bf16 array (bf16 storage mode)
+extern "C" int vx_expand_fwd_mfma_bf16_h(const float* x, const float* w, const float* bias, float* wt_ws, void* y, int B, int Cc, int D, int H, int W, int y_h16, void* stream) {
     VX_REQUIRE(x && w && wt_ws && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma_bf16: bad args");
     if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
-    vx_expand_fwd_bf16_k<<<dim3((unsigned)nblk), 256, 0, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W);
+    if (y_h16) vx_expand_fwd_bf16_k<vx_bf16><<<dim3((unsigned)nblk), 256, 0, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, (vx_bf16*)y, B, Cc, D, H, W);
+    else vx_expand_fwd_bf16_k<float><<<dim3((unsigned)nblk), 256, 0, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, (float*)y, B, Cc, D, H, W);
     VX_LAUNCH_CHECK("vx_expand_fwd_mfma_bf16");
     return 0;
+}
+extern "C" int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, void* stream) {
+    return vx_expand_fwd_mfma_bf16_h(x, w, bias, wt_ws, y, B, Cc, D, H, W, 0, stream);
 }
 
 // input gradient, bf16 operands: the block / wave / halo layout of vx_expand_bwd_data_lds_k (fp32 halo of one (c, s1) group in LDS), rows = 16 coarse
 // voxels, cols = 16 ci; A = 2 x 4 contiguous fine-gradient floats of this lane's tap (rounded to bf16 here), B = the operand-order weight image
-__global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
+template <typename TD>
+__global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const TD* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
                                                                  int B, int Cc, int D, int H, int W, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float vx_halo_t[];          // [6][6][4][72]
     const int lane = threadIdx.x & 63;
@@ -772,7 +780,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
     const long V = (long)D * H * W;
     const long FH = 4L * H, FW = 4L * W;
     const long fplane = (4L * D) * FH * FW;
-    const float* __restrict__ dyb = dyf + (long)b * Cc * fplane;
+    const TD* __restrict__ dyb = dyf + (long)b * Cc * fplane;
     vx_f4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
@@ -788,7 +796,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
                     const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
                     const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
                     const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
-                    const float4 t_ = *reinterpret_cast<const float4*>(dyb + (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
+                    const float4 t_ = vx_ld4(dyb, (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
                     v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
@@ -831,17 +839,23 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const float* __
     }
 }
 
-extern "C" int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
-                                            int accumulate, void* stream) {
+// dy_h16 != 0: the fine gradient is a vx_bf16 array (bf16 storage mode)
+extern "C" int vx_expand_bwd_data_mfma_bf16_h(const void* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
+                                              int accumulate, int dy_h16, void* stream) {
     VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma_bf16: bad args");
     if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int groups = Cc * 4;
     vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
-    vx_expand_bwd_data_bf16_k<<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    if (dy_h16) vx_expand_bwd_data_bf16_k<vx_bf16><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>((const vx_bf16*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    else vx_expand_bwd_data_bf16_k<float><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>((const float*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
     VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_bf16");
     return 0;
+}
+extern "C" int vx_expand_bwd_data_mfma_bf16(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W,
+                                            int accumulate, void* stream) {
+    return vx_expand_bwd_data_mfma_bf16_h(dy_fine, w, wt_ws, dx, B, Cc, D, H, W, accumulate, 0, stream);
 }
 
 
@@ -1318,8 +1332,8 @@ extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* 
 //   38 of 107 us; atomics in runs of 9 floats into the (co, ci, 27) layout were 8 x slower per element than full-line ones: hence the workspace rows.)
 // ------------------------------------------------------------------------------------------------------------------
 #define VX_WS_PITCH 20                 // dwords per (piece, slot, ci) row image: 32 bf16 + 8 bytes (bank spread)
-template <int NS>
-__global__ void __launch_bounds__(256, 3) vx_expand_wgrad_split_k(const float* __restrict__ x, const float* __restrict__ dyf, float* __restrict__ part, float* __restrict__ db,
+template <int NS, typename TD = float>
+__global__ void __launch_bounds__(256, 3) vx_expand_wgrad_split_k(const float* __restrict__ x, const TD* __restrict__ dyf, float* __restrict__ part, float* __restrict__ db,
                                                                    int B, int Cc, int D, int H, int W, int HL, int nHs, int nWc, int nUnits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t vx_wx[];       // [NS][4][16][VX_WS_PITCH], then the flush image [4][16][16][9]
     using TT = VxSplitTerms<NS>;
@@ -1364,14 +1378,14 @@ __global__ void __launch_bounds__(256, 3) vx_expand_wgrad_split_k(const float* _
     // ---- the fine gradient of this wave's group: lane (r, q), voxels 8q-1 .. 8q+8 ----
     const int s1 = wave, s2 = r >> 2, s3 = r & 3;
     const long FH = 4L * H, FW = 4L * W;
-    const float* __restrict__ dyb = dyf + (((long)b * Cc + c) * (4L * D) + 4 * d + s1) * FH * FW + (long)s2 * FW + 4L * (wc0 + 8 * q) + s3;
+    const TD* __restrict__ dyb = dyf + (((long)b * Cc + c) * (4L * D) + 4 * d + s1) * FH * FW + (long)s2 * FW + 4L * (wc0 + 8 * q) + s3;
     float dv[10];
     auto fetch_dy = [&](int h) {
-        const float* __restrict__ p = dyb + 4L * h * FW;
+        const TD* __restrict__ p = dyb + 4L * h * FW;
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
             const int w = wc0 + 8 * q + j - 1;
-            dv[j] = (h < h_hi && (unsigned)w < (unsigned)W) ? p[4 * (j - 1)] : 0.0f;
+            dv[j] = (h < h_hi && (unsigned)w < (unsigned)W) ? vx_ld1(p, 4L * (j - 1)) : 0.0f;
         }
     };
     vx_f4 acc[9];
@@ -1499,9 +1513,12 @@ extern "C" int vx_expand_wgrad_split_ws_floats(int B, int Cc, int D, int H, int 
     return n > 0x7fffffffL ? -1 : (int)n;
 }
 // returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernel), 0 on success.  part_ws: vx_expand_wgrad_split_ws_floats floats
-extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
-                                          int ns, void* stream) {
+// dy_h16 != 0 (ns = 1 only): the fine gradient is a vx_bf16 array (bf16 storage mode)
+extern "C" int vx_expand_wgrad_mfma_split_h(const float* x, const void* dy_fine_, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
+                                            int ns, int dy_h16, void* stream) {
+    const float* dy_fine = (const float*)dy_fine_;
     VX_REQUIRE(x && dy_fine && dw && part_ws && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && ns >= 1 && ns <= 3, "vx_expand_wgrad_mfma_split: bad args");
+    VX_REQUIRE(!dy_h16 || ns == 1, "vx_expand_wgrad_mfma_split: a 16-bit gradient needs plain bf16 operands (ns = 1)");
     if (W % 4 != 0) return 1;
     int HL, nHs, nWc;
     vx_wgs_plan(B, Cc, D, H, W, HL, nHs, nWc);
@@ -1512,10 +1529,15 @@ extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, 
     const size_t lds = shm > need ? shm : need;
     const int nUnits = (int)(nStrips * Cc);
     dim3 grid((unsigned)(((nUnits + 7) / 8) * 8 * 3));
-    if (ns == 1) vx_expand_wgrad_split_k<1><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    if (ns == 1 && dy_h16) vx_expand_wgrad_split_k<1, vx_bf16><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const vx_bf16*)dy_fine_, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
+    else if (ns == 1) vx_expand_wgrad_split_k<1><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
     else if (ns == 2) vx_expand_wgrad_split_k<2><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
     else vx_expand_wgrad_split_k<3><<<grid, 256, lds, (hipStream_t)stream>>>(x, dy_fine, part_ws, db, B, Cc, D, H, W, HL, nHs, nWc, nUnits);
     vx_expand_wgrad_fold_k<<<vx_cdiv((long)Cc * 3 * 2304, 16), 256, 0, (hipStream_t)stream>>>(part_ws, dw, Cc, D, (int)nStrips, nHs * nWc);
     VX_LAUNCH_CHECK("vx_expand_wgrad_mfma_split");
     return 0;
+}
+extern "C" int vx_expand_wgrad_mfma_split(const float* x, const float* dy_fine, float* dw, float* db, float* part_ws, long ws_floats, int B, int Cc, int D, int H, int W,
+                                          int ns, void* stream) {
+    return vx_expand_wgrad_mfma_split_h(x, dy_fine, dw, db, part_ws, ws_floats, B, Cc, D, H, W, ns, 0, stream);
 }

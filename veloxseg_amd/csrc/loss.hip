@@ -593,47 +593,52 @@ extern "C" int vx_sqdiff_sum_bs(const float* a, const float* b, long n_per_sampl
 // The same sum AND the MSE gradient in one pass (staged loss, round 5): the gradient's coefficient 2 w_rc / N_rc is known before the loss value is -- N_rc is the size of the
 // network input -- so the reconstruction branch writes da = scale (a - b) while it forms its sum of squares, and its backward fan starts from that tensor: the second read of
 // a and b (vx_mse_bwd_bs: 67 MB per reconstruction decoder at 128^3 x 4) and one launch per decoder go away.
-__global__ void __launch_bounds__(256) vx_sqdiff_sum_grad_bs_k(const float* __restrict__ a, const float* __restrict__ b, long n, long bstride, double* __restrict__ acc,
-                                                               float scale, float* __restrict__ da) {
-    const float* __restrict__ as = a + (long)blockIdx.y * n;
+// TA = element type of the reconstruction a and of its gradient da (float, or vx_bf16 in the bf16 storage mode); b = the network input (fp32)
+template <typename TA>
+__global__ void __launch_bounds__(256) vx_sqdiff_sum_grad_bs_k(const TA* __restrict__ a, const float* __restrict__ b, long n, long bstride, double* __restrict__ acc,
+                                                               float scale, TA* __restrict__ da) {
+    const TA* __restrict__ as = a + (long)blockIdx.y * n;
     const float* __restrict__ bs = b + (long)blockIdx.y * bstride;
-    float* __restrict__ ds = da + (long)blockIdx.y * n;
+    TA* __restrict__ ds = da + (long)blockIdx.y * n;
     float s = 0.0f;
     if (((n | bstride) & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) & 15) == 0)) {
         const long n4 = n >> 2, step = (long)gridDim.x * 256;
-        const float4* __restrict__ a4 = reinterpret_cast<const float4*>(as);
         const float4* __restrict__ b4 = reinterpret_cast<const float4*>(bs);
-        float4* __restrict__ d4 = reinterpret_cast<float4*>(ds);
         float s0 = 0.0f, s1 = 0.0f;
         long i = (long)blockIdx.x * 256 + threadIdx.x;
         for (; i + step < n4; i += 2 * step) {
-            const float4 x0 = a4[i], y0 = b4[i], x1 = a4[i + step], y1 = b4[i + step];
+            const float4 x0 = vx_ld4(as, 4 * i), y0 = b4[i], x1 = vx_ld4(as, 4 * (i + step)), y1 = b4[i + step];
             const float4 e0 = make_float4(x0.x - y0.x, x0.y - y0.y, x0.z - y0.z, x0.w - y0.w), e1 = make_float4(x1.x - y1.x, x1.y - y1.y, x1.z - y1.z, x1.w - y1.w);
             s0 = fmaf(e0.x, e0.x, s0); s0 = fmaf(e0.y, e0.y, s0); s0 = fmaf(e0.z, e0.z, s0); s0 = fmaf(e0.w, e0.w, s0);
             s1 = fmaf(e1.x, e1.x, s1); s1 = fmaf(e1.y, e1.y, s1); s1 = fmaf(e1.z, e1.z, s1); s1 = fmaf(e1.w, e1.w, s1);
-            d4[i] = make_float4(scale * e0.x, scale * e0.y, scale * e0.z, scale * e0.w);
-            d4[i + step] = make_float4(scale * e1.x, scale * e1.y, scale * e1.z, scale * e1.w);
+            vx_st4(ds, 4 * i, make_float4(scale * e0.x, scale * e0.y, scale * e0.z, scale * e0.w));
+            vx_st4(ds, 4 * (i + step), make_float4(scale * e1.x, scale * e1.y, scale * e1.z, scale * e1.w));
         }
         if (i < n4) {
-            const float4 x0 = a4[i], y0 = b4[i];
+            const float4 x0 = vx_ld4(as, 4 * i), y0 = b4[i];
             const float4 e0 = make_float4(x0.x - y0.x, x0.y - y0.y, x0.z - y0.z, x0.w - y0.w);
             s0 = fmaf(e0.x, e0.x, s0); s0 = fmaf(e0.y, e0.y, s0); s0 = fmaf(e0.z, e0.z, s0); s0 = fmaf(e0.w, e0.w, s0);
-            d4[i] = make_float4(scale * e0.x, scale * e0.y, scale * e0.z, scale * e0.w);
+            vx_st4(ds, 4 * i, make_float4(scale * e0.x, scale * e0.y, scale * e0.z, scale * e0.w));
         }
         s = s0 + s1;
     } else
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float d = as[i] - bs[i]; s = fmaf(d, d, s); ds[i] = scale * d; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float d = vx_ld1(as, i) - bs[i]; s = fmaf(d, d, s); vx_st1(ds, i, scale * d); }
     __shared__ float red[4];
     s = vx_block_sum_256(s, red);
     if (threadIdx.x == 0) atomicAdd(acc, (double)s);
 }
-extern "C" int vx_sqdiff_sum_grad_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, float* da, void* stream) {
+// a_h16 != 0: a and da are vx_bf16 arrays (bf16 storage mode: the full-resolution reconstruction and its gradient)
+extern "C" int vx_sqdiff_sum_grad_bs_h(const void* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, void* da, int a_h16, void* stream) {
     VX_REQUIRE(a && b && acc && da && n_per_sample > 0 && B > 0 && b_batch_stride >= n_per_sample, "vx_sqdiff_sum_grad_bs: bad args");
     int blocks = vx_cdiv(n_per_sample, 256 * 16);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(vx_sqdiff_sum_grad_bs_k, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, a, b, n_per_sample, b_batch_stride, acc, scale, da);
+    if (a_h16) hipLaunchKernelGGL(vx_sqdiff_sum_grad_bs_k<vx_bf16>, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, (const vx_bf16*)a, b, n_per_sample, b_batch_stride, acc, scale, (vx_bf16*)da);
+    else hipLaunchKernelGGL(vx_sqdiff_sum_grad_bs_k<float>, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, (const float*)a, b, n_per_sample, b_batch_stride, acc, scale, (float*)da);
     VX_LAUNCH_CHECK("vx_sqdiff_sum_grad_bs");
     return 0;
+}
+extern "C" int vx_sqdiff_sum_grad_bs(const float* a, const float* b, long n_per_sample, long b_batch_stride, int B, double* acc, float scale, float* da, void* stream) {
+    return vx_sqdiff_sum_grad_bs_h(a, b, n_per_sample, b_batch_stride, B, acc, scale, da, 0, stream);
 }
 __global__ void __launch_bounds__(256) vx_mse_bwd_bs_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ coef,
                                                        const float* __restrict__ gout, float* __restrict__ da, long n, long bstride) {

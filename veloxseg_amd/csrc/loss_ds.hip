@@ -542,9 +542,11 @@ __device__ __forceinline__ void vx_ds_interp_col(const VxDs& P, int hh, const fl
     }
 }
 
-template <int C, int NK>
+// TL = element type of the full-resolution head l0 and (backward) of its gradient dl0: float, or vx_bf16 in the bf16 storage mode (P.l0 / P.dl0 are then bf16 arrays)
+template <int C, int NK, typename TL = float>
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const void* __restrict__ lab, int lab_kind, double* __restrict__ acc) {
     constexpr int NS = 1 + 2 * C;
+    const TL* __restrict__ l0p = reinterpret_cast<const TL*>(P.l0);
     extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
     const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
     const int W4 = P.W >> 2, NRG = 256 / W4;
@@ -584,7 +586,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
         const long o = ((long)Z * P.H + Y) * P.W + X0;
         vx_lab4(lab, lab_kind, (long)b * V + o, yn);
 #pragma unroll
-        for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
+        for (int c = 0; c < C; ++c) ln[c] = vx_ld4(l0p, ((long)b * C + c) * V + o);
     };
     if (y0 < y1) fetch(y0, ynA, lnA);
     if (y0 + 1 < y1) fetch(y0 + 1, ynB, lnB);
@@ -693,10 +695,12 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_fwd_col_k(VxDs P, const vo
 }
 
 // backward, column owners.  LDS: accw[wave][nacc] (layout [head][ca][y][x], as the row-sweep kernel) | padded slices
-template <int C, int NK>
+template <int C, int NK, typename TL = float>
 __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const void* __restrict__ lab, int lab_kind, const float* __restrict__ coef, int coef_stride,
                                                                 const float* __restrict__ gout, int nacc) {
     extern __shared__ __attribute__((aligned(16))) float vx_ds_lds[];
+    const TL* __restrict__ l0p = reinterpret_cast<const TL*>(P.l0);
+    TL* __restrict__ dl0p = reinterpret_cast<TL*>(P.dl0);
     const int b = blockIdx.y, Z = blockIdx.x / P.nsplit, part = blockIdx.x % P.nsplit;
     const int W4 = P.W >> 2, NRG = 256 / W4, nlow = P.nh - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
         const long o = ((long)Z * P.H + Y) * P.W + X0;
         vx_lab4(lab, lab_kind, (long)b * V + o, yn);
 #pragma unroll
-        for (int c = 0; c < C; ++c) ln[c] = *reinterpret_cast<const float4*>(P.l0 + ((long)b * C + c) * V + o);
+        for (int c = 0; c < C; ++c) ln[c] = vx_ld4(l0p, ((long)b * C + c) * V + o);
     };
     if (y0 < y1) fetch(y0);
     for (int Y = y0; Y < y1; ++Y) {          // (the row's global operands one row ahead of the arithmetic; two rows ahead -- two register buffers -- costs 60 VGPRs here and gains nothing)
@@ -808,7 +812,7 @@ __global__ void __launch_bounds__(256) vx_seg_loss_ds_bwd_col_k(VxDs P, const vo
                 if (h == 0) {
 #pragma unroll
                     for (int c = 0; c < C; ++c)
-                        *reinterpret_cast<float4*>(P.dl0 + ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0) = make_float4(g[c][0], g[c][1], g[c][2], g[c][3]);
+                        vx_st4(dl0p, ((long)b * C + c) * V + ((long)Z * P.H + Y) * P.W + X0, make_float4(g[c][0], g[c][1], g[c][2], g[c][3]));
                 } else {
                     const int hh = h - 1;
                     if (a1 != cur[hh]) {                                   // the row pair moves on (by one row, every 1 / scale rows): the finished coarse row leaves the registers
@@ -905,6 +909,10 @@ static size_t vx_ds_slice_floats(const VxDs& P, int C) {
     return n;
 }
 
+// bf16 storage mode (the *_h entries): head 0 and its gradient are vx_bf16 arrays -- column-owner kernels only; call-scoped flag
+static thread_local int t_ds_h16 = 0;
+namespace { struct DsH16Scope { int prev; explicit DsH16Scope(int h) : prev(t_ds_h16) { t_ds_h16 = h; } ~DsH16Scope() { t_ds_h16 = prev; } }; }
+
 // 1 when the fused kernels cover this shape (else: up-sample + vx_seg_loss_fwd / _bwd4)
 extern "C" int vx_seg_loss_ds_ok(int C, int D, int H, int W) {
     (void)D; (void)H;
@@ -943,13 +951,16 @@ extern "C" int vx_seg_loss_ds_fwd(const float* l0, const float* l1, const float*
         { const char* e = getenv("VX_DS_DBG"); P.dbg = e ? atoi(e) : 0; }
         const dim3 grid(D * P.nsplit, B);
 #define VX_DS_FWD_COL(CC)                                                                                                              \
-        { if (nk == 3) vx_seg_loss_ds_fwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc);                            \
+        { if (t_ds_h16) { if (nk == 3) vx_seg_loss_ds_fwd_col_k<CC, 3, vx_bf16><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc);            \
+                          else vx_seg_loss_ds_fwd_col_k<CC, 4, vx_bf16><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc); }                  \
+          else if (nk == 3) vx_seg_loss_ds_fwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc);                       \
           else vx_seg_loss_ds_fwd_col_k<CC, 4><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, acc); }
         if (C == 2) VX_DS_FWD_COL(2) else if (C == 3) VX_DS_FWD_COL(3) else VX_DS_FWD_COL(4)
 #undef VX_DS_FWD_COL
         VX_LAUNCH_CHECK("vx_seg_loss_ds_fwd (columns)");
         return 0;
     }
+    VX_REQUIRE(!t_ds_h16, "vx_seg_loss_ds_fwd_h: a 16-bit head 0 needs the column-owner kernels (vx_seg_loss_ds_h16_ok)");
     if (C == 2) VX_DS_FWD(2) else if (C == 3) VX_DS_FWD(3) else VX_DS_FWD(4)
 #undef VX_DS_FWD
     VX_LAUNCH_CHECK("vx_seg_loss_ds_fwd");
@@ -1023,14 +1034,56 @@ extern "C" int vx_seg_loss_ds_bwd(const float* l0, const float* l1, const float*
     const size_t shm_col = ((size_t)4 * nacc + vx_ds_slice_pad_floats(P, C)) * sizeof(float);
     if (nk && shm_col <= 48 * 1024) {
 #define VX_DS_BWD_COL(CC)                                                                                                              \
-        { if (nk == 3) vx_seg_loss_ds_bwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);   \
+        { if (t_ds_h16) { if (nk == 3) vx_seg_loss_ds_bwd_col_k<CC, 3, vx_bf16><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);   \
+                          else vx_seg_loss_ds_bwd_col_k<CC, 4, vx_bf16><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc); }         \
+          else if (nk == 3) vx_seg_loss_ds_bwd_col_k<CC, 3><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc);   \
           else vx_seg_loss_ds_bwd_col_k<CC, 4><<<grid, blk, shm_col, st>>>(P, labels, lab_kind, coef, coef_stride, gout, nacc); }
         if (C == 2) VX_DS_BWD_COL(2) else if (C == 3) VX_DS_BWD_COL(3) else VX_DS_BWD_COL(4)
 #undef VX_DS_BWD_COL
-    } else
+    } else if (t_ds_h16) { VX_FAIL(-1, "vx_seg_loss_ds_bwd_h: a 16-bit head 0 needs the column-owner kernels (vx_seg_loss_ds_h16_ok)"); }
+    else
     if (C == 2) VX_DS_BWD(2) else if (C == 3) VX_DS_BWD(3) else VX_DS_BWD(4)
 #undef VX_DS_BWD
     if (nh > 1) vx_seg_loss_ds_adj_z_k<<<dim3(vx_cdiv(total, 32)), blk, 0, st>>>(Zp);
     VX_LAUNCH_CHECK("vx_seg_loss_ds_bwd");
     return 0;
+}
+
+
+// ---- bf16 storage mode: head 0 (the full-resolution logits) and its gradient as 16-bit arrays; the low-resolution heads, the accumulators and the workspace stay fp32
+// 1 when both directions would run the column-owner kernels at this geometry (the only ones with 16-bit instances)
+extern "C" int vx_seg_loss_ds_h16_ok(const int* low_dims, int nh, int B, int C, int D, int H, int W) {
+    if (!vx_seg_loss_ds_ok(C, D, H, W) || nh < 2 || nh > 4 || !low_dims) return 0;
+    VxDs P = {};
+    static const float dummy = 0.0f;
+    if (vx_ds_fill(P, &dummy, &dummy, &dummy, &dummy, low_dims, nh, B, C, D, H, W, "vx_seg_loss_ds_h16_ok") != 0) return 0;
+    if (vx_ds_slice_floats(P, C) * sizeof(float) > 120 * 1024) return 0;                     // (forward: P.stage)
+    const int nk = vx_ds_columns_nk(P);
+    if (!nk) return 0;
+    int nacc = 0;
+    for (int hh = 0; hh < nh - 1; ++hh) nacc += C * P.ld[hh][1] * P.ld[hh][2];
+    if (vx_ds_slice_pad_floats(P, C) * sizeof(float) > 48 * 1024) return 0;
+    if (((size_t)4 * nacc + vx_ds_slice_pad_floats(P, C)) * sizeof(float) > 48 * 1024) return 0;
+    // backward: P.stage of vx_seg_loss_ds_bwd
+    const int RPW = 64 / (W >> 2);
+    size_t ntab = 0;
+    for (int hh = 0; hh < nh - 1; ++hh) {
+        const int wl = P.ld[hh][2];
+        const float ratio = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.0f;
+        const int bwd_ = (wl == W || ratio <= 0.0f) ? W : ((int)(2.0f / ratio) + 4 < W ? (int)(2.0f / ratio) + 4 : W);
+        ntab += (size_t)wl * bwd_;
+    }
+    const size_t shm_base = ((size_t)4 * nacc + (size_t)4 * RPW * 3 * C * W + ((ntab + 3) & ~(size_t)3) + (size_t)3 * W) * sizeof(float);
+    return shm_base + vx_ds_slice_floats(P, C) * sizeof(float) <= 150 * 1024 ? 1 : 0;
+}
+extern "C" int vx_seg_loss_ds_fwd_h(const void* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                                    double* acc, int B, int C, int D, int H, int W, int l0_h16, void* stream) {
+    DsH16Scope sc(l0_h16 ? 1 : 0);
+    return vx_seg_loss_ds_fwd((const float*)l0, l1, l2, l3, low_dims, nh, labels, lab_kind, acc, B, C, D, H, W, stream);
+}
+extern "C" int vx_seg_loss_ds_bwd_h(const void* l0, const float* l1, const float* l2, const float* l3, const int* low_dims, int nh, const void* labels, int lab_kind,
+                                    const float* coef, int coef_stride, const float* gout, void* dl0, float* dl1, float* dl2, float* dl3, float* ws,
+                                    int B, int C, int D, int H, int W, int l0_h16, void* stream) {
+    DsH16Scope sc(l0_h16 ? 1 : 0);
+    return vx_seg_loss_ds_bwd((const float*)l0, l1, l2, l3, low_dims, nh, labels, lab_kind, coef, coef_stride, gout, (float*)dl0, dl1, dl2, dl3, ws, B, C, D, H, W, stream);
 }

@@ -601,7 +601,12 @@ class TrainEngine:
         encs, flat_attn = leaves[:4], leaves[4:]
         attn = [flat_attn[L * M:(L + 1) * M] for L in range(4)]
         self._leaves[k] = leaves
-        self._outs[k] = list(self.model.decode_branch(k, attn, encs))
+        dec = self.model.decoder if k == 0 else self.model.rc_decoders[k - 1]
+        dec.head_bf16 = self._head_bf16(k)          # bf16 storage mode: this branch's full-resolution output (and, from the staged loss, its gradient) as bfloat16
+        try:
+            self._outs[k] = list(self.model.decode_branch(k, attn, encs))
+        finally:
+            dec.head_bf16 = False
         bl = self._branch_loss()
         if bl is not None:        # this branch's share of the loss forward, on this branch's stream (functional.StagedLoss)
             if k == 0:
@@ -610,6 +615,27 @@ class TrainEngine:
                 bl.seg_forward([t.detach() for t in self._outs[0][:-1]], self.labels)
             else:
                 self._rc_c[k] = bl.rc_forward(self._outs[k][0].detach(), self.x, self._ch_off[k - 1])
+
+    def _head_bf16(self, k):
+        """bf16 storage mode (precision "bf16", functional.BF16_STORAGE): may decoder branch k hand its full-resolution output to the staged loss as a bfloat16 tensor?
+        The reconstruction branches always (vx_sqdiff_sum_grad_bs_h takes any shape); the segmentation branch when the fused deep-supervision loss runs its column-owner
+        kernels at this geometry (vx_seg_loss_ds_h16_ok), the only ones with 16-bit instances.  Only inside the staged passes: a criterion called on the assembled output
+        list (eager single pass, foreign criteria) gets fp32 tensors."""
+        if self.precision != "bf16" or not VF.BF16_STORAGE or getattr(self, "_bl", None) is None or VF.get_precision() != "bf16":
+            return False
+        if k > 0:
+            return True
+        ok = getattr(self, "_seg_h16_ok", None)
+        if ok is None:
+            import ctypes
+            ok = False
+            if getattr(self, "_ds_fused", False) and getattr(self.model.decoder, "deep_supervision", False):
+                S = [int(v) for v in self.x.shape[2:]]
+                ps = int(self.model.patch_size)
+                dims = (ctypes.c_int * 9)(*[max(s // (ps * f), 1) for f in (2, 4, 8) for s in S])
+                ok = bool(H.query("vx_seg_loss_ds_h16_ok", ctypes.addressof(dims), 4, int(self.x.shape[0]), self._n_classes(), *S))
+            self._seg_h16_ok = ok
+        return ok
 
     def _branch_loss(self):
         """the loss taken apart into per-branch pieces (taped steps with the library's own Loss only; any other criterion runs as one call in _s_loss)"""

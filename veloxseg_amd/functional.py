@@ -465,9 +465,12 @@ def _ops():
     return torch.ops.veloxseg if (USE_DISPATCH and _cpp_node("conv") is not None) else None
 
 
-def conv3d(x, w, b=None, *, x2=None, stride=1, padding=0, groups=1, pixel_shuffle=1):
-    """Conv3d (+ optional channel-concat input, + optional PixelShuffle store)."""
+def conv3d(x, w, b=None, *, x2=None, stride=1, padding=0, groups=1, pixel_shuffle=1, out_bf16=False):
+    """Conv3d (+ optional channel-concat input, + optional PixelShuffle store).  out_bf16 (bf16 storage mode, patch-expand layers only): the output is a bfloat16 tensor
+    -- the full-resolution logits / reconstructions -- and the backward accepts a bfloat16 gradient; ignored wherever the 16-bit kernels do not apply."""
     m = _cpp_node("conv") if x.is_cuda else None
+    if out_bf16 and m is not None and x2 is None and _PRECISION == "bf16" and BF16_STORAGE:
+        return m.conv_h(x, w, b, int(w.shape[2]), int(stride), int(padding), int(groups), int(pixel_shuffle))
     if m is not None and x2 is None and USE_DISPATCH:
         return torch.ops.veloxseg.conv3d(x, w, b, int(stride), int(padding), int(groups), int(pixel_shuffle))
     if m is not None:
@@ -1518,7 +1521,9 @@ class StagedLoss:
 
     def seg_forward(self, logits, labels):
         logits = [_c(t) for t in logits]
-        _check(logits[0], "loss")
+        h16 = logits[0].dtype == torch.bfloat16          # bf16 storage mode: head 0 (the full-resolution logits) is a bfloat16 tensor; the low-resolution heads stay fp32
+        if not h16:
+            _check(logits[0], "loss")
         nh, B, C = self.nh, self.B, self.C
         assert len(logits) == nh and logits[0].shape[0] == B and logits[0].shape[1] == C
         if labels.dtype not in _LAB_KIND:
@@ -1526,15 +1531,17 @@ class StagedLoss:
         labels = _c(labels)
         V = logits[0][0, 0].numel()
         st = H.stream_ptr()
-        lp = [H.P(t) for t in logits] + [None] * (4 - nh)
+        lp = [H.P(logits[0], None)] + [H.P(t) for t in logits[1:]] + [None] * (4 - nh)
         if any(tuple(t.shape[2:]) != tuple(logits[0].shape[2:]) for t in logits[1:]):
             D_, H_, W_ = (int(v) for v in logits[0].shape[2:])
             if not H.query("vx_seg_loss_ds_ok", C, D_, H_, W_):
                 raise RuntimeError("veloxseg_loss: deep-supervision heads on coarser grids need C in 2..4 and W % 4 == 0 with W/4 dividing 64; up-sample them first")
             dims = (H.ctypes.c_int * (3 * max(nh - 1, 1)))(*[int(v) for t in logits[1:] for v in t.shape[2:]])
             self.ds = (dims, D_, H_, W_)
-            H.call("vx_seg_loss_ds_fwd", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(self.seg_acc, torch.float64), B, C, D_, H_, W_, st)
+            H.call("vx_seg_loss_ds_fwd_h", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(self.seg_acc, torch.float64), B, C, D_, H_, W_, int(h16), st)
         else:
+            if h16:
+                raise RuntimeError("staged loss: a bfloat16 head 0 needs the fused deep-supervision kernels (heads 1.. on their own grids)")
             H.call("vx_seg_loss_fwd", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], H.P(self.seg_acc, torch.float64), B, C, V, st)
         self.logits, self.labels, self.V = logits, labels, V
 
@@ -1546,7 +1553,8 @@ class StagedLoss:
 
     def rc_forward(self, rc, x, ch_off):
         """this branch's sum of squares against its channels of the input AND -- the coefficient 2 w_rc / N_rc is known already: the reconstructions cover the input, so
-        N_rc = x.numel() (checked in finalize) -- its MSE gradient, in one pass (vx_sqdiff_sum_grad_bs); rc_backward hands the stored gradient out"""
+        N_rc = x.numel() (checked in finalize) -- its MSE gradient, in one pass (vx_sqdiff_sum_grad_bs); rc_backward hands the stored gradient out.
+        A bfloat16 reconstruction (bf16 storage mode) gets a bfloat16 gradient; the sum of squares is formed in fp32 / fp64 either way."""
         import numpy as _np
         rc = _c(rc)
         ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
@@ -1554,7 +1562,7 @@ class StagedLoss:
         self.n_rc_expected = int(x.numel())
         scale = float(_np.float32(2.0 * self.w_rc / float(self.n_rc_expected))) if self.w_rc != 0.0 else 0.0
         drc = torch.empty_like(rc)
-        H.call("vx_sqdiff_sum_grad_bs", H.P(rc), ptr, n, bstride, rc.shape[0], H.P(self.rc_acc, torch.float64), scale, H.P(drc), H.stream_ptr())
+        H.call("vx_sqdiff_sum_grad_bs_h", H.P(rc, None), ptr, n, bstride, rc.shape[0], H.P(self.rc_acc, torch.float64), scale, H.P(drc, None), int(rc.dtype == torch.bfloat16), H.stream_ptr())
         self._drc = getattr(self, "_drc", {})
         self._drc[int(ch_off)] = drc
         return rc
@@ -1585,17 +1593,18 @@ class StagedLoss:
     def seg_backward(self):
         nh, B, C = self.nh, self.B, self.C
         logits, labels = self.logits, self.labels
+        h16 = logits[0].dtype == torch.bfloat16
         st = H.stream_ptr()
         stride = (1 + B * C * 2) * 4
-        grads = [torch.empty_like(t) for t in logits]
-        lp = [H.P(t) for t in logits] + [None] * (4 - nh)
-        gp = [H.P(d) for d in grads] + [None] * (4 - nh)
+        grads = [torch.empty_like(t) for t in logits]          # (head 0's gradient has head 0's dtype)
+        lp = [H.P(logits[0], None)] + [H.P(t) for t in logits[1:]] + [None] * (4 - nh)
+        gp = [H.P(grads[0], None)] + [H.P(d) for d in grads[1:]] + [None] * (4 - nh)
         if self.ds is not None:
             dims, D_, H_, W_ = self.ds
             nws = H.query("vx_seg_loss_ds_ws_floats", H.ctypes.addressof(dims), nh, B, C, D_)
             ws = torch.empty((max(nws, 1),), device=grads[0].device, dtype=torch.float32)
-            H.call("vx_seg_loss_ds_bwd", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], self.coef.data_ptr(), stride // 4, None, *gp,
-                   H.P(ws), B, C, D_, H_, W_, st)
+            H.call("vx_seg_loss_ds_bwd_h", *lp, H.ctypes.addressof(dims), nh, H.P(labels, None), _LAB_KIND[labels.dtype], self.coef.data_ptr(), stride // 4, None, *gp,
+                   H.P(ws), B, C, D_, H_, W_, int(h16), st)
         else:
             H.call("vx_seg_loss_bwd4", *lp, nh, H.P(labels, None), _LAB_KIND[labels.dtype], self.coef.data_ptr(), stride // 4, None, *gp, B, C, self.V, st)
         return grads
@@ -1605,6 +1614,8 @@ class StagedLoss:
         if drc is not None and drc.shape == rc.shape:
             return drc                                   # formed by rc_forward
         ptr, bstride, n = self._slice(x, ch_off, rc.shape[1])
+        if rc.dtype != torch.float32:
+            raise RuntimeError("staged loss: the gradient of a bfloat16 reconstruction is formed by rc_forward")
         drc = torch.empty_like(rc)
         H.call("vx_mse_bwd_bs", H.P(rc), ptr, n, bstride, rc.shape[0], self.misc, None, H.P(drc), H.stream_ptr())
         return drc

@@ -42,7 +42,8 @@ class RC_Decoder(nn.Module):
         """attn_feats / enc_feats: 4 tensors each; the channel concat (VeloxSeg.py:209-214) happens inside the 1x1 kernel."""
         e = [VF.instnorm_sum([getattr(self, f"enc2rc_{L + 1}")[0](attn_feats[L], x2=enc_feats[L])]) for L in range(4)]
         up1, _, _ = _trunk_forward(self, *e)
-        rc = self.out_conv[0](up1, pixel_shuffle=self.patch_size)
+        # head_bf16 (set by engine.TrainEngine for its staged passes in the bf16 storage mode): the full-resolution output as a bfloat16 tensor
+        rc = self.out_conv[0](up1, pixel_shuffle=self.patch_size, out_bf16=self.training and getattr(self, "head_bf16", False))
         if self.training:
             return rc, get_pram_matrix(up1)
         return rc
@@ -66,7 +67,7 @@ class Seg_Decoder(nn.Module):
 
     def forward(self, enc1, enc2, enc3, enc4):
         up1, up2, up3 = _trunk_forward(self, enc1, enc2, enc3, enc4)
-        out = self.out_conv1[0](up1, pixel_shuffle=self.patch_size)
+        out = self.out_conv1[0](up1, pixel_shuffle=self.patch_size, out_bf16=self.training and getattr(self, "head_bf16", False))
         if self.training:
             if self.deep_supervision:
                 return [out, self.out_conv2(up2), self.out_conv3(up3), self.out_conv4(enc4)], get_pram_matrix(up1)

@@ -15,9 +15,9 @@ class ParamConv3d(nn.Conv3d):
     """nn.Conv3d used as a PARAMETER HOLDER (same names, shapes, default init and RNG consumption as the
     reference's nn.Conv3d); the arithmetic is the HIP kernel behind veloxseg_amd.functional.conv3d."""
 
-    def forward(self, x, x2=None, pixel_shuffle: int = 1):
+    def forward(self, x, x2=None, pixel_shuffle: int = 1, out_bf16: bool = False):
         return VF.conv3d(x, self.weight, self.bias, x2=x2, stride=self.stride[0], padding=self.padding[0],
-                         groups=self.groups, pixel_shuffle=pixel_shuffle)
+                         groups=self.groups, pixel_shuffle=pixel_shuffle, out_bf16=out_bf16)
 
 
 class ParamConvTranspose3d(nn.ConvTranspose3d):
