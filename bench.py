@@ -48,7 +48,9 @@ STEP_WORK = {"autopet128": (58.50, 569.1, 73.0), "autopet96": (24.11, 240.1, 73.
              "hecktor": (28.83, 284.6, 73.3)}
 EVAL_GFLOP = {"autopet96": 3.50, "autopet128": 8.75, "brats96": 5.13, "brats128": 12.26, "hecktor": 4.19}      # eval forward, 2 x MAC per patch (hecktor: round 6, same method)
 PUBLISHED_EVAL = {"autopet96": 599.06}      # README.md:215 (RTX 3090, autocast, batch <= 16, 10 s + 60 s: speed_test.py:117-134) -- the reference's only GPU number
-BF16_DTYPE = "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions of the 32^3 / 16^3 levels (fp32 accumulate, fp32 storage, fp32-level arithmetic everywhere else)"
+BF16_DTYPE = ("bf16: 16-bit STORAGE of the full-resolution logits / reconstructions and their gradients and of the block-internal tensors (y_k, o, dn, d_o, g_k) of the 32^3-level JLC blocks; "
+              "bf16 MFMA operands in the patch-expand layers and the JLC grouped convolutions of the 32^3 / 16^3 levels; fp32: accumulation, InstanceNorm / LayerNorm statistics, soft-max, "
+              "loss sums, master weights, flat gradients, AdamW, every block-boundary tensor and everything at <= 16^3 (VELOXSEG_BF16_STORAGE=0: operands only, fp32 storage)")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector / fp32-input MFMA peak
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is NOT used)
@@ -423,7 +425,7 @@ def main():
                                 "achieved_gbs": round(byts / sec / 1e9, 1), "frac_hbm": round(byts / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
                                 "note": "whole step against the fp32 vector/MFMA peak and the HBM peak of the GPUs used (SURVEY.md 8d work model)"}
     if rank == 0:
-        st_ = _step_traffic(args.workload, B)
+        st_ = _step_traffic(args.workload, B, None, args.dtype)
         if st_ is not None:
             st_["algorithmic_bytes"] = byts / world
             st_["ratio"] = round(st_["counter_bytes_per_step"] / (byts / world), 2)
@@ -634,7 +636,18 @@ def _kernel_pass(out, prof, model, workload, B):
     alias = {"vx_pwa_attn_fwd_mb": "vx_pwa_attn_fwd", "vx_pwa_attn_bwd_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold_mb": "vx_pwa_attn_bwd", "vx_pwa_attn_bwd_nofold": "vx_pwa_attn_bwd",
              # (round 5: the operator code calls the entries that take the pieces mode explicitly -- same kernels, one more trailing integer in the key)
              "vx_jlc_wgrad_tz_ns": "vx_jlc_wgrad_tz", "vx_jlc_tz_fwd_ns": "vx_jlc_tz_fwd", "vx_jlc_tz_bwd_ns": "vx_jlc_tz_bwd", "vx_jlc_tz_prep_ns": "vx_jlc_tz_prep"}
-    rows = [(t_, n_, (alias.get(nm, nm) if nm.endswith("_ns") else nm, (tuple(k_[:-1]) if nm.endswith("_ns") and nm != "vx_jlc_tz_prep_ns" else k_))) for t_, n_, (nm, k_) in rows]
+    # (round 6: the *_h entries = the same kernels with the storage type of some tensors as trailing flags -- h16 = 0 in the fp32 mode: (entry, trailing integers to drop))
+    h_alias = {"vx_jlc_tz_fwd_h": ("vx_jlc_tz_fwd", 2), "vx_jlc_tz_bwd_h": ("vx_jlc_tz_bwd", 2), "vx_jlc_wgrad_tz_h": ("vx_jlc_wgrad_tz", 2), "vx_mlp_fwd_h": ("vx_mlp_fwd", 1),
+               "vx_mlp_bwd_h": ("vx_mlp_bwd", 1), "vx_seg_loss_ds_fwd_h": ("vx_seg_loss_ds_fwd", 1), "vx_seg_loss_ds_bwd_h": ("vx_seg_loss_ds_bwd", 1),
+               "vx_jlc_mid_fwd_h": ("vx_jlc_mid_fwd", 1), "vx_jlc_mid_bwd_h": ("vx_jlc_mid_bwd", 1), "vx_jlc_gk_h": ("vx_jlc_gk", 1)}
+
+    def _canon(nm, k_):
+        if nm in h_alias:
+            return h_alias[nm][0], tuple(k_[:-h_alias[nm][1]])
+        if nm.endswith("_ns"):
+            return alias.get(nm, nm), (tuple(k_[:-1]) if nm != "vx_jlc_tz_prep_ns" else k_)
+        return nm, k_
+    rows = [(t_, n_, _canon(nm, k_)) for t_, n_, (nm, k_) in rows]
     fam = {}
     for tot_ms, n, (name, key) in rows:
         base = alias.get(name, name)
@@ -716,23 +729,37 @@ def _kernel_pass(out, prof, model, workload, B):
         out["roofline_jlc"] = rj
 
 
-def _newest_pmc():
+def _pmc_file(workload="autopet128", B=4, dtype="f32"):
+    """the newest committed PMC summary (tools/pmc_traffic.py) taken on this workload, batch and dtype; files of rounds 1-5 carry no such fields: autopet128, B = 4, f32"""
     import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
-    return fs[-1] if fs else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    import re as _re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_traffic*.json")):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if (d.get("workload", "autopet128"), int(d.get("batch", 4)), d.get("dtype", "f32")) != (workload, int(B), dtype):
+            continue
+        m = _re.match(r"r(\d+)", os.path.basename(f))
+        key = (int(m.group(1)) if m else 0, os.path.basename(f))
+        if best is None or key > best[0]:
+            best = (key, f)
+    return best[1] if best else None
 
 
-PMC_FILE = _newest_pmc()
+PMC_FILE = _pmc_file() or os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 PMC_NAME = "profiles/" + os.path.basename(PMC_FILE)
 
 
-def _step_traffic(workload, B, trace_steps=None):
+def _step_traffic(workload, B, trace_steps=None, dtype="f32"):
     """HBM bytes of ONE training step summed over every kernel of the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, gfx950 correction:
-    tools/pmc_traffic.py) -- valid for the workload / batch they were collected on (autopet128, B = 4), null otherwise"""
+    tools/pmc_traffic.py) of THIS workload, batch and dtype; null when no such passes are committed"""
     try:
-        d = json.load(open(PMC_FILE))
-        if B != 4 or workload != "autopet128":
+        f = _pmc_file(workload, B, dtype)
+        if f is None:
             return None
+        d = json.load(open(f))
         # forward/backward passes covered by the trace: the launches of a once-per-pass kernel (the optimiser kernel undercounts: capture / self-check passes run no AdamW)
         steps = trace_steps or d.get("passes_in_trace") or next((v["launches_in_trace"] for k, v in d["kernels"].items() if k.startswith("vx_loss_finalize_k")), None)
         if not steps:
@@ -742,7 +769,14 @@ def _step_traffic(workload, B, trace_steps=None):
             for g in k.get("by_grid", {}).values():
                 if "hbm_bytes_per_launch_corrected" not in k:
                     tot += float(g["hbm_bytes_per_launch_corrected"]) * g["launches_in_trace"]
-        return {"counter_bytes_per_step": round(tot / steps), "source": PMC_NAME, "passes_in_trace": steps}
+        out = {"counter_bytes_per_step": round(tot / steps), "source": "profiles/" + os.path.basename(f), "passes_in_trace": steps}
+        if dtype != "f32":                           # the bf16 line carries the fp32 figure of the same workload beside its own (<= 0.6 x asked)
+            f32 = _step_traffic(workload, B, None, "f32")
+            if f32 is not None:
+                out["f32_counter_bytes_per_step"] = f32["counter_bytes_per_step"]
+                out["f32_source"] = f32["source"]
+                out["vs_f32"] = round(out["counter_bytes_per_step"] / f32["counter_bytes_per_step"], 3)
+        return out
     except Exception:
         return None
 

@@ -850,8 +850,10 @@ def test_loss_backward_one_launch_for_all_heads_equals_per_head_launches():
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 2), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 2),
                                                     ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 16, 1), ([16, 16, 16], [8, 8, 8], 2, 8, 32, 1),
                                                     ([12, 12, 12], [6, 6, 6], 2, 8, 32, 2), ([6, 6, 6], [3, 3, 3], 2, 8, 64, 2), ([3, 3, 3], [3, 3, 3], 4, 16, 128, 2),
-                                                    ([24, 24, 24], [3, 3, 3], 1, 4, 16, 2), ([8, 8, 4], [4, 4, 2], 2, 8, 64, 2)],
-                         ids=["c8v8_ML1024", "c8v16", "c16v32", "c4v8", "c4v4_M1", "c8v8_M1", "96_L2_l216", "96_L3_l27", "96_L4_l27", "96_L1_l27", "aniso_l32"])
+                                                    ([24, 24, 24], [3, 3, 3], 1, 4, 16, 2), ([8, 8, 4], [4, 4, 2], 2, 8, 64, 2),
+                                                    # (round 6) the BraTS coarse levels: one modality, a handful of 64-token windows -> the one-pass kernel with ONE query tile per block
+                                                    ([8, 8, 8], [4, 4, 4], 2, 8, 64, 1), ([4, 4, 4], [4, 4, 4], 4, 16, 128, 1)],
+                         ids=["c8v8_ML1024", "c8v16", "c16v32", "c4v8", "c4v4_M1", "c8v8_M1", "96_L2_l216", "96_L3_l27", "96_L4_l27", "96_L1_l27", "aniso_l32", "c8v16_M1_few", "c16v32_M1_few"])
 def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh, C, M):
     """The MFMA attention kernels (csrc/pwa_mfma.hip) against the fp32-VALU kernels of the same library on the same inputs, dropout ON (p = 0.2: both
     draw the same Philox words for the same (query, key) element): outputs, dq / dk / dv and the bias-table gradient agree to fp32 summation noise.
@@ -955,6 +957,7 @@ def test_pwa_attention_valu_backward_reads_the_forwards_keep_bits(grid, big, hea
     res = {}
     try:
         H.call("vx_pwa_attn_set_f16_bwd", 0)               # (levels 1 / 2 would otherwise take the f16-pipe one-pass backward)
+        H.call("vx_pwa_attn_set_short", 0)                 # (round 6: single-modality windows would otherwise take the one-pass MFMA backward)
         for bits in (1, 0):
             H.call("vx_pwa_attn_set_valu_bits", bits)
             assert H.query("vx_pwa_attn_bwd1_ok", pp, 2, M, pl["c_qk"], pl["c_v"]) == 0          # the default rule keeps these geometries on the VALU backward
@@ -970,6 +973,7 @@ def test_pwa_attention_valu_backward_reads_the_forwards_keep_bits(grid, big, hea
     finally:
         H.call("vx_pwa_attn_set_valu_bits", 0)
         H.call("vx_pwa_attn_set_f16_bwd", 1)
+        H.call("vx_pwa_attn_set_short", 1)
     for i, (a, b) in enumerate(zip(res[1], res[0])):
         if i < M:
             assert torch.equal(a, b), f"output {i}: the forward must not depend on whether it stores the keep bits"

@@ -10,8 +10,10 @@ from oracle import veloxseg_oracle as O          # plan geometry only (tools are
 
 ONLY = os.environ.get("VX_PROBE_ONLY")
 LEVELS = {"128": [([32] * 3, [4] * 3, 1, 4, 16), ([16] * 3, [8] * 3, 2, 8, 32), ([8] * 3, [4] * 3, 2, 8, 64), ([4] * 3, [4] * 3, 4, 16, 128)],
-          "96": [([24] * 3, [3] * 3, 1, 4, 16), ([12] * 3, [6] * 3, 2, 8, 32), ([6] * 3, [3] * 3, 2, 8, 64), ([3] * 3, [3] * 3, 4, 16, 128)]}
-B, M, p = 4, 2, 0.1
+          "96": [([24] * 3, [3] * 3, 1, 4, 16), ([12] * 3, [6] * 3, 2, 8, 32), ([6] * 3, [3] * 3, 2, 8, 64), ([3] * 3, [3] * 3, 4, 16, 128)],
+          # config/models_config_hecktor2022.json: 128 x 128 x 64 patch, anisotropic windows (l = 32 / 256 tokens)
+          "heck": [([32, 32, 16], [4, 4, 2], 1, 4, 16), ([16, 16, 8], [8, 8, 4], 2, 8, 32), ([8, 8, 4], [4, 4, 2], 2, 8, 64), ([4, 4, 2], [4, 4, 2], 4, 16, 128)]}
+B, M, p = int(os.environ.get("VX_PROBE_B", "4")), int(os.environ.get("VX_PROBE_M", "2")), 0.1
 d = torch.device("cuda")
 for name, levels in LEVELS.items():
     for L, (grid, big, heads, mdh, C) in enumerate(levels, 1):

@@ -2,7 +2,8 @@
 profiles/<tag>_pmc_traffic.json: per kernel (template arguments kept, parameter list dropped) the average KB per launch and the corrected
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-byte read requests at 64 bytes).
 
-  python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [name-filter ...]
+  python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [--workload W --batch B --dtype f32|bf16] [name-filter ...]
+(the workload / batch / dtype of the traced bench.py run are recorded in the JSON: bench.py attaches a file's figures only to a line of the same workload, batch and dtype)
 """
 import csv
 import json
@@ -40,7 +41,12 @@ def collect(path, counter, by_grid=False):
 
 def main():
     fetch, write, out = sys.argv[1:4]
-    filters = sys.argv[4:] or ["vx_"]
+    rest = sys.argv[4:]
+    meta = {"workload": "autopet128", "batch": 4, "dtype": "f32"}
+    while rest and rest[0].startswith("--"):
+        meta[rest[0][2:]] = int(rest[1]) if rest[0] == "--batch" else rest[1]
+        rest = rest[2:]
+    filters = rest or ["vx_"]
     f, w = collect(fetch, "FETCH_SIZE"), collect(write, "WRITE_SIZE")
     kernels = {}
     for k in sorted(f, key=lambda k: -f[k][1]):
@@ -63,9 +69,9 @@ def main():
     passes = once[0] if once and all(o == once[0] for o in once) else None
     adamw = next((v["launches_in_trace"] for k, v in kernels.items() if k.startswith("vx_adamw_k")), None)
     total = sum(float(v["hbm_bytes_per_launch_corrected"]) * v["launches_in_trace"] for v in kernels.values())
-    doc = {"passes_in_trace": passes, "optimizer_steps_in_trace": adamw,
+    doc = {"workload": meta["workload"], "batch": meta["batch"], "dtype": meta["dtype"], "passes_in_trace": passes, "optimizer_steps_in_trace": adamw,
            "counter_bytes_per_pass": (round(total / passes) if passes else None),
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2 --dispersion-steps 0`, B=4 autopet128; traffic = "
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2 --dispersion-steps 0 --no-kernel-pass` (workload / batch / dtype: the fields above); traffic = "
                      "2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), KB -> bytes; "
                      "per-pass sum = sum over kernels of bytes per launch x launches, divided by the launches of the once-per-pass kernels",
            "kernels": kernels}

@@ -1270,19 +1270,34 @@ __global__ void __launch_bounds__(256) vx_zero_many_k(VxZeroMany z) {
         if (i < n) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-// fewer than 64 blocks with four query tiles per block: split the queries (A/B experiment: VELOXSEG_B1_FEW=1)
+// Where the one-pass kernel is the faster backward although the window length is a multiple of 16 (round 6, tools/attn_bwd_probe.py with VX_PROBE_M / VX_PROBE_B; the
+// selection of rounds 3 - 5 was measured at M = 2, B = 4 only).  The VALU kernels work in units of 64 query rows of one window and are efficient when a window has
+// many such units; microseconds per backward, one-pass / VALU:
+//   BraTS (M = 1), 128^3, B = 2:   l = 64: 35 / 87 (level 1), 22 / 49 (level 3), 27 / 60 (level 4);   l = 512 (level 2): 82 / 75
+//   Hecktor (M = 2, l = 32 / 256), B = 4:   l = 32: 75 / 81, 21 / 38, 27 / 48;   l = 256 (level 2): 124 / 103
+//   M = 2, l = 64 (128^3 levels 3 / 4):   34 / 33, 44 / 44 -- unchanged (VALU)
+// => one-pass for a single modality below 512 tokens.  (Hecktor's 32-token windows -- 64 rows per window at M = 2 -- are faster alone too, but the STEP is not: 1445 vs
+// 1455 patches/s with them on the one-pass kernel, whose blocks hold more LDS beside the other lanes' kernels; BraTS 128^3: 730 -> 748 fp32, 780 -> 821 in the bf16 mode.)
+static bool vx_b1_short(const VxAttnM& A) { return A.M == 1 && A.l < 512; }
+static int g_b1_short = -1;
+static int vx_b1_short_on() { if (g_b1_short < 0) g_b1_short = getenv("VELOXSEG_B1_SHORT") ? atoi(getenv("VELOXSEG_B1_SHORT")) : 1; return g_b1_short; }      // A/B: 0 = the selection of rounds 3 - 5
+extern "C" int vx_pwa_attn_set_short(int on) { g_b1_short = on ? 1 : 0; return 0; }
+// fewer than 64 blocks with four query tiles per block: split the queries.  M = 2 (A/B experiment, VELOXSEG_B1_FEW=1): 44 -> 32 us alone at the 4^3 level, no change of the
+// step (894 vs 895) -> off.  The short-window geometries above: 22 -> 20 us (level 3) and 27 -> 20 us (level 4) at M = 1 -> on.
 static bool vx_b1_few(const VxAttnM& A) {
-    static const int on = getenv("VELOXSEG_B1_FEW") ? atoi(getenv("VELOXSEG_B1_FEW")) : 0;          // off: 44 -> 32 us alone at the 4^3 level, no change of the step (894 vs 895)
+    static const int on = getenv("VELOXSEG_B1_FEW") ? atoi(getenv("VELOXSEG_B1_FEW")) : -1;
     const int NT = (A.l + 15) / 16;
-    return on && NT >= 2 && (long)A.BH * A.Nt * ((NT + 3) / 4) * ((NT + 3) / 4) < 64;
+    const bool use = on >= 0 ? on != 0 : (vx_b1_short_on() && vx_b1_short(A) && A.l % 16 == 0);
+    return use && NT >= 2 && (long)A.BH * A.Nt * ((NT + 3) / 4) * ((NT + 3) / 4) < 64;
 }
 extern "C" int vx_pwa_attn_bwd1_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
     if (!(vx_am_enabled & 10) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M < 1 || M > 2) return 0;
     if (!((cq == 4 && cv == 4) || (cq == 8 && cv == 8) || (cq == 8 && cv == 16) || (cq == 16 && cv == 32) || (cq == 16 && cv == 16) || (cq == 4 && cv == 8))) return 0;
     VxAttnM A;
     vx_am_fill(A, P, B, M, cq);
-    // (measured: see vx_am_enabled; a level with a handful of windows -- 16 at the 4^3 level of a 128^3 patch, B = 4 -- takes it with one query tile per block: 44 -> 34 us)
-    if (!(vx_am_enabled & 8) && P->l % 16 == 0 && !vx_b1_few(A)) return 0;
+    // (measured: see vx_am_enabled and vx_b1_short)
+    const bool prefer = (vx_am_enabled & 8) || P->l % 16 != 0 || vx_b1_few(A) || (vx_b1_short_on() && vx_b1_short(A));
+    if (!prefer) return 0;
     return vx_b1_geo(A, cq, M, vx_b1_few(A)).shm <= 80 * 1024 ? 1 : 0;
 }
 int vx_pwa_attn_bwd1(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE, const float* dO, float* dQ,
