@@ -120,6 +120,8 @@ int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, float* dx2, 
                         int B, int Cin, int Cout, long V, int accumulate, void* stream);
 int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                           int B, int Cin, int Cout, long V, void* stream);
+int vx_pw_conv_fwd_h(const void* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, long V, int x_h16, void* stream);
+int vx_pw_conv_bwd_weight_h(const void* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, long V, int x_h16, void* stream);
 
 /* small-volume variant (fp32 MFMA tiles of 16 channels x 16 voxels): dst[b,m,v] = bias[m] + sum_k Wt(m,k) src[b,k,v].
  * forward: transpose_w=0, Mch=Cout, Kch=Cin; input gradient: transpose_w=1, Mch=Cin, Kch=Cout (src:=dy, dst:=dx).  Cin_of_w = row length of w.
@@ -327,6 +329,8 @@ int vx_space_to_depth2(const float* x, float* out, int B, int C, int Dc, int Hc,
 int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, int K, void* stream);
 /* the same for a channel slice of a wider tensor: batch_stride = floats between consecutive samples of x (the slice itself contiguous within a sample) */
 int vx_patchify_bs(const float* x, long batch_stride, float* out, int B, int C, int d, int h, int w, int K, void* stream);
+/* bf16 storage mode: the patchified copy as a bf16 array (out_h16 != 0; patch size 2 / 4), read by vx_pw_conv_fwd_h / vx_pw_conv_bwd_weight_h with x_h16 != 0 */
+int vx_patchify_bs_h(const float* x, long batch_stride, void* out, int B, int C, int d, int h, int w, int K, int out_h16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Paired-Window Attention (model/components/PWA.py).  Geometry of one layer:

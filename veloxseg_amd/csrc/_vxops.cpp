@@ -207,10 +207,15 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     if (st.patch) {
         const int Ck = Cin * K * K * K;
         const long Vo = (long)Do * Ho * Wo;
-        Tensor xs = at::empty({B, Ck, Do, Ho, Wo}, x.options());
-        VX(vx_patchify_bs, fp(x), (long)x.stride(0), mp(xs), B, Cin, Do, Ho, Wo, K, stream);
+        // bf16 storage mode: the patchified copy of the network input (written once, read by this product and by its weight gradient) as a bf16 array on the large grids
+        static const bool patch_h16 = !(getenv("VELOXSEG_BF16_PATCH") && getenv("VELOXSEG_BF16_PATCH")[0] == '0');      // (A/B)
+        // (only where the product runs on the 16-byte-per-lane kernel vx_pw_fwd_v4_k -- at most 64 patch channels, one input channel per modality: with BraTS' 256
+        // patch channels the one-voxel-per-thread kernel would issue 2-byte loads and the step gets SLOWER: brats128 808 vs 818 patches/s, same box, twice)
+        const bool xs_h16 = patch_h16 && F.act_bf16 && Vo >= 16384 && Vo % 4 == 0 && (K == 2 || K == 4) && Cout % 16 == 0 && Ck <= 64 && Ck % 4 == 0 && Wo % 2 == 0;
+        Tensor xs = at::empty({B, Ck, Do, Ho, Wo}, xs_h16 ? x.options().dtype(at::kBFloat16) : x.options());
+        VX(vx_patchify_bs_h, fp(x), (long)x.stride(0), xs.data_ptr(), B, Cin, Do, Ho, Wo, K, (int)xs_h16, stream);
         if (Vo <= F.pw_mfma_max_v) VX(vx_pw_conv_mfma, fp(xs), nullptr, Ck, fp(w), 0, fp(b), mp(y), nullptr, 0, B, Cout, Ck, Ck, Vo, 0, stream);
-        else VX(vx_pw_conv_fwd, fp(xs), nullptr, Ck, fp(w), fp(b), mp(y), B, Ck, Cout, Vo, stream);
+        else VX(vx_pw_conv_fwd_h, (const void*)xs.data_ptr(), fp(w), fp(b), mp(y), B, Ck, Cout, Vo, (int)xs_h16, stream);
         st.x = xs;
         st.pw = false;
         return y;
@@ -258,8 +263,9 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
     if (st.patch) {
         if (w.requires_grad()) {
             float* dw = grad_ptr(w); float* db = grad_ptr(b);
+            const int x_h16 = x.scalar_type() == at::kBFloat16 ? 1 : 0;          // (the patchified copy of the bf16 storage mode)
             wgrad_submit(stream, dev, [=](void* s) {
-                VX(vx_pw_conv_bwd_weight, fp(x), nullptr, Cin * K * K * K, fp(dy), dw, db, B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), s);
+                VX(vx_pw_conv_bwd_weight_h, (const void*)x.data_ptr(), fp(dy), dw, db, B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), x_h16, s);
             });
         }
         return;

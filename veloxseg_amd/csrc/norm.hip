@@ -4,6 +4,7 @@
 //   the residual (conv_blocks.py:72-75, 18-21, 36-39; Encoder.py:351-360; Decoder.py:85-88,160-164).
 //   channels-first LayerNorm (attention_utils.py:29-43, eps 1e-6) is thread-local: one thread = one voxel.
 #include "vx_common.h"
+#include <type_traits>
 #include "../../include/veloxseg_hip.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -680,37 +681,52 @@ extern "C" int vx_space_to_depth2(const float* x, float* out, int B, int C, int 
 // direct-conv ones (weight gradient of the 128^3 PatchEmbed: 220 us -> s2d once in the forward + 15 us).
 // thread = one (input row, x): reads K contiguous floats, writes one float to each of K channel planes (coalesced across lanes).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ in, float* __restrict__ out, int C, int d, int h, int w, long bstride) {
+// (TO: element type of the patchified copy -- float, or vx_bf16 in the bf16 storage mode, round 6: a thread then takes TWO consecutive x, so that a plane gets 4-byte stores)
+template <int K, typename TO = float>
+__global__ void __launch_bounds__(256) vx_patchify_k(const float* __restrict__ in, TO* __restrict__ out, int C, int d, int h, int w, long bstride) {
+    constexpr int XP = std::is_same<TO, float>::value ? 1 : 2;      // x positions per thread (the host checked w % XP == 0)
     const long rows = (long)C * d * K * h * K;                  // input rows of one sample, each w*K floats long
-    const long n = rows * w;
+    const int wq = w / XP;
+    const long n = rows * wq;
     const long b = blockIdx.y;
     const long Vo = (long)d * h * w;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int x = (int)(i % w);
-        long r = i / w;
+        const int x = (int)(i % wq) * XP;
+        long r = i / wq;
         const int kh = (int)(r % K); r /= K;
         const int y = (int)(r % h); r /= h;
         const int kd = (int)(r % K); r /= K;
         const int z = (int)(r % d);
         const int c = (int)(r / d);
         const float* __restrict__ src = in + b * bstride + (((long)c * (d * K) + (z * K + kd)) * (long)(h * K) + (y * K + kh)) * (long)(w * K) + (long)x * K;
-        float v[K];
-        if (K == 4) { const float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[K - 1] = t.w; }
-        else if (K == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[0] = t.x; v[K - 1] = t.y; }
-        else {
+        float v[XP][K];
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) v[kw] = src[kw];
+        for (int p = 0; p < XP; ++p) {
+            if (K == 4) { const float4 t = *reinterpret_cast<const float4*>(src + p * K); v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][K - 1] = t.w; }
+            else if (K == 2) { const float2 t = *reinterpret_cast<const float2*>(src + p * K); v[p][0] = t.x; v[p][K - 1] = t.y; }
+            else {
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) v[p][kw] = src[p * K + kw];
+            }
         }
-        float* __restrict__ dst = out + ((b * C + c) * (long)(K * K * K) + (long)(kd * K + kh) * K) * Vo + ((long)z * h + y) * w + x;
+        TO* __restrict__ dst = out + ((b * C + c) * (long)(K * K * K) + (long)(kd * K + kh) * K) * Vo + ((long)z * h + y) * w + x;
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) dst[(long)kw * Vo] = v[kw];
+        for (int kw = 0; kw < K; ++kw) {
+            if constexpr (XP == 1) vx_st1(dst, (long)kw * Vo, v[0][kw]);
+            else *reinterpret_cast<uint32_t*>(dst + (long)kw * Vo) = vx_pack_bf16x2(v[0][kw], v[1][kw]);
+        }
     }
 }
 
 // batch_stride (floats) = distance between the samples of x: C * (d K)(h K)(w K) for a contiguous tensor, larger for a channel slice of a wider one
 // (the per-modality chunks of the network input, Encoder.py:192 of the reference) -- no .contiguous() copy in front of the patch embedding
+extern "C" int vx_patchify_bs_h(const float* x, long batch_stride, void* out_, int B, int C, int d, int h, int w, int K, int out_h16, void* stream);
 extern "C" int vx_patchify_bs(const float* x, long batch_stride, float* out, int B, int C, int d, int h, int w, int K, void* stream) {
+    return vx_patchify_bs_h(x, batch_stride, out, B, C, d, h, w, K, 0, stream);
+}
+// out_h16 != 0: the patchified copy is a vx_bf16 array (bf16 storage mode: read by vx_pw_conv_fwd_h / vx_pw_conv_bwd_weight_h)
+extern "C" int vx_patchify_bs_h(const float* x, long batch_stride, void* out_, int B, int C, int d, int h, int w, int K, int out_h16, void* stream) {
+    float* out = (float*)out_;
     VX_REQUIRE(x && out && B > 0 && C > 0 && d > 0 && h > 0 && w > 0, "vx_patchify: bad args");
     VX_REQUIRE(K == 2 || K == 3 || K == 4, "vx_patchify: patch size 2, 3 or 4 (got %d)", K);
     VX_REQUIRE(batch_stride >= (long)C * d * K * h * K * w * K && (K == 3 || batch_stride % K == 0), "vx_patchify: bad batch stride %ld", batch_stride);
@@ -719,6 +735,13 @@ extern "C" int vx_patchify_bs(const float* x, long batch_stride, float* out, int
     if (g > 16384) g = 16384;
     const dim3 grid(g, B), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    if (out_h16) {
+        VX_REQUIRE((K == 4 || K == 2) && w % 2 == 0, "vx_patchify: 16-bit output for patch size 2 / 4 and an even grid width");
+        if (K == 4) vx_patchify_k<4, vx_bf16><<<grid, blk, 0, st>>>(x, (vx_bf16*)out_, C, d, h, w, batch_stride);
+        else vx_patchify_k<2, vx_bf16><<<grid, blk, 0, st>>>(x, (vx_bf16*)out_, C, d, h, w, batch_stride);
+        VX_LAUNCH_CHECK("vx_patchify");
+        return 0;
+    }
     if (K == 4) vx_patchify_k<4><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);
     else if (K == 3) vx_patchify_k<3><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);
     else vx_patchify_k<2><<<grid, blk, 0, st>>>(x, out, C, d, h, w, batch_stride);

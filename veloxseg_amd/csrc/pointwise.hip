@@ -15,7 +15,9 @@
 
 typedef float vx_f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ const float* vx_pw_row(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin, int b, int c, long V) {
+// (TX: element type of the INPUT activations -- float, or vx_bf16 for the patchified network input of the bf16 storage mode, round 6)
+template <typename TX>
+__device__ __forceinline__ const TX* vx_pw_row(const TX* __restrict__ x, const TX* __restrict__ x2, int C1, int Cin, int b, int c, long V) {
     return (c < C1) ? x + ((long)b * C1 + c) * V : x2 + ((long)b * (Cin - C1) + (c - C1)) * V;
 }
 
@@ -37,8 +39,8 @@ __device__ __forceinline__ float vx_pw_epi(const VxPwEpi& e, float val, long idx
 static inline VxPwEpi vx_no_epi() { VxPwEpi e; e.mode = 0; e.aux = nullptr; e.drop.seed_ptr = nullptr; e.drop.stream = 0; e.drop.p = 0.0f; e.alpha = 1.0f; return e; }
 
 // y[b,co,v] = bias[co] + sum_ci w[co,ci] * x[b,ci,v]          (Cin % 4 == 0)
-template <int COT>
-__global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+template <int COT, typename TX = float>
+__global__ void __launch_bounds__(256) vx_pw_fwd_k(const TX* __restrict__ x, const TX* __restrict__ x2, int C1, int Cin,
                                                    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
                                                    int Cout, long V, VxPwEpi epi) {
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
     for (int ci = 0; ci < Cin; ci += CIB) {
         float xv[CIB];
 #pragma unroll
-        for (int u = 0; u < CIB; ++u) xv[u] = (ci + u < Cin) ? vx_pw_row(x, x2, C1, Cin, b, ci + u, V)[v] : 0.0f;
+        for (int u = 0; u < CIB; ++u) xv[u] = (ci + u < Cin) ? vx_ld1(vx_pw_row(x, x2, C1, Cin, b, ci + u, V), v) : 0.0f;
 #pragma unroll
         for (int u4 = 0; u4 < CIB; u4 += 4) {
             if (ci + u4 < Cin) {                  // wave-uniform
@@ -76,8 +78,8 @@ __global__ void __launch_bounds__(256) vx_pw_fwd_k(const float* __restrict__ x, 
 // The same product for the large volumes (V >= 16 K voxels per sample: the 32^3 level), where the kernel above spends its time on scalar weight loads between the FMAs
 // (64 s_load_dwordx4 + waits per 16 input channels) with 4-byte activation loads: one WAVE per block, 4 consecutive voxels per lane (16-byte loads / stores, every input
 // channel's load in flight before the first FMA), the 16 x Cin weight tile transposed in LDS and read as broadcast ds_read_b128.  Cout % 16 == 0, Cin <= 64, V % 4 == 0.
-template <int CINB>
-__global__ void __launch_bounds__(64) vx_pw_fwd_v4_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+template <int CINB, typename TX = float>
+__global__ void __launch_bounds__(64) vx_pw_fwd_v4_k(const TX* __restrict__ x, const TX* __restrict__ x2, int C1, int Cin,
                                                      const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int Cout, long V) {
     __shared__ __attribute__((aligned(16))) float wt[64 * 16];          // [ci][16 output channels]
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -98,7 +100,13 @@ __global__ void __launch_bounds__(64) vx_pw_fwd_v4_k(const float* __restrict__ x
             const int c = c0 + u;
             // (address arithmetic on integers + an explicit global address space: a pointer select between x and x2 would make these FLAT loads)
             const unsigned long long base = (c < C1) ? (unsigned long long)(x + ((long)b * C1 + c) * V) : (unsigned long long)(x2 + ((long)b * (Cin - C1) + (c - C1)) * V);
-            xv[u] = (c < Cin) ? *(gf4)(base + (unsigned long long)v * 4ull) : (f4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (std::is_same<TX, float>::value) xv[u] = (c < Cin) ? *(gf4)(base + (unsigned long long)v * 4ull) : (f4){0.f, 0.f, 0.f, 0.f};
+            else {
+                typedef unsigned int u2_ __attribute__((ext_vector_type(2)));
+                typedef const __attribute__((address_space(1))) u2_* gu2;
+                const u2_ t = (c < Cin) ? *(gu2)(base + (unsigned long long)v * 2ull) : (u2_){0u, 0u};
+                xv[u] = (f4){vx_bf16_lo(t[0]), vx_bf16_hi(t[0]), vx_bf16_lo(t[1]), vx_bf16_hi(t[1])};
+            }
         }
 #pragma unroll
         for (int u = 0; u < CINB; ++u) {
@@ -168,7 +176,8 @@ __global__ void __launch_bounds__(256) vx_pw_bwd_data_k(const float* __restrict_
 // iteration with all eight 16-byte operand loads issued before the 16 MFMAs; the 4 waves of a block (same tile, adjacent chunks) are
 // summed through LDS so that a block issues 256 float atomics, not 1024 (with ~2 k waves on one 16x16 tile the atomics on its 256
 // addresses, not the loads, were the cost: 56 us for 17 MB).
-__device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+template <typename TX = float>
+__device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, const TX* __restrict__ x, const TX* __restrict__ x2, int C1, int Cin,
                                                      const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
                                                      float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
     __shared__ float red[4][4 * 64 + 16];
@@ -184,7 +193,7 @@ __device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, c
     const int co = mt * 16 + r, ci = nt * 16 + r;
     const bool co_ok = co < Cout, ci_ok = ci < Cin;
     const float* __restrict__ arow = dy + ((long)b * Cout + (co_ok ? co : 0)) * V;
-    const float* __restrict__ brow = vx_pw_row(x, x2, C1, Cin, b, ci_ok ? ci : 0, V);
+    const TX* __restrict__ brow = vx_pw_row(x, x2, C1, Cin, b, ci_ok ? ci : 0, V);
     vx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     const bool vec = (V & 3) == 0;
@@ -196,7 +205,7 @@ __device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, c
             for (int s4 = 0; s4 < 4; ++s4) {
                 const long v = vb + 16 * s4 + 4 * q;
                 av[s4] = co_ok ? *reinterpret_cast<const float4*>(arow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[s4] = ci_ok ? *reinterpret_cast<const float4*>(brow + v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[s4] = ci_ok ? vx_ld4(brow, v) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -215,7 +224,7 @@ __device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, c
         for (int u = 0; u < 4; ++u) {
             const bool in = v + u < v1;
             a4[u] = (in && co_ok) ? arow[v + u] : 0.0f;
-            b4[u] = (in && ci_ok) ? brow[v + u] : 0.0f;
+            b4[u] = (in && ci_ok) ? vx_ld1(brow, v + u) : 0.0f;
         }
         bsum += (a4[0] + a4[1]) + (a4[2] + a4[3]);
 #pragma unroll
@@ -237,10 +246,11 @@ __device__ __forceinline__ void vx_pw_wgrad_body(const int vbx, const int vby, c
     if (db != nullptr && nt == 0 && q == 0 && co_ok)
         atomicAdd(db + co, (red[0][256 + r] + red[1][256 + r]) + (red[2][256 + r] + red[3][256 + r]));
 }
-__global__ void __launch_bounds__(256) vx_pw_wgrad_k(const float* __restrict__ x, const float* __restrict__ x2, int C1, int Cin,
+template <typename TX = float>
+__global__ void __launch_bounds__(256) vx_pw_wgrad_k(const TX* __restrict__ x, const TX* __restrict__ x2, int C1, int Cin,
                                                      const float* __restrict__ dy, int Cout, long V, int B, float* __restrict__ dw,
                                                      float* __restrict__ db, int vox_per_wave, int chunks_per_b, int n_ci_tiles) {
-    vx_pw_wgrad_body(blockIdx.x, blockIdx.y, x, x2, C1, Cin, dy, Cout, V, B, dw, db, vox_per_wave, chunks_per_b, n_ci_tiles);
+    vx_pw_wgrad_body<TX>(blockIdx.x, blockIdx.y, x, x2, C1, Cin, dy, Cout, V, B, dw, db, vox_per_wave, chunks_per_b, n_ci_tiles);
 }
 
 template <int N> using vx_ic3 = std::integral_constant<int, N>;
@@ -248,8 +258,9 @@ template <int N> using vx_ic3 = std::integral_constant<int, N>;
 static int vx_pw_v4 = 1;
 extern "C" int vx_pw_conv_set_v4(int on) { vx_pw_v4 = on ? 1 : 0; return 0; }      // A/B knob: the one-wave 16-byte forward kernel for large volumes (vx_pw_fwd_v4_k)
 static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
-                               int B, int Cin, int Cout, long V, void* stream, const VxPwEpi& epi) {
+                               int B, int Cin, int Cout, long V, void* stream, const VxPwEpi& epi, int x_h16 = 0) {
     VX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_fwd: bad args");
+    VX_REQUIRE(!x_h16 || (!x2 && epi.mode == 0), "vx_pw_conv_fwd: a 16-bit input takes no concat source and no epilogue");
     VX_REQUIRE(Cin % 4 == 0, "vx_pw_conv_fwd: Cin must be a multiple of 4 (got %d)", Cin);
     if (C1 <= 0 || C1 > Cin) C1 = Cin;
     VX_REQUIRE(C1 == Cin || x2, "vx_pw_conv_fwd: x2 missing");
@@ -258,6 +269,11 @@ static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const fl
     hipStream_t st = (hipStream_t)stream;
     if (vx_pw_v4 && epi.mode == 0 && Cout % 16 == 0 && Cin <= 64 && V % 4 == 0 && V >= 16384) {
         const dim3 g4(vx_cdiv(V, 256), Cout / 16, B);
+        if (x_h16) {
+            const vx_bf16* xh = reinterpret_cast<const vx_bf16*>(x);
+            if (Cin <= 32) vx_pw_fwd_v4_k<32, vx_bf16><<<g4, 64, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V);
+            else vx_pw_fwd_v4_k<16, vx_bf16><<<g4, 64, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V);
+        } else
         if (Cin <= 32) vx_pw_fwd_v4_k<32><<<g4, 64, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V);
         else vx_pw_fwd_v4_k<16><<<g4, 64, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V);
         VX_LAUNCH_CHECK("vx_pw_conv_fwd (v4)");
@@ -265,6 +281,18 @@ static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const fl
     }
     while (T > 1 && (long)vx_cdiv(V, 256) * (Cout / T) * B < 512) T >>= 1;     // small volumes: trade register blocking for more blocks
     dim3 grid(vx_cdiv(V, 256), Cout / T, B);
+    if (x_h16) {
+        const vx_bf16* xh = reinterpret_cast<const vx_bf16*>(x);
+        switch (T) {
+            case 16: vx_pw_fwd_k<16, vx_bf16><<<grid, 256, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V, epi); break;
+            case 8: vx_pw_fwd_k<8, vx_bf16><<<grid, 256, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V, epi); break;
+            case 4: vx_pw_fwd_k<4, vx_bf16><<<grid, 256, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V, epi); break;
+            case 2: vx_pw_fwd_k<2, vx_bf16><<<grid, 256, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V, epi); break;
+            default: vx_pw_fwd_k<1, vx_bf16><<<grid, 256, 0, st>>>(xh, nullptr, C1, Cin, w, bias, y, Cout, V, epi); break;
+        }
+        VX_LAUNCH_CHECK("vx_pw_conv_fwd");
+        return 0;
+    }
     switch (T) {
         case 16: vx_pw_fwd_k<16><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
         case 8: vx_pw_fwd_k<8><<<grid, 256, 0, st>>>(x, x2, C1, Cin, w, bias, y, Cout, V, epi); break;
@@ -279,6 +307,10 @@ static int vx_pw_conv_fwd_impl(const float* x, const float* x2, int C1, const fl
 extern "C" int vx_pw_conv_fwd(const float* x, const float* x2, int C1, const float* w, const float* bias, float* y,
                               int B, int Cin, int Cout, long V, void* stream) {
     return vx_pw_conv_fwd_impl(x, x2, C1, w, bias, y, B, Cin, Cout, V, stream, vx_no_epi());
+}
+// x_h16 != 0: x is a vx_bf16 array (bf16 storage mode: the patchified network input); no concat source
+extern "C" int vx_pw_conv_fwd_h(const void* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, long V, int x_h16, void* stream) {
+    return vx_pw_conv_fwd_impl((const float*)x, nullptr, Cin, w, bias, y, B, Cin, Cout, V, stream, vx_no_epi(), x_h16 ? 1 : 0);
 }
 
 static int vx_pw_conv_bwd_data_impl(const float* dy, const float* w, float* dx, float* dx2, int C1,
@@ -307,6 +339,17 @@ extern "C" int vx_pw_conv_bwd_data(const float* dy, const float* w, float* dx, f
     return vx_pw_conv_bwd_data_impl(dy, w, dx, dx2, C1, B, Cin, Cout, V, accumulate, stream, vx_no_epi());
 }
 
+static thread_local int t_pw_x_h16 = 0;
+extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
+                                     int B, int Cin, int Cout, long V, void* stream);
+// x_h16 != 0: x is a vx_bf16 array (the patchified network input of the bf16 storage mode)
+extern "C" int vx_pw_conv_bwd_weight_h(const void* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, long V, int x_h16, void* stream) {
+    const int prev = t_pw_x_h16;
+    t_pw_x_h16 = x_h16 ? 1 : 0;
+    const int rc = vx_pw_conv_bwd_weight((const float*)x, nullptr, Cin, dy, dw, db, B, Cin, Cout, V, stream);
+    t_pw_x_h16 = prev;
+    return rc;
+}
 extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, const float* dy, float* dw, float* db,
                                      int B, int Cin, int Cout, long V, void* stream) {
     VX_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && V > 0, "vx_pw_conv_bwd_weight: bad args");
@@ -321,7 +364,8 @@ extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, co
     if (vpw < 256) vpw = 256;
     const int chunks_per_b = vx_cdiv(V, vpw);
     dim3 grid(vx_cdiv((long)B * chunks_per_b, 4), mt * nt);
-    vx_pw_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, x2, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);
+    if (t_pw_x_h16) vx_pw_wgrad_k<vx_bf16><<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const vx_bf16*>(x), nullptr, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);
+    else vx_pw_wgrad_k<float><<<grid, 256, 0, (hipStream_t)stream>>>(x, x2, C1, Cin, dy, Cout, V, B, dw, db, (int)vpw, chunks_per_b, nt);
     VX_LAUNCH_CHECK("vx_pw_conv_bwd_weight");
     return 0;
 }
@@ -704,7 +748,7 @@ __global__ void __launch_bounds__(256) vx_pw_wgrad_group_k(VxWgGroup g) {
         const VxWgJob& J = g.j[k];
         if (id >= J.blk0 && id < J.blk0 + J.nblk) {
             const int l = id - J.blk0;
-            vx_pw_wgrad_body(l % J.gx, l / J.gx, J.x, nullptr, J.Cin, J.Cin, J.dy, J.Cout, J.V, J.B, J.dw, J.db, J.vpw, J.chunks_per_b, J.nt);
+            vx_pw_wgrad_body<float>(l % J.gx, l / J.gx, J.x, (const float*)nullptr, J.Cin, J.Cin, J.dy, J.Cout, J.V, J.B, J.dw, J.db, J.vpw, J.chunks_per_b, J.nt);
             return;
         }
     }
