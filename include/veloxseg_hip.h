@@ -517,6 +517,8 @@ int vx_rotate_z(const float* x, float* out, int C, int D, int H, int W, float co
  * into dx.  vx_conv_mfma_ok: 1 when the shape is covered (D, H, W multiples of the stride, Cout % 4 == 0). */
 int vx_conv_mfma_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P, int G, int ps);
 int vx_conv_mfma_set_stem_f16(int on);   /* opt-in (default 0, or VELOXSEG_STEM_F16): the stem (k = 7, s = 4, p = 3, 16 output channels, W % 64 == 0, H % 16 == 0; 1: <= 2 input channels, 2: also 4) as a Toeplitz GEMM on the f16 pipe with LDS-staged input rows */
+int vx_conv_mfma_set_stem_pieces(int np);      /* 2 (default, the fp32 mode): fp32-accurate products from two scaled fp16 pieces; 1 (the bf16 mode): plain fp16 operands, one MFMA per step, half the LDS -- also selects the f16-pipe stem for 4 input channels */
+int vx_conv_mfma_stem_pieces(void);
 int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward);
 int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P,
                      void* stream);

@@ -310,14 +310,17 @@ __global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict_
     }
 }
 // block = (b, od, 4 output rows oh0.., 16 outputs ow0..); wave = one output row
-template <int CIN>
+// NP = operand pieces: 2 = every fp32 product from two scaled fp16 pieces (three MFMAs per step: the fp32 mode); 1 (round 6, the bf16 mode: reference speed_test.py:122,127
+// autocast) = plain fp16 operands scaled per block / per tensor -- 11 significant bits against bf16's 8 --, ONE MFMA per step and half the LDS (4 input channels: 77 instead
+// of 153 KB, two blocks per CU instead of one)
+template <int CIN, int NP = 2>
 __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x, const cm_u4* __restrict__ img, const float* __restrict__ esc, const float* __restrict__ bias,
                                                      float* __restrict__ y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
     constexpr int NROW = CIN * 7 * 19, NSTEP = (CIN * 49 + 3) / 4, NIT = (NROW * (VX_STEM_RL / 4) + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
-    _Float16* __restrict__ xh = reinterpret_cast<_Float16*>(cm_lds);                   // [NROW][72] hi pieces, then the lo pieces
-    _Float16* __restrict__ xl = xh + NROW * VX_STEM_RL;
-    int* __restrict__ rowoff = reinterpret_cast<int*>(xl + NROW * VX_STEM_RL);         // [4 NSTEP]: staged row of reduction row r (for output row 0), in halfs
+    _Float16* __restrict__ xh = reinterpret_cast<_Float16*>(cm_lds);                   // [NROW][72] hi pieces, then (NP = 2) the lo pieces
+    _Float16* __restrict__ xl = xh + (NP == 2 ? NROW * VX_STEM_RL : 0);
+    int* __restrict__ rowoff = reinterpret_cast<int*>(xh + NP * NROW * VX_STEM_RL);    // [4 NSTEP]: staged row of reduction row r (for output row 0), in halfs
     float* __restrict__ red = reinterpret_cast<float*>(rowoff + 4 * NSTEP);            // [4]
     const int nwb = (Wo + 15) / 16, nhb = Ho / 4;              // (a ragged last tile along W -- 24 outputs per row at 96^3 -- stores only its valid columns)
     int t = blockIdx.x;
@@ -364,7 +367,7 @@ __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x
             cm_split2(v[u][0] * sc, v[u][1] * sc, h0, l0);
             cm_split2(v[u][2] * sc, v[u][3] * sc, h1, l1);
             *reinterpret_cast<uint2*>(xh + (long)it * 4) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(xl + (long)it * 4) = make_uint2(l0, l1);
+            if constexpr (NP == 2) *reinterpret_cast<uint2*>(xl + (long)it * 4) = make_uint2(l0, l1);
         }
     }
     __syncthreads();
@@ -376,14 +379,17 @@ __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x
 #pragma unroll 2
     for (int s = 0; s < NSTEP; ++s) {
         cm_u4 nh = ah, nl = al;
-        if (s + 1 < NSTEP) { nh = ig[(s + 1) * 128]; nl = ig[(s + 1) * 128 + 64]; }
+        if (s + 1 < NSTEP) { nh = ig[(s + 1) * 128]; if constexpr (NP == 2) nl = ig[(s + 1) * 128 + 64]; }
         const int o = rowoff[4 * s + G] + base;
         const uint2 b0 = *reinterpret_cast<const uint2*>(xh + o), b1 = *reinterpret_cast<const uint2*>(xh + o + 4);
-        const uint2 c0 = *reinterpret_cast<const uint2*>(xl + o), c1 = *reinterpret_cast<const uint2*>(xl + o + 4);
-        const cm_u4 bh = {b0.x, b0.y, b1.x, b1.y}, bl = {c0.x, c0.y, c1.x, c1.y};
+        const cm_u4 bh = {b0.x, b0.y, b1.x, b1.y};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, ah), __builtin_bit_cast(cm_h8, bh), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, ah), __builtin_bit_cast(cm_h8, bl), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, al), __builtin_bit_cast(cm_h8, bh), acc, 0, 0, 0);
+        if constexpr (NP == 2) {
+            const uint2 c0 = *reinterpret_cast<const uint2*>(xl + o), c1 = *reinterpret_cast<const uint2*>(xl + o + 4);
+            const cm_u4 bl = {c0.x, c0.y, c1.x, c1.y};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, ah), __builtin_bit_cast(cm_h8, bl), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cm_h8, al), __builtin_bit_cast(cm_h8, bh), acc, 0, 0, 0);
+        }
         ah = nh; al = nl;
     }
     const float f = ldexpf(1.0f, -(ex + (int)esc[0]));
@@ -407,8 +413,13 @@ static int vx_stem_mode() {
     return vx_stem_f16;
 }
 extern "C" int vx_conv_mfma_set_stem_f16(int on) { vx_stem_f16 = on < 0 ? 0 : on; return 0; }      // A/B knob: the stem (k7 s4, 16 channels) on the f16 pipe or the fp32 gather kernel (default)
+// plain fp16 operands (one piece) for the stem forward: the bf16 mode (functional.set_precision("bf16") -> vx_conv_mfma_set_stem_pieces(1)); 2 = the fp32 mode
+static int g_stem_pieces = 2;
+extern "C" int vx_conv_mfma_set_stem_pieces(int np) { if (np != 1 && np != 2) return -1; g_stem_pieces = np; return 0; }
+extern "C" int vx_conv_mfma_stem_pieces(void) { return g_stem_pieces; }
 static bool vx_stem_ok(int Cin, int Cout, int D, int H, int W, int K, int S, int P) {
-    return vx_stem_mode() && K == 7 && S == 4 && P == 3 && Cout == 16 && (Cin == 1 || Cin == 2 || (Cin == 4 && vx_stem_mode() > 1)) && W % 64 == 0 && H % 16 == 0 && D % 4 == 0;      // (4 input channels = 153 KB of LDS, one block per CU: brats128 B = 4 851 vs 864 patches/s, off unless the knob is 2)      // (rows of 24 outputs -- the 96^3 patches -- measured no gain: 1207 vs 1216, 724 vs 731 patches/s)
+    // (4 input channels: with one piece the block needs 77 KB of LDS and the kernel is selected; with two, 153 KB = one block per CU, it is not faster than the gather kernel)
+    return vx_stem_mode() && K == 7 && S == 4 && P == 3 && Cout == 16 && (Cin == 1 || Cin == 2 || (Cin == 4 && (vx_stem_mode() > 1 || g_stem_pieces == 1))) && W % 64 == 0 && H % 16 == 0 && D % 4 == 0;      // (4 input channels = 153 KB of LDS, one block per CU: brats128 B = 4 851 vs 864 patches/s, off unless the knob is 2)      // (rows of 24 outputs -- the 96^3 patches -- measured no gain: 1207 vs 1216, 724 vs 731 patches/s)
 }
 extern "C" int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward) {
     const int K3 = K * K * K;
@@ -428,11 +439,15 @@ extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bia
         cm_u4* img = reinterpret_cast<cm_u4*>(ws);
         float* esc = ws + (long)nsteps * 2 * 64 * 4;
         vx_stem_wprep_k<<<dim3((unsigned)nsteps), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps);
-        const size_t shm = (size_t)Cin * 7 * 19 * VX_STEM_RL * 2 * 2 + (size_t)4 * nsteps * 4 + 64;
+        // (one piece only where it brings the f16-pipe kernel in at all -- 4 input channels: brats128 bf16 816 -> 830 patches/s; with 2 channels the two-piece kernel stays:
+        //  autopet128 bf16 1156 vs 1151 with one piece -- its shorter blocks only crowd the other lanes, the stem is not on that step's critical path)
+        const int np = (g_stem_pieces == 1 && Cin == 4) ? 1 : 2;
+        const size_t shm = (size_t)Cin * 7 * 19 * VX_STEM_RL * 2 * np + (size_t)4 * nsteps * 4 + 64;
         const dim3 grid((unsigned)((long)B * Do * (Ho / 4) * ((Wo + 15) / 16)));
-#define VX_STEM(CI) { static bool once = false; if (!once) { if (hipFuncSetAttribute((const void*)vx_stem_fwd_k<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); once = true; } \
-        vx_stem_fwd_k<CI><<<grid, dim3(256), shm, st>>>(x, img, esc, bias, y, B, D, H, W, Do, Ho, Wo); }
-        if (Cin == 1) VX_STEM(1) else if (Cin == 2) VX_STEM(2) else VX_STEM(4)
+#define VX_STEM(CI, NP_) { static bool once = false; if (!once) { if (hipFuncSetAttribute((const void*)vx_stem_fwd_k<CI, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); once = true; } \
+        vx_stem_fwd_k<CI, NP_><<<grid, dim3(256), shm, st>>>(x, img, esc, bias, y, B, D, H, W, Do, Ho, Wo); }
+        if (np == 1) { if (Cin == 1) VX_STEM(1, 1) else if (Cin == 2) VX_STEM(2, 1) else VX_STEM(4, 1) }
+        else { if (Cin == 1) VX_STEM(1, 2) else if (Cin == 2) VX_STEM(2, 2) else VX_STEM(4, 2) }
 #undef VX_STEM
         VX_LAUNCH_CHECK("vx_conv_mfma_fwd (stem, f16 pipe)");
         return 0;

@@ -254,6 +254,8 @@ def set_precision(mode: str):
     # at the 32^3 level (y_k, o, dn, d_o, g_k) and the full-resolution heads / reconstructions with their gradients; fp32: statistics, sums, soft-max, loss, master weights,
     # flat gradients, AdamW, every block-boundary tensor
     m.set_act_bf16(mode == "bf16" and BF16_STORAGE)
+    # the stem DownConv (k7 s4, conv_blocks.py:4-21) on plain fp16 operands in the bf16 mode (one MFMA per step instead of three, half the LDS)
+    H.call("vx_conv_mfma_set_stem_pieces", 1 if (mode == "bf16" and os.environ.get("VELOXSEG_BF16_STEM", "1") != "0") else 2)
     # the JLC grouped convolutions and their weight gradients on the matrix pipe (csrc/jlc_mfma.hip): 3 bf16 pieces per operand (six piece products = the fp32
     # product) in the fp32 mode, ONE piece (plain bf16 operands, fp32 accumulation) in the bf16 mode
     H.call("vx_jlc_tz_set_pieces", 1 if mode == "bf16" else int(os.environ.get("VELOXSEG_TZ_PIECES", "22")))     # 22 = two scaled fp16 pieces (22 significant bits, three piece products: csrc/jlc_mfma.hip); 3 = three bf16 pieces (A/B)
