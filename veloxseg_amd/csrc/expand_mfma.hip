@@ -8,6 +8,7 @@
 //        -> A is one coalesced 256-B load of the fine gradient, B one coalesced 256-B load of the tap-major weights WT[t][co][ci].
 // Exact fp32 (the MFMA is a k-ordered fmaf chain), so it is interchangeable with the VALU kernels within round-off.
 #include "vx_common.h"
+#include <type_traits>
 #include "../../include/veloxseg_hip.h"
 
 typedef float vx_f4 __attribute__((ext_vector_type(4)));
@@ -763,10 +764,13 @@ extern "C" int vx_expand_fwd_mfma_bf16(const float* x, const float* w, const flo
 
 // input gradient, bf16 operands: the block / wave / halo layout of vx_expand_bwd_data_lds_k (fp32 halo of one (c, s1) group in LDS), rows = 16 coarse
 // voxels, cols = 16 ci; A = 2 x 4 contiguous fine-gradient floats of this lane's tap (rounded to bf16 here), B = the operand-order weight image
+// (round 6) the halo of a (c, s1) group is staged in LDS AS bf16 -- rounded once when it is staged, or copied when the gradient already is a bf16 array (TD = vx_bf16) --
+// instead of as fp32 with four v_cvt_pk per MFMA operand in the inner loop: the loop was VALU-bound (32 conversions + 8 16-byte LDS reads per 4 MFMAs and lane); now it
+// reads two 8-byte pieces per operand and converts nothing.  Half the LDS (21 KB per block).
 template <typename TD>
 __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const TD* __restrict__ dyf, const uint4* __restrict__ wimg, float* __restrict__ dx,
                                                                  int B, int Cc, int D, int H, int W, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float vx_halo_t[];          // [6][6][4][72]
+    extern __shared__ __attribute__((aligned(16))) unsigned short vx_halo_h[];          // [6][6][4][72] bf16
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
@@ -784,26 +788,38 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const TD* __res
     vx_f4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (vx_f4){0.f, 0.f, 0.f, 0.f};
+    // the thread's staging items do not depend on (c, s1): offsets and inside flags once
+    long goff[11];
+    int loff[11];
+#pragma unroll
+    for (int u = 0; u < 11; ++u) {
+        const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
+        const int f4 = e % 18, row = e / 18;
+        const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
+        const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
+        const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+        goff[u] = ok ? ((long)(4 * qd) * FH + 4 * qh + s2) * FW + 4 * qw : -1;
+        loff[u] = ((int)threadIdx.x + u * 256 < 144 * 18) ? (e / 18) * 72 + (e % 18) * 4 : -1;
+    }
     for (int c = 0; c < Cc; ++c) {
         for (int s1 = 0; s1 < 4; ++s1) {
             __syncthreads();
             {
-                float4 v[11];
+                uint2 v[11];
 #pragma unroll
                 for (int u = 0; u < 11; ++u) {
-                    const int e = min((int)threadIdx.x + u * 256, 144 * 18 - 1);
-                    const int f4 = e % 18, row = e / 18;
-                    const int s2 = row & 3, hh = (row >> 2) % 6, hd = row / 24;
-                    const int qd = d0 - 1 + hd, qh = h0 - 1 + hh, qw = w0 - 1 + f4;
-                    const bool ok = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
-                    const float4 t_ = vx_ld4(dyb, (long)c * fplane + (ok ? ((long)(4 * qd + s1) * FH + 4 * qh + s2) * FW + 4 * qw : 0));
-                    v[u] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const long o = (long)c * fplane + (goff[u] >= 0 ? goff[u] + (long)s1 * FH * FW : 0);
+                    if constexpr (std::is_same<TD, vx_bf16>::value) {
+                        const uint2 t_ = *reinterpret_cast<const uint2*>(dyb + o);
+                        v[u] = goff[u] >= 0 ? t_ : make_uint2(0u, 0u);
+                    } else {
+                        const float4 t_ = *reinterpret_cast<const float4*>(dyb + o);
+                        v[u] = goff[u] >= 0 ? make_uint2(vx_pack_bf16(t_.x, t_.y), vx_pack_bf16(t_.z, t_.w)) : make_uint2(0u, 0u);
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 11; ++u) {
-                    const int e = (int)threadIdx.x + u * 256;
-                    if (e < 144 * 18) *reinterpret_cast<float4*>(vx_halo_t + (e / 18) * 72 + (e % 18) * 4) = v[u];
-                }
+                for (int u = 0; u < 11; ++u)
+                    if (loff[u] >= 0) *reinterpret_cast<uint2*>(vx_halo_h + loff[u]) = v[u];
             }
             __syncthreads();
             const uint4* __restrict__ wg = wimg + (long)(c * 4 + s1) * 14 * 64 + lane;
@@ -815,13 +831,13 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const TD* __res
                 const uint4 bv = wg[p * 64];
                 const int hd = wave - td + 2;
                 const int s2 = 2 * (q & 1);
-                const float* __restrict__ ht = vx_halo_t + ((hd * 6 + (2 - th)) * 4 + s2) * 72 + (r - tw + 2) * 4;
+                const unsigned short* __restrict__ ht = vx_halo_h + ((hd * 6 + (2 - th)) * 4 + s2) * 72 + (r - tw + 2) * 4;
                 uint4 av[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const float4 lo = *reinterpret_cast<const float4*>(ht + m * 4 * 72);
-                    const float4 hi = *reinterpret_cast<const float4*>(ht + m * 4 * 72 + 72);
-                    av[m] = make_uint4(vx_pack_bf16(lo.x, lo.y), vx_pack_bf16(lo.z, lo.w), vx_pack_bf16(hi.x, hi.y), vx_pack_bf16(hi.z, hi.w));
+                    const uint2 lo = *reinterpret_cast<const uint2*>(ht + m * 4 * 72);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(ht + m * 4 * 72 + 72);
+                    av[m] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vx_as_bf8(av[m]), vx_as_bf8(bv), acc[m], 0, 0, 0);
@@ -848,8 +864,8 @@ extern "C" int vx_expand_bwd_data_mfma_bf16_h(const void* dy_fine, const float* 
     const int groups = Cc * 4;
     vx_expand_wimg_bf16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
-    if (dy_h16) vx_expand_bwd_data_bf16_k<vx_bf16><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>((const vx_bf16*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
-    else vx_expand_bwd_data_bf16_k<float><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(float), st>>>((const float*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    if (dy_h16) vx_expand_bwd_data_bf16_k<vx_bf16><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(unsigned short), st>>>((const vx_bf16*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
+    else vx_expand_bwd_data_bf16_k<float><<<dim3((unsigned)nblk), 256, 6 * 6 * 4 * 72 * sizeof(unsigned short), st>>>((const float*)dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate);
     VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_bf16");
     return 0;
 }
