@@ -34,7 +34,7 @@ if __name__ == "__main__":
     parser.add_argument("--data_module", type=str, default=None, help="python module with build_loaders(args, train_config, model_config)")
     parser.add_argument("--save_path", type=str, default=None, help="checkpoint directory (default ./checkpoints/<date>_<dataset>)")
     parser.add_argument("--graph", action="store_true", dest="use_graph", help="capture the training step once and replay it as a launch tape (csrc/tape.hip: ~2 ms of host time per step instead of ~10 ms; falls back to eager launches if the capture cannot be verified)")
-    parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16 = opt-in mode: bf16 MFMA operands (fp32 accumulate, fp32 storage) in the patch-expand layers")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16 = the mode of BASELINE configs[1] (reference speed_test.py:122,127 autocast): 16-bit storage of the full-resolution heads and the 32^3-level JLC internals, bf16 matrix-pipe operands; fp32 statistics, loss, master weights (INTEGRATION.md)")
     args = parser.parse_args()
     with open(args.train_config, "r", encoding="utf-8") as f:
         train_config = json.load(f)
