@@ -892,7 +892,7 @@ def _latest_profile(pattern):
     import re as _re
     best = None
     for f in glob.glob(os.path.join(ROOT, "profiles", pattern)):
-        if _re.search(r"autopet96|brats", os.path.basename(f)):      # summaries of the other workloads (profiles/r05_kernel_stats_autopet96.csv): not the headline's
+        if _re.search(r"autopet96|brats|hecktor", os.path.basename(f)):      # summaries of the other workloads (profiles/r06_kernel_stats_autopet96_*.csv): not the headline's
             continue
         m = _re.match(r"r(\d+)", os.path.basename(f))
         if m and (best is None or (int(m.group(1)), f) > best):
