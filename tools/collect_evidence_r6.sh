@@ -34,7 +34,7 @@ for cfg in "autopet128 f32 4" "autopet128 bf16 4" "brats128 f32 2" "brats128 bf1
 done
 find $O -name '*counter_collection.csv' -delete
 find $O -name '*kernel_trace.csv' -delete
-timeout 300 python tools/comm_world1_nccl.py > $O/comm_world1_nccl.json 2> $O/comm.err
+timeout 500 python tools/comm_world1_nccl.py 2> $O/comm.err | grep "^RESULT" | sed "s/^RESULT //" > $O/comm_world1_nccl.json
 for f in $O/bench_*.json; do echo $f $(tail -1 $f | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d.get('ms_per_step'))"); done
 for f in stats stats96 statsbr statshk; do echo $f $(tail -1 $O/$f.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config'].get('lanes_on_distinct_hw_queues'), d['config'].get('lane_calibration_spin_us'))"); done
 python - <<'PY'
