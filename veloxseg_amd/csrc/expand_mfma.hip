@@ -11,6 +11,10 @@
 #include <type_traits>
 #include "../../include/veloxseg_hip.h"
 
+// consecutive block ids go to different XCDs (8 L2 slices): tiles that share halo planes should sit on ONE XCD, whose L2 then serves the overlap -- de-interleave the
+// block id so that every XCD walks a contiguous run of tiles (as vx_tz_k does)
+__device__ __forceinline__ int vx_xcd_tile(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+
 typedef float vx_f4 __attribute__((ext_vector_type(4)));
 
 // WT[t][co][ci] = W[co][ci][t]
@@ -691,7 +695,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_bf16_k(const float* __restr
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
     const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
-    int tile = blockIdx.x;
+    int tile = vx_xcd_tile(blockIdx.x, gridDim.x);
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
     const int td_i = tile % nTd;
@@ -775,7 +779,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_bf16_k(const TD* __res
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
     const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;          // W % 16 != 0 (W % 4 == 0): the last tile along W is partly outside the volume
-    int tile = blockIdx.x;
+    int tile = vx_xcd_tile(blockIdx.x, gridDim.x);
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
     const int td_i = tile % nTd;
