@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x
     float* __restrict__ red = reinterpret_cast<float*>(rowoff + 4 * NSTEP);            // [4]
     const int nwb = (Wo + 15) / 16, nhb = Ho / 4;              // (a ragged last tile along W -- 24 outputs per row at 96^3 -- stores only its valid columns)
     int t = blockIdx.x;
+    if ((gridDim.x & 7) == 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);          // (round 6) consecutive block ids go to different XCDs: every XCD walks a contiguous run of tiles, whose 7^3 halos overlap in ITS L2
     const int wb = t % nwb; t /= nwb;
     const int hb = t % nhb; t /= nhb;
     const int od = t % Do;

@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(256) vx_expand_fwd_split_k(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
     const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;
-    int tile = blockIdx.x;
+    int tile = vx_xcd_tile(blockIdx.x, gridDim.x);          // (round 6: every XCD walks a contiguous run of tiles -- halo overlap from its own L2)
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
     const int td_i = tile % nTd;
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, q = lane >> 4;
     const int nTw = (W + 15) / 16, nTh = H / 4, nTd = D / 4;
-    int tile = blockIdx.x;
+    int tile = vx_xcd_tile(blockIdx.x, gridDim.x);
     const int tw_i = tile % nTw; tile /= nTw;
     const int th_i = tile % nTh; tile /= nTh;
     const int td_i = tile % nTd;
