@@ -1,7 +1,7 @@
 set -x
 export TMPDIR=/tmp
 O=gpurun_out/r6h; mkdir -p $O
-python -m pytest tests/test_hip_ops_gpu.py tests/test_hip_model_gpu.py -x -q 2>&1 | tail -2
+python -m pytest tests/test_hip_ops_gpu.py -x -q -k "stem or down" 2>&1 | tail -2
 NB="--no-eager-baseline --no-cpu-baseline --no-kernel-pass"
 for i in 1 2 3; do echo autopet128 $(python bench.py $NB 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['dispersion']['step_ms_p50'])"); done
 for w in brats128 autopet96 hecktor; do echo $w $(python bench.py $NB --dispersion-steps 0 --workload $w 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"); done

@@ -728,7 +728,10 @@ __global__ void __launch_bounds__(256) vx_stem_wgrad_f16_k(const float* __restri
     const int kw = (n & 7) < 7 ? (n & 7) : 0;                  // (slot 7 of a row is idle: its column is never stored)
     const long Vi = (long)Di * Hi * Wi, Vo = (long)Do * Ho * Wo;
     const int nHg = Ho / 4;
-    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
+    // (round 6) consecutive block ids go to different XCDs; tiles of neighbouring output planes share 3 of their 7 staged input planes: every XCD takes a contiguous run of
+    // blocks, so the overlap is served by its L2 instead of being fetched by two XCDs (counted 134 MB per launch for 75 MB of operands)
+    const int bx = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int t_begin = bx * tiles_per_block, t_end = min(t_begin + tiles_per_block, ntiles);
     for (int t = t_begin; t < t_end; ++t) {
         int tt = t;
         const int hg = tt % nHg; tt /= nHg;
