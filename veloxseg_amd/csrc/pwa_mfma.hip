@@ -28,6 +28,7 @@ struct VxAttnM {
     int n[3];
     float scale;
     int lin_cst, Tsz;
+    int xcd;       // (round 6) bit 0 / 1: forward / backward blocks of one window are placed on one XCD (vx_xcd_rows); VELOXSEG_ATTN_XCD
 };
 
 // Staging loops: 8 independent loads per thread are issued before the first LDS store (a rolled load -> store loop pays one L2 round trip per
@@ -80,7 +81,9 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
     float* __restrict__ bias = vx_am_lds + ((A.l + 3) & ~3);
     float* __restrict__ Kop = bias + ((A.Tsz + 3) & ~3);
     float* __restrict__ Vs = Kop + A.ML * CQ;
-    const long win = blockIdx.y;
+    int bx_, by_;
+    vx_xcd_rows(bx_, by_, A.xcd & 1);         // (round 6) the blocks of a window on ONE XCD: they all stage the window's K and V
+    const long win = by_;
     const int a = (int)((win / A.Nt) % A.heads);
     const float* __restrict__ kp = K + win * A.ML * CQ;
     const float* __restrict__ vp = Vt + win * A.ML * CV;
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(512) vx_pwa_attn_mfma_fwd_k(const float* __res
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
-    const int q0 = (blockIdx.x * 8 + wave) * 16;
+    const int q0 = (bx_ * 8 + wave) * 16;
     if (q0 >= A.ML) return;
     const VxDropCtx dc = vx_attn_ctx(drop);
     const long row = win * A.ML + q0 + m;
@@ -435,11 +438,13 @@ __global__ void __launch_bounds__(256) vx_pwa_attn_bwd1_k(const float* __restric
     float* __restrict__ del_s = lse_s + MF * nq;                                 // [MF * nq]
     float* __restrict__ dqw = del_s + MF * nq;                                   // [4 waves][MF * nq][CQ]
     float* __restrict__ trb = dqw + 4 * MF * nq * CQ;                            // [4 waves][MF][16 * TS]
-    const long win = blockIdx.y;
+    int bx_, by_;
+    vx_xcd_rows(bx_, by_, A.xcd & 2);                                            // (round 6) the blocks of a window on ONE XCD
+    const long win = by_;
     const int a = (int)((win / A.Nt) % A.heads);
     const long wrow = win * A.ML;
-    const int qsi = blockIdx.x % QS, q_lo = qsi * NTq;                           // this block's query tiles: [q_lo, q_lo + NTq)
-    const int kc = blockIdx.x / QS;                                              // its key chunk: tiles kc * waves_used ..
+    const int qsi = bx_ % QS, q_lo = qsi * NTq;                                  // this block's query tiles: [q_lo, q_lo + NTq)
+    const int kc = bx_ / QS;                                                     // its key chunk: tiles kc * waves_used ..
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
     // ---- token -> linear coordinate, this block's lse / delta = rowsum(dO * O), zeroed accumulators
     for (int t = threadIdx.x; t < lp; t += 256) {
@@ -800,11 +805,13 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     _Float16* __restrict__ rq = reinterpret_cast<_Float16*>(trb + 4 * 2 * 16 * TS);      // [NR][VX_BH_RS]: Q hi | Q lo | dO hi | dO lo | 0
     _Float16* __restrict__ tq = rq + NR * VX_BH_RS;                              // [2 (Q, dO)][16][VX_BH_TS]: rows 0..C-1 hi, C..2C-1 lo, rest 0
     float* __restrict__ red = reinterpret_cast<float*>(tq + 2 * 16 * VX_BH_TS);  // [16] block maxima, [16..19] the waves' window offsets
-    const long win = blockIdx.y;
+    int bx_, by_;
+    vx_xcd_rows(bx_, by_, A.xcd & 2);         // (round 6) the blocks of a window on ONE XCD: they read the same Q / dO / K / V rows and keep bits
+    const long win = by_;
     const int a = (int)((win / A.Nt) % A.heads);
     const long wrow = win * A.ML;
-    const int qsi = blockIdx.x % QS;
-    const int kc = blockIdx.x / QS;
+    const int qsi = bx_ % QS;
+    const int kc = bx_ / QS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, qg = lane >> 4;
     // ---- this wave's keys
     const int kt = kc * 4 + wave;                             // key tile (of both modalities)
@@ -1155,6 +1162,8 @@ static bool vx_am_fill(VxAttnM& A, const VxPwaPlan* P, int B, int M, int cq) {
     A.scale = 1.0f / sqrtf((float)cq);
     A.lin_cst = ((P->n[0] - 1) * (2 * P->n[1] - 1) + (P->n[1] - 1)) * (2 * P->n[2] - 1) + (P->n[2] - 1);
     A.Tsz = (2 * A.n[0] - 1) * (2 * A.n[1] - 1) * (2 * A.n[2] - 1);
+    static const int xcd = [] { const char* e = getenv("VELOXSEG_ATTN_XCD"); return e ? atoi(e) : 3; }();
+    A.xcd = xcd;
     return true;
 }
 static size_t vx_am_tab_floats(const VxAttnM& A) { return (size_t)((A.l + 3) & ~3) + (size_t)((A.Tsz + 3) & ~3); }

@@ -82,6 +82,23 @@ __device__ __forceinline__ void vx_st1(vx_bf16* p, long i, float v) { p[i].v = (
 template <typename T> __device__ __forceinline__ float vx_round_as(float v) { return v; }
 template <> __device__ __forceinline__ float vx_round_as<vx_bf16>(float v) { return vx_bf16_lo(vx_pack_bf16x2(v, 0.0f)); }
 
+// ---- XCD-aware block coordinates (round 6) --------------------------------------------------------------------------------------------------------
+// The blocks of a 2-D grid are dispatched in linear order (x fastest) and consecutive linear ids go to different XCDs (8 L2 slices).  When the blocks of one ROW (same
+// blockIdx.y: one attention window, one sample ...) share their operands, the row is spread over all eight L2s and every one of them fetches the operands from HBM.
+// vx_xcd_rows gives the block other coordinates: eight rows are interleaved, so that all blocks of a row carry the same (linear id & 7) = sit on one XCD.  Rows beyond
+// the last multiple of eight keep their own coordinates.
+__device__ __forceinline__ void vx_xcd_rows(int& bx, int& by, int on = 1) {
+    const int nbx = (int)gridDim.x;
+    const long L = (long)blockIdx.x + (long)nbx * blockIdx.y;
+    const long full = (long)nbx * ((gridDim.y >> 3) << 3);
+    if (on && L < full) {
+        const long g = L / (8L * nbx);
+        const int r = (int)(L - g * 8L * nbx);
+        by = (int)(g * 8 + (r & 7));
+        bx = r >> 3;
+    } else { bx = (int)blockIdx.x; by = (int)blockIdx.y; }
+}
+
 // ---- exact-erf GELU (nn.GELU() default) ---------------------------------------------------
 __device__ __forceinline__ float vx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float vx_gelu_grad(float x) {
