@@ -331,6 +331,13 @@ int vx_patchify(const float* x, float* out, int B, int C, int d, int h, int w, i
 int vx_patchify_bs(const float* x, long batch_stride, float* out, int B, int C, int d, int h, int w, int K, void* stream);
 /* bf16 storage mode: the patchified copy as a bf16 array (out_h16 != 0; patch size 2 / 4), read by vx_pw_conv_fwd_h / vx_pw_conv_bwd_weight_h with x_h16 != 0 */
 int vx_patchify_bs_h(const float* x, long batch_stride, void* out, int B, int C, int d, int h, int w, int K, int out_h16, void* stream);
+/* (round 6) the patch embedding itself (kernel == stride == 4, no padding; Encoder.py:150-156, MONAI PatchEmbed "conv") WITHOUT a patchified copy: the
+ * product and its weight gradient gather the 4 x 4 x 4 patches from x by address.  Do, Ho, Wo: the OUTPUT grid (x is Cin x 4Do x 4Ho x 4Wo per sample,
+ * batch_stride floats apart); Cout % 16 == 0, Wo % 4 == 0, Cin <= 8.  The forward sums in the order of vx_patchify + vx_pw_conv_fwd (bit-identical).
+ * vx_patch_embed_ok: 1 where the dispatcher takes these kernels (VELOXSEG_PATCH_FUSED=0: never) */
+int vx_patch_embed_ok(int Cin, int Cout, int Do, int Ho, int Wo, int K);
+int vx_patch_embed_fwd(const float* x, long batch_stride, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Do, int Ho, int Wo, void* stream);
+int vx_patch_embed_bwd_weight(const float* x, long batch_stride, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int Do, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Paired-Window Attention (model/components/PWA.py).  Geometry of one layer:

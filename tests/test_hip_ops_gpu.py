@@ -681,6 +681,50 @@ def test_patch_conv_via_patchify_matches_direct_conv_and_oracle(Cin, Cout, K, sp
         close(res[flag][2], bc.grad, 1e-4 * float(bc.grad.abs().max()), 5e-4, f"patchify={flag} db")
 
 
+@pytest.mark.parametrize("B,Cin,Ctot,c_off,Cout,grid", [(2, 1, 2, 1, 16, (32, 32, 16)), (2, 4, 4, 0, 32, (8, 12, 24)), (1, 1, 1, 0, 16, (16, 16, 4)), (3, 2, 5, 2, 48, (4, 6, 8))],
+                         ids=["modality_slice_128x128x64", "brats_4ch_Wo24", "hecktor_like_Wo4", "slice_2_of_5"])
+def test_patch_embed_in_place_equals_patchify_plus_pointwise(B, Cin, Ctot, c_off, Cout, grid):
+    """vx_patch_embed_fwd / _bwd_weight (no patchified copy) vs vx_patchify_bs + vx_pw_conv_fwd / vx_pw_conv_bwd_weight on a channel slice of a wider tensor:
+    the product bit-identical (same order of the sums), the weight / bias gradients to fp32 rounding, and against aten on the CPU"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    Do, Ho, Wo = grid
+    Vo = Do * Ho * Wo
+    xw = rnd(B, Ctot, 4 * Do, 4 * Ho, 4 * Wo, seed=1)
+    w = rnd(Cout, Cin, 4, 4, 4, seed=2) * 0.2
+    bias = rnd(Cout, seed=3)
+    gy = rnd(B, Cout, Do, Ho, Wo, seed=4)
+    xd, wd, bd, gd = xw.to(d), w.to(d), bias.to(d), gy.to(d)
+    xs = xd[:, c_off:c_off + Cin]
+    st = H.stream_ptr()
+    assert H.LIB.load().vx_patch_embed_ok(Cin, Cout, 32, 32, 32, 4) == 1 and H.LIB.load().vx_patch_embed_ok(Cin, Cout, 32, 32, 30, 4) == 0
+    # reference: the patchified copy and the 1x1 kernels
+    ck = Cin * 64
+    pat = torch.empty(B, ck, Vo, device=d)
+    H.call("vx_patchify_bs", xs.data_ptr(), xs.stride(0), H.P(pat), B, Cin, Do, Ho, Wo, 4, st)
+    y_ref = torch.empty(B, Cout, Vo, device=d)
+    H.call("vx_pw_conv_fwd", H.P(pat), None, ck, H.P(wd), H.P(bd), H.P(y_ref), B, ck, Cout, Vo, st)
+    dw_ref, db_ref = torch.zeros(Cout, ck, device=d), torch.zeros(Cout, device=d)
+    H.call("vx_pw_conv_bwd_weight", H.P(pat), None, ck, H.P(gd), H.P(dw_ref), H.P(db_ref), B, ck, Cout, Vo, st)
+    y = torch.empty(B, Cout, Vo, device=d)
+    H.call("vx_patch_embed_fwd", xs.data_ptr(), xs.stride(0), H.P(wd), H.P(bd), H.P(y), B, Cin, Cout, Do, Ho, Wo, st)
+    dw, db = torch.zeros(Cout, ck, device=d), torch.zeros(Cout, device=d)
+    H.call("vx_patch_embed_bwd_weight", xs.data_ptr(), xs.stride(0), H.P(gd), H.P(dw), H.P(db), B, Cin, Cout, Do, Ho, Wo, st)
+    H.call("vx_patch_embed_bwd_weight", xs.data_ptr(), xs.stride(0), H.P(gd), H.P(dw), None, B, Cin, Cout, Do, Ho, Wo, st)       # accumulates; null bias gradient
+    torch.cuda.synchronize()
+    if Vo >= 16384 and ck <= 64:        # (the 1x1 product on vx_pw_fwd_v4_k: the same order of the sums)
+        assert torch.equal(y, y_ref), float((y - y_ref).abs().max())
+    close(y, y_ref, 2e-6 * float(y_ref.abs().max()), 2e-6, "y vs patchified")
+    close(dw.cpu() * 0.5, dw_ref.cpu(), 2e-5 * float(dw_ref.abs().max()), 2e-4, "dw vs patchified")
+    close(db.cpu(), db_ref.cpu(), 2e-5 * float(db_ref.abs().max()), 2e-4, "db vs patchified")
+    wc, bc = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yc = F.conv3d(xw[:, c_off:c_off + Cin], wc, bc, stride=4)
+    yc.backward(gy)
+    close(y.cpu().view_as(yc), yc.detach(), 2e-5, 2e-4, "y vs aten")
+    close(dw.cpu().view_as(wc.grad) * 0.5, wc.grad, 1e-4 * float(wc.grad.abs().max()), 5e-4, "dw vs aten")
+    close(db.cpu(), bc.grad, 1e-4 * float(bc.grad.abs().max()), 5e-4, "db vs aten")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,V,C1", [(2, 32, 48, 512, 0), (1, 16, 64, 4096, 0), (2, 24, 20, 64, 8), (2, 32, 16, 216, 0)],
                          ids=["V512", "V4096_ksplit", "concat_V64", "V216"])
 def test_pw_conv_bwd_fused_equals_two_launches(B, Cin, Cout, V, C1):

@@ -174,6 +174,7 @@ struct ConvState {
     Tensor x, x2, w, b;
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
     bool pw = false, s1 = false, patch = false, cm = false;      // cm: strided dense conv on MFMA (csrc/conv_mfma.hip)
+    bool patch_fused = false;                                    // patch embedding read in place (vx_patch_embed_*): x is the network input, not a patchified copy
 };
 
 Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
@@ -207,6 +208,14 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     if (st.patch) {
         const int Ck = Cin * K * K * K;
         const long Vo = (long)Do * Ho * Wo;
+        // (round 6) no patchified copy where the fused kernels take the layer: the product and (later) the weight gradient gather the patches from x by address
+        st.patch_fused = vx_patch_embed_ok(Cin, Cout, Do, Ho, Wo, K) == 1 && x.stride(0) % 4 == 0 && (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) == 0;
+        if (st.patch_fused) {
+            VX(vx_patch_embed_fwd, fp(x), (long)x.stride(0), fp(w), fp(b), mp(y), B, Cin, Cout, Do, Ho, Wo, stream);
+            st.x = x;
+            st.pw = false;
+            return y;
+        }
         // bf16 storage mode: the patchified copy of the network input (written once, read by this product and by its weight gradient) as a bf16 array on the large grids
         static const bool patch_h16 = !(getenv("VELOXSEG_BF16_PATCH") && getenv("VELOXSEG_BF16_PATCH")[0] == '0');      // (A/B)
         // (only where the product runs on the 16-byte-per-lane kernel vx_pw_fwd_v4_k -- at most 64 patch channels, one input channel per modality: with BraTS' 256
@@ -264,6 +273,13 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         if (w.requires_grad()) {
             float* dw = grad_ptr(w); float* db = grad_ptr(b);
             const int x_h16 = x.scalar_type() == at::kBFloat16 ? 1 : 0;          // (the patchified copy of the bf16 storage mode)
+            if (st.patch_fused) {
+                const long bs = x.stride(0);
+                wgrad_submit(stream, dev, [=](void* s) {
+                    VX(vx_patch_embed_bwd_weight, fp(x), bs, fp(dy), dw, db, B, Cin, Cout, D / K, H / K, W / K, s);
+                });
+                return;
+            }
             wgrad_submit(stream, dev, [=](void* s) {
                 VX(vx_pw_conv_bwd_weight_h, (const void*)x.data_ptr(), fp(dy), dw, db, B, Cin * K * K * K, Cout, (long)(D / K) * (H / K) * (W / K), x_h16, s);
             });

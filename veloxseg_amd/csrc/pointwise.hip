@@ -371,6 +371,178 @@ extern "C" int vx_pw_conv_bwd_weight(const float* x, const float* x2, int C1, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Patch embedding (a convolution with kernel == stride == 4, no padding; PatchEmbed, Encoder.py:150-156 of the reference) WITHOUT the patchified copy
+// (round 6): the product and its weight gradient read the network input in place.  Until round 5 vx_patchify wrote the (Cin 64, Vo)
+// channel image (one read + one write of the whole input) and the 1x1 kernels read it twice more; here the 64 "channels" of an output voxel are gathered
+// by address: a lane owns 4 consecutive output voxels of one row, whose 16 taps (kw = 0..3 of each) are 64 contiguous bytes of the input row (kd, kh)
+// -- four 16-byte loads per row, and the (voxel, kw) transposition is register naming.
+//   forward     : one wave per block, 16 output channels, the 16 x Ck weight tile in LDS, channels summed in the order of the patchified product
+//                 (bias first, then c = ((cin 4 + kd) 4 + kh) 4 + kw ascending: the results are bit-identical to vx_patchify + vx_pw_fwd_v4_k)
+//   weight grad : block = one (cin, kd) and a chunk of voxels, wave = kh: 16 co x 4 kw sums per lane over its voxels (256 FMAs per 20 loads), summed
+//                 over the lanes through LDS, one atomic per (co, kw) and wave.  The rows of a chunk sit on one XCD (vx_xcd_rows): its dy is read once from HBM.
+// ------------------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ void __launch_bounds__(64) vx_patch4_fwd_k(const float* __restrict__ x, long bstride, int Cin, int Do, int Ho, int Wo, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float vx_p4_wt[];      // [Ck][16 output channels]
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f4* gf4;
+    const int lane = threadIdx.x;
+    const int Ck = Cin * 64;
+    const long Vo = (long)Do * Ho * Wo;
+    const long v = ((long)blockIdx.x * 64 + lane) * 4;
+    const int co0 = blockIdx.y * 16, b = blockIdx.z;
+    for (int e = lane; e < 16 * Ck; e += 64) { const int co = e & 15, c = e >> 4; vx_p4_wt[e] = w[(long)(co0 + co) * Ck + c]; }
+    f4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float bj = bias ? bias[co0 + j] : 0.0f; acc[j] = (f4){bj, bj, bj, bj}; }
+    __syncthreads();
+    if (v >= Vo) return;
+    const int wo = (int)(v % Wo), ho = (int)((v / Wo) % Ho), dz = (int)(v / ((long)Wo * Ho));
+    const long W = 4L * Wo, HW = 4L * Ho * W, Vin = 4L * Do * HW;
+    const unsigned long long base = (unsigned long long)(x + (long)b * bstride + 4L * dz * HW + 4L * ho * W + 4L * wo);
+    const int nrows = Cin * 16;
+    for (int r0 = 0; r0 < nrows; r0 += RB) {
+        f4 xr[RB][4];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + u, cin = r >> 4, kd = (r >> 2) & 3, kh = r & 3;
+            const unsigned long long p = base + (unsigned long long)((long)cin * Vin + kd * HW + kh * W) * 4ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[u][j] = *(gf4)(p + 16ull * j);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const f4 xv = (f4){xr[u][0][kw], xr[u][1][kw], xr[u][2][kw], xr[u][3][kw]};
+                const f4* wr = reinterpret_cast<const f4*>(vx_p4_wt + ((r0 + u) * 4 + kw) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 w4 = wr[q];
+                    acc[4 * q + 0] += w4[0] * xv;
+                    acc[4 * q + 1] += w4[1] * xv;
+                    acc[4 * q + 2] += w4[2] * xv;
+                    acc[4 * q + 3] += w4[3] * xv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) *reinterpret_cast<f4*>(y + ((long)b * Cout + co0 + j) * Vo + v) = acc[j];
+}
+
+// grid (Cin * 4 * (Cout / 16), chunks); block 256 = 4 waves (kh); quads of a chunk: [chunk * qpc, (chunk + 1) * qpc) of the B * Vo / 4 voxel quads
+__global__ void __launch_bounds__(256) vx_patch4_wgrad_k(const float* __restrict__ x, long bstride, int Cin, int Do, int Ho, int Wo, const float* __restrict__ dy,
+                                                         int Cout, int B, float* __restrict__ dw, float* __restrict__ db, long qpc) {
+    __shared__ float red[4][64 * 32];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int bx, chunk;
+    vx_xcd_rows(bx, chunk);
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nrk = Cin * 4;
+    const int rk = bx % nrk, cot = bx / nrk;
+    const int cin = rk >> 2, kd = rk & 3, co0 = cot * 16;
+    const int Ck = Cin * 64;
+    const long Vo = (long)Do * Ho * Wo, Q = Vo >> 2, NQ = (long)B * Q;
+    const long W = 4L * Wo, HW = 4L * Ho * W, Vin = 4L * Do * HW;
+    const bool do_bias = db != nullptr && rk == 0 && kh == 0;
+    f4 acc[16];                         // acc[co][kw]
+    float bs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = (f4){0.f, 0.f, 0.f, 0.f}; bs[j] = 0.0f; }
+    const long q1 = ((long)chunk + 1) * qpc < NQ ? ((long)chunk + 1) * qpc : NQ;
+    for (long qd = (long)chunk * qpc + lane; qd < q1; qd += 64) {
+        const int b = (int)(qd / Q);
+        const long v = (qd - (long)b * Q) * 4;
+        const int wo = (int)(v % Wo), ho = (int)((v / Wo) % Ho), dz = (int)(v / ((long)Wo * Ho));
+        const float* __restrict__ px = x + (long)b * bstride + (long)cin * Vin + (4L * dz + kd) * HW + (4L * ho + kh) * W + 4L * wo;
+        const float* __restrict__ pd = dy + ((long)b * Cout + co0) * Vo + v;
+        f4 xr[4], g[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const f4*>(px + 4 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[j] = *reinterpret_cast<const f4*>(pd + (long)j * Vo);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[j] += g[j][u] * xr[u];
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bs[j] += (g[j][0] + g[j][1]) + (g[j][2] + g[j][3]);
+        }
+    }
+    // sum over the lanes: halves added by one cross-lane exchange, then [64 sums][32 lanes] through LDS (column index swizzled: conflict-free both ways)
+    float* __restrict__ rw = red[kh];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int a = 4 * j + kw;
+            const float t = acc[j][kw] + __shfl_xor(acc[j][kw], 32, 64);
+            if (lane < 32) rw[a * 32 + (lane ^ (a & 31))] = t;
+        }
+    __syncthreads();
+    {
+        float s_ = 0.0f;
+        const float* row = rw + lane * 32;
+#pragma unroll 8
+        for (int l = 0; l < 32; ++l) s_ += row[l ^ (lane & 31)];
+        const int j = lane >> 2, kw = lane & 3;
+        atomicAdd(dw + (long)(co0 + j) * Ck + ((cin * 4 + kd) * 4 + kh) * 4 + kw, s_);
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float t = vx_wave_sum(bs[j]);
+            if (lane == 0) atomicAdd(db + co0 + j, t);
+        }
+    }
+}
+
+// 1 where the fused patch embedding takes the layer (callers fall back to vx_patchify + the 1x1 kernels elsewhere: other patch sizes, ragged rows, tiny grids)
+extern "C" int vx_patch_embed_ok(int Cin, int Cout, int Do, int Ho, int Wo, int K) {
+    static const int off = getenv("VELOXSEG_PATCH_FUSED") && getenv("VELOXSEG_PATCH_FUSED")[0] == '0';      // (A/B)
+    static const long minv = getenv("VELOXSEG_PATCH_FUSED_MINV") ? atol(getenv("VELOXSEG_PATCH_FUSED_MINV")) : 8192;
+    return (!off && K == 4 && Cin >= 1 && Cin <= 8 && Cout % 16 == 0 && Wo % 4 == 0 && Do > 0 && Ho > 0 && (long)Do * Ho * Wo >= minv) ? 1 : 0;
+}
+// y[b, co, z, y, x] = bias[co] + sum w[co, cin, kd, kh, kw] * x[b, cin, 4z + kd, 4y + kh, 4x + kw];  batch_stride: floats between the samples of x (a channel slice
+// of a wider tensor is read in place)
+extern "C" int vx_patch_embed_fwd(const float* x, long batch_stride, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Do, int Ho, int Wo,
+                                  void* stream) {
+    VX_REQUIRE(x && w && y && B > 0, "vx_patch_embed_fwd: bad args");
+    VX_REQUIRE(vx_patch_embed_ok(Cin, Cout, Do, Ho, Wo, 4) == 1 || (Cin >= 1 && Cin <= 8 && Cout % 16 == 0 && Wo % 4 == 0), "vx_patch_embed_fwd: needs 16 | Cout, 4 | Wo, Cin <= 8");
+    VX_REQUIRE(batch_stride >= (long)Cin * 64 * Do * Ho * Wo && batch_stride % 4 == 0 && ((uintptr_t)x & 15) == 0, "vx_patch_embed_fwd: bad batch stride / alignment");
+    const long Vo = (long)Do * Ho * Wo;
+    const dim3 grid(vx_cdiv(Vo, 256), Cout / 16, B);
+    vx_patch4_fwd_k<4><<<grid, 64, (size_t)Cin * 64 * 16 * sizeof(float), (hipStream_t)stream>>>(x, batch_stride, Cin, Do, Ho, Wo, w, bias, y, Cout);
+    VX_LAUNCH_CHECK("vx_patch_embed_fwd");
+    return 0;
+}
+// dw[co, cin, kd, kh, kw] += sum_{b, voxels} dy[b, co, v] * x[b, cin, patch of v];  db[co] += sum dy  (db may be null)
+extern "C" int vx_patch_embed_bwd_weight(const float* x, long batch_stride, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int Do, int Ho, int Wo,
+                                         void* stream) {
+    VX_REQUIRE(x && dy && dw && B > 0, "vx_patch_embed_bwd_weight: bad args");
+    VX_REQUIRE(Cin >= 1 && Cin <= 8 && Cout % 16 == 0 && Wo % 4 == 0, "vx_patch_embed_bwd_weight: needs 16 | Cout, 4 | Wo, Cin <= 8");
+    VX_REQUIRE(batch_stride >= (long)Cin * 64 * Do * Ho * Wo && batch_stride % 4 == 0 && ((uintptr_t)x & 15) == 0, "vx_patch_embed_bwd_weight: bad batch stride / alignment");
+    const long NQ = (long)B * Do * Ho * Wo / 4;
+    const int nbx = Cin * 4 * (Cout / 16);
+    // chunks: about 1024 blocks in all, at least 2 quads per lane, a multiple of 8 chunks (vx_xcd_rows)
+    static const long blocks_env = getenv("VELOXSEG_PATCH_WG_BLOCKS") ? atol(getenv("VELOXSEG_PATCH_WG_BLOCKS")) : 256;      // (A/B)
+    long chunks = blocks_env / nbx;
+    if (chunks > NQ / 128) chunks = NQ / 128;
+    chunks = chunks / 8 * 8;
+    if (chunks < 8) chunks = 8;
+    const long qpc = ((NQ + chunks - 1) / chunks + 63) / 64 * 64;
+    chunks = (NQ + qpc - 1) / qpc;
+    vx_patch4_wgrad_k<<<dim3((unsigned)nbx, (unsigned)chunks), 256, 0, (hipStream_t)stream>>>(x, batch_stride, Cin, Do, Ho, Wo, dy, Cout, B, dw, db, qpc);
+    VX_LAUNCH_CHECK("vx_patch_embed_bwd_weight");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // ConvTranspose3d(k=2, s=2): every output voxel has exactly one (input voxel, tap) -> a pointwise conv to 8*Co channels
 // with a depth-to-space store.  One thread = one INPUT voxel x COT output channels x 8 taps.
 // ------------------------------------------------------------------------------------------------------------------
