@@ -55,6 +55,9 @@ int vx_conv3d_bwd_weight_tiled(const float* x, const float* x2, int C1, const fl
 int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, int Cout);
 int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                        int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
+/* (round 6) the same with max |x| handed over from the forward (vx_conv_mfma_fwd_mx left its bits at x_absmax; null = find it here): the f16-pipe kernel's scale pass reads dy only */
+int vx_down_wgrad_mfma_mx(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, const unsigned* x_absmax,
+                          int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
 int vx_down_wgrad_set_f16(int on);   /* A/B (tests): the stem weight gradient on the f16 matrix pipe (default, 128-wide rows, 16 output channels) or the fp32 MFMA kernel */
 /* Weight gradient of a dense strided Conv3d (the DownConvs of encoder levels 2 - 4: Conv3d k3 s2 p1, conv_blocks.py:4-21) as a gather-GEMM on v_mfma_f32_16x16x4_f32: exact
  * fp32 products, dw +=, db += (db may be NULL).  _ok: 1 when the shape is covered (Cout 32 / 64 / 128). */
@@ -529,6 +532,11 @@ int vx_conv_mfma_stem_pieces(void);
 int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward);
 int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P,
                      void* stream);
+/* (round 6) x_absmax (one unsigned on the device, may be null): where vx_conv_mfma_fwd_writes_absmax(...) == 1 (the f16-pipe stem kernel takes the layer) the bits of max |x|
+ * are left there as a by-product of the staging, for vx_down_wgrad_mfma_mx */
+int vx_conv_mfma_fwd_writes_absmax(int Cin, int Cout, int D, int H, int W, int K, int S, int P);
+int vx_conv_mfma_fwd_mx(const float* x, const float* w, const float* bias, float* y, float* ws, unsigned* x_absmax, int B, int Cin, int D, int H, int W, int Cout,
+                        int K, int S, int P, void* stream);
 int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P, int accumulate,
                           void* stream);
 

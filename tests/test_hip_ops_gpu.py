@@ -266,6 +266,49 @@ def test_stem_weight_gradient_on_the_f16_pipe(B, Cin, sp, scale):
     assert float((outs[0][1] - ref_b).abs().max()) <= 2e-5 * scb + 2.5e-7          # (db is accumulated into a buffer that holds -0.5: fp32 rounding there)
 
 
+@pytest.mark.parametrize("B,Cin,sp", [(2, 2, (64, 64, 128)), (1, 1, (32, 48, 128))], ids=["two_channels", "one_channel"])
+def test_stem_forward_hands_max_abs_x_to_its_weight_gradient(B, Cin, sp):
+    """vx_conv_mfma_fwd_mx leaves the bits of max |x| (a by-product of the stem kernel's staging); vx_down_wgrad_mfma_mx with it == vx_down_wgrad_mfma that reads x to
+    find it: bit-identical dw / db, and the forward output is the one of the plain entry"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    x = (rnd(B, Cin, *sp) * 3.0).to(d)
+    x[0, 0, 5, 7, 9] = -41.5                                   # (the maximum is a negative element well inside a tile)
+    w, bias = (rnd(16, Cin, 7, 7, 7, seed=1) * 0.1).to(d), rnd(16, seed=2).to(d)
+    Do, Ho, Wo = sp[0] // 4, sp[1] // 4, sp[2] // 4
+    dy = rnd(B, 16, Do, Ho, Wo, seed=3).to(d)
+    st = H.stream_ptr()
+    assert H.query("vx_conv_mfma_fwd_writes_absmax", Cin, 16, *sp, 7, 4, 3) == 1
+    nf = H.query("vx_conv_mfma_ws_floats", Cin, 16, 7, 0)
+    y0, y1 = torch.empty(B, 16, Do, Ho, Wo, device=d), torch.empty(B, 16, Do, Ho, Wo, device=d)
+    wsf = torch.empty(nf, device=d)
+    mx = torch.full((1,), 12345, device=d, dtype=torch.int32)
+    H.call("vx_conv_mfma_fwd", H.P(x), H.P(w), H.P(bias), H.P(y0), H.P(wsf), B, Cin, *sp, 16, 7, 4, 3, st)
+    H.call("vx_conv_mfma_fwd_mx", H.P(x), H.P(w), H.P(bias), H.P(y1), H.P(wsf), mx.data_ptr(), B, Cin, *sp, 16, 7, 4, 3, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert mx.view(torch.float32).item() == 41.5
+    nws = H.query("vx_down_wgrad_ws_floats", B, Cin, *sp, 16)
+    outs = []
+    for hand in (False, False, True):
+        dw, db, ws = torch.full((16, Cin, 7, 7, 7), 0.25, device=d), torch.full((16,), -0.5, device=d), torch.empty(nws, device=d)
+        if hand:
+            H.call("vx_down_wgrad_mfma_mx", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, mx.data_ptr(), B, Cin, *sp, 16, st)
+        else:
+            H.call("vx_down_wgrad_mfma", H.P(x), H.P(dy), H.P(dw), H.P(db), H.P(ws), nws, B, Cin, *sp, 16, st)
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    # (the same scales -> the same operand pieces; the sums themselves are folded with float atomics where the kernel says so: bit-identity only where two plain runs agree)
+    if torch.equal(outs[0][0], outs[1][0]):
+        assert torch.equal(outs[0][0], outs[2][0])
+    if torch.equal(outs[0][1], outs[1][1]):
+        assert torch.equal(outs[0][1], outs[2][1])
+    sc = float(outs[0][0].abs().max())
+    rr = float((outs[0][0] - outs[1][0]).abs().max()) / sc               # run-to-run spread of the plain entry
+    assert float((outs[0][0] - outs[2][0]).abs().max()) / sc <= max(4.0 * rr, 1e-6), rr
+    close(outs[2][1], outs[0][1], 1e-5 * float(outs[0][1].abs().max()), 1e-5, "db")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(4, 16, 32, (32, 32, 32)), (2, 32, 64, (16, 16, 16)), (4, 64, 128, (8, 8, 8)), (1, 16, 32, (24, 24, 24)), (2, 32, 64, (12, 12, 12)), (2, 64, 128, (6, 6, 6))],
                          ids=["down2_128", "down3_128", "down4_128", "down2_96", "down3_96", "down4_96"])
 def test_downconv_weight_gradient_gather_gemm(B, Cin, Cout, sp):
@@ -697,7 +740,7 @@ def test_patch_embed_in_place_equals_patchify_plus_pointwise(B, Cin, Ctot, c_off
     xd, wd, bd, gd = xw.to(d), w.to(d), bias.to(d), gy.to(d)
     xs = xd[:, c_off:c_off + Cin]
     st = H.stream_ptr()
-    assert H.LIB.load().vx_patch_embed_ok(Cin, Cout, 32, 32, 32, 4) == 1 and H.LIB.load().vx_patch_embed_ok(Cin, Cout, 32, 32, 30, 4) == 0
+    assert H.query("vx_patch_embed_ok", Cin, Cout, 32, 32, 32, 4) == 1 and H.query("vx_patch_embed_ok", Cin, Cout, 32, 32, 30, 4) == 0
     # reference: the patchified copy and the 1x1 kernels
     ck = Cin * 64
     pat = torch.empty(B, ck, Vo, device=d)

@@ -174,6 +174,7 @@ struct ConvState {
     Tensor x, x2, w, b;
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
     bool pw = false, s1 = false, patch = false, cm = false;      // cm: strided dense conv on MFMA (csrc/conv_mfma.hip)
+    Tensor xmax;                                                 // stem: the bits of max |x| left by the forward kernel for the weight gradient (one int32)
     bool patch_fused = false;                                    // patch embedding read in place (vx_patch_embed_*): x is the network input, not a patchified copy
 };
 
@@ -249,7 +250,10 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
     }
     else if (st.cm) {
         Tensor ws = at::empty({(long)vx_conv_mfma_ws_floats(Cin, Cout, K, 0)}, x.options());
-        VX(vx_conv_mfma_fwd, fp(x), fp(w), fp(b), mp(y), mp(ws), B, Cin, D, H, W, Cout, K, S, P, stream);
+        static const bool mx_on = !(getenv("VELOXSEG_STEM_ABSMAX_FWD") && getenv("VELOXSEG_STEM_ABSMAX_FWD")[0] == '0');      // (A/B)
+        st.xmax = Tensor();
+        if (mx_on && w.requires_grad() && vx_conv_mfma_fwd_writes_absmax(Cin, Cout, D, H, W, K, S, P) == 1) st.xmax = at::empty({1}, x.options().dtype(at::kInt));
+        VX(vx_conv_mfma_fwd_mx, fp(x), fp(w), fp(b), mp(y), mp(ws), st.xmax.defined() ? reinterpret_cast<unsigned*>(st.xmax.data_ptr()) : nullptr, B, Cin, D, H, W, Cout, K, S, P, stream);
     }
     else VX(vx_conv3d_fwd, fp(x), fp(x2), C1, fp(w), fp(b), mp(y), B, Cin, D, H, W, Cout, K, S, P, G, ps, stream);
     st.x = x; st.x2 = x2;
@@ -328,6 +332,7 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
         float* dw = grad_ptr(w);
         float* db = skip_bias ? nullptr : grad_ptr(b);       // skip_bias: the caller fused the bias gradient into the InstanceNorm backward
         const bool s1 = st.s1;
+        const Tensor xmax = st.xmax;                         // (stem only: max |x| from the forward kernel)
         // the closure owns dy, x, x2 (by value) and its temporaries: with the side stream on, it is released only after the final join
         wgrad_submit(stream, dev, [=](void* s) {
             if (K == 1 && S == 1 && P == 0 && G == 1 && ps == 1) VX(vx_pw_conv_bwd_weight, fp(x), fp(x2), C1, fp(dy), dw, db, B, Cin, Cout, V, s);
@@ -352,7 +357,7 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 const int nws = vx_down_wgrad_ws_floats(B, Cin, D, H, W, Cout);          // stem DownConv: MFMA tiles + partial-sum slices
                 auto ws = std::make_shared<Tensor>(at::empty({(long)nws}, x.options()));
                 WG.done.push_back([ws](void*) {});
-                VX(vx_down_wgrad_mfma, fp(x), fp(dy), dw, db, mp(*ws), nws, B, Cin, D, H, W, Cout, s);
+                VX(vx_down_wgrad_mfma_mx, fp(x), fp(dy), dw, db, mp(*ws), nws, xmax.defined() ? reinterpret_cast<const unsigned*>(xmax.data_ptr()) : nullptr, B, Cin, D, H, W, Cout, s);
             } else if (G == 1 && ps == 1 && S > 1 && !x2.defined() && vx_conv_wgrad_gather_ok(B, Cin, D, H, W, Cout, K, S, P) == 1) {
                 VX(vx_conv_wgrad_gather_mfma, fp(x), fp(dy), dw, db, B, Cin, D, H, W, Cout, K, S, P, s);      // DownConv levels 2 - 4: gather-GEMM on the fp32 matrix pipe
             } else if (F.use_wgrad_ws) {

@@ -281,8 +281,9 @@ __device__ __forceinline__ int cm_exp16(float m) {
 }
 #define VX_STEM_RL 72          // halfs per staged input row (67 used)
 // img[(step * 2 + piece) * 64 + lane]: lane (co = lane & 15, G = lane >> 4): row r = 4 step + G = (ci * 7 + kd) * 7 + kh, the 8 halfs = w[co][ci][kd][kh][0..6], 0
-__global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict__ w, cm_u4* __restrict__ img, float* __restrict__ esc, int Cin, int nsteps) {
+__global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict__ w, cm_u4* __restrict__ img, float* __restrict__ esc, int Cin, int nsteps, unsigned* __restrict__ xmax) {
     __shared__ float sm[16];
+    if (xmax != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *xmax = 0u;          // (the stem kernel that follows on this stream folds max |x| into it)
     const int n = 16 * Cin * 343;
     float mx = 0.0f;
     for (int i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(1024) vx_stem_wprep_k(const float* __restrict_
 // of 153 KB, two blocks per CU instead of one)
 template <int CIN, int NP = 2>
 __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x, const cm_u4* __restrict__ img, const float* __restrict__ esc, const float* __restrict__ bias,
-                                                     float* __restrict__ y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+                                                     float* __restrict__ y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, unsigned* __restrict__ xmax) {
     constexpr int NROW = CIN * 7 * 19, NSTEP = (CIN * 49 + 3) / 4, NIT = (NROW * (VX_STEM_RL / 4) + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
     _Float16* __restrict__ xh = reinterpret_cast<_Float16*>(cm_lds);                   // [NROW][72] hi pieces, then (NP = 2) the lo pieces
@@ -358,7 +359,11 @@ __global__ void __launch_bounds__(256) vx_stem_fwd_k(const float* __restrict__ x
     mx = vx_wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    const int ex = cm_exp16(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    const float bmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // (round 6) max |x| of the whole input as a by-product (every input is staged by some block; non-negative floats order like unsigned integers): the weight
+    // gradient of this layer scales its operands by it and no longer reads the 67 MB input a second time to find it
+    if (xmax != nullptr && threadIdx.x == 0 && bmx > 0.0f) atomicMax(xmax, __float_as_uint(bmx));
+    const int ex = cm_exp16(bmx);
     const float sc = ldexpf(1.0f, ex);
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
@@ -430,8 +435,19 @@ extern "C" int vx_conv_mfma_ws_floats(int Cin, int Cout, int K, int backward) {
     return n > stem ? n : stem;
 }
 
+extern "C" int vx_conv_mfma_fwd_mx(const float* x, const float* w, const float* bias, float* y, float* ws, unsigned* x_absmax, int B, int Cin, int D, int H, int W, int Cout,
+                                   int K, int S, int P, void* stream);
 extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int B, int Cin, int D, int H, int W, int Cout, int K, int S, int P,
                                 void* stream) {
+    return vx_conv_mfma_fwd_mx(x, w, bias, y, ws, nullptr, B, Cin, D, H, W, Cout, K, S, P, stream);
+}
+// 1 when vx_conv_mfma_fwd_mx with these arguments writes max |x| (the f16-pipe stem kernel takes the layer)
+extern "C" int vx_conv_mfma_fwd_writes_absmax(int Cin, int Cout, int D, int H, int W, int K, int S, int P) {
+    return (vx_conv_mfma_ok(Cin, Cout, D, H, W, K, S, P, 1, 1) && vx_stem_ok(Cin, Cout, D, H, W, K, S, P)) ? 1 : 0;
+}
+// x_absmax (may be null; one unsigned, device): where vx_conv_mfma_fwd_writes_absmax says so, the bits of max |x| are left there for vx_down_wgrad_mfma_mx
+extern "C" int vx_conv_mfma_fwd_mx(const float* x, const float* w, const float* bias, float* y, float* ws, unsigned* x_absmax, int B, int Cin, int D, int H, int W, int Cout,
+                                   int K, int S, int P, void* stream) {
     VX_REQUIRE(x && w && y && ws && B > 0, "vx_conv_mfma_fwd: null argument");
     VX_REQUIRE(vx_conv_mfma_ok(Cin, Cout, D, H, W, K, S, P, 1, 1), "vx_conv_mfma_fwd: unsupported shape Cin=%d Cout=%d %dx%dx%d K=%d S=%d P=%d", Cin, Cout, D, H, W, K, S, P);
     hipStream_t st = (hipStream_t)stream;
@@ -439,14 +455,14 @@ extern "C" int vx_conv_mfma_fwd(const float* x, const float* w, const float* bia
         const int nsteps = (Cin * 49 + 3) / 4, Do = D / 4, Ho = H / 4, Wo = W / 4;
         cm_u4* img = reinterpret_cast<cm_u4*>(ws);
         float* esc = ws + (long)nsteps * 2 * 64 * 4;
-        vx_stem_wprep_k<<<dim3((unsigned)nsteps), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps);
+        vx_stem_wprep_k<<<dim3((unsigned)nsteps), dim3(1024), 0, st>>>(w, img, esc, Cin, nsteps, x_absmax);
         // (one piece only where it brings the f16-pipe kernel in at all -- 4 input channels: brats128 bf16 816 -> 830 patches/s; with 2 channels the two-piece kernel stays:
         //  autopet128 bf16 1156 vs 1151 with one piece -- its shorter blocks only crowd the other lanes, the stem is not on that step's critical path)
         const int np = (g_stem_pieces == 1 && Cin == 4) ? 1 : 2;
         const size_t shm = (size_t)Cin * 7 * 19 * VX_STEM_RL * 2 * np + (size_t)4 * nsteps * 4 + 64;
         const dim3 grid((unsigned)((long)B * Do * (Ho / 4) * ((Wo + 15) / 16)));
 #define VX_STEM(CI, NP_) { static bool once = false; if (!once) { if (hipFuncSetAttribute((const void*)vx_stem_fwd_k<CI, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); once = true; } \
-        vx_stem_fwd_k<CI, NP_><<<grid, dim3(256), shm, st>>>(x, img, esc, bias, y, B, D, H, W, Do, Ho, Wo); }
+        vx_stem_fwd_k<CI, NP_><<<grid, dim3(256), shm, st>>>(x, img, esc, bias, y, B, D, H, W, Do, Ho, Wo, x_absmax); }
         if (np == 1) { if (Cin == 1) VX_STEM(1, 1) else if (Cin == 2) VX_STEM(2, 1) else VX_STEM(4, 1) }
         else { if (Cin == 1) VX_STEM(1, 2) else if (Cin == 2) VX_STEM(2, 2) else VX_STEM(4, 2) }
 #undef VX_STEM

@@ -697,8 +697,11 @@ __device__ __forceinline__ int vx_sw_exp16(float m) {          // |m| * 2^e in [
     return e > 100 ? 100 : (e < -100 ? -100 : e);
 }
 // mx[0] = max |x|, mx[1] = max |dy| as float bits (non-negative floats order like unsigned integers); mx zeroed by the caller
-__global__ void __launch_bounds__(256) vx_stem_absmax_k(const float4* __restrict__ x, long nx4, const float4* __restrict__ dy, long ny4, unsigned* __restrict__ mx) {
-    const bool second = blockIdx.y == 1;
+// (round 6) xin != null: max |x| is already known (left by the forward stem kernel, vx_conv_mfma_fwd_mx) -- it is copied, and only dy is read (grid (n, 1), x = null)
+__global__ void __launch_bounds__(256) vx_stem_absmax_k(const float4* __restrict__ x, long nx4, const float4* __restrict__ dy, long ny4, unsigned* __restrict__ mx,
+                                                        const unsigned* __restrict__ xin) {
+    if (xin != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(mx, *xin);
+    const bool second = blockIdx.y == 1 || x == nullptr;
     const float4* __restrict__ p = second ? dy : x;
     const long n = second ? ny4 : nx4;
     float m = 0.0f;
@@ -864,8 +867,15 @@ extern "C" int vx_down_wgrad_ws_floats(int B, int Cin, int Di, int Hi, int Wi, i
     return n > 0x7fffffffL ? 0 : (int)n;
 }
 // Conv3d(k7, s4, p3) weight + bias gradient (dw +=, db += ; db may be NULL).  Returns 1 (nothing launched) when the shape is not covered.
+extern "C" int vx_down_wgrad_mfma_mx(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, const unsigned* x_absmax,
+                                     int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream);
 extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream) {
+    return vx_down_wgrad_mfma_mx(x, dy, dw, db, ws, ws_floats, nullptr, B, Cin, Di, Hi, Wi, Cout, stream);
+}
+// x_absmax (may be null): the bits of max |x| left by vx_conv_mfma_fwd_mx for the same x -- the f16-pipe kernel then reads only dy to find its scales
+extern "C" int vx_down_wgrad_mfma_mx(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, const unsigned* x_absmax,
+                                     int B, int Cin, int Di, int Hi, int Wi, int Cout, void* stream) {
     VX_REQUIRE(x && dy && dw && ws && B > 0 && Cin > 0 && Cout > 0, "vx_down_wgrad_mfma: bad args");
     int CB, Do, Ho, Wo, ntiles, tpb, nblk;
     if (vx_down_cfg(B, Cin, Di, Hi, Wi, Cout, CB, Do, Ho, Wo, ntiles, tpb, nblk)) return 1;
@@ -881,7 +891,8 @@ extern "C" int vx_down_wgrad_mfma(const float* x, const float* dy, float* dw, fl
         unsigned* mx = reinterpret_cast<unsigned*>(ws + (long)nblk * nw);
         VX_REQUIRE(hipMemsetAsync(mx, 0, 8, st) == hipSuccess, "vx_down_wgrad_mfma: memset");
         const long nx4 = (long)B * Cin * Di * Hi * Wi / 4, ny4 = (long)B * Cout * Do * Ho * Wo / 4;
-        vx_stem_absmax_k<<<dim3(256, 2), dim3(256), 0, st>>>(reinterpret_cast<const float4*>(x), nx4, reinterpret_cast<const float4*>(dy), ny4, mx);
+        if (x_absmax != nullptr) vx_stem_absmax_k<<<dim3(256, 1), dim3(256), 0, st>>>(nullptr, 0, reinterpret_cast<const float4*>(dy), ny4, mx, x_absmax);
+        else vx_stem_absmax_k<<<dim3(256, 2), dim3(256), 0, st>>>(reinterpret_cast<const float4*>(x), nx4, reinterpret_cast<const float4*>(dy), ny4, mx, nullptr);
         const int nt16 = B * Do * (Ho / 4);                        // tiles: (b, od, group of 4 output rows)
         int nb16 = 256 / Cin;                                       // one block per CU (119 KB of LDS)
         if (nb16 < 1) nb16 = 1;
