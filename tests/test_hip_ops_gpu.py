@@ -983,8 +983,12 @@ def test_pwa_attention_mfma_kernels_equal_the_valu_kernels(grid, big, heads, mdh
 @pytest.mark.parametrize("p_attn", [0.2, 0.0], ids=["dropout", "no_dropout"])
 @pytest.mark.parametrize("scale", [1.0, 300.0, 1e-4], ids=["unit", "large", "tiny"])
 @pytest.mark.parametrize("grid,big,heads,mdh,C,B", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([16, 16, 16], [4, 4, 4], 1, 4, 12, 2), ([8, 8, 8], [8, 8, 8], 2, 8, 8, 1),
-                                                    ([8, 8, 8], [4, 4, 4], 1, 4, 8, 3)],
-                         ids=["L2_512tok_c8", "L1_64tok_c4", "L2_one_window_per_head", "L1_small_grid"])
+                                                    ([8, 8, 8], [4, 4, 4], 1, 4, 8, 3),
+                                                    # (round 6) ragged windows = the shipped geometries: 27 / 216 tokens (96^3 patches, windows [3, 6, ..]), 32 (Hecktor), 125
+                                                    ([12, 12, 12], [3, 3, 3], 1, 4, 12, 2), ([12, 12, 12], [6, 6, 6], 2, 8, 32, 2), ([8, 8, 4], [4, 4, 2], 1, 4, 8, 2),
+                                                    ([10, 10, 10], [5, 5, 5], 2, 8, 16, 1), ([6, 6, 6], [6, 6, 6], 1, 4, 4, 3)],
+                         ids=["L2_512tok_c8", "L1_64tok_c4", "L2_one_window_per_head", "L1_small_grid", "ragged_27tok_c4", "ragged_216tok_c8", "ragged_32tok_aniso_c4", "ragged_125tok_c8",
+                              "ragged_216tok_c4_one_window"])
 def test_pwa_attention_f16_pipe_backward_equals_the_fp32_kernels(grid, big, heads, mdh, C, B, scale, p_attn):
     """The one-pass attention backward on the 16x16x32 f16 matrix pipe (csrc/pwa_mfma.hip vx_pwa_attn_bwd1h_k: levels 1 / 2 of the 128^3 configurations -- windows of
     64 / 512 tokens, two modalities, head widths 4 / 8) against the fp32-VALU kernels of the same library on the same inputs and the same dropout mask (the f16
@@ -998,7 +1002,19 @@ def test_pwa_attention_f16_pipe_backward_equals_the_fp32_kernels(grid, big, head
     pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
     plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
     pp = H.ctypes.addressof(plan)
-    assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == 1 and H.query("vx_pwa_attn_mbits_useful", pp, B, M, pl["c_qk"], pl["c_v"]) == 1
+    H.call("vx_pwa_attn_set_f16_bwd_ragged", 2)                # (every ragged length: by default the short windows -- 27 / 32 tokens -- stay on the fp32 kernels, which are faster there)
+    try:
+        assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == 1 and H.query("vx_pwa_attn_mbits_useful", pp, B, M, pl["c_qk"], pl["c_v"]) == 1
+        _f16_pipe_backward_case(VF, H, d, pl, plan, B, M, scale, p_attn)
+    finally:
+        H.call("vx_pwa_attn_set_f16_bwd_ragged", 1)
+    l = pl["n"][0] * pl["n"][1] * pl["n"][2]
+    assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == (1 if (l % 64 == 0 or 4 * l >= 3 * ((l + 63) // 64 * 64)) else 0)
+
+
+def _f16_pipe_backward_case(VF, H, d, pl, plan, B, M, scale, p_attn):
+    grid = pl["grid"]
+    heads = pl["heads"]
     n = pl["n"]
     vs = 30.0 if scale > 1 else (0.03 if scale < 1 else 1.0)
     base = []

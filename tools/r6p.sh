@@ -1,0 +1,8 @@
+export TMPDIR=/tmp
+NB="--no-eager-baseline --no-cpu-baseline --no-kernel-pass"
+for r in 1 2 3; do for x in 0 1; do
+echo ragged=$x autopet96 $(VELOXSEG_F16_BWD_RAGGED=$x python bench.py $NB --dispersion-steps 0 --workload autopet96 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+done; done
+for w in "hecktor f32"; do set -- $w; for r in 1 2; do for x in 0 1; do
+echo ragged=$x $1 $2 $(VELOXSEG_F16_BWD_RAGGED=$x python bench.py $NB --dispersion-steps 0 --workload $1 --dtype $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+done; done; done
