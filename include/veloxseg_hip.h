@@ -429,6 +429,7 @@ int vx_pwa_attn_set_mfma(int on);
 int vx_pwa_attn_bwd1h_ok(const VxPwaPlan* plan, int B, int M, int cq, int cv);
 int vx_pwa_attn_set_f16_bwd(int on);
 int vx_pwa_attn_set_f16_bwd_ragged(int on);   /* A/B (round 6): window lengths that are not multiples of 64 (27 / 216 / 32 tokens: the shipped 96^3 and Hecktor geometries) on the f16-pipe backward too -- padded 64-token chunks: 0 off, 1 (default, VELOXSEG_F16_BWD_RAGGED) where a window fills >= 3/4 of its chunks (216 tokens), 2 every ragged length (tests) */
+int vx_pwa_attn_set_f16_bwd_m1(int on);       /* A/B (round 6): windows of ONE modality (BraTS) on the f16-pipe backward (MF = 1 instance): 0 (default, VELOXSEG_F16_BWD_M1: measured no gain at BraTS' batch of 2), 1 on, 2 on for >= 512 tokens */
 int vx_pwa_attn_set_short(int on);       /* 1 (default; VELOXSEG_B1_SHORT): single-modality windows below 512 tokens take the one-pass MFMA backward although l % 16 == 0 (BraTS: 2 x faster than the VALU kernels there); 0: the selection of rounds 3 - 5 (A/B, tests) */
 
 /* ---------------------------------------------------------------------------------------------

@@ -1039,6 +1039,32 @@ def _f16_pipe_backward_case(VF, H, d, pl, plan, B, M, scale, p_attn):
         close(a, b, 1e-5 * float(b.abs().max()), 2e-4, f"f16 pipe vs fp32 kernels, tensor {i}")
 
 
+@pytest.mark.parametrize("p_attn", [0.2, 0.0], ids=["dropout", "no_dropout"])
+@pytest.mark.parametrize("scale", [1.0, 300.0], ids=["unit", "large"])
+@pytest.mark.parametrize("grid,big,heads,mdh,C,B", [([16, 16, 16], [4, 4, 4], 1, 4, 12, 2), ([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([12, 12, 12], [6, 6, 6], 2, 8, 32, 2), ([8, 8, 8], [8, 8, 8], 1, 4, 4, 1)],
+                         ids=["brats_L1_64tok_c4", "brats_L2_512tok_c8", "brats96_L2_216tok_c8", "one_window_512tok_c4"])
+def test_pwa_attention_f16_pipe_backward_one_modality(grid, big, heads, mdh, C, B, scale, p_attn):
+    """The same kernel with ONE modality per window (MF = 1 instance; BraTS: `in_ch = [4]`, reference config/models_config_brats2021.json) against the fp32 kernels"""
+    VF = _vf()
+    from veloxseg_amd import _hip as H
+    d = dev()
+    M = 1
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, mdh, C)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    pp = H.ctypes.addressof(plan)
+    assert pl["c_qk"] == pl["c_v"] and pl["c_qk"] in (4, 8), (pl["c_qk"], pl["c_v"])
+    # OFF by default: measured no gain (brats128 B = 2: 36 windows of 512 tokens -- 68 vs 74 us alone at level 2, 38 vs 35 at level 1; the step 746 vs 751 patches/s)
+    assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == 0
+    H.call("vx_pwa_attn_set_f16_bwd_m1", 1)
+    H.call("vx_pwa_attn_set_f16_bwd_ragged", 2)
+    try:
+        assert H.query("vx_pwa_attn_bwd1h_ok", pp, B, M, pl["c_qk"], pl["c_v"]) == 1 and H.query("vx_pwa_attn_mbits_useful", pp, B, M, pl["c_qk"], pl["c_v"]) == 1
+        _f16_pipe_backward_case(VF, H, d, pl, plan, B, M, scale, p_attn)
+    finally:
+        H.call("vx_pwa_attn_set_f16_bwd_m1", 0)
+        H.call("vx_pwa_attn_set_f16_bwd_ragged", 1)
+
+
 @pytest.mark.parametrize("grid,big,heads,mdh,C,M", [([16, 16, 16], [8, 8, 8], 2, 8, 32, 2), ([16, 16, 16], [4, 4, 4], 1, 4, 16, 2), ([8, 8, 8], [4, 4, 4], 2, 8, 64, 1),
                                                     ([8, 8, 16], [4, 4, 8], 2, 8, 32, 3)],
                          ids=["L2_512tok", "L1_64tok", "M1", "M3_aniso"])

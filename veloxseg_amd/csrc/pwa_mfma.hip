@@ -790,13 +790,15 @@ __device__ __forceinline__ int vx_a_exp(float mx, int target) {
 // coordinate repeats the last token's (every bias index stays in range and the bin windows are those vx_b1_span measures), their pairs are forced to P = dS = 0 by a
 // select, nothing is stored for them; the forward's keep bits are read from words that straddle 16-key boundaries (key index f l + 16 kt is not a multiple of 16).
 // `win_r`: the bias-gradient window of a lane group (a multiple of 64 >= the span the host measured; VX_B1_WIN in the aligned instances).
-template <int CQ, int CV, bool DROP, bool RAG = false>
+// MF (round 6): modalities of a window -- 2, or 1 (BraTS: one 4-channel modality group): the second modality's rows are staged as zeros and its loops are not run
+template <int CQ, int CV, bool DROP, bool RAG = false, int MF = 2>
 __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                                                            const float* __restrict__ table, const float* __restrict__ O, const float* __restrict__ LSE,
                                                            const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
                                                            float* __restrict__ dtable_rep, VxAttnM A, float inv_keep, int atomic_dq, int QS, int QCB,
                                                            const unsigned short* __restrict__ mbits, int LP_r, int win_r) {
     static_assert(CQ == CV && (CQ == 4 || CQ == 8), "head widths (4, 4) and (8, 8)");
+    static_assert(MF == 1 || MF == 2, "one or two modalities");
     constexpr int C = CQ, TS = 20, NTq = 4, nq = 64, NR = 2 * nq;              // NR: query rows of a chunk (2 modalities x 64 tokens)
     constexpr float LOG2E = 1.4426950408889634f;
     const int LP = RAG ? LP_r : A.l, WIN = RAG ? win_r : VX_B1_WIN;
@@ -827,10 +829,14 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     float kmax = 0.0f, vmax = 0.0f;
     vx_au4 kop[2], vop[2], kth, ktl;
     float kv[2][C], vv[2][C], t8[8];
+    if constexpr (MF == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t8[e] = 0.0f;
+    }
     // every global load of the block's start is issued before the first wait: the key rows here, the first chunk's query rows below, then the LDS tables are built
     // (one exposed memory latency per block instead of three: 83 -> see DESIGN.md section 9.5)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < MF; ++f) {
         const long kr = wrow + (long)f * A.l + kcc;
 #pragma unroll
         for (int c4 = 0; c4 < C / 4; ++c4) {
@@ -852,8 +858,8 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     float xv[C], lse_r = 0.0f, del_r = 0.0f, omax = 0.0f;
     auto load_rows = [&](int qc) {
         const int tq_ = 64 * qc + rloc;
-        const bool rv = !RAG || tq_ < A.l;                   // (RAG: rows beyond the window's last token are staged as zeros)
-        const long grow = wrow + (long)rf * A.l + (RAG ? min(tq_, A.l - 1) : tq_);
+        const bool rv = (!RAG || tq_ < A.l) && rf < MF;      // (RAG: rows beyond the window's last token are staged as zeros; MF = 1: the second modality's rows too)
+        const long grow = wrow + (long)(rf < MF ? rf : 0) * A.l + (RAG ? min(tq_, A.l - 1) : tq_);
         del_r = 0.0f; omax = 0.0f;
         if (threadIdx.x < 128) {
 #pragma unroll
@@ -871,7 +877,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
                 omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
             }
         }
-        if (RAG && !rv) {
+        if ((RAG || MF == 1) && !rv) {
 #pragma unroll
             for (int c = 0; c < C; ++c) xv[c] = 0.0f;
             lse_r = 0.0f; del_r = 0.0f; omax = 0.0f;
@@ -899,7 +905,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     }
     {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < MF; ++f) {
 #pragma unroll
             for (int c = 0; c < C; ++c) { kmax = fmaxf(kmax, fabsf(kv[f][c])); vmax = fmaxf(vmax, fabsf(vv[f][c])); }
         }
@@ -911,7 +917,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         const float sk = ldexpf(1.0f, vx_a_exp(kmax, 10)), sv = ldexpf(1.0f, vx_a_exp(vmax, 5));
         // B of S / dP: lane (key m of tile f, group G) = the piece (G & 1) of K / V  [C = 4: groups 0, 1 hold hi | lo, groups 2, 3 nothing]
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < MF; ++f) {
             uint32_t kh[C / 2], kl[C / 2], vh[C / 2], vl[C / 2];
 #pragma unroll
             for (int c = 0; c < C; c += 2) {
@@ -951,7 +957,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     const int poffP = (C == 4 && qg >= 2) ? 32 : 16 + poffS;
     float totk[2][4], totv[2][4];                             // dK / dV of this wave's keys in true units (rows still stacked hi | lo)
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < MF; ++f)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { totk[f][i] = 0.0f; totv[f][i] = 0.0f; }
     const int NW16 = (A.ML + 15) >> 4;
@@ -966,16 +972,16 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         auto load_bits = [&](int j) {
             if constexpr (DROP && !RAG) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < MF; ++g)
 #pragma unroll
-                    for (int f = 0; f < 2; ++f)
+                    for (int f = 0; f < MF; ++f)
                         mk[g][f] = *reinterpret_cast<const uint2*>(mbw + (long)(f * (A.l >> 4) + kt) * A.ML + g * A.l + mrow0 + 16 * j);
             }
             if constexpr (DROP && RAG) {          // the tile's 16 keys start at bit (f l + 16 kt) & 15 of word (f l + 16 kt) >> 4; the 4 query rows are 4 halfwords apart by one
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < MF; ++g)
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) {
+                    for (int f = 0; f < MF; ++f) {
                         const int k0 = f * A.l + min(16 * kt, A.l - 1);
                         const int w0 = k0 >> 4, w1 = min(w0 + 1, NW16 - 1), sh = k0 & 15;
                         unsigned b4[4];
@@ -1034,7 +1040,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         __syncthreads();
         vx_f32x4 dk[2], dv[2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) { dk[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; dv[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int f = 0; f < MF; ++f) { dk[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; dv[f] = (vx_f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
         for (int j = 0; j < NTq; ++j) {
             const int qt = q_lo + j;
@@ -1045,17 +1051,21 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
             for (int i = 0; i < 4; ++i) bs[i] = bias[raw[i] + A.lin_cst];
             uint2 mkc[2][2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < MF; ++g)
 #pragma unroll
-                for (int f = 0; f < 2; ++f) mkc[g][f] = mk[g][f];
+                for (int f = 0; f < MF; ++f) mkc[g][f] = mk[g][f];
             if (j + 1 < NTq) load_bits(j + 1);
             float dssum[4] = {0.f, 0.f, 0.f, 0.f};
             bool pv[4];                                      // (RAG) the pair (query row 4 qg + i of this step, this lane's key) exists
 #pragma unroll
             for (int i = 0; i < 4; ++i) pv[i] = !RAG || (kval && 16 * qt + 4 * qg + i < A.l);
             uint32_t pmh[2][4], pml[2][4], dsh[2][4], dsl[2][4];          // [f][2 g + pair]: B operands of dV / dK (slots 4 g + i)
+            if constexpr (MF == 1) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+                for (int e = 2; e < 4; ++e) { pmh[0][e] = 0u; pml[0][e] = 0u; dsh[0][e] = 0u; dsl[0][e] = 0u; }
+            }
+#pragma unroll
+            for (int g = 0; g < MF; ++g) {
                 const _Float16* rrow = rq + (g * nq + 16 * j + m) * VX_BH_RS;
                 const vx_au4 aS = *reinterpret_cast<const vx_au4*>(rrow + poffS), aP = *reinterpret_cast<const vx_au4*>(rrow + poffP);
                 const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[g * nq + 16 * j + 4 * qg]);
@@ -1063,12 +1073,12 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
                 const float bl[4] = {bs[0] - l4.x, bs[1] - l4.y, bs[2] - l4.z, bs[3] - l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
                 vx_f32x4 sv_[2], dp[2];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < MF; ++f) {
                     sv_[f] = VX_MFMA_H(aS, kop[f], ((vx_f32x4){0.f, 0.f, 0.f, 0.f}));
                     dp[f] = VX_MFMA_H(aP, vop[f], ((vx_f32x4){0.f, 0.f, 0.f, 0.f}));
                 }
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < MF; ++f) {
                     float pm[4], ds[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1091,14 +1101,15 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
                 // dQ^T of query tile g: dS transposed through the wave's two patches (one per key tile), one dword = (hi | lo << 16) per element
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int f = 0; f < 2; ++f)
+                for (int f = 0; f < MF; ++f)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const uint32_t h = dsh[f][2 * g + (i >> 1)], l = dsl[f][2 * g + (i >> 1)];
                         tr[f * (16 * TS) + (4 * qg + i) * TS + m] = (i & 1) ? __builtin_amdgcn_perm(l, h, 0x07060302u) : __builtin_amdgcn_perm(l, h, 0x05040100u);
                     }
                 __builtin_amdgcn_wave_barrier();
-                const vx_au4 r0 = *reinterpret_cast<const vx_au4*>(&tr[m * TS + 4 * qg]), r1 = *reinterpret_cast<const vx_au4*>(&tr[16 * TS + m * TS + 4 * qg]);
+                const vx_au4 r0 = *reinterpret_cast<const vx_au4*>(&tr[m * TS + 4 * qg]);
+                const vx_au4 r1 = MF == 2 ? *reinterpret_cast<const vx_au4*>(&tr[16 * TS + m * TS + 4 * qg]) : (vx_au4){0u, 0u, 0u, 0u};
                 __builtin_amdgcn_wave_barrier();
                 const vx_au4 bh = {__builtin_amdgcn_perm(r0[1], r0[0], 0x05040100u), __builtin_amdgcn_perm(r0[3], r0[2], 0x05040100u),
                                    __builtin_amdgcn_perm(r1[1], r1[0], 0x05040100u), __builtin_amdgcn_perm(r1[3], r1[2], 0x05040100u)};
@@ -1121,7 +1132,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
                 const uint2 o0 = *reinterpret_cast<const uint2*>(tcol + 16 * VX_BH_TS), o1 = *reinterpret_cast<const uint2*>(tcol + 16 * VX_BH_TS + nq);
                 const vx_au4 aQ = {q0.x, q0.y, q1.x, q1.y}, aO = {o0.x, o0.y, o1.x, o1.y};
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < MF; ++f) {
                     dv[f] = VX_MFMA_H(aO, ((vx_au4){pmh[f][0], pmh[f][1], pmh[f][2], pmh[f][3]}), dv[f]);
                     dv[f] = VX_MFMA_H(aO, ((vx_au4){pml[f][0], pml[f][1], pml[f][2], pml[f][3]}), dv[f]);
                     dk[f] = VX_MFMA_H(aQ, ((vx_au4){dsh[f][0], dsh[f][1], dsh[f][2], dsh[f][3]}), dk[f]);
@@ -1136,7 +1147,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
         // ---- the chunk's results: dK / dV into the totals (true units); the four dQ images and the bias-gradient windows leave (and are zeroed for the next chunk)
         const float fK = A.scale * ldexpf(1.0f, -(eq + ed + ev)), fV = ldexpf(1.0f, -ed), fQ = A.scale * ldexpf(1.0f, -(ek + ed + ev)), fB = ldexpf(1.0f, -(ed + ev));
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { totk[f][i] = fmaf(dk[f][i], fK, totk[f][i]); totv[f][i] = fmaf(dv[f][i], fV, totv[f][i]); }
         __syncthreads();
@@ -1146,7 +1157,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
             float* dst = dQ + (wrow + (long)f * A.l + t) * C + c;
             const float v = ((dqw[e] + dqw[img + e]) + (dqw[2 * img + e] + dqw[3 * img + e])) * fQ;
             dqw[e] = 0.0f; dqw[img + e] = 0.0f; dqw[2 * img + e] = 0.0f; dqw[3 * img + e] = 0.0f;
-            if (RAG && t >= A.l) continue;                   // (a padding row)
+            if ((RAG && t >= A.l) || f >= MF) continue;      // (a padding row)
             if (atomic_dq) atomicAdd(dst, v); else *dst = v;
         }
         {
@@ -1178,7 +1189,7 @@ __global__ void __launch_bounds__(256, 2) vx_pwa_attn_bwd1h_k(const float* __res
     }
     // ---- dK / dV: rows 0..C-1 (hi piece of the A operand) + rows C..2C-1 (lo piece) = lanes l and l ^ (4 C)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < MF; ++f) {
         const long kr = wrow + (long)f * A.l + kcc;
         float k4[4], v4[4];
 #pragma unroll
@@ -1421,9 +1432,15 @@ static VxB1hRag vx_b1h_rag(const VxAttnM& A, int c) {
     r.LP = LP; r.win = win;
     return r;
 }
+static int g_b1h_m1 = -1;
+extern "C" int vx_pwa_attn_set_f16_bwd_m1(int on) { g_b1h_m1 = on < 0 ? 0 : on; return 0; }
 extern "C" int vx_pwa_attn_bwd1h_ok(const VxPwaPlan* P, int B, int M, int cq, int cv) {
-    if (!vx_am_f16_bwd || !(vx_am_enabled & 2) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M != 2) return 0;
+    if (!vx_am_f16_bwd || !(vx_am_enabled & 2) || (vx_am_enabled & 4) || P == nullptr || B <= 0 || M < 1 || M > 2) return 0;
     if (!((cq == 4 && cv == 4) || (cq == 8 && cv == 8))) return 0;
+    if (M == 1) {        // (round 6) one modality (BraTS): the MF = 1 instance.  VELOXSEG_F16_BWD_M1=0 / vx_pwa_attn_set_f16_bwd_m1(0): the fp32 kernels (A/B)
+        if (g_b1h_m1 < 0) g_b1h_m1 = getenv("VELOXSEG_F16_BWD_M1") ? atoi(getenv("VELOXSEG_F16_BWD_M1")) : 0;
+        if (!g_b1h_m1 || (g_b1h_m1 == 2 && P->l < 512)) return 0;
+    }
     VxAttnM A;
     vx_am_fill(A, P, B, M, cq);
     if (P->l % 64 != 0) return vx_b1h_rag(A, cq).LP > 0 ? 1 : 0;
@@ -1464,22 +1481,21 @@ int vx_pwa_attn_bwd1h(const float* Q, const float* K, const float* V, const floa
     }
     const float inv_keep = drop ? vx_attn_keep_scale(d.p) : 1.0f;          // (the forward's 16-bit threshold: vx_common.h vx_attn_ctx)
     const size_t shm = vx_b1h_shm(rg.LP, A.Tsz, rg.win, cq);
-#define VX_B1H(C_, D_, R_)                                                                                                                        \
+#define VX_B1H(C_, D_, R_, M_)                                                                                                                    \
     {                                                                                                                                             \
         static bool once = false;                                                                                                                 \
         if (!once) {                                                                                                                              \
-            if (hipFuncSetAttribute((const void*)vx_pwa_attn_bwd1h_k<C_, C_, D_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            if (hipFuncSetAttribute((const void*)vx_pwa_attn_bwd1h_k<C_, C_, D_, R_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) (void)hipGetLastError(); \
             once = true;                                                                                                                          \
         }                                                                                                                                         \
-        vx_pwa_attn_bwd1h_k<C_, C_, D_, R_><<<grid, dim3(256), shm, st>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, A, inv_keep, atomic_dq, QS, nchunk / QS, mbits, rg.LP, rg.win); \
+        vx_pwa_attn_bwd1h_k<C_, C_, D_, R_, M_><<<grid, dim3(256), shm, st>>>(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, A, inv_keep, atomic_dq, QS, nchunk / QS, mbits, rg.LP, rg.win); \
     }
-    if (rag) {
-        if (cq == 8) { if (drop) VX_B1H(8, true, true) else VX_B1H(8, false, true) }
-        else { if (drop) VX_B1H(4, true, true) else VX_B1H(4, false, true) }
-    } else {
-        if (cq == 8) { if (drop) VX_B1H(8, true, false) else VX_B1H(8, false, false) }
-        else { if (drop) VX_B1H(4, true, false) else VX_B1H(4, false, false) }
-    }
+#define VX_B1H_D(C_, R_, M_) { if (drop) VX_B1H(C_, true, R_, M_) else VX_B1H(C_, false, R_, M_) }
+#define VX_B1H_C(R_, M_) { if (cq == 8) VX_B1H_D(8, R_, M_) else VX_B1H_D(4, R_, M_) }
+    if (M == 1) { if (rag) VX_B1H_C(true, 1) else VX_B1H_C(false, 1) }
+    else { if (rag) VX_B1H_C(true, 2) else VX_B1H_C(false, 2) }
+#undef VX_B1H_C
+#undef VX_B1H_D
 #undef VX_B1H
     return 0;
 }
