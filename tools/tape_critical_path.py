@@ -13,6 +13,9 @@ from veloxseg_amd.utils.loss import Loss
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "autopet128"
 cfg, B = WORKLOADS[wl]
+if os.environ.get("VX_ALL_DROP"):      # what-if: every dropout probability (proj / conv / attn) -> the cost of ALL Philox work of the step
+    pd = float(os.environ["VX_ALL_DROP"])
+    cfg = dict(cfg, attn_drop=pd, proj_drop=pd, conv_drop=pd)
 if os.environ.get("VX_ATTN_DROP"):
     cfg = dict(cfg, attn_drop=float(os.environ["VX_ATTN_DROP"]))      # what-if: cost of the attention dropout (Philox) in the attention kernels
 torch.manual_seed(12345)
