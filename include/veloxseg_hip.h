@@ -371,6 +371,9 @@ int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPlan* plan, in
 /* all M <= 4 modalities in one launch per kernel kind (host arrays of M device pointers) */
 int vx_pwa_scatter_fwd_all(const float* tok, float* const* outs, const VxPwaPlan* plan, int c, int M, int B, void* stream);
 int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream);
+/* (round 6) the same into a destination the caller did NOT zero: the sole-owner kernels assign and the identity-scale kernel zeroes the window ranges of the
+ * scales that add with atomics.  Returns 1 and launches nothing where that does not apply (scale 0 not an identity scale): zero dtok and call vx_pwa_scatter_bwd_all. */
+int vx_pwa_scatter_bwd_all_w(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream);
 int vx_pwa_attn_set_fused_bwd(int on); /* A/B knob: 1 (default) = the dQ and dK/dV passes of vx_pwa_attn_bwd share one launch (interleaved blocks), 0 = two launches */
 int vx_pwa_scatter_set_ident(int on);   /* A/B knob: 1 (default) = 1x1x1 small windows take the transpose kernel, 0 = always the general adjoint */
 /* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).

@@ -822,6 +822,32 @@ def test_scatter_adjoint_transpose_kernel_equals_general_adjoint(grid, big, head
     close(res[0], res[1], 2e-6 * max(1.0, float(res[1].abs().max())), 1e-5, "scatter adjoint")       # the general adjoint sums with float atomics
 
 
+@pytest.mark.parametrize("grid,big,heads,c,M", [([16, 16, 16], [8, 8, 8], 2, 8, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 2), ([8, 8, 8], [4, 4, 4], 4, 32, 1), ([4, 4, 4], [4, 4, 4], 2, 16, 2),
+                                                ([24, 24, 24], [3, 3, 3], 1, 4, 2), ([16, 16, 8], [4, 4, 2], 2, 8, 3)],
+                         ids=["two_scales", "three_scales_incl_separable", "one_modality", "single_scale", "96_L1", "aniso_three_modalities"])
+def test_scatter_adjoint_into_an_unzeroed_destination(grid, big, heads, c, M):
+    """vx_pwa_scatter_bwd_all_w (no fill launch in front: the sole-owner kernels assign, the identity-scale kernel zeroes the window ranges of the scales that add with
+    atomics) into a buffer full of NaNs == vx_pwa_scatter_bwd_all into a zeroed buffer: bit-identical where only sole-owner scales exist, float-atomic order otherwise"""
+    import ctypes
+    from veloxseg_amd import _hip as H
+    d = dev()
+    pl = O.plan_pwa(grid, big, [1, 1, 1], 2, heads, c, heads * c * 2)
+    plan = H.make_plan(grid, pl["n"], heads, pl["small"], pl["nwin"])
+    B = 2
+    pp = H.ctypes.addressof(plan)
+    dout = [rnd(B, plan.nb * heads * c, *grid, seed=60 + m).to(d) for m in range(M)]
+    ptrs = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in dout] + [None] * (4 - M)))
+    ref = torch.zeros(B, heads, plan.Ntot, M * plan.l, c, device=d)
+    H.call("vx_pwa_scatter_bwd_all", ctypes.addressof(ptrs), H.P(ref), pp, c, M, B, H.stream_ptr())
+    got = torch.full_like(ref, float("nan"))
+    assert H.query("vx_pwa_scatter_bwd_all_w", ctypes.addressof(ptrs), H.P(got), pp, c, M, B, H.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    close(got, ref, 2e-6 * max(1.0, float(ref.abs().max())), 1e-5, "scatter adjoint, unzeroed destination")
+    if plan.nb <= 2:
+        assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("B,Cin,sp", [(2, 2, (64, 64, 64)), (1, 1, (32, 64, 128)), (2, 4, (16, 32, 64)), (4, 2, (128, 128, 128)), (2, 2, (32, 48, 96)), (1, 2, (96, 96, 96))],
                          ids=["m2_64", "m1_aniso", "m4", "bench_shape", "w96_rows_of_24", "shipped_96"])
 def test_stem_weight_gradient_mfma_equals_tiled_kernel(B, Cin, sp):

@@ -820,16 +820,24 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         variable_list out(7 + 3 * M);
         if (!ref.defined()) { ctx->saved_data.clear(); return out; }
         void* s_ = cur_stream(ref);
-        Tensor dO = at::zeros_like(st.O);
+        Tensor dO;
         {
             std::vector<Tensor> gm(M);
             const float* gptr[4] = {nullptr, nullptr, nullptr, nullptr};
             bool all = true;
             for (int m = 0; m < M; ++m) { all = all && g[m].defined(); if (g[m].defined()) { gm[m] = contig(g[m]); gptr[m] = gm[m].data_ptr<float>(); } }
-            if (all) VX(vx_pwa_scatter_bwd_all, gptr, mp(dO), pp, st.cv, M, B, s_);       // every modality in one launch per scale
-            else
+            if (all) {                                   // every modality in one launch per scale
+                // (round 6) no fill launch in front: the adjoint kernels write every element themselves (vx_pwa_scatter_bwd_all_w; 1 = not for this plan)
+                dO = at::empty_like(st.O);
+                if (VXR(vx_pwa_scatter_bwd_all_w, gptr, mp(dO), pp, st.cv, M, B, s_) == 1) {
+                    dO.zero_();
+                    VX(vx_pwa_scatter_bwd_all, gptr, mp(dO), pp, st.cv, M, B, s_);
+                }
+            } else {
+                dO = at::zeros_like(st.O);
                 for (int m = 0; m < M; ++m)
                     if (gptr[m]) VX(vx_pwa_scatter_bwd, gptr[m], mp(dO), pp, st.cv, m, M, B, s_);
+            }
         }
         Tensor dq = at::empty_like(st.tq), dk = at::empty_like(st.tk), dv = at::empty_like(st.tv);
         const int nws = vx_pwa_attn_bwd_ws_floats(pp, B, M);

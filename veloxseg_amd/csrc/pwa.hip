@@ -315,6 +315,8 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
 // ---------------------------------------------------------------------------------------------
 // all M modalities of one direction in ONE launch: grid.x = (blocks of one modality) * M; block (mm, bx) works on modality m0 + mm with its own tensor
 struct VxScPtrs { const float* in[4]; float* out[4]; };
+// (round 6) the window ranges of the scales whose adjoint kernels ADD with atomics: the identity-scale kernel, which runs first on the stream, zeroes them (no separate fill launch)
+struct VxScZero { int n; int w0[4], wn[4]; int assign; };
 
 __device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int& i1, float& lam) {
     if (bw == n) { i0 = j; i1 = j; lam = 0.0f; return; }
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_k(VxScPtrs ptrs, float
 // small window 1x1x1 (every shipped config: min_small_window_sizes = [[1,1,1]] * 4): the per-window resampling is the identity, so the adjoint
 // is a transpose of the window's (c, voxels) slab into its (tokens, c) rows -- staged through LDS (pitch c + 1), coalesced on both sides, no atomics.
 // One block = one (b, head, window); every element of the destination rows is written exactly once, which equals "+=" on the zeroed buffer.
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int nx) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int nx, VxScZero z) {
     int bx;
     const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
@@ -462,6 +464,15 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs,
     }
     __syncthreads();
     float* __restrict__ dt = dtok + ((((long)b * P.heads + a) * P.Ntot + N) * ((long)M * l) + (long)m * l) * c;
+    if (z.assign) {                                      // (round 6) the destination is NOT zeroed by the caller: this kernel writes its rows and zeroes the rows of the atomic scales
+        for (int k = threadIdx.x; k < l * c; k += 256) { int kc; const int kt = vx_fdivmod(k, fc, kc); dt[k] = vx_sacc[kt * pitch + kc]; }
+        for (int r = 0; r < z.n; ++r) {
+            float* __restrict__ zb = dtok + (((long)b * P.heads + a) * P.Ntot + z.w0[r]) * ((long)M * l) * c;
+            const long len = (long)z.wn[r] * M * l * c;
+            for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < len; k += (long)gridDim.x * 256) zb[k] = 0.0f;
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < l * c; k += 256) { int kc; const int kt = vx_fdivmod(k, fc, kc); dt[k] += vx_sacc[kt * pitch + kc]; }       // sole owner of these rows: "+=" without atomics
 }
 
@@ -470,7 +481,7 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs,
 // staged in LDS; PT = 256 / l threads share a token (they split the outermost tap axis) and are summed with shuffles.  Replaces 8 scattered
 // ds_add_f32 per voxel of the atomic kernel below (45 us per launch at the second scale) by 8 LDS reads per voxel.
 #define VX_SC_TAPS 12
-__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int PT, int nx) {
+__global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs, float* __restrict__ dtok, VxPwaPlan P, int c, int m0, int M, int scale, int PT, int nx, int assign) {
     int bx;
     const int mm = vx_fdivmod(blockIdx.x, vx_fd(nx), bx);
     const int m = m0 + mm;
@@ -535,7 +546,7 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_gather_k(VxScPtrs ptrs
                 acc = fmaf(w01, r, acc);
             }
         for (int o = 1; o < PT; o <<= 1) acc += __shfl_xor(acc, o, 64);
-        if (sub == 0) dt[(long)t * c] += acc;               // sole owner of this element: "+=" without atomics
+        if (sub == 0) { if (assign) dt[(long)t * c] = acc; else dt[(long)t * c] += acc; }               // sole owner of this element: "+=" without atomics (assign: the destination was not zeroed)
     }
 }
 
@@ -1251,7 +1262,29 @@ extern "C" int vx_pwa_scatter_fwd_all(const float* tok, float* const* outs, cons
 static int vx_scatter_ident_enabled = 1;
 static const int vx_scatter_gather_max = 2;      // cells up to 2^3: the per-token gather; wider cells: the separable kernel (4^3 cells measured 36 -> 17 us per launch)
 extern "C" int vx_pwa_scatter_set_ident(int on) { vx_scatter_ident_enabled = on ? 1 : 0; return 0; }      // A/B knob: 0 = always the general (LDS-atomic) adjoint
-static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream) {
+// which adjoint kernel takes scale i: 0 identity (sole owner), 1 per-token gather (sole owner), 2 separable (atomics), 3 general (atomics)
+static int vx_scatter_bwd_kind(const VxPwaPlan* plan, int c, int B, int i) {
+    if (plan->small[i][0] == 1 && plan->small[i][1] == 1 && plan->small[i][2] == 1 && vx_scatter_ident_enabled) return 0;
+    const long nv = (long)plan->n[0] * plan->small[i][0] * plan->n[1] * plan->small[i][1] * plan->n[2] * plan->small[i][2];
+    const int smax = plan->small[i][0] > plan->small[i][1] ? (plan->small[i][0] > plan->small[i][2] ? plan->small[i][0] : plan->small[i][2])
+                                                            : (plan->small[i][1] > plan->small[i][2] ? plan->small[i][1] : plan->small[i][2]);
+    const int nmax = plan->n[0] > plan->n[1] ? (plan->n[0] > plan->n[2] ? plan->n[0] : plan->n[2]) : (plan->n[1] > plan->n[2] ? plan->n[1] : plan->n[2]);
+    const size_t shm2 = sizeof(float) * (((size_t)nv + 3) / 4 * 4 + (size_t)3 * nmax * VX_SC_TAPS * 2 + 3 * nmax);
+    if (smax <= vx_scatter_gather_max && shm2 <= 64 * 1024 && c <= 65535 && vx_scatter_ident_enabled) return 1;
+    const int bw0 = plan->n[0] * plan->small[i][0], bw1 = plan->n[1] * plan->small[i][1], bw2 = plan->n[2] * plan->small[i][2];
+    (void)bw0;
+    const size_t shm3 = sizeof(float) * ((size_t)bw1 * bw2 + (size_t)bw1 * plan->n[2] + (size_t)plane_l(plan) + (size_t)plan->n[2] * bw2 + (size_t)plan->n[1] * bw1);
+    if (vx_scatter_ident_enabled && shm3 <= 60 * 1024 && (long)B * plan->heads * c <= 65535) return 2;
+    return 3;
+}
+// writes_all: the caller did NOT zero dtok (needs every modality in this call and scale 0 on the identity kernel -- checked by the entry)
+static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream, bool writes_all = false) {
+    VxScZero z = {};
+    if (writes_all) {
+        z.assign = 1;
+        for (int i = 1; i < plan->nb; ++i)
+            if (vx_scatter_bwd_kind(plan, c, B, i) >= 2) { z.w0[z.n] = plan->woff[i]; z.wn[z.n] = plan->nwin[i][0] * plan->nwin[i][1] * plan->nwin[i][2]; ++z.n; }
+    }
     const size_t shm = sizeof(float) * (size_t)plane_l(plan) * c;
     VX_REQUIRE(shm <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
     for (int i = 0; i < plan->nb; ++i) {
@@ -1262,7 +1295,7 @@ static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaP
         if (plan->small[i][0] == 1 && plan->small[i][1] == 1 && plan->small[i][2] == 1 && vx_scatter_ident_enabled) {
             const size_t shm1 = sizeof(float) * (size_t)plane_l(plan) * (c + 1);
             VX_REQUIRE(shm1 <= 128 * 1024, "vx_pwa_scatter_bwd: window (%d tokens x %d) does not fit LDS", plan->l, c);
-            hipLaunchKernelGGL(vx_pwa_scatter_bwd_ident_k, dim3(nwin * mcount, B * plan->heads), dim3(256), shm1, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, nwin);
+            hipLaunchKernelGGL(vx_pwa_scatter_bwd_ident_k, dim3(nwin * mcount, B * plan->heads), dim3(256), shm1, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, nwin, z);
             continue;
         }
         {
@@ -1273,7 +1306,7 @@ static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaP
             if (smax <= vx_scatter_gather_max && shm2 <= 64 * 1024 && c <= 65535 && vx_scatter_ident_enabled) {      // <= 4x4x4: at most 5 + 4 taps per token and axis (VX_SC_TAPS = 12)
                 int PT = 256 / plan->l;                       // threads per token: power of two in 1..4
                 PT = PT >= 4 ? 4 : (PT >= 2 ? 2 : 1);
-                hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin * mcount, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, PT, nwin);
+                hipLaunchKernelGGL(vx_pwa_scatter_bwd_gather_k, dim3(nwin * mcount, B * plan->heads, c), dim3(256), shm2, (hipStream_t)stream, ptrs, dtok, *plan, c, m0, M, i, PT, nwin, z.assign);
                 continue;
             }
         }
@@ -1300,6 +1333,19 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
     VxScPtrs ptrs = {};
     ptrs.in[0] = dout;
     return vx_scatter_bwd_launch(ptrs, dtok, plan, c, m, 1, M, B, stream);
+}
+// the same WITHOUT a zeroed destination (round 6: the fill launch in front of every PWA backward was 6 us on the encoder backward's chain): the sole-owner kernels assign,
+// the identity-scale kernel -- first on the stream -- zeroes the window ranges of the scales that add with atomics.  Returns 1 (nothing launched) where that does not
+// apply (scale 0 not on the identity kernel, more than 4 atomic scales): the caller zeroes dtok and calls vx_pwa_scatter_bwd_all.
+extern "C" int vx_pwa_scatter_bwd_all_w(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
+    if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd_all_w")) return e;
+    VX_REQUIRE(douts && dtok && c > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_scatter_bwd_all_w: bad args");
+    static const int off = getenv("VELOXSEG_SCATTER_BWD_W") && getenv("VELOXSEG_SCATTER_BWD_W")[0] == '0';      // (A/B)
+    if (off || plan->nb > 4 || vx_scatter_bwd_kind(plan, c, B, 0) != 0) return 1;
+    for (int i = 1; i < plan->nb; ++i) if (vx_scatter_bwd_kind(plan, c, B, i) == 0) return 1;      // (a second identity scale would zero nothing but is not expected: keep the old path)
+    VxScPtrs ptrs = {};
+    for (int m = 0; m < M; ++m) { VX_REQUIRE(douts[m], "vx_pwa_scatter_bwd_all_w: null gradient %d", m); ptrs.in[m] = douts[m]; }
+    return vx_scatter_bwd_launch(ptrs, dtok, plan, c, 0, M, M, B, stream, true);
 }
 // every modality in one launch per scale (douts[m] may not be NULL; dtok zeroed by the caller)
 extern "C" int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
