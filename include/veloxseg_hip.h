@@ -374,6 +374,8 @@ int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPl
 /* (round 6) the same into a destination the caller did NOT zero: the sole-owner kernels assign and the identity-scale kernel zeroes the window ranges of the
  * scales that add with atomics.  Returns 1 and launches nothing where that does not apply (scale 0 not an identity scale): zero dtok and call vx_pwa_scatter_bwd_all. */
 int vx_pwa_scatter_bwd_all_w(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream);
+/* ... and one more buffer zeroed by the same launch (16-byte aligned, extra_floats % 4 == 0; NULL: none): the bias-gradient replicas of the attention backward that follows */
+int vx_pwa_scatter_bwd_all_wz(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, float* extra_zero, long extra_floats, void* stream);
 int vx_pwa_attn_set_fused_bwd(int on); /* A/B knob: 1 (default) = the dQ and dK/dV passes of vx_pwa_attn_bwd share one launch (interleaved blocks), 0 = two launches */
 int vx_pwa_scatter_set_ident(int on);   /* A/B knob: 1 (default) = 1x1x1 small windows take the transpose kernel, 0 = always the general adjoint */
 /* MultiModal attention_operation (PWA.py:308-327) + relative bias (attention_utils.py:120-125); table = (Tsz, heads).
@@ -383,6 +385,10 @@ int vx_pwa_attn_fwd(const float* Q, const float* K, const float* V, const float*
                     const VxPwaPlan* plan, int B, int M, int cq, int cv,
                     const void* seed_ptr, unsigned long long dstream, float p_drop, void* stream);
 int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M);   /* answer, not a status; negative = error */
+/* (round 6) float offset of the bias-gradient replicas inside delta_ws (they run to its end; answer, not a status), and a one-shot note that the caller has zeroed them:
+ * the next attention backward of this host thread on that workspace skips its zeroing launch */
+int vx_pwa_attn_bwd_rep_offset(const VxPwaPlan* plan, int B, int M);
+int vx_pwa_attn_bwd_mark_rep_zeroed(const float* delta_ws);
 int vx_pwa_gather_set_vec(int on);   /* A/B knob for tests: 0 = the one-lane-per-(cell, channel) gather kernels instead of the channel-vectorised ones */
 int vx_pwa_attn_bwd(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                     const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,

@@ -841,7 +841,14 @@ def test_scatter_adjoint_into_an_unzeroed_destination(grid, big, heads, c, M):
     H.call("vx_pwa_scatter_bwd_all", ctypes.addressof(ptrs), H.P(ref), pp, c, M, B, H.stream_ptr())
     got = torch.full_like(ref, float("nan"))
     assert H.query("vx_pwa_scatter_bwd_all_w", ctypes.addressof(ptrs), H.P(got), pp, c, M, B, H.stream_ptr()) == 0
+    # ... and with one more buffer to zero (the attention backward's bias-gradient replicas ride on the same launch)
+    got2, extra = torch.full_like(ref, float("nan")), torch.full((4 * 1237,), float("nan"), device=d)
+    assert H.query("vx_pwa_scatter_bwd_all_wz", ctypes.addressof(ptrs), H.P(got2), pp, c, M, B, H.P(extra), extra.numel(), H.stream_ptr()) == 0
     torch.cuda.synchronize()
+    assert float(extra.abs().max()) == 0.0
+    close(got2, got, 2e-6 * max(1.0, float(ref.abs().max())), 1e-5, "with / without the extra buffer")
+    if plan.nb <= 2:
+        assert torch.equal(got2, got)
     assert torch.isfinite(got).all()
     close(got, ref, 2e-6 * max(1.0, float(ref.abs().max())), 1e-5, "scatter adjoint, unzeroed destination")
     if plan.nb <= 2:

@@ -161,5 +161,5 @@ if "dec_wg" in G:
 m_step = measure(lambda: eng.step(x, lab))
 print(f"step: measured {m_step:.0f} us (input copies + tapes + AdamW)")
 print("kernels on the critical paths (time on path / time in the whole step):")
-for nm, u in on_path.most_common(40):
+for nm, u in on_path.most_common(int(os.environ.get("VX_CP_TOP", "40"))):
     print(f"  {u:7.1f} us {cnt_path[nm]:3d}x / {everything[nm]:7.1f} us  {nm}")

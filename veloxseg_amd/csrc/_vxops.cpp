@@ -820,16 +820,21 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         variable_list out(7 + 3 * M);
         if (!ref.defined()) { ctx->saved_data.clear(); return out; }
         void* s_ = cur_stream(ref);
-        Tensor dO;
+        Tensor dO, delta_pre;                            // delta_pre: the attention backward's workspace when its replicas were zeroed by the scatter adjoint
         {
             std::vector<Tensor> gm(M);
             const float* gptr[4] = {nullptr, nullptr, nullptr, nullptr};
             bool all = true;
             for (int m = 0; m < M; ++m) { all = all && g[m].defined(); if (g[m].defined()) { gm[m] = contig(g[m]); gptr[m] = gm[m].data_ptr<float>(); } }
             if (all) {                                   // every modality in one launch per scale
-                // (round 6) no fill launch in front: the adjoint kernels write every element themselves (vx_pwa_scatter_bwd_all_w; 1 = not for this plan)
+                // (round 6) no fill launch in front: the adjoint kernels write every element themselves (vx_pwa_scatter_bwd_all_wz; 1 = not for this plan), and the same
+                // launch zeroes the bias-gradient replicas of the attention backward below (one more 6 us launch off the chain)
                 dO = at::empty_like(st.O);
-                if (VXR(vx_pwa_scatter_bwd_all_w, gptr, mp(dO), pp, st.cv, M, B, s_) == 1) {
+                const int nws0 = vx_pwa_attn_bwd_ws_floats(pp, B, M), roff = vx_pwa_attn_bwd_rep_offset(pp, B, M);
+                TORCH_CHECK(nws0 >= 0 && roff >= 0, "vx_pwa_attn_bwd_ws_floats failed");
+                delta_pre = at::empty({(long)nws0}, st.tq.options());
+                if (VXR(vx_pwa_scatter_bwd_all_wz, gptr, mp(dO), pp, st.cv, M, B, delta_pre.data_ptr<float>() + roff, (long)(nws0 - roff), s_) == 1) {
+                    delta_pre = Tensor();
                     dO.zero_();
                     VX(vx_pwa_scatter_bwd_all, gptr, mp(dO), pp, st.cv, M, B, s_);
                 }
@@ -842,7 +847,8 @@ struct PwaCoreFn : public torch::autograd::Function<PwaCoreFn> {
         Tensor dq = at::empty_like(st.tq), dk = at::empty_like(st.tk), dv = at::empty_like(st.tv);
         const int nws = vx_pwa_attn_bwd_ws_floats(pp, B, M);
         TORCH_CHECK(nws >= 0, "vx_pwa_attn_bwd_ws_floats failed");
-        Tensor delta = at::empty({(long)nws}, st.tq.options());
+        Tensor delta = delta_pre.defined() ? delta_pre : at::empty({(long)nws}, st.tq.options());
+        if (delta_pre.defined()) vx_pwa_attn_bwd_mark_rep_zeroed(delta.data_ptr<float>());
         Tensor dtab_tmp;
         float* dtab = grad_ptr(st.table);
         if (!dtab) { dtab_tmp = at::zeros_like(st.tbl); dtab = dtab_tmp.data_ptr<float>(); }

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) vx_pwa_gather_all_bwd_v_k(VxGatherPtrs pt
 // all M modalities of one direction in ONE launch: grid.x = (blocks of one modality) * M; block (mm, bx) works on modality m0 + mm with its own tensor
 struct VxScPtrs { const float* in[4]; float* out[4]; };
 // (round 6) the window ranges of the scales whose adjoint kernels ADD with atomics: the identity-scale kernel, which runs first on the stream, zeroes them (no separate fill launch)
-struct VxScZero { int n; int w0[4], wn[4]; int assign; };
+struct VxScZero { int n; int w0[4], wn[4]; int assign; float* extra; long extra_n4; };      // extra: one more buffer the identity-scale kernel zeroes (float4 units; the attention backward's bias-gradient replicas)
 
 __device__ __forceinline__ void vx_src_coord(int j, int n, int bw, int& i0, int& i1, float& lam) {
     if (bw == n) { i0 = j; i1 = j; lam = 0.0f; return; }
@@ -470,6 +470,11 @@ __global__ void __launch_bounds__(256) vx_pwa_scatter_bwd_ident_k(VxScPtrs ptrs,
             float* __restrict__ zb = dtok + (((long)b * P.heads + a) * P.Ntot + z.w0[r]) * ((long)M * l) * c;
             const long len = (long)z.wn[r] * M * l * c;
             for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < len; k += (long)gridDim.x * 256) zb[k] = 0.0f;
+        }
+        if (z.extra != nullptr) {
+            float4* __restrict__ e4 = reinterpret_cast<float4*>(z.extra);
+            const long nb = (long)gridDim.x * gridDim.y, bid = blockIdx.x + (long)gridDim.x * blockIdx.y;
+            for (long k = bid * 256 + threadIdx.x; k < z.extra_n4; k += nb * 256) e4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
@@ -1278,10 +1283,12 @@ static int vx_scatter_bwd_kind(const VxPwaPlan* plan, int c, int B, int i) {
     return 3;
 }
 // writes_all: the caller did NOT zero dtok (needs every modality in this call and scale 0 on the identity kernel -- checked by the entry)
-static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream, bool writes_all = false) {
+static int vx_scatter_bwd_launch(const VxScPtrs& ptrs, float* dtok, const VxPwaPlan* plan, int c, int m0, int mcount, int M, int B, void* stream, bool writes_all = false,
+                                 float* extra_zero = nullptr, long extra_floats = 0) {
     VxScZero z = {};
     if (writes_all) {
         z.assign = 1;
+        z.extra = extra_zero; z.extra_n4 = extra_zero ? extra_floats / 4 : 0;
         for (int i = 1; i < plan->nb; ++i)
             if (vx_scatter_bwd_kind(plan, c, B, i) >= 2) { z.w0[z.n] = plan->woff[i]; z.wn[z.n] = plan->nwin[i][0] * plan->nwin[i][1] * plan->nwin[i][2]; ++z.n; }
     }
@@ -1337,15 +1344,22 @@ extern "C" int vx_pwa_scatter_bwd(const float* dout, float* dtok, const VxPwaPla
 // the same WITHOUT a zeroed destination (round 6: the fill launch in front of every PWA backward was 6 us on the encoder backward's chain): the sole-owner kernels assign,
 // the identity-scale kernel -- first on the stream -- zeroes the window ranges of the scales that add with atomics.  Returns 1 (nothing launched) where that does not
 // apply (scale 0 not on the identity kernel, more than 4 atomic scales): the caller zeroes dtok and calls vx_pwa_scatter_bwd_all.
+extern "C" int vx_pwa_scatter_bwd_all_wz(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, float* extra_zero, long extra_floats, void* stream);
 extern "C" int vx_pwa_scatter_bwd_all_w(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
+    return vx_pwa_scatter_bwd_all_wz(douts, dtok, plan, c, M, B, nullptr, 0, stream);
+}
+// ... and one more buffer zeroed by the same launch (extra_floats % 4 == 0, 16-byte aligned): the bias-gradient replicas of the attention backward that follows
+// (vx_pwa_attn_bwd_rep_offset; vx_pwa_attn_bwd_mark_rep_zeroed tells that call to skip its own zeroing launch)
+extern "C" int vx_pwa_scatter_bwd_all_wz(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, float* extra_zero, long extra_floats, void* stream) {
     if (int e = vx_plan_check(plan, "vx_pwa_scatter_bwd_all_w")) return e;
     VX_REQUIRE(douts && dtok && c > 0 && M >= 1 && M <= 4 && B > 0, "vx_pwa_scatter_bwd_all_w: bad args");
+    VX_REQUIRE(extra_zero == nullptr || (extra_floats > 0 && extra_floats % 4 == 0 && ((uintptr_t)extra_zero & 15) == 0), "vx_pwa_scatter_bwd_all_wz: the extra buffer must be 16-byte aligned, a multiple of 4 floats");
     static const int off = getenv("VELOXSEG_SCATTER_BWD_W") && getenv("VELOXSEG_SCATTER_BWD_W")[0] == '0';      // (A/B)
     if (off || plan->nb > 4 || vx_scatter_bwd_kind(plan, c, B, 0) != 0) return 1;
     for (int i = 1; i < plan->nb; ++i) if (vx_scatter_bwd_kind(plan, c, B, i) == 0) return 1;      // (a second identity scale would zero nothing but is not expected: keep the old path)
     VxScPtrs ptrs = {};
     for (int m = 0; m < M; ++m) { VX_REQUIRE(douts[m], "vx_pwa_scatter_bwd_all_w: null gradient %d", m); ptrs.in[m] = douts[m]; }
-    return vx_scatter_bwd_launch(ptrs, dtok, plan, c, 0, M, M, B, stream, true);
+    return vx_scatter_bwd_launch(ptrs, dtok, plan, c, 0, M, M, B, stream, true, extra_zero, extra_floats);
 }
 // every modality in one launch per scale (douts[m] may not be NULL; dtok zeroed by the caller)
 extern "C" int vx_pwa_scatter_bwd_all(const float* const* douts, float* dtok, const VxPwaPlan* plan, int c, int M, int B, void* stream) {
@@ -1481,6 +1495,17 @@ extern "C" int vx_pwa_attn_bwd_ws_floats(const VxPwaPlan* plan, int B, int M) {
     return (int)n;
 }
 
+// (round 6) where the bias-gradient replicas start inside delta_ws (floats; they run to the end of the workspace), and a one-shot note from the caller that it has
+// zeroed them already (the scatter adjoint in front did: vx_pwa_scatter_bwd_all_wz): the NEXT attention backward of this host thread on that workspace launches no vx_zero4_k
+extern "C" int vx_pwa_attn_bwd_rep_offset(const VxPwaPlan* plan, int B, int M) {
+    VxAttn A;
+    if (int e = vx_attn_fill(A, plan, B, M, 4, 4, "vx_pwa_attn_bwd_rep_offset")) return e;
+    const long rows = (long)A.BH * A.Nt * A.ML;
+    VX_REQUIRE(((rows + 3) & ~3L) < 0x7fffffffL, "vx_pwa_attn_bwd_rep_offset: workspace too large");
+    return (int)((rows + 3) & ~3L);
+}
+static thread_local const float* t_rep_zeroed = nullptr;
+extern "C" int vx_pwa_attn_bwd_mark_rep_zeroed(const float* delta_ws) { t_rep_zeroed = delta_ws; return 0; }
 static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, const float* table, const float* O, const float* LSE,
                                const float* dO, float* dQ, float* dK, float* dV, float* dtable, float* delta_ws,
                                const VxPwaPlan* plan, int B, int M, int cq, int cv,
@@ -1582,7 +1607,9 @@ static int vx_pwa_attn_bwd_run(const float* Q, const float* K, const float* V, c
     float* rep = delta_ws + ((rows + 3) & ~3L);
     const long rep_floats = (long)VX_DTABLE_REPLICAS * Tsz * A.heads;
     const unsigned nblk = (unsigned)vx_cdiv(units, 4 / S);
-    vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
+    const bool prezeroed = t_rep_zeroed == delta_ws;
+    t_rep_zeroed = nullptr;
+    if (!prezeroed) vx_zero4_k<<<dim3((unsigned)vx_cdiv(rep_floats / 4, 256)), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(rep), rep_floats / 4);   // VX_DTABLE_REPLICAS % 4 == 0
     if (vx_pwa_attn_bwd1h_ok(plan, B, M, cq, cv) && (!(p_drop > 0 && seed_ptr) || mbits != nullptr)) {      // one pass, two fp16 pieces per operand on the 16x16x32 pipe (csrc/pwa_mfma.hip)
         const int rc = vx_pwa_attn_bwd1h(Q, K, V, table, O, LSE, dO, dQ, dK, dV, rep, mbits, plan, B, M, cq, cv, d, stream);
         if (rc) VX_FAIL(rc, "vx_pwa_attn_bwd: f16-pipe one-pass kernel could not be launched");
