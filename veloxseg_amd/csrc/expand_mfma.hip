@@ -1518,7 +1518,8 @@ __global__ void __launch_bounds__(256) vx_expand_wgrad_fold_k(const float* __res
 static void vx_wgs_plan(int B, int Cc, int D, int H, int W, int& HL, int& nHs, int& nWc) {
     nWc = (W + 31) / 32;
     const long base = (long)B * D * nWc * Cc * 3;
-    int want = (int)((768 + base - 1) / base);               // strips per (b, d, chunk, c, plane): three blocks per CU
+    static const long target = getenv("VELOXSEG_EXPAND_WG_BLOCKS") ? atol(getenv("VELOXSEG_EXPAND_WG_BLOCKS")) : 384;      // (round 6 A/B, same box: 768 -> 384 blocks for the one-channel decoders -- half the partial-sum rows -- autopet128 1051.6 -> 1056.4, autopet96 +0.4 %, hecktor -0.2 %; this kernel is a sink beside the encoder backward)
+    int want = (int)((target + base - 1) / base);            // strips per (b, d, chunk, c, plane)
     if (want < 1) want = 1;
     HL = (H + want - 1) / want;
     if (HL < 8) HL = H < 8 ? H : 8;
