@@ -559,6 +559,11 @@ int vx_conv_mfma_bwd_data(const float* dy, const float* w, float* dx, float* ws,
 int vx_expand_split_ws_floats(int Cc, int ns);
 int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream);
 int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns, void* stream);
+/* (round 6) with the weight tensor's scale word handed over from the forward of the same layer (ns = 22: it sits vx_expand_split_ew_offset(Cc) floats into the forward's
+ * workspace, 2 floats; NULL = find it here): no memset / max launch in front of the backward's weight image */
+int vx_expand_split_ew_offset(int Cc);
+int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
+                                     const float* ew_fwd, void* stream);
 
 /* ---- fused per-voxel chains of a PWA transformer block, every modality of the block in one launch (csrc/pwa_fused.hip) ------------------------------
  * "pre": xn = LN_channels(x) (attention_utils.py:29-43, eps as given) followed by NS <= 3 1x1 projections out_s = W_s xn + b_s (PWA.py:291-298: q, k, v).

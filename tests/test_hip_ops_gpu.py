@@ -822,6 +822,29 @@ def test_scatter_adjoint_transpose_kernel_equals_general_adjoint(grid, big, head
     close(res[0], res[1], 2e-6 * max(1.0, float(res[1].abs().max())), 1e-5, "scatter adjoint")       # the general adjoint sums with float atomics
 
 
+@pytest.mark.parametrize("B,Cc,sp", [(2, 1, (8, 8, 16)), (1, 2, (4, 8, 8))], ids=["one_channel", "two_channels"])
+def test_patch_expand_backward_takes_the_weight_scale_from_its_forward(B, Cc, sp):
+    """fp16-piece mode (ns = 22): the input gradient with the forward's scale word (vx_expand_bwd_data_mfma_split_ew) == the one that finds max |w| itself, bit for bit"""
+    from veloxseg_amd import _hip as H
+    d = dev()
+    D, Hh, W = sp
+    Cout = 64 * Cc
+    x, w, bias = rnd(B, 16, *sp, seed=1).to(d), (rnd(Cout, 16, 3, 3, 3, seed=2) * 0.3).to(d), rnd(Cout, seed=3).to(d)
+    dy = rnd(B, Cc, 4 * D, 4 * Hh, 4 * W, seed=4).to(d)
+    st = H.stream_ptr()
+    nws = max(H.query("vx_expand_split_ws_floats", Cc, 22), Cout * 16 * 27)
+    wt_f, wt_b1, wt_b2 = (torch.empty(nws, device=d) for _ in range(3))
+    y = torch.empty(B, Cc, 4 * D, 4 * Hh, 4 * W, device=d)
+    assert H.query("vx_expand_fwd_mfma_split", H.P(x), H.P(w), H.P(bias), H.P(wt_f), H.P(y), B, Cc, D, Hh, W, 22, st) == 0
+    off = H.query("vx_expand_split_ew_offset", Cc)
+    assert off + 2 <= nws
+    dx1, dx2 = torch.empty_like(x), torch.full_like(x, float("nan"))
+    assert H.query("vx_expand_bwd_data_mfma_split", H.P(dy), H.P(w), H.P(wt_b1), H.P(dx1), B, Cc, D, Hh, W, 0, 22, st) == 0
+    assert H.query("vx_expand_bwd_data_mfma_split_ew", H.P(dy), H.P(w), H.P(wt_b2), H.P(dx2), B, Cc, D, Hh, W, 0, 22, wt_f.data_ptr() + 4 * off, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2) and float(dx1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("grid,big,heads,c,M", [([16, 16, 16], [8, 8, 8], 2, 8, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 2), ([8, 8, 8], [4, 4, 4], 4, 32, 1), ([4, 4, 4], [4, 4, 4], 2, 16, 2),
                                                 ([24, 24, 24], [3, 3, 3], 1, 4, 2), ([16, 16, 8], [4, 4, 2], 2, 8, 3)],
                          ids=["two_scales", "three_scales_incl_separable", "one_modality", "single_scale", "96_L1", "aniso_three_modalities"])

@@ -175,6 +175,7 @@ struct ConvState {
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
     bool pw = false, s1 = false, patch = false, cm = false;      // cm: strided dense conv on MFMA (csrc/conv_mfma.hip)
     Tensor xmax;                                                 // stem: the bits of max |x| left by the forward kernel for the weight gradient (one int32)
+    Tensor wt_fwd;                                               // patch-expand, fp16-piece mode: the forward's weight-image workspace (its tail holds the weight tensor's scale word for the backward)
     bool patch_fused = false;                                    // patch embedding read in place (vx_patch_embed_*): x is the network input, not a patchified copy
 };
 
@@ -242,6 +243,8 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
                 TORCH_CHECK(rc == 0 || !y_h16, "conv3d: the 16-bit patch-expand output needs the bf16-operand kernel");
             } else if (F.expand_split) {
                 rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
+                static const bool ew_on = !(getenv("VELOXSEG_EXPAND_EW_FWD") && getenv("VELOXSEG_EXPAND_EW_FWD")[0] == '0');      // (A/B)
+                st.wt_fwd = (rc == 0 && F.expand_split == 22 && ew_on && w.requires_grad()) ? wt : Tensor();
             }
             if (rc == 1) rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
@@ -318,7 +321,8 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 rcb = VXR(vx_expand_bwd_data_mfma_bf16_h, (const void*)dy.data_ptr(), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, (int)dy_h16, stream);
                 TORCH_CHECK(rcb == 0 || !dy_h16, "conv3d backward: the 16-bit gradient needs the bf16-operand kernel");
             } else if (F.expand_split) {
-                rcb = VXR(vx_expand_bwd_data_mfma_split, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, stream);
+                const float* ew_fwd = (st.wt_fwd.defined() && F.expand_split == 22) ? st.wt_fwd.data_ptr<float>() + vx_expand_split_ew_offset(Cout / 64) : nullptr;
+                rcb = VXR(vx_expand_bwd_data_mfma_split_ew, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, ew_fwd, stream);
             }
             if (rcb == 1) VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
         } else if (st.s1) VX(vx_conv_s1, fp(dy), fp(w), nullptr, mp(dx), B, Cout, Cin, D, H, W, K, G, 1, ps, 1, acc, stream);

@@ -1311,8 +1311,17 @@ extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const fl
     VX_LAUNCH_CHECK("vx_expand_fwd_mfma_split");
     return 0;
 }
+extern "C" int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
+                                                const float* ew_fwd, void* stream);
 extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
                                              void* stream) {
+    return vx_expand_bwd_data_mfma_split_ew(dy_fine, w, wt_ws, dx, B, Cc, D, H, W, accumulate, ns, nullptr, stream);
+}
+// the scale word of the weight tensor as the forward of the same layer left it (vx_expand_split_ew_offset floats into ITS workspace; the weights have not changed since):
+// ns = 22 then launches neither the memset nor vx_expand_wmax_k -- two 6 us launches per decoder off the backward chain (round 6).  ew_fwd null: found here.
+extern "C" int vx_expand_split_ew_offset(int Cc) { return Cc * 4 * 14 * 64 * 4 * 2; }
+extern "C" int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
+                                                const float* ew_fwd, void* stream) {
     VX_REQUIRE(dy_fine && w && wt_ws && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0 && (ns == 2 || ns == 3 || ns == 22), "vx_expand_bwd_data_mfma_split: bad args");
     if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
     hipStream_t st = (hipStream_t)stream;
@@ -1320,8 +1329,9 @@ extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* 
     const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
     const size_t shm = (size_t)(ns == 22 ? 2 : ns) * 144 * 18 * sizeof(uint2) + (ns == 22 ? 32 : 0);
     if (ns == 22) {
-        float* ew = wt_ws + (long)groups * 14 * 64 * 4 * 2;
-        VX_REQUIRE(vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew, st) == 0, "vx_expand: memset of the scale word failed");
+        float* ew_own = wt_ws + (long)groups * 14 * 64 * 4 * 2;
+        if (ew_fwd == nullptr) VX_REQUIRE(vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew_own, st) == 0, "vx_expand: memset of the scale word failed");
+        const float* ew = ew_fwd ? ew_fwd : ew_own;
         vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 1);
         vx_expand_bwd_data_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate, ew);
     } else if (ns == 2) {
