@@ -1,0 +1,10 @@
+export TMPDIR=/tmp
+python -m pytest tests/test_hip_ops_gpu.py -x -q -k "expand" 2>&1 | tail -2
+python -m pytest tests/test_hip_model_gpu.py -x -q 2>&1 | tail -2
+NB="--no-eager-baseline --no-cpu-baseline --no-kernel-pass"
+for r in 1 2 3; do for x in 1 0; do
+echo memset=$x autopet128 $(VELOXSEG_EXPAND_WMAX_MEMSET=$x python bench.py $NB 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['dispersion']['step_ms_p50'])")
+done; done
+for w in "autopet96 f32" "brats128 f32" "hecktor f32"; do set -- $w; for r in 1 2; do for x in 1 0; do
+echo memset=$x $1 $2 $(VELOXSEG_EXPAND_WMAX_MEMSET=$x python bench.py $NB --dispersion-steps 0 --workload $1 --dtype $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+done; done; done

@@ -955,6 +955,8 @@ __device__ __forceinline__ int vx_exp16(float m) {              // |m| * 2^e in 
 // largest magnitude of a whole weight tensor: the blocks' maxima meet in out[1] through atomicMax on the bit pattern (non-negative floats order like unsigned integers;
 // the host zeroes the word first).  Consumers take the scale exponent from it: vx_expand_wexp(ew).  (One block of 1024 threads walked the whole tensor before: 12 us for the
 // 110 K weights of the 128^3 two-modality decoders, 30 us for BraTS' -- on every decoder's forward and backward chain.)
+// (round 6) the blocks' maxima are left in part[blockIdx.x] (out + 4 ...) and met by the consumer -- vx_expand_wimg_f16_k, the next launch on the stream -- which also stores
+// the tensor's maximum into out[1] for the matrix kernel: no atomics, hence no memset node in front (one 6 us launch less on every decoder's forward chain)
 __global__ void __launch_bounds__(256) vx_expand_wmax_k(const float* __restrict__ w, long n, float* __restrict__ out) {
     __shared__ float sm[4];
     float mx = 0.0f;
@@ -968,23 +970,34 @@ __global__ void __launch_bounds__(256) vx_expand_wmax_k(const float* __restrict_
     mx = vx_wave_max(mx);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out) + 1, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+    if (threadIdx.x == 0) out[4 + blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 __device__ __forceinline__ int vx_expand_wexp(const float* __restrict__ ew) { return vx_exp16(__uint_as_float(reinterpret_cast<const unsigned*>(ew)[1])); }
+// returns the number of partial maxima left at ew + 4 (<= 64): the argument `nparts` of vx_expand_wimg_f16_k
 static inline int vx_expand_wmax_launch(const float* w, long n, float* ew, hipStream_t st) {
-    if (hipMemsetAsync(ew, 0, 2 * sizeof(float), st) != hipSuccess) return -2;
+    static const bool ms = getenv("VELOXSEG_EXPAND_WMAX_MEMSET") && getenv("VELOXSEG_EXPAND_WMAX_MEMSET")[0] == '1';      // (A/B: the memset node of rounds 4 - 5 back in front; results unchanged)
+    if (ms && hipMemsetAsync(ew, 0, 2 * sizeof(float), st) != hipSuccess) return 1;
     int nb = (int)((n / 4 + 255) / 256);
     if (nb > 64) nb = 64;
     if (nb < 1) nb = 1;
     vx_expand_wmax_k<<<nb, 256, 0, st>>>(w, n, ew);
-    return 0;
+    return nb;
 }
 // the operand-order weight image as two scaled fp16 pieces: img[s][...] as vx_expand_wimg_split_k<2>
-__global__ void __launch_bounds__(256) vx_expand_wimg_f16_k(const float* __restrict__ w, uint32_t* __restrict__ img, const float* __restrict__ ew, int groups, int backward) {
+// nparts > 0: the tensor's maximum is met here from vx_expand_wmax_k's partial maxima (ew_out + 4 ...) and stored to ew_out[1] by block 0; nparts == 0: ew holds it already
+__global__ void __launch_bounds__(256) vx_expand_wimg_f16_k(const float* __restrict__ w, uint32_t* __restrict__ img, const float* __restrict__ ew, int groups, int backward,
+                                                            int nparts, float* __restrict__ ew_out) {
     const long n = (long)groups * 14 * 64 * 4;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    int wexp;
+    if (nparts > 0) {
+        float mx = 0.0f;
+        for (int i = 0; i < nparts; ++i) mx = fmaxf(mx, ew_out[4 + i]);
+        wexp = vx_exp16(mx);
+        if (e == 0) { reinterpret_cast<unsigned*>(ew_out)[0] = 0u; reinterpret_cast<unsigned*>(ew_out)[1] = __float_as_uint(mx); }
+    } else wexp = vx_expand_wexp(ew);
     if (e >= n) return;
-    const float sc = ldexpf(1.0f, vx_expand_wexp(ew));
+    const float sc = ldexpf(1.0f, wexp);
     const int jp = (int)(e & 3), lane = (int)((e >> 2) & 63);
     const long t = e >> 8;
     const int p = (int)(t % 14), g = (int)(t / 14);
@@ -1286,7 +1299,7 @@ __global__ void __launch_bounds__(256) vx_expand_bwd_data_split_k(const float* _
 
 // floats of wt_ws for NS pieces: NS operand-order bf16 images of (Cc * 4) groups x 14 tap pairs x 64 lanes x 16 bytes
 // (ns = 22: two scaled fp16 pieces + one float for the weight tensor's scale exponent)
-extern "C" int vx_expand_split_ws_floats(int Cc, int ns) { return (Cc <= 0 || !(ns == 2 || ns == 3 || ns == 22)) ? -1 : Cc * 4 * 14 * 64 * 4 * (ns == 22 ? 2 : ns) + (ns == 22 ? 4 : 0); }
+extern "C" int vx_expand_split_ws_floats(int Cc, int ns) { return (Cc <= 0 || !(ns == 2 || ns == 3 || ns == 22)) ? -1 : Cc * 4 * 14 * 64 * 4 * (ns == 22 ? 2 : ns) + (ns == 22 ? 4 + 64 : 0); }      // (+ the scale word and the 64 partial maxima)
 
 // returns 1 when the shape is not covered (the caller uses the fp32 MFMA kernels), 0 on success.  ns = 2 (3 products) or 3 (6 products: fp32-exact products)
 extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const float* bias, float* wt_ws, float* y, int B, int Cc, int D, int H, int W, int ns, void* stream) {
@@ -1298,8 +1311,8 @@ extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const fl
     const size_t shm = (size_t)(ns == 22 ? 2 : ns) * 2 * 648 * sizeof(uint4) + (ns == 22 ? 32 : 0);
     if (ns == 22) {
         float* ew = wt_ws + (long)groups * 14 * 64 * 4 * 2;
-        VX_REQUIRE(vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew, st) == 0, "vx_expand: memset of the scale word failed");
-        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 0);
+        const int nparts = vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew, st);
+        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 0, nparts, ew);
         vx_expand_fwd_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, st>>>(x, reinterpret_cast<const uint4*>(wt_ws), bias, y, B, Cc, D, H, W, ew);
     } else if (ns == 2) {
         vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 0);
@@ -1330,9 +1343,9 @@ extern "C" int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const floa
     const size_t shm = (size_t)(ns == 22 ? 2 : ns) * 144 * 18 * sizeof(uint2) + (ns == 22 ? 32 : 0);
     if (ns == 22) {
         float* ew_own = wt_ws + (long)groups * 14 * 64 * 4 * 2;
-        if (ew_fwd == nullptr) VX_REQUIRE(vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew_own, st) == 0, "vx_expand: memset of the scale word failed");
+        const int nparts = ew_fwd == nullptr ? vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew_own, st) : 0;
         const float* ew = ew_fwd ? ew_fwd : ew_own;
-        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 1);
+        vx_expand_wimg_f16_k<<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), ew, groups, 1, nparts, ew_own);
         vx_expand_bwd_data_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, st>>>(dy_fine, reinterpret_cast<const uint4*>(wt_ws), dx, B, Cc, D, H, W, accumulate, ew);
     } else if (ns == 2) {
         vx_expand_wimg_split_k<2><<<vx_cdiv((long)groups * 14 * 64 * 4, 256), 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_ws), groups, 1);
