@@ -24,6 +24,8 @@ from . import _hip as H
 from . import functional as VF
 
 TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
+# the flat-gradient fill at the tail of the segmentation decoder's forward lane (default) or at the head of the encoder forward (0; A/B)
+ZERO_GRAD_IN_DEC_FWD = os.environ.get("VELOXSEG_ZERO_GRAD_DEC", "1") != "0"
 TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
 TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
@@ -525,8 +527,8 @@ class TrainEngine:
     def _s_enc_fwd(self):
         if self._pipe_active():
             self.flat.grad[:self.flat.split].zero_()       # (pipelined tail: the decoder half may still be in use by the previous step's dec_wg / AdamW: zeroed in _s_loss)
-        else:
-            self.flat.zero_grad()
+        elif not ZERO_GRAD_IN_DEC_FWD:
+            self.flat.zero_grad()                          # (default: at the end of the segmentation decoder's forward lane, _s_dec_fwd -- off the head of the step's chain)
         VF.advance_rng(self.dev)
         self._drop_level_hooks()
         if self._mark_levels():
@@ -615,6 +617,10 @@ class TrainEngine:
                 bl.seg_forward([t.detach() for t in self._outs[0][:-1]], self.labels)
             else:
                 self._rc_c[k] = bl.rc_forward(self._outs[k][0].detach(), self.x, self._ch_off[k - 1])
+        if k == 0 and ZERO_GRAD_IN_DEC_FWD and not self._pipe_active():
+            # (round 6) the flat gradient is zeroed HERE, at the tail of the segmentation decoder's forward lane (the shortest of the fan: 439 / 452 / 451 us), instead of at the
+            # head of the encoder forward: nothing accumulates into it before the backward stages, and the 9 MB fill leaves the step's critical chain
+            self.flat.zero_grad()
 
     def _head_bf16(self, k):
         """bf16 storage mode (precision "bf16", functional.BF16_STORAGE): may decoder branch k hand its full-resolution output to the staged loss as a bfloat16 tensor?
