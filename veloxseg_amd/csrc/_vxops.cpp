@@ -18,6 +18,7 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <map>
+#include <unordered_map>
 #include <tuple>
 #include <functional>
 #include <type_traits>
@@ -989,6 +990,16 @@ struct GramFn : public torch::autograd::Function<GramFn> {
     }
 };
 
+// (round 6) weight images prepared AHEAD of their block (engine.TrainEngine prefetches them on a side lane at the head of the encoder forward: the two or three 6 us
+// preparation launches in front of every JLC block's convolutions leave the forward chains).  Keyed by the data pointer of the 1x1x1 weight; consumed once by jlc_fwd_f.
+struct JlcPreImg { Tensor img; int kind = 0, pieces = 0, C = 0, G = 0; };      // kind 1: Toeplitz images (jlc_mfma.hip), 2: channels-last images (jlc_cl.hip)
+static std::unordered_map<const void*, JlcPreImg> JLC_PRE;
+static int jlc_img_kind(int C, int G, int D, int H, int W) {
+    if (!F.fuse_blocks || !F.jlc_tz || (C / G) % 4 != 0) return 0;
+    if (vx_jlc_tz_ok(C, G, D, H, W)) return 1;
+    if (vx_jlc_cl_ok(C, G, D, H, W)) return 2;
+    return 0;
+}
 static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, const std::vector<Tensor>& ws, const std::vector<Tensor>& bs, int G, const Tensor& l1w, const Tensor& l1b, const Tensor& l2w,
                         const Tensor& l2b, double p, int64_t site, int64_t rs, int64_t stream) {
         auto st = std::make_shared<JLCState>();
@@ -1023,14 +1034,28 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                 char* yp = (char*)f.y.data_ptr();
                 const long n1 = BC * V;
                 void *y1 = yp, *y3 = yp + esz * n1, *y5 = yp + 2 * esz * n1;
+                bool pre = false;
+                {
+                    auto it = JLC_PRE.find(f.w1.data_ptr());
+                    if (it != JLC_PRE.end()) {
+                        const JlcPreImg& q = it->second;
+                        pre = q.C == C && q.G == G && ((tz && q.kind == 1 && q.pieces == f.tz_pieces) || (cl && q.kind == 2));
+                        if (pre) f.img = q.img;
+                        JLC_PRE.erase(it);           // (a stale or mismatching entry is dropped: the images are then built here as before)
+                    }
+                }
                 if (tz) {
-                    f.img = at::empty({(long)vx_jlc_tz_img_floats_ns(C, G, f.tz_pieces)}, f.x.options());
-                    VX(vx_jlc_tz_prep_ns, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, f.tz_pieces, s_);
+                    if (!pre) {
+                        f.img = at::empty({(long)vx_jlc_tz_img_floats_ns(C, G, f.tz_pieces)}, f.x.options());
+                        VX(vx_jlc_tz_prep_ns, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, f.tz_pieces, s_);
+                    }
                     VX(vx_jlc_tz_fwd_h, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), y1, y3, y5, part_y.data_ptr<double>(), B, C, G, D, H, W, f.tz_pieces, (int)f.h16, s_);
                 } else if (cl) {
-                    f.img = at::empty({(long)vx_jlc_cl_img_floats(C, G)}, f.x.options());
                     f.img_cl = true;
-                    VX(vx_jlc_cl_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
+                    if (!pre) {
+                        f.img = at::empty({(long)vx_jlc_cl_img_floats(C, G)}, f.x.options());
+                        VX(vx_jlc_cl_prep, fp(f.w1), fp(f.w3), fp(f.w5), mp(f.img), C, G, s_);
+                    }
                     VX(vx_jlc_cl_fwd, fp(f.x), fp(f.img), fp(f.b1), fp(f.b3), fp(f.b5), (float*)y1, (float*)y3, (float*)y5, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
                 } else
                 VX(vx_jlc_conv_fwd, fp(f.x), fp(f.w1), fp(f.w3), fp(f.w5), fp(f.b1), fp(f.b3), fp(f.b5), (float*)y1, (float*)y3, (float*)y5, part_y.data_ptr<double>(), B, C, G, D, H, W, s_);
@@ -1624,6 +1649,31 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("qkv", [](const Tensor& x, const Tensor& wq, const OptT& bq, const Tensor& wk, const OptT& bk, const Tensor& wv, const OptT& bv) {
         return QKVFn::apply(x, wq, bq, wk, bk, wv, bv);
     });
+    // weight images of a JLC block ahead of its forward: jlc_img_plan -> (kind, floats) for a block of C channels / G groups on a D x H x W grid (kind 0: the block builds
+    // nothing ahead); jlc_prep_into builds them into `img` on `stream` and leaves them for the block's next forward (jlc_fwd_f); jlc_prefetch_clear drops what was not taken
+    m.def("jlc_img_plan", [](int64_t C, int64_t G, int64_t D, int64_t H, int64_t W) {
+        const int kind = jlc_img_kind((int)C, (int)G, (int)D, (int)H, (int)W);
+        const long n = kind == 1 ? (long)vx_jlc_tz_img_floats_ns((int)C, (int)G, vx_jlc_tz_pieces()) : kind == 2 ? (long)vx_jlc_cl_img_floats((int)C, (int)G) : 0;
+        return std::make_pair((int64_t)kind, (int64_t)n);
+    });
+    m.def("jlc_prep_into", [](const Tensor& w1, const Tensor& w3, const Tensor& w5, Tensor img, int64_t C, int64_t G, int64_t D, int64_t H, int64_t W, int64_t stream) {
+        const int kind = jlc_img_kind((int)C, (int)G, (int)D, (int)H, (int)W);
+        if (kind == 0) return false;
+        void* s_ = sp(stream);
+        JlcPreImg q;
+        q.img = img; q.kind = kind; q.C = (int)C; q.G = (int)G;
+        if (kind == 1) {
+            q.pieces = vx_jlc_tz_pieces();
+            TORCH_CHECK(img.numel() >= (long)vx_jlc_tz_img_floats_ns((int)C, (int)G, q.pieces), "jlc_prep_into: image buffer too small");
+            VX(vx_jlc_tz_prep_ns, fp(w1), fp(w3), fp(w5), mp(img), (int)C, (int)G, q.pieces, s_);
+        } else {
+            TORCH_CHECK(img.numel() >= (long)vx_jlc_cl_img_floats((int)C, (int)G), "jlc_prep_into: image buffer too small");
+            VX(vx_jlc_cl_prep, fp(w1), fp(w3), fp(w5), mp(img), (int)C, (int)G, s_);
+        }
+        JLC_PRE[w1.data_ptr()] = q;
+        return true;
+    });
+    m.def("jlc_prefetch_clear", []() { const int64_t n = (int64_t)JLC_PRE.size(); JLC_PRE.clear(); return n; });
     m.def("jlc", [](const Tensor& x, const Tensor& w0, const OptT& w1, const OptT& w2, const Tensor& b0, const OptT& b1, const OptT& b2, int64_t G, const Tensor& l1w,
                     const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site, int64_t rs) {
         return JLCFn::apply(x, w0, w1, w2, b0, b1, b2, G, l1w, l1b, l2w, l2b, p, site, rs);

@@ -26,6 +26,8 @@ from . import functional as VF
 TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
 # the flat-gradient fill at the tail of the segmentation decoder's forward lane (default) or at the head of the encoder forward (0; A/B)
 ZERO_GRAD_IN_DEC_FWD = os.environ.get("VELOXSEG_ZERO_GRAD_DEC", "1") != "0"
+# the weight images of the JLC blocks built ahead, on a side lane at the head of the encoder forward (0: in front of every block, A/B)
+WIMG_PREFETCH = os.environ.get("VELOXSEG_WIMG_PREFETCH", "1") != "0"
 TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
 TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
@@ -530,6 +532,7 @@ class TrainEngine:
         elif not ZERO_GRAD_IN_DEC_FWD:
             self.flat.zero_grad()                          # (default: at the end of the segmentation decoder's forward lane, _s_dec_fwd -- off the head of the step's chain)
         VF.advance_rng(self.dev)
+        self._prefetch_weight_images()
         self._drop_level_hooks()
         if self._mark_levels():
             # data-parallel tape: a marker where the gradients of a level's inputs are complete (multi-grad hooks, as in the eager overlapped step);
@@ -546,6 +549,10 @@ class TrainEngine:
             attn, encs = self.model.encoder(self.x)
         finally:
             self.model.encoder._on_level_inputs = None
+        if getattr(self, "_pf_blocks", None):
+            # the side lane that built the weight images re-joins this stage (the decoders' images are complete before the decoder fan; a captured stage may not end with
+            # work that never came back to its stream)
+            torch.cuda.current_stream(self.dev).wait_stream(VF.side_stream(self.dev, "weight_images"))
         self._boundary = list(encs) + [t for lvl in attn for t in lvl]
         if getattr(self, "_bl", None) is not None:
             if self._bl == "pending":
@@ -591,6 +598,7 @@ class TrainEngine:
 
     def _s_dec_fwd(self, k):
         # every branch gets its own leaves (same storage, separate .grad), so concurrent branches never accumulate into one tensor
+        self._prefetch_settle()
         M = self.model.num_modalities
         if self._pipe_active():
             # pipelined tail: this decoder's weight-gradient tape (dec_wg[k]) still runs while the NEXT step's encoder forward rewrites the boundary tensors, and some of
@@ -621,6 +629,36 @@ class TrainEngine:
             # (round 6) the flat gradient is zeroed HERE, at the tail of the segmentation decoder's forward lane (the shortest of the fan: 439 / 452 / 451 us), instead of at the
             # head of the encoder forward: nothing accumulates into it before the backward stages, and the 9 MB fill leaves the step's critical chain
             self.flat.zero_grad()
+
+    def _prefetch_weight_images(self):
+        """(round 6) the weight images of every JLC block of the step -- functions of the weights alone -- are built at the head of the encoder forward on a side lane, in the
+        order the blocks need them (encoder levels 1..4, then every decoder's levels 3, 2, 1), instead of in front of each block's convolutions on the forward chains
+        (two or three 6 us launches per block: functional.jlc_prefetch).  The decoders' images are ready long before the decoder fan starts (the stage joins its side streams)."""
+        if not WIMG_PREFETCH or self._pipe_active():
+            return
+        from .model.components.conv_blocks import JLC
+        enc = getattr(self.model, "encoder", None)
+        ce = getattr(enc, "encoder_conv", None)
+        if ce is None:
+            return
+        ps = self.model.patch_size
+        ps = [int(ps)] * 3 if not isinstance(ps, (tuple, list)) else [int(v) for v in ps]
+        base = [int(s_) // p_ for s_, p_ in zip(self.x.shape[2:], ps)]
+        grid = lambda lvl: [max(g // (2 ** (lvl - 1)), 1) for g in base]
+        todo = [(blk, grid(i)) for i in (1, 2, 3, 4) for blk in getattr(ce, f"layer{i}") if isinstance(blk, JLC)]
+        decs = [self.model.decoder] + list(getattr(self.model, "rc_decoders", []))
+        for lvl in (3, 2, 1):
+            for d in decs:
+                todo += [(blk, grid(lvl)) for blk in getattr(d, f"layer{lvl}", []) if isinstance(blk, JLC)]
+        side = VF.side_stream(self.dev, "weight_images")
+        cur = torch.cuda.current_stream(self.dev)
+        side.wait_stream(cur)
+        self._pf_blocks = [blk for blk, g in todo if VF.jlc_prefetch(blk, g, side)]
+
+    def _prefetch_settle(self):
+        """after the encoder-forward stage has joined its side streams: the decoders' blocks need not wait for an event of another stage; entries nobody took are dropped"""
+        for blk in getattr(self, "_pf_blocks", []):
+            blk.__dict__.pop("_pf_ev", None)
 
     def _head_bf16(self, k):
         """bf16 storage mode (precision "bf16", functional.BF16_STORAGE): may decoder branch k hand its full-resolution output to the staged loss as a bfloat16 tensor?

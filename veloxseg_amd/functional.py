@@ -852,8 +852,38 @@ class _JLCFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+def jlc_prefetch(mod, grid, stream) -> bool:
+    """Build the weight images of JLC block `mod` (its next forward runs on a `grid` = (D, H, W) volume) on `stream`, ahead of the block: the block's forward then launches
+    no preparation kernels (csrc/_vxops.cpp jlc_prep_into / jlc_fwd_f).  The image buffer is the block's own and is re-used every step; an event recorded on `stream` is left
+    on the block and waited for by its forward.  Returns False where the block builds nothing ahead (VALU convolutions, python bindings)."""
+    m = _cpp_node("jlc")
+    if m is None or len(mod.spatial_convs) != 3 or not hasattr(m, "jlc_prep_into"):
+        return False
+    convs = [seq[0] for seq in mod.spatial_convs]
+    w = convs[0].weight
+    if not w.is_cuda:
+        return False
+    C, G = int(w.shape[0]), int(convs[0].groups)
+    kind, n = m.jlc_img_plan(C, G, int(grid[0]), int(grid[1]), int(grid[2]))
+    if kind == 0:
+        return False
+    img = getattr(mod, "_pf_img", None)
+    if img is None or img.numel() < n or img.device != w.device:
+        img = mod._pf_img = torch.empty(int(n), device=w.device, dtype=torch.float32)          # (allocated on the CURRENT stream, before the side stream is entered)
+    with torch.cuda.stream(stream):
+        ok = m.jlc_prep_into(convs[0].weight, convs[1].weight, convs[2].weight, img, C, G, int(grid[0]), int(grid[1]), int(grid[2]), stream.cuda_stream)
+        if ok:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            mod._pf_ev = ev
+    return bool(ok)
+
+
 def jlc_block(x, mod, p: float, site: int):
     m = _cpp_node("jlc") if x.is_cuda else None
+    ev = mod.__dict__.pop("_pf_ev", None)                      # images prepared ahead on a side stream (jlc_prefetch): this stream waits for them
+    if ev is not None:
+        torch.cuda.current_stream(x.device).wait_event(ev)
     if m is not None and len(mod.spatial_convs) <= 3:          # the whole block as one C++ autograd node
         convs = [seq[0] for seq in mod.spatial_convs]
         l1, l2 = mod.channel_conv[1], mod.channel_conv[3]
