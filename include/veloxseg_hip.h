@@ -562,6 +562,11 @@ int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* w
 /* (round 6) with the weight tensor's scale word handed over from the forward of the same layer (ns = 22: it sits vx_expand_split_ew_offset(Cc) floats into the forward's
  * workspace, 2 floats; NULL = find it here): no memset / max launch in front of the backward's weight image */
 int vx_expand_split_ew_offset(int Cc);
+/* (round 6) both weight images of a layer built ahead of its forward (fp16-piece mode, ns = 22; workspaces of vx_expand_split_ws_floats(Cc, 22) floats each), and the
+ * matrix kernels alone on prepared images (ew_fwd = wt_fwd + vx_expand_split_ew_offset(Cc)) */
+int vx_expand_prep_split22(const float* w, float* wt_fwd, float* wt_bwd, int Cc, void* stream);
+int vx_expand_fwd_mfma_split_prepared(const float* x, const float* bias, const float* wt_fwd, float* y, int B, int Cc, int D, int H, int W, void* stream);
+int vx_expand_bwd_data_mfma_split_prepared(const float* dy_fine, const float* wt_bwd, const float* ew_fwd, float* dx, int B, int Cc, int D, int H, int W, int accumulate, void* stream);
 int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
                                      const float* ew_fwd, void* stream);
 

@@ -843,6 +843,14 @@ def test_patch_expand_backward_takes_the_weight_scale_from_its_forward(B, Cc, sp
     assert H.query("vx_expand_bwd_data_mfma_split_ew", H.P(dy), H.P(w), H.P(wt_b2), H.P(dx2), B, Cc, D, Hh, W, 0, 22, wt_f.data_ptr() + 4 * off, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(dx1, dx2) and float(dx1.abs().max()) > 0
+    # both images built ahead (vx_expand_prep_split22), the matrix kernels alone on them: the same bits again
+    wt_pf, wt_pb = torch.full((nws,), float("nan"), device=d), torch.full((nws,), float("nan"), device=d)
+    H.call("vx_expand_prep_split22", H.P(w), H.P(wt_pf), H.P(wt_pb), Cc, st)
+    y3, dx3 = torch.full_like(y, float("nan")), torch.full_like(x, float("nan"))
+    assert H.query("vx_expand_fwd_mfma_split_prepared", H.P(x), H.P(bias), H.P(wt_pf), H.P(y3), B, Cc, D, Hh, W, st) == 0
+    assert H.query("vx_expand_bwd_data_mfma_split_prepared", H.P(dy), H.P(wt_pb), wt_pf.data_ptr() + 4 * off, H.P(dx3), B, Cc, D, Hh, W, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y) and torch.equal(dx3, dx1)
 
 
 @pytest.mark.parametrize("grid,big,heads,c,M", [([16, 16, 16], [8, 8, 8], 2, 8, 2), ([32, 32, 32], [4, 4, 4], 1, 4, 2), ([8, 8, 8], [4, 4, 4], 4, 32, 1), ([4, 4, 4], [4, 4, 4], 2, 16, 2),

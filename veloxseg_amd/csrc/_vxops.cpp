@@ -176,10 +176,14 @@ struct ConvState {
     int B = 0, C1 = 0, Cin = 0, D = 0, H = 0, W = 0, Cout = 0, K = 0, S = 0, P = 0, G = 0, ps = 0;
     bool pw = false, s1 = false, patch = false, cm = false;      // cm: strided dense conv on MFMA (csrc/conv_mfma.hip)
     Tensor xmax;                                                 // stem: the bits of max |x| left by the forward kernel for the weight gradient (one int32)
+    Tensor wt_bwd_pre;                                           // patch-expand: the input gradient's weight image when it was built ahead (EXPAND_PRE)
     Tensor wt_fwd;                                               // patch-expand, fp16-piece mode: the forward's weight-image workspace (its tail holds the weight tensor's scale word for the backward)
     bool patch_fused = false;                                    // patch embedding read in place (vx_patch_embed_*): x is the network input, not a patchified copy
 };
 
+// (round 6) both weight images of a patch-expand layer built ahead of its forward (fp16-piece mode): keyed by the weight's data pointer, consumed once by conv_fwd_impl
+struct ExpandPreImg { Tensor wt_fwd, wt_bwd; int Cc = 0; };
+static std::unordered_map<const void*, ExpandPreImg> EXPAND_PRE;
 Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
                      bool x_requires_grad, void* stream) {
     check_in(x_in, "conv3d");
@@ -243,9 +247,18 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
                 rc = VXR(vx_expand_fwd_mfma_bf16_h, fp(x), fp(w), fp(b), mp(wt), y.data_ptr(), B, Cout / 64, D, H, W, (int)y_h16, stream);
                 TORCH_CHECK(rc == 0 || !y_h16, "conv3d: the 16-bit patch-expand output needs the bf16-operand kernel");
             } else if (F.expand_split) {
-                rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
+                st.wt_bwd_pre = Tensor();
+                bool pre = false;
+                auto it = EXPAND_PRE.find(w.data_ptr());
+                if (it != EXPAND_PRE.end()) {
+                    pre = F.expand_split == 22 && it->second.Cc == Cout / 64 && D % 4 == 0 && H % 4 == 0 && W % 4 == 0;
+                    if (pre) { wt = it->second.wt_fwd; st.wt_bwd_pre = it->second.wt_bwd; }
+                    EXPAND_PRE.erase(it);
+                }
+                if (pre) rc = VXR(vx_expand_fwd_mfma_split_prepared, fp(x), fp(b), fp(wt), mp(y), B, Cout / 64, D, H, W, stream);
+                else rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
                 static const bool ew_on = !(getenv("VELOXSEG_EXPAND_EW_FWD") && getenv("VELOXSEG_EXPAND_EW_FWD")[0] == '0');      // (A/B)
-                st.wt_fwd = (rc == 0 && F.expand_split == 22 && ew_on && w.requires_grad()) ? wt : Tensor();
+                st.wt_fwd = (rc == 0 && F.expand_split == 22 && (ew_on || pre) && w.requires_grad()) ? wt : Tensor();
             }
             if (rc == 1) rc = vx_expand_fwd_mfma(fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, stream);
             if (rc != 0 && rc != 1) chk(rc, "vx_expand_fwd_mfma");
@@ -323,6 +336,9 @@ void conv_bwd_impl(ConvState& st, const Tensor& dy_in, bool need_x, Tensor& dx, 
                 TORCH_CHECK(rcb == 0 || !dy_h16, "conv3d backward: the 16-bit gradient needs the bf16-operand kernel");
             } else if (F.expand_split) {
                 const float* ew_fwd = (st.wt_fwd.defined() && F.expand_split == 22) ? st.wt_fwd.data_ptr<float>() + vx_expand_split_ew_offset(Cout / 64) : nullptr;
+                if (ew_fwd && st.wt_bwd_pre.defined())
+                    rcb = VXR(vx_expand_bwd_data_mfma_split_prepared, fp(dy), fp(st.wt_bwd_pre), ew_fwd, mp(dx), B, Cout / 64, D, H, W, acc, stream);
+                else
                 rcb = VXR(vx_expand_bwd_data_mfma_split_ew, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, F.expand_split, ew_fwd, stream);
             }
             if (rcb == 1) VX(vx_expand_bwd_data_mfma, fp(dy), fp(w), mp(wt), mp(dx), B, Cout / 64, D, H, W, acc, stream);
@@ -1673,7 +1689,22 @@ PYBIND11_MODULE(_vxops, m) {
         JLC_PRE[w1.data_ptr()] = q;
         return true;
     });
-    m.def("jlc_prefetch_clear", []() { const int64_t n = (int64_t)JLC_PRE.size(); JLC_PRE.clear(); return n; });
+    m.def("jlc_prefetch_clear", []() { const int64_t n = (int64_t)(JLC_PRE.size() + EXPAND_PRE.size()); JLC_PRE.clear(); EXPAND_PRE.clear(); return n; });
+    // the same for a patch-expand layer (Conv3d k3 p1, 16 -> 64 Cc channels + PixelShuffle(4)) in the fp16-piece mode: -> floats per workspace (0: nothing is built ahead)
+    m.def("expand_img_floats", [](int64_t Cout) {
+        return (int64_t)((F.use_expand_mfma && !F.bf16_expand && F.expand_split == 22 && F.use_s1 && Cout % 64 == 0) ? vx_expand_split_ws_floats((int)(Cout / 64), 22) : 0);
+    });
+    m.def("expand_prep_into", [](const Tensor& w, Tensor wt_fwd, Tensor wt_bwd, int64_t stream) {
+        const int Cc = (int)(w.size(0) / 64);
+        if (!(F.use_expand_mfma && !F.bf16_expand && F.expand_split == 22 && F.use_s1) || w.size(0) % 64 != 0 || w.size(1) != 16 || w.size(2) != 3) return false;
+        const long n = vx_expand_split_ws_floats(Cc, 22);
+        TORCH_CHECK(wt_fwd.numel() >= n && wt_bwd.numel() >= n, "expand_prep_into: workspace too small");
+        VX(vx_expand_prep_split22, fp(w), mp(wt_fwd), mp(wt_bwd), Cc, sp(stream));
+        ExpandPreImg q;
+        q.wt_fwd = wt_fwd; q.wt_bwd = wt_bwd; q.Cc = Cc;
+        EXPAND_PRE[w.data_ptr()] = q;
+        return true;
+    });
     m.def("jlc", [](const Tensor& x, const Tensor& w0, const OptT& w1, const OptT& w2, const Tensor& b0, const OptT& b1, const OptT& b2, int64_t G, const Tensor& l1w,
                     const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site, int64_t rs) {
         return JLCFn::apply(x, w0, w1, w2, b0, b1, b2, G, l1w, l1b, l2w, l2b, p, site, rs);

@@ -1324,6 +1324,41 @@ extern "C" int vx_expand_fwd_mfma_split(const float* x, const float* w, const fl
     VX_LAUNCH_CHECK("vx_expand_fwd_mfma_split");
     return 0;
 }
+// ---- (round 6) the two weight images of a layer built AHEAD of its forward (fp16-piece mode, ns = 22; engine.TrainEngine does it on a side lane at the head of the step):
+// vx_expand_prep_split22 fills wt_fwd (image + scale word) and wt_bwd (the input gradient's image; same scale word, read from wt_fwd); the *_prepared entries launch the
+// matrix kernels only.  Workspaces: vx_expand_split_ws_floats(Cc, 22) floats each.
+extern "C" int vx_expand_prep_split22(const float* w, float* wt_fwd, float* wt_bwd, int Cc, void* stream) {
+    VX_REQUIRE(w && wt_fwd && wt_bwd && Cc > 0, "vx_expand_prep_split22: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = Cc * 4;
+    float* ew = wt_fwd + (long)groups * 14 * 64 * 4 * 2;
+    const int nparts = vx_expand_wmax_launch(w, (long)groups * 16 * 16 * 27, ew, st);
+    const unsigned nb = (unsigned)vx_cdiv((long)groups * 14 * 64 * 4, 256);
+    vx_expand_wimg_f16_k<<<nb, 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_fwd), ew, groups, 0, nparts, ew);
+    vx_expand_wimg_f16_k<<<nb, 256, 0, st>>>(w, reinterpret_cast<uint32_t*>(wt_bwd), ew, groups, 1, 0, nullptr);
+    VX_LAUNCH_CHECK("vx_expand_prep_split22");
+    return 0;
+}
+extern "C" int vx_expand_fwd_mfma_split_prepared(const float* x, const float* bias, const float* wt_fwd, float* y, int B, int Cc, int D, int H, int W, void* stream) {
+    VX_REQUIRE(x && wt_fwd && y && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_fwd_mfma_split_prepared: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
+    const int groups = Cc * 4;
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
+    const size_t shm = (size_t)2 * 2 * 648 * sizeof(uint4) + 32;
+    vx_expand_fwd_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, (hipStream_t)stream>>>(x, reinterpret_cast<const uint4*>(wt_fwd), bias, y, B, Cc, D, H, W, wt_fwd + (long)groups * 14 * 64 * 4 * 2);
+    VX_LAUNCH_CHECK("vx_expand_fwd_mfma_split_prepared");
+    return 0;
+}
+extern "C" int vx_expand_bwd_data_mfma_split_prepared(const float* dy_fine, const float* wt_bwd, const float* ew_fwd, float* dx, int B, int Cc, int D, int H, int W, int accumulate,
+                                                      void* stream) {
+    VX_REQUIRE(dy_fine && wt_bwd && ew_fwd && dx && B > 0 && Cc > 0 && D > 0 && H > 0 && W > 0, "vx_expand_bwd_data_mfma_split_prepared: bad args");
+    if (D % 4 != 0 || H % 4 != 0 || W % 4 != 0) return 1;
+    const long nblk = (long)B * (D / 4) * (H / 4) * ((W + 15) / 16);
+    const size_t shm = (size_t)2 * 144 * 18 * sizeof(uint2) + 32;
+    vx_expand_bwd_data_split_k<2, true><<<dim3((unsigned)nblk), 256, shm, (hipStream_t)stream>>>(dy_fine, reinterpret_cast<const uint4*>(wt_bwd), dx, B, Cc, D, H, W, accumulate, ew_fwd);
+    VX_LAUNCH_CHECK("vx_expand_bwd_data_mfma_split_prepared");
+    return 0;
+}
 extern "C" int vx_expand_bwd_data_mfma_split_ew(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,
                                                 const float* ew_fwd, void* stream);
 extern "C" int vx_expand_bwd_data_mfma_split(const float* dy_fine, const float* w, float* wt_ws, float* dx, int B, int Cc, int D, int H, int W, int accumulate, int ns,

@@ -28,6 +28,10 @@ TAPE_WGRAD_SIDE = os.environ.get("VELOXSEG_TAPE_WGRAD_SIDE", "0") != "0"
 ZERO_GRAD_IN_DEC_FWD = os.environ.get("VELOXSEG_ZERO_GRAD_DEC", "1") != "0"
 # the weight images of the JLC blocks built ahead, on a side lane at the head of the encoder forward (0: in front of every block, A/B)
 WIMG_PREFETCH = os.environ.get("VELOXSEG_WIMG_PREFETCH", "1") != "0"
+# ... and those of the patch-expand heads: OFF.  Same box, with / without: autopet128 +0.1 ... 0.3 %, autopet96 +0.4 %, hecktor +0.6 %, but brats128 fp32 -4 % (755 -> 723 patches/s):
+# its two decoder lanes then reach their 100 us patch-expand kernels at the same moment and the decoder fan takes 576 instead of 458 us although its critical path is 15 us
+# shorter (tools/tape_critical_path.py brats128) -- the two preparation launches had been staggering them.
+EXPAND_PREFETCH = os.environ.get("VELOXSEG_EXPAND_PREFETCH", "0") == "1"
 TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
 TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
@@ -654,6 +658,10 @@ class TrainEngine:
         cur = torch.cuda.current_stream(self.dev)
         side.wait_stream(cur)
         self._pf_blocks = [blk for blk, g in todo if VF.jlc_prefetch(blk, g, side)]
+        for d in (decs if EXPAND_PREFETCH else []):      # the patch-expand heads (out_conv / out_conv1: 3^3 conv + PixelShuffle): forward and input-gradient images
+            head = getattr(d, "out_conv1", None) or getattr(d, "out_conv", None)
+            if head is not None:
+                VF.expand_prefetch(head[0], side)
 
     def _prefetch_settle(self):
         """after the encoder-forward stage has joined its side streams: the decoders' blocks need not wait for an event of another stage; entries nobody took are dropped"""

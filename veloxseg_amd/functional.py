@@ -879,6 +879,24 @@ def jlc_prefetch(mod, grid, stream) -> bool:
     return bool(ok)
 
 
+def expand_prefetch(conv, stream) -> bool:
+    """Both weight images of a patch-expand layer (`conv`: the 3^3 convolution in front of PixelShuffle(4)) built on `stream` ahead of its forward (fp16-piece mode;
+    csrc/_vxops.cpp expand_prep_into): the layer's forward and input gradient then launch their matrix kernels only.  The buffers are the layer's own, re-used every step.
+    The caller joins `stream` before the layer runs (the engine's encoder-forward stage does)."""
+    m = _cpp_node("conv")
+    w = conv.weight
+    if m is None or not hasattr(m, "expand_prep_into") or not w.is_cuda or w.dim() != 5:
+        return False
+    n = int(m.expand_img_floats(int(w.shape[0])))
+    if n <= 0 or tuple(w.shape[1:]) != (16, 3, 3, 3):
+        return False
+    bufs = getattr(conv, "_pf_wt", None)
+    if bufs is None or bufs[0].numel() < n or bufs[0].device != w.device:
+        bufs = conv._pf_wt = (torch.empty(n, device=w.device, dtype=torch.float32), torch.empty(n, device=w.device, dtype=torch.float32))
+    with torch.cuda.stream(stream):
+        return bool(m.expand_prep_into(w, bufs[0], bufs[1], stream.cuda_stream))
+
+
 def jlc_block(x, mod, p: float, site: int):
     m = _cpp_node("jlc") if x.is_cuda else None
     ev = mod.__dict__.pop("_pf_ev", None)                      # images prepared ahead on a side stream (jlc_prefetch): this stream waits for them
