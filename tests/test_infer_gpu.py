@@ -41,6 +41,59 @@ def test_sliding_window_matches_oracle_bit_exactly(shape, roi, swb, overlap):
         IR.sliding_window_inference(x.cpu(), roi, swb, _pointwise, overlap=overlap)
 
 
+def test_taped_predictor_keeps_weight_images_only_while_the_weights_stand(golden_dir):
+    """engine.TapedPredictor builds the JLC blocks' weight images once and captures its tapes WITHOUT their preparation launches; the images must not outlive the weights:
+    an in-place torch update (version counters) and a TrainEngine step (fused AdamW through raw pointers: the weights epoch) both make the next call re-capture.
+    Every call is compared with the plain eager forward of the same weights."""
+    import sys
+    import types
+    sys.path.insert(0, golden_dir)
+    from recipe import CASES, fill_state_dict
+    from veloxseg_amd.engine import TapedPredictor, TrainEngine
+    from veloxseg_amd.model.VeloxSeg import VeloxSeg
+    from veloxseg_amd.utils.loss import Loss
+    cfg, _ = CASES["g2_32_m2"]
+    d = dev()
+    model = VeloxSeg(**cfg)
+    sd = model.state_dict()
+    fill_state_dict(sd)
+    model.load_state_dict(sd)
+    model = model.to(d).eval()
+    x = torch.randn((2, 2, 32, 32, 32), generator=torch.Generator().manual_seed(7)).to(d)
+    tp = TapedPredictor(model)
+
+    def both():
+        with torch.inference_mode():
+            a = tp(x).float().clone()
+            b = model(x)
+            b = (b[0] if isinstance(b, (list, tuple)) else b).float().clone()
+        return a, b
+    a0, b0 = both()
+    assert torch.equal(a0, b0)
+    a0b, _ = both()                                            # a replay
+    assert torch.equal(a0b, a0) and any(e is not None for e in tp._tapes.values())
+    with torch.no_grad():                                      # in place: same storage, version counters move
+        for p_ in model.parameters():
+            p_.mul_(1.25)
+    a1, b1 = both()
+    assert torch.equal(a1, b1) and not torch.equal(a1, a0), "the predictor replayed weight images of the old weights"
+    # a training step of the engine on the same model: parameters re-homed into the flat buffer, then updated through raw pointers
+    model.train()
+    from bench import LOSS_CFG as loss_cfg
+    crit = Loss(types.SimpleNamespace(model_name="VeloxSeg"), loss_cfg, None, num_modal=2)
+    eng = TrainEngine(model, crit, tuple(x.shape))
+    lab = (torch.rand((2, 1, 32, 32, 32), generator=torch.Generator().manual_seed(8)) > 0.9).long().to(d)
+    eng.step(x, lab)
+    model.eval()
+    a2, b2 = both()
+    assert torch.equal(a2, b2)
+    model.train()
+    eng.step(x, lab)                                           # same storage, no version bump: only the weights epoch tells
+    model.eval()
+    a3, b3 = both()
+    assert torch.equal(a3, b3) and not torch.equal(a3, a2), "the predictor replayed weight images of the weights before the optimisation step"
+
+
 def test_sliding_window_with_the_hip_model(golden_dir):
     """end to end: HIP VeloxSeg (eval) as the predictor of both drivers -> identical blended logits; and against the CPU oracle model
     within the logits tolerance of the model parity tests, argmax equal wherever the top-2 margin exceeds that tolerance."""

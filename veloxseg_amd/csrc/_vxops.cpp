@@ -1008,7 +1008,12 @@ struct GramFn : public torch::autograd::Function<GramFn> {
 
 // (round 6) weight images prepared AHEAD of their block (engine.TrainEngine prefetches them on a side lane at the head of the encoder forward: the two or three 6 us
 // preparation launches in front of every JLC block's convolutions leave the forward chains).  Keyed by the data pointer of the 1x1x1 weight; consumed once by jlc_fwd_f.
-struct JlcPreImg { Tensor img; int kind = 0, pieces = 0, C = 0, G = 0; };      // kind 1: Toeplitz images (jlc_mfma.hip), 2: channels-last images (jlc_cl.hip)
+struct JlcPreImg { Tensor img; int kind = 0, pieces = 0, C = 0, G = 0; bool keep = false; int64_t epoch = 0, ver = 0; };      // kind 1: Toeplitz images (jlc_mfma.hip), 2: channels-last images (jlc_cl.hip)
+// keep (inference: engine.TapedPredictor): the entry survives its use -- the weights do not change between forwards -- and is valid while the process-wide weights epoch
+// (bumped by every optimisation step of a TrainEngine, whose fused AdamW writes through raw pointers) and the version counters of the three weight tensors (bumped by any
+// in-place torch update: optimizers, load_state_dict) are those of the moment the images were built; an invalid entry is dropped and the images are built in place
+static int64_t WEIGHTS_EPOCH = 0;
+static int64_t jlc_wver(const Tensor& a, const Tensor& b, const Tensor& c) { return (int64_t)a._version() + (int64_t)b._version() + (int64_t)c._version(); }
 static std::unordered_map<const void*, JlcPreImg> JLC_PRE;
 static int jlc_img_kind(int C, int G, int D, int H, int W) {
     if (!F.fuse_blocks || !F.jlc_tz || (C / G) % 4 != 0) return 0;
@@ -1056,8 +1061,9 @@ static std::pair<Tensor, std::shared_ptr<JLCState>> jlc_fwd_f(const Tensor& x, c
                     if (it != JLC_PRE.end()) {
                         const JlcPreImg& q = it->second;
                         pre = q.C == C && q.G == G && ((tz && q.kind == 1 && q.pieces == f.tz_pieces) || (cl && q.kind == 2));
+                        if (pre && q.keep) pre = q.epoch == WEIGHTS_EPOCH && q.ver == jlc_wver(f.w1, f.w3, f.w5);
                         if (pre) f.img = q.img;
-                        JLC_PRE.erase(it);           // (a stale or mismatching entry is dropped: the images are then built here as before)
+                        if (!(pre && q.keep)) JLC_PRE.erase(it);           // (a stale or mismatching entry is dropped: the images are then built here as before)
                     }
                 }
                 if (tz) {
@@ -1672,7 +1678,9 @@ PYBIND11_MODULE(_vxops, m) {
         const long n = kind == 1 ? (long)vx_jlc_tz_img_floats_ns((int)C, (int)G, vx_jlc_tz_pieces()) : kind == 2 ? (long)vx_jlc_cl_img_floats((int)C, (int)G) : 0;
         return std::make_pair((int64_t)kind, (int64_t)n);
     });
-    m.def("jlc_prep_into", [](const Tensor& w1, const Tensor& w3, const Tensor& w5, Tensor img, int64_t C, int64_t G, int64_t D, int64_t H, int64_t W, int64_t stream) {
+    m.def("weights_epoch_bump", []() { return ++WEIGHTS_EPOCH; });
+    m.def("weights_epoch", []() { return WEIGHTS_EPOCH; });
+    m.def("jlc_prep_into", [](const Tensor& w1, const Tensor& w3, const Tensor& w5, Tensor img, int64_t C, int64_t G, int64_t D, int64_t H, int64_t W, int64_t stream, bool keep) {
         const int kind = jlc_img_kind((int)C, (int)G, (int)D, (int)H, (int)W);
         if (kind == 0) return false;
         void* s_ = sp(stream);
@@ -1686,9 +1694,10 @@ PYBIND11_MODULE(_vxops, m) {
             TORCH_CHECK(img.numel() >= (long)vx_jlc_cl_img_floats((int)C, (int)G), "jlc_prep_into: image buffer too small");
             VX(vx_jlc_cl_prep, fp(w1), fp(w3), fp(w5), mp(img), (int)C, (int)G, s_);
         }
+        q.keep = keep; q.epoch = WEIGHTS_EPOCH; q.ver = jlc_wver(w1, w3, w5);
         JLC_PRE[w1.data_ptr()] = q;
         return true;
-    });
+    }, py::arg("w1"), py::arg("w3"), py::arg("w5"), py::arg("img"), py::arg("C"), py::arg("G"), py::arg("D"), py::arg("H"), py::arg("W"), py::arg("stream"), py::arg("keep") = false);
     m.def("jlc_prefetch_clear", []() { const int64_t n = (int64_t)(JLC_PRE.size() + EXPAND_PRE.size()); JLC_PRE.clear(); EXPAND_PRE.clear(); return n; });
     // the same for a patch-expand layer (Conv3d k3 p1, 16 -> 64 Cc channels + PixelShuffle(4)) in the fp16-piece mode: -> floats per workspace (0: nothing is built ahead)
     m.def("expand_img_floats", [](int64_t Cout) {

@@ -32,6 +32,8 @@ WIMG_PREFETCH = os.environ.get("VELOXSEG_WIMG_PREFETCH", "1") != "0"
 # its two decoder lanes then reach their 100 us patch-expand kernels at the same moment and the decoder fan takes 576 instead of 458 us although its critical path is 15 us
 # shorter (tools/tape_critical_path.py brats128) -- the two preparation launches had been staggering them.
 EXPAND_PREFETCH = os.environ.get("VELOXSEG_EXPAND_PREFETCH", "0") == "1"
+# TapedPredictor: the weight images of the JLC blocks built once and kept across forwards (0: rebuilt inside every replay, A/B)
+PREDICTOR_KEEP_IMAGES = os.environ.get("VELOXSEG_PREDICTOR_KEEP_IMAGES", "1") != "0"
 TAPE_PGO = os.environ.get("VELOXSEG_TAPE_PGO", "0") == "1"                      # profile-guided lane layout of the encoder tapes (csrc/tape.hip vx_tape_build_pgo)
 TAPE_PGO_STAGES = tuple(k for k in os.environ.get("VELOXSEG_TAPE_PGO_STAGES", "enc_bwd,enc_fwd").split(",") if k)
 TAPE_WGRAD_DEFER = os.environ.get("VELOXSEG_TAPE_WGRAD_DEFER", "1") != "0"      # taped encoder backward: weight gradients at the end of their own stream
@@ -221,10 +223,37 @@ class TapedPredictor:
         with torch.inference_mode(False), torch.no_grad():
             return self._capture_body(x)
 
+    def _keep_weight_images(self, x):
+        """(round 6) between the forwards of a predictor the weights do not change: the weight images of the JLC blocks the eval forward runs (encoder conv branch, segmentation
+        decoder) are built ONCE, before the capture, and kept (functional.jlc_prefetch(keep=True)) -- the tape then holds none of their preparation launches (14 of ~250).
+        They are valid while the signature below holds (storage, version counters, the weights epoch a TrainEngine bumps); _vxops drops an entry that is not."""
+        if not PREDICTOR_KEEP_IMAGES:
+            return
+        from .model.components.conv_blocks import JLC
+        enc = getattr(self.model, "encoder", None)
+        ce = getattr(enc, "encoder_conv", None)
+        dec = getattr(self.model, "decoder", None)
+        if ce is None or dec is None or x.dim() != 5:
+            return
+        ps = self.model.patch_size
+        ps = [int(ps)] * 3 if not isinstance(ps, (tuple, list)) else [int(v) for v in ps]
+        base = [int(s_) // p_ for s_, p_ in zip(x.shape[2:], ps)]
+        grid = lambda lvl: [max(g // (2 ** (lvl - 1)), 1) for g in base]
+        cur = torch.cuda.current_stream(x.device)
+        for i in (1, 2, 3, 4):
+            for blk in getattr(ce, f"layer{i}"):
+                if isinstance(blk, JLC):
+                    VF.jlc_prefetch(blk, grid(i), cur, keep=True)
+        for lvl in (3, 2, 1):
+            for blk in getattr(dec, f"layer{lvl}", []):
+                if isinstance(blk, JLC):
+                    VF.jlc_prefetch(blk, grid(lvl), cur, keep=True)
+
     def _capture_body(self, x):
         dev = x.device
         xs = torch.empty(x.shape, dtype=x.dtype, device=dev)
         xs.copy_(x)
+        self._keep_weight_images(xs)
         prev_ms = VF.MODALITY_STREAMS
         VF.MODALITY_STREAMS = max(VF.MODALITY_STREAMS, 2)      # (for the capture only: the setting is baked into the tape, the process-wide value is restored)
         try:
@@ -258,10 +287,11 @@ class TapedPredictor:
         if slots is None:
             slots = self._sig_slots = ([(m._parameters, n) for m in self.model.modules() for n, p in m._parameters.items() if p is not None]
                                        + [(m._buffers, n) for m in self.model.modules() for n, b in m._buffers.items() if b is not None])
-        out = []
+        out = [VF.weights_epoch() if PREDICTOR_KEEP_IMAGES else 0]
         for d, n in slots:
             t = d.get(n)
-            out.append(None if t is None else (t.data_ptr(), t.dtype, t.device.index))
+            # (_version: an in-place update of a weight -- optimizer.step(), load_state_dict -- invalidates the weight images the tapes were captured without)
+            out.append(None if t is None else (t.data_ptr(), t.dtype, t.device.index, t._version if PREDICTOR_KEEP_IMAGES else 0))
         return tuple(out)
 
     # a tape holds a CUDAGraph and raw handles: copies / pickles of the model carry a FRESH, empty predictor (copy.deepcopy(model) for an EMA copy,
@@ -279,7 +309,7 @@ class TapedPredictor:
             return self.model(x)
         sig = self._signature()
         if sig != getattr(self, "_sig", None):
-            self._tapes, self._sig = {}, sig          # the storage moved since the capture: drop every tape of the old addresses
+            self._tapes, self._sig = {}, sig          # the storage moved (or the weights changed) since the capture: drop every tape of the old addresses / old weight images
         key = (tuple(x.shape), x.dtype, str(x.device))
         if key not in self._tapes:
             try:
@@ -1241,6 +1271,7 @@ class TrainEngine:
             self.labels.copy_(labels, non_blocking=True)
         if not self.model.training:
             self.model.train()
+        VF.weights_epoch_bump()                                # (weight images kept by a TapedPredictor of this model are stale after this step: its AdamW writes through raw pointers)
         if self.use_graph and self.graphs is None:
             try:
                 with self._settings(capture=True):

@@ -852,7 +852,18 @@ class _JLCFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-def jlc_prefetch(mod, grid, stream) -> bool:
+def weights_epoch_bump():
+    """the parameters changed through raw pointers (TrainEngine's fused AdamW): weight images kept for inference (jlc_prefetch(keep=True)) are stale from here on"""
+    m = _cpp()
+    return int(m.weights_epoch_bump()) if m is not None and hasattr(m, "weights_epoch_bump") else 0
+
+
+def weights_epoch() -> int:
+    m = _cpp()
+    return int(m.weights_epoch()) if m is not None and hasattr(m, "weights_epoch") else 0
+
+
+def jlc_prefetch(mod, grid, stream, keep: bool = False) -> bool:
     """Build the weight images of JLC block `mod` (its next forward runs on a `grid` = (D, H, W) volume) on `stream`, ahead of the block: the block's forward then launches
     no preparation kernels (csrc/_vxops.cpp jlc_prep_into / jlc_fwd_f).  The image buffer is the block's own and is re-used every step; an event recorded on `stream` is left
     on the block and waited for by its forward.  Returns False where the block builds nothing ahead (VALU convolutions, python bindings)."""
@@ -867,12 +878,13 @@ def jlc_prefetch(mod, grid, stream) -> bool:
     kind, n = m.jlc_img_plan(C, G, int(grid[0]), int(grid[1]), int(grid[2]))
     if kind == 0:
         return False
-    img = getattr(mod, "_pf_img", None)
+    bufs = mod.__dict__.setdefault("_pf_img", {})                # one buffer per image kind: a tape holds the address of the one it was captured with
+    img = bufs.get(int(kind))
     if img is None or img.numel() < n or img.device != w.device:
-        img = mod._pf_img = torch.empty(int(n), device=w.device, dtype=torch.float32)          # (allocated on the CURRENT stream, before the side stream is entered)
+        img = bufs[int(kind)] = torch.empty(int(n), device=w.device, dtype=torch.float32)          # (allocated on the CURRENT stream, before the side stream is entered)
     with torch.cuda.stream(stream):
-        ok = m.jlc_prep_into(convs[0].weight, convs[1].weight, convs[2].weight, img, C, G, int(grid[0]), int(grid[1]), int(grid[2]), stream.cuda_stream)
-        if ok:
+        ok = m.jlc_prep_into(convs[0].weight, convs[1].weight, convs[2].weight, img, C, G, int(grid[0]), int(grid[1]), int(grid[2]), stream.cuda_stream, bool(keep))
+        if ok and not keep:          # (keep: inference -- the images are built once on the stream the forwards run on, nobody waits for an event)
             ev = torch.cuda.Event()
             ev.record(stream)
             mod._pf_ev = ev
