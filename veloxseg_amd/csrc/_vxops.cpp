@@ -182,7 +182,8 @@ struct ConvState {
 };
 
 // (round 6) both weight images of a patch-expand layer built ahead of its forward (fp16-piece mode): keyed by the weight's data pointer, consumed once by conv_fwd_impl
-struct ExpandPreImg { Tensor wt_fwd, wt_bwd; int Cc = 0; };
+struct ExpandPreImg { Tensor wt_fwd, wt_bwd; int Cc = 0; bool keep = false; int64_t epoch = 0, ver = 0; };      // keep / epoch / ver: as JlcPreImg below (inference)
+static int64_t vx_weights_epoch_now();
 static std::unordered_map<const void*, ExpandPreImg> EXPAND_PRE;
 Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, const Tensor& w, const Tensor& b, int K, int S, int P, int G, int ps,
                      bool x_requires_grad, void* stream) {
@@ -251,9 +252,11 @@ Tensor conv_fwd_impl(ConvState& st, const Tensor& x_in, const Tensor& x2_in, con
                 bool pre = false;
                 auto it = EXPAND_PRE.find(w.data_ptr());
                 if (it != EXPAND_PRE.end()) {
-                    pre = F.expand_split == 22 && it->second.Cc == Cout / 64 && D % 4 == 0 && H % 4 == 0 && W % 4 == 0;
-                    if (pre) { wt = it->second.wt_fwd; st.wt_bwd_pre = it->second.wt_bwd; }
-                    EXPAND_PRE.erase(it);
+                    const ExpandPreImg& q = it->second;
+                    pre = F.expand_split == 22 && q.Cc == Cout / 64 && D % 4 == 0 && H % 4 == 0 && W % 4 == 0;
+                    if (pre && q.keep) pre = q.epoch == vx_weights_epoch_now() && q.ver == (int64_t)w._version();
+                    if (pre) { wt = q.wt_fwd; st.wt_bwd_pre = q.wt_bwd; }
+                    if (!(pre && q.keep)) EXPAND_PRE.erase(it);
                 }
                 if (pre) rc = VXR(vx_expand_fwd_mfma_split_prepared, fp(x), fp(b), fp(wt), mp(y), B, Cout / 64, D, H, W, stream);
                 else rc = VXR(vx_expand_fwd_mfma_split, fp(x), fp(w), fp(b), mp(wt), mp(y), B, Cout / 64, D, H, W, F.expand_split, stream);
@@ -1013,6 +1016,7 @@ struct JlcPreImg { Tensor img; int kind = 0, pieces = 0, C = 0, G = 0; bool keep
 // (bumped by every optimisation step of a TrainEngine, whose fused AdamW writes through raw pointers) and the version counters of the three weight tensors (bumped by any
 // in-place torch update: optimizers, load_state_dict) are those of the moment the images were built; an invalid entry is dropped and the images are built in place
 static int64_t WEIGHTS_EPOCH = 0;
+static int64_t vx_weights_epoch_now() { return WEIGHTS_EPOCH; }
 static int64_t jlc_wver(const Tensor& a, const Tensor& b, const Tensor& c) { return (int64_t)a._version() + (int64_t)b._version() + (int64_t)c._version(); }
 static std::unordered_map<const void*, JlcPreImg> JLC_PRE;
 static int jlc_img_kind(int C, int G, int D, int H, int W) {
@@ -1703,7 +1707,7 @@ PYBIND11_MODULE(_vxops, m) {
     m.def("expand_img_floats", [](int64_t Cout) {
         return (int64_t)((F.use_expand_mfma && !F.bf16_expand && F.expand_split == 22 && F.use_s1 && Cout % 64 == 0) ? vx_expand_split_ws_floats((int)(Cout / 64), 22) : 0);
     });
-    m.def("expand_prep_into", [](const Tensor& w, Tensor wt_fwd, Tensor wt_bwd, int64_t stream) {
+    m.def("expand_prep_into", [](const Tensor& w, Tensor wt_fwd, Tensor wt_bwd, int64_t stream, bool keep) {
         const int Cc = (int)(w.size(0) / 64);
         if (!(F.use_expand_mfma && !F.bf16_expand && F.expand_split == 22 && F.use_s1) || w.size(0) % 64 != 0 || w.size(1) != 16 || w.size(2) != 3) return false;
         const long n = vx_expand_split_ws_floats(Cc, 22);
@@ -1711,9 +1715,10 @@ PYBIND11_MODULE(_vxops, m) {
         VX(vx_expand_prep_split22, fp(w), mp(wt_fwd), mp(wt_bwd), Cc, sp(stream));
         ExpandPreImg q;
         q.wt_fwd = wt_fwd; q.wt_bwd = wt_bwd; q.Cc = Cc;
+        q.keep = keep; q.epoch = WEIGHTS_EPOCH; q.ver = (int64_t)w._version();
         EXPAND_PRE[w.data_ptr()] = q;
         return true;
-    });
+    }, py::arg("w"), py::arg("wt_fwd"), py::arg("wt_bwd"), py::arg("stream"), py::arg("keep") = false);
     m.def("jlc", [](const Tensor& x, const Tensor& w0, const OptT& w1, const OptT& w2, const Tensor& b0, const OptT& b1, const OptT& b2, int64_t G, const Tensor& l1w,
                     const Tensor& l1b, const Tensor& l2w, const Tensor& l2b, double p, int64_t site, int64_t rs) {
         return JLCFn::apply(x, w0, w1, w2, b0, b1, b2, G, l1w, l1b, l2w, l2b, p, site, rs);

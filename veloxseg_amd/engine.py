@@ -248,6 +248,9 @@ class TapedPredictor:
             for blk in getattr(dec, f"layer{lvl}", []):
                 if isinstance(blk, JLC):
                     VF.jlc_prefetch(blk, grid(lvl), cur, keep=True)
+        head = getattr(dec, "out_conv1", None)
+        if head is not None:                             # the patch-expand head's forward image too (one decoder: no second lane to collide with, cf. EXPAND_PREFETCH)
+            VF.expand_prefetch(head[0], cur, keep=True)
 
     def _capture_body(self, x):
         dev = x.device

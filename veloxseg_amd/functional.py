@@ -891,7 +891,7 @@ def jlc_prefetch(mod, grid, stream, keep: bool = False) -> bool:
     return bool(ok)
 
 
-def expand_prefetch(conv, stream) -> bool:
+def expand_prefetch(conv, stream, keep: bool = False) -> bool:
     """Both weight images of a patch-expand layer (`conv`: the 3^3 convolution in front of PixelShuffle(4)) built on `stream` ahead of its forward (fp16-piece mode;
     csrc/_vxops.cpp expand_prep_into): the layer's forward and input gradient then launch their matrix kernels only.  The buffers are the layer's own, re-used every step.
     The caller joins `stream` before the layer runs (the engine's encoder-forward stage does)."""
@@ -906,7 +906,7 @@ def expand_prefetch(conv, stream) -> bool:
     if bufs is None or bufs[0].numel() < n or bufs[0].device != w.device:
         bufs = conv._pf_wt = (torch.empty(n, device=w.device, dtype=torch.float32), torch.empty(n, device=w.device, dtype=torch.float32))
     with torch.cuda.stream(stream):
-        return bool(m.expand_prep_into(w, bufs[0], bufs[1], stream.cuda_stream))
+        return bool(m.expand_prep_into(w, bufs[0], bufs[1], stream.cuda_stream, bool(keep)))
 
 
 def jlc_block(x, mod, p: float, site: int):
