@@ -230,12 +230,13 @@ class TapedPredictor:
         if not PREDICTOR_KEEP_IMAGES:
             return
         from .model.components.conv_blocks import JLC
-        enc = getattr(self.model, "encoder", None)
+        mdl = getattr(self.model, "_model", self.model)        # (utils.inference_runtime.Net wraps the network)
+        enc = getattr(mdl, "encoder", None)
         ce = getattr(enc, "encoder_conv", None)
-        dec = getattr(self.model, "decoder", None)
-        if ce is None or dec is None or x.dim() != 5:
+        dec = getattr(mdl, "decoder", None)
+        if ce is None or dec is None or x.dim() != 5 or not hasattr(mdl, "patch_size"):
             return
-        ps = self.model.patch_size
+        ps = mdl.patch_size
         ps = [int(ps)] * 3 if not isinstance(ps, (tuple, list)) else [int(v) for v in ps]
         base = [int(s_) // p_ for s_, p_ in zip(x.shape[2:], ps)]
         grid = lambda lvl: [max(g // (2 ** (lvl - 1)), 1) for g in base]
