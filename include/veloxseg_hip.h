@@ -622,6 +622,9 @@ int vx_tape_build(void* hip_graph, int max_lanes, VxTape** out);
    list-scheduled (longest remaining path first, earliest-start lane) instead of laid out greedily in capture order */
 int vx_tape_build_pgo(void* graph, int max_lanes, const float* dur_us, int n, VxTape** out);
 int vx_tape_info(const VxTape* tape, int* n_nodes, int* n_kernels, int* n_lanes, int* n_events);
+/* (round 6) lane l of this tape runs on pool stream (l + k) % 4, k = 0 .. 3: a tape replayed beside another one (two window batches of a sliding-window inference in flight) takes
+ * the other hardware queues for its main chains */
+int vx_tape_set_lane_rotation(VxTape* tape, int k);
 int vx_tape_replay(VxTape* tape, void* stream);
 int vx_tape_free(VxTape* tape);
 /* markers: vx_tape_mark(id, stream) inside the captured code; the tape records an event at that point of its schedule instead of launching anything,

@@ -117,6 +117,16 @@ def test_sliding_window_with_the_hip_model(golden_dir):
         got_eager, _ = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5, taped=False)
     assert torch.equal(got, want)                       # infer_volume replays the captured forward of a window batch (engine.TapedPredictor) ...
     assert torch.equal(got, got_eager)                  # ... which is bit for bit the eager forward
+    # two window batches in flight (the default) == one after the other: the blending keeps the window order
+    assert IR.SW_PIPELINE
+    IR.SW_PIPELINE = False
+    try:
+        with torch.inference_mode():
+            got_seq, labels_seq = IR.infer_volume(model, x.to(d), (32, 32, 32), 2, 0.5)
+    finally:
+        IR.SW_PIPELINE = True
+    assert torch.equal(got, got_seq) and torch.equal(labels, labels_seq)
+    assert any(k != "sig" and e is not None for k, e in model.__dict__["_vx_taped_predictor"].__dict__.get("_replicas", {}).items()), "no replica of the tape was replayed"
     tp = model.__dict__["_vx_taped_predictor"]          # the predictor hangs on the model (no process-wide cache)
     assert any(e is not None and e[2].n_kernels > 0 for e in tp._tapes.values()), "the window batches were expected to replay a launch tape"
     # re-homed parameters (what engine.FlatParams does, or model.to()): the tape holds the OLD addresses and must be re-captured, not replayed

@@ -40,6 +40,7 @@ struct TapeNode {
 }  // namespace
 
 struct VxTape {
+    int lane_rot = 0;          // lanes l of this tape run on pool stream (l + lane_rot) % kPool (vx_tape_set_lane_rotation)
     std::vector<TapeNode> nodes;        // in launch order (a topological order of the captured DAG)
     std::vector<hipStream_t> lanes;     // set at replay: the caller's stream for a one-lane tape, else the process-wide lane streams
     std::vector<int> lane_last;         // last node of each lane (-1: unused)
@@ -675,6 +676,14 @@ static int tape_replay_body(VxTape* T, hipStream_t s0, bool fl, unsigned seq, in
 }
 
 static int tape_replay_impl(VxTape* T, void* stream, int limit, bool tail);
+// Two tapes that are replayed from different caller streams at the same time (two window batches of a sliding-window inference in flight: utils/inference_runtime.py) queue behind each
+// other lane by lane when they use the same pool streams in the same order.  A rotation k sends this tape's lane l to pool stream (l + k) % 4: with k = 2 its two main chains
+// (lanes 0, 1) sit on the hardware queues the other tape uses for its side lanes.
+extern "C" int vx_tape_set_lane_rotation(VxTape* T, int k) {
+    VX_REQUIRE(T && k >= 0 && k < kPool, "vx_tape_set_lane_rotation: 0 .. 3");
+    T->lane_rot = k;
+    return 0;
+}
 extern "C" int vx_tape_replay(VxTape* T, void* stream) { return tape_replay_impl(T, stream, -1, true); }      // (-1 = the whole tape)
 // diagnostics (tools/tape_memdiff.py): the first `k` nodes the way vx_tape_replay runs them (lanes, cross-lane waits), the lanes joined, then the remaining nodes one after
 // the other on the caller's stream -- a binary search over k finds the launch from which on a timing-dependent deviation exists
@@ -692,7 +701,7 @@ static int tape_replay_impl(VxTape* T, void* stream, int limit, bool tail) {
     else {
         int rc = pool_init(s0);
         if (rc) return rc;
-        for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[l % kPool];
+        for (size_t l = 0; l < L; ++l) T->lanes[l] = g_pool.lane[(l + (size_t)T->lane_rot) % kPool];      // (lane_rot: vx_tape_set_lane_rotation -- a second tape replayed BESIDE this one takes the other queues for its main chains)
     }
     const bool fl = flags_ok() && T->flags != nullptr;
     const unsigned seq = ++T->seq;

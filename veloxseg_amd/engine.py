@@ -166,6 +166,10 @@ class LaunchTape:
     def replay(self):
         H.call("vx_tape_replay", self.handle, H.stream_ptr())
 
+    def set_lane_rotation(self, k: int):
+        """lane l of this tape on pool stream (l + k) % 4: a tape replayed BESIDE another one (csrc/tape.hip vx_tape_set_lane_rotation)"""
+        H.call("vx_tape_set_lane_rotation", self.handle, int(k) % 4)
+
     def relayout(self, max_lanes: int):
         """profile-guided layout (csrc/tape.hip vx_tape_build_pgo): every node is timed alone (its buffers must hold the values of a real replay), then
         the graph is laid out again by list scheduling with those durations -- longest remaining path first, each node on the lane where it can start
@@ -325,6 +329,44 @@ class TapedPredictor:
         ent = self._tapes[key]
         if ent is None:
             return self.model(x)
+        xs, out, tape = ent
+        xs.copy_(x, non_blocking=True)
+        tape.replay()
+        return out
+
+    @torch.inference_mode()
+    def forward_slot(self, x: torch.Tensor, slot: int):
+        """(round 6) the same forward from one of several REPLICAS of the tape (own static input / output, lanes rotated by 2 per slot): two window batches of a sliding-window
+        inference in flight at once, each replayed from its own caller stream (utils.inference_runtime.sliding_window_inference).  Returns None where this shape has no tape
+        (the caller then calls the predictor the plain way)."""
+        if slot <= 0:
+            return self(x)
+        if self.model.training or not x.is_cuda:
+            return None
+        sig = self._signature()
+        if sig != getattr(self, "_sig", None):
+            return None                                     # (slot 0 notices first and drops the tapes; until then the plain call)
+        key = (tuple(x.shape), x.dtype, str(x.device))
+        if self._tapes.get(key) is None:
+            return None
+        rk = (key, int(slot))
+        reps = self.__dict__.setdefault("_replicas", {})
+        if reps.get("sig") != sig:
+            reps.clear()
+            reps["sig"] = sig
+        if rk not in reps:
+            try:
+                ent = self._capture(x.contiguous())
+                if ent is not None:
+                    ent[2].set_lane_rotation({1: 2, 2: 0, 3: 1, 4: 3}.get(int(slot), int(slot)))      # (replica 1 beside the plain tape: its main chains on the other two queues)
+                reps[rk] = ent
+            except Exception as e:
+                warnings.warn(f"TapedPredictor: capture of replica {slot} failed ({type(e).__name__}: {str(e)[:200]})")
+                reps[rk] = None
+                torch.cuda.synchronize(x.device)
+        ent = reps[rk]
+        if ent is None:
+            return None
         xs, out, tape = ent
         xs.copy_(x, non_blocking=True)
         tape.replay()

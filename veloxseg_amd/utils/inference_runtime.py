@@ -54,6 +54,73 @@ def _axis_counts(starts_axis: Sequence[int], r: int, m: int, device) -> torch.Te
     return c.to(device)
 
 
+# two window batches in flight (round 6): each forward of a window batch is a ~250-launch tape that leaves most of the chip idle at the reference's sw_batch_size of 2; the next
+# batch's forward is replayed from a second caller stream on a replica of the tape (engine.TapedPredictor.forward_slot) while the first one runs.  The blending stays in the
+# reference's window order -- the accumulation of batch i + 1 waits for the one of batch i -- so the result is bit for bit the sequential one.  VELOXSEG_SW_PIPELINE=0: sequential.
+SW_PIPELINE = os.environ.get("VELOXSEG_SW_PIPELINE", "1") != "0"
+SW_INFLIGHT = max(2, min(4, int(os.environ.get("VELOXSEG_SW_INFLIGHT", "2"))))      # window batches in flight (A/B)
+
+
+def _pipelined(inputs, predictor, starts, num_win, total, swb, cdhw, roi):
+    C, D, Hh, W = cdhw
+    rd, rh, rw = roi
+    dev = inputs.device
+    cur = torch.cuda.current_stream(dev)
+    streams = _SW_STREAMS.setdefault(str(dev), [torch.cuda.Stream(device=dev) for _ in range(SW_INFLIGHT)])
+    wins = [torch.empty((swb, C, rd, rh, rw), device=dev, dtype=torch.float32) for _ in range(SW_INFLIGHT)]
+    # the first batch the plain way (captures / validates the tape of this shape; tells us K)
+    g0 = 0
+    for k in range(swb):
+        z0, y0, x0 = starts[k % num_win]
+        H.call("vx_sw_extract", H.P(inputs[k // num_win]), H.P(wins[0][k]), C, D, Hh, W, rd, rh, rw, z0, y0, x0, H.stream_ptr())
+    prob = predictor(wins[0])
+    if isinstance(prob, (list, tuple)):
+        prob = prob[0]
+    if prob.dtype != torch.float32 or not prob.is_contiguous() or tuple(prob.shape[2:]) != (rd, rh, rw):
+        return None
+    K = int(prob.shape[1])
+    B = inputs.shape[0]
+    acc = torch.zeros((B, K, D, Hh, W), device=dev, dtype=torch.float32)
+    for k in range(swb):
+        z0, y0, x0 = starts[k % num_win]
+        H.call("vx_sw_accumulate", H.P(prob[k]), H.P(acc[k // num_win]), K, D, Hh, W, rd, rh, rw, z0, y0, x0, 1.0, H.stream_ptr())
+    # the rest alternately on the two slot streams
+    for s_ in streams:
+        s_.wait_stream(cur)
+    last_acc = None                                          # event after the accumulation of the previous batch
+    nb = total // swb
+    for bi in range(1, nb):
+        # replicas 1 and 2 of the tape, each always replayed from ITS stream (replica 0 -- the plain call above -- stays on the caller's stream: a tape whose caller stream
+        # changes between replays synchronises the host once)
+        slot = bi % SW_INFLIGHT
+        st_ = streams[slot]
+        with torch.cuda.stream(st_):
+            for k in range(swb):
+                i = bi * swb + k
+                z0, y0, x0 = starts[i % num_win]
+                H.call("vx_sw_extract", H.P(inputs[i // num_win]), H.P(wins[slot][k]), C, D, Hh, W, rd, rh, rw, z0, y0, x0, st_.cuda_stream)
+            out = predictor.forward_slot(wins[slot], 1 + slot)
+            if out is None:                                  # no replica (capture refused): this batch on the eager launches, on this stream
+                out = predictor.model(wins[slot]) if hasattr(predictor, "model") else predictor(wins[slot])
+            if isinstance(out, (list, tuple)):
+                out = out[0]
+            out = out.contiguous().float()
+            if last_acc is not None:
+                st_.wait_event(last_acc)                     # blending in window order: bit for bit the sequential sums
+            for k in range(swb):
+                i = bi * swb + k
+                z0, y0, x0 = starts[i % num_win]
+                H.call("vx_sw_accumulate", H.P(out[k]), H.P(acc[i // num_win]), K, D, Hh, W, rd, rh, rw, z0, y0, x0, 1.0, st_.cuda_stream)
+            last_acc = torch.cuda.Event()
+            last_acc.record(st_)
+    for s_ in streams:
+        cur.wait_stream(s_)
+    return acc, K
+
+
+_SW_STREAMS = {}
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int, predictor: Callable, overlap: float = 0.25,
                              mode: str = "constant", padding_mode: str = "constant", cval: float = 0.0, return_labels: bool = False,
                              **unsupported):
@@ -92,6 +159,11 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     total = num_win * B
     acc = None
     K = None
+    if (SW_PIPELINE and hasattr(predictor, "forward_slot") and total >= 2 * sw_batch_size and total % sw_batch_size == 0):
+        done = _pipelined(inputs, predictor, starts, num_win, total, sw_batch_size, (C, D, Hh, W), (rd, rh, rw))
+        if done is not None:
+            acc, K = done
+            total = 0                                       # (every window batch is in; the loop below has nothing left)
     for g in range(0, total, sw_batch_size):
         idxs = range(g, min(g + sw_batch_size, total))
         win = torch.empty((len(idxs), C, rd, rh, rw), device=dev, dtype=torch.float32)
